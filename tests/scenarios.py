@@ -1,0 +1,165 @@
+"""Scenario definitions shared by tests/golden/make_golden.py and the parity tests.
+
+Each scenario is rebuilt byte-identically from its seed by tests/synth.py; the golden files
+pin a sha256 of the generated inputs next to the reference's outputs.
+"""
+import os
+
+import numpy as np
+
+from . import synth
+
+K = 31
+
+# ------------------------------------------------------------------------------------------------
+# F1: jellyfish semantics -- tiny hand-made kmer.fa + reads (k = 31)
+# ------------------------------------------------------------------------------------------------
+def f1_case(lower_only=False):
+    rs = np.random.RandomState(101)
+    g = synth.rand_seq(rs, 400)
+    kms = [g[i:i + K] for i in range(0, 120, 7)]
+    rows = []
+    for km in kms:
+        rows.append(km)
+        rows.append(synth.revcomp(km))
+    rows.append(kms[0][:10] + b"N" + kms[0][11:])      # N row: never dumped -> not valid
+    rows.append(kms[1].lower())                          # lower-case row: valid in identify.py only
+    rows.append(kms[2])                                  # duplicate of row 4: last index wins
+    rows.append(synth.rand_seq(rs, K))                   # absent from reads: count 0, still valid
+    rows.append(kms[3][:K - 1])                          # 30-mer: yields no k-mer
+    if lower_only:                                       # lower-case row WITHOUT an upper-case twin:
+        rows.append(g[200:200 + K].lower())              # KeyError in identify_low_mem/low_depth
+    kfa = b"".join(b">1\n" + r + b"\n" for r in rows)
+    reads_fq = (
+        b"@r1\n" + g[:150] + b"\n+\n" + b"I" * 150 + b"\n"
+        b"@r2 rev\n" + synth.revcomp(g[:150]) + b"\n+\n" + b"I" * 150 + b"\n"
+        b"@r3 lower\n" + g[:150].lower() + b"\n+\n" + b"A" * 150 + b"\n"      # quality = 'A's
+        b"@r4 withN\n" + g[:40] + b"N" + g[41:150] + b"\n+\n" + b"@" + b"I" * 149 + b"\n"
+        b"@r5 multiline\n" + g[:75] + b"\n" + g[75:150] + b"\n+\n" + b"I" * 75 + b"\n" + b"I" * 75 + b"\n"
+        b"@r6 short\n" + g[:30] + b"\n+\n" + b"I" * 30 + b"\n"
+        b"\n"
+        b"@r7 exact\n" + g[7:7 + K] + b"\n+\n" + b"+" + b"I" * (K - 1) + b"\n"
+    )
+    reads_fa = b">a desc\n" + g[:60] + b"\n" + g[60:140] + b"\n>b\n" + g[100:160].lower() + b"\n"
+    return dict(kmer_fa=kfa, reads=[reads_fq, reads_fa], n_rows=len(rows))
+
+
+# ------------------------------------------------------------------------------------------------
+# F2/F3: L1 cluster-search-tree databases
+# ------------------------------------------------------------------------------------------------
+#            7
+#        8        10
+#      9   3     4   11(weak)
+#     1 2           5  6
+PARENT_T11 = {1: 9, 2: 9, 3: 8, 4: 10, 5: 11, 6: 11, 7: None, 8: 7, 9: 8, 10: 7, 11: 10}
+
+L1_DBS = {
+    # deterministic adjust_profile branch (enough non-overlapping k-mers remain)
+    "A": dict(parent=PARENT_T11,
+              sites={1: 2500, 2: 1800, 3: 1000, 4: 2200, 5: 1700, 6: 400, 7: 2000, 8: 1600, 9: 1200,
+                     10: 1500, 11: 300},
+              seed=11, singleton={2: "GCF_SINGLE2", 6: "GCF_SINGLE6"},
+              clusters={1: ["GCF_A1", "GCF_A2", "GCF_A3"], 3: ["GCF_C1", "GCF_C2"], 4: ["GCF_D1", "GCF_D2"],
+                        5: ["GCF_E1", "GCF_E2", "GCF_E3", "GCF_E4"]},
+              reconstructed=[4, 2, 10], overlaps=[(3, 4, 0, 300), (3, 2, 100, 400), (1, 10, 0, 200)]),
+    # Poisson branch of adjust_profile (fewer than 1000 k-mers survive the overlap removal)
+    "B": dict(parent=PARENT_T11,
+              sites={1: 2500, 2: 1800, 3: 1000, 4: 2200, 5: 1700, 6: 1600, 7: 2000, 8: 1600, 9: 1200,
+                     10: 1500, 11: 1500},
+              seed=12, singleton={2: "GCF_SINGLE2"},
+              clusters={1: ["GCF_A1", "GCF_A2"], 3: ["GCF_C1", "GCF_C2"], 4: ["GCF_D1", "GCF_D2"],
+                        5: ["GCF_E1", "GCF_E2"], 6: ["GCF_F1", "GCF_F2"]},
+              reconstructed=[4, 2, 5], overlaps=[(3, 4, 0, 1900), (3, 2, 0, 1500), (3, 5, 100, 1600)]),
+    # two-leaf tree: root is the LAST line of tree_structure.txt -> reversed() creation order
+    "C": dict(parent={1: 3, 2: 3, 3: None}, sites={1: 1600, 2: 1700, 3: 1500}, seed=13,
+              singleton={1: "GCF_ONLY1"}, clusters={2: ["GCF_T1", "GCF_T2"]}, reconstructed=[], overlaps=[]),
+}
+
+# samples: name -> (db, [(leaf or ('path', node) or ('random', length), depth)], read seed)
+L1_SAMPLES = {
+    "A_mix3": ("A", [(1, 20.0), (3, 8.0), (4, 5.0)], 201),
+    "A_leaf5": ("A", [(5, 12.0)], 202),
+    "A_leaf6_single": ("A", [(6, 15.0), (2, 6.0)], 203),
+    "A_low": ("A", [(1, 0.6)], 204),
+    "A_verylow": ("A", [(3, 0.15)], 205),
+    "A_none": ("A", [(("random", 60000), 5.0)], 206),
+    "A_novel": ("A", [(("path", 9), 15.0)], 207),
+    "B_mix": ("B", [(3, 12.0), (4, 6.0), (2, 9.0), (5, 4.0)], 211),
+    "C_two": ("C", [(1, 10.0), (2, 3.0)], 221),
+}
+
+CUTOFFS = [[0.1, 0.4, 1], [0.05, 0.05, 1], [0.01, 0.05, 1], [0.005, 0.01, 1]]   # StrainScan.py:196-216
+POISSON_SEED = 4321
+
+
+def build_l1(name, root_dir):
+    spec = L1_DBS[name]
+    db_dir = os.path.join(root_dir, "DB_" + name)
+    info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["seed"], spec.get("singleton"),
+                             spec.get("clusters"), spec.get("reconstructed", ()), spec.get("overlaps", ()))
+    info["db_dir"] = db_dir
+    return info
+
+
+def sample_reads(info, sample_name):
+    db, mix, seed = L1_SAMPLES[sample_name]
+    rs = np.random.RandomState(seed + 5000)
+    gd = []
+    for src, depth in mix:
+        if isinstance(src, tuple) and src[0] == "random":
+            g = synth.rand_seq(rs, src[1])
+        elif isinstance(src, tuple) and src[0] == "path":
+            g = b"".join(info["node_seq"][i] for i in info["tree"].path(src[1]))
+        else:
+            g = info["leaf_genome"][src]
+        gd.append((g, depth))
+    return synth.simulate_reads(gd, seed)
+
+
+# ------------------------------------------------------------------------------------------------
+# F4/F5: intra-cluster (L2) cases
+# ------------------------------------------------------------------------------------------------
+def l2_case(name):
+    """-> dict(X csr K x S int8, O csr K x C int8, ids, y int64[K], kwargs for detect_strains)."""
+    import scipy.sparse as sp
+    P4 = [[1, 1, 0, 0, 1], [1, 0, 1, 0, 0], [0, 1, 1, 1, 0], [0, 0, 0, 1, 1]]
+    P5 = [[1, 1, 0, 0, 1, 0], [1, 0, 1, 0, 0, 1], [0, 1, 1, 1, 0, 0], [0, 0, 0, 1, 1, 1], [1, 1, 1, 0, 0, 0]]
+    rsm = np.random.RandomState(77)
+    P12 = (rsm.random_sample((12, 16)) < 0.45).astype(int).tolist()
+    cases = {
+        # name: (seed, sites per segment, presence rows, depth per strain, all_cls, l2, emode, n_cls, outliers)
+        "one": (31, [700, 500, 600, 400], [[1, 1, 0, 0], [1, 0, 1, 0], [0, 1, 1, 1]], [14, 0, 0], [2], 0, 0, 4, 0),
+        "two": (32, [900, 800, 700, 600, 500], P4, [30, 0, 11, 0], [2, 3], 0, 0, 4, 0),
+        "two_out": (32, [900, 800, 700, 600, 500], P4, [30, 0, 11, 0], [2, 3], 0, 0, 4, 0.002),
+        "three": (33, [900, 800, 700, 600, 500, 900], P5, [40, 12, 0, 6, 0], [1, 2], 0, 0, 3, 0),
+        "three_l2": (33, [900, 800, 700, 600, 500, 900], P5, [3, 1.2, 0, 0.8, 0], [1, 2], 1, 0, 3, 0),
+        "emode": (34, [900, 800, 700, 600, 500], P4, [25, 0, 9, 3], [2], 0, 1, 4, 0),
+        "lowcov": (35, [900, 800, 700, 600], [[1, 1, 0, 0], [1, 0, 1, 0], [0, 1, 1, 1]], [0.3, 0, 0], [1], 1, 0, 2, 0),
+        "many": (36, [400] * 16, P12, [22, 0, 0, 9, 0, 0, 0, 0, 4, 0, 0, 0], [3], 0, 0, 5, 0),
+    }
+    seed, segs, pres, depths, all_cls, l2, emode, n_cls, outl = cases[name]
+    rs = np.random.RandomState(seed)
+    pres = np.array(pres, bool)
+    S, G = pres.shape
+    seg_of_row = np.repeat(np.arange(G), [2 * n for n in segs])
+    Kn = seg_of_row.size
+    Xd = pres[:, seg_of_row].T.astype(np.int8)                       # K x S
+    cid = all_cls[0]
+    O = np.zeros((Kn, n_cls), np.int8)
+    O[:, cid - 1] = 1
+    if len(all_cls) > 1:                                            # some k-mers shared with 2nd cluster
+        shared = rs.random_sample(Kn) < 0.15
+        O[shared, all_cls[1] - 1] = 1
+    lam = Xd.astype(np.float64) @ (np.array(depths, float) * 0.4)  # strand-specific k-mer depth
+    y = rs.poisson(lam).astype(np.int64)
+    if outl:
+        y[rs.random_sample(Kn) < outl] += 5000                      # a few repeats/outliers
+    y[y == 1] = 0                                                   # remove_1 (Vote_...:312-322)
+    ids = ["GCF_%s_%d" % (name.upper(), i + 1) for i in range(S)]
+    nz = y[y != 0]
+    npp_out = float(np.median(nz) * 1000) if nz.size else 0.0
+    return dict(X=sp.csr_matrix(Xd), O=sp.csr_matrix(O), ids=ids, y=y, ksize=31, npp25=0, npp75=npp_out,
+                npp_out=npp_out, cls_cov=0.9, all_cls=all_cls, l2=l2, msn=40, pmode=0, emode=emode)
+
+
+L2_CASES = ["one", "two", "two_out", "three", "three_l2", "emode", "lowcov", "many"]
