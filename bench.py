@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the identification hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic E. coli-shaped database -- 823 leaf clusters =
+1645 cluster-search-tree nodes, each node owning U[1000, 30000] k-mer rows (both orientations),
+about 25 M rows in all -- and 10 M pairs = 20 M synthetic 150-bp reads of a 70/20/10 three-strain
+mix (strand 50/50, 0.5 % substitutions), all resident in HBM before the timed region.
+
+One step = one pass of the hot path over the whole read batch on each GPU:
+    reset counters -> encode+probe+count kernel over the flat base block -> gather slot counts
+    to kmer.fa rows -> [N > 1: RCCL all-reduce of the uint32 row counts] -> per-node reductions
+    (length / covered / outlier-cut sums for all 1645 nodes).
+`value` = reads of all ranks / max-over-ranks step time.  Weak scaling: every rank scans its
+own 20 M-read shard (reads shard, the table is replicated).
+
+Extra objects on the JSON line:
+  roofline     -- the scan kernel against the HBM roof: algorithmic bytes per launch
+                  (150 B bases + 120 probes x 8 B per read) / its average duration
+                  from HIP events on the launch stream.
+  cpu_baseline -- the oracle's flat-stream counter (oracle/ss_oracle.c, OpenMP) on a bounded
+                  sample of the same reads against the same table, on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+READ_LEN = 150
+K = 31
+BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 8   # 1110 B algorithmic
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_db(torch, dev, n_leaves, seed, lo_sites=500, hi_sites=15000):
+    """Node-private random sequences -> k-mer rows (forward, reverse complement adjacent).
+    Returns keys (device-convention uint64, numpy), oracle-convention keys, node row lists
+    (offsets), the per-node code tensors and the tree parent array."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n_nodes = 2 * n_leaves - 1
+    rs = np.random.RandomState(seed)
+    sites = rs.randint(lo_sites, hi_sites + 1, size=n_nodes).astype(np.int64)
+    seq_len = sites + K - 1
+    seq_off = np.concatenate([[0], np.cumsum(seq_len)])
+    total = int(seq_off[-1])
+    codes = torch.randint(0, 4, (total,), generator=g, device=dev, dtype=torch.int64)
+    n_sites = int(sites.sum())
+    # start offsets of every site in the concatenated code stream
+    site_node = np.repeat(np.arange(n_nodes), sites)
+    site_pos = np.arange(n_sites) - np.repeat(np.concatenate([[0], np.cumsum(sites)[:-1]]), sites)
+    start = torch.from_numpy(seq_off[site_node] + site_pos).to(dev)
+    key = torch.zeros(n_sites, dtype=torch.int64, device=dev)
+    rc = torch.zeros(n_sites, dtype=torch.int64, device=dev)
+    okey = torch.zeros(n_sites, dtype=torch.int64, device=dev)   # oracle convention
+    orc_ = torch.zeros(n_sites, dtype=torch.int64, device=dev)
+    # device code: A0 C1 T2 G3 (first base LSB); oracle code: A0 C1 G2 T3 (first base MSB)
+    to_or = torch.tensor([0, 1, 3, 2], device=dev, dtype=torch.int64)
+    for j in range(K):
+        cj = codes[start + j]
+        key |= cj << (2 * j)
+        rc |= (cj ^ 2) << (2 * (K - 1 - j))
+        oj = to_or[cj]
+        okey |= oj << (2 * (K - 1 - j))
+        orc_ |= (3 - oj) << (2 * j)
+    keys = torch.stack([key, rc], 1).reshape(-1).cpu().numpy().view(np.uint64)
+    okeys = torch.stack([okey, orc_], 1).reshape(-1).cpu().numpy().view(np.uint64)
+    row_off = np.concatenate([[0], np.cumsum(2 * sites)]).astype(np.uint64)
+    # balanced binary tree in heap order: node 0 root, children 2i+1, 2i+2; leaves are the last n_leaves
+    return dict(keys=keys, okeys=okeys, row_off=row_off, sites=sites, seq_off=seq_off, codes=codes,
+                n_nodes=n_nodes)
+
+
+def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
+    """Reads of a three-strain mix.  A strain genome = the node sequences on its root->leaf path
+    (these are the reads' database hits) + private filler so that about `hit_frac` of the read
+    k-mers are database k-mers, as for a 5 Mb genome against its ~1e5 path k-mers."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    n_nodes = db["n_nodes"]
+    genomes = []
+    leaves = rs.choice(np.arange(n_nodes // 2, n_nodes), size=len(mix), replace=False)
+    for leaf in leaves:
+        path = []
+        i = int(leaf)
+        while True:
+            path.append(i)
+            if i == 0:
+                break
+            i = (i - 1) // 2
+        parts = [db["codes"][int(db["seq_off"][p]):int(db["seq_off"][p + 1])] for p in path[::-1]]
+        core = torch.cat(parts)
+        filler = torch.randint(0, 4, (int(core.numel() * (1.0 / hit_frac - 1.0)),), generator=g, device=dev,
+                               dtype=torch.int64)
+        # interleave core pieces into the filler so hits are spread over the genome
+        chunks = list(torch.tensor_split(filler, len(parts)))
+        genomes.append(torch.cat([x for pair in zip(chunks, parts) for x in pair]))
+    asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)      # device codes 0..3 -> A C T G
+    out = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, device=dev)
+    view = out.view(n_reads, READ_LEN + 1)
+    counts = (np.array(mix) * n_reads).astype(np.int64)
+    counts[0] += n_reads - counts.sum()
+    ar = torch.arange(READ_LEN, device=dev)
+    row = 0
+    chunk = 1 << 20
+    for gi, cnt in enumerate(counts):
+        gen = genomes[gi]
+        done = 0
+        while done < cnt:
+            m = int(min(chunk, cnt - done))
+            st = torch.randint(0, gen.numel() - READ_LEN, (m,), generator=g, device=dev)
+            c = gen[st[:, None] + ar[None, :]]
+            err = torch.rand((m, READ_LEN), generator=g, device=dev) < 0.005
+            c = torch.where(err, torch.randint(0, 4, (m, READ_LEN), generator=g, device=dev), c)
+            rev = torch.rand((m,), generator=g, device=dev) < 0.5
+            c = torch.where(rev[:, None], c.flip(1) ^ 2, c)
+            view[row:row + m, :READ_LEN] = asc[c]
+            row += m
+            done += m
+    view[:, READ_LEN] = 10
+    # interleave the strains (a FASTQ is not sorted by source genome)
+    perm = torch.randperm(n_reads, generator=g, device=dev)
+    out = view[perm].contiguous().view(-1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU (10 M pairs)")
+    ap.add_argument("--leaves", type=int, default=823)
+    ap.add_argument("--hit-frac", type=float, default=0.05)
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from strainscan_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path to time")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.check(_lib.lib().ss_set_device(local), "ss_set_device")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    t0 = time.time()
+    db_spec = make_db(torch, dev, args.leaves, seed=20231013)
+    n_rows = db_spec["keys"].size
+    db = _lib.KmerDB(db_spec["keys"], np.ones(n_rows, np.uint8), K, True)
+    info = db.info()
+    rows = np.arange(n_rows, dtype=np.uint32)
+    nodes = _lib.NodeSet.__new__(_lib.NodeSet)
+    import ctypes as C
+    h = C.c_void_p()
+    _lib.check(_lib.lib().ss_nodes_create(_lib.ptr(rows), _lib.ptr(db_spec["row_off"]), db_spec["n_nodes"],
+                                          C.byref(h)), "ss_nodes_create")
+    nodes._h, nodes.n_nodes = h, db_spec["n_nodes"]
+    log("[bench] db: %d rows, %d distinct, capacity 2^%d, %.2f GB on device (%.1f s)" % (
+        n_rows, info["n_distinct"], int(np.log2(info["capacity"])), info["device_bytes"] / 1e9, time.time() - t0))
+    t0 = time.time()
+    reads = make_reads(torch, dev, db_spec, args.reads, seed=2 + rank, hit_frac=args.hit_frac)
+    torch.cuda.synchronize()
+    log("[bench] reads: %d x %d bp = %.2f GB in HBM (%.1f s)" % (args.reads, READ_LEN, reads.numel() / 1e9,
+                                                                 time.time() - t0))
+
+    counts_rows = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    stats = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i=None):
+        db.reset(stream)
+        if i is not None:
+            ev[i][0].record()
+        db.scan_flat_dev(reads.data_ptr(), reads.numel(), stream)
+        if i is not None:
+            ev[i][1].record()
+        db.counts_rows_dev(counts_rows.data_ptr(), stream)
+        if world > 1:
+            dist.all_reduce(counts_rows)       # RCCL sum of the per-GPU hit-count vectors
+        nodes.reduce_dev(counts_rows.data_ptr(), db.row_valid_dev, stats.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    reads_per_s = args.reads * world * args.steps / dt
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    hits = int(counts_rows.to(torch.int64).sum().item())
+    st_np = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
+
+    achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="scan_kernel", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel_ms=round(kern_ms, 3),
+                    bytes_per_read=BYTES_PER_READ,
+                    sector_gbs=round(args.reads * (READ_LEN + 120 * 64) / (kern_ms * 1e-3) / 1e9, 1))
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        threads = orc.lib().orc_omp_threads()
+        flat = reads[: 20000 * (READ_LEN + 1)].cpu().numpy()
+        t1 = time.perf_counter()
+        orc.count_flat(db_spec["okeys"], K, flat, threads)      # includes the table build
+        t_small = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        orc.count_flat(db_spec["okeys"], K, flat[: 151 * 100], threads)
+        t_build = time.perf_counter() - t1                       # ~ table build only
+        rate = 20000 / max(1e-6, t_small - t_build)
+        n_s = args.cpu_sample_reads or int(min(args.reads, max(20000, rate * 15)))
+        flat = reads[: n_s * (READ_LEN + 1)].cpu().numpy()
+        t1 = time.perf_counter()
+        got = orc.count_flat(db_spec["okeys"], K, flat, threads)
+        t_cpu = time.perf_counter() - t1 - t_build
+        cpu = dict(value=round(n_s / t_cpu / 1e6, 4), unit="M reads/s", cores=threads, kind="port",
+                   sample="first %d reads of the rank-0 batch vs the same %d-row table; oracle/ss_oracle.c "
+                          "orc_count_flat (OpenMP), table build excluded" % (n_s, n_rows))
+        # and use it as a checker on that sample (never the other way round)
+        db.reset(stream)
+        db.scan_flat_dev(reads.data_ptr(), n_s * (READ_LEN + 1), stream)
+        torch.cuda.synchronize()
+        chk = db.counts_rows()
+        cpu["parity_on_sample"] = bool(np.array_equal(chk, got))
+
+    if rank == 0:
+        out = dict(metric="M reads/sec vs 1433-strain E. coli DB", value=round(reads_per_s / 1e6, 3),
+                   unit="M reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="u64", data="synthetic",
+                   config=dict(workload="E. coli 1433-strain/823-cluster DB, 10M synthetic 150 bp PE reads (20M reads) per GPU",
+                               db_rows=int(n_rows), tree_nodes=int(db_spec["n_nodes"]), reads_per_gpu=args.reads,
+                               read_len=READ_LEN, k=K, hit_frac=args.hit_frac, table_capacity=int(info["capacity"]),
+                               parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
+                   roofline=roofline, cpu_baseline=cpu,
+                   check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum())))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

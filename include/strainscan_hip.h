@@ -1,0 +1,165 @@
+/*
+ * strainscan_hip.h -- C ABI of the MI355X (gfx950) identification hot path of StrainScan.
+ *
+ * This is the drop-in boundary: plain C, caller-owned buffers, integer status codes (0 = ok,
+ * negative = error, see ss_strerror).  Python reaches it through ctypes
+ * (strainscan_amd/_lib.py); nothing in the signatures depends on PyTorch.  Each entry point
+ * names the reference interface (file:line under liaoherui/StrainScan) it replaces.
+ *
+ * Conventions
+ *   - "dev" pointers are HIP device pointers on the current device; "stream" is a hipStream_t
+ *     passed as void* (NULL = the default stream).  Functions whose name ends in _dev only
+ *     enqueue work on that stream; everything else is synchronous on return.
+ *   - k-mer keys are 2 bits per base, FIRST base in the LEAST significant bits, with the code
+ *     (ascii >> 1) & 3, i.e. A=0 C=1 T=2 G=3 (case-insensitive); k <= 31.
+ *   - a "flat base block" is the device input format of the scan: the sequence bytes of the
+ *     reads, one '\n' after every record.  Any byte outside ACGTacgt ends a k-mer window, so
+ *     k-mers never span records and N / IUPAC codes behave as in `jellyfish count`.
+ */
+#ifndef STRAINSCAN_HIP_H
+#define STRAINSCAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_OK 0
+#define SS_EINVAL (-22)   /* bad argument */
+#define SS_ENOMEM (-12)   /* host or device allocation failed */
+#define SS_EIO (-5)       /* file could not be read */
+#define SS_EHIP (-1000)   /* a HIP runtime call failed; ss_last_error() has the text */
+#define SS_ENODEV (-19)   /* no usable GPU */
+#define SS_EKEY (-2)      /* the reference would raise KeyError here */
+#define SS_ERANGE (-34)   /* value out of the supported range (k > 31, p > 16, ...) */
+
+#define SS_ROW_VALID 1u   /* row flag: ACGT-only k-mer of length k */
+#define SS_ROW_LOWER 2u   /* row flag: text contains lower-case letters */
+#define SS_NO_SLOT 0xFFFFFFFFu
+
+int ss_version(void);
+const char *ss_strerror(int code);
+const char *ss_last_error(void);         /* thread-local text of the last SS_EHIP */
+int ss_device_count(int *n);             /* does not initialise the GPU runtime beyond counting */
+int ss_set_device(int dev);
+int ss_device_sync(void);
+int ss_stream_sync(void *stream);
+
+/* device memory helpers for callers that do not bring their own allocator */
+int ss_dev_alloc(void **dptr, uint64_t bytes);
+int ss_dev_free(void *dptr);
+int ss_memcpy_h2d(void *dst_dev, const void *src, uint64_t bytes, void *stream);
+int ss_memcpy_d2h(void *dst, const void *src_dev, uint64_t bytes, void *stream);
+int ss_memset_dev(void *dst_dev, int byte, uint64_t bytes, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * seqpy.revcomp  (library/seqpy.c:24-36): reverse + IUPAC complement, case preserved.
+ * ss_revcomp is the host form (what the CPython extension did); ss_revcomp_dev runs the same
+ * table on the GPU for n_seq equal-length sequences stored back to back.
+ * ------------------------------------------------------------------------------------------ */
+int ss_revcomp(const char *in, char *out, uint64_t n);
+int ss_revcomp_dev(const char *in_dev, char *out_dev, uint64_t seq_len, uint64_t n_seq, void *stream);
+
+/* --------------------------------------------------------------------------------------------
+ * k-mer FASTA rows  (the `--if <db>/kmer.fa` / `all_kmer.fasta` argument of
+ * library/identify.py:82-86 and library/Vote_Strain_L2_Lasso_new_sp.py:359-371, and the
+ * kmer_index_dict loop of identify.py:90-95).
+ * Row i = i-th record (line 2i+1).  A row whose text is an ACGT-only k-mer (either case) gets
+ * SS_ROW_VALID and its 2-bit key; other rows get flags 0.
+ * ------------------------------------------------------------------------------------------ */
+int ss_kmerfa_count_rows(const char *path, uint64_t *n_rows);
+int ss_kmerfa_encode(const char *path, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags, int threads);
+/* same on an in-memory text */
+int ss_kmerfa_encode_mem(const char *text, uint64_t len, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags);
+/* one ASCII k-mer -> key; returns SS_EINVAL if it is not ACGT-only */
+int ss_encode_kmer(const char *kmer, int k, uint64_t *key);
+
+/* --------------------------------------------------------------------------------------------
+ * Device k-mer database = what `jellyfish count --if` builds from the FASTA
+ * (identify.py:82-86): an open-address table of the distinct valid row k-mers.
+ *   upper_keys = 1: identify.py semantics (dict keyed by .upper(), identify.py:94)
+ *   upper_keys = 0: identify_low_mem.py:81 / identify_low_depth.py:64 (raw keys): a lower-case
+ *                   row never owns a k-mer; ss_db_build returns SS_EKEY when a k-mer is left
+ *                   without an owning row (the reference raises KeyError at :88).
+ * Duplicate k-mers: the LAST row owns the count (dict overwrite); earlier rows are not valid.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ss_db ss_db;
+int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int k, int upper_keys,
+                ss_db **out);
+int ss_db_destroy(ss_db *db);
+int ss_db_info(const ss_db *db, uint64_t *n_rows, uint64_t *n_distinct, uint64_t *capacity, int *k);
+/* row_valid[i] = 1 iff row i is a key of the reference's match_results (identify.py:96-101) */
+int ss_db_row_valid(const ss_db *db, uint8_t *row_valid);
+const uint8_t *ss_db_row_valid_dev(const ss_db *db);
+uint64_t ss_db_device_bytes(const ss_db *db);
+
+/* --------------------------------------------------------------------------------------------
+ * The scan  (the `jellyfish count` + `dump -c` pair of identify.py:82-87,
+ * identify_low_mem.py:73-75, identify_low_depth.py:53-59, Vote_...:359-372).
+ * Counts accumulate in the db handle until ss_scan_reset.
+ *   ss_scan_flat_dev : flat base block already in HBM (n bytes), enqueued on `stream`
+ *   ss_scan_flat_host: flat base block in host memory; staged through pinned buffers, overlapping
+ *                      copies with kernels; synchronous
+ *   ss_scan_files    : FASTA/FASTQ files (plain or .gz), parsed on the host the way jellyfish
+ *                      reads them (multi-line records, '+'/'@' quality lines), then scanned
+ * ------------------------------------------------------------------------------------------ */
+int ss_scan_reset(ss_db *db, void *stream);
+int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream);
+int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n);
+int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records, uint64_t *n_bases);
+/* counts per ROW (match_results as an array; 0 for rows that are not valid) */
+int ss_counts_rows_dev(const ss_db *db, uint32_t *counts_rows_dev, void *stream);
+int ss_counts_rows(const ss_db *db, uint32_t *counts_rows);
+/* replace the accumulated counts by row counts (after an all-reduce across GPUs): not needed by
+ * single-GPU callers */
+uint64_t ss_scan_kernel_launches(const ss_db *db);
+
+/* --------------------------------------------------------------------------------------------
+ * Host FASTA/FASTQ -> flat base block (what jellyfish's sequence parser feeds its counter).
+ * out must hold at least len + 2 bytes.  Used by ss_scan_files and exposed for callers that
+ * shard reads themselves (multi-GPU).
+ * ------------------------------------------------------------------------------------------ */
+int ss_fastx_to_flat(const char *text, uint64_t len, char *out, uint64_t *out_len, uint64_t *n_records);
+typedef struct ss_reader ss_reader;
+int ss_reader_open(const char *const *paths, int n_paths, ss_reader **out);
+/* a record longer than the caller's buffer is cut and its last `overlap` bases are repeated at
+ * the start of the next block; must be k-1 for exact counts (default 30) */
+int ss_reader_set_overlap(ss_reader *r, int overlap);
+/* fills `out` with whole records up to cap bytes; *out_len == 0 at end of input */
+int ss_reader_next(ss_reader *r, char *out, uint64_t cap, uint64_t *out_len, uint64_t *n_records);
+int ss_reader_close(ss_reader *r);
+
+/* --------------------------------------------------------------------------------------------
+ * Per-node reductions = match_node + del_outlier for every tree node at once
+ * (library/identify.py:106-127; identify_low_depth.py:77-101).
+ * Node lists are the files <db>/kmers/<id> (0-based rows of kmer.fa), de-duplicated by the
+ * caller (the reference turns them into a set, identify.py:118).
+ * For node j with rows R_j:
+ *   length  = |{r in R_j : row_valid[r]}|                      (identify.py:119,127)
+ *   n_pos   = |{r : valid, counts[r] > 0}|                      (:121-124)
+ *   median2 = 2 * np.median(profile)  (exact integer)           (:107)
+ *   n_kept / sum_kept = size / sum of {c : c < 100*median}      (:106-112)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ss_nodes ss_nodes;
+typedef struct {
+    uint32_t length;
+    uint32_t n_pos;
+    uint32_t n_kept;
+    uint32_t reserved;
+    uint64_t sum_kept;
+    uint64_t median2;
+} ss_node_stat;
+int ss_nodes_create(const uint32_t *rows, const uint64_t *offsets, uint32_t n_nodes, ss_nodes **out);
+int ss_nodes_destroy(ss_nodes *ns);
+int ss_nodes_reduce_dev(const ss_nodes *ns, const uint32_t *counts_rows_dev, const uint8_t *row_valid_dev,
+                        ss_node_stat *stats_dev, void *stream);
+int ss_nodes_reduce(const ss_nodes *ns, const ss_db *db, ss_node_stat *stats /* host, n_nodes */);
+/* one ad-hoc row list (adjust_profile's `remain` set, identify.py:181-189) */
+int ss_rows_reduce(const ss_db *db, const uint32_t *rows, uint64_t n, ss_node_stat *stat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRAINSCAN_HIP_H */

@@ -1,0 +1,329 @@
+"""ctypes binding of libstrainscan_hip.so (the C ABI declared in include/strainscan_hip.h).
+
+Fails loudly: a missing library is an ImportError-like RuntimeError, a missing GPU surfaces as
+SSError(SS_ENODEV) from the first call that needs the device.  Nothing here falls back to a CPU
+implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstrainscan_hip.so")
+
+SS_OK, SS_EINVAL, SS_ENOMEM, SS_EIO, SS_EHIP, SS_ENODEV, SS_EKEY, SS_ERANGE = 0, -22, -12, -5, -1000, -19, -2, -34
+ROW_VALID, ROW_LOWER = 1, 2
+
+
+class SSError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        lib = _lib
+        msg = lib.ss_strerror(code).decode() if lib is not None else str(code)
+        if code == SS_EHIP and lib is not None:
+            msg += ": " + lib.ss_last_error().decode()
+        super().__init__("%s failed: %s (%d)" % (where, msg, code))
+
+
+class NodeStat(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("n_pos", C.c_uint32), ("n_kept", C.c_uint32), ("reserved", C.c_uint32),
+                ("sum_kept", C.c_uint64), ("median2", C.c_uint64)]
+
+
+NODE_STAT_DTYPE = np.dtype([("length", "<u4"), ("n_pos", "<u4"), ("n_kept", "<u4"), ("reserved", "<u4"),
+                            ("sum_kept", "<u8"), ("median2", "<u8")])
+
+_lib = None
+
+u64, u32, i32, vp, cp = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_char_p
+P = C.POINTER
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "ss_version": (i32, []),
+    "ss_strerror": (cp, [i32]),
+    "ss_last_error": (cp, []),
+    "ss_device_count": (i32, [P(i32)]),
+    "ss_set_device": (i32, [i32]),
+    "ss_device_sync": (i32, []),
+    "ss_stream_sync": (i32, [vp]),
+    "ss_dev_alloc": (i32, [P(vp), u64]),
+    "ss_dev_free": (i32, [vp]),
+    "ss_memcpy_h2d": (i32, [vp, vp, u64, vp]),
+    "ss_memcpy_d2h": (i32, [vp, vp, u64, vp]),
+    "ss_memset_dev": (i32, [vp, i32, u64, vp]),
+    "ss_revcomp": (i32, [cp, cp, u64]),
+    "ss_revcomp_dev": (i32, [vp, vp, u64, u64, vp]),
+    "ss_kmerfa_count_rows": (i32, [cp, P(u64)]),
+    "ss_kmerfa_encode": (i32, [cp, i32, u64, vp, vp, i32]),
+    "ss_kmerfa_encode_mem": (i32, [cp, u64, i32, u64, vp, vp]),
+    "ss_encode_kmer": (i32, [cp, i32, P(u64)]),
+    "ss_db_build": (i32, [vp, vp, u64, i32, i32, P(vp)]),
+    "ss_db_destroy": (i32, [vp]),
+    "ss_db_info": (i32, [vp, P(u64), P(u64), P(u64), P(i32)]),
+    "ss_db_row_valid": (i32, [vp, vp]),
+    "ss_db_row_valid_dev": (vp, [vp]),
+    "ss_db_device_bytes": (u64, [vp]),
+    "ss_scan_reset": (i32, [vp, vp]),
+    "ss_scan_flat_dev": (i32, [vp, vp, u64, vp]),
+    "ss_scan_flat_host": (i32, [vp, cp, u64]),
+    "ss_scan_files": (i32, [vp, P(cp), i32, P(u64), P(u64)]),
+    "ss_counts_rows_dev": (i32, [vp, vp, vp]),
+    "ss_counts_rows": (i32, [vp, vp]),
+    "ss_scan_kernel_launches": (u64, [vp]),
+    "ss_fastx_to_flat": (i32, [cp, u64, vp, P(u64), P(u64)]),
+    "ss_reader_open": (i32, [P(cp), i32, P(vp)]),
+    "ss_reader_set_overlap": (i32, [vp, i32]),
+    "ss_reader_next": (i32, [vp, vp, u64, P(u64), P(u64)]),
+    "ss_reader_close": (i32, [vp]),
+    "ss_nodes_create": (i32, [vp, vp, u32, P(vp)]),
+    "ss_nodes_destroy": (i32, [vp]),
+    "ss_nodes_reduce_dev": (i32, [vp, vp, vp, vp, vp]),
+    "ss_nodes_reduce": (i32, [vp, vp, vp]),
+    "ss_rows_reduce": (i32, [vp, vp, u64, P(NodeStat)]),
+}
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same soname as
+    /opt/rocm's); whichever is loaded first serves both.  If this library were loaded first it
+    would pull /opt/rocm's runtime and a later `import torch` (multi-GPU plumbing, bench.py)
+    then fails with "No HIP GPUs are available".  So when torch is installed, map ITS runtime
+    first; without torch the RUNPATH of libstrainscan_hip.so finds /opt/rocm's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "strainscan_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C strainscan_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+        _preload_hip_runtime()
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = library older than the binding
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != SS_OK:
+        if rc == SS_EKEY:
+            raise KeyError("%s: a database k-mer has no owning row (identify_low_mem.py:88)" % where)
+        raise SSError(rc, where)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().ss_device_count(C.byref(n))
+    return n.value if rc == SS_OK else 0
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise SSError(SS_ENODEV, "strainscan_amd (no MI355X visible; there is no CPU fallback)")
+
+
+# -------------------------------------------------------------------------------------------------
+class KmerDB:
+    """Device k-mer table built from a k-mer FASTA (`--if` argument of the reference's jellyfish
+    calls, library/identify.py:82-86) with per-row bookkeeping of identify.py:90-101."""
+
+    def __init__(self, keys, flags, k=31, upper_keys=True):
+        require_gpu()
+        keys = np.ascontiguousarray(keys, np.uint64)
+        flags = np.ascontiguousarray(flags, np.uint8)
+        assert keys.shape == flags.shape
+        h = C.c_void_p()
+        check(lib().ss_db_build(ptr(keys), ptr(flags), keys.size, int(k), int(bool(upper_keys)), C.byref(h)),
+              "ss_db_build")
+        self._h = h
+        self.k = int(k)
+        self.n_rows = int(keys.size)
+        self._row_valid = None
+
+    @classmethod
+    def from_fasta(cls, path, k=31, upper_keys=True, threads=0):
+        n = C.c_uint64()
+        check(lib().ss_kmerfa_count_rows(os.fsencode(path), C.byref(n)), "ss_kmerfa_count_rows(%s)" % path)
+        keys = np.empty(n.value, np.uint64)
+        flags = np.empty(n.value, np.uint8)
+        check(lib().ss_kmerfa_encode(os.fsencode(path), int(k), n.value, ptr(keys), ptr(flags), threads),
+              "ss_kmerfa_encode(%s)" % path)
+        return cls(keys, flags, k, upper_keys)
+
+    @classmethod
+    def from_text(cls, text, k=31, upper_keys=True):
+        keys, flags = encode_kmer_fasta(text, k)
+        return cls(keys, flags, k, upper_keys)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss_db_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        a, b, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        check(lib().ss_db_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(k)), "ss_db_info")
+        return dict(n_rows=a.value, n_distinct=b.value, capacity=c.value, k=k.value,
+                    device_bytes=int(lib().ss_db_device_bytes(self._h)))
+
+    @property
+    def row_valid(self):
+        if self._row_valid is None:
+            v = np.zeros(self.n_rows, np.uint8)
+            check(lib().ss_db_row_valid(self._h, ptr(v)), "ss_db_row_valid")
+            self._row_valid = v
+        return self._row_valid
+
+    @property
+    def row_valid_dev(self):
+        return lib().ss_db_row_valid_dev(self._h)
+
+    def reset(self, stream=None):
+        check(lib().ss_scan_reset(self._h, stream), "ss_scan_reset")
+
+    def scan_flat_dev(self, dptr, n, stream=None):
+        check(lib().ss_scan_flat_dev(self._h, dptr, int(n), stream), "ss_scan_flat_dev")
+
+    def scan_flat(self, bases):
+        b = bytes(bases) if not isinstance(bases, bytes) else bases
+        check(lib().ss_scan_flat_host(self._h, b, len(b)), "ss_scan_flat_host")
+
+    def scan_files(self, paths):
+        paths = [os.fsencode(p) for p in paths if p]
+        arr = (C.c_char_p * len(paths))(*paths)
+        nrec, nb = C.c_uint64(), C.c_uint64()
+        check(lib().ss_scan_files(self._h, arr, len(paths), C.byref(nrec), C.byref(nb)), "ss_scan_files")
+        return nrec.value, nb.value
+
+    def counts_rows(self):
+        out = np.zeros(self.n_rows, np.uint32)
+        check(lib().ss_counts_rows(self._h, ptr(out)), "ss_counts_rows")
+        return out
+
+    def counts_rows_dev(self, dptr, stream=None):
+        check(lib().ss_counts_rows_dev(self._h, dptr, stream), "ss_counts_rows_dev")
+
+
+class NodeSet:
+    """All tree-node k-mer row lists on the device (files <db>/kmers/<id>, identify.py:116-118)."""
+
+    def __init__(self, row_lists):
+        require_gpu()
+        offs = np.zeros(len(row_lists) + 1, np.uint64)
+        dedup = []
+        for i, r in enumerate(row_lists):
+            r = np.unique(np.asarray(r, np.int64))  # set(map(int, ...)) at identify.py:118
+            dedup.append(r.astype(np.uint32))
+            offs[i + 1] = offs[i] + r.size
+        rows = np.concatenate(dedup) if dedup else np.zeros(0, np.uint32)
+        rows = np.ascontiguousarray(rows, np.uint32)
+        h = C.c_void_p()
+        check(lib().ss_nodes_create(ptr(rows), ptr(offs), len(row_lists), C.byref(h)), "ss_nodes_create")
+        self._h = h
+        self.n_nodes = len(row_lists)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss_nodes_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reduce(self, db):
+        st = np.zeros(self.n_nodes, NODE_STAT_DTYPE)
+        check(lib().ss_nodes_reduce(self._h, db.handle, ptr(st)), "ss_nodes_reduce")
+        return st
+
+    def reduce_dev(self, counts_rows_dptr, row_valid_dptr, stats_dptr, stream=None):
+        check(lib().ss_nodes_reduce_dev(self._h, counts_rows_dptr, row_valid_dptr, stats_dptr, stream),
+              "ss_nodes_reduce_dev")
+
+
+def rows_reduce(db, rows):
+    rows = np.ascontiguousarray(np.unique(np.asarray(rows, np.int64)), np.uint32)
+    st = NodeStat()
+    check(lib().ss_rows_reduce(db.handle, ptr(rows), rows.size, C.byref(st)), "ss_rows_reduce")
+    return dict(length=st.length, n_pos=st.n_pos, n_kept=st.n_kept, sum_kept=st.sum_kept, median2=st.median2)
+
+
+def encode_kmer_fasta(text, k=31):
+    nl = text.count(b"\n") + (1 if text and not text.endswith(b"\n") else 0)
+    n = nl // 2
+    keys = np.empty(n, np.uint64)
+    flags = np.empty(n, np.uint8)
+    check(lib().ss_kmerfa_encode_mem(text, len(text), int(k), n, ptr(keys), ptr(flags)), "ss_kmerfa_encode_mem")
+    return keys, flags
+
+
+def fastx_to_flat(text):
+    out = np.empty(len(text) + 2, np.uint8)
+    n, nrec = C.c_uint64(), C.c_uint64()
+    check(lib().ss_fastx_to_flat(text, len(text), ptr(out), C.byref(n), C.byref(nrec)), "ss_fastx_to_flat")
+    return out[:n.value].tobytes(), nrec.value
+
+
+def read_flat_blocks(paths, cap=32 << 20, overlap=30):
+    """Generator of (flat block bytes, n_records) from FASTA/FASTQ(.gz) files."""
+    paths = [os.fsencode(p) for p in paths if p]
+    arr = (C.c_char_p * len(paths))(*paths)
+    h = C.c_void_p()
+    check(lib().ss_reader_open(arr, len(paths), C.byref(h)), "ss_reader_open")
+    try:
+        check(lib().ss_reader_set_overlap(h, overlap), "ss_reader_set_overlap")
+        buf = np.empty(cap, np.uint8)
+        while True:
+            n, nrec = C.c_uint64(), C.c_uint64()
+            check(lib().ss_reader_next(h, ptr(buf), cap, C.byref(n), C.byref(nrec)), "ss_reader_next")
+            if n.value == 0:
+                break
+            yield buf[:n.value].tobytes(), nrec.value
+    finally:
+        lib().ss_reader_close(h)
+
+
+def revcomp(s):
+    b = s.encode() if isinstance(s, str) else bytes(s)
+    out = C.create_string_buffer(len(b))
+    check(lib().ss_revcomp(b, out, len(b)), "ss_revcomp")
+    return out.raw.decode() if isinstance(s, str) else out.raw

@@ -1,0 +1,76 @@
+// Internal helpers shared by the gfx950 translation units.  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "strainscan_hip.h"
+
+namespace ss {
+
+void set_last_error(const char *what, const char *file, int line, hipError_t e);
+
+#define SS_HIP(call)                                               \
+    do {                                                           \
+        hipError_t _e = (call);                                    \
+        if (_e != hipSuccess) {                                    \
+            ss::set_last_error(#call, __FILE__, __LINE__, _e);     \
+            return (_e == hipErrorOutOfMemory) ? SS_ENOMEM         \
+                   : (_e == hipErrorNoDevice)  ? SS_ENODEV         \
+                                               : SS_EHIP;          \
+        }                                                          \
+    } while (0)
+
+constexpr uint64_t EMPTY_KEY = ~0ull;
+
+// Table hash.  Two odd multipliers with a fold in between: the keys are overlapping windows of
+// genomes (key[p+1] = key[p] >> 2 | base << 2(k-1)), so a single multiplicative hash would map
+// neighbouring windows to related slots.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x *= 0x9E3779B97F4A7C15ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 29;
+    return x;
+}
+
+__host__ __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t log2cap)
+{
+    return (uint32_t)(mix64(key) >> (64 - log2cap));
+}
+
+// ascii -> 2-bit code ((c >> 1) & 3: A0 C1 T2 G3) or -1
+__host__ __device__ __forceinline__ int base_code(unsigned char c)
+{
+    unsigned char u = c & 0xDF;
+    if (u == 'A' || u == 'C' || u == 'G' || u == 'T') return (c >> 1) & 3;
+    return -1;
+}
+
+inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+
+}  // namespace ss
+
+// The opaque database handle.
+struct ss_db {
+    int k = 0;
+    int device = 0;
+    uint64_t n_rows = 0;
+    uint64_t n_distinct = 0;
+    uint32_t log2cap = 0;
+    uint64_t capacity = 0;
+    uint64_t *d_keys = nullptr;        // [capacity] table keys, EMPTY_KEY where free
+    uint32_t *d_counts = nullptr;      // [capacity] occurrences per slot (accumulated by scans)
+    uint32_t *d_slot_of_row = nullptr; // [n_rows]   slot owning row i, SS_NO_SLOT if none
+    uint8_t *d_row_valid = nullptr;    // [n_rows]   1 iff row i is a key of match_results
+    // pinned staging for host-resident base blocks
+    char *h_stage[2] = {nullptr, nullptr};
+    char *d_stage[2] = {nullptr, nullptr};
+    uint64_t stage_bytes = 0;
+    hipStream_t streams[2] = {nullptr, nullptr};
+    hipEvent_t stage_free[2] = {nullptr, nullptr};
+    uint64_t launches = 0;
+    uint64_t device_bytes = 0;
+};

@@ -1,0 +1,472 @@
+// ss_host.hip -- host side of the C ABI: error text, device helpers, k-mer FASTA rows,
+// FASTA/FASTQ -> flat base blocks (what jellyfish's sequence parser hands its counter), revcomp.
+#include "ss_common.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace ss {
+static thread_local char g_last_error[512] = "";
+void set_last_error(const char *what, const char *file, int line, hipError_t e)
+{
+    snprintf(g_last_error, sizeof(g_last_error), "%s failed at %s:%d: %s", what, file, line, hipGetErrorString(e));
+}
+}  // namespace ss
+
+namespace {
+
+// IUPAC complement of library/seqpy.c:5-22 stated as a rule (letters only, case kept; '`' -> '@').
+__host__ __device__ inline unsigned char comp_base(unsigned char c)
+{
+    const char *up = "TVGHEFCDIJMLKNOPQYSAABWXRZ";
+    if (c >= 'A' && c <= 'Z') return (unsigned char)up[c - 'A'];
+    if (c >= 'a' && c <= 'z') return (unsigned char)(up[c - 'a'] + 32);
+    if (c == 0x60) return 0x40;
+    return c;
+}
+
+__global__ void revcomp_kernel(const char *__restrict__ in, char *__restrict__ out, uint64_t seq_len, uint64_t n_seq)
+{
+    const uint64_t total = seq_len * n_seq;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t s = i / seq_len, p = i - s * seq_len;
+        out[s * seq_len + (seq_len - 1 - p)] = (char)comp_base((unsigned char)in[i]);
+    }
+}
+
+bool read_whole_file(const char *path, std::string &out)
+{
+    gzFile f = gzopen(path, "rb");
+    if (!f) return false;
+    gzbuffer(f, 1 << 20);
+    std::vector<char> buf(8 << 20);
+    for (;;) {
+        int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n < 0) { gzclose(f); return false; }
+        if (n == 0) break;
+        out.append(buf.data(), (size_t)n);
+    }
+    gzclose(f);
+    return true;
+}
+
+// rows of a k-mer FASTA exactly like f.readlines()[2*i+1].rstrip()  (identify.py:92-94)
+struct RowSpan { uint64_t s, e; };
+
+void split_rows(const char *t, uint64_t len, std::vector<RowSpan> &rows)
+{
+    uint64_t pos = 0, line = 0;
+    while (pos < len) {
+        uint64_t s = pos;
+        const void *nl = memchr(t + pos, '\n', len - pos);
+        uint64_t e = nl ? (uint64_t)((const char *)nl - t) : len;
+        pos = nl ? e + 1 : len;
+        if (line & 1) {
+            while (e > s && (t[e - 1] == ' ' || t[e - 1] == '\r' || t[e - 1] == '\t' || t[e - 1] == '\v' ||
+                             t[e - 1] == '\f'))
+                e--;
+            rows.push_back({s, e});
+        }
+        line++;
+    }
+}
+
+void encode_rows(const char *t, const RowSpan *rows, uint64_t n, int k, uint64_t *keys, uint8_t *flags)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        keys[i] = 0;
+        flags[i] = 0;
+        if (rows[i].e - rows[i].s != (uint64_t)k) continue;
+        uint64_t key = 0;
+        uint8_t f = SS_ROW_VALID;
+        for (int j = 0; j < k; j++) {
+            unsigned char c = (unsigned char)t[rows[i].s + j];
+            int code = ss::base_code(c);
+            if (code < 0) { f = 0; break; }
+            if (c >= 'a') f |= SS_ROW_LOWER;
+            key |= (uint64_t)code << (2 * j);
+        }
+        if (f) { keys[i] = key; flags[i] = f; }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// FASTA/FASTQ reader: the record grammar jellyfish 2.3.0 accepts [probed, tests/golden/f1]:
+//   '>' header, sequence lines up to the next '>' line;
+//   '@' header, sequence lines up to a '+' line, then quality lines until as many quality
+//   characters as sequence characters were consumed; blank lines between records are skipped;
+//   the sequence lines of one record are concatenated.
+// Output: sequence bytes, one '\n' after each record.  A record that does not fit the caller's
+// buffer is cut, the continuation re-emitting the last `overlap` bases so that no k-mer
+// (k <= overlap + 1) is lost or counted twice.
+// ---------------------------------------------------------------------------------------------
+struct ss_reader {
+    std::vector<std::string> paths;
+    size_t file_idx = 0;
+    gzFile f = nullptr;
+    std::vector<char> in;
+    size_t in_pos = 0, in_len = 0;
+    bool eof_file = true;
+    enum State { START, FA_HDR, FA_SEQ_BOL, FA_SEQ, FQ_HDR, FQ_SEQ_BOL, FQ_SEQ, FQ_PLUS, FQ_QUAL } st = START;
+    uint64_t seqlen = 0, qlen = 0;
+    int overlap = 30;
+    std::string tail;      // last `overlap` bases of the current record (for cut records)
+    bool need_tail = false;
+};
+
+namespace {
+
+bool reader_fill(ss_reader *r)
+{
+    for (;;) {
+        if (r->f) {
+            int n = gzread(r->f, r->in.data(), (unsigned)r->in.size());
+            if (n > 0) { r->in_pos = 0; r->in_len = (size_t)n; return true; }
+            gzclose(r->f);
+            r->f = nullptr;
+            // end of file ends the record in flight
+            return false;
+        }
+        return false;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_version(void) { return 100; }
+
+const char *ss_strerror(int code)
+{
+    switch (code) {
+    case SS_OK: return "ok";
+    case SS_EINVAL: return "invalid argument";
+    case SS_ENOMEM: return "out of memory";
+    case SS_EIO: return "I/O error";
+    case SS_EHIP: return "HIP runtime error";
+    case SS_ENODEV: return "no usable GPU";
+    case SS_EKEY: return "k-mer without an owning row (KeyError in the reference)";
+    case SS_ERANGE: return "value out of supported range";
+    default: return "unknown error";
+    }
+}
+
+const char *ss_last_error(void) { return ss::g_last_error; }
+
+int ss_device_count(int *n)
+{
+    if (!n) return SS_EINVAL;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; ss::set_last_error("hipGetDeviceCount", __FILE__, __LINE__, e); return SS_ENODEV; }
+    *n = c;
+    return SS_OK;
+}
+
+int ss_set_device(int dev) { SS_HIP(hipSetDevice(dev)); return SS_OK; }
+int ss_device_sync(void) { SS_HIP(hipDeviceSynchronize()); return SS_OK; }
+int ss_stream_sync(void *stream) { SS_HIP(hipStreamSynchronize(ss::as_stream(stream))); return SS_OK; }
+
+int ss_dev_alloc(void **dptr, uint64_t bytes)
+{
+    if (!dptr) return SS_EINVAL;
+    SS_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return SS_OK;
+}
+int ss_dev_free(void *dptr) { SS_HIP(hipFree(dptr)); return SS_OK; }
+int ss_memcpy_h2d(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    SS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ss::as_stream(stream)));
+    SS_HIP(hipStreamSynchronize(ss::as_stream(stream)));
+    return SS_OK;
+}
+int ss_memcpy_d2h(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    SS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ss::as_stream(stream)));
+    SS_HIP(hipStreamSynchronize(ss::as_stream(stream)));
+    return SS_OK;
+}
+int ss_memset_dev(void *dst, int byte, uint64_t bytes, void *stream)
+{
+    SS_HIP(hipMemsetAsync(dst, byte, bytes, ss::as_stream(stream)));
+    return SS_OK;
+}
+
+int ss_revcomp(const char *in, char *out, uint64_t n)
+{
+    if (n && (!in || !out)) return SS_EINVAL;
+    for (uint64_t i = 0; i < n; i++) out[n - 1 - i] = (char)comp_base((unsigned char)in[i]);
+    return SS_OK;
+}
+
+int ss_revcomp_dev(const char *in_dev, char *out_dev, uint64_t seq_len, uint64_t n_seq, void *stream)
+{
+    if (!seq_len || !n_seq) return SS_OK;
+    if (!in_dev || !out_dev) return SS_EINVAL;
+    const uint64_t total = seq_len * n_seq;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(revcomp_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), in_dev, out_dev, seq_len,
+                       n_seq);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_encode_kmer(const char *kmer, int k, uint64_t *key)
+{
+    if (!kmer || !key || k < 1 || k > 31) return SS_EINVAL;
+    uint64_t v = 0;
+    for (int j = 0; j < k; j++) {
+        int code = ss::base_code((unsigned char)kmer[j]);
+        if (code < 0) return SS_EINVAL;
+        v |= (uint64_t)code << (2 * j);
+    }
+    *key = v;
+    return SS_OK;
+}
+
+int ss_kmerfa_count_rows(const char *path, uint64_t *n_rows)
+{
+    if (!path || !n_rows) return SS_EINVAL;
+    std::string t;
+    if (!read_whole_file(path, t)) return SS_EIO;
+    uint64_t nl = 0;
+    for (char c : t) nl += (c == '\n');
+    if (!t.empty() && t.back() != '\n') nl++;
+    *n_rows = nl / 2;
+    return SS_OK;
+}
+
+int ss_kmerfa_encode_mem(const char *text, uint64_t len, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags)
+{
+    if ((len && !text) || (n_rows && (!keys || !flags))) return SS_EINVAL;
+    if (k < 1 || k > 31) return SS_ERANGE;
+    std::vector<RowSpan> rows;
+    split_rows(text, len, rows);
+    if (rows.size() != n_rows) return SS_EINVAL;
+    encode_rows(text, rows.data(), n_rows, k, keys, flags);
+    return SS_OK;
+}
+
+int ss_kmerfa_encode(const char *path, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags, int threads)
+{
+    if (!path || (n_rows && (!keys || !flags))) return SS_EINVAL;
+    if (k < 1 || k > 31) return SS_ERANGE;
+    std::string t;
+    if (!read_whole_file(path, t)) return SS_EIO;
+    std::vector<RowSpan> rows;
+    split_rows(t.data(), t.size(), rows);
+    if (rows.size() != n_rows) return SS_EINVAL;
+    if (threads <= 0) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (n_rows < 100000) threads = 1;
+    std::vector<std::thread> pool;
+    const uint64_t per = (n_rows + threads - 1) / threads;
+    for (int w = 0; w < threads; w++) {
+        const uint64_t lo = std::min<uint64_t>(n_rows, per * w), hi = std::min<uint64_t>(n_rows, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back([&, lo, hi] { encode_rows(t.data(), rows.data() + lo, hi - lo, k, keys + lo, flags + lo); });
+    }
+    for (auto &th : pool) th.join();
+    return SS_OK;
+}
+
+int ss_reader_open(const char *const *paths, int n_paths, ss_reader **out)
+{
+    if (!paths || n_paths < 1 || !out) return SS_EINVAL;
+    ss_reader *r = new (std::nothrow) ss_reader();
+    if (!r) return SS_ENOMEM;
+    for (int i = 0; i < n_paths; i++) {
+        if (!paths[i]) { delete r; return SS_EINVAL; }
+        if (paths[i][0]) r->paths.emplace_back(paths[i]);  // '' = no second file (StrainScan.py:182)
+    }
+    r->in.resize(4 << 20);
+    for (const auto &p : r->paths) {  // fail early on unreadable inputs
+        gzFile f = gzopen(p.c_str(), "rb");
+        if (!f) { delete r; return SS_EIO; }
+        gzclose(f);
+    }
+    *out = r;
+    return SS_OK;
+}
+
+int ss_reader_set_overlap(ss_reader *r, int overlap)
+{
+    if (!r || overlap < 0 || overlap > 62) return SS_EINVAL;
+    r->overlap = overlap;
+    return SS_OK;
+}
+
+int ss_reader_close(ss_reader *r)
+{
+    if (!r) return SS_OK;
+    if (r->f) gzclose(r->f);
+    delete r;
+    return SS_OK;
+}
+
+int ss_reader_next(ss_reader *r, char *out, uint64_t cap, uint64_t *out_len, uint64_t *n_records)
+{
+    if (!r || !out || !out_len || cap < 4096) return SS_EINVAL;
+    uint64_t o = 0, recs = 0;
+    const uint64_t ov = (uint64_t)r->overlap;
+    auto in_seq = [&] { return r->st == ss_reader::FA_SEQ_BOL || r->st == ss_reader::FA_SEQ ||
+                               r->st == ss_reader::FQ_SEQ_BOL || r->st == ss_reader::FQ_SEQ; };
+    if (r->need_tail) {  // continuation of a record cut at the previous buffer end
+        memcpy(out, r->tail.data(), r->tail.size());
+        o = r->tail.size();
+        r->need_tail = false;
+    }
+    auto end_record = [&] {
+        out[o++] = '\n';
+        recs++;
+        r->tail.clear();
+    };
+    for (;;) {
+        if (r->in_pos >= r->in_len) {
+            if (!r->f) {
+                // finish a record that the previous file left open, then open the next file
+                if (r->st != ss_reader::START) {
+                    if (in_seq()) end_record();
+                    r->st = ss_reader::START;
+                }
+                if (r->file_idx >= r->paths.size()) break;
+                r->f = gzopen(r->paths[r->file_idx++].c_str(), "rb");
+                if (!r->f) return SS_EIO;
+                gzbuffer(r->f, 1 << 20);
+            }
+            if (!reader_fill(r)) continue;  // file ended: loop closes the record / opens the next
+        }
+        // leave room for the longest thing one step can append: a line chunk is bounded below
+        if (o + 2 >= cap) {
+            if (in_seq()) {  // cut inside a sequence: remember the last `overlap` bases
+                uint64_t s = o;
+                while (s > 0 && out[s - 1] != '\n' && o - s < ov) s--;
+                r->tail.assign(out + s, out + o);
+                r->need_tail = true;
+            }
+            break;
+        }
+        const char *p = r->in.data() + r->in_pos;
+        const size_t avail = r->in_len - r->in_pos;
+        switch (r->st) {
+        case ss_reader::START: {
+            const char c = *p;
+            if (c == '\n') { r->in_pos++; }
+            else if (c == '>') { r->st = ss_reader::FA_HDR; }
+            else if (c == '@') { r->st = ss_reader::FQ_HDR; r->seqlen = 0; r->qlen = 0; }
+            else { r->st = ss_reader::FQ_PLUS; r->seqlen = 0; r->qlen = 0; }  // stray line: skip it
+            break;
+        }
+        case ss_reader::FA_HDR:
+        case ss_reader::FQ_HDR:
+        case ss_reader::FQ_PLUS: {
+            const void *nl = memchr(p, '\n', avail);
+            if (!nl) { r->in_pos = r->in_len; break; }
+            r->in_pos += (size_t)((const char *)nl - p) + 1;
+            r->st = (r->st == ss_reader::FA_HDR)   ? ss_reader::FA_SEQ_BOL
+                    : (r->st == ss_reader::FQ_HDR) ? ss_reader::FQ_SEQ_BOL
+                    : (r->qlen < r->seqlen)        ? ss_reader::FQ_QUAL
+                                                   : ss_reader::START;
+            break;
+        }
+        case ss_reader::FA_SEQ_BOL:
+            if (*p == '>') { end_record(); r->st = ss_reader::FA_HDR; }
+            else r->st = ss_reader::FA_SEQ;
+            break;
+        case ss_reader::FQ_SEQ_BOL:
+            if (*p == '+') { end_record(); r->st = ss_reader::FQ_PLUS; }
+            else r->st = ss_reader::FQ_SEQ;
+            break;
+        case ss_reader::FA_SEQ:
+        case ss_reader::FQ_SEQ: {
+            const void *nl = memchr(p, '\n', avail);
+            size_t n = nl ? (size_t)((const char *)nl - p) : avail;
+            const uint64_t room = cap - 2 - o;
+            bool whole = true;
+            if (n > room) { n = (size_t)room; whole = false; }
+            memcpy(out + o, p, n);
+            o += n;
+            r->seqlen += n;
+            r->in_pos += n;
+            if (whole && nl) {
+                r->in_pos++;
+                r->st = (r->st == ss_reader::FA_SEQ) ? ss_reader::FA_SEQ_BOL : ss_reader::FQ_SEQ_BOL;
+            }
+            break;
+        }
+        case ss_reader::FQ_QUAL: {
+            const void *nl = memchr(p, '\n', avail);
+            size_t n = nl ? (size_t)((const char *)nl - p) : avail;
+            r->qlen += n;
+            r->in_pos += n + (nl ? 1 : 0);
+            if (nl && r->qlen >= r->seqlen) r->st = ss_reader::START;
+            break;
+        }
+        }
+    }
+    *out_len = o;
+    if (n_records) *n_records = recs;
+    return SS_OK;
+}
+
+int ss_fastx_to_flat(const char *text, uint64_t len, char *out, uint64_t *out_len, uint64_t *n_records)
+{
+    if ((len && !text) || !out || !out_len) return SS_EINVAL;
+    // same grammar as ss_reader_next, on an in-memory text (single pass, no cuts)
+    uint64_t i = 0, o = 0, recs = 0;
+    const char *t = text;
+    while (i < len) {
+        if (t[i] == '\n') { i++; continue; }
+        if (t[i] == '>') {
+            const void *nl = memchr(t + i, '\n', len - i);
+            i = nl ? (uint64_t)((const char *)nl - t) + 1 : len;
+            while (i < len && t[i] != '>') {
+                nl = memchr(t + i, '\n', len - i);
+                uint64_t e = nl ? (uint64_t)((const char *)nl - t) : len;
+                memcpy(out + o, t + i, e - i);
+                o += e - i;
+                i = nl ? e + 1 : len;
+            }
+            out[o++] = '\n';
+            recs++;
+        } else if (t[i] == '@') {
+            uint64_t seqlen = 0, qlen = 0;
+            const void *nl = memchr(t + i, '\n', len - i);
+            i = nl ? (uint64_t)((const char *)nl - t) + 1 : len;
+            while (i < len && t[i] != '+') {
+                nl = memchr(t + i, '\n', len - i);
+                uint64_t e = nl ? (uint64_t)((const char *)nl - t) : len;
+                memcpy(out + o, t + i, e - i);
+                o += e - i;
+                seqlen += e - i;
+                i = nl ? e + 1 : len;
+            }
+            out[o++] = '\n';
+            recs++;
+            nl = (i < len) ? memchr(t + i, '\n', len - i) : nullptr;
+            i = nl ? (uint64_t)((const char *)nl - t) + 1 : len;
+            while (i < len && qlen < seqlen) {
+                nl = memchr(t + i, '\n', len - i);
+                uint64_t e = nl ? (uint64_t)((const char *)nl - t) : len;
+                qlen += e - i;
+                i = nl ? e + 1 : len;
+            }
+        } else {
+            const void *nl = memchr(t + i, '\n', len - i);
+            i = nl ? (uint64_t)((const char *)nl - t) + 1 : len;
+        }
+    }
+    *out_len = o;
+    if (n_records) *n_records = recs;
+    return SS_OK;
+}
+
+}  // extern "C"

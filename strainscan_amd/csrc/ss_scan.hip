@@ -1,0 +1,473 @@
+// ss_scan.hip -- device k-mer table + the read-vs-database scan for gfx950 (MI355X).
+//
+// Replaces the `jellyfish count -m k --if <fasta> ... ; jellyfish dump -c` pair the reference
+// spawns at library/identify.py:82-87, identify_low_mem.py:73-75, identify_low_depth.py:53-59
+// and Vote_Strain_L2_Lasso_new_sp.py:359-372, and the Python tail that maps the dumped k-mers
+// back to rows of kmer.fa (identify.py:90-101).
+//
+// Data layout in HBM
+//   d_keys[capacity]   u64  open-address table (linear probing, load <= 0.5), EMPTY = ~0
+//   d_counts[capacity] u32  occurrences per slot; scans only ever atomicAdd into it
+//   d_slot_of_row[n]   u32  slot that owns kmer.fa row i (SS_NO_SLOT if the row has no k-mer)
+//   d_row_valid[n]     u8   1 iff row i is a key of the reference's match_results
+// Keeping the counters slot-indexed means a hit costs one atomic on the line next to the key
+// that was just read and no row-index lookup; rows are resolved once per scan by a gather.
+//
+// The scan kernel is HBM/latency bound (random 8-byte gathers into a table far larger than
+// L2): 150 B of bases + 120 probes x 8 B per 150-bp read and ~40 VALU ops per probe.
+#include "ss_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int PPT = 16;                        // k-mer start positions per thread per tile
+constexpr int TILE = SCAN_THREADS * PPT;       // bytes of the base stream per tile
+constexpr uint64_t STAGE_BYTES = 32ull << 20;  // pinned staging chunk for host-resident blocks
+
+// ---------------------------------------------------------------------------------------------
+// 16 ASCII bases (4 dwords) -> 32 bits of 2-bit codes (base i at bits 2i) + 16 invalid flags.
+// SWAR: no per-byte loop, no LDS lookup table.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v)
+{   // 0x80 in every byte of v that is zero (exact form, no borrow artefacts)
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+}
+
+__device__ __forceinline__ void encode4(uint32_t w, uint32_t &code8, uint32_t &bad4)
+{
+    uint32_t x = (w & 0xDFDFDFDFu) ^ 0x41414141u;           // A->00 C->02 G->06 T->15 (either case)
+    uint32_t ok = zero_bytes(x) | zero_bytes(x ^ 0x02020202u) | zero_bytes(x ^ 0x06060606u) |
+                  zero_bytes(x ^ 0x15151515u);
+    bad4 = (((ok ^ 0x80808080u) >> 7) * 0x01020408u) >> 24; // bit i = byte i is not ACGT
+    uint32_t c = (w >> 1) & 0x03030303u;                    // (ascii >> 1) & 3 per byte
+    code8 = (c * 0x01041040u) >> 24;                        // pack the four 2-bit fields
+}
+
+__device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t &code, uint32_t &inv)
+{
+    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
+    encode4(w[0], c0, b0);
+    encode4(w[1], c1, b1);
+    encode4(w[2], c2, b2);
+    encode4(w[3], c3, b3);
+    code = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+    inv = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+}
+
+// 16 bytes at `off` of the base stream; bytes at or beyond n read as '\n'.
+template <bool ALIGNED>
+__device__ __forceinline__ void load16(const uint8_t *__restrict__ bases, uint64_t off, uint64_t n,
+                                       uint32_t w[4])
+{
+    if (ALIGNED && off + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(bases + off);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                uint64_t p = off + d * 4 + b;
+                uint32_t c = (p < n) ? bases[p] : 0x0Au;
+                x |= c << (8 * b);
+            }
+            w[d] = x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode + probe + count.  One tile = 4096 consecutive start positions of the flat base stream
+// (+30 bytes of halo).  Phase 1: coalesced 16-byte loads, SWAR 2-bit encode, codes to LDS.
+// Phase 2: each lane rebuilds its 16 overlapping k-mers from three LDS dwords with funnel
+// shifts, issues the 16 first-probe loads back to back (16 independent HBM gathers in flight
+// per lane), then resolves them; only the rare collision chains loop.
+// ---------------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(
+    const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles,
+    const uint64_t *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t log2cap, int k)
+{
+    __shared__ uint32_t s_code[2][SCAN_THREADS + 2];
+    __shared__ uint16_t s_inv[2][SCAN_THREADS + 2];
+
+    const int t = threadIdx.x;
+    const uint64_t kmask = (~0ull) >> (64 - 2 * k);
+    const uint64_t wmask = (1ull << k) - 1;
+    const uint32_t smask = (uint32_t)((1ull << log2cap) - 1);
+    int buf = 0;
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        const uint64_t base = tile * (uint64_t)TILE;
+        {
+            uint32_t w[4], code, inv;
+            load16<ALIGNED>(bases, base + (uint64_t)t * 16, n, w);
+            encode16(w, code, inv);
+            s_code[buf][t] = code;
+            s_inv[buf][t] = (uint16_t)inv;
+            if (t < 2) {  // halo: the last k-mers of the tile reach k-1 bytes past it
+                load16<ALIGNED>(bases, base + TILE + (uint64_t)t * 16, n, w);
+                encode16(w, code, inv);
+                s_code[buf][SCAN_THREADS + t] = code;
+                s_inv[buf][SCAN_THREADS + t] = (uint16_t)inv;
+            }
+        }
+        __syncthreads();  // one barrier per tile: the next tile writes the other LDS buffer
+
+        const uint64_t lo = (uint64_t)s_code[buf][t] | ((uint64_t)s_code[buf][t + 1] << 32);
+        const uint64_t hi = (uint64_t)s_code[buf][t + 2];
+        const uint64_t inv = (uint64_t)s_inv[buf][t] | ((uint64_t)s_inv[buf][t + 1] << 16) |
+                             ((uint64_t)s_inv[buf][t + 2] << 32);
+
+        uint64_t key[PPT], got[PPT];
+        uint32_t slot[PPT];
+        uint32_t live = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            uint64_t km = (j == 0) ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)));
+            key[j] = km & kmask;
+            slot[j] = ss::slot_of(key[j], log2cap);
+            if (((inv >> j) & wmask) == 0) live |= 1u << j;
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; j++)
+            got[j] = ((live >> j) & 1u) ? keys[slot[j]] : ss::EMPTY_KEY;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            uint64_t g = got[j];
+            uint32_t s = slot[j];
+            while (g != key[j] && g != ss::EMPTY_KEY) {
+                s = (s + 1) & smask;
+                g = keys[s];
+            }
+            if (g == key[j]) atomicAdd(&counts[s], 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// table build
+// ---------------------------------------------------------------------------------------------
+__global__ void build_insert_kernel(const uint64_t *__restrict__ in_keys, const uint8_t *__restrict__ flags,
+                                    uint64_t n_rows, int upper_keys, uint64_t *keys, uint32_t *last_row,
+                                    uint32_t *slot_of_row, uint32_t log2cap, unsigned long long *n_distinct)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint8_t f = flags[i];
+    if (!(f & SS_ROW_VALID)) { slot_of_row[i] = SS_NO_SLOT; return; }
+    const uint64_t key = in_keys[i];
+    const uint32_t smask = (uint32_t)((1ull << log2cap) - 1);
+    uint32_t s = ss::slot_of(key, log2cap);
+    for (;;) {
+        unsigned long long old = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)ss::EMPTY_KEY,
+                                           (unsigned long long)key);
+        if (old == ss::EMPTY_KEY) { atomicAdd(n_distinct, 1ull); break; }
+        if (old == key) break;
+        s = (s + 1) & smask;
+    }
+    slot_of_row[i] = s;
+    // dict overwrite at identify.py:94: the LAST row with this text owns the count.  With raw
+    // (non-upper) keys a lower-case row can never equal jellyfish's upper-case dump.
+    if (upper_keys || !(f & SS_ROW_LOWER)) atomicMax(&last_row[s], (uint32_t)(i + 1));
+}
+
+__global__ void build_finalize_kernel(const uint32_t *__restrict__ slot_of_row, const uint32_t *__restrict__ last_row,
+                                      uint64_t n_rows, uint8_t *row_valid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t s = slot_of_row[i];
+    row_valid[i] = (s != SS_NO_SLOT && last_row[s] == (uint32_t)(i + 1)) ? 1 : 0;
+}
+
+__global__ void build_orphans_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ last_row,
+                                     uint64_t capacity, unsigned long long *n_orphans)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= capacity) return;
+    if (keys[s] != ss::EMPTY_KEY && last_row[s] == 0) atomicAdd(n_orphans, 1ull);
+}
+
+__global__ void gather_rows_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ slot_of_row,
+                                   const uint8_t *__restrict__ row_valid, uint64_t n_rows, uint32_t *out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = row_valid[i] ? counts[slot_of_row[i]] : 0u;
+}
+
+int cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+int ensure_staging(ss_db *db)
+{
+    if (db->stage_bytes) return SS_OK;
+    for (int i = 0; i < 2; i++) {
+        SS_HIP(hipHostMalloc((void **)&db->h_stage[i], STAGE_BYTES, hipHostMallocDefault));
+        SS_HIP(hipMalloc((void **)&db->d_stage[i], STAGE_BYTES));
+        SS_HIP(hipStreamCreateWithFlags(&db->streams[i], hipStreamNonBlocking));
+        SS_HIP(hipEventCreateWithFlags(&db->stage_free[i], hipEventDisableTiming));
+    }
+    db->stage_bytes = STAGE_BYTES;
+    db->device_bytes += 2 * STAGE_BYTES;
+    return SS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int k, int upper_keys,
+                ss_db **out)
+{
+    if (!out || (n_rows && (!keys || !flags))) return SS_EINVAL;
+    if (k < 1 || k > 31) return SS_ERANGE;
+    if (n_rows >= 0xFFFFFFFEull) return SS_ERANGE;
+    uint64_t n_valid = 0;
+    for (uint64_t i = 0; i < n_rows; i++) n_valid += (flags[i] & SS_ROW_VALID) ? 1 : 0;
+    uint32_t log2cap = 10;
+    while ((1ull << log2cap) < 2 * n_valid) log2cap++;
+    if (log2cap > 31) return SS_ERANGE;
+
+    ss_db *db = new (std::nothrow) ss_db();
+    if (!db) return SS_ENOMEM;
+    db->k = k;
+    db->n_rows = n_rows;
+    db->log2cap = log2cap;
+    db->capacity = 1ull << log2cap;
+    if (hipGetDevice(&db->device) != hipSuccess) { delete db; return SS_ENODEV; }
+
+    uint64_t *d_in = nullptr;
+    uint8_t *d_flags = nullptr;
+    uint32_t *d_last = nullptr;
+    unsigned long long *d_ctr = nullptr;
+    const uint64_t nr = n_rows ? n_rows : 1;
+    int rc = SS_OK;
+    auto fail = [&](int code) {
+        hipFree(d_in); hipFree(d_flags); hipFree(d_last); hipFree(d_ctr);
+        ss_db_destroy(db);
+        return code;
+    };
+#define SS_TRY(call)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ss::set_last_error(#call, __FILE__, __LINE__, _e);                           \
+            return fail(_e == hipErrorOutOfMemory ? SS_ENOMEM : SS_EHIP);                \
+        }                                                                                \
+    } while (0)
+    SS_TRY(hipMalloc((void **)&db->d_keys, db->capacity * sizeof(uint64_t)));
+    SS_TRY(hipMalloc((void **)&db->d_counts, db->capacity * sizeof(uint32_t)));
+    SS_TRY(hipMalloc((void **)&db->d_slot_of_row, nr * sizeof(uint32_t)));
+    SS_TRY(hipMalloc((void **)&db->d_row_valid, nr));
+    SS_TRY(hipMalloc((void **)&d_in, nr * sizeof(uint64_t)));
+    SS_TRY(hipMalloc((void **)&d_flags, nr));
+    SS_TRY(hipMalloc((void **)&d_last, db->capacity * sizeof(uint32_t)));
+    SS_TRY(hipMalloc((void **)&d_ctr, 2 * sizeof(unsigned long long)));
+    db->device_bytes = db->capacity * 12 + nr * 5;
+    SS_TRY(hipMemset(db->d_keys, 0xFF, db->capacity * sizeof(uint64_t)));
+    SS_TRY(hipMemset(db->d_counts, 0, db->capacity * sizeof(uint32_t)));
+    SS_TRY(hipMemset(d_last, 0, db->capacity * sizeof(uint32_t)));
+    SS_TRY(hipMemset(d_ctr, 0, 2 * sizeof(unsigned long long)));
+    if (n_rows) {
+        SS_TRY(hipMemcpy(d_in, keys, n_rows * sizeof(uint64_t), hipMemcpyHostToDevice));
+        SS_TRY(hipMemcpy(d_flags, flags, n_rows, hipMemcpyHostToDevice));
+        const unsigned blocks = (unsigned)((n_rows + 255) / 256);
+        hipLaunchKernelGGL(build_insert_kernel, dim3(blocks), dim3(256), 0, 0, d_in, d_flags, n_rows, upper_keys,
+                           db->d_keys, d_last, db->d_slot_of_row, log2cap, d_ctr);
+        hipLaunchKernelGGL(build_finalize_kernel, dim3(blocks), dim3(256), 0, 0, db->d_slot_of_row, d_last, n_rows,
+                           db->d_row_valid);
+        const unsigned cblocks = (unsigned)((db->capacity + 255) / 256);
+        hipLaunchKernelGGL(build_orphans_kernel, dim3(cblocks), dim3(256), 0, 0, db->d_keys, d_last, db->capacity,
+                           d_ctr + 1);
+        SS_TRY(hipGetLastError());
+    }
+    unsigned long long ctr[2] = {0, 0};
+    SS_TRY(hipMemcpy(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost));
+    db->n_distinct = ctr[0];
+    hipFree(d_in); hipFree(d_flags); hipFree(d_last); hipFree(d_ctr);
+    d_in = nullptr; d_flags = nullptr; d_last = nullptr; d_ctr = nullptr;
+#undef SS_TRY
+    if (ctr[1] != 0) {  // a dumped k-mer no row can own: KeyError in the reference
+        ss_db_destroy(db);
+        return SS_EKEY;
+    }
+    (void)rc;
+    *out = db;
+    return SS_OK;
+}
+
+int ss_db_destroy(ss_db *db)
+{
+    if (!db) return SS_OK;
+    hipFree(db->d_keys);
+    hipFree(db->d_counts);
+    hipFree(db->d_slot_of_row);
+    hipFree(db->d_row_valid);
+    for (int i = 0; i < 2; i++) {
+        if (db->h_stage[i]) hipHostFree(db->h_stage[i]);
+        if (db->d_stage[i]) hipFree(db->d_stage[i]);
+        if (db->streams[i]) hipStreamDestroy(db->streams[i]);
+        if (db->stage_free[i]) hipEventDestroy(db->stage_free[i]);
+    }
+    delete db;
+    return SS_OK;
+}
+
+int ss_db_info(const ss_db *db, uint64_t *n_rows, uint64_t *n_distinct, uint64_t *capacity, int *k)
+{
+    if (!db) return SS_EINVAL;
+    if (n_rows) *n_rows = db->n_rows;
+    if (n_distinct) *n_distinct = db->n_distinct;
+    if (capacity) *capacity = db->capacity;
+    if (k) *k = db->k;
+    return SS_OK;
+}
+
+int ss_db_row_valid(const ss_db *db, uint8_t *row_valid)
+{
+    if (!db || !row_valid) return SS_EINVAL;
+    if (db->n_rows) SS_HIP(hipMemcpy(row_valid, db->d_row_valid, db->n_rows, hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+const uint8_t *ss_db_row_valid_dev(const ss_db *db) { return db ? db->d_row_valid : nullptr; }
+uint64_t ss_db_device_bytes(const ss_db *db) { return db ? db->device_bytes : 0; }
+uint64_t ss_scan_kernel_launches(const ss_db *db) { return db ? db->launches : 0; }
+
+int ss_scan_reset(ss_db *db, void *stream)
+{
+    if (!db) return SS_EINVAL;
+    SS_HIP(hipMemsetAsync(db->d_counts, 0, db->capacity * sizeof(uint32_t), ss::as_stream(stream)));
+    return SS_OK;
+}
+
+int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream)
+{
+    if (!db || (n && !bases_dev)) return SS_EINVAL;
+    if (n < (uint64_t)db->k) return SS_OK;
+    const uint64_t n_tiles = (n + TILE - 1) / TILE;
+    const uint64_t max_blocks = (uint64_t)cu_count() * 8;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, max_blocks);
+    const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
+    if (aligned)
+        hipLaunchKernelGGL(scan_kernel<true>, dim3(blocks), dim3(SCAN_THREADS), 0, ss::as_stream(stream),
+                           (const uint8_t *)bases_dev, n, n_tiles, db->d_keys, db->d_counts, db->log2cap, db->k);
+    else
+        hipLaunchKernelGGL(scan_kernel<false>, dim3(blocks), dim3(SCAN_THREADS), 0, ss::as_stream(stream),
+                           (const uint8_t *)bases_dev, n, n_tiles, db->d_keys, db->d_counts, db->log2cap, db->k);
+    SS_HIP(hipGetLastError());
+    db->launches++;
+    return SS_OK;
+}
+
+int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n)
+{
+    if (!db || (n && !bases)) return SS_EINVAL;
+    int rc = ensure_staging(db);
+    if (rc) return rc;
+    // Chunks overlap by k-1 bytes: a k-mer starting in the last k-1 bytes of chunk A is invalid
+    // there (it runs past the end) and is counted exactly once in chunk B.
+    const uint64_t ov = (uint64_t)db->k - 1;
+    uint64_t pos = 0;
+    int b = 0;
+    bool used[2] = {false, false};
+    while (pos < n) {
+        const uint64_t len = std::min<uint64_t>(db->stage_bytes, n - pos);
+        if (used[b]) SS_HIP(hipEventSynchronize(db->stage_free[b]));
+        memcpy(db->h_stage[b], bases + pos, len);
+        SS_HIP(hipMemcpyAsync(db->d_stage[b], db->h_stage[b], len, hipMemcpyHostToDevice, db->streams[b]));
+        rc = ss_scan_flat_dev(db, db->d_stage[b], len, db->streams[b]);
+        if (rc) return rc;
+        SS_HIP(hipEventRecord(db->stage_free[b], db->streams[b]));
+        used[b] = true;
+        if (pos + len >= n) break;
+        pos += len - ov;
+        b ^= 1;
+    }
+    for (int i = 0; i < 2; i++)
+        if (used[i]) SS_HIP(hipStreamSynchronize(db->streams[i]));
+    return SS_OK;
+}
+
+int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records, uint64_t *n_bases)
+{
+    if (!db || !paths || n_paths < 1) return SS_EINVAL;
+    int rc = ensure_staging(db);
+    if (rc) return rc;
+    ss_reader *rd = nullptr;
+    rc = ss_reader_open(paths, n_paths, &rd);
+    if (rc) return rc;
+    ss_reader_set_overlap(rd, db->k - 1);
+    uint64_t recs = 0, total = 0;
+    int b = 0;
+    bool used[2] = {false, false};
+    for (;;) {
+        if (used[b]) {
+            hipError_t e = hipEventSynchronize(db->stage_free[b]);
+            if (e != hipSuccess) { ss_reader_close(rd); ss::set_last_error("hipEventSynchronize", __FILE__, __LINE__, e); return SS_EHIP; }
+        }
+        uint64_t len = 0, nr = 0;
+        rc = ss_reader_next(rd, db->h_stage[b], db->stage_bytes, &len, &nr);
+        if (rc) { ss_reader_close(rd); return rc; }
+        if (len == 0) break;
+        recs += nr;
+        total += len;
+        hipError_t e = hipMemcpyAsync(db->d_stage[b], db->h_stage[b], len, hipMemcpyHostToDevice, db->streams[b]);
+        if (e != hipSuccess) { ss_reader_close(rd); ss::set_last_error("hipMemcpyAsync", __FILE__, __LINE__, e); return SS_EHIP; }
+        rc = ss_scan_flat_dev(db, db->d_stage[b], len, db->streams[b]);
+        if (rc) { ss_reader_close(rd); return rc; }
+        hipEventRecord(db->stage_free[b], db->streams[b]);
+        used[b] = true;
+        b ^= 1;
+    }
+    ss_reader_close(rd);
+    for (int i = 0; i < 2; i++)
+        if (used[i]) SS_HIP(hipStreamSynchronize(db->streams[i]));
+    if (n_records) *n_records = recs;
+    if (n_bases) *n_bases = total;
+    return SS_OK;
+}
+
+int ss_counts_rows_dev(const ss_db *db, uint32_t *counts_rows_dev, void *stream)
+{
+    if (!db || (db->n_rows && !counts_rows_dev)) return SS_EINVAL;
+    if (!db->n_rows) return SS_OK;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((db->n_rows + 255) / 256, (uint64_t)cu_count() * 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), db->d_counts,
+                       db->d_slot_of_row, db->d_row_valid, db->n_rows, counts_rows_dev);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_counts_rows(const ss_db *db, uint32_t *counts_rows)
+{
+    if (!db || (db->n_rows && !counts_rows)) return SS_EINVAL;
+    if (!db->n_rows) return SS_OK;
+    uint32_t *d = nullptr;
+    SS_HIP(hipMalloc((void **)&d, db->n_rows * sizeof(uint32_t)));
+    int rc = ss_counts_rows_dev(db, d, nullptr);
+    if (rc == SS_OK) {
+        hipError_t e = hipMemcpy(counts_rows, d, db->n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { ss::set_last_error("hipMemcpy", __FILE__, __LINE__, e); rc = SS_EHIP; }
+    }
+    hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""Parity of the HIP scan + node reductions (through the C ABI) with the reference's golden
+vectors and with the pinned oracle.  Bit-exact: integer work."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from strainscan_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+def _golden(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def test_f1_semantics_vs_real_jellyfish(L, golden_dir, tmp_path):
+    g = _golden(golden_dir, "f1_counts.json")
+    c = sc.f1_case()
+    paths = []
+    for i, r in enumerate(c["reads"]):
+        p = tmp_path / ("r%d.fx" % i)
+        p.write_bytes(r)
+        paths.append(str(p))
+    for upper, key in ((True, "match_results"), (False, "low_mem_match_results")):
+        db = L.KmerDB.from_text(c["kmer_fa"], 31, upper)
+        nrec, _ = db.scan_files(paths)
+        assert nrec == 9
+        counts, valid = db.counts_rows(), db.row_valid
+        got = {int(i): int(counts[i]) for i in np.nonzero(valid)[0]}
+        assert got == {int(k): v for k, v in g[key].items()}
+        assert not counts[valid == 0].any()
+        db.close()
+    # a lower-case row without an upper-case twin: KeyError in identify_low_mem / low_depth
+    c2 = sc.f1_case(lower_only=True)
+    with pytest.raises(KeyError):
+        L.KmerDB.from_text(c2["kmer_fa"], 31, False)
+    db = L.KmerDB.from_text(c2["kmer_fa"], 31, True)
+    db.scan_files(paths)
+    counts, valid = db.counts_rows(), db.row_valid
+    assert {int(i): int(counts[i]) for i in np.nonzero(valid)[0]} == \
+        {int(k): v for k, v in g["lower_only"]["match_results"].items()}
+
+
+def test_l1_samples_counts_and_all_nodes(L, golden_dir, l1_dbs, l1_reads):
+    from oracle import oracle as orc
+    g = _golden(golden_dir, "l1_search.json")
+    for sname, (dbn, _, _) in sc.L1_SAMPLES.items():
+        info = l1_dbs[dbn]
+        tdb = os.path.join(info["db_dir"], "Tree_database")
+        db = L.KmerDB.from_fasta(os.path.join(tdb, "kmer.fa"), 31, True)
+        db.scan_files([l1_reads[sname][0], ""])
+        counts, valid = db.counts_rows(), db.row_valid
+        # the sha256 was taken over the REAL jellyfish counts in the build container
+        assert synth.sha256_of(counts.tobytes()) == g[sname]["counts_sha256"], sname
+        assert int(valid.sum()) == g[sname]["n_valid"]
+        ids = info["tree"].ids
+        ns = L.NodeSet([info["row_of_node"][i] for i in ids])
+        st = ns.reduce(db)
+        for j, i in enumerate(ids):
+            o = orc.match_node(counts, valid, np.array(info["row_of_node"][i]))
+            assert (int(st[j]["length"]), int(st[j]["n_pos"]), int(st[j]["n_kept"]), int(st[j]["sum_kept"])) == \
+                (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"]), (sname, i)
+            if o["n_pos"]:
+                assert int(st[j]["median2"]) == int(round(2 * o["median"]))
+        ns.close()
+        db.close()
+
+
+def _random_db_and_reads(seed, n_sites, n_reads, read_len=150, k=31):
+    rs = np.random.RandomState(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    genome = lut[rs.randint(0, 4, size=n_sites + 5000)]
+    g = genome.tobytes()
+    step = 2
+    kms = [g[i:i + k] for i in range(0, n_sites, step)]
+    kfa = b"".join(b">1\n" + km + b"\n>1\n" + synth.revcomp(km) + b"\n" for km in kms)
+    starts = rs.randint(0, len(g) - read_len, size=n_reads)
+    recs = []
+    for s in starts:
+        r = genome[s:s + rs.randint(20, read_len + 1)].copy()      # ragged lengths, some < k
+        m = rs.random_sample(r.size) < 0.01
+        r[m] = lut[rs.randint(0, 4, size=int(m.sum()))]
+        b = r.tobytes()
+        if rs.random_sample() < 0.5:
+            b = synth.revcomp(b)
+        if rs.random_sample() < 0.03:
+            b = b[:len(b) // 2] + b"N" + b[len(b) // 2 + 1:]
+        recs.append(b)
+    return kfa, b"\n".join(recs) + b"\n"
+
+
+@pytest.mark.parametrize("k", [31, 21, 5])
+def test_random_vs_oracle(L, k):
+    from oracle import oracle as orc
+    kfa, flat = _random_db_and_reads(1234 + k, 120000 if k > 5 else 300, 30000, k=k)
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+    want, want_valid = orc.jellyfish_count(kfa, [fq], k=k, upper=True)
+    db = L.KmerDB.from_text(kfa, k, True)
+    db.scan_flat(flat)
+    assert np.array_equal(db.row_valid, want_valid)
+    assert np.array_equal(db.counts_rows(), want)
+    # accumulate: a second scan of the same block doubles every count; reset clears
+    db.scan_flat(flat)
+    assert np.array_equal(db.counts_rows(), 2 * want)
+    db.reset()
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert not db.counts_rows().any()
+
+
+def test_edge_inputs(L):
+    import torch
+    from oracle import oracle as orc
+    kfa, flat = _random_db_and_reads(99, 20000, 2000)
+    db = L.KmerDB.from_text(kfa, 31, True)
+    keys = None
+    # empty, shorter than k, all-N, no trailing separator
+    for blob in (b"", b"ACGT", b"N" * 5000, b"\n" * 100, flat[:-1]):
+        db.reset()
+        db.scan_flat(blob)
+        fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in blob.split(b"\n") if r)
+        want, _ = orc.jellyfish_count(kfa, [fq], k=31, upper=True)
+        assert np.array_equal(db.counts_rows(), want)
+    # device-resident block at an UNALIGNED address and a non-multiple-of-tile length
+    want, _ = orc.jellyfish_count(kfa, [b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n"
+                                                  for r in flat.split(b"\n") if r)], k=31, upper=True)
+    t = torch.zeros(len(flat) + 64, dtype=torch.uint8, device="cuda")
+    for off in (0, 1, 7, 16):
+        t[off:off + len(flat)] = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+        db.reset()
+        torch.cuda.synchronize()
+        db.scan_flat_dev(t.data_ptr() + off, len(flat), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(db.counts_rows(), want), off
+    # empty database
+    e = L.KmerDB(np.zeros(0, np.uint64), np.zeros(0, np.uint8), 31, True)
+    e.scan_flat(flat)
+    assert e.counts_rows().size == 0
+
+
+def test_chunked_host_scan_equals_single_block(L):
+    """ss_scan_flat_host stages 32 MiB chunks overlapping by k-1 bytes: exact-once counting."""
+    import torch
+    kfa, flat = _random_db_and_reads(5, 50000, 20000)
+    big = flat * 24                                   # ~70 MB: three staging chunks
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_flat(flat)
+    one = db.counts_rows().astype(np.int64)
+    db.reset()
+    db.scan_flat(big)
+    assert np.array_equal(db.counts_rows().astype(np.int64), 24 * one)
+
+
+def test_shard_linearity_large(L):
+    """Size-independent properties on a table far larger than L2 (8M rows, 2M reads): counts are
+    additive over read shards (what the multi-GPU all-reduce relies on), invariant under the
+    order of the shards, and their total equals an independent count of matching windows."""
+    import torch
+    rs = np.random.RandomState(42)
+    n_sites = 4_000_000
+    codes = torch.from_numpy(rs.randint(0, 4, size=n_sites + 30).astype(np.int64)).cuda()
+    key = torch.zeros(n_sites, dtype=torch.int64, device="cuda")
+    rc = torch.zeros(n_sites, dtype=torch.int64, device="cuda")
+    for j in range(31):
+        key |= codes[j:j + n_sites] << (2 * j)
+        rc |= (codes[30 - j:30 - j + n_sites] ^ 2) << (2 * j)
+    keys = torch.stack([key, rc], 1).reshape(-1).cpu().numpy().view(np.uint64)
+    db = L.KmerDB(keys, np.ones(keys.size, np.uint8), 31, True)
+    asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device="cuda")[codes]   # A C T G for codes 0..3
+    n_reads = 2_000_000
+    starts = torch.from_numpy(rs.randint(0, n_sites - 150, size=n_reads)).cuda()
+    idx = starts[:, None] + torch.arange(151, device="cuda")[None, :]
+    reads = asc[idx]
+    reads[:, 150] = 10
+    reads = reads.reshape(-1).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    half = (n_reads // 2) * 151
+    db.scan_flat_dev(reads.data_ptr(), half, st)
+    torch.cuda.synchronize()
+    a = db.counts_rows().astype(np.int64)
+    db.reset()
+    db.scan_flat_dev(reads.data_ptr() + half, reads.numel() - half, st)
+    torch.cuda.synchronize()
+    b = db.counts_rows().astype(np.int64)
+    db.reset()
+    db.scan_flat_dev(reads.data_ptr(), reads.numel(), st)
+    torch.cuda.synchronize()
+    full = db.counts_rows().astype(np.int64)
+    assert np.array_equal(a + b, full)
+    # every read is an exact substring of the forward strand: all 120 windows hit, and only
+    # forward rows (even indices) unless a window also occurs reversed (vanishingly rare)
+    valid = db.row_valid
+    assert int(full.sum()) >= n_reads * 120 * 0.999
+    assert int(full[0::2][valid[0::2] == 1].sum()) + int(full[1::2][valid[1::2] == 1].sum()) == int(full.sum())
+    per_site = np.bincount(np.repeat(starts.cpu().numpy(), 1), minlength=n_sites)
+    cov = np.convolve(per_site, np.ones(120, np.int64))[:n_sites]
+    fwd = full[0::2]
+    ok = valid[0::2] == 1
+    assert np.array_equal(fwd[ok], cov[ok]) or (np.abs(fwd[ok] - cov[ok]).sum() < 10)
