@@ -112,8 +112,10 @@ int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_
 /* counts per ROW (match_results as an array; 0 for rows that are not valid) */
 int ss_counts_rows_dev(const ss_db *db, uint32_t *counts_rows_dev, void *stream);
 int ss_counts_rows(const ss_db *db, uint32_t *counts_rows);
-/* replace the accumulated counts by row counts (after an all-reduce across GPUs): not needed by
- * single-GPU callers */
+/* replace the accumulated counts by the given per-row counts (multi-GPU: every rank scans its
+ * read shard, the uint32[n_rows] vectors are sum-all-reduced over RCCL, and each rank loads the
+ * global vector back so that all later reductions see whole-sample counts) */
+int ss_counts_load_rows_dev(ss_db *db, const uint32_t *counts_rows_dev, void *stream);
 uint64_t ss_scan_kernel_launches(const ss_db *db);
 
 /* --------------------------------------------------------------------------------------------

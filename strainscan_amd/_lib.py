@@ -71,6 +71,7 @@ SIGNATURES = {
     "ss_scan_files": (i32, [vp, P(cp), i32, P(u64), P(u64)]),
     "ss_counts_rows_dev": (i32, [vp, vp, vp]),
     "ss_counts_rows": (i32, [vp, vp]),
+    "ss_counts_load_rows_dev": (i32, [vp, vp, vp]),
     "ss_scan_kernel_launches": (u64, [vp]),
     "ss_fastx_to_flat": (i32, [cp, u64, vp, P(u64), P(u64)]),
     "ss_reader_open": (i32, [P(cp), i32, P(vp)]),
@@ -236,6 +237,9 @@ class KmerDB:
         out = np.zeros(self.n_rows, np.uint32)
         check(lib().ss_counts_rows(self._h, ptr(out)), "ss_counts_rows")
         return out
+
+    def load_counts_rows_dev(self, dptr, stream=None):
+        check(lib().ss_counts_load_rows_dev(self._h, dptr, stream), "ss_counts_load_rows_dev")
 
     def counts_rows_dev(self, dptr, stream=None):
         check(lib().ss_counts_rows_dev(self._h, dptr, stream), "ss_counts_rows_dev")

@@ -201,6 +201,14 @@ __global__ void gather_rows_kernel(const uint32_t *__restrict__ counts, const ui
         out[i] = row_valid[i] ? counts[slot_of_row[i]] : 0u;
 }
 
+__global__ void scatter_rows_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ slot_of_row,
+                                    const uint8_t *__restrict__ row_valid, uint64_t n_rows, uint32_t *counts)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        if (row_valid[i]) counts[slot_of_row[i]] = in[i];   // one valid row per slot: no race
+}
+
 int cu_count()
 {
     static int cus = 0;
@@ -451,6 +459,17 @@ int ss_counts_rows_dev(const ss_db *db, uint32_t *counts_rows_dev, void *stream)
     const unsigned blocks = (unsigned)std::min<uint64_t>((db->n_rows + 255) / 256, (uint64_t)cu_count() * 16);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), db->d_counts,
                        db->d_slot_of_row, db->d_row_valid, db->n_rows, counts_rows_dev);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_counts_load_rows_dev(ss_db *db, const uint32_t *counts_rows_dev, void *stream)
+{
+    if (!db || (db->n_rows && !counts_rows_dev)) return SS_EINVAL;
+    if (!db->n_rows) return SS_OK;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((db->n_rows + 255) / 256, (uint64_t)cu_count() * 16);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), counts_rows_dev,
+                       db->d_slot_of_row, db->d_row_valid, db->n_rows, db->d_counts);
     SS_HIP(hipGetLastError());
     return SS_OK;
 }

@@ -1,0 +1,143 @@
+"""On-disk StrainScan databases -> device images.
+
+Tree_database/ (written by the reference's library/Build_tree.py:494-526,648-698):
+    kmer.fa                 `>1\\n<31-mer>\\n` per row
+    kmers/<id>              space separated 0-based rows of kmer.fa, one line
+    node_length.txt         `id \\t len`
+    reconstructed_nodes.txt one id per line
+    overlapping_info/<leaf>, <leaf>_supple
+Kmer_Sets_L2/Kmer_Sets/C<id>/ is handled by strainscan_amd/l2db.py.
+
+A TreeImage owns the device k-mer table of kmer.fa and the node row lists; scans accumulate in
+it.  Images are cached per (directory, key mode) for the life of the process so that the cutoff
+ladder of StrainScan.py:196-216 (which calls identify_cluster up to twice) parses and uploads a
+database once.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+
+L1_K = 31  # the reference hard-codes `-m 31` for the tree scan (identify.py:82,86)
+
+
+class CountsView:
+    """`match_results` of library/identify.py:96-101 without materialising a dict: a read-only
+    mapping row -> count over the per-row arrays (only valid rows are keys)."""
+
+    def __init__(self, counts, valid):
+        self.counts = counts
+        self.valid = valid
+
+    def __getitem__(self, row):
+        if not self.valid[row]:
+            raise KeyError(row)
+        return int(self.counts[row])
+
+    def __contains__(self, row):
+        return 0 <= row < self.valid.size and bool(self.valid[row])
+
+    def __len__(self):
+        return int(self.valid.sum())
+
+    def keys(self):
+        return np.nonzero(self.valid)[0]
+
+    def __iter__(self):
+        return iter(self.keys().tolist())
+
+    def items(self):
+        k = self.keys()
+        return zip(k.tolist(), self.counts[k].tolist())
+
+    def get(self, row, default=None):
+        return int(self.counts[row]) if row in self else default
+
+
+class TreeImage:
+    def __init__(self, db_dir, upper_keys=True):
+        self.db_dir = db_dir
+        self.upper_keys = upper_keys
+        self.kdb = _lib.KmerDB.from_fasta(os.path.join(db_dir, "kmer.fa"), L1_K, upper_keys)
+        self.node_ids = []
+        self.node_rows = {}           # id -> np.int64 rows in FILE order (adjust_profile indexes it)
+        kdir = os.path.join(db_dir, "kmers")
+        ids = sorted(int(f) for f in os.listdir(kdir) if f.isdigit())
+        lists = []
+        for i in ids:
+            with open(os.path.join(kdir, str(i)), "r") as f:
+                first = f.readline()
+            rows = np.array(first.split(), dtype=np.int64) if first.strip() else np.zeros(0, np.int64)
+            self.node_rows[i] = rows
+            self.node_ids.append(i)
+            lists.append(rows)
+        self.node_index = {i: j for j, i in enumerate(self.node_ids)}
+        self.nodes = _lib.NodeSet(lists)
+        self._scanned = None          # key of the inputs whose counts are in the table
+        self._counts = None
+        self._stats = None
+
+    # -- scanning ---------------------------------------------------------------------------
+    def scan(self, paths):
+        """Count the table's k-mers in the given FASTA/FASTQ(.gz) files (replaces the
+        `jellyfish count` + `dump -c` pair, identify.py:82-87)."""
+        key = tuple((os.path.abspath(p), os.path.getmtime(p), os.path.getsize(p)) for p in paths if p)
+        if self._scanned == key:
+            return
+        self.kdb.reset()
+        self.kdb.scan_files([p for p in paths if p])
+        self._scanned = key
+        self._counts = None
+        self._stats = None
+
+    def mark_external(self, tag):
+        """The table now holds counts produced elsewhere (multi-GPU: every rank scanned a shard,
+        the row vectors were all-reduced and loaded back with KmerDB.load_counts_rows_dev)."""
+        self._scanned = ("external", tag)
+        self._counts = None
+        self._stats = None
+
+    @property
+    def is_external(self):
+        return bool(self._scanned) and self._scanned[0] == "external"
+
+    @property
+    def counts(self):
+        if self._counts is None:
+            self._counts = self.kdb.counts_rows()
+        return self._counts
+
+    @property
+    def valid(self):
+        return self.kdb.row_valid
+
+    def match_results(self):
+        return CountsView(self.counts, self.valid)
+
+    def node_stats(self):
+        """match_node + del_outlier for every node in one launch (identify.py:106-127)."""
+        if self._stats is None:
+            self._stats = self.nodes.reduce(self.kdb)
+        return self._stats
+
+    def rows_stat(self, rows):
+        """Ad-hoc row set (adjust_profile's `remain`, identify.py:181-189)."""
+        return _lib.rows_reduce(self.kdb, rows)
+
+
+_CACHE = {}
+
+
+def tree_image(db_dir, upper_keys=True):
+    key = (os.path.realpath(db_dir), bool(upper_keys), os.path.getmtime(os.path.join(db_dir, "kmer.fa")))
+    img = _CACHE.get(key)
+    if img is None:
+        img = TreeImage(db_dir, upper_keys)
+        _CACHE.clear()               # one database image at a time on the device
+        _CACHE[key] = img
+    return img
+
+
+def clear_cache():
+    _CACHE.clear()

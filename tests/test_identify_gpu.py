@@ -1,0 +1,77 @@
+"""Layer 1 end to end on the GPU: strainscan_amd.identify / identify_low_mem /
+identify_low_depth against the reference's golden results (real jellyfish + reference Python)."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import hostlogic as hl
+from tests import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "l1_search.json")) as f:
+        return json.load(f)
+
+
+def _run(fn, *a):
+    buf = io.StringIO()
+    err = res = None
+    with contextlib.redirect_stdout(buf):
+        try:
+            res = fn(*a)
+        except BaseException as e:  # noqa: B902
+            err = type(e).__name__
+    return res, err, buf.getvalue()
+
+
+@pytest.mark.parametrize("sname", list(sc.L1_SAMPLES))
+def test_identify_cluster(sname, golden, l1_dbs, l1_reads):
+    from strainscan_amd import identify, identify_low_mem, identify_low_depth
+    dbn = sc.L1_SAMPLES[sname][0]
+    tdb = os.path.join(l1_dbs[dbn]["db_dir"], "Tree_database")
+    fq = l1_reads[sname][0]
+    mods = {"identify": identify, "identify_low_mem": identify_low_mem}
+    for run in golden[sname]["runs"]:
+        np.random.seed(sc.POISSON_SEED)
+        res, err, text = _run(mods[run["module"]].identify_cluster, (fq, ""), tdb, list(run["cutoff"]))
+        tag = (sname, run["module"], run["cutoff"])
+        assert err == run["error"], (tag, err, text[-300:])
+        if err is None:
+            hl.assert_result_equal(res, run["result"], tag)
+        got_tr = hl.parse_trace(text)
+        assert [g[0] for g in got_tr] == [w[0] for w in run["trace"]], tag
+    res, err, _ = _run(identify_low_depth.identify_ranks, (fq, ""), tdb)
+    want = golden[sname]["ranks"]
+    assert err == want["error"]
+    assert [a for a, _ in res] == [a for a, _ in want["result"]]
+    for (a, b), (_, wb) in zip(res, want["result"]):
+        assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+
+
+def test_gz_and_pair_inputs(l1_dbs, l1_reads, tmp_path):
+    """(fq1, fq2) pairs and .gz inputs (identify.py:75-87): counts add over the two files."""
+    import gzip
+    from strainscan_amd import identify
+    tdb = os.path.join(l1_dbs["A"]["db_dir"], "Tree_database")
+    fq, data = l1_reads["A_mix3"]
+    recs = data.split(b"@r")[1:]
+    half = len(recs) // 2
+    p1, p2 = tmp_path / "a_1.fq", tmp_path / "a_2.fq.gz"
+    p1.write_bytes(b"".join(b"@r" + r for r in recs[:half]))
+    with gzip.open(p2, "wb") as f:
+        f.write(b"".join(b"@r" + r for r in recs[half:]))
+    os.environ["STRAINSCAN_QUIET"] = "1"
+    try:
+        whole = identify.jellyfish_count((fq, ""), tdb)
+        c0 = whole.counts.copy()
+        both = identify.jellyfish_count((str(p1), str(p2)), tdb)
+        assert np.array_equal(both.counts, c0)
+    finally:
+        del os.environ["STRAINSCAN_QUIET"]
