@@ -83,6 +83,9 @@ int ss_encode_kmer(const char *kmer, int k, uint64_t *key);
  *   upper_keys = 0: identify_low_mem.py:81 / identify_low_depth.py:64 (raw keys): a lower-case
  *                   row never owns a k-mer; ss_db_build returns SS_EKEY when a k-mer is left
  *                   without an owning row (the reference raises KeyError at :88).
+ *   upper_keys = 2: raw keys, lenient -- Vote_Strain_L2_Lasso_new_sp.py:312-322 looks each
+ *                   all_kid.pkl key up in the dump and takes 0 when it is absent, so a lower-case
+ *                   row simply never gets a count.
  * Duplicate k-mers: the LAST row owns the count (dict overwrite); earlier rows are not valid.
  * ------------------------------------------------------------------------------------------ */
 typedef struct ss_db ss_db;
@@ -160,6 +163,52 @@ int ss_nodes_reduce_dev(const ss_nodes *ns, const uint32_t *counts_rows_dev, con
 int ss_nodes_reduce(const ss_nodes *ns, const ss_db *db, ss_node_stat *stats /* host, n_nodes */);
 /* one ad-hoc row list (adjust_profile's `remain` set, identify.py:181-189) */
 int ss_rows_reduce(const ss_db *db, const uint32_t *rows, uint64_t n, ss_node_stat *stat);
+
+/* --------------------------------------------------------------------------------------------
+ * Layer 2: the k-mer x strain matrix of one cluster as bit planes
+ * (library/identify_strains_L2_Enet_Pscan_new_sp.py:191-201 densifies all_strains_re.npz into
+ * int8; here one bit per entry, plane-major, K bits per strain padded to 128-bit words).
+ * Bit vectors passed in (A, B, nu) are device arrays of words_per_plane dwords, bit k of row k
+ * at word k/32, bit k%32.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ss_l2 ss_l2;
+/* CSR of the K x S binary matrix (scipy.sparse.load_npz of all_strains_re.npz, :200) */
+int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out);
+int ss_l2_destroy(ss_l2 *h);
+int ss_l2_info(const ss_l2 *h, uint64_t *K, uint32_t *S, uint64_t *words_per_plane);
+/* out1[s] = |X_s & A|, out2[s] = |X_s & A & B|; NULL = all ones.  Serves stat_cov/cal_cov_all
+ * (:33-49: A = NULL, B = [y > 1]), get_remainc (:94-108) and get_candidate_arr (:121-134):
+ * A = not-yet-used k-mers, B = [y_u > 1] or [y > 1]. */
+int ss_l2_popc2(const ss_l2 *h, const uint32_t *A_dev, const uint32_t *B_dev, uint64_t *out1, uint64_t *out2);
+/* nu &= ~X_col : "used_kmer = used_kmer + pXt[candidate]; used_kmer[used_kmer>1]=1" (:367-369) */
+int ss_l2_andnot_col(const ss_l2 *h, uint32_t col, uint32_t *nu_dev);
+/* For each listed column: over rows with X = 1 and y != 0, n_nz = how many, v_lo / v_hi =
+ * np.percentile(.., q_lo / q_hi, interpolation='nearest'), cnt_in / sum_in = size and sum of the
+ * values inside [v_lo, v_hi].  optimize_dominat_y (:136-175, q = 5/95, uses sum_in) and
+ * get_avg_depth (:110-120, q = 25/75, uses sum_in / cnt_in). */
+int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *cols, uint32_t ncols, double q_lo,
+                        double q_hi, uint64_t *n_nz, uint32_t *v_lo, uint32_t *v_hi, uint64_t *cnt_in,
+                        uint64_t *sum_in);
+/* Sufficient statistics of the elastic net over the p <= 16 selected columns: for every p-bit row
+ * pattern m, {rows, sum y, sum y^2} over (f < n_folds) the kept rows in the TEST half of fold f,
+ * and (f = n_folds) all kept rows.  fold_dev[k]: bit 31 = row kept by the filter of :402-415,
+ * bit f = row in the test half of ShuffleSplit fold f.  stats: host, [(n_folds+1)][2^p][3]. */
+int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint32_t *y_dev,
+                        const uint32_t *fold_dev, int n_folds, uint64_t *stats);
+
+/* --------------------------------------------------------------------------------------------
+ * Positive elastic-net coordinate descent along a descending alpha path, warm-started, on Gram
+ * statistics -- scikit-learn's _cd_fast.enet_coordinate_descent_gram inside enet_path
+ * (ElasticNetCV at identify_strains...:437-442) and, with F = 1 and one alpha, the refit of
+ * ElasticNet(...).fit (:451-455).  One workgroup per problem f < F.  All pointers are host
+ * memory: Q [F][p][p], q [F][p], yy / n_train / n_test [F]; test_stats [F][2^p][3] (from
+ * ss_l2_pattern_stats) or NULL; out: mse [n_alphas][F] (needs test_stats), coefs
+ * [F][n_alphas][p], iters / gaps [F][n_alphas] (any may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+int ss_enet_path_gram(const double *Q, const double *q, const double *yy, const double *n_train,
+                      const double *n_test, int F, int p, const double *alphas, int n_alphas, double l1_ratio,
+                      int max_iter, double tol, int positive, const uint64_t *test_stats, double *mse,
+                      double *coefs, int *iters, double *gaps);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,15 @@ SIGNATURES = {
     "ss_nodes_reduce_dev": (i32, [vp, vp, vp, vp, vp]),
     "ss_nodes_reduce": (i32, [vp, vp, vp]),
     "ss_rows_reduce": (i32, [vp, vp, u64, P(NodeStat)]),
+    "ss_l2_create": (i32, [vp, vp, u64, u32, P(vp)]),
+    "ss_l2_destroy": (i32, [vp]),
+    "ss_l2_info": (i32, [vp, P(u64), P(u32), P(u64)]),
+    "ss_l2_popc2": (i32, [vp, vp, vp, vp, vp]),
+    "ss_l2_andnot_col": (i32, [vp, u32, vp]),
+    "ss_l2_quantile_sums": (i32, [vp, vp, vp, u32, C.c_double, C.c_double, vp, vp, vp, vp, vp]),
+    "ss_l2_pattern_stats": (i32, [vp, vp, i32, vp, vp, i32, vp]),
+    "ss_enet_path_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, i32, C.c_double, i32, C.c_double, i32, vp, vp,
+                                vp, vp, vp]),
 }
 
 
@@ -161,7 +170,7 @@ class KmerDB:
         flags = np.ascontiguousarray(flags, np.uint8)
         assert keys.shape == flags.shape
         h = C.c_void_p()
-        check(lib().ss_db_build(ptr(keys), ptr(flags), keys.size, int(k), int(bool(upper_keys)), C.byref(h)),
+        check(lib().ss_db_build(ptr(keys), ptr(flags), keys.size, int(k), int(upper_keys), C.byref(h)),
               "ss_db_build")
         self._h = h
         self.k = int(k)

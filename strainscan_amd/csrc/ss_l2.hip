@@ -1,0 +1,406 @@
+// ss_l2.hip -- intra-cluster (layer 2) kernels: the k-mer x strain matrix as bit planes.
+//
+// Replaces the dense numpy passes of library/identify_strains_L2_Enet_Pscan_new_sp.py:
+//   stat_cov / cal_cov_all (:33-49), get_remainc (:94-108), get_candidate_arr (:121-134),
+//   optimize_dominat_y (:136-175), get_avg_depth (:110-120), the Pre_Scan loop (:302-371),
+//   the row filter (:402-415) and the fold slicing + Gram products inside ElasticNetCV.fit
+//   (:437-442, scikit-learn _path_residuals).
+//
+// X is binary (Build_kmer_sets_..._sp.py:412-414 writes only 1s), so the reference's products
+//   ix * iy > 1   <=>   X bit set AND y > 1
+// and every "count" it derives is a popcount of ANDed bit vectors.  Layout in HBM: one bit plane
+// per strain, K bits each (W = ceil(K/32) dwords), plane-major: Xb[s * W + w].  A pre-scan
+// iteration streams S*K/8 bytes once; HBM-bound, coalesced 16-byte loads, wave popcounts.
+//
+// The elastic-net inputs are sufficient statistics: with <= 16 selected strains a row of X is a
+// <= 16-bit pattern m, and every Gram entry, X'y, y'y and test-fold residual sum is a function
+// of per-pattern (count, sum y, sum y^2).  Those are exact integers (u64), so the fold
+// statistics equal the reference's BLAS results to the last bit regardless of summation order.
+#include "ss_common.h"
+
+#include <algorithm>
+#include <vector>
+
+struct ss_l2 {
+    uint64_t K = 0;
+    uint32_t S = 0;
+    uint64_t W = 0;          // dwords per plane (multiple of 4 for 16-byte loads)
+    uint32_t *d_x = nullptr; // [S][W]
+};
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ void pack_csr_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                uint64_t K, uint32_t S, uint64_t W, uint32_t *x, int *bad)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    for (int64_t j = indptr[k]; j < indptr[k + 1]; j++) {
+        const int32_t s = indices[j];
+        if (s < 0 || (uint32_t)s >= S) { *bad = 1; continue; }
+        atomicOr(&x[(uint64_t)s * W + (k >> 5)], 1u << (k & 31));
+    }
+}
+
+// out1[s] = popc(X_s & A), out2[s] = popc(X_s & A & B); A or B may be null (= all ones)
+__global__ __launch_bounds__(NT) void popc2_kernel(const uint32_t *__restrict__ x, uint64_t W,
+                                                   const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
+                                                   unsigned long long *out1, unsigned long long *out2)
+{
+    const uint32_t s = blockIdx.y;
+    const uint4 *xs = reinterpret_cast<const uint4 *>(x + (uint64_t)s * W);
+    const uint4 *a4 = reinterpret_cast<const uint4 *>(A);
+    const uint4 *b4 = reinterpret_cast<const uint4 *>(B);
+    const uint64_t W4 = W >> 2;
+    uint32_t c1 = 0, c2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < W4; i += (uint64_t)gridDim.x * NT) {
+        uint4 v = xs[i];
+        if (A) { const uint4 a = a4[i]; v.x &= a.x; v.y &= a.y; v.z &= a.z; v.w &= a.w; }
+        c1 += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        if (B) { const uint4 b = b4[i]; v.x &= b.x; v.y &= b.y; v.z &= b.z; v.w &= b.w; }
+        c2 += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        c1 += __shfl_down(c1, off, 64);
+        c2 += __shfl_down(c2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (c1) atomicAdd(&out1[s], (unsigned long long)c1);
+        if (c2) atomicAdd(&out2[s], (unsigned long long)c2);
+    }
+}
+
+__global__ void andnot_col_kernel(const uint32_t *__restrict__ x, uint64_t W, uint32_t col, uint32_t *nu)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < W; i += (uint64_t)gridDim.x * blockDim.x)
+        nu[i] &= ~x[(uint64_t)col * W + i];
+}
+
+// ---- masked order statistics: per listed column, values y[k] over rows with X bit set and
+// y[k] != 0; two ranks per column are selected together (8-bit radix passes) ------------------
+struct SelState {
+    unsigned long long n;     // number of non-zero values in the column
+    uint32_t prefix[2];       // selected high bits so far
+    unsigned long long rank[2];
+    uint32_t done;
+};
+
+__global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
+                                                      const uint32_t *__restrict__ y,
+                                                      const uint32_t *__restrict__ cols, int shift,
+                                                      const SelState *__restrict__ st, uint32_t *hist /*[ncols][2][256]*/)
+{
+    __shared__ uint32_t h[2][256];
+    const uint32_t c = blockIdx.y;
+    const uint32_t *xs = x + (uint64_t)cols[c] * W;
+    h[0][threadIdx.x] = 0;
+    h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t p0 = st[c].prefix[0], p1 = st[c].prefix[1];
+    for (uint64_t w = (uint64_t)blockIdx.x * NT + threadIdx.x; w < W; w += (uint64_t)gridDim.x * NT) {
+        uint32_t bits = xs[w];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const uint64_t k = (w << 5) + b;
+            if (k >= K) break;
+            const uint32_t v = y[k];
+            if (v == 0) continue;
+            const uint32_t d = (v >> shift) & 255u;
+            if (shift == 24) {
+                atomicAdd(&h[0][d], 1u);
+            } else {
+                const uint32_t hi = v >> (shift + 8);
+                if (hi == p0) atomicAdd(&h[0][d], 1u);
+                if (hi == p1) atomicAdd(&h[1][d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *g = hist + (uint64_t)c * 512;
+    if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
+    if (shift != 24 && h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
+}
+
+// numpy.percentile(..., interpolation='nearest'): index = around(q/100 * (n-1)), half to even
+__device__ __forceinline__ unsigned long long nearest_rank(double q, unsigned long long n)
+{
+    return (unsigned long long)rint((q / 100.0) * (double)(n - 1));
+}
+
+__global__ void sel_pick_kernel(int shift, double q_lo, double q_hi, SelState *st, uint32_t *hist, uint32_t ncols)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    uint32_t *g = hist + (uint64_t)c * 512;
+    SelState s = st[c];
+    if (shift == 24) {
+        unsigned long long n = 0;
+        for (int b = 0; b < 256; b++) n += g[b];
+        s.n = n;
+        s.rank[0] = n ? nearest_rank(q_lo, n) : 0;
+        s.rank[1] = n ? nearest_rank(q_hi, n) : 0;
+        s.prefix[0] = s.prefix[1] = 0;
+    }
+    if (s.n) {
+        for (int t = 0; t < 2; t++) {
+            const uint32_t *h = (shift == 24) ? g : g + 256 * t;
+            unsigned long long cum = 0;
+            int b = 0;
+            for (; b < 255; b++) {
+                if (cum + h[b] > s.rank[t]) break;
+                cum += h[b];
+            }
+            s.rank[t] -= cum;
+            s.prefix[t] = (s.prefix[t] << 8) | (uint32_t)b;
+        }
+    }
+    st[c] = s;
+    for (int b = 0; b < 512; b++) g[b] = 0;
+}
+
+// sums over rows with X bit set and lo <= y <= hi (y != 0): count and sum of y
+__global__ __launch_bounds__(NT) void sel_sum_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
+                                                     const uint32_t *__restrict__ y,
+                                                     const uint32_t *__restrict__ cols,
+                                                     const SelState *__restrict__ st, unsigned long long *out /*[ncols][2]*/)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t *xs = x + (uint64_t)cols[c] * W;
+    const uint32_t lo = st[c].prefix[0], hi = st[c].prefix[1];
+    unsigned long long cnt = 0, sum = 0;
+    if (st[c].n) {
+        for (uint64_t w = (uint64_t)blockIdx.x * NT + threadIdx.x; w < W; w += (uint64_t)gridDim.x * NT) {
+            uint32_t bits = xs[w];
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint64_t k = (w << 5) + b;
+                if (k >= K) break;
+                const uint32_t v = y[k];
+                if (v == 0 || v < lo || v > hi) continue;
+                cnt++;
+                sum += v;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        sum += __shfl_down(sum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(&out[(uint64_t)c * 2], cnt);
+        atomicAdd(&out[(uint64_t)c * 2 + 1], sum);
+    }
+}
+
+// ---- per-pattern sufficient statistics for the elastic net ------------------------------------
+// rows: fold[k] bit 31 = row kept by the filter (:402-415); bit f (< n_folds) = row is in the
+// TEST half of fold f.  blockIdx.y = f for f < n_folds (test-half stats) and n_folds = all kept
+// rows.  stats[f][m] = {count, sum y, sum y^2} as u64.
+__global__ __launch_bounds__(NT) void pattern_stats_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
+                                                           const uint32_t *__restrict__ cols, int p,
+                                                           const uint32_t *__restrict__ y,
+                                                           const uint32_t *__restrict__ fold, int n_folds,
+                                                           unsigned long long *stats, int use_lds)
+{
+    extern __shared__ unsigned long long s_acc[];   // [M][3] when use_lds
+    const int f = blockIdx.y;
+    const uint32_t M = 1u << p;
+    const uint32_t want = (f < n_folds) ? ((1u << 31) | (1u << f)) : (1u << 31);
+    unsigned long long *g = stats + (uint64_t)f * M * 3;
+    if (use_lds) {
+        for (uint32_t i = threadIdx.x; i < M * 3; i += NT) s_acc[i] = 0;
+        __syncthreads();
+    }
+    for (uint64_t w = (uint64_t)blockIdx.x * NT + threadIdx.x; w < W; w += (uint64_t)gridDim.x * NT) {
+        uint32_t xw[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) xw[j] = (j < p) ? x[(uint64_t)cols[j] * W + w] : 0u;
+        const uint64_t k0 = w << 5;
+        const int nb = (int)min((uint64_t)32, K > k0 ? K - k0 : 0);
+        for (int b = 0; b < nb; b++) {
+            const uint32_t fb = fold[k0 + b];
+            if ((fb & want) != want) continue;
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) m |= ((xw[j] >> b) & 1u) << j;
+            const unsigned long long v = y[k0 + b];
+            if (use_lds) {
+                atomicAdd(&s_acc[m * 3], 1ull);
+                if (v) { atomicAdd(&s_acc[m * 3 + 1], v); atomicAdd(&s_acc[m * 3 + 2], v * v); }
+            } else {
+                atomicAdd(&g[(uint64_t)m * 3], 1ull);
+                if (v) { atomicAdd(&g[(uint64_t)m * 3 + 1], v); atomicAdd(&g[(uint64_t)m * 3 + 2], v * v); }
+            }
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < M * 3; i += NT)
+            if (s_acc[i]) atomicAdd(&g[i], s_acc[i]);
+    }
+}
+
+unsigned grid_for(uint64_t work_items, unsigned rows)
+{
+    const uint64_t want = (work_items + NT - 1) / NT;
+    const uint64_t cap = std::max<uint64_t>(1, (256ull * 8) / std::max(1u, rows));
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, std::max<uint64_t>(cap, 8)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out)
+{
+    if (!out || !indptr || (indptr[K] && !indices)) return SS_EINVAL;
+    ss_l2 *h = new (std::nothrow) ss_l2();
+    if (!h) return SS_ENOMEM;
+    h->K = K;
+    h->S = S;
+    h->W = ((K + 31) / 32 + 3) & ~3ull;
+    if (h->W == 0) h->W = 4;
+    const uint64_t nnz = (uint64_t)indptr[K];
+    int64_t *d_ptr = nullptr;
+    int32_t *d_idx = nullptr;
+    int *d_bad = nullptr;
+    int rc = SS_OK, bad = 0;
+    const uint64_t xbytes = std::max<uint64_t>(1, (uint64_t)S) * h->W * 4;
+    if (hipMalloc((void **)&h->d_x, xbytes) != hipSuccess || hipMalloc((void **)&d_ptr, (K + 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&d_idx, std::max<uint64_t>(1, nnz) * 4) != hipSuccess ||
+        hipMalloc((void **)&d_bad, 4) != hipSuccess) {
+        rc = SS_ENOMEM;
+    } else if (hipMemset(h->d_x, 0, xbytes) != hipSuccess || hipMemset(d_bad, 0, 4) != hipSuccess ||
+               hipMemcpy(d_ptr, indptr, (K + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+               (nnz && hipMemcpy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+        rc = SS_EHIP;
+    } else if (K) {
+        hipLaunchKernelGGL(pack_csr_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
+                           h->W, h->d_x, d_bad);
+        if (hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+        else if (bad) rc = SS_EINVAL;
+    }
+    hipFree(d_ptr); hipFree(d_idx); hipFree(d_bad);
+    if (rc) { hipFree(h->d_x); delete h; return rc; }
+    *out = h;
+    return SS_OK;
+}
+
+int ss_l2_destroy(ss_l2 *h)
+{
+    if (!h) return SS_OK;
+    hipFree(h->d_x);
+    delete h;
+    return SS_OK;
+}
+
+int ss_l2_info(const ss_l2 *h, uint64_t *K, uint32_t *S, uint64_t *words_per_plane)
+{
+    if (!h) return SS_EINVAL;
+    if (K) *K = h->K;
+    if (S) *S = h->S;
+    if (words_per_plane) *words_per_plane = h->W;
+    return SS_OK;
+}
+
+int ss_l2_popc2(const ss_l2 *h, const uint32_t *A_dev, const uint32_t *B_dev, uint64_t *out1, uint64_t *out2)
+{
+    if (!h || !out1 || !out2) return SS_EINVAL;
+    if (!h->S) return SS_OK;
+    unsigned long long *d = nullptr;
+    SS_HIP(hipMalloc((void **)&d, (uint64_t)h->S * 16));
+    hipMemset(d, 0, (uint64_t)h->S * 16);
+    hipLaunchKernelGGL(popc2_kernel, dim3(grid_for(h->W / 4, h->S), h->S), dim3(NT), 0, 0, h->d_x, h->W, A_dev, B_dev,
+                       d, d + h->S);
+    hipError_t e = hipMemcpy(out1, d, (uint64_t)h->S * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out2, d + h->S, (uint64_t)h->S * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) { ss::set_last_error("ss_l2_popc2", __FILE__, __LINE__, e); return SS_EHIP; }
+    return SS_OK;
+}
+
+int ss_l2_andnot_col(const ss_l2 *h, uint32_t col, uint32_t *nu_dev)
+{
+    if (!h || !nu_dev || col >= h->S) return SS_EINVAL;
+    hipLaunchKernelGGL(andnot_col_kernel, dim3((unsigned)std::min<uint64_t>((h->W + 255) / 256, 2048)), dim3(256), 0, 0,
+                       h->d_x, h->W, col, nu_dev);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *cols, uint32_t ncols, double q_lo,
+                        double q_hi, uint64_t *n_nz, uint32_t *v_lo, uint32_t *v_hi, uint64_t *cnt_in,
+                        uint64_t *sum_in)
+{
+    if (!h || !y_dev || (ncols && !cols)) return SS_EINVAL;
+    if (!ncols) return SS_OK;
+    for (uint32_t i = 0; i < ncols; i++) if (cols[i] >= h->S) return SS_EINVAL;
+    uint32_t *d_cols = nullptr, *d_hist = nullptr;
+    SelState *d_st = nullptr;
+    unsigned long long *d_out = nullptr;
+    int rc = SS_OK;
+    if (hipMalloc((void **)&d_cols, ncols * 4) != hipSuccess || hipMalloc((void **)&d_hist, (uint64_t)ncols * 2048) != hipSuccess ||
+        hipMalloc((void **)&d_st, ncols * sizeof(SelState)) != hipSuccess ||
+        hipMalloc((void **)&d_out, (uint64_t)ncols * 16) != hipSuccess)
+        rc = SS_ENOMEM;
+    if (!rc) {
+        hipMemcpy(d_cols, cols, ncols * 4, hipMemcpyHostToDevice);
+        hipMemset(d_hist, 0, (uint64_t)ncols * 2048);
+        hipMemset(d_st, 0, ncols * sizeof(SelState));
+        hipMemset(d_out, 0, (uint64_t)ncols * 16);
+        const dim3 grid(grid_for(h->W, ncols), ncols);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(sel_hist_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, shift, d_st, d_hist);
+            hipLaunchKernelGGL(sel_pick_kernel, dim3((ncols + 63) / 64), dim3(64), 0, 0, shift, q_lo, q_hi, d_st, d_hist, ncols);
+        }
+        hipLaunchKernelGGL(sel_sum_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, d_st, d_out);
+        std::vector<SelState> st(ncols);
+        std::vector<unsigned long long> o((size_t)ncols * 2);
+        hipError_t e = hipMemcpy(st.data(), d_st, ncols * sizeof(SelState), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(o.data(), d_out, (uint64_t)ncols * 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { ss::set_last_error("ss_l2_quantile_sums", __FILE__, __LINE__, e); rc = SS_EHIP; }
+        else
+            for (uint32_t i = 0; i < ncols; i++) {
+                if (n_nz) n_nz[i] = st[i].n;
+                if (v_lo) v_lo[i] = st[i].prefix[0];
+                if (v_hi) v_hi[i] = st[i].prefix[1];
+                if (cnt_in) cnt_in[i] = o[(size_t)i * 2];
+                if (sum_in) sum_in[i] = o[(size_t)i * 2 + 1];
+            }
+    }
+    hipFree(d_cols); hipFree(d_hist); hipFree(d_st); hipFree(d_out);
+    return rc;
+}
+
+int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint32_t *y_dev,
+                        const uint32_t *fold_dev, int n_folds, uint64_t *stats /* [(n_folds+1)][2^p][3] host */)
+{
+    if (!h || !cols || !y_dev || !fold_dev || !stats) return SS_EINVAL;
+    if (p < 1 || p > 16 || n_folds < 0 || n_folds > 30) return SS_ERANGE;
+    for (int i = 0; i < p; i++) if (cols[i] >= h->S) return SS_EINVAL;
+    const uint64_t M = 1ull << p;
+    const uint64_t n = (uint64_t)(n_folds + 1) * M * 3;
+    uint32_t *d_cols = nullptr;
+    unsigned long long *d_stats = nullptr;
+    SS_HIP(hipMalloc((void **)&d_cols, 16 * 4));
+    if (hipMalloc((void **)&d_stats, n * 8) != hipSuccess) { hipFree(d_cols); return SS_ENOMEM; }
+    uint32_t c16[16] = {0};
+    for (int i = 0; i < p; i++) c16[i] = cols[i];
+    hipMemcpy(d_cols, c16, 64, hipMemcpyHostToDevice);
+    hipMemset(d_stats, 0, n * 8);
+    const int use_lds = (M * 24 <= 48 * 1024) ? 1 : 0;   // p <= 11
+    const size_t lds = use_lds ? (size_t)M * 24 : 0;
+    hipLaunchKernelGGL(pattern_stats_kernel, dim3(grid_for(h->W, (unsigned)n_folds + 1), (unsigned)n_folds + 1), dim3(NT),
+                       lds, 0, h->d_x, h->W, h->K, d_cols, p, y_dev, fold_dev, n_folds, d_stats, use_lds);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(stats, d_stats, n * 8, hipMemcpyDeviceToHost);
+    hipFree(d_cols); hipFree(d_stats);
+    if (e != hipSuccess) { ss::set_last_error("ss_l2_pattern_stats", __FILE__, __LINE__, e); return SS_EHIP; }
+    return SS_OK;
+}
+
+}  // extern "C"

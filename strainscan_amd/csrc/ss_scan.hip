@@ -173,7 +173,7 @@ __global__ void build_insert_kernel(const uint64_t *__restrict__ in_keys, const 
     slot_of_row[i] = s;
     // dict overwrite at identify.py:94: the LAST row with this text owns the count.  With raw
     // (non-upper) keys a lower-case row can never equal jellyfish's upper-case dump.
-    if (upper_keys || !(f & SS_ROW_LOWER)) atomicMax(&last_row[s], (uint32_t)(i + 1));
+    if (upper_keys == 1 || !(f & SS_ROW_LOWER)) atomicMax(&last_row[s], (uint32_t)(i + 1));
 }
 
 __global__ void build_finalize_kernel(const uint32_t *__restrict__ slot_of_row, const uint32_t *__restrict__ last_row,
@@ -311,7 +311,7 @@ int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int
     hipFree(d_in); hipFree(d_flags); hipFree(d_last); hipFree(d_ctr);
     d_in = nullptr; d_flags = nullptr; d_last = nullptr; d_ctr = nullptr;
 #undef SS_TRY
-    if (ctr[1] != 0) {  // a dumped k-mer no row can own: KeyError in the reference
+    if (ctr[1] != 0 && upper_keys == 0) {  // a dumped k-mer no row can own: KeyError in the reference
         ss_db_destroy(db);
         return SS_EKEY;
     }

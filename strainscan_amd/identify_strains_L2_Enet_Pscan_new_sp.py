@@ -1,0 +1,191 @@
+"""Intra-cluster strain detection -- drop-in for
+library/identify_strains_L2_Enet_Pscan_new_sp.py.
+
+detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_cov, omatrix, all_cls,
+               l2, msn, pmode, emode) -> (res, res2, strain_cov, strain_val, final_src)
+keeps the reference's signature and return value (:177, :373-382, :478).  The dense K x S numpy
+passes become bit-plane popcounts and masked radix selects on the MI355X
+(strainscan_amd/csrc/ss_l2.hip) and scikit-learn's ElasticNetCV / ElasticNet become a Gram
+coordinate descent on exact per-pattern statistics (ss_enet.hip); see SURVEY.md Appendix B/C.
+"""
+import pickle
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import l2 as L2
+
+CV_NITER = 20        # :433
+NALPHA = 50          # :434
+MAX_NITER = 5000     # :435
+TEST_SIZE = 0.5      # :436
+MAX_PRESCAN_ITER = 15  # :302
+
+
+def lasso_mpm(alphas, mse_path):
+    """:14-31 -- 1-SE rule: the largest alpha whose mean CV error lies within one (population)
+    standard deviation of the minimum."""
+    mse_mean = np.mean(mse_path, axis=1)
+    mse_std = np.std(mse_path, axis=1)
+    i0 = int(np.argmin(mse_mean))
+    lo = mse_mean[i0] - mse_std[i0]
+    hi = mse_mean[i0] + mse_std[i0]
+    pick = i0
+    for i in range(i0 - 1, -1, -1):
+        if (mse_mean[i] >= lo) and (mse_mean[i] <= hi):
+            pick = i
+    return alphas[pick], mse_mean[pick], mse_std[pick]
+
+
+def _stat_cov(valid, total):
+    """:33-43 with the popcounts already done."""
+    valid, total = int(valid), int(total)
+    return [float(valid / total) if total != 0 else 0, valid, total]
+
+
+def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
+    """Pre_Scan (:228-373) on the device image `img` (strainscan_amd.l2.ClusterImage).
+    -> out_columns, out_strain, strain_cov, strain_val, final_src, dominat_avg_depth"""
+    S = img.S
+    strain_cov, strain_val, strain_remainc, final_src = {}, {}, {}, {}
+    G = img.bits((py > 1) | (py < 0))                 # ic = ix*iy; ic[ic==1]=0; count_nonzero (:36-38)
+    total, valid = img.popc2(None, G)
+    cov_arr = np.array([_stat_cov(valid[i], total[i])[0] for i in range(S)], dtype=float)
+    default_cov = 0 if (pmode == 1 or emode == 1) else 0.7
+    if np.max(cov_arr) > default_cov:                  # :256-259: strains below the coverage bar drop out
+        keep = cov_arr > default_cov
+        cov_arr = keep.astype(float)                   # the reference overwrites cov_arr with 0/1
+        float_counts = True                            # pXt_tem becomes float64 -> np.sum gives floats
+    else:
+        keep = np.ones(S, bool)
+        float_counts = False
+        if np.max(cov_arr) < 0.01:
+            l2 = 2
+    use_u = bool(np.sum(py_u) > 0)
+    yy = py_u if use_u else py
+    yy_dev = img.u32(yy)
+    if l2 == 2:
+        dom = int(np.where(cov_arr == np.max(cov_arr))[0][0])
+    else:                                              # optimize_dominat_y (:136-175), all S columns
+        qs = img.quantile_sums(yy_dev, np.arange(S), 5, 95)
+        res = np.where(qs["n_nz"] > 0, qs["sum_in"], 0)
+        dom = int(np.where(res == np.max(res))[0][0])
+    qd = img.quantile_sums(yy_dev, [dom], 25, 75)      # get_avg_depth (:110-120)
+    if qd["n_nz"][0] == 0:
+        raise IndexError("index -1 is out of bounds for axis 0 with size 0")   # np.percentile of []
+    depth = float(qd["sum_in"][0]) / float(qd["cnt_in"][0])
+
+    out_columns, out_strain = [dom], [sid[dom]]
+    strain_cov[sid[dom]] = _stat_cov(valid[dom], total[dom])
+    strain_val[sid[dom]] = strain_cov[sid[dom]][1]
+    strain_remainc[sid[dom]] = strain_cov[sid[dom]][0]
+    final_src[sid[dom]] = strain_cov[sid[dom]][0]
+
+    nu = img.ones()                                    # not-yet-used k-mers = ~used_kmer
+    img.andnot_col(dom, nu)
+    Gu = img.bits(py_u > 1)
+    all_k, chk = img.popc2(nu, Gu)                     # get_remainc (:94-108): once, always with py_u
+    for i in range(S):
+        if i == dom:
+            continue
+        ak = int(all_k[i]) if keep[i] else 0
+        ck = int(chk[i]) if keep[i] else 0
+        strain_remainc[i] = 0 if ak == 0 else ck / ak
+    Gyy = Gu if use_u else img.bits(py > 1)
+    for _ in range(MAX_PRESCAN_ITER):
+        _, check_all = img.popc2(nu, Gyy)              # get_candidate_arr (:121-134)
+        check_all = np.where(keep, check_all, 0)
+        cand = int(np.argmax(check_all))               # stable sort, reverse=True: first maximum
+        check = float(check_all[cand]) if float_counts else int(check_all[cand])
+        if emode == 1:
+            remainc_cutoff, check_c = 0, 5000
+        else:
+            remainc_cutoff, check_c = 0.2, cutoff
+        if check >= check_c:
+            if strain_remainc[cand] > remainc_cutoff:
+                out_columns.append(cand)
+                out_strain.append(sid[cand])
+                strain_cov[sid[cand]] = _stat_cov(valid[cand], total[cand])
+                strain_val[sid[cand]] = check
+                final_src[sid[cand]] = strain_remainc[cand]
+            img.andnot_col(cand, nu)
+        else:
+            break
+    return out_columns, out_strain, strain_cov, strain_val, final_src, depth
+
+
+def enet_cv_fit(img, cols, py, keep_rows, trace=None):
+    """ElasticNetCV -> lasso_mpm -> ElasticNet (:433-456) on the selected columns / kept rows.
+    -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests."""
+    p = len(cols)
+    kept = np.nonzero(keep_rows)[0]
+    n = int(kept.size)
+    bits, n_test = L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
+    fold = np.zeros(img.K, np.uint32)
+    fold[kept] = bits | np.uint32(1 << 31)
+    y_dev = img.u32(np.where(keep_rows, py, 0))
+    stats = img.pattern_stats(cols, y_dev, L2.DevBuf.from_array(fold), CV_NITER)
+    total = stats[CV_NITER]
+    Qt, qt, yyt, nt = L2.gram_from_stats(total, p)
+    assert int(nt) == n
+    alphas = L2.alpha_grid(qt, n, 0.5, 1e-3, NALPHA)
+    Q = np.zeros((CV_NITER, p, p))
+    q = np.zeros((CV_NITER, p))
+    yy = np.zeros(CV_NITER)
+    ntr = np.zeros(CV_NITER)
+    nte = np.zeros(CV_NITER)
+    for f in range(CV_NITER):
+        Q[f], q[f], yy[f], ntr[f] = L2.gram_from_stats(total - stats[f], p)   # train = all - test, exact
+        nte[f] = float(stats[f][:, 0].astype(np.int64).sum())
+    cv = L2.enet_path_gram(Q, q, yy, ntr, alphas, n_test=nte, test_stats=stats[:CV_NITER], l1_ratio=0.5,
+                           max_iter=MAX_NITER, tol=1e-4, positive=True)
+    alpha, _, _ = lasso_mpm(alphas, cv["mse"])
+    fit = L2.enet_path_gram(Qt[None], qt[None], [yyt], [nt], [alpha], l1_ratio=0.5, max_iter=MAX_NITER, tol=1e-4,
+                            positive=True)
+    coef = fit["coefs"][0, 0].copy()
+    if trace is not None:
+        trace.update(alphas_=alphas, mse_path_=cv["mse"], alpha=float(alpha), coef_=coef, n_rows=n, p=p,
+                     n_iter=int(fit["iters"][0, 0]))
+    return coef
+
+
+def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_cls, l2, msn, pmode, emode,
+                trace=None):
+    """detect_strains on in-memory matrices (X: K x S CSR, om: K x n_clusters CSR)."""
+    new_als = [int(a - 1) for a in all_cls]
+    ln = np.asarray(om.tocsr()[:, new_als].sum(axis=1)).ravel().astype(np.int64)   # :191-197
+    ln[ln > 1] = 0
+    py = np.asarray(input_y).astype(np.int64)
+    py_u = py * ln
+    cutoff = msn * ksize
+    img = L2.ClusterImage(X)
+    try:
+        out_columns, out_strains, strain_cov, strain_val, final_src, depth = pre_scan(
+            img, py, py_u, sid, cutoff, l2, pmode, emode)
+        if len(out_columns) == 1:                                              # :379-382
+            return dict(zip(out_strains, [1])), dict(zip(out_strains, [depth])), strain_cov, strain_val, final_src
+        with np.errstate(invalid="ignore"):
+            drop = (py < npp25) | (py > npp75) | (py > npp_out)                # :402-415
+        print("Pre-scan finished, now we will start ElasticNet fitting...")
+        coef = enet_cv_fit(img, out_columns, py, ~drop, trace)
+    finally:
+        img.close()
+    lasso_coef = np.atleast_1d(coef)
+    if not np.sum(lasso_coef) == 0:                                            # :465-471
+        coef_norm = lasso_coef / np.sum(lasso_coef)
+        res = dict(zip(out_strains, list(coef_norm)))
+        res2 = dict(zip(out_strains, list(lasso_coef)))
+    else:
+        res, res2 = {}, {}
+    return res, res2, strain_cov, strain_val, final_src
+
+
+def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_cov, omatrix, all_cls, l2, msn, pmode,
+                   emode):
+    """:177-478.  input_csv = <C>/all_strains_re.npz, ids = <C>/id2strain_re.pkl,
+    omatrix = <C>/overlap_matrix.npz, input_y = counts ordered by k-mer id with 1s zeroed."""
+    X = sp.load_npz(input_csv)
+    om = sp.load_npz(omatrix)
+    with open(ids, "rb") as f:
+        sid = pickle.load(f)
+    return detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_cls, l2, msn, pmode, emode)

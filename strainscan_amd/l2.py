@@ -1,0 +1,184 @@
+"""Device image of one cluster's k-mer x strain matrix and the numeric steps of layer 2.
+
+Everything here maps one-to-one onto functions of
+library/identify_strains_L2_Enet_Pscan_new_sp.py; the O(K*S) work runs in
+strainscan_amd/csrc/ss_l2.hip and the coordinate descent in ss_enet.hip.  The host keeps only
+O(K) vector bookkeeping (bit packing of y-derived masks) and O(S) decisions.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+
+class DevBuf:
+    """A device allocation owned by Python (freed on close/GC)."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        _lib.check(_lib.lib().ss_dev_alloc(C.byref(self.ptr), max(16, self.nbytes)), "ss_dev_alloc")
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        if a.nbytes:
+            _lib.check(_lib.lib().ss_memcpy_h2d(b.ptr, _lib.ptr(a), a.nbytes, None), "ss_memcpy_h2d")
+        return b
+
+    def close(self):
+        if self.ptr:
+            _lib.lib().ss_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ClusterImage:
+    """all_strains_re.npz (CSR int8, K x S, entries 1) as S bit planes in HBM."""
+
+    def __init__(self, X_csr):
+        _lib.require_gpu()
+        X = X_csr.tocsr()
+        X.sum_duplicates()
+        if X.nnz and not np.all(X.data == 1):
+            raise ValueError("all_strains_re.npz must be binary (Build_kmer_sets_..._sp.py:412-414 writes 1s)")
+        self.K, self.S = X.shape
+        indptr = np.ascontiguousarray(X.indptr, np.int64)
+        indices = np.ascontiguousarray(X.indices, np.int32)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ss_l2_create(_lib.ptr(indptr), _lib.ptr(indices), self.K, self.S, C.byref(h)),
+                   "ss_l2_create")
+        self._h = h
+        w = C.c_uint64()
+        _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
+        self.W = int(w.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ss_l2_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- bit vectors over the K rows ------------------------------------------------------------
+    def bits(self, mask):
+        """bool[K] -> device bit vector (W dwords, bit k%32 of word k/32)."""
+        packed = np.packbits(np.asarray(mask, bool), bitorder="little")
+        buf = np.zeros(self.W * 4, np.uint8)
+        buf[:packed.size] = packed
+        return DevBuf.from_array(buf)
+
+    def ones(self):
+        return DevBuf.from_array(np.full(self.W * 4, 0xFF, np.uint8))
+
+    def u32(self, v):
+        v = np.asarray(v)
+        if v.size and (v.min() < 0 or v.max() > 0xFFFFFFFF):
+            raise OverflowError("k-mer counts must fit uint32")
+        return DevBuf.from_array(v.astype(np.uint32))
+
+    # -- kernels --------------------------------------------------------------------------------
+    def popc2(self, A=None, B=None):
+        o1 = np.zeros(self.S, np.uint64)
+        o2 = np.zeros(self.S, np.uint64)
+        _lib.check(_lib.lib().ss_l2_popc2(self._h, A.ptr if A else None, B.ptr if B else None, _lib.ptr(o1),
+                                          _lib.ptr(o2)), "ss_l2_popc2")
+        return o1.astype(np.int64), o2.astype(np.int64)
+
+    def andnot_col(self, col, nu):
+        _lib.check(_lib.lib().ss_l2_andnot_col(self._h, int(col), nu.ptr), "ss_l2_andnot_col")
+
+    def quantile_sums(self, y_dev, cols, q_lo, q_hi):
+        cols = np.ascontiguousarray(cols, np.uint32)
+        n = cols.size
+        n_nz, cnt, tot = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        lo, hi = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        _lib.check(_lib.lib().ss_l2_quantile_sums(self._h, y_dev.ptr, _lib.ptr(cols), n, float(q_lo), float(q_hi),
+                                                  _lib.ptr(n_nz), _lib.ptr(lo), _lib.ptr(hi), _lib.ptr(cnt),
+                                                  _lib.ptr(tot)), "ss_l2_quantile_sums")
+        return dict(n_nz=n_nz.astype(np.int64), v_lo=lo, v_hi=hi, cnt_in=cnt.astype(np.int64),
+                    sum_in=tot.astype(np.int64))
+
+    def pattern_stats(self, cols, y_dev, fold_dev, n_folds):
+        cols = np.ascontiguousarray(cols, np.uint32)
+        p = cols.size
+        st = np.zeros((n_folds + 1, 1 << p, 3), np.uint64)
+        _lib.check(_lib.lib().ss_l2_pattern_stats(self._h, _lib.ptr(cols), p, y_dev.ptr, fold_dev.ptr, n_folds,
+                                                  _lib.ptr(st)), "ss_l2_pattern_stats")
+        return st
+
+
+def enet_path_gram(Q, q, yy, n_train, alphas, n_test=None, test_stats=None, l1_ratio=0.5, max_iter=5000,
+                   tol=1e-4, positive=True):
+    """-> dict(mse [n_alphas, F] or None, coefs [F, n_alphas, p], iters, gaps)."""
+    Q = np.ascontiguousarray(Q, np.float64)
+    F, p = Q.shape[0], Q.shape[1]
+    q = np.ascontiguousarray(q, np.float64)
+    yy = np.ascontiguousarray(yy, np.float64)
+    n_train = np.ascontiguousarray(n_train, np.float64)
+    alphas = np.ascontiguousarray(alphas, np.float64)
+    na = alphas.size
+    coefs = np.zeros((F, na, p))
+    iters = np.zeros((F, na), np.int32)
+    gaps = np.zeros((F, na))
+    mse = None
+    ts = None
+    nt = None
+    if test_stats is not None:
+        ts = np.ascontiguousarray(test_stats, np.uint64)
+        nt = np.ascontiguousarray(n_test, np.float64)
+        mse = np.zeros((na, F))
+    _lib.check(_lib.lib().ss_enet_path_gram(
+        _lib.ptr(Q), _lib.ptr(q), _lib.ptr(yy), _lib.ptr(n_train), _lib.ptr(nt) if nt is not None else None, F, p,
+        _lib.ptr(alphas), na, float(l1_ratio), int(max_iter), float(tol), int(positive),
+        _lib.ptr(ts) if ts is not None else None, _lib.ptr(mse) if mse is not None else None, _lib.ptr(coefs),
+        _lib.ptr(iters), _lib.ptr(gaps)), "ss_enet_path_gram")
+    return dict(mse=mse, coefs=coefs, iters=iters, gaps=gaps)
+
+
+def gram_from_stats(stats, p):
+    """{count, sum y, sum y^2} per p-bit pattern -> (Q [p,p], q [p], yy, n) as exact integers
+    converted once to float64 (what X'X, X'y, y'y, len(y) are for a 0/1 matrix)."""
+    M = 1 << p
+    P = ((np.arange(M)[:, None] >> np.arange(p)[None, :]) & 1).astype(np.int64)
+    c = stats[:, 0].astype(np.int64)
+    s = stats[:, 1].astype(np.int64)
+    t = stats[:, 2].astype(np.int64)
+    Q = (P.T * c) @ P
+    q = P.T @ s
+    return Q.astype(np.float64), q.astype(np.float64), float(t.sum()), float(c.sum())
+
+
+def alpha_grid(q_total, n, l1_ratio=0.5, eps=1e-3, n_alphas=50):
+    """sklearn _alpha_grid (linear_model/_coordinate_descent.py) with Xy = X'y given."""
+    Xy = np.asarray(q_total, np.float64)[:, np.newaxis]
+    alpha_max = (np.sqrt(np.sum(Xy ** 2, axis=1)).max() / (n * l1_ratio))
+    if alpha_max <= np.finfo(float).resolution:
+        alphas = np.empty(n_alphas)
+        alphas.fill(np.finfo(float).resolution)
+        return alphas
+    return np.logspace(np.log10(alpha_max * eps), np.log10(alpha_max), num=n_alphas)[::-1]
+
+
+def shuffle_split_test_bits(n, n_splits=20, test_size=0.5, seed=0):
+    """ShuffleSplit(n_splits, test_size, random_state=seed) -> uint32[n], bit f = in test of fold f.
+    numpy's legacy RandomState.permutation IS the specification here (sklearn calls it)."""
+    rng = np.random.RandomState(seed)
+    n_test = int(math.ceil(test_size * n))
+    bits = np.zeros(n, np.uint32)
+    for f in range(n_splits):
+        perm = rng.permutation(n)
+        bits[perm[:n_test]] |= np.uint32(1 << f)
+    return bits, n_test

@@ -1,0 +1,116 @@
+"""Layer 2 on the GPU: detect_strains (pre-scan kernels + elastic-net path) and the report
+writers against the reference's golden outputs (sklearn 0.24.2 + reference Python)."""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+ABUND_TOL = 1e-5     # BASELINE.json north_star: abundances within 1e-5 of the reference CPU path
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    with open(os.path.join(golden_dir, "l2_detect.json")) as f:
+        g = json.load(f)
+    return g, np.load(os.path.join(golden_dir, "l2_enet_arrays.npz"))
+
+
+@pytest.mark.parametrize("name", sc.L2_CASES)
+def test_detect_strains(name, golden):
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    g, arrs = golden
+    g = g[name]
+    case = sc.l2_case(name)
+    trace = {}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res, res2, scov, sval, fsrc = m.detect_core(
+            case["X"], case["O"], case["ids"], case["y"].copy(), case["ksize"], case["npp25"], case["npp75"],
+            case["npp_out"], case["cls_cov"], case["all_cls"], case["l2"], case["msn"], case["pmode"], case["emode"],
+            trace=trace)
+    assert g["error"] is None
+    # integer work: bit-exact
+    assert {k: list(v) for k, v in scov.items()} == g["strain_cov"]
+    assert {k: float(v) for k, v in sval.items()} == {k: float(v) for k, v in g["strain_val"].items()}
+    assert {k: str(v) for k, v in sval.items()} == {k: str(v) for k, v in _retype(g["strain_val"], sval).items()}
+    for k, v in g["final_src"].items():
+        assert abs(fsrc[k] - v) < 1e-12
+    # floating point: abundances within 1e-5 (tolerance stated by north_star)
+    assert set(res) == set(g["res"])
+    for k, v in g["res"].items():
+        assert abs(float(res[k]) - float(v)) <= ABUND_TOL, (name, k, res[k], v)
+        assert abs(float(res2[k]) - float(g["res2"][k])) <= ABUND_TOL * max(1.0, abs(float(g["res2"][k])))
+    if "alpha" in g:
+        assert trace["n_rows"] == g["n_rows"] and trace["p"] == g["p"]
+        assert np.allclose(trace["alphas_"], arrs[name + "_alphas"], rtol=1e-12, atol=0)
+        assert np.allclose(trace["mse_path_"], arrs[name + "_mse_path"], rtol=1e-7, atol=1e-9)
+        assert abs(trace["alpha"] - g["alpha"]) <= 1e-12 * max(1.0, abs(g["alpha"]))
+        assert np.allclose(trace["coef_"], arrs[name + "_coef"], rtol=0, atol=ABUND_TOL)
+        assert trace["n_iter"] == g["n_iter"]
+
+
+def _retype(gold_vals, got_vals):
+    """JSON keeps 2678.0 and 2678 apart; make the golden values the types str() saw in the reference
+    (np.float64 when the coverage filter ran, int otherwise) for the string comparison."""
+    out = {}
+    for k, v in gold_vals.items():
+        out[k] = float(v) if isinstance(got_vals[k], float) else int(v)
+    return out
+
+
+def test_end_to_end_reports(golden_dir, l1_dbs, tmp_path):
+    """L1 -> L2 -> report files, byte-for-byte in the integer columns and within 1e-5 in the
+    abundance columns, against the reference run recorded in e2e_reports.json."""
+    from strainscan_amd import StrainScan
+    with open(os.path.join(golden_dir, "e2e_reports.json")) as f:
+        g = json.load(f)
+    info = l1_dbs["A"]
+    dbA = info["db_dir"]
+    strains = ["GCF_A1", "GCF_A2", "GCF_A3"]
+    l2info = synth.build_l2_cluster(dbA, 1, 6, strains, [1500, 1200, 1000, 1400, 900],
+                                    [[1, 1, 0, 0, 1], [1, 0, 1, 0, 0], [0, 1, 1, 1, 0]], seed=77, shared_with={4: [3]})
+    g1 = info["leaf_genome"][1]
+    mix = [(g1 + l2info["strain_extra"]["GCF_A1"], 18.0), (g1 + l2info["strain_extra"]["GCF_A3"], 7.0),
+           (info["leaf_genome"][6], 9.0)]
+    reads = synth.simulate_reads(mix, 301)
+    assert synth.sha256_of(reads) == g["A_l2"]["sha256"]
+    fq = tmp_path / "e2e.fq"
+    fq.write_bytes(reads)
+    out = tmp_path / "out"
+    np.random.seed(sc.POISSON_SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        StrainScan.main(["-i", str(fq), "-d", dbA, "-o", str(out)])
+    _cmp_report((out / "final_report.txt").read_text(), g["A_l2"]["final_report"], float_cols=(3, 4, 5, 6))
+    _cmp_report((out / "C1" / "StrainVote.report").read_text(), g["A_l2"]["strain_vote"],
+                float_cols=(3, 4, 5, 6, 8, 9))
+    # all-singleton sample -> generate_single_report + exit()
+    reads = synth.simulate_reads([(info["leaf_genome"][6], 9.0), (info["leaf_genome"][2], 14.0)], 302)
+    assert synth.sha256_of(reads) == g["A_single"]["sha256"]
+    fq2 = tmp_path / "single.fq"
+    fq2.write_bytes(reads)
+    out2 = tmp_path / "out2"
+    with contextlib.redirect_stdout(io.StringIO()), pytest.raises(SystemExit):
+        StrainScan.main(["-i", str(fq2), "-d", dbA, "-o", str(out2)])
+    _cmp_report((out2 / "final_report.txt").read_text(), g["A_single"]["final_report"], float_cols=(3, 4, 5))
+
+
+def _cmp_report(got, want, float_cols):
+    gl, wl = got.strip().split("\n"), want.strip().split("\n")
+    assert gl[0] == wl[0]                      # header line, character for character
+    assert len(gl) == len(wl), (got, want)
+    for a, b in zip(gl[1:], wl[1:]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert len(fa) == len(fb), (a, b)
+        for i, (x, y) in enumerate(zip(fa, fb)):
+            if i in float_cols and x != y:
+                assert abs(float(x) - float(y)) <= ABUND_TOL * max(1.0, abs(float(y))), (i, a, b)
+            else:
+                assert x == y, (i, a, b)
