@@ -103,6 +103,11 @@ def main(argv=None):
     if not os.path.exists(out_dir):
         os.makedirs(out_dir)
 
+    from . import dist
+    rank, world = dist.init_from_env()      # torchrun: one process per GPU, reads shard across ranks
+    if rank != 0:                           # every rank computes; rank 0 owns the output directory
+        import tempfile
+        out_dir = tempfile.mkdtemp(prefix="strainscan_rank%d_" % rank)
     in_fq = (fq_dir, fq2)
     tdb = db_dir + "/Tree_database"
     if sprob == 1:

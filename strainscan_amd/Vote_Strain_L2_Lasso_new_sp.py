@@ -124,7 +124,11 @@ def cluster_counts(input_fq, fq2, cls_db_dir, ksize):
     (Build_kmer_sets_unique_region_lasso_test_allinone_sp.py:397-399,409-410)."""
     db = _lib.KmerDB.from_fasta(os.path.join(cls_db_dir, "all_kmer.fasta"), int(ksize), upper_keys=2)
     try:
-        db.scan_files([p for p in (input_fq, fq2) if p])
+        from . import dist
+        if dist.is_distributed():
+            dist.scan_files_sharded(db, [input_fq, fq2])
+        else:
+            db.scan_files([p for p in (input_fq, fq2) if p])
         return db.counts_rows()
     finally:
         db.close()

@@ -85,8 +85,12 @@ class TreeImage:
         key = tuple((os.path.abspath(p), os.path.getmtime(p), os.path.getsize(p)) for p in paths if p)
         if self._scanned == key:
             return
-        self.kdb.reset()
-        self.kdb.scan_files([p for p in paths if p])
+        from . import dist
+        if dist.is_distributed():
+            dist.scan_files_sharded(self.kdb, paths)     # shard reads, RCCL all-reduce of row counts
+        else:
+            self.kdb.reset()
+            self.kdb.scan_files([p for p in paths if p])
         self._scanned = key
         self._counts = None
         self._stats = None

@@ -1,0 +1,95 @@
+"""Multi-GPU identification: reads shard, the k-mer table is replicated, hit counts are summed.
+
+One process per GPU (torchrun / torch.distributed, backend "nccl" = RCCL over xGMI).  k-mers never
+span reads, so the scan partitions by read block with no data-path exchange; the
+only collective is ONE sum-all-reduce of the uint32[n_rows] hit-count vector per scan
+(<= 4 * N_db bytes, ~100 MB for the E. coli table).  Integer sums commute, so the reduced
+counts are bit-identical to a single-GPU scan whatever the block-to-rank assignment.  After the
+all-reduce every rank loads the global vector back into its table and runs the (tiny, sequential)
+tree walk redundantly; rank 0 writes the reports.  Layer 2 scans shard the same way.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+
+CHUNK = 1 << 26      # elements per all-reduce call (256 MiB of int32): bounded staging, few large collectives
+
+
+def is_distributed():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return False
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank_world():
+    if not is_distributed():
+        return 0, 1
+    import torch.distributed as dist
+    return dist.get_rank(), dist.get_world_size()
+
+
+def rank_blocks(blocks, rank, world):
+    """Round-robin assignment of flat base blocks (any iterable) to ranks."""
+    for i, b in enumerate(blocks):
+        if i % world == rank:
+            yield b
+
+
+def allreduce_counts(t, group=None):
+    """In-place sum over ranks of a hit-count vector.  `t` is a torch tensor (int32 on the GPU for
+    RCCL, or on the CPU for gloo) holding uint32 bit patterns: two's-complement addition IS uint32
+    addition modulo 2^32, so int32 SUM is exact for the unsigned counts."""
+    import torch
+    import torch.distributed as dist
+    assert t.dtype == torch.int32 and t.is_contiguous()
+    if dist.get_world_size(group) == 1:
+        return t
+    flat = t.view(-1)
+    for lo in range(0, flat.numel(), CHUNK):
+        dist.all_reduce(flat[lo:lo + CHUNK], op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def scan_files_sharded(kdb, paths, cap=32 << 20):
+    """Scan this rank's share of the reads into `kdb`, all-reduce, load the global counts back.
+    Every rank parses the input (the flat-block reader is deterministic) and keeps blocks
+    i % world == rank.  Returns (n_records, n_bases) of the whole input."""
+    import torch
+    rank, world = rank_world()
+    kdb.reset()
+    nrec = nb = 0
+    blocks = _lib.read_flat_blocks([p for p in paths if p], cap=cap, overlap=kdb.k - 1)
+    for i, (blk, nr) in enumerate(blocks):
+        nrec += nr
+        nb += len(blk)
+        if i % world == rank:
+            kdb.scan_flat(blk)
+    if world > 1:
+        t = torch.empty(kdb.n_rows, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")
+        kdb.counts_rows_dev(t.data_ptr(), stream)
+        allreduce_counts(t)
+        kdb.load_counts_rows_dev(t.data_ptr(), stream)
+        torch.cuda.synchronize()
+    return nrec, nb
+
+
+def init_from_env():
+    """torchrun environment -> process group on this rank's GPU (no-op for a single process)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    _lib.check(_lib.lib().ss_set_device(local), "ss_set_device")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist.get_rank(), dist.get_world_size()

@@ -1,0 +1,156 @@
+"""CPU-side checks of the boundary and of host logic that needs no device:
+  - the shared library loads and exports every symbol include/strainscan_hip.h declares
+    (and the ctypes table binds exactly that set);
+  - the FASTA/FASTQ -> flat-block reader (record grammar, cuts with k-1 overlap, gz);
+  - k-mer FASTA row encoding;
+  - layer-2 host helpers (Gram from pattern statistics, alpha grid, ShuffleSplit bits, 1-SE rule);
+  - report writers against the reference's recorded reports.
+No compute entry point is called here."""
+import ctypes
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+from tests import synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(REPO, "include", "strainscan_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from strainscan_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(L, s), "declared in strainscan_hip.h but not exported: " + s
+    assert sorted(_lib.SIGNATURES) == syms, (set(syms) ^ set(_lib.SIGNATURES))
+    assert _lib.lib().ss_version() >= 100
+    assert _lib.lib().ss_strerror(-2).decode().startswith("k-mer without")
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must fail loudly, not fall back."""
+    from strainscan_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.SSError):
+        _lib.KmerDB(np.zeros(1, np.uint64), np.ones(1, np.uint8))
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "strainscan_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(root, f)
+
+
+def test_kmer_fasta_rows():
+    from strainscan_amd import _lib
+    c = sc.f1_case()
+    keys, flags = _lib.encode_kmer_fasta(c["kmer_fa"], 31)
+    rows = c["kmer_fa"].split(b"\n")[1::2]
+    assert len(rows) == keys.size == c["n_rows"]
+    code = {65: 0, 67: 1, 84: 2, 71: 3}
+    for r, k, f in zip(rows, keys, flags):
+        ok = len(r) == 31 and all(ch in b"ACGTacgt" for ch in r)
+        assert bool(f & 1) == ok
+        if ok:
+            assert int(k) == sum(code[ch & 0xDF] << (2 * i) for i, ch in enumerate(r))
+            assert bool(f & 2) == any(ch >= 97 for ch in r)
+
+
+def test_reader_grammar_cuts_and_gz(tmp_path):
+    from oracle import oracle as orc
+    from strainscan_amd import _lib
+    rs = np.random.RandomState(3)
+    g = synth.rand_seq(rs, 60000)
+    # long multi-line FASTA records (forces cuts at cap=4096) + ragged FASTQ + blank lines + '\r'
+    fa = b">c1 x\n" + b"\n".join(g[i:i + 70] for i in range(0, 30000, 70)) + b"\n>c2\n" + g[30000:41000] + b"\n"
+    fq = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, g[s:s + n], b"@" * n)
+                  for i, (s, n) in enumerate(zip(rs.randint(0, 50000, 300), rs.randint(1, 200, 300))))
+    fq += b"\n@last\r\n" + g[100:180] + b"\r\n+\r\n" + b"I" * 81 + b"\n"
+    p1, p2 = tmp_path / "a.fa", tmp_path / "b.fq.gz"
+    p1.write_bytes(fa)
+    with gzip.open(p2, "wb") as f:
+        f.write(fq)
+    whole = synth.flat_bases_from_fastx(fa) + synth.flat_bases_from_fastx(fq)
+    flat, nrec = _lib.fastx_to_flat(fa)
+    assert flat == synth.flat_bases_from_fastx(fa) and nrec == 2
+    big = list(_lib.read_flat_blocks([str(p1), str(p2)], cap=32 << 20, overlap=30))
+    assert b"".join(b for b, _ in big) == whole and sum(n for _, n in big) == 2 + 301
+    kms = [g[i:i + 31] for i in range(0, 45000, 5)]
+    keys = np.array([orc.encode_kmer(k.decode()) for k in kms], np.uint64)
+    want = orc.count_flat(keys, 31, whole)
+    for k, ov in ((31, 30), (21, 20)):
+        kk = np.array([orc.encode_kmer(km[:k].decode()) for km in kms], np.uint64)
+        kk, first = np.unique(kk, return_index=True)
+        want = orc.count_flat(kk, k, whole)
+        small = list(_lib.read_flat_blocks([str(p1), str(p2)], cap=4096, overlap=ov))
+        assert len(small) > 10 and all(len(b) <= 4096 for b, _ in small)
+        got = sum(orc.count_flat(kk, k, b) for b, _ in small)
+        assert np.array_equal(got, want), k          # cut records: every k-mer counted exactly once
+
+
+def test_l2_host_helpers(golden_dir):
+    from strainscan_amd import l2 as L2
+    from strainscan_amd.identify_strains_L2_Enet_Pscan_new_sp import lasso_mpm
+    rs = np.random.RandomState(0)
+    p, n = 5, 4000
+    X = (rs.random_sample((n, p)) < 0.4).astype(np.int64)
+    y = rs.poisson(7, n).astype(np.int64)
+    pat = (X << np.arange(p)).sum(axis=1)
+    st = np.zeros((1 << p, 3), np.uint64)
+    np.add.at(st[:, 0], pat, 1)
+    np.add.at(st[:, 1], pat, y.astype(np.uint64))
+    np.add.at(st[:, 2], pat, (y * y).astype(np.uint64))
+    Q, q, yy, nn = L2.gram_from_stats(st, p)
+    assert np.array_equal(Q, (X.T @ X).astype(float)) and np.array_equal(q, (X.T @ y).astype(float))
+    assert yy == float(y @ y) and nn == n
+    from oracle import oracle as orc
+    assert np.array_equal(L2.alpha_grid(q, n), orc.alpha_grid(X, y))
+    with open(os.path.join(golden_dir, "shuffle_split.json")) as f:
+        g = json.load(f)
+    for ns, e in g.items():
+        bits, n_test = L2.shuffle_split_test_bits(int(ns))
+        assert n_test == e["n_test"]
+        assert sorted(np.nonzero(bits & 1)[0].tolist()) == sorted(e["test0"])
+        assert set(np.nonzero(bits & (1 << 19))[0].tolist()) >= set(e["test19"])
+    arrs = np.load(os.path.join(golden_dir, "l2_enet_arrays.npz"))
+    with open(os.path.join(golden_dir, "l2_detect.json")) as f:
+        gd = json.load(f)
+    for name in ("two", "three", "many", "two_out"):
+        a, _, _ = lasso_mpm(arrs[name + "_alphas"], arrs[name + "_mse_path"])
+        assert a == gd[name]["alpha"]
+
+
+def test_report_writers_match_reference(golden_dir, tmp_path):
+    from strainscan_amd import Vote_Strain_L2_Lasso_new_sp as vote
+    with open(os.path.join(golden_dir, "e2e_reports.json")) as f:
+        g = json.load(f)
+    with open(os.path.join(golden_dir, "report_headers.json")) as f:
+        hdr = json.load(f)
+    for ex in hdr.values():                       # committed Output_Example headers (format contract)
+        # one identified cluster: final_report.txt is a copy of StrainVote.report (Vote_...:273)
+        assert ex["final_report"] == vote.STRAINVOTE_HEADER
+        assert ex["strain_vote"] == vote.STRAINVOTE_HEADER
+    cls = {int(k): v for k, v in g["A_single"]["cls_dict"].items()}
+    vote.generate_single_report(cls, str(tmp_path))
+    assert (tmp_path / "final_report.txt").read_text() == g["A_single"]["final_report"]
+    cls = {int(k): v for k, v in g["A_l2"]["cls_dict"].items()}
+    (tmp_path / "C1").mkdir()
+    (tmp_path / "C1" / "StrainVote.report").write_text(g["A_l2"]["strain_vote"])
+    vote.merge_res(str(tmp_path), cls)
+    assert (tmp_path / "final_report.txt").read_text() == g["A_l2"]["final_report"]
