@@ -175,8 +175,9 @@ def main():
     _lib.check(_lib.lib().ss_nodes_create(_lib.ptr(rows), _lib.ptr(db_spec["row_off"]), db_spec["n_nodes"],
                                           C.byref(h)), "ss_nodes_create")
     nodes._h, nodes.n_nodes = h, db_spec["n_nodes"]
-    log("[bench] db: %d rows, %d distinct, capacity 2^%d, %.2f GB on device (%.1f s)" % (
-        n_rows, info["n_distinct"], int(np.log2(info["capacity"])), info["device_bytes"] / 1e9, time.time() - t0))
+    layout = os.environ.get("SS_LAYOUT", "mini")
+    log("[bench] db: %d rows, %d distinct, %d slots (%s layout), %.2f GB on device (%.1f s)" % (
+        n_rows, info["n_distinct"], info["capacity"], layout, info["device_bytes"] / 1e9, time.time() - t0))
     t0 = time.time()
     reads = make_reads(torch, dev, db_spec, args.reads, seed=2 + rank, hit_frac=args.hit_frac)
     torch.cuda.synchronize()
@@ -264,7 +265,8 @@ def main():
                    dtype="u64", data="synthetic",
                    config=dict(workload="E. coli 1433-strain/823-cluster DB, 10M synthetic 150 bp PE reads (20M reads) per GPU",
                                db_rows=int(n_rows), tree_nodes=int(db_spec["n_nodes"]), reads_per_gpu=args.reads,
-                               read_len=READ_LEN, k=K, hit_frac=args.hit_frac, table_capacity=int(info["capacity"]),
+                               read_len=READ_LEN, k=K, hit_frac=args.hit_frac, table_slots=int(info["capacity"]),
+                               table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
                    roofline=roofline, cpu_baseline=cpu,
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum())))

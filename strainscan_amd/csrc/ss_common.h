@@ -61,8 +61,14 @@ struct ss_db {
     uint64_t n_distinct = 0;
     uint32_t log2cap = 0;
     uint64_t capacity = 0;
-    uint64_t *d_keys = nullptr;        // [capacity] table keys, EMPTY_KEY where free
-    uint32_t *d_counts = nullptr;      // [capacity] occurrences per slot (accumulated by scans)
+    int layout = 0;                    // 0 = flat open-address table, 1 = minimizer buckets (k = 31)
+    uint64_t n_slots = 0;              // length of d_counts: capacity (flat) or n_distinct (buckets)
+    uint64_t *d_keys = nullptr;        // flat: [capacity] table keys, EMPTY_KEY where free
+    uint64_t *d_mkeys = nullptr;       // buckets: [n_distinct] k-mers grouped by minimizer, bit 63 = last of bucket
+    uint64_t *d_dir = nullptr;         // buckets: [2^dirbits] (minimizer hash << 32) | bucket start
+    uint32_t dirbits = 0;
+    uint64_t n_buckets = 0;
+    uint32_t *d_counts = nullptr;      // [n_slots] occurrences per slot (accumulated by scans)
     uint32_t *d_slot_of_row = nullptr; // [n_rows]   slot owning row i, SS_NO_SLOT if none
     uint8_t *d_row_valid = nullptr;    // [n_rows]   1 iff row i is a key of match_results
     // pinned staging for host-resident base blocks
@@ -74,3 +80,9 @@ struct ss_db {
     uint64_t launches = 0;
     uint64_t device_bytes = 0;
 };
+
+namespace ss {
+int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
+int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
+                     uint64_t n_tiles);
+}  // namespace ss

@@ -1,0 +1,543 @@
+// ss_mini.hip -- minimizer-bucketed k-mer index and its scan kernel (k = 31).
+//
+// Why: with the flat open-address table (ss_scan.hip) every one of the 120 k-mers of a 150-bp
+// read costs a random 64-byte HBM sector although ~95 % of them are not in the database
+// (profiles/r01a: 213 GB fetched per 22 GB of algorithmic bytes).  Consecutive k-mers of a read
+// share their minimizer (the 15-mer with the smallest hash inside the k-mer) for ~9 positions
+// on average, so:
+//   * database k-mers are stored grouped by minimizer ("buckets"), contiguous in HBM;
+//   * a small exact directory minimizer -> bucket start (8 B per bucket, tens of MB: Infinity-
+//     Cache/L2 resident) answers "no database k-mer has this minimizer" for most read windows;
+//   * a lane probes the directory once per run of equal minimizers (~13 per read instead of
+//     120) and touches a bucket only when the minimizer exists.
+// Counting semantics are unchanged and exact: a k-mer is looked up in the bucket of ITS OWN
+// minimizer, which is a function of the k-mer alone, on the database side and on the read side.
+//
+// Layout in HBM
+//   d_mkeys[n_slots] u64  buckets back to back.  A bucket = 1 header word + its k-mers sorted by
+//                         (offset of the minimizer inside the k-mer, rest):
+//                           header: bits 0..16 = which offsets occur, bit 17 = some offset occurs more
+//                                   than once ("multi"), bits 32..63 = number of k-mers
+//                           k-mer : the 62-bit key
+//                         With one k-mer per offset (the normal case: a bucket is one super-k-mer)
+//                         the k-mer with offset o sits at header + 1 + popcount(mask & ((1 << o) - 1)):
+//                         a hit costs two dependent loads, a miss inside an existing bucket one.
+//   d_counts[n_slots] u32 occurrences per slot (same index; header slots unused)
+//   d_dir[2^dirbits]  u64 cuckoo directory (two hash functions, one entry per slot):
+//                         (minimizer hash << 32) | bucket start, EMPTY = ~0.  A lookup is exactly two
+//                         independent 8-byte loads -- one memory round trip, no probe chains (with
+//                         linear probing ~40 % of the mostly-unsuccessful lookups needed a dependent
+//                         second load and the per-position retry loops serialised into ~25 round trips
+//                         per tile)
+#include "ss_common.h"
+#include "ss_scan_dev.h"
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+namespace ss {
+
+constexpr int MINI_M = 15;                       // minimizer length (30 bits)
+constexpr uint32_t M30 = 0x3FFFFFFFu;
+constexpr uint32_t HDR_MULTI = 1u << 17;
+
+// 32-bit mix of a 30-bit m-mer: the ordering that picks the minimizer (avoids poly-A bias).  Two
+// 24x24-bit multiplies (v_mul_u32_u24: full rate on CDNA, v_mul_lo_u32 is quarter rate), a rotate
+// and an xor-shift.  It need not be injective: bucket entries carry the full k-mer.
+__host__ __device__ __forceinline__ uint32_t mmhash(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t a = (uint32_t)__umul24(x & 0xFFFFFFu, 0x9E3779u);
+    const uint32_t b = (uint32_t)__umul24(x >> 6, 0x85EBCBu);
+#else
+    const uint32_t a = (x & 0xFFFFFFu) * 0x9E3779u;
+    const uint32_t b = (x >> 6) * 0x85EBCBu;
+#endif
+    uint32_t h = a ^ ((b << 13) | (b >> 19));
+    h ^= h >> 15;
+    return h;
+}
+
+// the two cuckoo slots of a minimizer hash (minimizers are the SMALL hashes: take high product bits)
+// slot 1 = low bits of the hash (choosing the minimum conditions the HIGH bits; the low bits stay
+// uniform), slot 2 = a 24x24-bit product of the middle bits: no quarter-rate 32-bit multiply
+__host__ __device__ __forceinline__ uint32_t dir_slot1(uint32_t mini, uint32_t dirbits)
+{
+    return mini & ((1u << dirbits) - 1u);
+}
+__host__ __device__ __forceinline__ uint32_t dir_slot2(uint32_t mini, uint32_t dirbits)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // NB: this HIP's __umul24 returns a signed int; cast before the logical shift
+    return (uint32_t)__umul24((mini >> 5) & 0xFFFFFFu, 0x9E3779u) >> (32 - dirbits);
+#else
+    return (uint32_t)(((mini >> 5) & 0xFFFFFFu) * 0x9E3779u) >> (32 - dirbits);
+#endif
+}
+
+// minimizer hash and its LEFTMOST offset inside the k-mer
+static inline uint32_t mini_of_key(uint64_t key, int k, uint32_t *offset)
+{
+    const int w = k - MINI_M + 1;
+    uint32_t best = 0, bo = 0;
+    for (int i = 0; i < w; i++) {
+        const uint32_t h = mmhash((uint32_t)(key >> (2 * i)) & M30);
+        if (i == 0 || h < best) { best = h; bo = (uint32_t)i; }
+    }
+    *offset = bo;
+    return best;
+}
+
+}  // namespace ss
+
+namespace {
+
+using namespace ss::dev;
+
+struct Ent {
+    uint32_t mini;
+    uint32_t row;
+    uint64_t key;
+    uint32_t off;   // offset of the minimizer inside the k-mer (sort key inside the bucket)
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------------------------
+// scan kernel, minimizer layout: dense SIMD for the arithmetic, compacted LDS work queues for
+// the memory probes.
+//
+// Measured on MI355X (profiles/r01b): what bounds this kernel is not HBM bytes but the NUMBER of
+// divergent vector-memory instructions a wave issues (each costs the texture-address unit tens
+// of cycles whatever the number of active lanes) and the dependent round trips per tile.  A lane
+// that probes once per position (or even once per run, predicated per position) issues 32+ such
+// instructions per tile for ~3 useful lookups.  So per tile of 4096 start positions:
+//   phase 0  coalesced 16-byte loads of the bases, SWAR 2-bit encode, codes -> LDS
+//   phase 1  every lane: minimizer (hash, leftmost offset) of its 16 k-mers; runs of equal
+//            minimizers are pushed to LDS queue q1 through a wave ballot/prefix-sum
+//            (one entry per run: ~450 per tile instead of 4096 positions)
+//   phase 2  lanes pull runs from q1: ONE directory lookup per run (two independent 8-byte loads,
+//            cuckoo: no probe chains).  Runs whose minimizer exists go to q2 and are expanded to
+//            per-position items in q3 (rare: ~5 % of the positions of a typical sample)
+//   phase 3  lanes pull items from q3: bucket header -> candidate slot -> compare -> atomicAdd
+// ---------------------------------------------------------------------------------------------
+constexpr int Q1CAP = 1024;        // runs per tile held in LDS (mean ~450); overflow is handled inline
+
+struct QShared {
+    uint32_t code[SCAN_THREADS + 2];
+    uint16_t inv[SCAN_THREADS + 2];
+    uint32_t off[SCAN_THREADS * 3];    // 16 offsets x 5 bits per lane
+    uint64_t q1[Q1CAP];                // run:   minimizer hash << 32 | len << 12 | tile position
+    uint64_t q2[Q1CAP];                // found: bucket start   << 32 | len << 12 | tile position
+    uint16_t q3[TILE];                 // item:  q2 index << 5 | position inside the run
+    uint32_t cnt[4];                   // n1, n2, n3
+};
+
+__device__ __forceinline__ uint64_t kmer_at(const QShared &S, uint32_t pos, uint64_t kmask)
+{
+    const uint32_t w = pos >> 4, sh = 2 * (pos & 15);
+    const uint64_t lo = (uint64_t)S.code[w] | ((uint64_t)S.code[w + 1] << 32);
+    const uint64_t hi = (uint64_t)S.code[w + 2];
+    return (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & kmask;
+}
+
+// one k-mer against its bucket: header -> candidate -> compare -> count
+__device__ __forceinline__ void lookup_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t hdr,
+                                            uint64_t cand_or_0, bool have_cand, const uint64_t *__restrict__ mkeys,
+                                            uint32_t *__restrict__ counts, uint64_t kmask)
+{
+    (void)cand_or_0; (void)have_cand;
+    const uint32_t lane = pos >> 4, j = pos & 15;
+    const uint32_t o = (S.off[lane * 3 + j / 6] >> (5 * (j % 6))) & 31u;
+    const uint32_t mask = hdr & 0x1FFFFu;
+    if (!((mask >> o) & 1u)) return;
+    const uint32_t cpos = bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u));
+    const uint64_t km = kmer_at(S, pos, kmask);
+    if (mkeys[cpos] == km) {
+        atomicAdd(&counts[cpos], 1u);
+    } else if (hdr & ss::HDR_MULTI) {   // several k-mers share an offset (repeated / colliding minimizer)
+        const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
+        for (uint32_t q = 0; q < cnt; q++)
+            if (mkeys[bstart + 1 + q] == km) { atomicAdd(&counts[bstart + 1 + q], 1u); break; }
+    }
+}
+
+template <bool ALIGNED, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel(
+    const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
+    const uint64_t *__restrict__ dir, uint32_t dirbits, uint32_t *__restrict__ counts)
+{
+    constexpr int K = 31, W = K - ss::MINI_M + 1;   // 17 m-mers per k-mer
+    __shared__ QShared S;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const uint64_t kmask = (~0ull) >> (64 - 2 * K);
+    const uint32_t *mk32 = reinterpret_cast<const uint32_t *>(mkeys);
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t base = tile * (uint64_t)TILE;
+        // ---- phase 0 ---------------------------------------------------------------------------
+        {
+            uint32_t w[4], code, inv;
+            load16<ALIGNED>(bases, base + (uint64_t)t * 16, n, w);
+            encode16(w, code, inv);
+            S.code[t] = code;
+            S.inv[t] = (uint16_t)inv;
+            if (t < 2) {
+                load16<ALIGNED>(bases, base + TILE + (uint64_t)t * 16, n, w);
+                encode16(w, code, inv);
+                S.code[SCAN_THREADS + t] = code;
+                S.inv[SCAN_THREADS + t] = (uint16_t)inv;
+            }
+            if (t < 4) S.cnt[t] = 0;
+        }
+        __syncthreads();
+
+        // ---- phase 1: minimizers and runs ------------------------------------------------------
+        const uint32_t c0 = S.code[t], c1 = S.code[t + 1], c2 = S.code[t + 2];
+        uint32_t live;
+        {
+            uint64_t x = (uint64_t)S.inv[t] | ((uint64_t)S.inv[t + 1] << 16) | ((uint64_t)S.inv[t + 2] << 32);
+            x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 15;   // any invalid base in [j, j+31)
+            live = ~(uint32_t)x & 0xFFFFu;
+        }
+        uint32_t need = 0;
+        uint32_t mh[PPT];
+        if (live) {
+            // k-mer j covers m-mers j..j+16.  Split at m-mer 16/17: suffix minima over m-mers j..16 are
+            // built rolling LEFT from m-mer 16, prefix minima over 17..16+j rolling RIGHT from m-mer 17.
+            // Ties go to the leftmost m-mer (the database side uses the same rule).
+            uint32_t suf_h[W], suf_i[W];
+            {
+                uint32_t x = c1 & ss::M30;                                   // m-mer 16 = bases 16..30
+                suf_h[W - 1] = ss::mmhash(x);
+                suf_i[W - 1] = W - 1;
+#pragma unroll
+                for (int i = W - 2; i >= 0; i--) {
+                    x = ((x << 2) & ss::M30) | ((c0 >> (2 * i)) & 3u);       // m-mer i: base i enters at the bottom
+                    const uint32_t h = ss::mmhash(x);
+                    const bool take = h <= suf_h[i + 1];
+                    suf_h[i] = take ? h : suf_h[i + 1];
+                    suf_i[i] = take ? (uint32_t)i : suf_i[i + 1];
+                }
+            }
+            uint32_t offw[3] = {0, 0, 0};
+            mh[0] = suf_h[0];
+            offw[0] = suf_i[0];
+            uint32_t x = ((c1 >> 2) | (c2 << 30)) & ss::M30;                 // m-mer 17 = bases 17..31
+            uint32_t pre_h = ss::mmhash(x), pre_i = W;
+#pragma unroll
+            for (int j = 1; j < PPT; j++) {
+                if (j > 1) {
+                    const int p = W - 1 + j + ss::MINI_M - 1;                // last base of m-mer 16+j (32..45)
+                    x = (x >> 2) | (((c2 >> (2 * (p - 32))) & 3u) << 28);
+                    const uint32_t h = ss::mmhash(x);
+                    if (h < pre_h) { pre_h = h; pre_i = (uint32_t)(W - 1 + j); }
+                }
+                const bool take_pre = pre_h < suf_h[j];
+                mh[j] = take_pre ? pre_h : suf_h[j];
+                const uint32_t o = (take_pre ? pre_i : suf_i[j]) - (uint32_t)j;
+                offw[j / 6] |= o << (5 * (j % 6));
+            }
+            S.off[t * 3] = offw[0];
+            S.off[t * 3 + 1] = offw[1];
+            S.off[t * 3 + 2] = offw[2];
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const bool lv = (live >> j) & 1u;
+                const bool first = (j == 0) || !((live >> (j - 1)) & 1u) || (mh[j] != mh[j > 0 ? j - 1 : 0]);
+                if (lv && first) need |= 1u << j;
+            }
+        }
+        // wave prefix sum of the run counts, one LDS atomic per wave, predicated queue writes
+        uint32_t ovf = 0;   // runs that did not fit q1 (processed inline below)
+        {
+            const uint32_t mine = (uint32_t)__popc(need);
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            const uint32_t total = __shfl(incl, 63, 64);
+            uint32_t wbase = 0;
+            if (lane == 63 && total) wbase = atomicAdd(&S.cnt[0], total);
+            wbase = __shfl(wbase, 63, 64);
+            const uint32_t mybase = wbase + incl - mine;
+            if (need) {
+                const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
+#pragma unroll
+                for (int j = 0; j < PPT; j++) {
+                    if (!((need >> j) & 1u)) continue;
+                    const uint32_t idx = mybase + (uint32_t)__popc(need & ((1u << j) - 1u));
+                    const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));   // positions until the next run / gap
+                    if (idx < Q1CAP)
+                        S.q1[idx] = ((uint64_t)mh[j] << 32) | (len << 12) | (uint32_t)(t * PPT + j);
+                    else
+                        ovf |= 1u << j;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: one directory lookup per run ----------------------------------------------
+        {
+            const uint32_t n1 = min(S.cnt[0], (uint32_t)Q1CAP);
+            for (uint32_t r0 = 0; r0 < n1; r0 += 2 * SCAN_THREADS) {
+                const uint32_t ra = r0 + t, rb = r0 + SCAN_THREADS + t;
+                const bool va = ra < n1, vb = rb < n1;
+                const uint64_t ea = va ? S.q1[ra] : 0, eb = vb ? S.q1[rb] : 0;
+                const uint32_t ha = (uint32_t)(ea >> 32), hb = (uint32_t)(eb >> 32);
+                const uint64_t a1 = dir[va ? ss::dir_slot1(ha, dirbits) : 0u], a2 = dir[va ? ss::dir_slot2(ha, dirbits) : 0u];
+                const uint64_t b1 = dir[vb ? ss::dir_slot1(hb, dirbits) : 0u], b2 = dir[vb ? ss::dir_slot2(hb, dirbits) : 0u];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const bool v = u ? vb : va;
+                    const uint64_t e = u ? eb : ea, d1 = u ? b1 : a1, d2 = u ? b2 : a2;
+                    const uint32_t h = (uint32_t)(e >> 32);
+                    const bool m1 = v && d1 != ss::EMPTY_KEY && (uint32_t)(d1 >> 32) == h;
+                    const bool m2 = v && d2 != ss::EMPTY_KEY && (uint32_t)(d2 >> 32) == h;
+                    if (m1 || m2) {
+                        const uint32_t bstart = m1 ? (uint32_t)d1 : (uint32_t)d2;
+                        const uint32_t len = ((uint32_t)e >> 12) & 31u;
+                        const uint32_t i2 = atomicAdd(&S.cnt[1], 1u);
+                        const uint32_t i3 = atomicAdd(&S.cnt[2], len);
+                        S.q2[i2] = ((uint64_t)bstart << 32) | ((uint32_t)e & 0x1FFFFu);
+                        for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: the k-mers whose minimizer exists in the database -------------------------
+        {
+            const uint32_t n3 = S.cnt[2];
+            for (uint32_t i0 = 0; i0 < n3; i0 += 2 * SCAN_THREADS) {
+                const uint32_t ia = i0 + t, ib = i0 + SCAN_THREADS + t;
+                const bool va = ia < n3, vb = ib < n3;
+                const uint32_t ta = va ? S.q3[ia] : 0, tb = vb ? S.q3[ib] : 0;
+                const uint64_t ra = S.q2[ta >> 5], rb = S.q2[tb >> 5];
+                const uint32_t sa = va ? (uint32_t)(ra >> 32) : 0u, sb = vb ? (uint32_t)(rb >> 32) : 0u;
+                const uint32_t hda = mk32[2 * (uint64_t)sa], hdb = mk32[2 * (uint64_t)sb];   // both headers in flight
+                if (va) lookup_item(S, ((uint32_t)ra & 0xFFFu) + (ta & 31u), sa, hda, 0, false, mkeys, counts, kmask);
+                if (vb) lookup_item(S, ((uint32_t)rb & 0xFFFu) + (tb & 31u), sb, hdb, 0, false, mkeys, counts, kmask);
+            }
+        }
+        // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
+        if (ovf) {
+            const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
+            for (int j = 0; j < PPT; j++) {
+                if (!((ovf >> j) & 1u)) continue;
+                uint32_t h = 0;
+#pragma unroll
+                for (int q = 0; q < PPT; q++) if (q == j) h = mh[q];
+                const uint64_t d1 = dir[ss::dir_slot1(h, dirbits)], d2 = dir[ss::dir_slot2(h, dirbits)];
+                const bool m1 = d1 != ss::EMPTY_KEY && (uint32_t)(d1 >> 32) == h;
+                const bool m2 = d2 != ss::EMPTY_KEY && (uint32_t)(d2 >> 32) == h;
+                if (!(m1 || m2)) continue;
+                const uint32_t bstart = m1 ? (uint32_t)d1 : (uint32_t)d2;
+                const uint32_t hdr = mk32[2 * (uint64_t)bstart];
+                const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
+                for (uint32_t q = 0; q < len; q++)
+                    lookup_item(S, (uint32_t)(t * PPT + j) + q, bstart, hdr, 0, false, mkeys, counts, kmask);
+            }
+        }
+        __syncthreads();   // queues and codes are rewritten by the next tile
+    }
+}
+
+void parallel_for(unsigned nthreads, uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)> &fn)
+{
+    if (nthreads <= 1 || n < 65536) { fn(0, n, 0); return; }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n + nthreads - 1) / nthreads;
+    for (unsigned w = 0; w < nthreads; w++) {
+        const uint64_t lo = std::min<uint64_t>(n, per * w), hi = std::min<uint64_t>(n, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back(fn, lo, hi, w);
+    }
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+namespace ss {
+
+// Host build of the minimizer index.  Fills db->d_mkeys / d_dir / d_counts / d_slot_of_row /
+// d_row_valid and n_distinct; returns SS_EKEY for an un-owned k-mer when upper_keys == 0.
+int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys)
+{
+    const int k = db->k;
+    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    // 1. entries of valid rows with their minimizer
+    std::vector<uint64_t> pos(n_rows + 1, 0);
+    for (uint64_t i = 0; i < n_rows; i++) pos[i + 1] = pos[i] + ((flags[i] & SS_ROW_VALID) ? 1 : 0);
+    const uint64_t nv = pos[n_rows];
+    std::vector<Ent> ents(nv), sorted(nv);
+    parallel_for(nthreads, n_rows, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t i = lo; i < hi; i++)
+            if (flags[i] & SS_ROW_VALID) {
+                uint32_t o;
+                const uint32_t mh = mini_of_key(keys[i], k, &o);
+                ents[pos[i]] = Ent{mh, (uint32_t)i, keys[i], o, 0};
+            }
+    });
+    // 2. counting partition on the top 8 bits of the minimizer hash, then per-partition sort
+    constexpr int PB = 8, NP = 1 << PB;
+    std::vector<uint64_t> pcount(NP + 1, 0);
+    for (uint64_t i = 0; i < nv; i++) pcount[(ents[i].mini >> (32 - PB)) + 1]++;
+    for (int p = 0; p < NP; p++) pcount[p + 1] += pcount[p];
+    {
+        std::vector<uint64_t> cur(pcount.begin(), pcount.end() - 1);
+        for (uint64_t i = 0; i < nv; i++) sorted[cur[ents[i].mini >> (32 - PB)]++] = ents[i];
+    }
+    ents.clear();
+    ents.shrink_to_fit();
+    {
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nthreads; w++)
+            pool.emplace_back([&] {
+                for (int p; (p = next.fetch_add(1)) < NP;)
+                    std::sort(sorted.begin() + pcount[p], sorted.begin() + pcount[p + 1], [](const Ent &a, const Ent &b) {
+                        if (a.mini != b.mini) return a.mini < b.mini;
+                        if (a.off != b.off) return a.off < b.off;
+                        if (a.key != b.key) return a.key < b.key;
+                        return a.row < b.row;
+                    });
+            });
+        for (auto &th : pool) th.join();
+    }
+    // 3. distinct k-mers, buckets (header + entries), row bookkeeping (dict overwrite: the last
+    //    allowed row owns the count)
+    std::vector<uint64_t> mkeys;
+    mkeys.reserve(nv + nv / 4 + 2);
+    std::vector<uint32_t> slot_of_row(std::max<uint64_t>(1, n_rows), SS_NO_SLOT);
+    std::vector<uint8_t> row_valid(std::max<uint64_t>(1, n_rows), 0);
+    std::vector<std::pair<uint32_t, uint32_t>> buckets;   // (minimizer hash, header slot)
+    uint64_t orphans = 0, n_distinct = 0;
+    for (uint64_t i = 0; i < nv;) {
+        // one bucket = all entries with this minimizer hash
+        uint64_t e = i;
+        while (e < nv && sorted[e].mini == sorted[i].mini) e++;
+        const uint32_t hslot = (uint32_t)mkeys.size();
+        buckets.emplace_back(sorted[i].mini, hslot);
+        mkeys.push_back(0);
+        uint32_t mask = 0, multi = 0, cnt = 0;
+        for (uint64_t a = i; a < e;) {
+            uint64_t b = a;
+            int64_t owner = -1;
+            while (b < e && sorted[b].key == sorted[a].key) {
+                const uint32_t r = sorted[b].row;
+                if (upper_keys == 1 || !(flags[r] & SS_ROW_LOWER)) owner = r;   // rows ascend within equal k-mers
+                b++;
+            }
+            const uint32_t o = sorted[a].off;
+            if ((mask >> o) & 1u) multi = HDR_MULTI;
+            mask |= 1u << o;
+            const uint32_t slot = (uint32_t)mkeys.size();
+            mkeys.push_back(sorted[a].key);
+            for (uint64_t q = a; q < b; q++) slot_of_row[sorted[q].row] = slot;
+            if (owner >= 0) row_valid[owner] = 1;
+            else orphans++;
+            cnt++;
+            n_distinct++;
+            a = b;
+        }
+        mkeys[hslot] = ((uint64_t)cnt << 32) | multi | mask;
+        i = e;
+    }
+    sorted.clear();
+    sorted.shrink_to_fit();
+    if (orphans && upper_keys == 0) return SS_EKEY;
+    if (mkeys.size() >= 0xFFFFFFF0ull) return SS_ERANGE;
+    db->n_distinct = n_distinct;
+    db->n_slots = std::max<uint64_t>(1, mkeys.size());
+    // cuckoo directory: load <= 1/3 so that random-walk insertion practically never fails; a failed
+    // build doubles the table
+    uint32_t dirbits = 10;
+    while ((1ull << dirbits) < 3 * buckets.size()) dirbits++;
+    std::vector<uint64_t> dir;
+    for (;; dirbits++) {
+        if (dirbits > 31) return SS_ERANGE;
+        dir.assign(1ull << dirbits, EMPTY_KEY);
+        bool ok = true;
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        for (const auto &b : buckets) {
+            uint64_t cur = ((uint64_t)b.first << 32) | b.second;
+            uint32_t slot = dir_slot1(b.first, dirbits);
+            if (dir[slot] != EMPTY_KEY && dir[dir_slot2(b.first, dirbits)] == EMPTY_KEY) slot = dir_slot2(b.first, dirbits);
+            int kicks = 0;
+            for (; kicks < 2000; kicks++) {
+                if (dir[slot] == EMPTY_KEY) { dir[slot] = cur; break; }
+                std::swap(cur, dir[slot]);
+                const uint32_t h = (uint32_t)(cur >> 32);
+                const uint32_t s1 = dir_slot1(h, dirbits), s2 = dir_slot2(h, dirbits);
+                rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+                slot = (slot == s1) ? s2 : (slot == s2) ? s1 : ((rng & 1) ? s1 : s2);
+            }
+            if (kicks == 2000) { ok = false; break; }
+        }
+        if (ok) break;
+    }
+    db->dirbits = dirbits;
+    db->n_buckets = buckets.size();
+    db->capacity = db->n_slots;
+    // 4. upload
+    const uint64_t nr = std::max<uint64_t>(1, n_rows);
+    SS_HIP(hipMalloc((void **)&db->d_mkeys, db->n_slots * sizeof(uint64_t)));
+    SS_HIP(hipMalloc((void **)&db->d_dir, dir.size() * sizeof(uint64_t)));
+    SS_HIP(hipMalloc((void **)&db->d_counts, db->n_slots * sizeof(uint32_t)));
+    SS_HIP(hipMalloc((void **)&db->d_slot_of_row, nr * sizeof(uint32_t)));
+    SS_HIP(hipMalloc((void **)&db->d_row_valid, nr));
+    db->device_bytes = db->n_slots * 12 + dir.size() * 8 + nr * 5;
+    if (!mkeys.empty())
+        SS_HIP(hipMemcpy(db->d_mkeys, mkeys.data(), mkeys.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    else
+        SS_HIP(hipMemset(db->d_mkeys, 0xFF, sizeof(uint64_t)));
+    SS_HIP(hipMemcpy(db->d_dir, dir.data(), dir.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    SS_HIP(hipMemset(db->d_counts, 0, db->n_slots * sizeof(uint32_t)));
+    SS_HIP(hipMemcpy(db->d_slot_of_row, slot_of_row.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SS_HIP(hipMemcpy(db->d_row_valid, row_valid.data(), nr, hipMemcpyHostToDevice));
+    return SS_OK;
+}
+
+template <int LB>
+static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const uint8_t *bases, uint64_t n,
+                      uint64_t n_tiles, ss_db *db)
+{
+    if (aligned)
+        hipLaunchKernelGGL((scan_mini_kernel<true, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
+                           db->d_mkeys, db->d_dir, db->dirbits, db->d_counts);
+    else
+        hipLaunchKernelGGL((scan_mini_kernel<false, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
+                           db->d_mkeys, db->d_dir, db->dirbits, db->d_counts);
+}
+
+int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
+                     uint64_t n_tiles)
+{
+    const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
+    static int lb = -1, bpc = 0;
+    if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
+        const char *e = getenv("SS_MINI_LB");
+        lb = e ? atoi(e) : 4;
+        const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
+        bpc = g ? atoi(g) : 0;
+    }
+    if (bpc > 0) blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)bpc * 256);
+    const uint8_t *b = (const uint8_t *)bases_dev;
+    switch (lb) {
+    case 1: launch_lb<1>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 5: launch_lb<5>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    default: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    }
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+}  // namespace ss

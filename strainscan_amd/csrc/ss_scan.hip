@@ -16,69 +16,17 @@
 // The scan kernel is HBM/latency bound (random 8-byte gathers into a table far larger than
 // L2): 150 B of bases + 120 probes x 8 B per 150-bp read and ~40 VALU ops per probe.
 #include "ss_common.h"
+#include "ss_scan_dev.h"
+
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
 
 namespace {
 
-constexpr int SCAN_THREADS = 256;
-constexpr int PPT = 16;                        // k-mer start positions per thread per tile
-constexpr int TILE = SCAN_THREADS * PPT;       // bytes of the base stream per tile
+using namespace ss::dev;
 constexpr uint64_t STAGE_BYTES = 32ull << 20;  // pinned staging chunk for host-resident blocks
-
-// ---------------------------------------------------------------------------------------------
-// 16 ASCII bases (4 dwords) -> 32 bits of 2-bit codes (base i at bits 2i) + 16 invalid flags.
-// SWAR: no per-byte loop, no LDS lookup table.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zero_bytes(uint32_t v)
-{   // 0x80 in every byte of v that is zero (exact form, no borrow artefacts)
-    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
-}
-
-__device__ __forceinline__ void encode4(uint32_t w, uint32_t &code8, uint32_t &bad4)
-{
-    uint32_t x = (w & 0xDFDFDFDFu) ^ 0x41414141u;           // A->00 C->02 G->06 T->15 (either case)
-    uint32_t ok = zero_bytes(x) | zero_bytes(x ^ 0x02020202u) | zero_bytes(x ^ 0x06060606u) |
-                  zero_bytes(x ^ 0x15151515u);
-    bad4 = (((ok ^ 0x80808080u) >> 7) * 0x01020408u) >> 24; // bit i = byte i is not ACGT
-    uint32_t c = (w >> 1) & 0x03030303u;                    // (ascii >> 1) & 3 per byte
-    code8 = (c * 0x01041040u) >> 24;                        // pack the four 2-bit fields
-}
-
-__device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t &code, uint32_t &inv)
-{
-    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-    encode4(w[0], c0, b0);
-    encode4(w[1], c1, b1);
-    encode4(w[2], c2, b2);
-    encode4(w[3], c3, b3);
-    code = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    inv = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
-}
-
-// 16 bytes at `off` of the base stream; bytes at or beyond n read as '\n'.
-template <bool ALIGNED>
-__device__ __forceinline__ void load16(const uint8_t *__restrict__ bases, uint64_t off, uint64_t n,
-                                       uint32_t w[4])
-{
-    if (ALIGNED && off + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(bases + off);
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                uint64_t p = off + d * 4 + b;
-                uint32_t c = (p < n) ? bases[p] : 0x0Au;
-                x |= c << (8 * b);
-            }
-            w[d] = x;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // encode + probe + count.  One tile = 4096 consecutive start positions of the flat base stream
@@ -258,7 +206,19 @@ int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int
     db->n_rows = n_rows;
     db->log2cap = log2cap;
     db->capacity = 1ull << log2cap;
+    db->n_slots = db->capacity;
     if (hipGetDevice(&db->device) != hipSuccess) { delete db; return SS_ENODEV; }
+    // layout: minimizer buckets for k = 31 (the tree scan and the default layer-2 k), flat table
+    // otherwise; SS_LAYOUT=flat|mini overrides for A/B measurements
+    const char *lay = getenv("SS_LAYOUT");
+    db->layout = (k == 31) ? 1 : 0;
+    if (lay && !strcmp(lay, "flat")) db->layout = 0;
+    if (db->layout == 1) {
+        int mrc = ss::build_mini(db, keys, flags, n_rows, upper_keys);
+        if (mrc != SS_OK) { ss_db_destroy(db); return mrc; }
+        *out = db;
+        return SS_OK;
+    }
 
     uint64_t *d_in = nullptr;
     uint8_t *d_flags = nullptr;
@@ -324,6 +284,8 @@ int ss_db_destroy(ss_db *db)
 {
     if (!db) return SS_OK;
     hipFree(db->d_keys);
+    hipFree(db->d_mkeys);
+    hipFree(db->d_dir);
     hipFree(db->d_counts);
     hipFree(db->d_slot_of_row);
     hipFree(db->d_row_valid);
@@ -361,7 +323,7 @@ uint64_t ss_scan_kernel_launches(const ss_db *db) { return db ? db->launches : 0
 int ss_scan_reset(ss_db *db, void *stream)
 {
     if (!db) return SS_EINVAL;
-    SS_HIP(hipMemsetAsync(db->d_counts, 0, db->capacity * sizeof(uint32_t), ss::as_stream(stream)));
+    SS_HIP(hipMemsetAsync(db->d_counts, 0, db->n_slots * sizeof(uint32_t), ss::as_stream(stream)));
     return SS_OK;
 }
 
@@ -372,6 +334,11 @@ int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream)
     const uint64_t n_tiles = (n + TILE - 1) / TILE;
     const uint64_t max_blocks = (uint64_t)cu_count() * 8;
     const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, max_blocks);
+    if (db->layout == 1) {
+        int rc = ss::launch_scan_mini(db, bases_dev, n, ss::as_stream(stream), blocks, n_tiles);
+        if (rc == SS_OK) db->launches++;
+        return rc;
+    }
     const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
     if (aligned)
         hipLaunchKernelGGL(scan_kernel<true>, dim3(blocks), dim3(SCAN_THREADS), 0, ss::as_stream(stream),
