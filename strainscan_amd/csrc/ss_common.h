@@ -67,6 +67,7 @@ struct ss_db {
     uint64_t *d_mkeys = nullptr;       // buckets: [n_distinct] k-mers grouped by minimizer, bit 63 = last of bucket
     uint64_t *d_dir = nullptr;         // buckets: [2^dirbits] (minimizer hash << 32) | bucket start
     uint32_t dirbits = 0;
+    uint32_t n_dir = 0;                // buckets: number of 16-byte directory buckets
     uint64_t n_buckets = 0;
     uint32_t *d_counts = nullptr;      // [n_slots] occurrences per slot (accumulated by scans)
     uint32_t *d_slot_of_row = nullptr; // [n_rows]   slot owning row i, SS_NO_SLOT if none

@@ -23,12 +23,12 @@
 //                         the k-mer with offset o sits at header + 1 + popcount(mask & ((1 << o) - 1)):
 //                         a hit costs two dependent loads, a miss inside an existing bucket one.
 //   d_counts[n_slots] u32 occurrences per slot (same index; header slots unused)
-//   d_dir[2^dirbits]  u64 cuckoo directory (two hash functions, one entry per slot):
-//                         (minimizer hash << 32) | bucket start, EMPTY = ~0.  A lookup is exactly two
-//                         independent 8-byte loads -- one memory round trip, no probe chains (with
-//                         linear probing ~40 % of the mostly-unsuccessful lookups needed a dependent
-//                         second load and the per-position retry loops serialised into ~25 round trips
-//                         per tile)
+//   d_dir[n_dir][2]   u64 cuckoo directory of 16-byte buckets (two entries each, two hash functions):
+//                         entry = (minimizer hash << 32) | bucket start (31 bits), EMPTY = ~0.  A key
+//                         lives in its FIRST bucket unless that one was full when it arrived; bit 31
+//                         of a first bucket's entry 0 says "a key of this bucket lives in its second
+//                         bucket".  A lookup is one 16-byte load (one HBM sector), plus a second one
+//                         only behind that flag (a few % of the lookups): no probe chains.
 #include "ss_common.h"
 #include "ss_scan_dev.h"
 
@@ -62,21 +62,26 @@ __host__ __device__ __forceinline__ uint32_t mmhash(uint32_t x)
 }
 
 // the two cuckoo slots of a minimizer hash (minimizers are the SMALL hashes: take high product bits)
-// slot 1 = low bits of the hash (choosing the minimum conditions the HIGH bits; the low bits stay
-// uniform), slot 2 = a 24x24-bit product of the middle bits: no quarter-rate 32-bit multiply
-__host__ __device__ __forceinline__ uint32_t dir_slot1(uint32_t mini, uint32_t dirbits)
-{
-    return mini & ((1u << dirbits) - 1u);
-}
-__host__ __device__ __forceinline__ uint32_t dir_slot2(uint32_t mini, uint32_t dirbits)
+// the two directory buckets of a minimizer hash: 32-bit mixes reduced to [0, n_dir) by the high half
+// of a 32x32 product (any table size, no power-of-two rounding).  Once per RUN, not per position.
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // NB: this HIP's __umul24 returns a signed int; cast before the logical shift
-    return (uint32_t)__umul24((mini >> 5) & 0xFFFFFFu, 0x9E3779u) >> (32 - dirbits);
+    return __umulhi(a, b);
 #else
-    return (uint32_t)(((mini >> 5) & 0xFFFFFFu) * 0x9E3779u) >> (32 - dirbits);
+    return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
+__host__ __device__ __forceinline__ uint32_t dir_bucket1(uint32_t mini, uint32_t n_dir)
+{
+    return mulhi32(mini * 0x9E3779B1u, n_dir);
+}
+__host__ __device__ __forceinline__ uint32_t dir_bucket2(uint32_t mini, uint32_t n_dir)
+{
+    return mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir);
+}
+constexpr uint64_t DIR_MOVED = 1ull << 31;        // flag in entry 0 of a first bucket
+constexpr uint32_t START_MASK = 0x7FFFFFFFu;
 
 // minimizer hash and its LEFTMOST offset inside the k-mer
 static inline uint32_t mini_of_key(uint64_t key, int k, uint32_t *offset)
@@ -167,7 +172,7 @@ __device__ __forceinline__ void lookup_item(const QShared &S, uint32_t pos, uint
 template <bool ALIGNED, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
-    const uint64_t *__restrict__ dir, uint32_t dirbits, uint32_t *__restrict__ counts)
+    const uint64_t *__restrict__ dir, uint32_t n_dir, uint32_t *__restrict__ counts)
 {
     constexpr int K = 31, W = K - ss::MINI_M + 1;   // 17 m-mers per k-mer
     __shared__ QShared S;
@@ -285,22 +290,29 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         // ---- phase 2: one directory lookup per run ----------------------------------------------
         {
             const uint32_t n1 = min(S.cnt[0], (uint32_t)Q1CAP);
+            const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
             for (uint32_t r0 = 0; r0 < n1; r0 += 2 * SCAN_THREADS) {
                 const uint32_t ra = r0 + t, rb = r0 + SCAN_THREADS + t;
                 const bool va = ra < n1, vb = rb < n1;
                 const uint64_t ea = va ? S.q1[ra] : 0, eb = vb ? S.q1[rb] : 0;
                 const uint32_t ha = (uint32_t)(ea >> 32), hb = (uint32_t)(eb >> 32);
-                const uint64_t a1 = dir[va ? ss::dir_slot1(ha, dirbits) : 0u], a2 = dir[va ? ss::dir_slot2(ha, dirbits) : 0u];
-                const uint64_t b1 = dir[vb ? ss::dir_slot1(hb, dirbits) : 0u], b2 = dir[vb ? ss::dir_slot2(hb, dirbits) : 0u];
+                ulonglong2 ba = dir2[va ? ss::dir_bucket1(ha, n_dir) : 0u];      // both 16-byte loads in flight
+                ulonglong2 bb = dir2[vb ? ss::dir_bucket1(hb, n_dir) : 0u];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const bool v = u ? vb : va;
-                    const uint64_t e = u ? eb : ea, d1 = u ? b1 : a1, d2 = u ? b2 : a2;
+                    const uint64_t e = u ? eb : ea;
+                    ulonglong2 bk = u ? bb : ba;
                     const uint32_t h = (uint32_t)(e >> 32);
-                    const bool m1 = v && d1 != ss::EMPTY_KEY && (uint32_t)(d1 >> 32) == h;
-                    const bool m2 = v && d2 != ss::EMPTY_KEY && (uint32_t)(d2 >> 32) == h;
-                    if (m1 || m2) {
-                        const uint32_t bstart = m1 ? (uint32_t)d1 : (uint32_t)d2;
+                    bool m0 = v && bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
+                    bool m1 = v && bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
+                    if (v && !m0 && !m1 && bk.x != ss::EMPTY_KEY && (bk.x & ss::DIR_MOVED)) {
+                        bk = dir2[ss::dir_bucket2(h, n_dir)];                  // the key may live in its second bucket
+                        m0 = bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
+                        m1 = bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
+                    }
+                    if (m0 || m1) {
+                        const uint32_t bstart = (uint32_t)(m0 ? bk.x : bk.y) & ss::START_MASK;
                         const uint32_t len = ((uint32_t)e >> 12) & 31u;
                         const uint32_t i2 = atomicAdd(&S.cnt[1], 1u);
                         const uint32_t i3 = atomicAdd(&S.cnt[2], len);
@@ -334,11 +346,17 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 uint32_t h = 0;
 #pragma unroll
                 for (int q = 0; q < PPT; q++) if (q == j) h = mh[q];
-                const uint64_t d1 = dir[ss::dir_slot1(h, dirbits)], d2 = dir[ss::dir_slot2(h, dirbits)];
-                const bool m1 = d1 != ss::EMPTY_KEY && (uint32_t)(d1 >> 32) == h;
-                const bool m2 = d2 != ss::EMPTY_KEY && (uint32_t)(d2 >> 32) == h;
-                if (!(m1 || m2)) continue;
-                const uint32_t bstart = m1 ? (uint32_t)d1 : (uint32_t)d2;
+                const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
+                ulonglong2 bk = dir2[ss::dir_bucket1(h, n_dir)];
+                bool m0 = bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
+                bool m1 = bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
+                if (!m0 && !m1 && bk.x != ss::EMPTY_KEY && (bk.x & ss::DIR_MOVED)) {
+                    bk = dir2[ss::dir_bucket2(h, n_dir)];
+                    m0 = bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
+                    m1 = bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
+                }
+                if (!(m0 || m1)) continue;
+                const uint32_t bstart = (uint32_t)(m0 ? bk.x : bk.y) & ss::START_MASK;
                 const uint32_t hdr = mk32[2 * (uint64_t)bstart];
                 const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
                 for (uint32_t q = 0; q < len; q++)
@@ -456,33 +474,46 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     if (mkeys.size() >= 0xFFFFFFF0ull) return SS_ERANGE;
     db->n_distinct = n_distinct;
     db->n_slots = std::max<uint64_t>(1, mkeys.size());
-    // cuckoo directory: load <= 1/3 so that random-walk insertion practically never fails; a failed
-    // build doubles the table
-    uint32_t dirbits = 10;
-    while ((1ull << dirbits) < 3 * buckets.size()) dirbits++;
+    // cuckoo directory of 2-entry buckets, ~0.67 keys per bucket (1/3 load).  Keys prefer their first
+    // bucket; a key that ends up in its second bucket sets DIR_MOVED on its first one.
+    if (mkeys.size() >= 0x7FFFFFF0ull) return SS_ERANGE;
+    uint64_t n_dir = std::max<uint64_t>(16, buckets.size() + buckets.size() / 2);
     std::vector<uint64_t> dir;
-    for (;; dirbits++) {
-        if (dirbits > 31) return SS_ERANGE;
-        dir.assign(1ull << dirbits, EMPTY_KEY);
+    std::vector<uint8_t> moved;
+    for (;; n_dir += n_dir / 4) {
+        if (n_dir >= 0xFFFFFFF0ull) return SS_ERANGE;
+        dir.assign(2 * n_dir, EMPTY_KEY);
+        moved.assign(n_dir, 0);
         bool ok = true;
         uint64_t rng = 0x9E3779B97F4A7C15ull;
-        for (const auto &b : buckets) {
-            uint64_t cur = ((uint64_t)b.first << 32) | b.second;
-            uint32_t slot = dir_slot1(b.first, dirbits);
-            if (dir[slot] != EMPTY_KEY && dir[dir_slot2(b.first, dirbits)] == EMPTY_KEY) slot = dir_slot2(b.first, dirbits);
-            int kicks = 0;
-            for (; kicks < 2000; kicks++) {
-                if (dir[slot] == EMPTY_KEY) { dir[slot] = cur; break; }
-                std::swap(cur, dir[slot]);
+        auto place = [&](uint64_t cur) -> bool {
+            for (int kicks = 0; kicks < 1000; kicks++) {
                 const uint32_t h = (uint32_t)(cur >> 32);
-                const uint32_t s1 = dir_slot1(h, dirbits), s2 = dir_slot2(h, dirbits);
+                const uint32_t b1 = dir_bucket1(h, (uint32_t)n_dir), b2 = dir_bucket2(h, (uint32_t)n_dir);
+                if (dir[2 * b1] == EMPTY_KEY) { dir[2 * b1] = cur; return true; }
+                if (dir[2 * b1 + 1] == EMPTY_KEY) { dir[2 * b1 + 1] = cur; return true; }
+                moved[b1] = 1;                                     // from now on look in b2 as well
+                if (dir[2 * b2] == EMPTY_KEY) { dir[2 * b2] = cur; return true; }
+                if (dir[2 * b2 + 1] == EMPTY_KEY) { dir[2 * b2 + 1] = cur; return true; }
                 rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
-                slot = (slot == s1) ? s2 : (slot == s2) ? s1 : ((rng & 1) ? s1 : s2);
+                const uint64_t victim = 2 * (uint64_t)((rng & 2) ? b1 : b2) + (rng & 1);
+                std::swap(cur, dir[victim]);                       // evict; the victim is re-placed next round
             }
-            if (kicks == 2000) { ok = false; break; }
-        }
+            return false;
+        };
+        for (const auto &b : buckets)
+            if (!place(((uint64_t)b.first << 32) | b.second)) { ok = false; break; }
         if (ok) break;
     }
+    for (uint64_t b = 0; b < n_dir; b++)
+        if (moved[b]) {
+            if (dir[2 * b] == EMPTY_KEY) std::swap(dir[2 * b], dir[2 * b + 1]);   // keep the flag carrier in entry 0
+            if (dir[2 * b] != EMPTY_KEY) dir[2 * b] |= DIR_MOVED;
+            // a flagged bucket that became empty again cannot hide a key: moved keys are only ever
+            // displaced from FULL buckets, and evictions swap, they never empty a slot
+        }
+    const uint32_t dirbits = 0;
+    db->n_dir = (uint32_t)n_dir;
     db->dirbits = dirbits;
     db->n_buckets = buckets.size();
     db->capacity = db->n_slots;
@@ -511,10 +542,10 @@ static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const u
 {
     if (aligned)
         hipLaunchKernelGGL((scan_mini_kernel<true, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
-                           db->d_mkeys, db->d_dir, db->dirbits, db->d_counts);
+                           db->d_mkeys, db->d_dir, db->n_dir, db->d_counts);
     else
         hipLaunchKernelGGL((scan_mini_kernel<false, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
-                           db->d_mkeys, db->d_dir, db->dirbits, db->d_counts);
+                           db->d_mkeys, db->d_dir, db->n_dir, db->d_counts);
 }
 
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
