@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--hit-frac", type=float, default=0.05)
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calib-stream", action="store_true",
+                    help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
     args = ap.parse_args()
 
     import torch
@@ -180,6 +182,8 @@ def main():
         n_rows, info["n_distinct"], info["capacity"], layout, info["device_bytes"] / 1e9, time.time() - t0))
     t0 = time.time()
     reads = make_reads(torch, dev, db_spec, args.reads, seed=2 + rank, hit_frac=args.hit_frac)
+    if args.calib_stream:
+        reads.view(args.reads, READ_LEN + 1)[:, :READ_LEN] = 78      # 'N'
     torch.cuda.synchronize()
     log("[bench] reads: %d x %d bp = %.2f GB in HBM (%.1f s)" % (args.reads, READ_LEN, reads.numel() / 1e9,
                                                                  time.time() - t0))
@@ -226,8 +230,15 @@ def main():
     st_np = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
 
     achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="scan_kernel", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel_ms=round(kern_ms, 3),
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # written from rocprofv3 --pmc passes of THIS command
+    if os.path.exists(pmc_path) and args.reads == 20_000_000 and args.leaves == 823 and args.hit_frac == 0.05:
+        with open(pmc_path) as f:
+            traffic = json.load(f).get(layout, {}).get("traffic_gb_per_launch")
+    roofline = dict(bound="hbm", kernel="scan_mini_kernel" if layout == "mini" else "scan_kernel",
+                    achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_unit="GB per launch",
+                    kernel_ms=round(kern_ms, 3),
                     bytes_per_read=BYTES_PER_READ,
                     sector_gbs=round(args.reads * (READ_LEN + 120 * 64) / (kern_ms * 1e-3) / 1e9, 1))
 

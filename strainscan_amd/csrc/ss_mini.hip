@@ -45,8 +45,8 @@ constexpr uint32_t M30 = 0x3FFFFFFFu;
 constexpr uint32_t HDR_MULTI = 1u << 17;
 
 // 32-bit mix of a 30-bit m-mer: the ordering that picks the minimizer (avoids poly-A bias).  Two
-// 24x24-bit multiplies (v_mul_u32_u24: full rate on CDNA, v_mul_lo_u32 is quarter rate), a rotate
-// and an xor-shift.  It need not be injective: bucket entries carry the full k-mer.
+// 24x24-bit multiplies (v_mul_u32_u24: full rate on CDNA, v_mul_lo_u32 is quarter rate) and a
+// rotate.  It need not be injective: bucket entries carry the full k-mer.
 __host__ __device__ __forceinline__ uint32_t mmhash(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -56,9 +56,7 @@ __host__ __device__ __forceinline__ uint32_t mmhash(uint32_t x)
     const uint32_t a = (x & 0xFFFFFFu) * 0x9E3779u;
     const uint32_t b = (x >> 6) * 0x85EBCBu;
 #endif
-    uint32_t h = a ^ ((b << 13) | (b >> 19));
-    h ^= h >> 15;
-    return h;
+    return a ^ ((b << 13) | (b >> 19));
 }
 
 // the two cuckoo slots of a minimizer hash (minimizers are the SMALL hashes: take high product bits)
@@ -129,14 +127,24 @@ struct Ent {
 //   phase 3  lanes pull items from q3: bucket header -> candidate slot -> compare -> atomicAdd
 // ---------------------------------------------------------------------------------------------
 constexpr int Q1CAP = 1024;        // runs per tile held in LDS (mean ~450); overflow is handled inline
+// A tile is 255 x 16 start positions: all 256 lanes load 16 bases and hash the 16 m-mers that START
+// in them (every m-mer hash is computed exactly once per tile and shared through LDS); lanes 0..254
+// own 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
+constexpr int MLANES = SCAN_THREADS - 1;
+constexpr int MTILE = MLANES * PPT;
 
 struct QShared {
     uint32_t code[SCAN_THREADS + 2];
     uint16_t inv[SCAN_THREADS + 2];
     uint32_t off[SCAN_THREADS * 3];    // 16 offsets x 5 bits per lane
     uint64_t q1[Q1CAP];                // run:   minimizer hash << 32 | len << 12 | tile position
-    uint64_t q2[Q1CAP];                // found: bucket start   << 32 | len << 12 | tile position
-    uint16_t q3[TILE];                 // item:  q2 index << 5 | position inside the run
+    union {                            // hm is dead once every lane has its minimizers (barrier after phase 1)
+        uint32_t hm[SCAN_THREADS * PPT];   // hash of the m-mer starting at each position of the tile
+        struct {
+            uint64_t q2[Q1CAP];        // found: bucket start   << 32 | len << 12 | tile position
+            uint16_t q3[MTILE];        // item:  q2 index << 5 | position inside the run
+        };
+    };
     uint32_t cnt[4];                   // n1, n2, n3
 };
 
@@ -182,28 +190,46 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
     const uint32_t *mk32 = reinterpret_cast<const uint32_t *>(mkeys);
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t base = tile * (uint64_t)TILE;
-        // ---- phase 0 ---------------------------------------------------------------------------
+        const uint64_t base = tile * (uint64_t)MTILE;
+        // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
         {
             uint32_t w[4], code, inv;
             load16<ALIGNED>(bases, base + (uint64_t)t * 16, n, w);
             encode16(w, code, inv);
             S.code[t] = code;
             S.inv[t] = (uint16_t)inv;
-            if (t < 2) {
-                load16<ALIGNED>(bases, base + TILE + (uint64_t)t * 16, n, w);
+            if (t < 1) {       // halo: the k-mers of lane 254 reach into word 256
+                load16<ALIGNED>(bases, base + (uint64_t)SCAN_THREADS * 16, n, w);
                 encode16(w, code, inv);
-                S.code[SCAN_THREADS + t] = code;
-                S.inv[SCAN_THREADS + t] = (uint16_t)inv;
+                S.code[SCAN_THREADS] = code;
+                S.inv[SCAN_THREADS] = (uint16_t)inv;
             }
             if (t < 4) S.cnt[t] = 0;
         }
         __syncthreads();
 
-        // ---- phase 1: minimizers and runs ------------------------------------------------------
-        const uint32_t c0 = S.code[t], c1 = S.code[t + 1], c2 = S.code[t + 2];
-        uint32_t live;
+        // ---- phase 1a: hash the 16 m-mers that start in this lane's 16 bases ----------------------
+        uint32_t hm[PPT];
         {
+            const uint32_t c0 = S.code[t], c1 = S.code[t + 1];
+            uint32_t x = c0 & ss::M30;
+#pragma unroll
+            for (int i = 0; i < PPT; i++) {
+                hm[i] = ss::mmhash(x);
+                const int p = i + ss::MINI_M;                              // next base to enter (15..30)
+                x = (x >> 2) | ((((p < 16 ? c0 : c1) >> (2 * (p & 15))) & 3u) << 28);
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(&S.hm[t * PPT]);
+            dst[0] = make_uint4(hm[0], hm[1], hm[2], hm[3]);
+            dst[1] = make_uint4(hm[4], hm[5], hm[6], hm[7]);
+            dst[2] = make_uint4(hm[8], hm[9], hm[10], hm[11]);
+            dst[3] = make_uint4(hm[12], hm[13], hm[14], hm[15]);
+        }
+        __syncthreads();
+
+        // ---- phase 1b: minimizer (hash, leftmost offset) of the lane's 16 k-mers, runs ------------
+        uint32_t live = 0;
+        if (t < MLANES) {
             uint64_t x = (uint64_t)S.inv[t] | ((uint64_t)S.inv[t + 1] << 16) | ((uint64_t)S.inv[t + 2] << 32);
             x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 15;   // any invalid base in [j, j+31)
             live = ~(uint32_t)x & 0xFFFFu;
@@ -211,36 +237,30 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         uint32_t need = 0;
         uint32_t mh[PPT];
         if (live) {
-            // k-mer j covers m-mers j..j+16.  Split at m-mer 16/17: suffix minima over m-mers j..16 are
-            // built rolling LEFT from m-mer 16, prefix minima over 17..16+j rolling RIGHT from m-mer 17.
-            // Ties go to the leftmost m-mer (the database side uses the same rule).
-            uint32_t suf_h[W], suf_i[W];
+            // k-mer j covers m-mers j..j+16 = own m-mers j..15 and the next lane's m-mers 0..j:
+            // suffix minima over the own hashes, prefix minima over the neighbour's; ties go to the
+            // leftmost m-mer (the database side uses the same rule).
+            uint32_t nx[PPT];
             {
-                uint32_t x = c1 & ss::M30;                                   // m-mer 16 = bases 16..30
-                suf_h[W - 1] = ss::mmhash(x);
-                suf_i[W - 1] = W - 1;
+                const uint4 *src = reinterpret_cast<const uint4 *>(&S.hm[(t + 1) * PPT]);
+                const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+                nx[0] = a.x; nx[1] = a.y; nx[2] = a.z; nx[3] = a.w; nx[4] = b.x; nx[5] = b.y; nx[6] = b.z; nx[7] = b.w;
+                nx[8] = c.x; nx[9] = c.y; nx[10] = c.z; nx[11] = c.w; nx[12] = d.x; nx[13] = d.y; nx[14] = d.z; nx[15] = d.w;
+            }
+            uint32_t suf_h[PPT], suf_i[PPT];
+            suf_h[PPT - 1] = hm[PPT - 1];
+            suf_i[PPT - 1] = PPT - 1;
 #pragma unroll
-                for (int i = W - 2; i >= 0; i--) {
-                    x = ((x << 2) & ss::M30) | ((c0 >> (2 * i)) & 3u);       // m-mer i: base i enters at the bottom
-                    const uint32_t h = ss::mmhash(x);
-                    const bool take = h <= suf_h[i + 1];
-                    suf_h[i] = take ? h : suf_h[i + 1];
-                    suf_i[i] = take ? (uint32_t)i : suf_i[i + 1];
-                }
+            for (int i = PPT - 2; i >= 0; i--) {
+                const bool take = hm[i] <= suf_h[i + 1];                  // i is left of everything in suf[i+1]
+                suf_h[i] = take ? hm[i] : suf_h[i + 1];
+                suf_i[i] = take ? (uint32_t)i : suf_i[i + 1];
             }
             uint32_t offw[3] = {0, 0, 0};
-            mh[0] = suf_h[0];
-            offw[0] = suf_i[0];
-            uint32_t x = ((c1 >> 2) | (c2 << 30)) & ss::M30;                 // m-mer 17 = bases 17..31
-            uint32_t pre_h = ss::mmhash(x), pre_i = W;
+            uint32_t pre_h = nx[0], pre_i = PPT;
 #pragma unroll
-            for (int j = 1; j < PPT; j++) {
-                if (j > 1) {
-                    const int p = W - 1 + j + ss::MINI_M - 1;                // last base of m-mer 16+j (32..45)
-                    x = (x >> 2) | (((c2 >> (2 * (p - 32))) & 3u) << 28);
-                    const uint32_t h = ss::mmhash(x);
-                    if (h < pre_h) { pre_h = h; pre_i = (uint32_t)(W - 1 + j); }
-                }
+            for (int j = 0; j < PPT; j++) {
+                if (j > 0 && nx[j] < pre_h) { pre_h = nx[j]; pre_i = (uint32_t)(PPT + j); }
                 const bool take_pre = pre_h < suf_h[j];
                 mh[j] = take_pre ? pre_h : suf_h[j];
                 const uint32_t o = (take_pre ? pre_i : suf_i[j]) - (uint32_t)j;
@@ -249,12 +269,12 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             S.off[t * 3] = offw[0];
             S.off[t * 3 + 1] = offw[1];
             S.off[t * 3 + 2] = offw[2];
+            // run starts as a bit mask, in vector arithmetic (no per-position lane-mask logic):
+            // position j starts a run if it is live and (j == 0, or j-1 is not live, or the minimizer changed)
+            uint32_t chg = 1u;
 #pragma unroll
-            for (int j = 0; j < PPT; j++) {
-                const bool lv = (live >> j) & 1u;
-                const bool first = (j == 0) || !((live >> (j - 1)) & 1u) || (mh[j] != mh[j > 0 ? j - 1 : 0]);
-                if (lv && first) need |= 1u << j;
-            }
+            for (int j = 1; j < PPT; j++) chg |= min(mh[j] ^ mh[j - 1], 1u) << j;
+            need = live & (chg | (~live << 1));
         }
         // wave prefix sum of the run counts, one LDS atomic per wave, predicated queue writes
         uint32_t ovf = 0;   // runs that did not fit q1 (processed inline below)
@@ -559,7 +579,8 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
-    if (bpc > 0) blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)bpc * 256);
+    n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 255 x 16 positions
+    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 8) * 256);
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
     case 1: launch_lb<1>(aligned, blocks, stream, b, n, n_tiles, db); break;
