@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string.h>
 
 #include "strainscan_hip.h"
@@ -78,12 +79,16 @@ struct ss_db {
     uint64_t stage_bytes = 0;
     hipStream_t streams[2] = {nullptr, nullptr};
     hipEvent_t stage_free[2] = {nullptr, nullptr};
-    uint64_t launches = 0;
+    std::atomic<uint64_t> launches{0};
+    // per-worker resources of the parallel ingest path (allocated on first use, kept for the handle's life)
+    struct Worker { char *h_buf = nullptr; char *d_buf = nullptr; hipStream_t stream = nullptr; uint64_t cap = 0; };
+    Worker workers[32];
     uint64_t device_bytes = 0;
 };
 
 namespace ss {
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
+int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles);
 }  // namespace ss

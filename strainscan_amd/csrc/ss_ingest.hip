@@ -1,0 +1,170 @@
+// ss_ingest.hip -- multi-threaded FASTA/FASTQ ingest feeding the scan.
+//
+// The reference hands the read files to `jellyfish count -t 8` (library/identify.py:82-86), which
+// parses them with its own threads.  Here a plain (uncompressed) file is mmap'ed and cut into
+// chunks at RECORD boundaries found from arbitrary byte offsets:
+//   FASTA : a line starting with '>' (sequence lines cannot start with '>')
+//   FASTQ : a line starting with '@' whose second-next line starts with '+' and whose next and
+//           third-next lines have equal length (a quality line may start with '@' or '+', but
+//           then the line two below it is a header or a sequence, never a '+' line of that shape)
+// Worker threads turn their chunk into a flat base block (same grammar as ss_fastx_to_flat) in a
+// pinned buffer and enqueue H2D copy + scan kernel on their own HIP stream, so parsing, PCIe
+// copies and kernels of different chunks overlap.  Counting is order independent (integer
+// atomics), so the result equals the sequential path bit for bit.  Anything else (gzip input,
+// multi-line FASTQ, files the boundary rule cannot segment) takes the sequential reader.
+#include "ss_common.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint64_t CHUNK = 24ull << 20;   // bytes of text per work item
+
+struct Line { uint64_t s, e; };   // [s, e) without the '\n'; s == npos when absent
+
+inline bool next_line(const char *t, uint64_t n, uint64_t pos, Line &ln)
+{
+    if (pos >= n) return false;
+    const void *nl = memchr(t + pos, '\n', n - pos);
+    ln.s = pos;
+    ln.e = nl ? (uint64_t)((const char *)nl - t) : n;
+    return true;
+}
+
+// first record start at or after `from` (from must be 0 or follow a '\n' search), or n
+uint64_t sync_record(const char *t, uint64_t n, uint64_t from, bool fastq)
+{
+    uint64_t pos = from;
+    if (pos > 0) {   // move to the start of the next line
+        const void *nl = memchr(t + pos - 1, '\n', n - pos + 1);
+        if (!nl) return n;
+        pos = (uint64_t)((const char *)nl - t) + 1;
+    }
+    while (pos < n) {
+        Line l0;
+        if (!next_line(t, n, pos, l0)) return n;
+        if (!fastq) {
+            if (t[pos] == '>') return pos;
+        } else if (t[pos] == '@') {
+            Line l1, l2, l3;
+            if (next_line(t, n, l0.e + 1, l1) && next_line(t, n, l1.e + 1, l2) && l2.e > l2.s && t[l2.s] == '+' &&
+                next_line(t, n, l2.e + 1, l3) && (l3.e - l3.s) == (l1.e - l1.s))
+                return pos;
+        }
+        pos = l0.e + 1;
+    }
+    return n;
+}
+
+// the head of the file must be plain 4-line FASTQ (or FASTA) for the chunked path
+bool head_is_simple(const char *t, uint64_t n, bool &fastq)
+{
+    if (n == 0) return false;
+    if (t[0] == '>') { fastq = false; return true; }
+    if (t[0] != '@') return false;
+    fastq = true;
+    uint64_t pos = 0;
+    for (int r = 0; r < 256 && pos < n; r++) {
+        Line h, s, p, q;
+        if (!next_line(t, n, pos, h) || t[h.s] != '@') return false;
+        if (!next_line(t, n, h.e + 1, s) || !next_line(t, n, s.e + 1, p) || p.e == p.s || t[p.s] != '+') return false;
+        if (!next_line(t, n, p.e + 1, q) || (q.e - q.s) != (s.e - s.s)) return false;
+        pos = q.e + 1;
+    }
+    return true;
+}
+
+}  // namespace
+
+namespace ss {
+
+// returns SS_OK and *handled = true when the file was scanned here; *handled = false => caller
+// must use the sequential reader for this file
+int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled)
+{
+    *handled = false;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return SS_EIO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < (off_t)(4 << 20)) { close(fd); return SS_OK; }
+    const uint64_t n = (uint64_t)st.st_size;
+    const char *t = (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (t == MAP_FAILED) return SS_OK;
+    bool fastq = true;
+    if ((unsigned char)t[0] == 0x1f || !head_is_simple(t, n, fastq)) { munmap((void *)t, n); return SS_OK; }
+    madvise((void *)t, n, MADV_SEQUENTIAL);
+
+    // chunk starts at record boundaries
+    std::vector<uint64_t> starts;
+    starts.push_back(0);
+    for (uint64_t off = CHUNK; off < n; off += CHUNK) {
+        const uint64_t s = sync_record(t, n, off, fastq);
+        if (s >= n) break;
+        if (s > starts.back()) starts.push_back(s);
+    }
+    starts.push_back(n);
+    const size_t n_chunks = starts.size() - 1;
+    uint64_t max_chunk = 0;
+    for (size_t c = 0; c < n_chunks; c++) max_chunk = std::max(max_chunk, starts[c + 1] - starts[c]);
+    if (max_chunk > 8 * CHUNK) { munmap((void *)t, n); return SS_OK; }   // a giant record: sequential path
+
+    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 24u);
+    nthreads = (unsigned)std::min<size_t>(nthreads, n_chunks);
+    std::atomic<size_t> next(0);
+    std::atomic<uint64_t> recs(0), bases(0);
+    std::atomic<int> err(SS_OK);
+    int device = 0;
+    hipGetDevice(&device);
+    auto worker = [&](unsigned wid) {
+        hipSetDevice(device);
+        ss_db::Worker &W = db->workers[wid];
+        if (W.cap < max_chunk + 64) {            // first use (or a larger chunk than ever before)
+            if (W.h_buf) hipHostFree(W.h_buf);
+            if (W.d_buf) hipFree(W.d_buf);
+            W.h_buf = W.d_buf = nullptr;
+            W.cap = 0;
+            const uint64_t cap = std::max<uint64_t>(max_chunk + 64, CHUNK + CHUNK / 8);
+            if (hipHostMalloc((void **)&W.h_buf, cap, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc((void **)&W.d_buf, cap) != hipSuccess)
+                err = SS_ENOMEM;
+            else
+                W.cap = cap;
+        }
+        if (!W.stream && hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking) != hipSuccess) err = SS_EHIP;
+        char *h_buf = W.h_buf, *d_buf = W.d_buf;
+        hipStream_t stream = W.stream;
+        for (size_t c; err == SS_OK && (c = next.fetch_add(1)) < n_chunks;) {
+            uint64_t out_len = 0, nr = 0;
+            int rc = ss_fastx_to_flat(t + starts[c], starts[c + 1] - starts[c], h_buf, &out_len, &nr);
+            if (rc != SS_OK) { err = rc; break; }
+            if (hipMemcpyAsync(d_buf, h_buf, out_len, hipMemcpyHostToDevice, stream) != hipSuccess) { err = SS_EHIP; break; }
+            rc = ss_scan_flat_dev(db, d_buf, out_len, stream);
+            if (rc != SS_OK) { err = rc; break; }
+            if (hipStreamSynchronize(stream) != hipSuccess) { err = SS_EHIP; break; }   // buffers are reused
+            recs += nr;
+            bases += out_len;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
+    for (auto &th : pool) th.join();
+    munmap((void *)t, n);
+    if (err != SS_OK) return err;
+    *n_records += recs;
+    *n_bases += bases;
+    *handled = true;
+    return SS_OK;
+}
+
+}  // namespace ss

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
     const uint64_t *__restrict__ dir, uint32_t n_dir, uint32_t *__restrict__ counts)
 {
-    constexpr int K = 31, W = K - ss::MINI_M + 1;   // 17 m-mers per k-mer
+    constexpr int K = 31;                            // 17 m-mers of length 15 per k-mer
+    static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
     const int t = threadIdx.x;
     const int lane = t & 63;

@@ -289,6 +289,11 @@ int ss_db_destroy(ss_db *db)
     hipFree(db->d_counts);
     hipFree(db->d_slot_of_row);
     hipFree(db->d_row_valid);
+    for (auto &w : db->workers) {
+        if (w.h_buf) hipHostFree(w.h_buf);
+        if (w.d_buf) hipFree(w.d_buf);
+        if (w.stream) hipStreamDestroy(w.stream);
+    }
     for (int i = 0; i < 2; i++) {
         if (db->h_stage[i]) hipHostFree(db->h_stage[i]);
         if (db->d_stage[i]) hipFree(db->d_stage[i]);
@@ -318,7 +323,7 @@ int ss_db_row_valid(const ss_db *db, uint8_t *row_valid)
 
 const uint8_t *ss_db_row_valid_dev(const ss_db *db) { return db ? db->d_row_valid : nullptr; }
 uint64_t ss_db_device_bytes(const ss_db *db) { return db ? db->device_bytes : 0; }
-uint64_t ss_scan_kernel_launches(const ss_db *db) { return db ? db->launches : 0; }
+uint64_t ss_scan_kernel_launches(const ss_db *db) { return db ? db->launches.load() : (uint64_t)0; }
 
 int ss_scan_reset(ss_db *db, void *stream)
 {
@@ -380,9 +385,9 @@ int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n)
     return SS_OK;
 }
 
-int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records, uint64_t *n_bases)
+static int scan_files_sequential(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records,
+                                 uint64_t *n_bases)
 {
-    if (!db || !paths || n_paths < 1) return SS_EINVAL;
     int rc = ensure_staging(db);
     if (rc) return rc;
     ss_reader *rd = nullptr;
@@ -414,6 +419,30 @@ int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_
     ss_reader_close(rd);
     for (int i = 0; i < 2; i++)
         if (used[i]) SS_HIP(hipStreamSynchronize(db->streams[i]));
+    *n_records += recs;
+    *n_bases += total;
+    return SS_OK;
+}
+
+int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records, uint64_t *n_bases)
+{
+    if (!db || !paths || n_paths < 1) return SS_EINVAL;
+    uint64_t recs = 0, total = 0;
+    const char *seq_env = getenv("SS_INGEST");
+    const bool allow_parallel = !(seq_env && !strcmp(seq_env, "sequential"));
+    for (int i = 0; i < n_paths; i++) {
+        if (!paths[i]) return SS_EINVAL;
+        if (!paths[i][0]) continue;            // '' = no second file (StrainScan.py:182)
+        bool handled = false;
+        if (allow_parallel) {
+            int rc = ss::scan_file_parallel(db, paths[i], &recs, &total, &handled);
+            if (rc) return rc;
+        }
+        if (!handled) {
+            int rc = scan_files_sequential(db, &paths[i], 1, &recs, &total);
+            if (rc) return rc;
+        }
+    }
     if (n_records) *n_records = recs;
     if (n_bases) *n_bases = total;
     return SS_OK;

@@ -207,3 +207,35 @@ def test_shard_linearity_large(L):
     fwd = full[0::2]
     ok = valid[0::2] == 1
     assert np.array_equal(fwd[ok], cov[ok]) or (np.abs(fwd[ok] - cov[ok]).sum() < 10)
+
+
+def test_parallel_ingest_equals_sequential(L, tmp_path):
+    """Files above 4 MB take the mmap + worker-thread path (record-boundary sync from arbitrary
+    offsets): counts must equal the sequential reader's, for FASTQ (incl. '@'/'+' quality lines)
+    and FASTA, and a multi-line FASTQ must fall back transparently."""
+    rs = np.random.RandomState(17)
+    kfa, flat = _random_db_and_reads(23, 60000, 60000)
+    seqs = [r for r in flat.split(b"\n") if r]
+    quals = [bytes(rs.choice(np.frombuffer(b"@+IA#5", np.uint8), size=len(r))) for r in seqs]
+    fq = b"".join(b"@r%d x\n%s\n+\n%s\n" % (i, r, q) for i, (r, q) in enumerate(zip(seqs, quals)))
+    fq = fq * 12                                       # ~ 110 MB: several 24 MB chunks
+    fa = b"".join(b">s%d\n%s\n" % (i, r) for i, r in enumerate(seqs)) * 12
+    ml = b"".join(b"@m%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:40], r[40:], q[:40], q[40:])
+                  for i, (r, q) in enumerate(zip(seqs, quals)) if len(r) > 80) * 12
+    for name, blob in (("a.fq", fq), ("b.fa", fa), ("c_multiline.fq", ml)):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        db = L.KmerDB.from_text(kfa, 31, True)
+        os.environ["SS_INGEST"] = "sequential"
+        try:
+            nrec_s, nb_s = db.scan_files([str(p)])
+        finally:
+            del os.environ["SS_INGEST"]
+        want = db.counts_rows().copy()
+        db.reset()
+        nrec_p, nb_p = db.scan_files([str(p)])
+        assert nrec_p == nrec_s, name
+        assert abs(nb_p - nb_s) <= 30 * 8, name      # the sequential reader re-emits k-1 bases per cut record
+        assert np.array_equal(db.counts_rows(), want), name
+        assert want.sum() > 0
+        db.close()
