@@ -122,6 +122,20 @@ int ss_counts_load_rows_dev(ss_db *db, const uint32_t *counts_rows_dev, void *st
 uint64_t ss_scan_kernel_launches(const ss_db *db);
 
 /* --------------------------------------------------------------------------------------------
+ * Resident read sets.  The reference re-reads the FASTQ for the tree scan, for every identified
+ * multi-strain cluster and twice more with -b (identify.py:409; Vote_Strain_L2_Lasso_new_sp.py:
+ * 354-372; identify_low_depth.py:119,124).  ss_reads_load parses the files ONCE (worker threads
+ * for plain files) and keeps the flat base blocks in HBM; ss_scan_reads scans them against any
+ * database image.  shard_rank / shard_world: keep every shard_world-th block (multi-GPU).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ss_reads ss_reads;
+int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int shard_world, ss_reads **out);
+int ss_reads_destroy(ss_reads *r);
+int ss_reads_info(const ss_reads *r, uint64_t *n_records, uint64_t *n_bases, uint64_t *n_blocks,
+                  uint64_t *device_bytes);
+int ss_scan_reads(ss_db *db, const ss_reads *r, void *stream);
+
+/* --------------------------------------------------------------------------------------------
  * Host FASTA/FASTQ -> flat base block (what jellyfish's sequence parser feeds its counter).
  * out must hold at least len + 2 bytes.  Used by ss_scan_files and exposed for callers that
  * shard reads themselves (multi-GPU).

@@ -124,11 +124,9 @@ def cluster_counts(input_fq, fq2, cls_db_dir, ksize):
     (Build_kmer_sets_unique_region_lasso_test_allinone_sp.py:397-399,409-410)."""
     db = _lib.KmerDB.from_fasta(os.path.join(cls_db_dir, "all_kmer.fasta"), int(ksize), upper_keys=2)
     try:
-        from . import dist
-        if dist.is_distributed():
-            dist.scan_files_sharded(db, [input_fq, fq2])
-        else:
-            db.scan_files([p for p in (input_fq, fq2) if p])
+        from .db import scan_into
+        scan_into(db, [input_fq, fq2])       # resident reads: no second parse, no second PCIe trip
+        _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")
         return db.counts_rows()
     finally:
         db.close()

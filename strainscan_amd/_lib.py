@@ -73,6 +73,10 @@ SIGNATURES = {
     "ss_counts_rows": (i32, [vp, vp]),
     "ss_counts_load_rows_dev": (i32, [vp, vp, vp]),
     "ss_scan_kernel_launches": (u64, [vp]),
+    "ss_reads_load": (i32, [P(cp), i32, i32, i32, P(vp)]),
+    "ss_reads_destroy": (i32, [vp]),
+    "ss_reads_info": (i32, [vp, P(u64), P(u64), P(u64), P(u64)]),
+    "ss_scan_reads": (i32, [vp, vp, vp]),
     "ss_fastx_to_flat": (i32, [cp, u64, vp, P(u64), P(u64)]),
     "ss_reader_open": (i32, [P(cp), i32, P(vp)]),
     "ss_reader_set_overlap": (i32, [vp, i32]),
@@ -252,6 +256,37 @@ class KmerDB:
 
     def counts_rows_dev(self, dptr, stream=None):
         check(lib().ss_counts_rows_dev(self._h, dptr, stream), "ss_counts_rows_dev")
+
+
+class ReadSet:
+    """FASTA/FASTQ(.gz) files parsed once and kept in HBM as flat base blocks."""
+
+    def __init__(self, paths, shard_rank=0, shard_world=1):
+        require_gpu()
+        ps = [os.fsencode(p) for p in paths if p]
+        arr = (C.c_char_p * len(ps))(*ps)
+        h = C.c_void_p()
+        check(lib().ss_reads_load(arr, len(ps), int(shard_rank), int(shard_world), C.byref(h)), "ss_reads_load")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ss_reads_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().ss_reads_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "ss_reads_info")
+        return dict(n_records=a.value, n_bases=b.value, n_blocks=c.value, device_bytes=d.value)
+
+    def scan_into(self, kdb, stream=None):
+        check(lib().ss_scan_reads(kdb.handle, self._h, stream), "ss_scan_reads")
 
 
 class NodeSet:

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <atomic>
+#include <functional>
 #include <string.h>
 
 #include "strainscan_hip.h"
@@ -83,11 +84,15 @@ struct ss_db {
     // per-worker resources of the parallel ingest path (allocated on first use, kept for the handle's life)
     struct Worker { char *h_buf = nullptr; char *d_buf = nullptr; hipStream_t stream = nullptr; uint64_t cap = 0; };
     Worker workers[32];
+    static void free_workers(Worker *w, int n);
     uint64_t device_bytes = 0;
 };
 
 namespace ss {
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
+using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
+int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
+                        uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink);
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles);

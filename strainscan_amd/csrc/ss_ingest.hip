@@ -92,6 +92,18 @@ namespace ss {
 // must use the sequential reader for this file
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled)
 {
+    return parse_file_parallel(db->workers, path, 0, 1, n_records, n_bases, handled,
+                               [db](const char *, char *d_buf, uint64_t len, hipStream_t stream) {
+                                   return ss_scan_flat_dev(db, d_buf, len, stream);
+                               });
+}
+
+// Parse `path` with worker threads; each flat block (already copied to the worker's device buffer
+// on `stream`) is handed to `sink`.  Chunks c with c % shard_world != shard_rank are skipped
+// (multi-GPU read sharding without parsing the other ranks' share).
+int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
+                        uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink)
+{
     *handled = false;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return SS_EIO;
@@ -128,7 +140,7 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
     hipGetDevice(&device);
     auto worker = [&](unsigned wid) {
         hipSetDevice(device);
-        ss_db::Worker &W = db->workers[wid];
+        ss_db::Worker &W = workers[wid];
         if (W.cap < max_chunk + 64) {            // first use (or a larger chunk than ever before)
             if (W.h_buf) hipHostFree(W.h_buf);
             if (W.d_buf) hipFree(W.d_buf);
@@ -145,11 +157,12 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
         char *h_buf = W.h_buf, *d_buf = W.d_buf;
         hipStream_t stream = W.stream;
         for (size_t c; err == SS_OK && (c = next.fetch_add(1)) < n_chunks;) {
+            if ((int)(c % (size_t)shard_world) != shard_rank) continue;
             uint64_t out_len = 0, nr = 0;
             int rc = ss_fastx_to_flat(t + starts[c], starts[c + 1] - starts[c], h_buf, &out_len, &nr);
             if (rc != SS_OK) { err = rc; break; }
             if (hipMemcpyAsync(d_buf, h_buf, out_len, hipMemcpyHostToDevice, stream) != hipSuccess) { err = SS_EHIP; break; }
-            rc = ss_scan_flat_dev(db, d_buf, out_len, stream);
+            rc = sink(h_buf, d_buf, out_len, stream);
             if (rc != SS_OK) { err = rc; break; }
             if (hipStreamSynchronize(stream) != hipSuccess) { err = SS_EHIP; break; }   // buffers are reused
             recs += nr;
@@ -168,3 +181,122 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
 }
 
 }  // namespace ss
+
+void ss_db::free_workers(Worker *w, int n)
+{
+    for (int i = 0; i < n; i++) {
+        if (w[i].h_buf) hipHostFree(w[i].h_buf);
+        if (w[i].d_buf) hipFree(w[i].d_buf);
+        if (w[i].stream) hipStreamDestroy(w[i].stream);
+        w[i] = Worker();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ss_reads: a read set parsed once and kept in HBM as flat base blocks.
+// The reference re-reads (and jellyfish re-parses) the whole FASTQ for the tree scan, for every
+// identified multi-strain cluster and twice more with -b (identify.py:409, Vote_...:354-372,
+// identify_low_depth.py:119,124).  With 288 GB of HBM the 2-byte-per-base text is parsed and
+// shipped over PCIe once; every later scan is a 10 ms kernel over resident blocks.
+// ---------------------------------------------------------------------------------------------
+struct ss_reads {
+    struct Block { char *d = nullptr; uint64_t len = 0; };
+    std::vector<Block> blocks;
+    std::mutex mu;
+    uint64_t n_records = 0, n_bases = 0, device_bytes = 0;
+    bool has_cut_record = false;      // a record longer than a block was cut with a 30-base overlap (k = 31 only)
+    ss_db::Worker workers[32];
+};
+
+extern "C" {
+
+int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int shard_world, ss_reads **out)
+{
+    if (!paths || n_paths < 1 || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return SS_EINVAL;
+    ss_reads *R = new (std::nothrow) ss_reads();
+    if (!R) return SS_ENOMEM;
+    uint64_t recs = 0, bases = 0;
+    auto keep = [R](const char *, char *d_buf, uint64_t len, hipStream_t stream) -> int {
+        ss_reads::Block b;
+        if (hipMalloc((void **)&b.d, std::max<uint64_t>(16, len)) != hipSuccess) return SS_ENOMEM;
+        b.len = len;
+        if (hipMemcpyAsync(b.d, d_buf, len, hipMemcpyDeviceToDevice, stream) != hipSuccess) { hipFree(b.d); return SS_EHIP; }
+        std::lock_guard<std::mutex> g(R->mu);
+        R->blocks.push_back(b);
+        R->device_bytes += len;
+        return SS_OK;
+    };
+    int rc = SS_OK;
+    uint64_t seq_block = 0;
+    for (int i = 0; i < n_paths && rc == SS_OK; i++) {
+        if (!paths[i]) { rc = SS_EINVAL; break; }
+        if (!paths[i][0]) continue;
+        bool handled = false;
+        rc = ss::parse_file_parallel(R->workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep);
+        if (rc != SS_OK || handled) continue;
+        // sequential reader (gzip, multi-line records, small files): blocks round-robin over the ranks
+        ss_reader *rd = nullptr;
+        rc = ss_reader_open(&paths[i], 1, &rd);
+        if (rc) break;
+        ss_reader_set_overlap(rd, 30);
+        const uint64_t cap = 32ull << 20;
+        std::vector<char> buf(cap);
+        for (;;) {
+            uint64_t len = 0, nr = 0;
+            rc = ss_reader_next(rd, buf.data(), cap, &len, &nr);
+            if (rc || len == 0) break;
+            if (buf[len - 1] != '\n') R->has_cut_record = true;
+            if ((int)(seq_block++ % (uint64_t)shard_world) != shard_rank) continue;
+            ss_reads::Block b;
+            if (hipMalloc((void **)&b.d, std::max<uint64_t>(16, len)) != hipSuccess) { rc = SS_ENOMEM; break; }
+            b.len = len;
+            if (hipMemcpy(b.d, buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) { hipFree(b.d); rc = SS_EHIP; break; }
+            R->blocks.push_back(b);
+            R->device_bytes += len;
+            recs += nr;
+            bases += len;
+        }
+        ss_reader_close(rd);
+    }
+    ss_db::free_workers(R->workers, 32);
+    if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
+    if (hipDeviceSynchronize() != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
+    R->n_records = recs;
+    R->n_bases = bases;
+    *out = R;
+    return SS_OK;
+}
+
+int ss_reads_destroy(ss_reads *R)
+{
+    if (!R) return SS_OK;
+    for (auto &b : R->blocks) hipFree(b.d);
+    ss_db::free_workers(R->workers, 32);
+    delete R;
+    return SS_OK;
+}
+
+int ss_reads_info(const ss_reads *R, uint64_t *n_records, uint64_t *n_bases, uint64_t *n_blocks, uint64_t *device_bytes)
+{
+    if (!R) return SS_EINVAL;
+    if (n_records) *n_records = R->n_records;
+    if (n_bases) *n_bases = R->n_bases;
+    if (n_blocks) *n_blocks = R->blocks.size();
+    if (device_bytes) *device_bytes = R->device_bytes;
+    return SS_OK;
+}
+
+int ss_scan_reads(ss_db *db, const ss_reads *R, void *stream)
+{
+    if (!db || !R) return SS_EINVAL;
+    int k = 0;
+    ss_db_info(db, nullptr, nullptr, nullptr, &k);
+    if (R->has_cut_record && k != 31) return SS_ERANGE;   // cut records carry a 30-base overlap
+    for (const auto &b : R->blocks) {
+        int rc = ss_scan_flat_dev(db, b.d, b.len, stream);
+        if (rc) return rc;
+    }
+    return SS_OK;
+}
+
+}  // extern "C"

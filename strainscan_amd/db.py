@@ -55,6 +55,51 @@ class CountsView:
         return int(self.counts[row]) if row in self else default
 
 
+_READS = {}          # one resident read set at a time: key -> _lib.ReadSet
+RESIDENT_LIMIT_BYTES = int(float(os.environ.get("SS_READS_RESIDENT_GB", "160")) * 1e9)
+
+
+def _reads_key(paths, rank, world):
+    return tuple((os.path.abspath(p), os.path.getmtime(p), os.path.getsize(p)) for p in paths if p) + (rank, world)
+
+
+def resident_reads(paths):
+    """The sample's reads as flat base blocks in HBM (parsed and copied over PCIe once), or None
+    when they would not fit the budget (then every scan streams the files again).  Under
+    torch.distributed each rank keeps only its shard of the blocks."""
+    from . import dist
+    rank, world = dist.rank_world()
+    total = sum(os.path.getsize(p) for p in paths if p)
+    gz = any(str(p).endswith(".gz") for p in paths if p)
+    if (total * (4 if gz else 1)) / world > RESIDENT_LIMIT_BYTES or RESIDENT_LIMIT_BYTES <= 0:
+        return None
+    key = _reads_key(paths, rank, world)
+    rs = _READS.get(key)
+    if rs is None:
+        for old in _READS.values():
+            old.close()
+        _READS.clear()
+        rs = _lib.ReadSet([p for p in paths if p], rank, world)
+        _READS[key] = rs
+    return rs
+
+
+def scan_into(kdb, paths):
+    """Count kdb's k-mers in the reads of `paths`: resident blocks when possible, streaming
+    otherwise; under torch.distributed the per-rank counts are all-reduced (RCCL) and loaded back."""
+    from . import dist
+    kdb.reset()
+    rs = resident_reads(paths)
+    if rs is not None:
+        rs.scan_into(kdb)
+        if dist.is_distributed():
+            dist.allreduce_table(kdb)
+    elif dist.is_distributed():
+        dist.scan_files_sharded(kdb, paths)
+    else:
+        kdb.scan_files([p for p in paths if p])
+
+
 class TreeImage:
     def __init__(self, db_dir, upper_keys=True):
         self.db_dir = db_dir
@@ -85,12 +130,7 @@ class TreeImage:
         key = tuple((os.path.abspath(p), os.path.getmtime(p), os.path.getsize(p)) for p in paths if p)
         if self._scanned == key:
             return
-        from . import dist
-        if dist.is_distributed():
-            dist.scan_files_sharded(self.kdb, paths)     # shard reads, RCCL all-reduce of row counts
-        else:
-            self.kdb.reset()
-            self.kdb.scan_files([p for p in paths if p])
+        scan_into(self.kdb, paths)
         self._scanned = key
         self._counts = None
         self._stats = None
@@ -145,3 +185,6 @@ def tree_image(db_dir, upper_keys=True):
 
 def clear_cache():
     _CACHE.clear()
+    for rs in _READS.values():
+        rs.close()
+    _READS.clear()

@@ -54,11 +54,22 @@ def allreduce_counts(t, group=None):
     return t
 
 
+def allreduce_table(kdb):
+    """Sum the per-rank hit counts of `kdb` over all ranks and load the global vector back."""
+    import torch
+    t = torch.empty(kdb.n_rows, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")
+    kdb.counts_rows_dev(t.data_ptr(), stream)
+    allreduce_counts(t)
+    kdb.load_counts_rows_dev(t.data_ptr(), stream)
+    torch.cuda.synchronize()
+
+
 def scan_files_sharded(kdb, paths, cap=32 << 20):
     """Scan this rank's share of the reads into `kdb`, all-reduce, load the global counts back.
     Every rank parses the input (the flat-block reader is deterministic) and keeps blocks
     i % world == rank.  Returns (n_records, n_bases) of the whole input."""
-    import torch
     rank, world = rank_world()
     kdb.reset()
     nrec = nb = 0
@@ -69,13 +80,7 @@ def scan_files_sharded(kdb, paths, cap=32 << 20):
         if i % world == rank:
             kdb.scan_flat(blk)
     if world > 1:
-        t = torch.empty(kdb.n_rows, dtype=torch.int32, device="cuda")
-        stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")
-        kdb.counts_rows_dev(t.data_ptr(), stream)
-        allreduce_counts(t)
-        kdb.load_counts_rows_dev(t.data_ptr(), stream)
-        torch.cuda.synchronize()
+        allreduce_table(kdb)
     return nrec, nb
 
 

@@ -239,3 +239,39 @@ def test_parallel_ingest_equals_sequential(L, tmp_path):
         assert np.array_equal(db.counts_rows(), want), name
         assert want.sum() > 0
         db.close()
+
+
+def test_resident_read_set_and_shards(L, tmp_path):
+    """ss_reads: parse once, scan many; the blocks of shard r/w are disjoint and cover the input
+    (what every rank holds in a multi-GPU run), for the worker-thread path and for the gz reader."""
+    import gzip
+    kfa, flat = _random_db_and_reads(31, 60000, 50000)
+    seqs = [r for r in flat.split(b"\n") if r]
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(seqs)) * 10
+    p1 = tmp_path / "big.fq"
+    p1.write_bytes(fq)
+    p2 = tmp_path / "small.fq.gz"
+    with gzip.open(p2, "wb") as f:
+        f.write(fq[: len(fq) // 10])
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_files([str(p1), str(p2)])
+    want = db.counts_rows().astype(np.int64)
+    rs = L.ReadSet([str(p1), str(p2)])
+    info = rs.info()
+    assert info["n_records"] == 11 * len(seqs) and info["n_blocks"] >= 2
+    for _ in range(2):                         # scan twice from HBM: same counts each time
+        db.reset()
+        rs.scan_into(db)
+        assert np.array_equal(db.counts_rows().astype(np.int64), want)
+    rs.close()
+    tot = np.zeros_like(want)
+    nrec = 0
+    for r in range(3):
+        part = L.ReadSet([str(p1), str(p2)], r, 3)
+        nrec += part.info()["n_records"]
+        db.reset()
+        part.scan_into(db)
+        tot += db.counts_rows().astype(np.int64)
+        part.close()
+    assert nrec == 11 * len(seqs)
+    assert np.array_equal(tot, want)
