@@ -114,3 +114,40 @@ def _cmp_report(got, want, float_cols):
                 assert abs(float(x) - float(y)) <= ABUND_TOL * max(1.0, abs(float(y))), (i, a, b)
             else:
                 assert x == y, (i, a, b)
+
+
+def test_detect_core_vs_oracle_medium():
+    """A cluster 10x the golden cases (K = 150k k-mers, S = 24 strains, three present): pre-scan
+    quantities bit-exact against the pinned oracle, abundances within 1e-5."""
+    import scipy.sparse as sp
+    from oracle import oracle as orc
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    rs = np.random.RandomState(11)
+    K, S, G = 150_000, 24, 40
+    pres = rs.random_sample((S, G)) < 0.4
+    seg = rs.randint(0, G, size=K)
+    Xd = pres[:, seg].T.astype(np.int8)
+    lam = pres[2, seg] * 25.0 + pres[9, seg] * 9.0 + pres[17, seg] * 4.0
+    y = rs.poisson(lam).astype(np.int64)
+    y[y == 1] = 0
+    O = np.zeros((K, 3), np.int8)
+    O[:, 0] = 1
+    O[rs.random_sample(K) < 0.1, 2] = 1                 # k-mers shared with another identified cluster
+    ids = ["T%02d" % i for i in range(S)]
+    npp = float(np.median(y[y != 0]) * 1000)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res, res2, scov, sval, fsrc = m.detect_core(sp.csr_matrix(Xd), sp.csr_matrix(O), ids, y.copy(), 31, 0, npp,
+                                                    npp, 0.9, [1, 3], 0, 40, 0, 0)
+    ln = O[:, [0, 2]].sum(axis=1)
+    ln[ln > 1] = 0
+    cols, names, oscov, osval, ofsrc, depth = orc.prescan(Xd, y, y * ln, ids, 40 * 31, 0, 0, 0)
+    assert list(scov.keys()) == names
+    assert {k: list(v) for k, v in scov.items()} == oscov
+    assert {k: float(v) for k, v in sval.items()} == {k: float(v) for k, v in osval.items()}
+    keep = (y >= 0) & (y <= npp)
+    al, mse = orc.enet_cv(Xd[keep][:, cols], y[keep])
+    a, _, _ = orc.lasso_mpm(al, mse)
+    coef = orc.enet_fit(Xd[keep][:, cols], y[keep], a)
+    assert len(names) >= 2
+    for nm, c in zip(names, coef / coef.sum()):
+        assert abs(float(res[nm]) - c) <= ABUND_TOL
