@@ -141,7 +141,7 @@ struct QShared {
     union {                            // hm is dead once every lane has its minimizers (barrier after phase 1)
         uint32_t hm[SCAN_THREADS * PPT];   // hash of the m-mer starting at each position of the tile
         struct {
-            uint64_t q2[Q1CAP];        // found: bucket start   << 32 | len << 12 | tile position
+            uint64_t q2[Q1CAP];        // found: bucket start << 32 | header (mask, multi) << 12 | tile position
             uint16_t q3[MTILE];        // item:  q2 index << 5 | position inside the run
         };
     };
@@ -156,21 +156,25 @@ __device__ __forceinline__ uint64_t kmer_at(const QShared &S, uint32_t pos, uint
     return (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & kmask;
 }
 
-// one k-mer against its bucket: header -> candidate -> compare -> count
-__device__ __forceinline__ void lookup_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t hdr,
-                                            uint64_t cand_or_0, bool have_cand, const uint64_t *__restrict__ mkeys,
-                                            uint32_t *__restrict__ counts, uint64_t kmask)
+// slot of the database k-mer that k-mer `pos` would be (0 = none: no k-mer with that minimizer offset)
+__device__ __forceinline__ uint32_t cand_slot(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t hdr)
 {
-    (void)cand_or_0; (void)have_cand;
     const uint32_t lane = pos >> 4, j = pos & 15;
     const uint32_t o = (S.off[lane * 3 + j / 6] >> (5 * (j % 6))) & 31u;
     const uint32_t mask = hdr & 0x1FFFFu;
-    if (!((mask >> o) & 1u)) return;
-    const uint32_t cpos = bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u));
+    return ((mask >> o) & 1u) ? bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u)) : 0u;
+}
+
+// compare the candidate (already loaded) with k-mer `pos`; count; fall back to a bucket scan when
+// several database k-mers share a minimizer offset (repeated / colliding minimizer)
+__device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t hdr, uint32_t cpos,
+                                            uint64_t cand, const uint64_t *__restrict__ mkeys,
+                                            uint32_t *__restrict__ counts, uint64_t kmask)
+{
     const uint64_t km = kmer_at(S, pos, kmask);
-    if (mkeys[cpos] == km) {
+    if (cand == km) {
         atomicAdd(&counts[cpos], 1u);
-    } else if (hdr & ss::HDR_MULTI) {   // several k-mers share an offset (repeated / colliding minimizer)
+    } else if (hdr & ss::HDR_MULTI) {
         const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
         for (uint32_t q = 0; q < cnt; q++)
             if (mkeys[bstart + 1 + q] == km) { atomicAdd(&counts[bstart + 1 + q], 1u); break; }
@@ -335,9 +339,10 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                     if (m0 || m1) {
                         const uint32_t bstart = (uint32_t)(m0 ? bk.x : bk.y) & ss::START_MASK;
                         const uint32_t len = ((uint32_t)e >> 12) & 31u;
+                        const uint32_t hdr = mk32[2 * (uint64_t)bstart] & 0x3FFFFu;      // offsets present + multi bit
                         const uint32_t i2 = atomicAdd(&S.cnt[1], 1u);
                         const uint32_t i3 = atomicAdd(&S.cnt[2], len);
-                        S.q2[i2] = ((uint64_t)bstart << 32) | ((uint32_t)e & 0x1FFFFu);
+                        S.q2[i2] = ((uint64_t)bstart << 32) | (hdr << 12) | ((uint32_t)e & 0xFFFu);
                         for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
                     }
                 }
@@ -346,17 +351,27 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         __syncthreads();
 
         // ---- phase 3: the k-mers whose minimizer exists in the database -------------------------
+        // four items per lane per round: all candidate loads in flight before any compare
         {
             const uint32_t n3 = S.cnt[2];
-            for (uint32_t i0 = 0; i0 < n3; i0 += 2 * SCAN_THREADS) {
-                const uint32_t ia = i0 + t, ib = i0 + SCAN_THREADS + t;
-                const bool va = ia < n3, vb = ib < n3;
-                const uint32_t ta = va ? S.q3[ia] : 0, tb = vb ? S.q3[ib] : 0;
-                const uint64_t ra = S.q2[ta >> 5], rb = S.q2[tb >> 5];
-                const uint32_t sa = va ? (uint32_t)(ra >> 32) : 0u, sb = vb ? (uint32_t)(rb >> 32) : 0u;
-                const uint32_t hda = mk32[2 * (uint64_t)sa], hdb = mk32[2 * (uint64_t)sb];   // both headers in flight
-                if (va) lookup_item(S, ((uint32_t)ra & 0xFFFu) + (ta & 31u), sa, hda, 0, false, mkeys, counts, kmask);
-                if (vb) lookup_item(S, ((uint32_t)rb & 0xFFFu) + (tb & 31u), sb, hdb, 0, false, mkeys, counts, kmask);
+            for (uint32_t i0 = 0; i0 < n3; i0 += 4 * SCAN_THREADS) {
+                uint32_t pos[4], bst[4], hdr[4], cps[4];
+                uint64_t cnd[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + u * SCAN_THREADS + t;
+                    const bool v = i < n3;
+                    const uint32_t it = v ? S.q3[i] : 0;
+                    const uint64_t r = S.q2[it >> 5];
+                    pos[u] = ((uint32_t)r & 0xFFFu) + (it & 31u);
+                    bst[u] = (uint32_t)(r >> 32);
+                    hdr[u] = ((uint32_t)r >> 12) & 0x3FFFFu;
+                    cps[u] = v ? cand_slot(S, pos[u], bst[u], hdr[u]) : 0u;
+                    cnd[u] = mkeys[cps[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (cps[u]) settle_item(S, pos[u], bst[u], hdr[u], cps[u], cnd[u], mkeys, counts, kmask);
             }
         }
         // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
@@ -378,10 +393,13 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 }
                 if (!(m0 || m1)) continue;
                 const uint32_t bstart = (uint32_t)(m0 ? bk.x : bk.y) & ss::START_MASK;
-                const uint32_t hdr = mk32[2 * (uint64_t)bstart];
+                const uint32_t hdr = mk32[2 * (uint64_t)bstart] & 0x3FFFFu;
                 const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
-                for (uint32_t q = 0; q < len; q++)
-                    lookup_item(S, (uint32_t)(t * PPT + j) + q, bstart, hdr, 0, false, mkeys, counts, kmask);
+                for (uint32_t q = 0; q < len; q++) {
+                    const uint32_t pos = (uint32_t)(t * PPT + j) + q;
+                    const uint32_t cpos = cand_slot(S, pos, bstart, hdr);
+                    if (cpos) settle_item(S, pos, bstart, hdr, cpos, mkeys[cpos], mkeys, counts, kmask);
+                }
             }
         }
         __syncthreads();   // queues and codes are rewritten by the next tile
@@ -576,7 +594,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     static int lb = -1, bpc = 0;
     if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
         const char *e = getenv("SS_MINI_LB");
-        lb = e ? atoi(e) : 4;
+        lb = e ? atoi(e) : 5;
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
@@ -586,8 +604,8 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     switch (lb) {
     case 1: launch_lb<1>(aligned, blocks, stream, b, n, n_tiles, db); break;
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    case 5: launch_lb<5>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    default: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 4: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    default: launch_lb<5>(aligned, blocks, stream, b, n, n_tiles, db); break;
     }
     SS_HIP(hipGetLastError());
     return SS_OK;
