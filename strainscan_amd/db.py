@@ -100,23 +100,70 @@ def scan_into(kdb, paths):
         kdb.scan_files([p for p in paths if p])
 
 
+def _cache_dir():
+    d = os.environ.get("SS_IMAGE_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "strainscan_amd"))
+    return None if d in ("", "0", "off") else d
+
+
+def load_tree_text(db_dir, k=L1_K):
+    """kmer.fa + kmers/<id> -> (keys u64[n], flags u8[n], node ids, node row lists in FILE order).
+    The text/directory parse (tens of millions of tokens) is done once per database: a binary
+    image (numpy arrays) is kept under SS_IMAGE_CACHE (default ~/.cache/strainscan_amd), keyed by
+    the database path, size and mtime of kmer.fa."""
+    import hashlib
+    fa = os.path.join(db_dir, "kmer.fa")
+    st = os.stat(fa)
+    kdir = os.path.join(db_dir, "kmers")
+    tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, int(st.st_mtime), k,
+                                             int(os.stat(kdir).st_mtime))).encode()).hexdigest()[:20]
+    cdir = _cache_dir()
+    path = os.path.join(cdir, "tree_%s.npz" % tag) if cdir else None
+    if path and os.path.exists(path):
+        try:
+            z = np.load(path)
+            ids = z["ids"].tolist()
+            offs = z["offsets"]
+            rows = z["rows"]
+            lists = [rows[offs[i]:offs[i + 1]] for i in range(len(ids))]
+            return z["keys"], z["flags"], ids, lists
+        except Exception:
+            pass
+    n = _lib.C.c_uint64()
+    _lib.check(_lib.lib().ss_kmerfa_count_rows(os.fsencode(fa), _lib.C.byref(n)), "ss_kmerfa_count_rows(%s)" % fa)
+    keys = np.empty(n.value, np.uint64)
+    flags = np.empty(n.value, np.uint8)
+    _lib.check(_lib.lib().ss_kmerfa_encode(os.fsencode(fa), int(k), n.value, _lib.ptr(keys), _lib.ptr(flags), 0),
+               "ss_kmerfa_encode(%s)" % fa)
+    ids = sorted(int(f) for f in os.listdir(kdir) if f.isdigit())
+    lists = []
+    for i in ids:
+        with open(os.path.join(kdir, str(i)), "rb") as f:
+            first = f.readline()
+        lists.append(np.array(first.split(), dtype=np.int64) if len(first) < 4096 else
+                     np.fromstring(first, dtype=np.int64, sep=" "))
+    if path:
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            offs = np.zeros(len(ids) + 1, np.int64)
+            for i, r in enumerate(lists):
+                offs[i + 1] = offs[i] + r.size
+            tmp = path + ".%d.tmp.npz" % os.getpid()
+            np.savez(tmp, keys=keys, flags=flags, ids=np.array(ids, np.int64), offsets=offs,
+                     rows=np.concatenate(lists) if lists else np.zeros(0, np.int64))
+            os.replace(tmp, path)
+        except OSError:
+            pass
+    return keys, flags, ids, lists
+
+
 class TreeImage:
     def __init__(self, db_dir, upper_keys=True):
         self.db_dir = db_dir
         self.upper_keys = upper_keys
-        self.kdb = _lib.KmerDB.from_fasta(os.path.join(db_dir, "kmer.fa"), L1_K, upper_keys)
-        self.node_ids = []
-        self.node_rows = {}           # id -> np.int64 rows in FILE order (adjust_profile indexes it)
-        kdir = os.path.join(db_dir, "kmers")
-        ids = sorted(int(f) for f in os.listdir(kdir) if f.isdigit())
-        lists = []
-        for i in ids:
-            with open(os.path.join(kdir, str(i)), "r") as f:
-                first = f.readline()
-            rows = np.array(first.split(), dtype=np.int64) if first.strip() else np.zeros(0, np.int64)
-            self.node_rows[i] = rows
-            self.node_ids.append(i)
-            lists.append(rows)
+        keys, flags, ids, lists = load_tree_text(db_dir, L1_K)
+        self.kdb = _lib.KmerDB(keys, flags, L1_K, upper_keys)
+        self.node_ids = list(ids)
+        self.node_rows = dict(zip(ids, lists))   # id -> np.int64 rows in FILE order (adjust_profile indexes it)
         self.node_index = {i: j for j, i in enumerate(self.node_ids)}
         self.nodes = _lib.NodeSet(lists)
         self._scanned = None          # key of the inputs whose counts are in the table

@@ -154,3 +154,22 @@ def test_report_writers_match_reference(golden_dir, tmp_path):
     (tmp_path / "C1" / "StrainVote.report").write_text(g["A_l2"]["strain_vote"])
     vote.merge_res(str(tmp_path), cls)
     assert (tmp_path / "final_report.txt").read_text() == g["A_l2"]["final_report"]
+
+
+def test_tree_image_cache_roundtrip(l1_dbs, tmp_path, monkeypatch):
+    """Text parse of kmer.fa + kmers/<id> and its binary cache give identical arrays."""
+    from strainscan_amd import db as sdb
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    tdb = os.path.join(l1_dbs["A"]["db_dir"], "Tree_database")
+    k1, f1, ids1, l1 = sdb.load_tree_text(tdb)
+    assert len(os.listdir(tmp_path / "cache")) == 1
+    k2, f2, ids2, l2 = sdb.load_tree_text(tdb)           # second call: from the cache
+    assert np.array_equal(k1, k2) and np.array_equal(f1, f2) and ids1 == ids2
+    assert all(np.array_equal(a, b) for a, b in zip(l1, l2))
+    info = l1_dbs["A"]
+    assert ids1 == info["tree"].ids
+    for i, rows in zip(ids1, l1):
+        assert rows.tolist() == info["row_of_node"][i]
+    monkeypatch.setenv("SS_IMAGE_CACHE", "off")
+    k3, _, _, _ = sdb.load_tree_text(tdb)
+    assert np.array_equal(k1, k3)
