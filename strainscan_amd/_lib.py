@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstrainscan_hip.so")
+LIB_PATH = os.environ.get("SS_LIB") or os.path.join(_HERE, "lib", "libstrainscan_hip.so")
 
 SS_OK, SS_EINVAL, SS_ENOMEM, SS_EIO, SS_EHIP, SS_ENODEV, SS_EKEY, SS_ERANGE = 0, -22, -12, -5, -1000, -19, -2, -34
 ROW_VALID, ROW_LOWER = 1, 2

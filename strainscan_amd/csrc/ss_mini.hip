@@ -23,12 +23,17 @@
 //                         the k-mer with offset o sits at header + 1 + popcount(mask & ((1 << o) - 1)):
 //                         a hit costs two dependent loads, a miss inside an existing bucket one.
 //   d_counts[n_slots] u32 occurrences per slot (same index; header slots unused)
-//   d_dir[n_dir][2]   u64 cuckoo directory of 16-byte buckets (two entries each, two hash functions):
-//                         entry = (minimizer hash << 32) | bucket start (31 bits), EMPTY = ~0.  A key
-//                         lives in its FIRST bucket unless that one was full when it arrived; bit 31
-//                         of a first bucket's entry 0 says "a key of this bucket lives in its second
-//                         bucket".  A lookup is one 16-byte load (one HBM sector), plus a second one
-//                         only behind that flag (a few % of the lookups): no probe chains.
+//   d_dir[n_dir][2]   u64 cuckoo directory of 16-byte buckets (two entries each, two hash functions).
+//                         entry = 14-bit fingerprint of the minimizer hash << 50 | multi << 49 |
+//                                 offset mask (17 bits) << 32 | moved flag << 31 | bucket start (31 bits)
+//                         i.e. the bucket's header travels with the directory entry: a found run goes
+//                         straight to its candidate k-mers (dir -> candidate: two dependent round trips
+//                         per tile instead of three).  A fingerprint false positive (2^-14) only costs a
+//                         candidate compare that fails: k-mers are compared in full, and a k-mer lives in
+//                         exactly one bucket, so every fingerprint match is simply tried.  A key lives
+//                         in its FIRST bucket unless that was full when it arrived; "moved" on a first
+//                         bucket's entry 0 means a key of that bucket lives in its second bucket, which is
+//                         then read too (a few % of the lookups).  EMPTY = ~0.
 #include "ss_common.h"
 #include "ss_scan_dev.h"
 
@@ -78,6 +83,7 @@ __host__ __device__ __forceinline__ uint32_t dir_bucket2(uint32_t mini, uint32_t
 {
     return mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir);
 }
+__host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return (mini * 0x2545F491u) >> 18; }
 constexpr uint64_t DIR_MOVED = 1ull << 31;        // flag in entry 0 of a first bucket
 constexpr uint32_t START_MASK = 0x7FFFFFFFu;
 
@@ -132,6 +138,8 @@ constexpr int Q1CAP = 1024;        // runs per tile held in LDS (mean ~450); ove
 // own 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
 constexpr int MLANES = SCAN_THREADS - 1;
 constexpr int MTILE = MLANES * PPT;
+constexpr int Q3CAP = MTILE + 496;   // items per tile: every position can hit once, plus fingerprint false positives
+constexpr uint32_t Q3_NONE = 0xFFFFu;
 
 struct QShared {
     uint32_t code[SCAN_THREADS + 2];
@@ -142,7 +150,7 @@ struct QShared {
         uint32_t hm[SCAN_THREADS * PPT];   // hash of the m-mer starting at each position of the tile
         struct {
             uint64_t q2[Q1CAP];        // found: bucket start << 32 | header (mask, multi) << 12 | tile position
-            uint16_t q3[MTILE];        // item:  q2 index << 5 | position inside the run
+            uint16_t q3[Q3CAP];        // item:  q2 index << 5 | position inside the run (Q3_NONE = void)
         };
     };
     uint32_t cnt[4];                   // n1, n2, n3
@@ -181,6 +189,13 @@ __device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint
     }
 }
 
+#ifdef SS_TIMING
+__device__ unsigned long long ss_timing[8];
+#define SS_T(i) do { if (t == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&ss_timing[i], now_ - t_prev); t_prev = now_; } } while (0)
+#else
+#define SS_T(i) do { } while (0)
+#endif
+
 template <bool ALIGNED, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
@@ -194,24 +209,39 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
     const uint64_t kmask = (~0ull) >> (64 - 2 * K);
     const uint32_t *mk32 = reinterpret_cast<const uint32_t *>(mkeys);
 
+    // the 16 bases of this lane (and the halo word, thread 0) are fetched one tile AHEAD: the HBM
+    // round trip of the stream overlaps the previous tile's phases
+    uint32_t wn[4], wh[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    if (blockIdx.x < n_tiles) {
+        const uint64_t b0 = (uint64_t)blockIdx.x * MTILE;
+        load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
+        if (t < 1) load16<ALIGNED>(bases, b0 + (uint64_t)SCAN_THREADS * 16, n, wh);
+    }
+#ifdef SS_TIMING
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t base = tile * (uint64_t)MTILE;
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
         {
-            uint32_t w[4], code, inv;
-            load16<ALIGNED>(bases, base + (uint64_t)t * 16, n, w);
-            encode16(w, code, inv);
+            uint32_t code, inv;
+            encode16(wn, code, inv);
             S.code[t] = code;
             S.inv[t] = (uint16_t)inv;
             if (t < 1) {       // halo: the k-mers of lane 254 reach into word 256
-                load16<ALIGNED>(bases, base + (uint64_t)SCAN_THREADS * 16, n, w);
-                encode16(w, code, inv);
+                encode16(wh, code, inv);
                 S.code[SCAN_THREADS] = code;
                 S.inv[SCAN_THREADS] = (uint16_t)inv;
             }
             if (t < 4) S.cnt[t] = 0;
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < n_tiles) {
+                const uint64_t nb = nt * (uint64_t)MTILE;
+                load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
+                if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)SCAN_THREADS * 16, n, wh);
+            }
         }
         __syncthreads();
+        SS_T(0);
 
         // ---- phase 1a: hash the 16 m-mers that start in this lane's 16 bases ----------------------
         uint32_t hm[PPT];
@@ -231,6 +261,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             dst[3] = make_uint4(hm[12], hm[13], hm[14], hm[15]);
         }
         __syncthreads();
+        SS_T(1);
 
         // ---- phase 1b: minimizer (hash, leftmost offset) of the lane's 16 k-mers, runs ------------
         uint32_t live = 0;
@@ -311,49 +342,68 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             }
         }
         __syncthreads();
+        SS_T(2);
 
         // ---- phase 2: one directory lookup per run ----------------------------------------------
         {
             const uint32_t n1 = min(S.cnt[0], (uint32_t)Q1CAP);
             const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
+            // every directory entry whose fingerprint matches becomes a found run (q2) whose positions
+            // are expanded into items (q3)
+            auto push_found = [&](uint64_t de, uint64_t run) {
+                const uint32_t len = ((uint32_t)run >> 12) & 31u, rpos = (uint32_t)run & 0xFFFu;
+                const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
+                const uint32_t i2 = atomicAdd(&S.cnt[1], 1u);
+                uint32_t i3 = Q3CAP;
+                if (i2 < Q1CAP) i3 = atomicAdd(&S.cnt[2], len);
+                if (i2 < Q1CAP && i3 + len <= (uint32_t)Q3CAP) {
+                    S.q2[i2] = ((uint64_t)bstart << 32) | (hdr << 12) | rpos;
+                    for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
+                } else {
+                    // a queue is full (only with floods of fingerprint collisions): void what was
+                    // reserved and settle this run here, so that no k-mer is ever dropped
+                    for (uint32_t q = 0; q < len && i3 + q < (uint32_t)Q3CAP; q++) S.q3[i3 + q] = (uint16_t)Q3_NONE;
+                    for (uint32_t q = 0; q < len; q++) {
+                        const uint32_t cpos = cand_slot(S, rpos + q, bstart, hdr);
+                        if (cpos) settle_item(S, rpos + q, bstart, hdr, cpos, mkeys[cpos], mkeys, counts, kmask);
+                    }
+                }
+            };
+            // two runs per lane per round: both 16-byte directory loads in flight before either is used
             for (uint32_t r0 = 0; r0 < n1; r0 += 2 * SCAN_THREADS) {
-                const uint32_t ra = r0 + t, rb = r0 + SCAN_THREADS + t;
-                const bool va = ra < n1, vb = rb < n1;
-                const uint64_t ea = va ? S.q1[ra] : 0, eb = vb ? S.q1[rb] : 0;
-                const uint32_t ha = (uint32_t)(ea >> 32), hb = (uint32_t)(eb >> 32);
-                ulonglong2 ba = dir2[va ? ss::dir_bucket1(ha, n_dir) : 0u];      // both 16-byte loads in flight
-                ulonglong2 bb = dir2[vb ? ss::dir_bucket1(hb, n_dir) : 0u];
+                uint64_t e[2];
+                ulonglong2 bk[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const bool v = u ? vb : va;
-                    const uint64_t e = u ? eb : ea;
-                    ulonglong2 bk = u ? bb : ba;
-                    const uint32_t h = (uint32_t)(e >> 32);
-                    bool m0 = v && bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
-                    bool m1 = v && bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
-                    if (v && !m0 && !m1 && bk.x != ss::EMPTY_KEY && (bk.x & ss::DIR_MOVED)) {
-                        bk = dir2[ss::dir_bucket2(h, n_dir)];                  // the key may live in its second bucket
-                        m0 = bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
-                        m1 = bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
+                    const uint32_t r = r0 + u * SCAN_THREADS + t;
+                    e[u] = (r < n1) ? S.q1[r] : ~0ull;                                   // ~0: no run
+                    bk[u] = dir2[(r < n1) ? ss::dir_bucket1((uint32_t)(e[u] >> 32), n_dir) : 0u];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (e[u] == ~0ull) continue;
+                    const uint32_t h = (uint32_t)(e[u] >> 32);
+                    const uint64_t fp = ss::dir_fp(h);
+                    uint64_t hit[4];
+                    int nh = 0;
+                    if (bk[u].x != ss::EMPTY_KEY && (bk[u].x >> 50) == fp) hit[nh++] = bk[u].x;
+                    if (bk[u].y != ss::EMPTY_KEY && (bk[u].y >> 50) == fp) hit[nh++] = bk[u].y;
+                    if (bk[u].x != ss::EMPTY_KEY && (bk[u].x & ss::DIR_MOVED)) {          // a key of this bucket moved
+                        const ulonglong2 b2 = dir2[ss::dir_bucket2(h, n_dir)];
+                        if (b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) hit[nh++] = b2.x;
+                        if (b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) hit[nh++] = b2.y;
                     }
-                    if (m0 || m1) {
-                        const uint32_t bstart = (uint32_t)(m0 ? bk.x : bk.y) & ss::START_MASK;
-                        const uint32_t len = ((uint32_t)e >> 12) & 31u;
-                        const uint32_t hdr = mk32[2 * (uint64_t)bstart] & 0x3FFFFu;      // offsets present + multi bit
-                        const uint32_t i2 = atomicAdd(&S.cnt[1], 1u);
-                        const uint32_t i3 = atomicAdd(&S.cnt[2], len);
-                        S.q2[i2] = ((uint64_t)bstart << 32) | (hdr << 12) | ((uint32_t)e & 0xFFFu);
-                        for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
-                    }
+                    for (int d = 0; d < nh; d++) push_found(hit[d], e[u]);
                 }
             }
         }
         __syncthreads();
+        SS_T(3);
 
         // ---- phase 3: the k-mers whose minimizer exists in the database -------------------------
         // four items per lane per round: all candidate loads in flight before any compare
         {
-            const uint32_t n3 = S.cnt[2];
+            const uint32_t n3 = min(S.cnt[2], (uint32_t)Q3CAP);
             for (uint32_t i0 = 0; i0 < n3; i0 += 4 * SCAN_THREADS) {
                 uint32_t pos[4], bst[4], hdr[4], cps[4];
                 uint64_t cnd[4];
@@ -361,12 +411,14 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 for (int u = 0; u < 4; u++) {
                     const uint32_t i = i0 + u * SCAN_THREADS + t;
                     const bool v = i < n3;
-                    const uint32_t it = v ? S.q3[i] : 0;
+                    uint32_t it = v ? S.q3[i] : Q3_NONE;
+                    const bool live_item = it != Q3_NONE;
+                    it = live_item ? it : 0u;
                     const uint64_t r = S.q2[it >> 5];
                     pos[u] = ((uint32_t)r & 0xFFFu) + (it & 31u);
                     bst[u] = (uint32_t)(r >> 32);
                     hdr[u] = ((uint32_t)r >> 12) & 0x3FFFFu;
-                    cps[u] = v ? cand_slot(S, pos[u], bst[u], hdr[u]) : 0u;
+                    cps[u] = live_item ? cand_slot(S, pos[u], bst[u], hdr[u]) : 0u;
                     cnd[u] = mkeys[cps[u]];
                 }
 #pragma unroll
@@ -383,26 +435,31 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
 #pragma unroll
                 for (int q = 0; q < PPT; q++) if (q == j) h = mh[q];
                 const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
-                ulonglong2 bk = dir2[ss::dir_bucket1(h, n_dir)];
-                bool m0 = bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
-                bool m1 = bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
-                if (!m0 && !m1 && bk.x != ss::EMPTY_KEY && (bk.x & ss::DIR_MOVED)) {
-                    bk = dir2[ss::dir_bucket2(h, n_dir)];
-                    m0 = bk.x != ss::EMPTY_KEY && (uint32_t)(bk.x >> 32) == h;
-                    m1 = bk.y != ss::EMPTY_KEY && (uint32_t)(bk.y >> 32) == h;
-                }
-                if (!(m0 || m1)) continue;
-                const uint32_t bstart = (uint32_t)(m0 ? bk.x : bk.y) & ss::START_MASK;
-                const uint32_t hdr = mk32[2 * (uint64_t)bstart] & 0x3FFFFu;
+                const uint64_t fp = ss::dir_fp(h);
                 const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
-                for (uint32_t q = 0; q < len; q++) {
-                    const uint32_t pos = (uint32_t)(t * PPT + j) + q;
-                    const uint32_t cpos = cand_slot(S, pos, bstart, hdr);
-                    if (cpos) settle_item(S, pos, bstart, hdr, cpos, mkeys[cpos], mkeys, counts, kmask);
+                uint64_t des[4];
+                int nd = 0;
+                const ulonglong2 b1 = dir2[ss::dir_bucket1(h, n_dir)];
+                if (b1.x != ss::EMPTY_KEY && (b1.x >> 50) == fp) des[nd++] = b1.x;
+                if (b1.y != ss::EMPTY_KEY && (b1.y >> 50) == fp) des[nd++] = b1.y;
+                if (b1.x != ss::EMPTY_KEY && (b1.x & ss::DIR_MOVED)) {
+                    const ulonglong2 b2 = dir2[ss::dir_bucket2(h, n_dir)];
+                    if (b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) des[nd++] = b2.x;
+                    if (b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) des[nd++] = b2.y;
+                }
+                for (int d = 0; d < nd; d++) {
+                    const uint32_t bstart = (uint32_t)des[d] & ss::START_MASK, hdr = (uint32_t)(des[d] >> 32) & 0x3FFFFu;
+                    for (uint32_t q = 0; q < len; q++) {
+                        const uint32_t pos = (uint32_t)(t * PPT + j) + q;
+                        const uint32_t cpos = cand_slot(S, pos, bstart, hdr);
+                        if (cpos) settle_item(S, pos, bstart, hdr, cpos, mkeys[cpos], mkeys, counts, kmask);
+                    }
                 }
             }
         }
+        SS_T(4);
         __syncthreads();   // queues and codes are rewritten by the next tile
+        SS_T(5);
     }
 }
 
@@ -474,14 +531,15 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     mkeys.reserve(nv + nv / 4 + 2);
     std::vector<uint32_t> slot_of_row(std::max<uint64_t>(1, n_rows), SS_NO_SLOT);
     std::vector<uint8_t> row_valid(std::max<uint64_t>(1, n_rows), 0);
-    std::vector<std::pair<uint32_t, uint32_t>> buckets;   // (minimizer hash, header slot)
+    struct Bkt { uint32_t first, second, hdr; };         // minimizer hash, header slot, offset mask | multi
+    std::vector<Bkt> buckets;
     uint64_t orphans = 0, n_distinct = 0;
     for (uint64_t i = 0; i < nv;) {
         // one bucket = all entries with this minimizer hash
         uint64_t e = i;
         while (e < nv && sorted[e].mini == sorted[i].mini) e++;
         const uint32_t hslot = (uint32_t)mkeys.size();
-        buckets.emplace_back(sorted[i].mini, hslot);
+        buckets.push_back(Bkt{sorted[i].mini, hslot, 0});
         mkeys.push_back(0);
         uint32_t mask = 0, multi = 0, cnt = 0;
         for (uint64_t a = i; a < e;) {
@@ -505,6 +563,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
             a = b;
         }
         mkeys[hslot] = ((uint64_t)cnt << 32) | multi | mask;
+        buckets.back().hdr = multi | mask;
         i = e;
     }
     sorted.clear();
@@ -518,38 +577,41 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     if (mkeys.size() >= 0x7FFFFFF0ull) return SS_ERANGE;
     uint64_t n_dir = std::max<uint64_t>(16, buckets.size() + buckets.size() / 2);
     std::vector<uint64_t> dir;
+    std::vector<uint32_t> dir_h;      // minimizer hash of each occupied slot (needed to re-place evicted keys)
     std::vector<uint8_t> moved;
     for (;; n_dir += n_dir / 4) {
         if (n_dir >= 0xFFFFFFF0ull) return SS_ERANGE;
         dir.assign(2 * n_dir, EMPTY_KEY);
+        dir_h.assign(2 * n_dir, 0);
         moved.assign(n_dir, 0);
         bool ok = true;
         uint64_t rng = 0x9E3779B97F4A7C15ull;
-        auto place = [&](uint64_t cur) -> bool {
+        auto place = [&](uint64_t cur, uint32_t h) -> bool {
             for (int kicks = 0; kicks < 1000; kicks++) {
-                const uint32_t h = (uint32_t)(cur >> 32);
                 const uint32_t b1 = dir_bucket1(h, (uint32_t)n_dir), b2 = dir_bucket2(h, (uint32_t)n_dir);
-                if (dir[2 * b1] == EMPTY_KEY) { dir[2 * b1] = cur; return true; }
-                if (dir[2 * b1 + 1] == EMPTY_KEY) { dir[2 * b1 + 1] = cur; return true; }
+                for (uint64_t sl : {2 * (uint64_t)b1, 2 * (uint64_t)b1 + 1})
+                    if (dir[sl] == EMPTY_KEY) { dir[sl] = cur; dir_h[sl] = h; return true; }
                 moved[b1] = 1;                                     // from now on look in b2 as well
-                if (dir[2 * b2] == EMPTY_KEY) { dir[2 * b2] = cur; return true; }
-                if (dir[2 * b2 + 1] == EMPTY_KEY) { dir[2 * b2 + 1] = cur; return true; }
+                for (uint64_t sl : {2 * (uint64_t)b2, 2 * (uint64_t)b2 + 1})
+                    if (dir[sl] == EMPTY_KEY) { dir[sl] = cur; dir_h[sl] = h; return true; }
                 rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
                 const uint64_t victim = 2 * (uint64_t)((rng & 2) ? b1 : b2) + (rng & 1);
                 std::swap(cur, dir[victim]);                       // evict; the victim is re-placed next round
+                std::swap(h, dir_h[victim]);
             }
             return false;
         };
-        for (const auto &b : buckets)
-            if (!place(((uint64_t)b.first << 32) | b.second)) { ok = false; break; }
+        for (const auto &b : buckets) {
+            const uint64_t e = ((uint64_t)dir_fp(b.first) << 50) | ((uint64_t)b.hdr << 32) | b.second;
+            if (!place(e, b.first)) { ok = false; break; }
+        }
         if (ok) break;
     }
     for (uint64_t b = 0; b < n_dir; b++)
         if (moved[b]) {
             if (dir[2 * b] == EMPTY_KEY) std::swap(dir[2 * b], dir[2 * b + 1]);   // keep the flag carrier in entry 0
             if (dir[2 * b] != EMPTY_KEY) dir[2 * b] |= DIR_MOVED;
-            // a flagged bucket that became empty again cannot hide a key: moved keys are only ever
-            // displaced from FULL buckets, and evictions swap, they never empty a slot
+            // a flagged bucket cannot be empty: keys only move on from FULL buckets and evictions swap
         }
     const uint32_t dirbits = 0;
     db->n_dir = (uint32_t)n_dir;
@@ -586,6 +648,16 @@ static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const u
         hipLaunchKernelGGL((scan_mini_kernel<false, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
                            db->d_mkeys, db->d_dir, db->n_dir, db->d_counts);
 }
+
+#ifdef SS_TIMING
+extern "C" int ss_debug_timing(unsigned long long *out8, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ss_timing), 64);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ss_timing), z, 64); }
+    return 0;
+}
+#endif
 
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles)
