@@ -119,7 +119,7 @@ int ss_counts_rows(const ss_db *db, uint32_t *counts_rows);
  * read shard, the uint32[n_rows] vectors are sum-all-reduced over RCCL, and each rank loads the
  * global vector back so that all later reductions see whole-sample counts) */
 int ss_counts_load_rows_dev(ss_db *db, const uint32_t *counts_rows_dev, void *stream);
-uint64_t ss_scan_kernel_launches(const ss_db *db);
+uint64_t ss_scan_kernel_launches(const ss_db *db);   /* scan kernels enqueued so far (diagnostics) */
 
 /* --------------------------------------------------------------------------------------------
  * Resident read sets.  The reference re-reads the FASTQ for the tree scan, for every identified

