@@ -369,18 +369,22 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                     }
                 }
             };
-            // two runs per lane per round: both 16-byte directory loads in flight before either is used
-            for (uint32_t r0 = 0; r0 < n1; r0 += 2 * SCAN_THREADS) {
-                uint64_t e[2];
-                ulonglong2 bk[2];
+            // RPL runs per lane per round: all 16-byte directory loads in flight before any is used
+#ifndef SS_RPL
+#define SS_RPL 4
+#endif
+            constexpr int RPL = SS_RPL;
+            for (uint32_t r0 = 0; r0 < n1; r0 += RPL * SCAN_THREADS) {
+                uint64_t e[RPL];
+                ulonglong2 bk[RPL];
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < RPL; u++) {
                     const uint32_t r = r0 + u * SCAN_THREADS + t;
                     e[u] = (r < n1) ? S.q1[r] : ~0ull;                                   // ~0: no run
                     bk[u] = dir2[(r < n1) ? ss::dir_bucket1((uint32_t)(e[u] >> 32), n_dir) : 0u];
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
+                for (int u = 0; u < RPL; u++) {
                     if (e[u] == ~0ull) continue;
                     const uint32_t h = (uint32_t)(e[u] >> 32);
                     const uint64_t fp = ss::dir_fp(h);
