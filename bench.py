@@ -243,7 +243,7 @@ def main():
                     sector_gbs=round(args.reads * (READ_LEN + 120 * 64) / (kern_ms * 1e-3) / 1e9, 1))
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
         from oracle import oracle as orc
         threads = orc.lib().orc_omp_threads()
         flat = reads[: 20000 * (READ_LEN + 1)].cpu().numpy()
