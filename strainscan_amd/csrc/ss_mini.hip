@@ -132,13 +132,20 @@ struct Ent {
 //            per-position items in q3 (rare: ~5 % of the positions of a typical sample)
 //   phase 3  lanes pull items from q3: bucket header -> candidate slot -> compare -> atomicAdd
 // ---------------------------------------------------------------------------------------------
-constexpr int Q1CAP = 1024;        // runs per tile held in LDS (mean ~450); overflow is handled inline
+#ifndef SS_Q1CAP
+#define SS_Q1CAP 1024
+#endif
+constexpr int Q1CAP = SS_Q1CAP;    // runs per tile held in LDS (mean ~680); overflow is handled inline
 // A tile is 255 x 16 start positions: all 256 lanes load 16 bases and hash the 16 m-mers that START
 // in them (every m-mer hash is computed exactly once per tile and shared through LDS); lanes 0..254
 // own 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
 constexpr int MLANES = SCAN_THREADS - 1;
 constexpr int MTILE = MLANES * PPT;
+#ifdef SS_Q3CAP                       // test builds shrink the queues to exercise the overflow paths
+constexpr int Q3CAP = SS_Q3CAP;
+#else
 constexpr int Q3CAP = MTILE + 496;   // items per tile: every position can hit once, plus fingerprint false positives
+#endif
 constexpr uint32_t Q3_NONE = 0xFFFFu;
 
 struct QShared {

@@ -275,3 +275,69 @@ def test_resident_read_set_and_shards(L, tmp_path):
         part.close()
     assert nrec == 11 * len(seqs)
     assert np.array_equal(tot, want)
+
+
+def _adversarial_case(seed=77):
+    """Low-complexity and repetitive sequence: homopolymers, tandem repeats with periods around the
+    minimizer length (ties between identical 15-mers inside one 31-mer window -> leftmost rule,
+    buckets holding several k-mers with the same minimizer offset -> 'multi' scan), dense overlaps."""
+    rs = np.random.RandomState(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    parts = [b"A" * 300, b"AC" * 200, b"ACG" * 150, b"ACGTTGA" * 80]
+    for period in (15, 16, 17, 23, 31, 32, 40):
+        unit = lut[rs.randint(0, 4, size=period)].tobytes()
+        parts.append(unit * (600 // period))
+    parts.append(lut[rs.randint(0, 4, size=3000)].tobytes())
+    core = lut[rs.randint(0, 4, size=400)].tobytes()
+    parts += [core, lut[rs.randint(0, 4, size=200)].tobytes(), core, core[:200] + b"T" + core[201:]]
+    genome = b"".join(parts)
+    kms = sorted(set(genome[i:i + 31] for i in range(len(genome) - 30)))
+    kfa = b"".join(b">1\n" + km + b"\n" for km in kms)
+    ga = np.frombuffer(genome, np.uint8)
+    recs = []
+    for s in rs.randint(0, len(genome) - 150, size=6000):
+        r = ga[s:s + rs.randint(31, 151)].copy()
+        m = rs.random_sample(r.size) < 0.003
+        r[m] = lut[rs.randint(0, 4, size=int(m.sum()))]
+        recs.append(r.tobytes())
+    recs += [b"A" * 150, b"AC" * 75, genome[:4000], genome[2000:9000]]
+    return kfa, b"\n".join(recs) + b"\n"
+
+
+def test_low_complexity_and_repeats(L):
+    from oracle import oracle as orc
+    kfa, flat = _adversarial_case()
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+    want, want_valid = orc.jellyfish_count(kfa, [fq], k=31, upper=True)
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_flat(flat)
+    assert np.array_equal(db.row_valid, want_valid)
+    assert np.array_equal(db.counts_rows(), want)
+    assert want.max() > 50          # the repeats really pile up on few k-mers
+
+
+def test_queue_overflow_paths(tmp_path):
+    """The same parity checks against a build whose LDS queues hold 64 runs / 96 items per tile
+    (libstrainscan_hip_tinyq.so): every tile overflows q1 and q3, so the inline paths do the work."""
+    import subprocess
+    import sys
+    from strainscan_amd import _lib
+    tiny = os.path.join(os.path.dirname(_lib.LIB_PATH), "libstrainscan_hip_tinyq.so")
+    assert os.path.exists(tiny), "run __graft_entry__.build()"
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from strainscan_amd import _lib\n"
+        "from oracle import oracle as orc\n"
+        "from tests.test_scan_gpu import _adversarial_case, _random_db_and_reads\n"
+        "assert _lib.LIB_PATH.endswith('tinyq.so')\n"
+        "for kfa, flat in (_adversarial_case(), _random_db_and_reads(8, 60000, 20000)):\n"
+        "    fq = b''.join(b'@r\\n' + r + b'\\n+\\n' + b'I' * len(r) + b'\\n' for r in flat.split(b'\\n') if r)\n"
+        "    want, _ = orc.jellyfish_count(kfa, [fq], k=31, upper=True)\n"
+        "    db = _lib.KmerDB.from_text(kfa, 31, True)\n"
+        "    db.scan_flat(flat)\n"
+        "    assert np.array_equal(db.counts_rows(), want)\n"
+        "print('tinyq ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, SS_LIB=tiny)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "tinyq ok" in out.stdout, out.stderr[-2000:]
