@@ -66,13 +66,24 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
     const uint64_t lo = offsets[node], hi = offsets[node + 1];
     const int t = threadIdx.x;
 
-    // pass 0: length (valid rows) and n_pos (valid rows seen at least once)
+    // pass 0: length (valid rows) and n_pos (valid rows seen at least once); four independent
+    // gathers in flight per lane (most nodes of a sample have no hits: this pass is all they cost)
     uint64_t len = 0, npos = 0;
-    for (uint64_t i = lo + t; i < hi; i += NT) {
-        const uint32_t r = rows[i];
-        if (valid[r]) {
-            len++;
-            if (counts[r] > 0) npos++;
+    {
+        uint64_t i = lo + t;
+        for (; i + 3 * NT < hi; i += 4 * NT) {
+            const uint32_t r0 = rows[i], r1 = rows[i + NT], r2 = rows[i + 2 * NT], r3 = rows[i + 3 * NT];
+            const uint32_t v0 = valid[r0], v1 = valid[r1], v2 = valid[r2], v3 = valid[r3];
+            const uint32_t c0 = counts[r0], c1 = counts[r1], c2 = counts[r2], c3 = counts[r3];
+            len += (v0 != 0) + (v1 != 0) + (v2 != 0) + (v3 != 0);
+            npos += (v0 && c0) + (v1 && c1) + (v2 && c2) + (v3 && c3);
+        }
+        for (; i < hi; i += NT) {
+            const uint32_t r = rows[i];
+            if (valid[r]) {
+                len++;
+                if (counts[r] > 0) npos++;
+            }
         }
     }
     len = block_sum(len, s_red64);
