@@ -93,6 +93,11 @@ int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int
                 ss_db **out);
 int ss_db_destroy(ss_db *db);
 int ss_db_info(const ss_db *db, uint64_t *n_rows, uint64_t *n_distinct, uint64_t *capacity, int *k);
+/* The built index as a file (device arrays dumped verbatim): a database is indexed once, later
+ * runs import the image.  Only the k = 31 minimizer layout is exported (SS_ERANGE otherwise);
+ * ss_db_import returns SS_EINVAL / SS_EIO for anything that is not a complete image. */
+int ss_db_export(const ss_db *db, const char *path);
+int ss_db_import(const char *path, ss_db **out);
 /* row_valid[i] = 1 iff row i is a key of the reference's match_results (identify.py:96-101) */
 int ss_db_row_valid(const ss_db *db, uint8_t *row_valid);
 const uint8_t *ss_db_row_valid_dev(const ss_db *db);

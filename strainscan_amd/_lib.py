@@ -61,6 +61,8 @@ SIGNATURES = {
     "ss_encode_kmer": (i32, [cp, i32, P(u64)]),
     "ss_db_build": (i32, [vp, vp, u64, i32, i32, P(vp)]),
     "ss_db_destroy": (i32, [vp]),
+    "ss_db_export": (i32, [vp, cp]),
+    "ss_db_import": (i32, [cp, P(vp)]),
     "ss_db_info": (i32, [vp, P(u64), P(u64), P(u64), P(i32)]),
     "ss_db_row_valid": (i32, [vp, vp]),
     "ss_db_row_valid_dev": (vp, [vp]),
@@ -180,6 +182,22 @@ class KmerDB:
         self.k = int(k)
         self.n_rows = int(keys.size)
         self._row_valid = None
+
+    @classmethod
+    def from_image(cls, path):
+        """A previously exported index image (ss_db_export); raises SSError if it is not usable."""
+        require_gpu()
+        h = C.c_void_p()
+        check(lib().ss_db_import(os.fsencode(path), C.byref(h)), "ss_db_import(%s)" % path)
+        self = cls.__new__(cls)
+        self._h = h
+        self._row_valid = None
+        i = self.info()
+        self.k, self.n_rows = i["k"], i["n_rows"]
+        return self
+
+    def export(self, path):
+        check(lib().ss_db_export(self._h, os.fsencode(path)), "ss_db_export(%s)" % path)
 
     @classmethod
     def from_fasta(cls, path, k=31, upper_keys=True, threads=0):

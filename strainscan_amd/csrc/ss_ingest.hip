@@ -227,36 +227,57 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
         return SS_OK;
     };
     int rc = SS_OK;
-    uint64_t seq_block = 0;
+    // plain files: chunked worker-thread path; everything else (gzip, multi-line records, small files)
+    // goes through the sequential reader -- one thread PER FILE, so the two mates of a paired
+    // .fastq.gz sample inflate concurrently (zlib is the limiter there)
+    std::vector<int> seq_files;
     for (int i = 0; i < n_paths && rc == SS_OK; i++) {
         if (!paths[i]) { rc = SS_EINVAL; break; }
         if (!paths[i][0]) continue;
         bool handled = false;
         rc = ss::parse_file_parallel(R->workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep);
-        if (rc != SS_OK || handled) continue;
-        // sequential reader (gzip, multi-line records, small files): blocks round-robin over the ranks
-        ss_reader *rd = nullptr;
-        rc = ss_reader_open(&paths[i], 1, &rd);
-        if (rc) break;
-        ss_reader_set_overlap(rd, 30);
-        const uint64_t cap = 32ull << 20;
-        std::vector<char> buf(cap);
-        for (;;) {
-            uint64_t len = 0, nr = 0;
-            rc = ss_reader_next(rd, buf.data(), cap, &len, &nr);
-            if (rc || len == 0) break;
-            if (buf[len - 1] != '\n') R->has_cut_record = true;
-            if ((int)(seq_block++ % (uint64_t)shard_world) != shard_rank) continue;
-            ss_reads::Block b;
-            if (hipMalloc((void **)&b.d, std::max<uint64_t>(16, len)) != hipSuccess) { rc = SS_ENOMEM; break; }
-            b.len = len;
-            if (hipMemcpy(b.d, buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) { hipFree(b.d); rc = SS_EHIP; break; }
-            R->blocks.push_back(b);
-            R->device_bytes += len;
-            recs += nr;
-            bases += len;
-        }
-        ss_reader_close(rd);
+        if (rc == SS_OK && !handled) seq_files.push_back(i);
+    }
+    if (rc == SS_OK && !seq_files.empty()) {
+        std::atomic<int> err(SS_OK);
+        std::atomic<uint64_t> srecs(0), sbases(0);
+        int device = 0;
+        hipGetDevice(&device);
+        auto one_file = [&](int fi) {
+            hipSetDevice(device);
+            ss_reader *rd = nullptr;
+            int r = ss_reader_open(&paths[fi], 1, &rd);
+            if (r) { err = r; return; }
+            ss_reader_set_overlap(rd, 30);
+            const uint64_t cap = 32ull << 20;
+            std::vector<char> buf(cap);
+            for (uint64_t blk = 0; err == SS_OK; blk++) {
+                uint64_t len = 0, nr = 0;
+                r = ss_reader_next(rd, buf.data(), cap, &len, &nr);
+                if (r) { err = r; break; }
+                if (len == 0) break;
+                if (buf[len - 1] != '\n') R->has_cut_record = true;
+                if ((int)((blk + (uint64_t)fi) % (uint64_t)shard_world) != shard_rank) continue;
+                ss_reads::Block b;
+                if (hipMalloc((void **)&b.d, std::max<uint64_t>(16, len)) != hipSuccess) { err = SS_ENOMEM; break; }
+                b.len = len;
+                if (hipMemcpy(b.d, buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) { hipFree(b.d); err = SS_EHIP; break; }
+                {
+                    std::lock_guard<std::mutex> g(R->mu);
+                    R->blocks.push_back(b);
+                    R->device_bytes += len;
+                }
+                srecs += nr;
+                sbases += len;
+            }
+            ss_reader_close(rd);
+        };
+        std::vector<std::thread> pool;
+        for (int fi : seq_files) pool.emplace_back(one_file, fi);
+        for (auto &th : pool) th.join();
+        rc = err;
+        recs += srecs;
+        bases += sbases;
     }
     ss_db::free_workers(R->workers, 32);
     if (rc != SS_OK) { ss_reads_destroy(R); return rc; }

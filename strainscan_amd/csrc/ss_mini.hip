@@ -695,3 +695,98 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 }
 
 }  // namespace ss
+
+// ---------------------------------------------------------------------------------------------
+// Index image on disk: the built minimizer index (device arrays) dumped verbatim, so that a
+// database is indexed once, not at every run (device image cache).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ImageHeader {
+    char magic[8];          // "SSIDX01\0"
+    int32_t k, layout;
+    uint64_t n_rows, n_distinct, n_slots, n_buckets;
+    uint32_t n_dir, pad;
+};
+
+bool write_dev(FILE *f, const void *d, uint64_t bytes)
+{
+    std::vector<char> buf(std::min<uint64_t>(bytes, 64ull << 20));
+    for (uint64_t off = 0; off < bytes; off += buf.size()) {
+        const uint64_t n = std::min<uint64_t>(buf.size(), bytes - off);
+        if (hipMemcpy(buf.data(), (const char *)d + off, n, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (fwrite(buf.data(), 1, n, f) != n) return false;
+    }
+    return true;
+}
+
+bool read_dev(FILE *f, void *d, uint64_t bytes)
+{
+    std::vector<char> buf(std::min<uint64_t>(bytes, 64ull << 20));
+    for (uint64_t off = 0; off < bytes; off += buf.size()) {
+        const uint64_t n = std::min<uint64_t>(buf.size(), bytes - off);
+        if (fread(buf.data(), 1, n, f) != n) return false;
+        if (hipMemcpy((char *)d + off, buf.data(), n, hipMemcpyHostToDevice) != hipSuccess) return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int ss_db_export(const ss_db *db, const char *path)
+{
+    if (!db || !path) return SS_EINVAL;
+    if (db->layout != 1) return SS_ERANGE;          // only the minimizer layout has a build worth caching
+    FILE *f = fopen(path, "wb");
+    if (!f) return SS_EIO;
+    ImageHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "SSIDX01", 8);
+    h.k = db->k; h.layout = db->layout;
+    h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
+    h.n_dir = db->n_dir;
+    const uint64_t nr = std::max<uint64_t>(1, db->n_rows);
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && write_dev(f, db->d_mkeys, db->n_slots * 8) &&
+              write_dev(f, db->d_dir, (uint64_t)db->n_dir * 16) && write_dev(f, db->d_slot_of_row, nr * 4) &&
+              write_dev(f, db->d_row_valid, nr);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(path); return SS_EIO; }
+    return SS_OK;
+}
+
+int ss_db_import(const char *path, ss_db **out)
+{
+    if (!path || !out) return SS_EINVAL;
+    FILE *f = fopen(path, "rb");
+    if (!f) return SS_EIO;
+    ImageHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX01", 8) != 0 || h.layout != 1 || h.k != 31 ||
+        h.n_slots == 0 || h.n_dir == 0) {
+        fclose(f);
+        return SS_EINVAL;
+    }
+    ss_db *db = new (std::nothrow) ss_db();
+    if (!db) { fclose(f); return SS_ENOMEM; }
+    db->k = h.k; db->layout = 1;
+    db->n_rows = h.n_rows; db->n_distinct = h.n_distinct; db->n_slots = h.n_slots; db->capacity = h.n_slots;
+    db->n_buckets = h.n_buckets; db->n_dir = h.n_dir;
+    hipGetDevice(&db->device);
+    const uint64_t nr = std::max<uint64_t>(1, db->n_rows);
+    bool ok = hipMalloc((void **)&db->d_mkeys, db->n_slots * 8) == hipSuccess &&
+              hipMalloc((void **)&db->d_dir, (uint64_t)db->n_dir * 16) == hipSuccess &&
+              hipMalloc((void **)&db->d_counts, db->n_slots * 4) == hipSuccess &&
+              hipMalloc((void **)&db->d_slot_of_row, nr * 4) == hipSuccess &&
+              hipMalloc((void **)&db->d_row_valid, nr) == hipSuccess;
+    ok = ok && read_dev(f, db->d_mkeys, db->n_slots * 8) && read_dev(f, db->d_dir, (uint64_t)db->n_dir * 16) &&
+         read_dev(f, db->d_slot_of_row, nr * 4) && read_dev(f, db->d_row_valid, nr) &&
+         hipMemset(db->d_counts, 0, db->n_slots * 4) == hipSuccess;
+    // the file must end exactly here
+    ok = ok && fgetc(f) == EOF;
+    fclose(f);
+    if (!ok) { ss_db_destroy(db); return SS_EIO; }
+    db->device_bytes = db->n_slots * 12 + (uint64_t)db->n_dir * 16 + nr * 5;
+    *out = db;
+    return SS_OK;
+}
+
+}  // extern "C"

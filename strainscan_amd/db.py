@@ -161,7 +161,7 @@ class TreeImage:
         self.db_dir = db_dir
         self.upper_keys = upper_keys
         keys, flags, ids, lists = load_tree_text(db_dir, L1_K)
-        self.kdb = _lib.KmerDB(keys, flags, L1_K, upper_keys)
+        self.kdb = self._index(db_dir, keys, flags, upper_keys)
         self.node_ids = list(ids)
         self.node_rows = dict(zip(ids, lists))   # id -> np.int64 rows in FILE order (adjust_profile indexes it)
         self.node_index = {i: j for j, i in enumerate(self.node_ids)}
@@ -169,6 +169,36 @@ class TreeImage:
         self._scanned = None          # key of the inputs whose counts are in the table
         self._counts = None
         self._stats = None
+
+    @staticmethod
+    def _index(db_dir, keys, flags, upper_keys):
+        """Device index of kmer.fa: imported from the image cache when present, else built and exported."""
+        import hashlib
+        cdir = _cache_dir()
+        path = None
+        if cdir:
+            st = os.stat(os.path.join(db_dir, "kmer.fa"))
+            tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, int(st.st_mtime), L1_K,
+                                                     int(upper_keys))).encode()).hexdigest()[:20]
+            path = os.path.join(cdir, "index_%s.bin" % tag)
+            if os.path.exists(path):
+                try:
+                    kdb = _lib.KmerDB.from_image(path)
+                    if kdb.n_rows == keys.size:
+                        return kdb
+                    kdb.close()
+                except RuntimeError:
+                    pass
+        kdb = _lib.KmerDB(keys, flags, L1_K, upper_keys)
+        if path:
+            try:
+                os.makedirs(cdir, exist_ok=True)
+                tmp = path + ".%d.tmp" % os.getpid()
+                kdb.export(tmp)
+                os.replace(tmp, path)
+            except (RuntimeError, OSError):
+                pass
+        return kdb
 
     # -- scanning ---------------------------------------------------------------------------
     def scan(self, paths):

@@ -341,3 +341,37 @@ def test_queue_overflow_paths(tmp_path):
     env = dict(os.environ, SS_LIB=tiny)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "tinyq ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_index_image_roundtrip(L, tmp_path):
+    """ss_db_export / ss_db_import: an imported index counts exactly like the one that was built;
+    anything that is not a complete image is refused."""
+    kfa, flat = _random_db_and_reads(4242, 150000, 20000)
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_flat(flat)
+    want, want_valid = db.counts_rows(), db.row_valid.copy()
+    assert want.any()
+    img = str(tmp_path / "index.bin")
+    db.export(img)
+    db2 = L.KmerDB.from_image(img)
+    i1, i2 = db.info(), db2.info()
+    assert all(i1[f] == i2[f] for f in ("n_rows", "n_distinct", "capacity", "k"))
+    assert not db2.counts_rows().any()                 # counts are not part of the image
+    db2.scan_flat(flat)
+    assert np.array_equal(db2.counts_rows(), want)
+    assert np.array_equal(db2.row_valid, want_valid)
+    db2.close()
+    raw = open(img, "rb").read()
+    for name, blob in (("short", raw[:len(raw) // 2]), ("long", raw + b"x"), ("magic", b"NOTANIDX" + raw[8:]),
+                       ("empty", b"")):
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        with pytest.raises(L.SSError):
+            L.KmerDB.from_image(p)
+    with pytest.raises(L.SSError):
+        L.KmerDB.from_image(str(tmp_path / "missing"))
+    # the flat layout (k != 31) is not exported
+    kfa5, _ = _random_db_and_reads(5, 300, 10, k=21)
+    with pytest.raises(L.SSError):
+        L.KmerDB.from_text(kfa5, 21, True).export(str(tmp_path / "flat.bin"))
+    db.close()
