@@ -224,11 +224,36 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
         if (t < 1) load16<ALIGNED>(bases, b0 + (uint64_t)SCAN_THREADS * 16, n, wh);
     }
+#ifdef SS_PF2
+    // The stream registers are turned into codes BEFORE phase 3 issues its atomics and the next
+    // load is issued AFTER them: on gfx9 loads and atomics share vmcnt, so a wait for the stream
+    // at the top of the loop would also wait for the acks of the previous tile's atomics (one
+    // exposed HBM round trip per tile).
+    uint32_t code_n, inv_n, code_h = 0, inv_h = 0;
+    encode16(wn, code_n, inv_n);
+    if (t < 1) encode16(wh, code_h, inv_h);
+    if (blockIdx.x + gridDim.x < n_tiles) {
+        const uint64_t b1 = ((uint64_t)blockIdx.x + gridDim.x) * MTILE;
+        load16<ALIGNED>(bases, b1 + (uint64_t)t * 16, n, wn);
+        if (t < 1) load16<ALIGNED>(bases, b1 + (uint64_t)SCAN_THREADS * 16, n, wh);
+    }
+#endif
 #ifdef SS_TIMING
     unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
+#ifdef SS_PF2
+        {
+            S.code[t] = code_n;
+            S.inv[t] = (uint16_t)inv_n;
+            if (t < 1) {       // halo: the k-mers of lane 254 reach into word 256
+                S.code[SCAN_THREADS] = code_h;
+                S.inv[SCAN_THREADS] = (uint16_t)inv_h;
+            }
+            if (t < 4) S.cnt[t] = 0;
+        }
+#else
         {
             uint32_t code, inv;
             encode16(wn, code, inv);
@@ -247,6 +272,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)SCAN_THREADS * 16, n, wh);
             }
         }
+#endif
         __syncthreads();
         SS_T(0);
 
@@ -395,19 +421,27 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                     if (e[u] == ~0ull) continue;
                     const uint32_t h = (uint32_t)(e[u] >> 32);
                     const uint64_t fp = ss::dir_fp(h);
-                    uint64_t hit[4];
-                    int nh = 0;
-                    if (bk[u].x != ss::EMPTY_KEY && (bk[u].x >> 50) == fp) hit[nh++] = bk[u].x;
-                    if (bk[u].y != ss::EMPTY_KEY && (bk[u].y >> 50) == fp) hit[nh++] = bk[u].y;
-                    if (bk[u].x != ss::EMPTY_KEY && (bk[u].x & ss::DIR_MOVED)) {          // a key of this bucket moved
-                        const ulonglong2 b2 = dir2[ss::dir_bucket2(h, n_dir)];
-                        if (b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) hit[nh++] = b2.x;
-                        if (b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) hit[nh++] = b2.y;
+                    // matching entries as a bit mask + selects (an indexed local array would live in scratch memory)
+                    ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
+                    if (bk[u].x != ss::EMPTY_KEY && (bk[u].x & ss::DIR_MOVED))            // a key of this bucket moved
+                        b2 = dir2[ss::dir_bucket2(h, n_dir)];
+                    uint32_t hits = (uint32_t)(bk[u].x != ss::EMPTY_KEY && (bk[u].x >> 50) == fp) |
+                                    (uint32_t)(bk[u].y != ss::EMPTY_KEY && (bk[u].y >> 50) == fp) << 1 |
+                                    (uint32_t)(b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) << 2 |
+                                    (uint32_t)(b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) << 3;
+                    while (hits) {
+                        const uint32_t d = (uint32_t)__ffs(hits) - 1u;
+                        hits &= hits - 1u;
+                        push_found(d == 0 ? bk[u].x : d == 1 ? bk[u].y : d == 2 ? b2.x : b2.y, e[u]);
                     }
-                    for (int d = 0; d < nh; d++) push_found(hit[d], e[u]);
                 }
             }
         }
+#ifdef SS_PF2
+        // the next tile's bases have arrived with the directory entries (same counter): encode now
+        encode16(wn, code_n, inv_n);
+        if (t < 1) encode16(wh, code_h, inv_h);
+#endif
         __syncthreads();
         SS_T(3);
 
@@ -448,18 +482,18 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
                 const uint64_t fp = ss::dir_fp(h);
                 const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
-                uint64_t des[4];
-                int nd = 0;
                 const ulonglong2 b1 = dir2[ss::dir_bucket1(h, n_dir)];
-                if (b1.x != ss::EMPTY_KEY && (b1.x >> 50) == fp) des[nd++] = b1.x;
-                if (b1.y != ss::EMPTY_KEY && (b1.y >> 50) == fp) des[nd++] = b1.y;
-                if (b1.x != ss::EMPTY_KEY && (b1.x & ss::DIR_MOVED)) {
-                    const ulonglong2 b2 = dir2[ss::dir_bucket2(h, n_dir)];
-                    if (b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) des[nd++] = b2.x;
-                    if (b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) des[nd++] = b2.y;
-                }
-                for (int d = 0; d < nd; d++) {
-                    const uint32_t bstart = (uint32_t)des[d] & ss::START_MASK, hdr = (uint32_t)(des[d] >> 32) & 0x3FFFFu;
+                ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
+                if (b1.x != ss::EMPTY_KEY && (b1.x & ss::DIR_MOVED)) b2 = dir2[ss::dir_bucket2(h, n_dir)];
+                uint32_t hits = (uint32_t)(b1.x != ss::EMPTY_KEY && (b1.x >> 50) == fp) |
+                                (uint32_t)(b1.y != ss::EMPTY_KEY && (b1.y >> 50) == fp) << 1 |
+                                (uint32_t)(b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) << 2 |
+                                (uint32_t)(b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) << 3;
+                while (hits) {
+                    const uint32_t d = (uint32_t)__ffs(hits) - 1u;
+                    hits &= hits - 1u;
+                    const uint64_t de = d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y;
+                    const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
                     for (uint32_t q = 0; q < len; q++) {
                         const uint32_t pos = (uint32_t)(t * PPT + j) + q;
                         const uint32_t cpos = cand_slot(S, pos, bstart, hdr);
@@ -469,6 +503,16 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             }
         }
         SS_T(4);
+#ifdef SS_PF2
+        {
+            const uint64_t nt = tile + 2ull * gridDim.x;
+            if (nt < n_tiles) {
+                const uint64_t nb = nt * (uint64_t)MTILE;
+                load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
+                if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)SCAN_THREADS * 16, n, wh);
+            }
+        }
+#endif
         __syncthreads();   // queues and codes are rewritten by the next tile
         SS_T(5);
     }
