@@ -49,24 +49,26 @@ constexpr int MINI_M = 15;                       // minimizer length (30 bits)
 constexpr uint32_t M30 = 0x3FFFFFFFu;
 constexpr uint32_t HDR_MULTI = 1u << 17;
 
-// 32-bit mix of a 30-bit m-mer: the ordering that picks the minimizer (avoids poly-A bias).  Two
-// 24x24-bit multiplies (v_mul_u32_u24: full rate on CDNA, v_mul_lo_u32 is quarter rate) and a
-// rotate.  It need not be injective: bucket entries carry the full k-mer.
-__host__ __device__ __forceinline__ uint32_t mmhash(uint32_t x)
+// Ordering key of a 30-bit m-mer: the m-mer with the smallest (key & ~31), leftmost on ties, is the
+// minimizer of a k-mer.  Three full-rate instructions on CDNA (v_mad_u32_u24 x2 + a shift; the
+// 24-bit multipliers ignore the operands' upper bits, so the device never masks the window), the
+// added constant keeps poly-A from being everybody's minimizer.  The low five bits are free: the
+// kernel stores the m-mer's index there, so ONE v_min_u32 per step compares (key, position).
+// It need not be injective: a bucket is named by the m-mer itself and holds full k-mers.
+__host__ __device__ __forceinline__ uint32_t mmkey(uint32_t x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t a = (uint32_t)__umul24(x & 0xFFFFFFu, 0x9E3779u);
-    const uint32_t b = (uint32_t)__umul24(x >> 6, 0x85EBCBu);
+    const uint32_t a = (uint32_t)__umul24(x, 0x9E3779u) + 0x7F4A7C15u;
+    return (uint32_t)__umul24(x >> 6, 0x85EBCBu) + a;
 #else
-    const uint32_t a = (x & 0xFFFFFFu) * 0x9E3779u;
-    const uint32_t b = (x >> 6) * 0x85EBCBu;
+    const uint32_t a = (x & 0xFFFFFFu) * 0x9E3779u + 0x7F4A7C15u;
+    return ((x >> 6) & 0xFFFFFFu) * 0x85EBCBu + a;
 #endif
-    return a ^ ((b << 13) | (b >> 19));
 }
+constexpr uint32_t KEY_MASK = ~31u;
 
-// the two cuckoo slots of a minimizer hash (minimizers are the SMALL hashes: take high product bits)
-// the two directory buckets of a minimizer hash: 32-bit mixes reduced to [0, n_dir) by the high half
-// of a 32x32 product (any table size, no power-of-two rounding).  Once per RUN, not per position.
+// the two directory buckets of a minimizer (the 30-bit m-mer): 32-bit mixes reduced to [0, n_dir)
+// by the high half of a 32x32 product (any table size, no power-of-two rounding).  Once per RUN.
 __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -75,29 +77,35 @@ __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b)
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
+__host__ __device__ __forceinline__ uint32_t dir_mix(uint32_t mini)
+{
+    uint32_t h = mini * 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
 __host__ __device__ __forceinline__ uint32_t dir_bucket1(uint32_t mini, uint32_t n_dir)
 {
-    return mulhi32(mini * 0x9E3779B1u, n_dir);
+    return mulhi32(dir_mix(mini), n_dir);
 }
 __host__ __device__ __forceinline__ uint32_t dir_bucket2(uint32_t mini, uint32_t n_dir)
 {
     return mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir);
 }
-__host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return (mini * 0x2545F491u) >> 18; }
+__host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return ((mini ^ (mini >> 13)) * 0x2545F491u) >> 18; }
 constexpr uint64_t DIR_MOVED = 1ull << 31;        // flag in entry 0 of a first bucket
 constexpr uint32_t START_MASK = 0x7FFFFFFFu;
 
-// minimizer hash and its LEFTMOST offset inside the k-mer
+// minimizer (the m-mer itself) of a k-mer and its LEFTMOST offset inside the k-mer
 static inline uint32_t mini_of_key(uint64_t key, int k, uint32_t *offset)
 {
     const int w = k - MINI_M + 1;
-    uint32_t best = 0, bo = 0;
+    uint32_t best = 0, bo = 0, bx = 0;
     for (int i = 0; i < w; i++) {
-        const uint32_t h = mmhash((uint32_t)(key >> (2 * i)) & M30);
-        if (i == 0 || h < best) { best = h; bo = (uint32_t)i; }
+        const uint32_t x = (uint32_t)(key >> (2 * i)) & M30;
+        const uint32_t h = mmkey(x) & KEY_MASK;
+        if (i == 0 || h < best) { best = h; bo = (uint32_t)i; bx = x; }
     }
     *offset = bo;
-    return best;
+    return bx;
 }
 
 }  // namespace ss
@@ -111,52 +119,56 @@ struct Ent {
     uint32_t row;
     uint64_t key;
     uint32_t off;   // offset of the minimizer inside the k-mer (sort key inside the bucket)
-    uint32_t pad;
+    uint32_t part;  // partition of the build sort
 };
 
 // ---------------------------------------------------------------------------------------------
 // scan kernel, minimizer layout: dense SIMD for the arithmetic, compacted LDS work queues for
 // the memory probes.
 //
-// Measured on MI355X (profiles/r01b): what bounds this kernel is not HBM bytes but the NUMBER of
-// divergent vector-memory instructions a wave issues (each costs the texture-address unit tens
-// of cycles whatever the number of active lanes) and the dependent round trips per tile.  A lane
-// that probes once per position (or even once per run, predicated per position) issues 32+ such
-// instructions per tile for ~3 useful lookups.  So per tile of 4096 start positions:
-//   phase 0  coalesced 16-byte loads of the bases, SWAR 2-bit encode, codes -> LDS
-//   phase 1  every lane: minimizer (hash, leftmost offset) of its 16 k-mers; runs of equal
-//            minimizers are pushed to LDS queue q1 through a wave ballot/prefix-sum
-//            (one entry per run: ~450 per tile instead of 4096 positions)
-//   phase 2  lanes pull runs from q1: ONE directory lookup per run (two independent 8-byte loads,
-//            cuckoo: no probe chains).  Runs whose minimizer exists go to q2 and are expanded to
+// Measured on MI355X (profiles/r01b..e): what bounds this kernel is not HBM bytes but the
+// instructions a wave issues per tile (VALU ~58 % busy, waves parked ~60 % of their life at
+// barriers / waitcnt) and the NUMBER of divergent vector-memory instructions.  So per tile of
+// 4080 start positions:
+//   phase 0  coalesced 16-byte loads of the bases (one tile ahead), SWAR 2-bit encode, codes -> LDS
+//   phase 1a every lane keys the 16 m-mers that start in its bases (3 instructions each) and tags
+//            them with their index: packed = (key & ~31) | index, shared through LDS
+//   phase 1b minimizer of the lane's 16 k-mers = suffix/prefix minima over the packed words
+//            (one v_min_u32 per step decides key AND leftmost position); runs of equal
+//            minimizers are pushed to LDS queue q1 through a DPP wave prefix-sum
+//            (one 32-bit entry per run: ~450 per tile instead of 4080 positions)
+//   phase 2  lanes pull runs from q1: the minimizer m-mer is re-read from the codes, ONE 16-byte
+//            directory load per run.  Runs whose minimizer exists go to q2 and are expanded to
 //            per-position items in q3 (rare: ~5 % of the positions of a typical sample)
-//   phase 3  lanes pull items from q3: bucket header -> candidate slot -> compare -> atomicAdd
+//   phase 3  lanes pull items from q3: candidate slot from the run's offset mask -> 64-bit
+//            compare -> atomicAdd
 // ---------------------------------------------------------------------------------------------
 #ifndef SS_Q1CAP
 #define SS_Q1CAP 1024
 #endif
-constexpr int Q1CAP = SS_Q1CAP;    // runs per tile held in LDS (mean ~680); overflow is handled inline
-// A tile is 255 x 16 start positions: all 256 lanes load 16 bases and hash the 16 m-mers that START
-// in them (every m-mer hash is computed exactly once per tile and shared through LDS); lanes 0..254
-// own 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
+constexpr int Q1CAP = SS_Q1CAP;    // runs per tile held in LDS (mean ~450); overflow is handled inline
+// A tile is 255 x 16 start positions: all 256 lanes load 16 bases and key the 16 m-mers that START
+// in them (every m-mer is keyed exactly once per tile and shared through LDS); lanes 0..254 own
+// 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
 constexpr int MLANES = SCAN_THREADS - 1;
 constexpr int MTILE = MLANES * PPT;
 #ifdef SS_Q3CAP                       // test builds shrink the queues to exercise the overflow paths
 constexpr int Q3CAP = SS_Q3CAP;
 #else
-constexpr int Q3CAP = MTILE + 496;   // items per tile: every position can hit once, plus fingerprint false positives
+constexpr int Q3CAP = 4096;           // items per tile: every position can hit once (4080); fingerprint false
+                                      // positives beyond that are settled inline.  q2 + q3 = the size of hm.
 #endif
 constexpr uint32_t Q3_NONE = 0xFFFFu;
+constexpr uint32_t Q1_NONE = 0xFFFFFFFFu;
 
 struct QShared {
     uint32_t code[SCAN_THREADS + 2];
     uint16_t inv[SCAN_THREADS + 2];
-    uint32_t off[SCAN_THREADS * 3];    // 16 offsets x 5 bits per lane
-    uint64_t q1[Q1CAP];                // run:   minimizer hash << 32 | len << 12 | tile position
+    uint32_t q1[Q1CAP];                // run:   minimizer position in the tile << 17 | len << 12 | tile position
     union {                            // hm is dead once every lane has its minimizers (barrier after phase 1)
-        uint32_t hm[SCAN_THREADS * PPT];   // hash of the m-mer starting at each position of the tile
+        uint32_t hm[SCAN_THREADS * PPT];   // packed key of the m-mer starting at each position of the tile
         struct {
-            uint64_t q2[Q1CAP];        // found: bucket start << 32 | header (mask, multi) << 12 | tile position
+            uint64_t q2[Q1CAP];        // found: bucket start << 32 | multi << 29 | aligned offset mask << 12 | tile position
             uint16_t q3[Q3CAP];        // item:  q2 index << 5 | position inside the run (Q3_NONE = void)
         };
     };
@@ -171,29 +183,51 @@ __device__ __forceinline__ uint64_t kmer_at(const QShared &S, uint32_t pos, uint
     return (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & kmask;
 }
 
-// slot of the database k-mer that k-mer `pos` would be (0 = none: no k-mer with that minimizer offset)
-__device__ __forceinline__ uint32_t cand_slot(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t hdr)
+// the 15-mer starting at tile position p (p <= 4095: the halo word covers the last one)
+__device__ __forceinline__ uint32_t mmer_at(const QShared &S, uint32_t p)
 {
-    const uint32_t lane = pos >> 4, j = pos & 15;
-    const uint32_t o = (S.off[lane * 3 + j / 6] >> (5 * (j % 6))) & 31u;
-    const uint32_t mask = hdr & 0x1FFFFu;
-    return ((mask >> o) & 1u) ? bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u)) : 0u;
+    const uint32_t w = p >> 4, sh = 2 * (p & 15);
+    const uint64_t lo = (uint64_t)S.code[w] | ((uint64_t)S.code[w + 1] << 32);
+    return (uint32_t)(lo >> sh) & ss::M30;
 }
+
+// A found run carries the bucket's offset mask shifted so that the offset of the run's FIRST k-mer
+// sits at bit 16: the k-mer q positions further has offset bit 16 - q (the minimizer stands still
+// while the k-mer start moves right).  Slot of the database k-mer that k-mer q would be, 0 = none.
+__device__ __forceinline__ uint32_t cand_slot(uint32_t bstart, uint32_t amask, uint32_t q)
+{
+    const uint32_t o = 16u - q;
+    return ((amask >> o) & 1u) ? bstart + 1u + (uint32_t)__popc(amask & ((1u << o) - 1u)) : 0u;
+}
+__device__ __forceinline__ uint32_t aligned_mask(uint32_t hdr, uint32_t o0) { return ((hdr & 0x1FFFFu) << (16u - o0)) & 0x1FFFFu; }
 
 // compare the candidate (already loaded) with k-mer `pos`; count; fall back to a bucket scan when
 // several database k-mers share a minimizer offset (repeated / colliding minimizer)
-__device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t hdr, uint32_t cpos,
+__device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t multi, uint32_t cpos,
                                             uint64_t cand, const uint64_t *__restrict__ mkeys,
                                             uint32_t *__restrict__ counts, uint64_t kmask)
 {
     const uint64_t km = kmer_at(S, pos, kmask);
     if (cand == km) {
         atomicAdd(&counts[cpos], 1u);
-    } else if (hdr & ss::HDR_MULTI) {
+    } else if (multi) {
         const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
         for (uint32_t q = 0; q < cnt; q++)
             if (mkeys[bstart + 1 + q] == km) { atomicAdd(&counts[bstart + 1 + q], 1u); break; }
     }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave in the VALU (DPP row shifts + row broadcasts):
+// no LDS round trips (ds_bpermute) on the critical path of every tile
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
 }
 
 #ifdef SS_TIMING
@@ -212,9 +246,8 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
     static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
     const int t = threadIdx.x;
-    const int lane = t & 63;
     const uint64_t kmask = (~0ull) >> (64 - 2 * K);
-    const uint32_t *mk32 = reinterpret_cast<const uint32_t *>(mkeys);
+    const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
 
     // the 16 bases of this lane (and the halo word, thread 0) are fetched one tile AHEAD: the HBM
     // round trip of the stream overlaps the previous tile's phases
@@ -224,36 +257,11 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
         if (t < 1) load16<ALIGNED>(bases, b0 + (uint64_t)SCAN_THREADS * 16, n, wh);
     }
-#ifdef SS_PF2
-    // The stream registers are turned into codes BEFORE phase 3 issues its atomics and the next
-    // load is issued AFTER them: on gfx9 loads and atomics share vmcnt, so a wait for the stream
-    // at the top of the loop would also wait for the acks of the previous tile's atomics (one
-    // exposed HBM round trip per tile).
-    uint32_t code_n, inv_n, code_h = 0, inv_h = 0;
-    encode16(wn, code_n, inv_n);
-    if (t < 1) encode16(wh, code_h, inv_h);
-    if (blockIdx.x + gridDim.x < n_tiles) {
-        const uint64_t b1 = ((uint64_t)blockIdx.x + gridDim.x) * MTILE;
-        load16<ALIGNED>(bases, b1 + (uint64_t)t * 16, n, wn);
-        if (t < 1) load16<ALIGNED>(bases, b1 + (uint64_t)SCAN_THREADS * 16, n, wh);
-    }
-#endif
 #ifdef SS_TIMING
     unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
-#ifdef SS_PF2
-        {
-            S.code[t] = code_n;
-            S.inv[t] = (uint16_t)inv_n;
-            if (t < 1) {       // halo: the k-mers of lane 254 reach into word 256
-                S.code[SCAN_THREADS] = code_h;
-                S.inv[SCAN_THREADS] = (uint16_t)inv_h;
-            }
-            if (t < 4) S.cnt[t] = 0;
-        }
-#else
         {
             uint32_t code, inv;
             encode16(wn, code, inv);
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 encode16(wh, code, inv);
                 S.code[SCAN_THREADS] = code;
                 S.inv[SCAN_THREADS] = (uint16_t)inv;
+                S.code[SCAN_THREADS + 1] = 0;
             }
             if (t < 4) S.cnt[t] = 0;
             const uint64_t nt = tile + gridDim.x;
@@ -272,21 +281,17 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)SCAN_THREADS * 16, n, wh);
             }
         }
-#endif
         __syncthreads();
         SS_T(0);
 
-        // ---- phase 1a: hash the 16 m-mers that start in this lane's 16 bases ----------------------
+        // ---- phase 1a: key the 16 m-mers that start in this lane's 16 bases -----------------------
         uint32_t hm[PPT];
         {
             const uint32_t c0 = S.code[t], c1 = S.code[t + 1];
-            uint32_t x = c0 & ss::M30;
+            const uint64_t cc = (uint64_t)c0 | ((uint64_t)c1 << 32);
 #pragma unroll
-            for (int i = 0; i < PPT; i++) {
-                hm[i] = ss::mmhash(x);
-                const int p = i + ss::MINI_M;                              // next base to enter (15..30)
-                x = (x >> 2) | ((((p < 16 ? c0 : c1) >> (2 * (p & 15))) & 3u) << 28);
-            }
+            for (int i = 0; i < PPT; i++)
+                hm[i] = (ss::mmkey((uint32_t)(cc >> (2 * i))) & ss::KEY_MASK) | (uint32_t)i;
             uint4 *dst = reinterpret_cast<uint4 *>(&S.hm[t * PPT]);
             dst[0] = make_uint4(hm[0], hm[1], hm[2], hm[3]);
             dst[1] = make_uint4(hm[4], hm[5], hm[6], hm[7]);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         __syncthreads();
         SS_T(1);
 
-        // ---- phase 1b: minimizer (hash, leftmost offset) of the lane's 16 k-mers, runs ------------
+        // ---- phase 1b: minimizer of the lane's 16 k-mers, runs ------------------------------------
         uint32_t live = 0;
         if (t < MLANES) {
             uint64_t x = (uint64_t)S.inv[t] | ((uint64_t)S.inv[t + 1] << 16) | ((uint64_t)S.inv[t + 2] << 32);
@@ -306,9 +311,10 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         uint32_t need = 0;
         uint32_t mh[PPT];
         if (live) {
-            // k-mer j covers m-mers j..j+16 = own m-mers j..15 and the next lane's m-mers 0..j:
-            // suffix minima over the own hashes, prefix minima over the neighbour's; ties go to the
-            // leftmost m-mer (the database side uses the same rule).
+            // k-mer j covers m-mers j..j+16 = own m-mers j..15 (index j..15) and the next lane's
+            // m-mers 0..j (index 16..16+j): suffix minima over the own packed words, prefix minima
+            // over the neighbour's; equal keys resolve to the smaller index = the leftmost m-mer
+            // (the database side uses the same rule).
             uint32_t nx[PPT];
             {
                 const uint4 *src = reinterpret_cast<const uint4 *>(&S.hm[(t + 1) * PPT]);
@@ -316,49 +322,31 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 nx[0] = a.x; nx[1] = a.y; nx[2] = a.z; nx[3] = a.w; nx[4] = b.x; nx[5] = b.y; nx[6] = b.z; nx[7] = b.w;
                 nx[8] = c.x; nx[9] = c.y; nx[10] = c.z; nx[11] = c.w; nx[12] = d.x; nx[13] = d.y; nx[14] = d.z; nx[15] = d.w;
             }
-            uint32_t suf_h[PPT], suf_i[PPT];
-            suf_h[PPT - 1] = hm[PPT - 1];
-            suf_i[PPT - 1] = PPT - 1;
 #pragma unroll
-            for (int i = PPT - 2; i >= 0; i--) {
-                const bool take = hm[i] <= suf_h[i + 1];                  // i is left of everything in suf[i+1]
-                suf_h[i] = take ? hm[i] : suf_h[i + 1];
-                suf_i[i] = take ? (uint32_t)i : suf_i[i + 1];
-            }
-            uint32_t offw[3] = {0, 0, 0};
-            uint32_t pre_h = nx[0], pre_i = PPT;
+            for (int i = PPT - 2; i >= 0; i--) hm[i] = min(hm[i], hm[i + 1]);         // suffix minima, in place
+            uint32_t pre = nx[0] | 16u;
+            mh[0] = min(hm[0], pre);
 #pragma unroll
-            for (int j = 0; j < PPT; j++) {
-                if (j > 0 && nx[j] < pre_h) { pre_h = nx[j]; pre_i = (uint32_t)(PPT + j); }
-                const bool take_pre = pre_h < suf_h[j];
-                mh[j] = take_pre ? pre_h : suf_h[j];
-                const uint32_t o = (take_pre ? pre_i : suf_i[j]) - (uint32_t)j;
-                offw[j / 6] |= o << (5 * (j % 6));
+            for (int j = 1; j < PPT; j++) {
+                pre = min(pre, nx[j] | 16u);
+                mh[j] = min(hm[j], pre);
             }
-            S.off[t * 3] = offw[0];
-            S.off[t * 3 + 1] = offw[1];
-            S.off[t * 3 + 2] = offw[2];
-            // run starts as a bit mask, in vector arithmetic (no per-position lane-mask logic):
-            // position j starts a run if it is live and (j == 0, or j-1 is not live, or the minimizer changed)
+            // run starts as a bit mask: position j starts a run if it is live and (j == 0, or j-1 is
+            // not live, or the minimizer changed)
             uint32_t chg = 1u;
 #pragma unroll
-            for (int j = 1; j < PPT; j++) chg |= min(mh[j] ^ mh[j - 1], 1u) << j;
+            for (int j = 1; j < PPT; j++) chg |= (uint32_t)(mh[j] != mh[j - 1]) << j;
             need = live & (chg | (~live << 1));
         }
         // wave prefix sum of the run counts, one LDS atomic per wave, predicated queue writes
         uint32_t ovf = 0;   // runs that did not fit q1 (processed inline below)
         {
             const uint32_t mine = (uint32_t)__popc(need);
-            uint32_t incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t v = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += v;
-            }
-            const uint32_t total = __shfl(incl, 63, 64);
+            const uint32_t incl = wave_inclusive_sum(mine);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             uint32_t wbase = 0;
-            if (lane == 63 && total) wbase = atomicAdd(&S.cnt[0], total);
-            wbase = __shfl(wbase, 63, 64);
+            if ((t & 63) == 63 && total) wbase = atomicAdd(&S.cnt[0], total);
+            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
             const uint32_t mybase = wbase + incl - mine;
             if (need) {
                 const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
@@ -368,7 +356,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                     const uint32_t idx = mybase + (uint32_t)__popc(need & ((1u << j) - 1u));
                     const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));   // positions until the next run / gap
                     if (idx < Q1CAP)
-                        S.q1[idx] = ((uint64_t)mh[j] << 32) | (len << 12) | (uint32_t)(t * PPT + j);
+                        S.q1[idx] = (((uint32_t)(t * PPT) + (mh[j] & 31u)) << 17) | (len << 12) | (uint32_t)(t * PPT + j);
                     else
                         ovf |= 1u << j;
                 }
@@ -377,71 +365,69 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         __syncthreads();
         SS_T(2);
 
+        // every directory entry whose fingerprint matches becomes a found run (q2) whose positions
+        // are expanded into items (q3)
+        auto push_found = [&](uint64_t de, uint32_t run, bool queued) {
+            const uint32_t len = (run >> 12) & 31u, rpos = run & 0xFFFu, o0 = (run >> 17) - rpos;
+            const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
+            const uint32_t amask = aligned_mask(hdr, o0), multi = (hdr >> 17) & 1u;
+            uint32_t i2 = Q1CAP, i3 = Q3CAP;
+            if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
+            if (i2 < Q1CAP) i3 = atomicAdd(&S.cnt[2], len);
+            if (i2 < Q1CAP && i3 + len <= (uint32_t)Q3CAP) {
+                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 29) | (amask << 12) | rpos;
+                for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
+            } else {
+                // a queue is full (only with floods of fingerprint collisions), or phase 3 is already
+                // over (runs that overflowed q1): void what was reserved and settle this run here,
+                // so that no k-mer is ever dropped
+                for (uint32_t q = 0; q < len && i3 + q < (uint32_t)Q3CAP; q++) S.q3[i3 + q] = (uint16_t)Q3_NONE;
+                for (uint32_t q = 0; q < len; q++) {
+                    const uint32_t cpos = cand_slot(bstart, amask, q);
+                    if (cpos) settle_item(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts, kmask);
+                }
+            }
+        };
+        // the directory entries (first bucket b1, second bucket behind the "moved" flag) that match run `run`
+        auto lookup_found = [&](const ulonglong2 &b1, uint32_t x, uint32_t run, bool queued) {
+            const uint64_t fp = ss::dir_fp(x);
+            // matching entries as a bit mask + selects (an indexed local array would live in scratch memory)
+            ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
+            if (b1.x != ss::EMPTY_KEY && (b1.x & ss::DIR_MOVED)) b2 = dir2[ss::dir_bucket2(x, n_dir)];   // a key of this bucket moved
+            uint32_t hits = (uint32_t)(b1.x != ss::EMPTY_KEY && (b1.x >> 50) == fp) |
+                            (uint32_t)(b1.y != ss::EMPTY_KEY && (b1.y >> 50) == fp) << 1 |
+                            (uint32_t)(b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) << 2 |
+                            (uint32_t)(b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) << 3;
+            while (hits) {
+                const uint32_t d = (uint32_t)__ffs(hits) - 1u;
+                hits &= hits - 1u;
+                push_found(d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y, run, queued);
+            }
+        };
+
         // ---- phase 2: one directory lookup per run ----------------------------------------------
         {
             const uint32_t n1 = min(S.cnt[0], (uint32_t)Q1CAP);
-            const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
-            // every directory entry whose fingerprint matches becomes a found run (q2) whose positions
-            // are expanded into items (q3)
-            auto push_found = [&](uint64_t de, uint64_t run) {
-                const uint32_t len = ((uint32_t)run >> 12) & 31u, rpos = (uint32_t)run & 0xFFFu;
-                const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
-                const uint32_t i2 = atomicAdd(&S.cnt[1], 1u);
-                uint32_t i3 = Q3CAP;
-                if (i2 < Q1CAP) i3 = atomicAdd(&S.cnt[2], len);
-                if (i2 < Q1CAP && i3 + len <= (uint32_t)Q3CAP) {
-                    S.q2[i2] = ((uint64_t)bstart << 32) | (hdr << 12) | rpos;
-                    for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
-                } else {
-                    // a queue is full (only with floods of fingerprint collisions): void what was
-                    // reserved and settle this run here, so that no k-mer is ever dropped
-                    for (uint32_t q = 0; q < len && i3 + q < (uint32_t)Q3CAP; q++) S.q3[i3 + q] = (uint16_t)Q3_NONE;
-                    for (uint32_t q = 0; q < len; q++) {
-                        const uint32_t cpos = cand_slot(S, rpos + q, bstart, hdr);
-                        if (cpos) settle_item(S, rpos + q, bstart, hdr, cpos, mkeys[cpos], mkeys, counts, kmask);
-                    }
-                }
-            };
             // RPL runs per lane per round: all 16-byte directory loads in flight before any is used
 #ifndef SS_RPL
 #define SS_RPL 4
 #endif
             constexpr int RPL = SS_RPL;
             for (uint32_t r0 = 0; r0 < n1; r0 += RPL * SCAN_THREADS) {
-                uint64_t e[RPL];
+                uint32_t e[RPL], xs[RPL];
                 ulonglong2 bk[RPL];
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     const uint32_t r = r0 + u * SCAN_THREADS + t;
-                    e[u] = (r < n1) ? S.q1[r] : ~0ull;                                   // ~0: no run
-                    bk[u] = dir2[(r < n1) ? ss::dir_bucket1((uint32_t)(e[u] >> 32), n_dir) : 0u];
+                    e[u] = (r < n1) ? S.q1[r] : Q1_NONE;                                 // no run: all ones
+                    xs[u] = mmer_at(S, (r < n1) ? (e[u] >> 17) : 0u);
+                    bk[u] = dir2[(r < n1) ? ss::dir_bucket1(xs[u], n_dir) : 0u];
                 }
 #pragma unroll
-                for (int u = 0; u < RPL; u++) {
-                    if (e[u] == ~0ull) continue;
-                    const uint32_t h = (uint32_t)(e[u] >> 32);
-                    const uint64_t fp = ss::dir_fp(h);
-                    // matching entries as a bit mask + selects (an indexed local array would live in scratch memory)
-                    ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
-                    if (bk[u].x != ss::EMPTY_KEY && (bk[u].x & ss::DIR_MOVED))            // a key of this bucket moved
-                        b2 = dir2[ss::dir_bucket2(h, n_dir)];
-                    uint32_t hits = (uint32_t)(bk[u].x != ss::EMPTY_KEY && (bk[u].x >> 50) == fp) |
-                                    (uint32_t)(bk[u].y != ss::EMPTY_KEY && (bk[u].y >> 50) == fp) << 1 |
-                                    (uint32_t)(b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) << 2 |
-                                    (uint32_t)(b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) << 3;
-                    while (hits) {
-                        const uint32_t d = (uint32_t)__ffs(hits) - 1u;
-                        hits &= hits - 1u;
-                        push_found(d == 0 ? bk[u].x : d == 1 ? bk[u].y : d == 2 ? b2.x : b2.y, e[u]);
-                    }
-                }
+                for (int u = 0; u < RPL; u++)
+                    if (e[u] != Q1_NONE) lookup_found(bk[u], xs[u], e[u], true);
             }
         }
-#ifdef SS_PF2
-        // the next tile's bases have arrived with the directory entries (same counter): encode now
-        encode16(wn, code_n, inv_n);
-        if (t < 1) encode16(wh, code_h, inv_h);
-#endif
         __syncthreads();
         SS_T(3);
 
@@ -450,25 +436,25 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         {
             const uint32_t n3 = min(S.cnt[2], (uint32_t)Q3CAP);
             for (uint32_t i0 = 0; i0 < n3; i0 += 4 * SCAN_THREADS) {
-                uint32_t pos[4], bst[4], hdr[4], cps[4];
+                uint32_t pos[4], bst[4], mul[4], cps[4];
                 uint64_t cnd[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t i = i0 + u * SCAN_THREADS + t;
-                    const bool v = i < n3;
-                    uint32_t it = v ? S.q3[i] : Q3_NONE;
+                    uint32_t it = (i < n3) ? S.q3[i] : Q3_NONE;
                     const bool live_item = it != Q3_NONE;
                     it = live_item ? it : 0u;
                     const uint64_t r = S.q2[it >> 5];
-                    pos[u] = ((uint32_t)r & 0xFFFu) + (it & 31u);
+                    const uint32_t q = it & 31u;
+                    pos[u] = ((uint32_t)r & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32);
-                    hdr[u] = ((uint32_t)r >> 12) & 0x3FFFFu;
-                    cps[u] = live_item ? cand_slot(S, pos[u], bst[u], hdr[u]) : 0u;
+                    mul[u] = ((uint32_t)r >> 29) & 1u;
+                    cps[u] = live_item ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q) : 0u;
                     cnd[u] = mkeys[cps[u]];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (cps[u]) settle_item(S, pos[u], bst[u], hdr[u], cps[u], cnd[u], mkeys, counts, kmask);
+                    if (cps[u]) settle_item(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, kmask);
             }
         }
         // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
@@ -476,43 +462,17 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
             for (int j = 0; j < PPT; j++) {
                 if (!((ovf >> j) & 1u)) continue;
-                uint32_t h = 0;
+                uint32_t m = 0;
 #pragma unroll
-                for (int q = 0; q < PPT; q++) if (q == j) h = mh[q];
-                const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
-                const uint64_t fp = ss::dir_fp(h);
+                for (int q = 0; q < PPT; q++) if (q == j) m = mh[q];
                 const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
-                const ulonglong2 b1 = dir2[ss::dir_bucket1(h, n_dir)];
-                ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
-                if (b1.x != ss::EMPTY_KEY && (b1.x & ss::DIR_MOVED)) b2 = dir2[ss::dir_bucket2(h, n_dir)];
-                uint32_t hits = (uint32_t)(b1.x != ss::EMPTY_KEY && (b1.x >> 50) == fp) |
-                                (uint32_t)(b1.y != ss::EMPTY_KEY && (b1.y >> 50) == fp) << 1 |
-                                (uint32_t)(b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) << 2 |
-                                (uint32_t)(b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) << 3;
-                while (hits) {
-                    const uint32_t d = (uint32_t)__ffs(hits) - 1u;
-                    hits &= hits - 1u;
-                    const uint64_t de = d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y;
-                    const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
-                    for (uint32_t q = 0; q < len; q++) {
-                        const uint32_t pos = (uint32_t)(t * PPT + j) + q;
-                        const uint32_t cpos = cand_slot(S, pos, bstart, hdr);
-                        if (cpos) settle_item(S, pos, bstart, hdr, cpos, mkeys[cpos], mkeys, counts, kmask);
-                    }
-                }
+                const uint32_t p = (uint32_t)(t * PPT) + (m & 31u);
+                const uint32_t run = (p << 17) | (len << 12) | (uint32_t)(t * PPT + j);
+                const uint32_t x = mmer_at(S, p);
+                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], x, run, false);
             }
         }
         SS_T(4);
-#ifdef SS_PF2
-        {
-            const uint64_t nt = tile + 2ull * gridDim.x;
-            if (nt < n_tiles) {
-                const uint64_t nb = nt * (uint64_t)MTILE;
-                load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
-                if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)SCAN_THREADS * 16, n, wh);
-            }
-        }
-#endif
         __syncthreads();   // queues and codes are rewritten by the next tile
         SS_T(5);
     }
@@ -540,6 +500,7 @@ namespace ss {
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys)
 {
     const int k = db->k;
+    constexpr int PB = 8, NP = 1 << PB;
     unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
     // 1. entries of valid rows with their minimizer
     std::vector<uint64_t> pos(n_rows + 1, 0);
@@ -550,18 +511,17 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
         for (uint64_t i = lo; i < hi; i++)
             if (flags[i] & SS_ROW_VALID) {
                 uint32_t o;
-                const uint32_t mh = mini_of_key(keys[i], k, &o);
-                ents[pos[i]] = Ent{mh, (uint32_t)i, keys[i], o, 0};
+                const uint32_t mx = mini_of_key(keys[i], k, &o);
+                ents[pos[i]] = Ent{mx, (uint32_t)i, keys[i], o, dir_mix(mx) >> (32 - PB)};
             }
     });
-    // 2. counting partition on the top 8 bits of the minimizer hash, then per-partition sort
-    constexpr int PB = 8, NP = 1 << PB;
+    // 2. counting partition on 8 mixed bits of the minimizer, then per-partition sort
     std::vector<uint64_t> pcount(NP + 1, 0);
-    for (uint64_t i = 0; i < nv; i++) pcount[(ents[i].mini >> (32 - PB)) + 1]++;
+    for (uint64_t i = 0; i < nv; i++) pcount[ents[i].part + 1]++;
     for (int p = 0; p < NP; p++) pcount[p + 1] += pcount[p];
     {
         std::vector<uint64_t> cur(pcount.begin(), pcount.end() - 1);
-        for (uint64_t i = 0; i < nv; i++) sorted[cur[ents[i].mini >> (32 - PB)]++] = ents[i];
+        for (uint64_t i = 0; i < nv; i++) sorted[cur[ents[i].part]++] = ents[i];
     }
     ents.clear();
     ents.shrink_to_fit();
@@ -586,11 +546,11 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     mkeys.reserve(nv + nv / 4 + 2);
     std::vector<uint32_t> slot_of_row(std::max<uint64_t>(1, n_rows), SS_NO_SLOT);
     std::vector<uint8_t> row_valid(std::max<uint64_t>(1, n_rows), 0);
-    struct Bkt { uint32_t first, second, hdr; };         // minimizer hash, header slot, offset mask | multi
+    struct Bkt { uint32_t first, second, hdr; };         // minimizer (m-mer), header slot, offset mask | multi
     std::vector<Bkt> buckets;
     uint64_t orphans = 0, n_distinct = 0;
     for (uint64_t i = 0; i < nv;) {
-        // one bucket = all entries with this minimizer hash
+        // one bucket = all entries with this minimizer
         uint64_t e = i;
         while (e < nv && sorted[e].mini == sorted[i].mini) e++;
         const uint32_t hslot = (uint32_t)mkeys.size();
@@ -632,7 +592,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     if (mkeys.size() >= 0x7FFFFFF0ull) return SS_ERANGE;
     uint64_t n_dir = std::max<uint64_t>(16, buckets.size() + buckets.size() / 2);
     std::vector<uint64_t> dir;
-    std::vector<uint32_t> dir_h;      // minimizer hash of each occupied slot (needed to re-place evicted keys)
+    std::vector<uint32_t> dir_h;      // minimizer of each occupied slot (needed to re-place evicted keys)
     std::vector<uint8_t> moved;
     for (;; n_dir += n_dir / 4) {
         if (n_dir >= 0xFFFFFFF0ull) return SS_ERANGE;
@@ -721,7 +681,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     static int lb = -1, bpc = 0;
     if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
         const char *e = getenv("SS_MINI_LB");
-        lb = e ? atoi(e) : 5;
+        lb = e ? atoi(e) : 4;
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
@@ -729,10 +689,11 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 8) * 256);
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
-    case 1: launch_lb<1>(aligned, blocks, stream, b, n, n_tiles, db); break;
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    case 4: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    default: launch_lb<5>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 5: launch_lb<5>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 6: launch_lb<6>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 7: launch_lb<7>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    default: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
     }
     SS_HIP(hipGetLastError());
     return SS_OK;
@@ -746,7 +707,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct ImageHeader {
-    char magic[8];          // "SSIDX01\0"
+    char magic[8];          // "SSIDX02\0"
     int32_t k, layout;
     uint64_t n_rows, n_distinct, n_slots, n_buckets;
     uint32_t n_dir, pad;
@@ -785,7 +746,7 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX01", 8);
+    memcpy(h.magic, "SSIDX02", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
     h.n_dir = db->n_dir;
@@ -804,7 +765,7 @@ int ss_db_import(const char *path, ss_db **out)
     FILE *f = fopen(path, "rb");
     if (!f) return SS_EIO;
     ImageHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX01", 8) != 0 || h.layout != 1 || h.k != 31 ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX02", 8) != 0 || h.layout != 1 || h.k != 31 ||
         h.n_slots == 0 || h.n_dir == 0) {
         fclose(f);
         return SS_EINVAL;
