@@ -164,7 +164,7 @@ constexpr uint32_t Q1_NONE = 0xFFFFFFFFu;
 struct QShared {
     uint32_t code[SCAN_THREADS + 2];
     uint16_t inv[SCAN_THREADS + 2];
-    uint32_t q1[Q1CAP];                // run:   minimizer position in the tile << 17 | len << 12 | tile position
+    uint32_t q1[Q1CAP + 64];           // run:   minimizer position in the tile << 17 | len << 12 | tile position (+64 dump slots)
     union {                            // hm is dead once every lane has its minimizers (barrier after phase 1)
         uint32_t hm[SCAN_THREADS * PPT];   // packed key of the m-mer starting at each position of the tile
         struct {
@@ -338,7 +338,10 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             for (int j = 1; j < PPT; j++) chg |= (uint32_t)(mh[j] != mh[j - 1]) << j;
             need = live & (chg | (~live << 1));
         }
-        // wave prefix sum of the run counts, one LDS atomic per wave, predicated queue writes
+        // wave prefix sum of the run counts, one LDS atomic per wave; then every lane walks ITS runs
+        // (about two, at most a handful: the loop is as long as the busiest lane of the wave) instead
+        // of testing all 16 positions.  The only per-position datum a run needs, the minimizer's
+        // index (low byte of the packed word), is gathered into four registers by byte permutes.
         uint32_t ovf = 0;   // runs that did not fit q1 (processed inline below)
         {
             const uint32_t mine = (uint32_t)__popc(need);
@@ -349,16 +352,28 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
             const uint32_t mybase = wbase + incl - mine;
             if (need) {
-                const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
+                uint32_t pk[4];
 #pragma unroll
-                for (int j = 0; j < PPT; j++) {
-                    if (!((need >> j) & 1u)) continue;
-                    const uint32_t idx = mybase + (uint32_t)__popc(need & ((1u << j) - 1u));
-                    const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));   // positions until the next run / gap
-                    if (idx < Q1CAP)
-                        S.q1[idx] = (((uint32_t)(t * PPT) + (mh[j] & 31u)) << 17) | (len << 12) | (uint32_t)(t * PPT + j);
-                    else
-                        ovf |= 1u << j;
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t lo = __builtin_amdgcn_perm(mh[4 * w + 1], mh[4 * w], 0x0c0c0400u);
+                    const uint32_t hi = __builtin_amdgcn_perm(mh[4 * w + 3], mh[4 * w + 2], 0x0c0c0400u);
+                    pk[w] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                }
+                const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
+                const uint32_t dummy = (uint32_t)Q1CAP + (uint32_t)(t & 63);   // where entries beyond the capacity go
+                const uint32_t base = ((uint32_t)(t * PPT) << 17) | (uint32_t)(t * PPT);
+                uint32_t idx = mybase;
+                for (uint32_t nd = need; nd; nd &= nd - 1u, idx++) {
+                    const uint32_t j = (uint32_t)__ffs(nd) - 1u;
+                    const uint32_t word = (j & 8u) ? ((j & 4u) ? pk[3] : pk[2]) : ((j & 4u) ? pk[1] : pk[0]);
+                    const uint32_t i5 = (word >> ((j & 3u) * 8u)) & 31u;
+                    const uint32_t len = (uint32_t)__ffs(stop >> (j + 1u));   // positions until the next run / gap
+                    S.q1[min(idx, dummy)] = base + (i5 << 17) + (len << 12) + j;
+                }
+                if (mybase + mine > (uint32_t)Q1CAP) {                          // rare: which of my runs did not fit
+                    uint32_t r = mybase;
+                    for (uint32_t nd = need; nd; nd &= nd - 1u, r++)
+                        if (r >= (uint32_t)Q1CAP) ovf |= nd & (0u - nd);
                 }
             }
         }
@@ -686,7 +701,10 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
         bpc = g ? atoi(g) : 0;
     }
     n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 255 x 16 positions
-    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 8) * 256);
+    // grid-stride over tiles with MANY more blocks than fit the chip (measured: 5 resident blocks per CU
+    // x 256 CUs = 8.0 ms, 40 per CU 7.5 ms, 128+ per CU 7.3 ms): short blocks start at scattered
+    // times, so the blocks sharing a CU stop marching through their ALU and memory phases in step
+    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 128) * 256);
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
