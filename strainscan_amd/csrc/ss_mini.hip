@@ -143,34 +143,31 @@ struct Ent {
 //   phase 3  lanes pull items from q3: candidate slot from the run's offset mask -> 64-bit
 //            compare -> atomicAdd
 // ---------------------------------------------------------------------------------------------
-#ifndef SS_Q1CAP
-#define SS_Q1CAP 1024
+// threads per workgroup of this kernel (a tile = (MT - 1) x 16 start positions)
+#ifndef SS_NT
+#define SS_NT 64
 #endif
-constexpr int Q1CAP = SS_Q1CAP;    // runs per tile held in LDS (mean ~450); overflow is handled inline
+constexpr int MT = SS_NT;
+#ifndef SS_Q1CAP
+#define SS_Q1CAP (4 * SS_NT)
+#endif
+constexpr int Q1CAP = SS_Q1CAP;    // runs (q1) and found runs (q2) per tile held in LDS (mean ~450 runs); overflow is
+                                   // handled inline.  Test builds shrink it to exercise those paths.
+static_assert(Q1CAP <= 4096, "q2 keeps a q1 index in 12 bits");
 // A tile is 255 x 16 start positions: all 256 lanes load 16 bases and key the 16 m-mers that START
 // in them (every m-mer is keyed exactly once per tile and shared through LDS); lanes 0..254 own
 // 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
-constexpr int MLANES = SCAN_THREADS - 1;
+constexpr int MLANES = MT - 1;
 constexpr int MTILE = MLANES * PPT;
-#ifdef SS_Q3CAP                       // test builds shrink the queues to exercise the overflow paths
-constexpr int Q3CAP = SS_Q3CAP;
-#else
-constexpr int Q3CAP = 4096;           // items per tile: every position can hit once (4080); fingerprint false
-                                      // positives beyond that are settled inline.  q2 + q3 = the size of hm.
-#endif
-constexpr uint32_t Q3_NONE = 0xFFFFu;
 constexpr uint32_t Q1_NONE = 0xFFFFFFFFu;
 
 struct QShared {
-    uint32_t code[SCAN_THREADS + 2];
-    uint16_t inv[SCAN_THREADS + 2];
+    uint32_t code[MT + 2];
+    uint16_t inv[MT + 2];
     uint32_t q1[Q1CAP + 64];           // run:   minimizer position in the tile << 17 | len << 12 | tile position (+64 dump slots)
     union {                            // hm is dead once every lane has its minimizers (barrier after phase 1)
-        uint32_t hm[SCAN_THREADS * PPT];   // packed key of the m-mer starting at each position of the tile
-        struct {
-            uint64_t q2[Q1CAP];        // found: bucket start << 32 | multi << 29 | aligned offset mask << 12 | tile position
-            uint16_t q3[Q3CAP];        // item:  q2 index << 5 | position inside the run (Q3_NONE = void)
-        };
+        uint32_t hm[MT * PPT];   // packed key of the m-mer starting at each position of the tile
+        uint64_t q2[Q1CAP];            // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1 index
     };
     uint32_t cnt[4];                   // n1, n2, n3
 };
@@ -238,7 +235,7 @@ __device__ unsigned long long ss_timing[8];
 #endif
 
 template <bool ALIGNED, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel(
+__global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
     const uint64_t *__restrict__ dir, uint32_t n_dir, uint32_t *__restrict__ counts)
 {
@@ -255,7 +252,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
     if (blockIdx.x < n_tiles) {
         const uint64_t b0 = (uint64_t)blockIdx.x * MTILE;
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
-        if (t < 1) load16<ALIGNED>(bases, b0 + (uint64_t)SCAN_THREADS * 16, n, wh);
+        if (t < 1) load16<ALIGNED>(bases, b0 + (uint64_t)MT * 16, n, wh);
     }
 #ifdef SS_TIMING
     unsigned long long t_prev = __builtin_readcyclecounter();
@@ -269,16 +266,16 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             S.inv[t] = (uint16_t)inv;
             if (t < 1) {       // halo: the k-mers of lane 254 reach into word 256
                 encode16(wh, code, inv);
-                S.code[SCAN_THREADS] = code;
-                S.inv[SCAN_THREADS] = (uint16_t)inv;
-                S.code[SCAN_THREADS + 1] = 0;
+                S.code[MT] = code;
+                S.inv[MT] = (uint16_t)inv;
+                S.code[MT + 1] = 0;
             }
             if (t < 4) S.cnt[t] = 0;
             const uint64_t nt = tile + gridDim.x;
             if (nt < n_tiles) {
                 const uint64_t nb = nt * (uint64_t)MTILE;
                 load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
-                if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)SCAN_THREADS * 16, n, wh);
+                if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)MT * 16, n, wh);
             }
         }
         __syncthreads();
@@ -380,23 +377,20 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
         __syncthreads();
         SS_T(2);
 
-        // every directory entry whose fingerprint matches becomes a found run (q2) whose positions
-        // are expanded into items (q3)
-        auto push_found = [&](uint64_t de, uint32_t run, bool queued) {
-            const uint32_t len = (run >> 12) & 31u, rpos = run & 0xFFFu, o0 = (run >> 17) - rpos;
+        // every directory entry whose fingerprint matches becomes a found run in q2 (phase 3 gives it
+        // 16 lanes, one per position)
+        auto push_found = [&](uint64_t de, uint32_t run, uint32_t r1, bool queued) {
             const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
+            const uint32_t rpos = run & 0xFFFu, o0 = (run >> 17) - rpos;
             const uint32_t amask = aligned_mask(hdr, o0), multi = (hdr >> 17) & 1u;
-            uint32_t i2 = Q1CAP, i3 = Q3CAP;
+            uint32_t i2 = Q1CAP;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
-            if (i2 < Q1CAP) i3 = atomicAdd(&S.cnt[2], len);
-            if (i2 < Q1CAP && i3 + len <= (uint32_t)Q3CAP) {
-                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 29) | (amask << 12) | rpos;
-                for (uint32_t q = 0; q < len; q++) S.q3[i3 + q] = (uint16_t)((i2 << 5) | q);
+            if (i2 < Q1CAP) {
+                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | r1;
             } else {
-                // a queue is full (only with floods of fingerprint collisions), or phase 3 is already
-                // over (runs that overflowed q1): void what was reserved and settle this run here,
-                // so that no k-mer is ever dropped
-                for (uint32_t q = 0; q < len && i3 + q < (uint32_t)Q3CAP; q++) S.q3[i3 + q] = (uint16_t)Q3_NONE;
+                // the queue is full (only with floods of fingerprint collisions), or phase 3 is already
+                // over (runs that overflowed q1): settle this run here, so that no k-mer is ever dropped
+                const uint32_t len = (run >> 12) & 31u;
                 for (uint32_t q = 0; q < len; q++) {
                     const uint32_t cpos = cand_slot(bstart, amask, q);
                     if (cpos) settle_item(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts, kmask);
@@ -404,7 +398,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             }
         };
         // the directory entries (first bucket b1, second bucket behind the "moved" flag) that match run `run`
-        auto lookup_found = [&](const ulonglong2 &b1, uint32_t x, uint32_t run, bool queued) {
+        auto lookup_found = [&](const ulonglong2 &b1, uint32_t x, uint32_t run, uint32_t r1, bool queued) {
             const uint64_t fp = ss::dir_fp(x);
             // matching entries as a bit mask + selects (an indexed local array would live in scratch memory)
             ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
@@ -416,7 +410,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
             while (hits) {
                 const uint32_t d = (uint32_t)__ffs(hits) - 1u;
                 hits &= hits - 1u;
-                push_found(d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y, run, queued);
+                push_found(d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y, run, r1, queued);
             }
         };
 
@@ -428,47 +422,50 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
 #define SS_RPL 4
 #endif
             constexpr int RPL = SS_RPL;
-            for (uint32_t r0 = 0; r0 < n1; r0 += RPL * SCAN_THREADS) {
+            for (uint32_t r0 = 0; r0 < n1; r0 += RPL * MT) {
                 uint32_t e[RPL], xs[RPL];
                 ulonglong2 bk[RPL];
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
-                    const uint32_t r = r0 + u * SCAN_THREADS + t;
+                    const uint32_t r = r0 + u * MT + t;
                     e[u] = (r < n1) ? S.q1[r] : Q1_NONE;                                 // no run: all ones
                     xs[u] = mmer_at(S, (r < n1) ? (e[u] >> 17) : 0u);
                     bk[u] = dir2[(r < n1) ? ss::dir_bucket1(xs[u], n_dir) : 0u];
                 }
 #pragma unroll
                 for (int u = 0; u < RPL; u++)
-                    if (e[u] != Q1_NONE) lookup_found(bk[u], xs[u], e[u], true);
+                    if (e[u] != Q1_NONE) lookup_found(bk[u], xs[u], e[u], r0 + u * MT + t, true);
             }
         }
         __syncthreads();
         SS_T(3);
 
         // ---- phase 3: the k-mers whose minimizer exists in the database -------------------------
-        // four items per lane per round: all candidate loads in flight before any compare
+        // 16 lanes per found run (one per position of the run), four runs per lane per round: all
+        // candidate loads in flight before any compare
         {
-            const uint32_t n3 = min(S.cnt[2], (uint32_t)Q3CAP);
-            for (uint32_t i0 = 0; i0 < n3; i0 += 4 * SCAN_THREADS) {
-                uint32_t pos[4], bst[4], mul[4], cps[4];
-                uint64_t cnd[4];
+#ifndef SS_U3
+#define SS_U3 4
+#endif
+            constexpr int U3 = SS_U3;
+            const uint32_t n2 = min(S.cnt[1], (uint32_t)Q1CAP);
+            for (uint32_t g0 = 0; g0 < n2 * 16u; g0 += U3 * MT) {
+                uint32_t pos[U3], bst[U3], mul[U3], cps[U3];
+                uint64_t cnd[U3];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + u * SCAN_THREADS + t;
-                    uint32_t it = (i < n3) ? S.q3[i] : Q3_NONE;
-                    const bool live_item = it != Q3_NONE;
-                    it = live_item ? it : 0u;
-                    const uint64_t r = S.q2[it >> 5];
-                    const uint32_t q = it & 31u;
-                    pos[u] = ((uint32_t)r & 0xFFFu) + q;
+                for (int u = 0; u < U3; u++) {
+                    const uint32_t g = g0 + u * MT + t, q = g & 15u;
+                    const bool v = (g >> 4) < n2;
+                    const uint64_t r = S.q2[v ? (g >> 4) : 0u];
+                    const uint32_t run = S.q1[(uint32_t)r & 0xFFFu];
+                    pos[u] = (run & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32);
-                    mul[u] = ((uint32_t)r >> 29) & 1u;
-                    cps[u] = live_item ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q) : 0u;
+                    mul[u] = (uint32_t)r >> 31;
+                    cps[u] = (v && q < ((run >> 12) & 31u)) ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q) : 0u;
                     cnd[u] = mkeys[cps[u]];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < U3; u++)
                     if (cps[u]) settle_item(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, kmask);
             }
         }
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(SCAN_THREADS, WAVES_PER_SIMD) void scan_mini_kernel
                 const uint32_t p = (uint32_t)(t * PPT) + (m & 31u);
                 const uint32_t run = (p << 17) | (len << 12) | (uint32_t)(t * PPT + j);
                 const uint32_t x = mmer_at(S, p);
-                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], x, run, false);
+                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], x, run, 0u, false);
             }
         }
         SS_T(4);
@@ -672,10 +669,10 @@ static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const u
                       uint64_t n_tiles, ss_db *db)
 {
     if (aligned)
-        hipLaunchKernelGGL((scan_mini_kernel<true, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
+        hipLaunchKernelGGL((scan_mini_kernel<true, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,
                            db->d_mkeys, db->d_dir, db->n_dir, db->d_counts);
     else
-        hipLaunchKernelGGL((scan_mini_kernel<false, LB>), dim3(blocks), dim3(SCAN_THREADS), 0, stream, bases, n, n_tiles,
+        hipLaunchKernelGGL((scan_mini_kernel<false, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,
                            db->d_mkeys, db->d_dir, db->n_dir, db->d_counts);
 }
 
@@ -704,7 +701,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     // grid-stride over tiles with MANY more blocks than fit the chip (measured: 5 resident blocks per CU
     // x 256 CUs = 8.0 ms, 40 per CU 7.5 ms, 128+ per CU 7.3 ms): short blocks start at scattered
     // times, so the blocks sharing a CU stop marching through their ALU and memory phases in step
-    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 128) * 256);
+    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 128) * 256 * (256 / MT));
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
