@@ -154,10 +154,12 @@ constexpr int MT = SS_NT;
 constexpr int Q1CAP = SS_Q1CAP;    // runs (q1) and found runs (q2) per tile held in LDS (mean ~450 runs); overflow is
                                    // handled inline.  Test builds shrink it to exercise those paths.
 static_assert(Q1CAP <= 4096, "q2 keeps a q1 index in 12 bits");
-// A tile is 255 x 16 start positions: all 256 lanes load 16 bases and key the 16 m-mers that START
-// in them (every m-mer is keyed exactly once per tile and shared through LDS); lanes 0..254 own
-// 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's m-mers.
-constexpr int MLANES = MT - 1;
+// A tile is (MT - 2) x 16 start positions: all MT lanes load 16 bases and key the 16 m-mers that
+// START in them (shared through LDS); lanes 0..MT-3 own 16 k-mers each, whose 17-m-mer windows end in
+// the NEXT lane's m-mers, whose last bases lie in the lane after that.  The last two lanes only
+// feed their neighbours: 3 % of the lanes idle is cheaper than a separate halo load + encode, which
+// costs a full wave instruction stream for one lane.
+constexpr int MLANES = MT - 2;
 constexpr int MTILE = MLANES * PPT;
 constexpr uint32_t Q1_NONE = 0xFFFFFFFFu;
 
@@ -165,8 +167,8 @@ struct QShared {
     uint32_t code[MT + 2];
     uint16_t inv[MT + 2];
     uint32_t q1[Q1CAP + 64];           // run:   minimizer position in the tile << 17 | len << 12 | tile position (+64 dump slots)
-    union {                            // hm is dead once every lane has its minimizers (barrier after phase 1)
-        uint32_t hm[MT * PPT];   // packed key of the m-mer starting at each position of the tile
+    alignas(16) union {                // hm is dead once every lane has its minimizers (barrier after phase 1)
+        uint32_t hm[MT * PPT];   // packed keys of the m-mers: 16-byte chunk c of lane t at uint4 index c * MT + t
         uint64_t q2[Q1CAP];            // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1 index
     };
     uint32_t cnt[4];                   // n1, n2, n3
@@ -246,13 +248,12 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
     const uint64_t kmask = (~0ull) >> (64 - 2 * K);
     const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
 
-    // the 16 bases of this lane (and the halo word, thread 0) are fetched one tile AHEAD: the HBM
+    // the 16 bases of this lane are fetched one tile AHEAD: the HBM
     // round trip of the stream overlaps the previous tile's phases
-    uint32_t wn[4], wh[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    uint32_t wn[4];
     if (blockIdx.x < n_tiles) {
         const uint64_t b0 = (uint64_t)blockIdx.x * MTILE;
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
-        if (t < 1) load16<ALIGNED>(bases, b0 + (uint64_t)MT * 16, n, wh);
     }
 #ifdef SS_TIMING
     unsigned long long t_prev = __builtin_readcyclecounter();
@@ -264,18 +265,11 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             encode16(wn, code, inv);
             S.code[t] = code;
             S.inv[t] = (uint16_t)inv;
-            if (t < 1) {       // halo: the k-mers of lane 254 reach into word 256
-                encode16(wh, code, inv);
-                S.code[MT] = code;
-                S.inv[MT] = (uint16_t)inv;
-                S.code[MT + 1] = 0;
-            }
             if (t < 4) S.cnt[t] = 0;
             const uint64_t nt = tile + gridDim.x;
             if (nt < n_tiles) {
                 const uint64_t nb = nt * (uint64_t)MTILE;
                 load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
-                if (t < 1) load16<ALIGNED>(bases, nb + (uint64_t)MT * 16, n, wh);
             }
         }
         __syncthreads();
@@ -289,11 +283,13 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
 #pragma unroll
             for (int i = 0; i < PPT; i++)
                 hm[i] = (ss::mmkey((uint32_t)(cc >> (2 * i))) & ss::KEY_MASK) | (uint32_t)i;
-            uint4 *dst = reinterpret_cast<uint4 *>(&S.hm[t * PPT]);
+            // chunk c of lane t lives at hm4[c * MT + t]: consecutive lanes touch consecutive 16-byte
+            // words (a lane-major layout makes every b128 access a 4-way bank conflict)
+            uint4 *dst = reinterpret_cast<uint4 *>(S.hm) + t;
             dst[0] = make_uint4(hm[0], hm[1], hm[2], hm[3]);
-            dst[1] = make_uint4(hm[4], hm[5], hm[6], hm[7]);
-            dst[2] = make_uint4(hm[8], hm[9], hm[10], hm[11]);
-            dst[3] = make_uint4(hm[12], hm[13], hm[14], hm[15]);
+            dst[MT] = make_uint4(hm[4], hm[5], hm[6], hm[7]);
+            dst[2 * MT] = make_uint4(hm[8], hm[9], hm[10], hm[11]);
+            dst[3 * MT] = make_uint4(hm[12], hm[13], hm[14], hm[15]);
         }
         __syncthreads();
         SS_T(1);
@@ -314,8 +310,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             // (the database side uses the same rule).
             uint32_t nx[PPT];
             {
-                const uint4 *src = reinterpret_cast<const uint4 *>(&S.hm[(t + 1) * PPT]);
-                const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+                const uint4 *src = reinterpret_cast<const uint4 *>(S.hm) + (t + 1);
+                const uint4 a = src[0], b = src[MT], c = src[2 * MT], d = src[3 * MT];
                 nx[0] = a.x; nx[1] = a.y; nx[2] = a.z; nx[3] = a.w; nx[4] = b.x; nx[5] = b.y; nx[6] = b.z; nx[7] = b.w;
                 nx[8] = c.x; nx[9] = c.y; nx[10] = c.z; nx[11] = c.w; nx[12] = d.x; nx[13] = d.y; nx[14] = d.z; nx[15] = d.w;
             }
