@@ -70,6 +70,8 @@ struct ss_db {
     uint64_t *d_dir = nullptr;         // buckets: [2^dirbits] (minimizer hash << 32) | bucket start
     uint32_t dirbits = 0;
     uint32_t n_dir = 0;                // buckets: number of 16-byte directory buckets
+    uint32_t *d_bloom = nullptr;       // buckets: one-probe Bloom filter over the minimizers (L2 resident), or null
+    uint32_t bloom_bits = 0;           // log2 of its size in bits
     uint64_t n_buckets = 0;
     uint32_t *d_counts = nullptr;      // [n_slots] occurrences per slot (accumulated by scans)
     uint32_t *d_slot_of_row = nullptr; // [n_rows]   slot owning row i, SS_NO_SLOT if none

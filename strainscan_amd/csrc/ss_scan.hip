@@ -286,6 +286,7 @@ int ss_db_destroy(ss_db *db)
     hipFree(db->d_keys);
     hipFree(db->d_mkeys);
     hipFree(db->d_dir);
+    hipFree(db->d_bloom);
     hipFree(db->d_counts);
     hipFree(db->d_slot_of_row);
     hipFree(db->d_row_valid);
