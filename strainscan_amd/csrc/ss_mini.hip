@@ -49,21 +49,18 @@ constexpr int MINI_M = 15;                       // minimizer length (30 bits)
 constexpr uint32_t M30 = 0x3FFFFFFFu;
 constexpr uint32_t HDR_MULTI = 1u << 17;
 
-// Ordering key of a 30-bit m-mer: the m-mer with the smallest (key & ~31), leftmost on ties, is the
-// minimizer of a k-mer.  Three full-rate instructions on CDNA (v_mad_u32_u24 x2 + a shift; the
-// 24-bit multipliers ignore the operands' upper bits, so the device never masks the window), the
-// added constant keeps poly-A from being everybody's minimizer.  The low five bits are free: the
-// kernel stores the m-mer's index there, so ONE v_min_u32 per step compares (key, position).
+// Ordering key of a 30-bit m-mer: the m-mer with the smallest key, leftmost on ties, is the
+// minimizer of a k-mer.  key = lo24(x) * C1 + lo24(x >> 6) * C2 + C0 with C1, C2 = odd 19-bit
+// constants << 5 and C0 a multiple of 32: two v_mad_u32_u24 per m-mer on the device (full rate;
+// the 24-bit multipliers ignore the operands' upper bits, so the device never masks the window,
+// and x >> 6 of m-mer i is simply the window of m-mer i + 3).  The low five bits are zero by
+// construction: the kernel adds the m-mer's index there (for free, inside C0), so ONE v_min_u32
+// per step compares (key, position).  The constant keeps poly-A from being everybody's minimizer.
 // It need not be injective: a bucket is named by the m-mer itself and holds full k-mers.
+constexpr uint32_t MMK_C1 = 0x4F1BBu << 5, MMK_C2 = 0x6A09Fu << 5, MMK_C0 = 0x7F4A7C00u;
 __host__ __device__ __forceinline__ uint32_t mmkey(uint32_t x)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t a = (uint32_t)__umul24(x, 0x9E3779u) + 0x7F4A7C15u;
-    return (uint32_t)__umul24(x >> 6, 0x85EBCBu) + a;
-#else
-    const uint32_t a = (x & 0xFFFFFFu) * 0x9E3779u + 0x7F4A7C15u;
-    return ((x >> 6) & 0xFFFFFFu) * 0x85EBCBu + a;
-#endif
+    return (x & 0xFFFFFFu) * MMK_C1 + ((x >> 6) & 0xFFFFFFu) * MMK_C2 + MMK_C0;
 }
 constexpr uint32_t KEY_MASK = ~31u;
 
@@ -86,9 +83,11 @@ __host__ __device__ __forceinline__ uint32_t dir_bucket1(uint32_t mini, uint32_t
 {
     return mulhi32(dir_mix(mini), n_dir);
 }
+// never the first bucket again (an entry reachable through both would be counted twice): n_dir >= 16
 __host__ __device__ __forceinline__ uint32_t dir_bucket2(uint32_t mini, uint32_t n_dir)
 {
-    return mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir);
+    const uint32_t b = dir_bucket1(mini, n_dir) + 1u + mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir - 1u);
+    return b >= n_dir ? b - n_dir : b;
 }
 __host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return ((mini ^ (mini >> 13)) * 0x2545F491u) >> 18; }
 constexpr uint64_t DIR_MOVED = 1ull << 31;        // flag in entry 0 of a first bucket
@@ -229,11 +228,31 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return v;
 }
 
+// v_mad_u32_u24 with the addend in a VGPR / as a scalar constant (one SGPR per VOP3 on gfx9)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+// m = 2 * m + (a != b): builds a bit mask from comparisons, two instructions per bit
+__device__ __forceinline__ uint32_t shift_in_ne(uint32_t m, uint32_t a, uint32_t b)
+{
+    asm("v_cmp_ne_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(b) : "vcc");
+    return m;
+}
+
 #ifdef SS_TIMING
 __device__ unsigned long long ss_timing[8];
 #define SS_T(i) do { if (t == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&ss_timing[i], now_ - t_prev); t_prev = now_; } } while (0)
 #else
-#define SS_T(i) do { } while (0)
+#define SS_T(i) asm volatile("; SSMARK " #i)
 #endif
 
 template <bool ALIGNED, int WAVES_PER_SIMD>
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
     const int t = threadIdx.x;
     const uint64_t kmask = (~0ull) >> (64 - 2 * K);
     const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
+    const uint32_t vc1 = ss::MMK_C1, vc2 = ss::MMK_C2;
 
     // the 16 bases of this lane are fetched one tile AHEAD: the HBM
     // round trip of the stream overlaps the previous tile's phases
@@ -280,10 +300,15 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
         uint32_t hm[PPT];
         {
             const uint32_t c0 = S.code[t], c1 = S.code[t + 1];
-            const uint64_t cc = (uint64_t)c0 | ((uint64_t)c1 << 32);
+            // windows of the m-mers 0..18 (bits 2i.. of c1:c0): 19 funnel shifts, then two multiply-adds
+            // per m-mer; the "+ i" of the packed word rides in the additive constant
+            uint32_t x[PPT + 3];
+            x[0] = c0;
 #pragma unroll
-            for (int i = 0; i < PPT; i++)
-                hm[i] = (ss::mmkey((uint32_t)(cc >> (2 * i))) & ss::KEY_MASK) | (uint32_t)i;
+            for (int i = 1; i < PPT; i++) x[i] = __builtin_amdgcn_alignbit(c1, c0, 2 * i);
+            x[PPT] = c1; x[PPT + 1] = c1 >> 2; x[PPT + 2] = c1 >> 4;
+#pragma unroll
+            for (int i = 0; i < PPT; i++) hm[i] = mad24(x[i + 3], vc2, mad24s(x[i], vc1, ss::MMK_C0 + (uint32_t)i));
             // chunk c of lane t lives at hm4[c * MT + t]: consecutive lanes touch consecutive 16-byte
             // words (a lane-major layout makes every b128 access a 4-way bank conflict)
             uint4 *dst = reinterpret_cast<uint4 *>(S.hm) + t;
@@ -327,11 +352,19 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             }
             // run starts as a bit mask: position j starts a run if it is live and (j == 0, or j-1 is
             // not live, or the minimizer changed)
+#ifdef SS_OLD_CHG
             uint32_t chg = 1u;
 #pragma unroll
             for (int j = 1; j < PPT; j++) chg |= (uint32_t)(mh[j] != mh[j - 1]) << j;
+#else
+            uint32_t chg = 0u;
+#pragma unroll
+            for (int j = PPT - 1; j >= 1; j--) chg = shift_in_ne(chg, mh[j], mh[j - 1]);   // bit j-1 <- (mh[j] != mh[j-1])
+            chg = (chg << 1) | 1u;
+#endif
             need = live & (chg | (~live << 1));
         }
+        SS_T(11);
         // wave prefix sum of the run counts, one LDS atomic per wave; then every lane walks ITS runs
         // (about two, at most a handful: the loop is as long as the busiest lane of the wave) instead
         // of testing all 16 positions.  The only per-position datum a run needs, the minimizer's
@@ -411,6 +444,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             }
         };
 
+        SS_T(20);
         // ---- phase 2: one directory lookup per run ----------------------------------------------
         {
             const uint32_t n1 = min(S.cnt[0], (uint32_t)Q1CAP);
@@ -752,7 +786,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct ImageHeader {
-    char magic[8];          // "SSIDX03\0"
+    char magic[8];          // "SSIDX04\0"
     int32_t k, layout;
     uint64_t n_rows, n_distinct, n_slots, n_buckets;
     uint32_t n_dir, bloom_bits;
@@ -791,7 +825,7 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX03", 8);
+    memcpy(h.magic, "SSIDX04", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
     h.n_dir = db->n_dir;
@@ -812,7 +846,7 @@ int ss_db_import(const char *path, ss_db **out)
     FILE *f = fopen(path, "rb");
     if (!f) return SS_EIO;
     ImageHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX03", 8) != 0 || h.layout != 1 || h.k != 31 ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX04", 8) != 0 || h.layout != 1 || h.k != 31 ||
         h.n_slots == 0 || h.n_dir == 0 || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         fclose(f);
         return SS_EINVAL;

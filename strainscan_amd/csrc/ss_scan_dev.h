@@ -10,32 +10,27 @@ constexpr int TILE = SCAN_THREADS * PPT;       // bytes of the base stream per t
 
 // ---------------------------------------------------------------------------------------------
 // 16 ASCII bases (4 dwords) -> 32 bits of 2-bit codes (base i at bits 2i) + 16 invalid flags.
-// SWAR: no per-byte loop, no LDS lookup table.
+// SWAR + byte permute + byte dot products: no per-byte loop, no LDS lookup table, no multiplies.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zero_bytes(uint32_t v)
-{   // 0x80 in every byte of v that is zero (exact form, no borrow artefacts)
-    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
-}
-
-__device__ __forceinline__ void encode4(uint32_t w, uint32_t &code8, uint32_t &bad4)
-{
-    uint32_t x = (w & 0xDFDFDFDFu) ^ 0x41414141u;           // A->00 C->02 G->06 T->15 (either case)
-    uint32_t ok = zero_bytes(x) | zero_bytes(x ^ 0x02020202u) | zero_bytes(x ^ 0x06060606u) |
-                  zero_bytes(x ^ 0x15151515u);
-    bad4 = (((ok ^ 0x80808080u) >> 7) * 0x01020408u) >> 24; // bit i = byte i is not ACGT
-    uint32_t c = (w >> 1) & 0x03030303u;                    // (ascii >> 1) & 3 per byte
-    code8 = (c * 0x01041040u) >> 24;                        // pack the four 2-bit fields
-}
-
+// Per dword: code bytes c = (ascii >> 1) & 3; a byte permute looks up the upper-case letter each
+// code stands for ('A','C','T','G'), so one xor with the case-folded input leaves a non-zero byte
+// exactly where the base is not ACGT/acgt; v_dot4_u32_u8 packs the four 2-bit codes (weights
+// 1,4,16,64) and the four flags (weights 1,2,4,8 / 16,..,128 on 0x80 bytes) in one instruction each.
 __device__ __forceinline__ void encode16(const uint32_t w[4], uint32_t &code, uint32_t &inv)
 {
-    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-    encode4(w[0], c0, b0);
-    encode4(w[1], c1, b1);
-    encode4(w[2], c2, b2);
-    encode4(w[3], c3, b3);
-    code = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    inv = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+    uint32_t cb[4], fl[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t c = (w[d] >> 1) & 0x03030303u;
+        const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, c);          // code -> 'A' 'C' 'T' 'G'
+        const uint32_t diff = (w[d] & 0xDFDFDFDFu) ^ letter;
+        fl[d] = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;       // 0x80 where the byte is not a base
+        cb[d] = __builtin_amdgcn_udot4(c, 0x40100401u, 0u, false);
+    }
+    code = cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24);
+    const uint32_t lo = __builtin_amdgcn_udot4(fl[1], 0x80402010u, __builtin_amdgcn_udot4(fl[0], 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(fl[3], 0x80402010u, __builtin_amdgcn_udot4(fl[2], 0x08040201u, 0u, false), false);
+    inv = (lo | (hi << 8)) >> 7;                                                    // sums are 128 x the flag masks
 }
 
 // 16 bytes at `off` of the base stream; bytes at or beyond n read as '\n'.

@@ -375,3 +375,17 @@ def test_index_image_roundtrip(L, tmp_path):
     with pytest.raises(L.SSError):
         L.KmerDB.from_text(kfa5, 21, True).export(str(tmp_path / "flat.bin"))
     db.close()
+
+
+def test_tiny_databases(L):
+    """Many tiny databases (a 16-bucket directory each): the two directory buckets of a minimizer
+    often coincide or collide there, multi-entry buckets and 'moved' flags are the rule."""
+    from oracle import oracle as orc
+    for seed in range(40):
+        kfa, flat = _random_db_and_reads(9000 + seed, 24 + 8 * (seed % 9), 300, read_len=90)
+        fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+        want, want_valid = orc.jellyfish_count(kfa, [fq], k=31, upper=True)
+        db = L.KmerDB.from_text(kfa, 31, True)
+        db.scan_flat(flat)
+        assert np.array_equal(db.counts_rows(), want), seed
+        db.close()
