@@ -89,7 +89,10 @@ __host__ __device__ __forceinline__ uint32_t dir_bucket2(uint32_t mini, uint32_t
     const uint32_t b = dir_bucket1(mini, n_dir) + 1u + mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir - 1u);
     return b >= n_dir ? b - n_dir : b;
 }
-__host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return ((mini ^ (mini >> 13)) * 0x2545F491u) >> 18; }
+// 14-bit fingerprint: the LOW bits of the mix (the bucket index uses its high bits), never 0x3FFF so that
+// an empty entry (all ones) matches nothing
+__host__ __device__ __forceinline__ uint32_t dir_fp_of_mix(uint32_t h) { const uint32_t f = h & 0x3FFFu; return f < 0x3FFEu ? f : 0x3FFEu; }
+__host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return dir_fp_of_mix(dir_mix(mini)); }
 constexpr uint64_t DIR_MOVED = 1ull << 31;        // flag in entry 0 of a first bucket
 constexpr uint32_t START_MASK = 0x7FFFFFFFu;
 
@@ -173,12 +176,13 @@ struct QShared {
     uint32_t cnt[4];                   // n1, n2, n3
 };
 
-__device__ __forceinline__ uint64_t kmer_at(const QShared &S, uint32_t pos, uint64_t kmask)
+// the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
+__device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t &lo, uint32_t &hi)
 {
     const uint32_t w = pos >> 4, sh = 2 * (pos & 15);
-    const uint64_t lo = (uint64_t)S.code[w] | ((uint64_t)S.code[w + 1] << 32);
-    const uint64_t hi = (uint64_t)S.code[w + 2];
-    return (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & kmask;
+    const uint32_t a = S.code[w], b = S.code[w + 1], c = S.code[w + 2];
+    lo = __builtin_amdgcn_alignbit(b, a, sh);
+    hi = __builtin_amdgcn_alignbit(c, b, sh) & 0x3FFFFFFFu;
 }
 
 // the 15-mer starting at tile position p (p <= 4095: the halo word covers the last one)
@@ -203,12 +207,14 @@ __device__ __forceinline__ uint32_t aligned_mask(uint32_t hdr, uint32_t o0) { re
 // several database k-mers share a minimizer offset (repeated / colliding minimizer)
 __device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t multi, uint32_t cpos,
                                             uint64_t cand, const uint64_t *__restrict__ mkeys,
-                                            uint32_t *__restrict__ counts, uint64_t kmask)
+                                            uint32_t *__restrict__ counts)
 {
-    const uint64_t km = kmer_at(S, pos, kmask);
-    if (cand == km) {
+    uint32_t klo, khi;
+    kmer_at(S, pos, klo, khi);
+    if ((uint32_t)cand == klo && (uint32_t)(cand >> 32) == khi) {
         atomicAdd(&counts[cpos], 1u);
     } else if (multi) {
+        const uint64_t km = ((uint64_t)khi << 32) | klo;
         const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
         for (uint32_t q = 0; q < cnt; q++)
             if (mkeys[bstart + 1 + q] == km) { atomicAdd(&counts[bstart + 1 + q], 1u); break; }
@@ -265,7 +271,6 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
     static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
     const int t = threadIdx.x;
-    const uint64_t kmask = (~0ull) >> (64 - 2 * K);
     const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
     const uint32_t vc1 = ss::MMK_C1, vc2 = ss::MMK_C2;
 
@@ -423,20 +428,20 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
                 const uint32_t len = (run >> 12) & 31u;
                 for (uint32_t q = 0; q < len; q++) {
                     const uint32_t cpos = cand_slot(bstart, amask, q);
-                    if (cpos) settle_item(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts, kmask);
+                    if (cpos) settle_item(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts);
                 }
             }
         };
         // the directory entries (first bucket b1, second bucket behind the "moved" flag) that match run `run`
-        auto lookup_found = [&](const ulonglong2 &b1, uint32_t x, uint32_t run, uint32_t r1, bool queued) {
-            const uint64_t fp = ss::dir_fp(x);
-            // matching entries as a bit mask + selects (an indexed local array would live in scratch memory)
+        auto lookup_found = [&](const ulonglong2 &b1, uint32_t x, uint32_t h, uint32_t run, uint32_t r1, bool queued) {
+            const uint32_t fp = ss::dir_fp_of_mix(h);
+            // matching entries as a bit mask + selects (an indexed local array would live in scratch memory);
+            // 32-bit compares on the upper halves: a fingerprint is never 0x3FFF, so empty entries match nothing
             ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
-            if (b1.x != ss::EMPTY_KEY && (b1.x & ss::DIR_MOVED)) b2 = dir2[ss::dir_bucket2(x, n_dir)];   // a key of this bucket moved
-            uint32_t hits = (uint32_t)(b1.x != ss::EMPTY_KEY && (b1.x >> 50) == fp) |
-                            (uint32_t)(b1.y != ss::EMPTY_KEY && (b1.y >> 50) == fp) << 1 |
-                            (uint32_t)(b2.x != ss::EMPTY_KEY && (b2.x >> 50) == fp) << 2 |
-                            (uint32_t)(b2.y != ss::EMPTY_KEY && (b2.y >> 50) == fp) << 3;
+            if (((uint32_t)b1.x & (uint32_t)ss::DIR_MOVED) && (uint32_t)(b1.x >> 32) != 0xFFFFFFFFu)   // a key of this bucket moved
+                b2 = dir2[ss::dir_bucket2(x, n_dir)];
+            uint32_t hits = (uint32_t)(((uint32_t)(b1.x >> 32) >> 18) == fp) | (uint32_t)(((uint32_t)(b1.y >> 32) >> 18) == fp) << 1 |
+                            (uint32_t)(((uint32_t)(b2.x >> 32) >> 18) == fp) << 2 | (uint32_t)(((uint32_t)(b2.y >> 32) >> 18) == fp) << 3;
             while (hits) {
                 const uint32_t d = (uint32_t)__ffs(hits) - 1u;
                 hits &= hits - 1u;
@@ -454,32 +459,33 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
 #endif
             constexpr int RPL = SS_RPL;
             for (uint32_t r0 = 0; r0 < n1; r0 += RPL * MT) {
-                uint32_t e[RPL], xs[RPL];
+                uint32_t e[RPL], xs[RPL], hs[RPL];
                 ulonglong2 bk[RPL];
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     const uint32_t r = r0 + u * MT + t;
                     e[u] = (r < n1) ? S.q1[r] : Q1_NONE;                                 // no run: all ones
                     xs[u] = mmer_at(S, (r < n1) ? (e[u] >> 17) : 0u);
+                    hs[u] = ss::dir_mix(xs[u]);                                          // one mix per run: Bloom bit, bucket, fingerprint
                 }
                 if (bloom) {
                     // one probe of an L2-resident bit array kills most of the ~90 % of the runs whose
                     // minimizer is not in the database before they cost a random HBM sector each
                     uint32_t bw[RPL];
 #pragma unroll
-                    for (int u = 0; u < RPL; u++) bw[u] = bloom[ss::dir_mix(xs[u]) >> (bloom_shift + 5)];
+                    for (int u = 0; u < RPL; u++) bw[u] = bloom[hs[u] >> (bloom_shift + 5)];
 #pragma unroll
                     for (int u = 0; u < RPL; u++)
-                        if (!((bw[u] >> ((ss::dir_mix(xs[u]) >> bloom_shift) & 31u)) & 1u)) e[u] = Q1_NONE;
+                        if (!((bw[u] >> ((hs[u] >> bloom_shift) & 31u)) & 1u)) e[u] = Q1_NONE;
                 }
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     bk[u] = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
-                    if (e[u] != Q1_NONE) bk[u] = dir2[ss::dir_bucket1(xs[u], n_dir)];
+                    if (e[u] != Q1_NONE) bk[u] = dir2[ss::mulhi32(hs[u], n_dir)];
                 }
 #pragma unroll
                 for (int u = 0; u < RPL; u++)
-                    if (e[u] != Q1_NONE) lookup_found(bk[u], xs[u], e[u], r0 + u * MT + t, true);
+                    if (e[u] != Q1_NONE) lookup_found(bk[u], xs[u], hs[u], e[u], r0 + u * MT + t, true);
             }
         }
         __syncthreads();
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
                 }
 #pragma unroll
                 for (int u = 0; u < U3; u++)
-                    if (cps[u]) settle_item(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, kmask);
+                    if (cps[u]) settle_item(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts);
             }
         }
         // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
                 const uint32_t p = (uint32_t)(t * PPT) + (m & 31u);
                 const uint32_t run = (p << 17) | (len << 12) | (uint32_t)(t * PPT + j);
                 const uint32_t x = mmer_at(S, p);
-                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], x, run, 0u, false);
+                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], x, ss::dir_mix(x), run, 0u, false);
             }
         }
         SS_T(4);
@@ -786,7 +792,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct ImageHeader {
-    char magic[8];          // "SSIDX04\0"
+    char magic[8];          // "SSIDX05\0"
     int32_t k, layout;
     uint64_t n_rows, n_distinct, n_slots, n_buckets;
     uint32_t n_dir, bloom_bits;
@@ -825,7 +831,7 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX04", 8);
+    memcpy(h.magic, "SSIDX05", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
     h.n_dir = db->n_dir;
@@ -846,7 +852,7 @@ int ss_db_import(const char *path, ss_db **out)
     FILE *f = fopen(path, "rb");
     if (!f) return SS_EIO;
     ImageHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX04", 8) != 0 || h.layout != 1 || h.k != 31 ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX05", 8) != 0 || h.layout != 1 || h.k != 31 ||
         h.n_slots == 0 || h.n_dir == 0 || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         fclose(f);
         return SS_EINVAL;
