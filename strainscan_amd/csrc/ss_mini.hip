@@ -3,11 +3,12 @@
 // Why: with the flat open-address table (ss_scan.hip) every one of the 120 k-mers of a 150-bp
 // read costs a random 64-byte HBM sector although ~95 % of them are not in the database
 // (profiles/r01a: 213 GB fetched per 22 GB of algorithmic bytes).  Consecutive k-mers of a read
-// share their minimizer (the 15-mer with the smallest hash inside the k-mer) for ~9 positions
+// share their minimizer (the 15-mer with the smallest ordering key inside the k-mer) for ~9 positions
 // on average, so:
 //   * database k-mers are stored grouped by minimizer ("buckets"), contiguous in HBM;
-//   * a small exact directory minimizer -> bucket start (8 B per bucket, tens of MB: Infinity-
-//     Cache/L2 resident) answers "no database k-mer has this minimizer" for most read windows;
+//   * a one-probe Bloom filter (<= 4 MB: L2 resident) and behind it a small exact directory
+//     minimizer -> bucket (tens of MB) answer "no database k-mer has this minimizer" for most
+//     read windows;
 //   * a lane probes the directory once per run of equal minimizers (~13 per read instead of
 //     120) and touches a bucket only when the minimizer exists.
 // Counting semantics are unchanged and exact: a k-mer is looked up in the bucket of ITS OWN
@@ -24,7 +25,8 @@
 //                         a hit costs two dependent loads, a miss inside an existing bucket one.
 //   d_counts[n_slots] u32 occurrences per slot (same index; header slots unused)
 //   d_dir[n_dir][2]   u64 cuckoo directory of 16-byte buckets (two entries each, two hash functions).
-//                         entry = 14-bit fingerprint of the minimizer hash << 50 | multi << 49 |
+//                         keyed by the minimizer itself (the 30-bit m-mer).
+//                         entry = 14-bit fingerprint (never 0x3FFF) << 50 | multi << 49 |
 //                                 offset mask (17 bits) << 32 | moved flag << 31 | bucket start (31 bits)
 //                         i.e. the bucket's header travels with the directory entry: a found run goes
 //                         straight to its candidate k-mers (dir -> candidate: two dependent round trips
@@ -33,7 +35,9 @@
 //                         exactly one bucket, so every fingerprint match is simply tried.  A key lives
 //                         in its FIRST bucket unless that was full when it arrived; "moved" on a first
 //                         bucket's entry 0 means a key of that bucket lives in its second bucket, which is
-//                         then read too (a few % of the lookups).  EMPTY = ~0.
+//                         then read too (a few % of the lookups; the second bucket is never the first
+//                         one again).  EMPTY = ~0.
+//   d_bloom[2^b/32]   u32 bit dir_mix(minimizer) >> (32 - b) set for every bucket
 #include "ss_common.h"
 #include "ss_scan_dev.h"
 
