@@ -84,8 +84,10 @@ struct ss_db {
     hipEvent_t stage_free[2] = {nullptr, nullptr};
     std::atomic<uint64_t> launches{0};
     // per-worker resources of the parallel ingest path (allocated on first use, kept for the handle's life)
-    struct Worker { char *h_buf = nullptr; char *d_buf = nullptr; hipStream_t stream = nullptr; uint64_t cap = 0; };
-    Worker workers[32];
+    struct Worker { char *h_buf = nullptr; char *d_buf = nullptr; hipStream_t stream = nullptr; uint64_t cap = 0;
+                    char *t_buf = nullptr; uint64_t t_cap = 0; };   // t_buf: private copy of the text chunk being parsed
+    static constexpr int MAX_WORKERS = 64;
+    Worker workers[MAX_WORKERS];
     static void free_workers(Worker *w, int n);
     uint64_t device_bytes = 0;
 };
@@ -94,7 +96,7 @@ namespace ss {
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
 using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
-                        uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink);
+                        uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink, bool copy = true);
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles);

@@ -92,17 +92,20 @@ namespace ss {
 // must use the sequential reader for this file
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled)
 {
+    // SS_INGEST_ZEROCOPY=1: the kernel streams the flat block straight out of the pinned host buffer
+    // (every base is read once, with 16-byte loads) instead of waiting for a DMA copy of it
+    static const bool zero_copy = getenv("SS_INGEST_ZEROCOPY") && atoi(getenv("SS_INGEST_ZEROCOPY")) != 0;
     return parse_file_parallel(db->workers, path, 0, 1, n_records, n_bases, handled,
-                               [db](const char *, char *d_buf, uint64_t len, hipStream_t stream) {
-                                   return ss_scan_flat_dev(db, d_buf, len, stream);
-                               });
+                               [db](const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream) {
+                                   return ss_scan_flat_dev(db, zero_copy ? h_buf : d_buf, len, stream);
+                               }, !zero_copy);
 }
 
 // Parse `path` with worker threads; each flat block (already copied to the worker's device buffer
 // on `stream`) is handed to `sink`.  Chunks c with c % shard_world != shard_rank are skipped
 // (multi-GPU read sharding without parsing the other ranks' share).
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
-                        uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink)
+                        uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink, bool copy)
 {
     *handled = false;
     const int fd = open(path, O_RDONLY);
@@ -131,11 +134,21 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     for (size_t c = 0; c < n_chunks; c++) max_chunk = std::max(max_chunk, starts[c + 1] - starts[c]);
     if (max_chunk > 8 * CHUNK) { munmap((void *)t, n); return SS_OK; }   // a giant record: sequential path
 
-    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 24u);
+    // parse threads: each owns a text buffer, a pinned buffer, a device buffer and a stream.  Measured on
+    // the MI355X host (scripts/bench_e2e.py): 21 M reads/s per thread up to ~20 threads (256 M reads/s =
+    // 79 GB/s of FASTQ text, 39 GB/s over PCIe), falling again beyond 24.  SS_INGEST_THREADS overrides.
+    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 20u);
+    if (const char *e = getenv("SS_INGEST_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));
+    nthreads = std::min<unsigned>(nthreads, (unsigned)ss_db::MAX_WORKERS);
     nthreads = (unsigned)std::min<size_t>(nthreads, n_chunks);
     std::atomic<size_t> next(0);
     std::atomic<uint64_t> recs(0), bases(0);
     std::atomic<int> err(SS_OK);
+    // chunks are pread() into a private buffer before parsing: parsing the mapping directly takes a minor page
+    // fault every 4 KB (1.2 M faults per 5 GB) and runs at half the rate.  SS_INGEST_PREAD=0 parses the mapping.
+    const bool use_pread = !(getenv("SS_INGEST_PREAD") && atoi(getenv("SS_INGEST_PREAD")) == 0);
+    const int fd2 = use_pread ? open(path, O_RDONLY) : -1;
+    if (use_pread && fd2 < 0) { munmap((void *)t, n); return SS_EIO; }
     int device = 0;
     hipGetDevice(&device);
     auto worker = [&](unsigned wid) {
@@ -159,9 +172,27 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
         for (size_t c; err == SS_OK && (c = next.fetch_add(1)) < n_chunks;) {
             if ((int)(c % (size_t)shard_world) != shard_rank) continue;
             uint64_t out_len = 0, nr = 0;
-            int rc = ss_fastx_to_flat(t + starts[c], starts[c + 1] - starts[c], h_buf, &out_len, &nr);
+            const char *src = t + starts[c];
+            const uint64_t clen = starts[c + 1] - starts[c];
+            if (use_pread) {
+                if (W.t_cap < clen) {
+                    free(W.t_buf);
+                    W.t_cap = std::max<uint64_t>(max_chunk, CHUNK + CHUNK / 8);
+                    W.t_buf = (char *)malloc(W.t_cap);
+                    if (!W.t_buf) { W.t_cap = 0; err = SS_ENOMEM; break; }
+                }
+                uint64_t got = 0;
+                while (got < clen) {
+                    const ssize_t r = pread(fd2, W.t_buf + got, clen - got, (off_t)(starts[c] + got));
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                if (got != clen) { err = SS_EIO; break; }
+                src = W.t_buf;
+            }
+            int rc = ss_fastx_to_flat(src, clen, h_buf, &out_len, &nr);
             if (rc != SS_OK) { err = rc; break; }
-            if (hipMemcpyAsync(d_buf, h_buf, out_len, hipMemcpyHostToDevice, stream) != hipSuccess) { err = SS_EHIP; break; }
+            if (copy && hipMemcpyAsync(d_buf, h_buf, out_len, hipMemcpyHostToDevice, stream) != hipSuccess) { err = SS_EHIP; break; }
             rc = sink(h_buf, d_buf, out_len, stream);
             if (rc != SS_OK) { err = rc; break; }
             if (hipStreamSynchronize(stream) != hipSuccess) { err = SS_EHIP; break; }   // buffers are reused
@@ -172,6 +203,7 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     std::vector<std::thread> pool;
     for (unsigned w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto &th : pool) th.join();
+    if (fd2 >= 0) close(fd2);
     munmap((void *)t, n);
     if (err != SS_OK) return err;
     *n_records += recs;
@@ -188,6 +220,7 @@ void ss_db::free_workers(Worker *w, int n)
         if (w[i].h_buf) hipHostFree(w[i].h_buf);
         if (w[i].d_buf) hipFree(w[i].d_buf);
         if (w[i].stream) hipStreamDestroy(w[i].stream);
+        free(w[i].t_buf);
         w[i] = Worker();
     }
 }
@@ -205,7 +238,7 @@ struct ss_reads {
     std::mutex mu;
     uint64_t n_records = 0, n_bases = 0, device_bytes = 0;
     bool has_cut_record = false;      // a record longer than a block was cut with a 30-base overlap (k = 31 only)
-    ss_db::Worker workers[32];
+    ss_db::Worker workers[ss_db::MAX_WORKERS];
 };
 
 extern "C" {
@@ -235,7 +268,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
         if (!paths[i]) { rc = SS_EINVAL; break; }
         if (!paths[i][0]) continue;
         bool handled = false;
-        rc = ss::parse_file_parallel(R->workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep);
+        rc = ss::parse_file_parallel(R->workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep, true);
         if (rc == SS_OK && !handled) seq_files.push_back(i);
     }
     if (rc == SS_OK && !seq_files.empty()) {
@@ -279,7 +312,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
         recs += srecs;
         bases += sbases;
     }
-    ss_db::free_workers(R->workers, 32);
+    ss_db::free_workers(R->workers, ss_db::MAX_WORKERS);
     if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
     if (hipDeviceSynchronize() != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
     R->n_records = recs;
@@ -292,7 +325,7 @@ int ss_reads_destroy(ss_reads *R)
 {
     if (!R) return SS_OK;
     for (auto &b : R->blocks) hipFree(b.d);
-    ss_db::free_workers(R->workers, 32);
+    ss_db::free_workers(R->workers, ss_db::MAX_WORKERS);
     delete R;
     return SS_OK;
 }

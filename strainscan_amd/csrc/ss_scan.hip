@@ -290,11 +290,7 @@ int ss_db_destroy(ss_db *db)
     hipFree(db->d_counts);
     hipFree(db->d_slot_of_row);
     hipFree(db->d_row_valid);
-    for (auto &w : db->workers) {
-        if (w.h_buf) hipHostFree(w.h_buf);
-        if (w.d_buf) hipFree(w.d_buf);
-        if (w.stream) hipStreamDestroy(w.stream);
-    }
+    ss_db::free_workers(db->workers, ss_db::MAX_WORKERS);
     for (int i = 0; i < 2; i++) {
         if (db->h_stage[i]) hipHostFree(db->h_stage[i]);
         if (db->d_stage[i]) hipFree(db->d_stage[i]);
