@@ -161,8 +161,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.check(_lib.lib().ss_set_device(local), "ss_set_device")
-    if world > 1:
+    # SS_BENCH_FORCE_PIPELINE=2: run the N > 1 code path (async RCCL all-reduce + deferred node reduction) in a
+    # one-rank group, to test it on a single-GPU box
+    self_group = world == 1 and os.environ.get("SS_BENCH_FORCE_PIPELINE") == "2"
+    if world > 1 or self_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t0 = time.time()
@@ -188,32 +192,55 @@ def main():
     log("[bench] reads: %d x %d bp = %.2f GB in HBM (%.1f s)" % (args.reads, READ_LEN, reads.numel() / 1e9,
                                                                  time.time() - t0))
 
-    counts_rows = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    # two row-count buffers: with N > 1 the all-reduce of batch i runs on RCCL's stream while batch i + 1
+    # is being scanned (the per-node reduction of batch i is enqueued one step later, after the collective)
+    bufs = [torch.zeros(n_rows, dtype=torch.int32, device=dev) for _ in range(2)]
     stats = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    pipelined = world > 1 or bool(os.environ.get("SS_BENCH_FORCE_PIPELINE"))
+    state = dict(k=0, pending=None, last=bufs[0])
+
+    def finish(work, buf):
+        if work is not None:
+            work.wait()                        # the compute stream waits for the collective
+        nodes.reduce_dev(buf.data_ptr(), db.row_valid_dev, stats.data_ptr(), stream)
+        state["last"] = buf
+
+    def drain():
+        if state["pending"] is not None:
+            finish(*state["pending"])
+            state["pending"] = None
 
     def step(i=None):
+        buf = bufs[state["k"] % 2]
+        state["k"] += 1
         db.reset(stream)
         if i is not None:
             ev[i][0].record()
         db.scan_flat_dev(reads.data_ptr(), reads.numel(), stream)
         if i is not None:
             ev[i][1].record()
-        db.counts_rows_dev(counts_rows.data_ptr(), stream)
-        if world > 1:
-            dist.all_reduce(counts_rows)       # RCCL sum of the per-GPU hit-count vectors
-        nodes.reduce_dev(counts_rows.data_ptr(), db.row_valid_dev, stats.data_ptr(), stream)
+        db.counts_rows_dev(buf.data_ptr(), stream)
+        if not pipelined:
+            finish(None, buf)
+            return
+        # RCCL sum of the per-GPU hit-count vectors (int32 view of uint32: two's-complement add)
+        work = dist.all_reduce(buf, async_op=True) if (world > 1 or self_group) else None
+        drain()                                # batch i - 1: wait for its collective, reduce its nodes
+        state["pending"] = (work, buf)
 
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -223,6 +250,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    counts_rows = state["last"]
     ms_per_step = dt / args.steps * 1e3
     reads_per_s = args.reads * world * args.steps / dt
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -282,7 +310,7 @@ def main():
                    roofline=roofline, cpu_baseline=cpu,
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum())))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or self_group:
         dist.destroy_process_group()
 
 
