@@ -9,6 +9,7 @@ passes become bit-plane popcounts and masked radix selects on the MI355X
 coordinate descent on exact per-pattern statistics (ss_enet.hip); see SURVEY.md Appendix B/C.
 """
 import pickle
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import scipy.sparse as sp
@@ -19,6 +20,7 @@ CV_NITER = 20        # :433
 NALPHA = 50          # :434
 MAX_NITER = 5000     # :435
 TEST_SIZE = 0.5      # :436
+_SPLIT_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ss-shufflesplit")
 MAX_PRESCAN_ITER = 15  # :302
 
 
@@ -114,13 +116,15 @@ def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
     return out_columns, out_strain, strain_cov, strain_val, final_src, depth
 
 
-def enet_cv_fit(img, cols, py, keep_rows, trace=None):
+def enet_cv_fit(img, cols, py, keep_rows, trace=None, split=None):
     """ElasticNetCV -> lasso_mpm -> ElasticNet (:433-456) on the selected columns / kept rows.
-    -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests."""
+    -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests.  `split`: a future
+    of shuffle_split_test_bits(n, ...) started earlier (the splits depend on the number of kept rows only)."""
     p = len(cols)
     kept = np.nonzero(keep_rows)[0]
     n = int(kept.size)
-    bits, n_test = L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
+    bits, n_test = split.result() if split is not None else L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
+    assert bits.size == n
     fold = np.zeros(img.K, np.uint32)
     fold[kept] = bits | np.uint32(1 << 31)
     y_dev = img.u32(np.where(keep_rows, py, 0))
@@ -158,16 +162,22 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     py = np.asarray(input_y).astype(np.int64)
     py_u = py * ln
     cutoff = msn * ksize
+    with np.errstate(invalid="ignore"):
+        drop = (py < npp25) | (py > npp75) | (py > npp_out)                    # :402-415
+    # ShuffleSplit's 20 permutations (numpy's sequential legacy generator: ~65 ms per million rows) depend on
+    # the NUMBER of kept rows only: for large clusters they run on a host thread while the matrix is packed
+    # and the pre-scan runs on the device
+    n_keep = int(drop.size - np.count_nonzero(drop))
+    split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, n_keep, CV_NITER, TEST_SIZE, 0) \
+        if n_keep >= 200000 else None
     img = L2.ClusterImage(X)
     try:
         out_columns, out_strains, strain_cov, strain_val, final_src, depth = pre_scan(
             img, py, py_u, sid, cutoff, l2, pmode, emode)
         if len(out_columns) == 1:                                              # :379-382
             return dict(zip(out_strains, [1])), dict(zip(out_strains, [depth])), strain_cov, strain_val, final_src
-        with np.errstate(invalid="ignore"):
-            drop = (py < npp25) | (py > npp75) | (py > npp_out)                # :402-415
         print("Pre-scan finished, now we will start ElasticNet fitting...")
-        coef = enet_cv_fit(img, out_columns, py, ~drop, trace)
+        coef = enet_cv_fit(img, out_columns, py, ~drop, trace, split)
     finally:
         img.close()
     lasso_coef = np.atleast_1d(coef)
