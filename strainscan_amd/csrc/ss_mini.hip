@@ -154,6 +154,7 @@ struct Ent {
 #define SS_NT 64
 #endif
 constexpr int MT = SS_NT;
+static_assert(MT == 64, "one wave per workgroup: phase 2 compacts with ballots and keeps its counters in scalar registers");
 #ifndef SS_Q1CAP
 #define SS_Q1CAP (4 * SS_NT)
 #endif
@@ -167,17 +168,20 @@ static_assert(Q1CAP <= 4096, "q2 keeps a q1 index in 12 bits");
 // costs a full wave instruction stream for one lane.
 constexpr int MLANES = MT - 2;
 constexpr int MTILE = MLANES * PPT;
-constexpr uint32_t Q1_NONE = 0xFFFFFFFFu;
 
 struct QShared {
     uint32_t code[MT + 2];
     uint16_t inv[MT + 2];
-    uint32_t q1[Q1CAP + 64];           // run:   minimizer position in the tile << 17 | len << 12 | tile position (+64 dump slots)
+    uint32_t q1[Q1CAP + 64];           // run:   len << 12 | tile position of its first k-mer (+64 dump slots)
+    alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
     alignas(16) union {                // hm is dead once every lane has its minimizers (barrier after phase 1)
-        uint32_t hm[MT * PPT];   // packed keys of the m-mers: 16-byte chunk c of lane t at uint4 index c * MT + t
-        uint64_t q2[Q1CAP];            // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1 index
+        uint32_t hm[MT * PPT];         // packed keys of the m-mers: 16-byte chunk c of lane t at uint4 index c * MT + t
+        struct {
+            uint64_t q1b[Q1CAP];       // run that passed the Bloom filter: mix << 32 | minimizer offset in the first k-mer << 17 | q1 entry
+            uint64_t q2[Q1CAP];        // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1b index
+        } q;
     };
-    uint32_t cnt[4];                   // n1, n2, n3
+    uint32_t cnt[4];                   // [1] = found runs
 };
 
 // the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
@@ -189,12 +193,11 @@ __device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t
     hi = __builtin_amdgcn_alignbit(c, b, sh) & 0x3FFFFFFFu;
 }
 
-// the 15-mer starting at tile position p (p <= 4095: the halo word covers the last one)
+// the 15-mer starting at tile position p (one funnel shift over two code words)
 __device__ __forceinline__ uint32_t mmer_at(const QShared &S, uint32_t p)
 {
-    const uint32_t w = p >> 4, sh = 2 * (p & 15);
-    const uint64_t lo = (uint64_t)S.code[w] | ((uint64_t)S.code[w + 1] << 32);
-    return (uint32_t)(lo >> sh) & ss::M30;
+    const uint32_t w = p >> 4;
+    return __builtin_amdgcn_alignbit(S.code[w + 1], S.code[w], 2 * (p & 15)) & ss::M30;
 }
 
 // A found run carries the bucket's offset mask shifted so that the offset of the run's FIRST k-mer
@@ -259,10 +262,18 @@ __device__ __forceinline__ uint32_t shift_in_ne(uint32_t m, uint32_t a, uint32_t
 }
 
 #ifdef SS_TIMING
-__device__ unsigned long long ss_timing[8];
-#define SS_T(i) do { if (t == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&ss_timing[i], now_ - t_prev); t_prev = now_; } } while (0)
+// debug build: cycles a wave spends between the phase markers, accumulated in registers and flushed once per block
+__device__ unsigned long long ss_timing[32];
+#define SS_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[(i) & 7] += (uint32_t)(now_ - t_prev); t_prev = now_; } while (0)
 #else
 #define SS_T(i) asm volatile("; SSMARK " #i)
+#endif
+// debug builds -DSS_STOP_AFTER=n end every tile after phase n (1 = m-mer keys, 2 = runs queued, 3 = directory):
+// dynamic instruction counts and times per phase (scripts/gpu_stop.sh); results are then of course wrong
+#ifdef SS_STOP_AFTER
+#define SS_STOP(n) if (SS_STOP_AFTER == (n)) { __syncthreads(); continue; }
+#else
+#define SS_STOP(n)
 #endif
 
 template <bool ALIGNED, int WAVES_PER_SIMD>
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
     }
 #ifdef SS_TIMING
     unsigned long long t_prev = __builtin_readcyclecounter();
+    uint32_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             encode16(wn, code, inv);
             S.code[t] = code;
             S.inv[t] = (uint16_t)inv;
-            if (t < 4) S.cnt[t] = 0;
+            if (t == 1) S.cnt[1] = 0;
             const uint64_t nt = tile + gridDim.x;
             if (nt < n_tiles) {
                 const uint64_t nb = nt * (uint64_t)MTILE;
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
         }
         __syncthreads();
         SS_T(1);
+        SS_STOP(1)
 
         // ---- phase 1b: minimizer of the lane's 16 k-mers, runs ------------------------------------
         uint32_t live = 0;
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
         }
         uint32_t need = 0;
         uint32_t mh[PPT];
+        mh[0] = 0; mh[PPT - 1] = 0;
         if (live) {
             // k-mer j covers m-mers j..j+16 = own m-mers j..15 (index j..15) and the next lane's
             // m-mers 0..j (index 16..16+j): suffix minima over the own packed words, prefix minima
@@ -361,50 +375,56 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             }
             // run starts as a bit mask: position j starts a run if it is live and (j == 0, or j-1 is
             // not live, or the minimizer changed)
-#ifdef SS_OLD_CHG
-            uint32_t chg = 1u;
-#pragma unroll
-            for (int j = 1; j < PPT; j++) chg |= (uint32_t)(mh[j] != mh[j - 1]) << j;
-#else
             uint32_t chg = 0u;
 #pragma unroll
             for (int j = PPT - 1; j >= 1; j--) chg = shift_in_ne(chg, mh[j], mh[j - 1]);   // bit j-1 <- (mh[j] != mh[j-1])
             chg = (chg << 1) | 1u;
-#endif
             need = live & (chg | (~live << 1));
+            // the minimizer's index (low byte of the packed word) of all 16 positions: one 16-byte store;
+            // phase 2 reads the byte of a run's first position (the walk below no longer gathers it)
+            uint32_t pk[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t lo = __builtin_amdgcn_perm(mh[4 * w + 1], mh[4 * w], 0x0c0c0400u);
+                const uint32_t hi = __builtin_amdgcn_perm(mh[4 * w + 3], mh[4 * w + 2], 0x0c0c0400u);
+                pk[w] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+            }
+            reinterpret_cast<uint4 *>(S.ib)[t] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
-        SS_T(11);
-        // wave prefix sum of the run counts, one LDS atomic per wave; then every lane walks ITS runs
-        // (about two, at most a handful: the loop is as long as the busiest lane of the wave) instead
-        // of testing all 16 positions.  The only per-position datum a run needs, the minimizer's
-        // index (low byte of the packed word), is gathered into four registers by byte permutes.
+        SS_T(6);
+        // A run that reaches the end of a lane goes on in the next lane when that lane's first k-mer has
+        // the same minimizer (same packed word: the left lane counts the right lane's m-mer i as 16 + i).
+        // The left lane then owns the whole run (at most 16 k-mers: phase 3 gives a run 16 lanes; a longer
+        // one stays cut) and the right lane drops its first run: a third fewer runs per tile.
+        const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
+        uint32_t ext12 = 0;                          // k-mers my last run takes over from the next lane, << 12
+        {
+            const uint32_t first = (uint32_t)__ffs(stop >> 1);                                   // length of the run starting at 0
+            const uint32_t ownlast = (live >> 15) ? (uint32_t)__clz(need) - 15u : 0u;            // 16 - start of my last run
+            const uint32_t l_mh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mh[PPT - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+            const uint32_t l_own = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ownlast, 0x138, 0xf, 0xf, false);
+            const bool cont = (live & 1u) && l_own && l_mh == mh[0] + 16u && l_own + first <= 16u;
+            const uint32_t give = cont ? first << 12 : 0u;
+            ext12 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)give, 0x130, 0xf, 0xf, false);                         // wave_shl:1
+            if (cont) need &= ~1u;
+        }
+        // wave prefix sum of the run counts; then every lane walks ITS runs (about two, at most a handful:
+        // the loop is as long as the busiest lane of the wave) instead of testing all 16 positions
         uint32_t ovf = 0;   // runs that did not fit q1 (processed inline below)
+        uint32_t n1;
         {
             const uint32_t mine = (uint32_t)__popc(need);
             const uint32_t incl = wave_inclusive_sum(mine);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t wbase = 0;
-            if ((t & 63) == 63 && total) wbase = atomicAdd(&S.cnt[0], total);
-            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
-            const uint32_t mybase = wbase + incl - mine;
+            n1 = min((uint32_t)__builtin_amdgcn_readlane((int)incl, 63), (uint32_t)Q1CAP);
+            const uint32_t mybase = incl - mine;
             if (need) {
-                uint32_t pk[4];
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const uint32_t lo = __builtin_amdgcn_perm(mh[4 * w + 1], mh[4 * w], 0x0c0c0400u);
-                    const uint32_t hi = __builtin_amdgcn_perm(mh[4 * w + 3], mh[4 * w + 2], 0x0c0c0400u);
-                    pk[w] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
-                }
-                const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
-                const uint32_t dummy = (uint32_t)Q1CAP + (uint32_t)(t & 63);   // where entries beyond the capacity go
-                const uint32_t base = ((uint32_t)(t * PPT) << 17) | (uint32_t)(t * PPT);
+                const uint32_t dummy = (uint32_t)Q1CAP + (uint32_t)t;   // where entries beyond the capacity go
                 uint32_t idx = mybase;
-                for (uint32_t nd = need; nd; nd &= nd - 1u, idx++) {
+                for (uint32_t nd = need; nd; idx++) {
                     const uint32_t j = (uint32_t)__ffs(nd) - 1u;
-                    const uint32_t word = (j & 8u) ? ((j & 4u) ? pk[3] : pk[2]) : ((j & 4u) ? pk[1] : pk[0]);
-                    const uint32_t i5 = (word >> ((j & 3u) * 8u)) & 31u;
-                    const uint32_t len = (uint32_t)__ffs(stop >> (j + 1u));   // positions until the next run / gap
-                    S.q1[min(idx, dummy)] = base + (i5 << 17) + (len << 12) + j;
+                    nd &= nd - 1u;
+                    const uint32_t len12 = ((uint32_t)__ffs(stop >> (j + 1u)) << 12) + (nd ? 0u : ext12);   // until the next run / gap
+                    S.q1[min(idx, dummy)] = len12 + (uint32_t)(t * PPT) + j;
                 }
                 if (mybase + mine > (uint32_t)Q1CAP) {                          // rare: which of my runs did not fit
                     uint32_t r = mybase;
@@ -415,85 +435,97 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
         }
         __syncthreads();
         SS_T(2);
+        SS_STOP(2)
 
         // every directory entry whose fingerprint matches becomes a found run in q2 (phase 3 gives it
-        // 16 lanes, one per position)
-        auto push_found = [&](uint64_t de, uint32_t run, uint32_t r1, bool queued) {
+        // 16 lanes, one per position).  meta = minimizer offset in the first k-mer << 17 | len << 12 | position
+        auto push_found = [&](uint64_t de, uint32_t meta, uint32_t ib, bool queued) {
             const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
-            const uint32_t rpos = run & 0xFFFu, o0 = (run >> 17) - rpos;
-            const uint32_t amask = aligned_mask(hdr, o0), multi = (hdr >> 17) & 1u;
+            const uint32_t amask = aligned_mask(hdr, (meta >> 17) & 31u), multi = (hdr >> 17) & 1u;
             uint32_t i2 = Q1CAP;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
             if (i2 < Q1CAP) {
-                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | r1;
+                S.q.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | ib;
             } else {
                 // the queue is full (only with floods of fingerprint collisions), or phase 3 is already
                 // over (runs that overflowed q1): settle this run here, so that no k-mer is ever dropped
-                const uint32_t len = (run >> 12) & 31u;
+                const uint32_t rpos = meta & 0xFFFu, len = (meta >> 12) & 31u;
                 for (uint32_t q = 0; q < len; q++) {
                     const uint32_t cpos = cand_slot(bstart, amask, q);
                     if (cpos) settle_item(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts);
                 }
             }
         };
-        // the directory entries (first bucket b1, second bucket behind the "moved" flag) that match run `run`
-        auto lookup_found = [&](const ulonglong2 &b1, uint32_t x, uint32_t h, uint32_t run, uint32_t r1, bool queued) {
+        // the directory entries (first bucket b1, second bucket behind the "moved" flag) that match the run
+        auto lookup_found = [&](const ulonglong2 &b1, uint32_t h, uint32_t meta, uint32_t ib, bool queued) {
             const uint32_t fp = ss::dir_fp_of_mix(h);
             // matching entries as a bit mask + selects (an indexed local array would live in scratch memory);
             // 32-bit compares on the upper halves: a fingerprint is never 0x3FFF, so empty entries match nothing
             ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
             if (((uint32_t)b1.x & (uint32_t)ss::DIR_MOVED) && (uint32_t)(b1.x >> 32) != 0xFFFFFFFFu)   // a key of this bucket moved
-                b2 = dir2[ss::dir_bucket2(x, n_dir)];
+                b2 = dir2[ss::dir_bucket2(mmer_at(S, (meta & 0xFFFu) + ((meta >> 17) & 31u)), n_dir)];
             uint32_t hits = (uint32_t)(((uint32_t)(b1.x >> 32) >> 18) == fp) | (uint32_t)(((uint32_t)(b1.y >> 32) >> 18) == fp) << 1 |
                             (uint32_t)(((uint32_t)(b2.x >> 32) >> 18) == fp) << 2 | (uint32_t)(((uint32_t)(b2.y >> 32) >> 18) == fp) << 3;
             while (hits) {
                 const uint32_t d = (uint32_t)__ffs(hits) - 1u;
                 hits &= hits - 1u;
-                push_found(d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y, run, r1, queued);
+                push_found(d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y, meta, ib, queued);
             }
         };
+        // minimizer offset (in the run's first k-mer) from the index byte of the run's first position
+        auto run_meta = [&](uint32_t e) {
+            const uint32_t rpos = e & 0xFFFu;
+            return e | ((((uint32_t)S.ib[rpos] & 31u) - (rpos & 15u)) << 17);
+        };
 
-        SS_T(20);
-        // ---- phase 2: one directory lookup per run ----------------------------------------------
+        SS_T(7);
+        // ---- phase 2a: Bloom filter, all lanes busy: one probe of an L2-resident bit array kills most of
+        // the ~90 % of the runs whose minimizer is not in the database before they cost a random HBM
+        // sector each.  Survivors are compacted into q1b (ballot + lane count: one wave per workgroup)
+        uint32_t ns = 0;
         {
-            const uint32_t n1 = min(S.cnt[0], (uint32_t)Q1CAP);
-            // RPL runs per lane per round: all 16-byte directory loads in flight before any is used
 #ifndef SS_RPL
 #define SS_RPL 2
 #endif
             constexpr int RPL = SS_RPL;
             for (uint32_t r0 = 0; r0 < n1; r0 += RPL * MT) {
-                uint32_t e[RPL], xs[RPL], hs[RPL];
-                ulonglong2 bk[RPL];
+                uint32_t meta[RPL], hs[RPL], bw[RPL];
+                bool ok[RPL];
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     const uint32_t r = r0 + u * MT + t;
-                    e[u] = (r < n1) ? S.q1[r] : Q1_NONE;                                 // no run: all ones
-                    xs[u] = mmer_at(S, (r < n1) ? (e[u] >> 17) : 0u);
-                    hs[u] = ss::dir_mix(xs[u]);                                          // one mix per run: Bloom bit, bucket, fingerprint
+                    ok[u] = r < n1;
+                    meta[u] = run_meta(S.q1[ok[u] ? r : 0u]);
+                    hs[u] = ss::dir_mix(mmer_at(S, (meta[u] & 0xFFFu) + (meta[u] >> 17)));   // one mix per run: Bloom bit, bucket, fingerprint
                 }
                 if (bloom) {
-                    // one probe of an L2-resident bit array kills most of the ~90 % of the runs whose
-                    // minimizer is not in the database before they cost a random HBM sector each
-                    uint32_t bw[RPL];
 #pragma unroll
                     for (int u = 0; u < RPL; u++) bw[u] = bloom[hs[u] >> (bloom_shift + 5)];
 #pragma unroll
-                    for (int u = 0; u < RPL; u++)
-                        if (!((bw[u] >> ((hs[u] >> bloom_shift) & 31u)) & 1u)) e[u] = Q1_NONE;
+                    for (int u = 0; u < RPL; u++) ok[u] = ok[u] && ((bw[u] >> ((hs[u] >> bloom_shift) & 31u)) & 1u);
                 }
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
-                    bk[u] = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
-                    if (e[u] != Q1_NONE) bk[u] = dir2[ss::mulhi32(hs[u], n_dir)];
+                    const uint64_t pass = __ballot(ok[u]);
+                    if (ok[u]) S.q.q1b[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(pass >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pass, 0u))] =
+                        ((uint64_t)hs[u] << 32) | meta[u];
+                    ns += (uint32_t)__popcll(pass);
                 }
-#pragma unroll
-                for (int u = 0; u < RPL; u++)
-                    if (e[u] != Q1_NONE) lookup_found(bk[u], xs[u], hs[u], e[u], r0 + u * MT + t, true);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2b: one 16-byte directory load per surviving run (about a tenth of the runs) ----
+        for (uint32_t i0 = 0; i0 < ns; i0 += MT) {
+            const uint32_t i = i0 + t;
+            if (i < ns) {
+                const uint64_t sv = S.q.q1b[i];
+                const uint32_t h = (uint32_t)(sv >> 32);
+                lookup_found(dir2[ss::mulhi32(h, n_dir)], h, (uint32_t)sv, i, true);
             }
         }
         __syncthreads();
         SS_T(3);
+        SS_STOP(3)
 
         // ---- phase 3: the k-mers whose minimizer exists in the database -------------------------
         // 16 lanes per found run (one per position of the run), four runs per lane per round: all
@@ -511,8 +543,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
                 for (int u = 0; u < U3; u++) {
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
                     const bool v = (g >> 4) < n2;
-                    const uint64_t r = S.q2[v ? (g >> 4) : 0u];
-                    const uint32_t run = S.q1[(uint32_t)r & 0xFFFu];
+                    const uint64_t r = S.q.q2[v ? (g >> 4) : 0u];
+                    const uint32_t run = (uint32_t)S.q.q1b[(uint32_t)r & 0xFFFu];
                     pos[u] = (run & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32);
                     mul[u] = (uint32_t)r >> 31;
@@ -526,23 +558,22 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
         }
         // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
         if (ovf) {
-            const uint32_t stop = need | (~live & 0xFFFFu) | 0x10000u;
             for (int j = 0; j < PPT; j++) {
                 if (!((ovf >> j) & 1u)) continue;
-                uint32_t m = 0;
-#pragma unroll
-                for (int q = 0; q < PPT; q++) if (q == j) m = mh[q];
-                const uint32_t len = (uint32_t)__ffs(stop >> (j + 1));
-                const uint32_t p = (uint32_t)(t * PPT) + (m & 31u);
-                const uint32_t run = (p << 17) | (len << 12) | (uint32_t)(t * PPT + j);
-                const uint32_t x = mmer_at(S, p);
-                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], x, ss::dir_mix(x), run, 0u, false);
+                const uint32_t len12 = ((uint32_t)__ffs(stop >> (j + 1)) << 12) + ((need >> (j + 1)) ? 0u : ext12);
+                const uint32_t meta = run_meta(len12 + (uint32_t)(t * PPT + j));
+                const uint32_t x = mmer_at(S, (meta & 0xFFFu) + (meta >> 17));
+                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], ss::dir_mix(x), meta, 0u, false);
             }
         }
         SS_T(4);
         __syncthreads();   // queues and codes are rewritten by the next tile
         SS_T(5);
     }
+#ifdef SS_TIMING
+    if (t == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&ss_timing[i], (unsigned long long)t_acc[i]);
+#endif
 }
 
 void parallel_for(unsigned nthreads, uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)> &fn)
@@ -751,11 +782,11 @@ static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const u
 }
 
 #ifdef SS_TIMING
-extern "C" int ss_debug_timing(unsigned long long *out8, int reset)
+extern "C" int ss_debug_timing(unsigned long long *out32, int reset)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ss_timing), 64);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ss_timing), z, 64); }
+    hipMemcpyFromSymbol(out32, HIP_SYMBOL(ss_timing), 256);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ss_timing), z, 256); }
     return 0;
 }
 #endif
