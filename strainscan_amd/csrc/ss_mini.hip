@@ -156,7 +156,7 @@ struct Ent {
 constexpr int MT = SS_NT;
 static_assert(MT == 64, "one wave per workgroup: phase 2 compacts with ballots and keeps its counters in scalar registers");
 #ifndef SS_Q1CAP
-#define SS_Q1CAP (4 * SS_NT)
+#define SS_Q1CAP 160
 #endif
 constexpr int Q1CAP = SS_Q1CAP;    // runs (q1) and found runs (q2) per tile held in LDS (mean ~450 runs); overflow is
                                    // handled inline.  Test builds shrink it to exercise those paths.
@@ -174,14 +174,12 @@ struct QShared {
     uint16_t inv[MT + 2];
     uint32_t q1[Q1CAP + 64];           // run:   len << 12 | tile position of its first k-mer (+64 dump slots)
     alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
-    alignas(16) union {                // hm is dead once every lane has its minimizers (barrier after phase 1)
-        uint32_t hm[MT * PPT];         // packed keys of the m-mers: 16-byte chunk c of lane t at uint4 index c * MT + t
-        struct {
-            uint64_t q1b[Q1CAP];       // run that passed the Bloom filter: mix << 32 | minimizer offset in the first k-mer << 17 | q1 entry
-            uint64_t q2[Q1CAP];        // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1b index
-        } q;
-    };
+    uint64_t q1b[Q1CAP];               // run that passed the Bloom filter: mix << 32 | minimizer offset in the first k-mer << 17 | q1 entry
+    uint64_t q2[Q1CAP];                // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1b index
     uint32_t cnt[4];                   // [1] = found runs
+#ifdef SS_LDS_PAD
+    uint32_t pad[SS_LDS_PAD / 4];      // occupancy experiments only
+#endif
 };
 
 // the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
@@ -254,6 +252,19 @@ __device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t b, uint32_t c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
+// a_i = min(a_i, p_i of the NEXT lane), eight at a time: the DPP wave shift rides in the v_min itself (the
+// compiler keeps a separate v_mov_dpp per word).  s_nop: a DPP read needs two wait states after the VALU
+// write of its source, which the hazard recognizer cannot see inside inline assembly.  Lane 63 reads 0.
+#define SS_MIN_DPP(i, j) "v_min_u32_dpp %" #i ", %" #j ", %" #i " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void min_next_lane8(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3, uint32_t &a4, uint32_t &a5,
+                                               uint32_t &a6, uint32_t &a7, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3,
+                                               uint32_t p4, uint32_t p5, uint32_t p6, uint32_t p7)
+{
+    asm("s_nop 1\n\t" SS_MIN_DPP(0, 8) SS_MIN_DPP(1, 9) SS_MIN_DPP(2, 10) SS_MIN_DPP(3, 11) SS_MIN_DPP(4, 12) SS_MIN_DPP(5, 13)
+        SS_MIN_DPP(6, 14) SS_MIN_DPP(7, 15)
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7));
+}
 // m = 2 * m + (a != b): builds a bit mask from comparisons, two instructions per bit
 __device__ __forceinline__ uint32_t shift_in_ne(uint32_t m, uint32_t a, uint32_t b)
 {
@@ -276,8 +287,14 @@ __device__ unsigned long long ss_timing[32];
 #define SS_STOP(n)
 #endif
 
+// SGPRs decide the residency of this kernel: a SIMD admits floor(800 / (ceil(sgprs / 16) * 16 + 16)) waves
+// (MI355X_MICROARCH.md, residency), i.e. 8 waves at <= 80, 7 at <= 96, 6 beyond; VGPRs (58) and LDS (4.9 KB per
+// one-wave workgroup = 32 per CU) allow 8.
+#ifndef SS_NUM_SGPR
+#define SS_NUM_SGPR 80
+#endif
 template <bool ALIGNED, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
+__global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(SS_NUM_SGPR))) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
     const uint64_t *__restrict__ dir, uint32_t n_dir, uint32_t *__restrict__ counts,
     const uint32_t *__restrict__ bloom, uint32_t bloom_shift)
@@ -308,6 +325,9 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             S.code[t] = code;
             S.inv[t] = (uint16_t)inv;
             if (t == 1) S.cnt[1] = 0;
+#ifdef SS_LDS_PAD
+        if (n == 1) S.pad[t] = 1;
+#endif
             const uint64_t nt = tile + gridDim.x;
             if (nt < n_tiles) {
                 const uint64_t nb = nt * (uint64_t)MTILE;
@@ -330,15 +350,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             x[PPT] = c1; x[PPT + 1] = c1 >> 2; x[PPT + 2] = c1 >> 4;
 #pragma unroll
             for (int i = 0; i < PPT; i++) hm[i] = mad24(x[i + 3], vc2, mad24s(x[i], vc1, ss::MMK_C0 + (uint32_t)i));
-            // chunk c of lane t lives at hm4[c * MT + t]: consecutive lanes touch consecutive 16-byte
-            // words (a lane-major layout makes every b128 access a 4-way bank conflict)
-            uint4 *dst = reinterpret_cast<uint4 *>(S.hm) + t;
-            dst[0] = make_uint4(hm[0], hm[1], hm[2], hm[3]);
-            dst[MT] = make_uint4(hm[4], hm[5], hm[6], hm[7]);
-            dst[2 * MT] = make_uint4(hm[8], hm[9], hm[10], hm[11]);
-            dst[3 * MT] = make_uint4(hm[12], hm[13], hm[14], hm[15]);
         }
-        __syncthreads();
         SS_T(1);
         SS_STOP(1)
 
@@ -349,30 +361,27 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 15;   // any invalid base in [j, j+31)
             live = ~(uint32_t)x & 0xFFFFu;
         }
+        // k-mer j covers m-mers j..j+16 = own m-mers j..15 (index j..15) and the next lane's m-mers 0..j
+        // (index 16..16+j): suffix minima over the own packed words, prefix minima over the neighbour's;
+        // equal keys resolve to the smaller index = the leftmost m-mer (the database side uses the same
+        // rule).  Every lane computes the prefix minima of ITS keys as its left neighbour counts them
+        // (index + 16); the neighbour reads them with a DPP wave shift inside the v_min: the keys never
+        // go through LDS.  All lanes execute this (a DPP source lane must be enabled).
         uint32_t need = 0;
         uint32_t mh[PPT];
-        mh[0] = 0; mh[PPT - 1] = 0;
-        if (live) {
-            // k-mer j covers m-mers j..j+16 = own m-mers j..15 (index j..15) and the next lane's
-            // m-mers 0..j (index 16..16+j): suffix minima over the own packed words, prefix minima
-            // over the neighbour's; equal keys resolve to the smaller index = the leftmost m-mer
-            // (the database side uses the same rule).
-            uint32_t nx[PPT];
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(S.hm) + (t + 1);
-                const uint4 a = src[0], b = src[MT], c = src[2 * MT], d = src[3 * MT];
-                nx[0] = a.x; nx[1] = a.y; nx[2] = a.z; nx[3] = a.w; nx[4] = b.x; nx[5] = b.y; nx[6] = b.z; nx[7] = b.w;
-                nx[8] = c.x; nx[9] = c.y; nx[10] = c.z; nx[11] = c.w; nx[12] = d.x; nx[13] = d.y; nx[14] = d.z; nx[15] = d.w;
-            }
+        {
+            uint32_t pf[PPT];
+            pf[0] = hm[0] + 16u;
+#pragma unroll
+            for (int j = 1; j < PPT; j++) pf[j] = min(pf[j - 1], hm[j] + 16u);
 #pragma unroll
             for (int i = PPT - 2; i >= 0; i--) hm[i] = min(hm[i], hm[i + 1]);         // suffix minima, in place
-            uint32_t pre = nx[0] | 16u;
-            mh[0] = min(hm[0], pre);
+            min_next_lane8(hm[0], hm[1], hm[2], hm[3], hm[4], hm[5], hm[6], hm[7], pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7]);
+            min_next_lane8(hm[8], hm[9], hm[10], hm[11], hm[12], hm[13], hm[14], hm[15], pf[8], pf[9], pf[10], pf[11], pf[12], pf[13], pf[14], pf[15]);
 #pragma unroll
-            for (int j = 1; j < PPT; j++) {
-                pre = min(pre, nx[j] | 16u);
-                mh[j] = min(hm[j], pre);
-            }
+            for (int j = 0; j < PPT; j++) mh[j] = hm[j];
+        }
+        if (live) {
             // run starts as a bit mask: position j starts a run if it is live and (j == 0, or j-1 is
             // not live, or the minimizer changed)
             uint32_t chg = 0u;
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
             uint32_t i2 = Q1CAP;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
             if (i2 < Q1CAP) {
-                S.q.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | ib;
+                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | ib;
             } else {
                 // the queue is full (only with floods of fingerprint collisions), or phase 3 is already
                 // over (runs that overflowed q1): settle this run here, so that no k-mer is ever dropped
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     const uint64_t pass = __ballot(ok[u]);
-                    if (ok[u]) S.q.q1b[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(pass >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pass, 0u))] =
+                    if (ok[u]) S.q1b[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(pass >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pass, 0u))] =
                         ((uint64_t)hs[u] << 32) | meta[u];
                     ns += (uint32_t)__popcll(pass);
                 }
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
         for (uint32_t i0 = 0; i0 < ns; i0 += MT) {
             const uint32_t i = i0 + t;
             if (i < ns) {
-                const uint64_t sv = S.q.q1b[i];
+                const uint64_t sv = S.q1b[i];
                 const uint32_t h = (uint32_t)(sv >> 32);
                 lookup_found(dir2[ss::mulhi32(h, n_dir)], h, (uint32_t)sv, i, true);
             }
@@ -543,8 +552,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) void scan_mini_kernel(
                 for (int u = 0; u < U3; u++) {
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
                     const bool v = (g >> 4) < n2;
-                    const uint64_t r = S.q.q2[v ? (g >> 4) : 0u];
-                    const uint32_t run = (uint32_t)S.q.q1b[(uint32_t)r & 0xFFFu];
+                    const uint64_t r = S.q2[v ? (g >> 4) : 0u];
+                    const uint32_t run = (uint32_t)S.q1b[(uint32_t)r & 0xFFFu];
                     pos[u] = (run & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32);
                     mul[u] = (uint32_t)r >> 31;
