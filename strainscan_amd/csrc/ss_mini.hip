@@ -54,17 +54,18 @@ constexpr uint32_t M30 = 0x3FFFFFFFu;
 constexpr uint32_t HDR_MULTI = 1u << 17;
 
 // Ordering key of a 30-bit m-mer: the m-mer with the smallest key, leftmost on ties, is the
-// minimizer of a k-mer.  key = lo24(x) * C1 + lo24(x >> 6) * C2 + C0 with C1, C2 = odd 19-bit
-// constants << 5 and C0 a multiple of 32: two v_mad_u32_u24 per m-mer on the device (full rate;
-// the 24-bit multipliers ignore the operands' upper bits, so the device never masks the window,
-// and x >> 6 of m-mer i is simply the window of m-mer i + 3).  The low five bits are zero by
+// minimizer of a k-mer.  key = lo24(x) * C1 + C0 with C1 = an odd 19-bit constant << 5 and C0 a
+// multiple of 32: ONE v_mad_u32_u24 per m-mer on the device (full rate; the 24-bit multiplier
+// ignores the operand's upper bits, so the device never masks the window).  The key orders the
+// m-mers by their first 12 bases (a bijection of those 24 bits onto the 27 key bits); m-mers that
+// agree there tie and resolve leftmost like any other tie.  The low five bits are zero by
 // construction: the kernel adds the m-mer's index there (for free, inside C0), so ONE v_min_u32
 // per step compares (key, position).  The constant keeps poly-A from being everybody's minimizer.
 // It need not be injective: a bucket is named by the m-mer itself and holds full k-mers.
-constexpr uint32_t MMK_C1 = 0x4F1BBu << 5, MMK_C2 = 0x6A09Fu << 5, MMK_C0 = 0x7F4A7C00u;
+constexpr uint32_t MMK_C1 = 0x4F1BBu << 5, MMK_C0 = 0x7F4A7C00u;
 __host__ __device__ __forceinline__ uint32_t mmkey(uint32_t x)
 {
-    return (x & 0xFFFFFFu) * MMK_C1 + ((x >> 6) & 0xFFFFFFu) * MMK_C2 + MMK_C0;
+    return (x & 0xFFFFFFu) * MMK_C1 + MMK_C0;
 }
 constexpr uint32_t KEY_MASK = ~31u;
 
@@ -239,13 +240,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return v;
 }
 
-// v_mad_u32_u24 with the addend in a VGPR / as a scalar constant (one SGPR per VOP3 on gfx9)
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// v_mad_u32_u24 with the addend as a scalar constant (one SGPR per VOP3 on gfx9)
 __device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
     __shared__ QShared S;
     const int t = threadIdx.x;
     const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
-    const uint32_t vc1 = ss::MMK_C1, vc2 = ss::MMK_C2;
+    const uint32_t vc1 = ss::MMK_C1;
 
     // the 16 bases of this lane are fetched one tile AHEAD: the HBM
     // round trip of the stream overlaps the previous tile's phases
@@ -341,25 +336,28 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         uint32_t hm[PPT];
         {
             const uint32_t c0 = S.code[t], c1 = S.code[t + 1];
-            // windows of the m-mers 0..18 (bits 2i.. of c1:c0): 19 funnel shifts, then two multiply-adds
+            // low 24 bits of the m-mers 0..15 (bits 2i.. of c1:c0): 15 funnel shifts, then one multiply-add
             // per m-mer; the "+ i" of the packed word rides in the additive constant
-            uint32_t x[PPT + 3];
-            x[0] = c0;
+            hm[0] = mad24s(c0, vc1, ss::MMK_C0);
 #pragma unroll
-            for (int i = 1; i < PPT; i++) x[i] = __builtin_amdgcn_alignbit(c1, c0, 2 * i);
-            x[PPT] = c1; x[PPT + 1] = c1 >> 2; x[PPT + 2] = c1 >> 4;
-#pragma unroll
-            for (int i = 0; i < PPT; i++) hm[i] = mad24(x[i + 3], vc2, mad24s(x[i], vc1, ss::MMK_C0 + (uint32_t)i));
+            for (int i = 1; i < PPT; i++) hm[i] = mad24s(__builtin_amdgcn_alignbit(c1, c0, 2 * i), vc1, ss::MMK_C0 + (uint32_t)i);
         }
         SS_T(1);
         SS_STOP(1)
 
         // ---- phase 1b: minimizer of the lane's 16 k-mers, runs ------------------------------------
+        // k-mer j is live iff none of the bases j..j+30 is invalid: flags of the positions 0..30 in lo
+        // (smeared downwards through a bit reversal: shift-left-or is one instruction), 31..46 in hi
+        // (smeared upwards; k-mer j sees hi bits 0..j-1)
         uint32_t live = 0;
         if (t < MLANES) {
-            uint64_t x = (uint64_t)S.inv[t] | ((uint64_t)S.inv[t + 1] << 16) | ((uint64_t)S.inv[t + 2] << 32);
-            x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 15;   // any invalid base in [j, j+31)
-            live = ~(uint32_t)x & 0xFFFFu;
+            uint32_t lo;
+            __builtin_memcpy(&lo, &S.inv[t], 4);
+            uint32_t hi = __builtin_amdgcn_alignbit(S.inv[t + 2], lo, 31);
+            lo = __builtin_bitreverse32(lo & 0x7FFFFFFFu);
+            lo |= lo << 1; lo |= lo << 2; lo |= lo << 4; lo |= lo << 8; lo |= lo << 16;
+            hi |= hi << 1; hi |= hi << 2; hi |= hi << 4; hi |= hi << 8;
+            live = ~(__builtin_bitreverse32(lo) | (hi << 1)) & 0xFFFFu;
         }
         // k-mer j covers m-mers j..j+16 = own m-mers j..15 (index j..15) and the next lane's m-mers 0..j
         // (index 16..16+j): suffix minima over the own packed words, prefix minima over the neighbour's;
@@ -836,7 +834,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct ImageHeader {
-    char magic[8];          // "SSIDX05\0"
+    char magic[8];          // "SSIDX06\0"
     int32_t k, layout;
     uint64_t n_rows, n_distinct, n_slots, n_buckets;
     uint32_t n_dir, bloom_bits;
@@ -875,7 +873,7 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX05", 8);
+    memcpy(h.magic, "SSIDX06", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
     h.n_dir = db->n_dir;
@@ -896,7 +894,7 @@ int ss_db_import(const char *path, ss_db **out)
     FILE *f = fopen(path, "rb");
     if (!f) return SS_EIO;
     ImageHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX05", 8) != 0 || h.layout != 1 || h.k != 31 ||
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX06", 8) != 0 || h.layout != 1 || h.k != 31 ||
         h.n_slots == 0 || h.n_dir == 0 || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         fclose(f);
         return SS_EINVAL;
