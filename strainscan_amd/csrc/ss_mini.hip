@@ -426,12 +426,13 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             const uint32_t mybase = incl - mine;
             if (need) {
                 const uint32_t dummy = (uint32_t)Q1CAP + (uint32_t)t;   // where entries beyond the capacity go
+                const uint32_t stop1 = stop >> 1, tbase = (uint32_t)(t * PPT);
                 uint32_t idx = mybase;
                 for (uint32_t nd = need; nd; idx++) {
                     const uint32_t j = (uint32_t)__ffs(nd) - 1u;
                     nd &= nd - 1u;
-                    const uint32_t len12 = ((uint32_t)__ffs(stop >> (j + 1u)) << 12) + (nd ? 0u : ext12);   // until the next run / gap
-                    S.q1[min(idx, dummy)] = len12 + (uint32_t)(t * PPT) + j;
+                    const uint32_t len = (uint32_t)__ffs(stop1 >> j);                       // until the next run / gap
+                    S.q1[min(idx, dummy)] = (len << 12) + (tbase + j + (nd ? 0u : ext12));
                 }
                 if (mybase + mine > (uint32_t)Q1CAP) {                          // rare: which of my runs did not fit
                     uint32_t r = mybase;
@@ -810,10 +811,11 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
         bpc = g ? atoi(g) : 0;
     }
     n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 255 x 16 positions
-    // grid-stride over tiles with MANY more blocks than fit the chip (measured: 5 resident blocks per CU
-    // x 256 CUs = 8.0 ms, 40 per CU 7.5 ms, 128+ per CU 7.3 ms): short blocks start at scattered
-    // times, so the blocks sharing a CU stop marching through their ALU and memory phases in step
-    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 128) * 256 * (256 / MT));
+    // grid-stride over tiles with MANY more blocks than fit the chip: short blocks start at scattered times, so
+    // the waves sharing a SIMD stop marching through their ALU and memory phases in step.  Measured with 8 waves
+    // per SIMD resident (20 M reads = 3.04 M tiles; blocks = x * 1024): x = 8 (one round of resident blocks)
+    // 4.03 ms, 32: 3.76, 128: 3.59, 512: 3.55, 2048 (1.5 tiles per block): 3.50, 4096 (one tile each): 3.51
+    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
