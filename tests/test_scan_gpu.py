@@ -317,8 +317,9 @@ def test_low_complexity_and_repeats(L):
 
 
 def test_queue_overflow_paths(tmp_path):
-    """The same parity checks against a build whose LDS queues hold 64 runs / 96 items per tile
-    (libstrainscan_hip_tinyq.so): every tile overflows q1 and q3, so the inline paths do the work."""
+    """The same parity checks against a build whose LDS queues hold 64 runs per tile and whose node
+    reduction keeps 64 positive counts in LDS (libstrainscan_hip_tinyq.so): every tile overflows the
+    run queues, so the inline paths do the work, and nodes with hits take the global-memory passes."""
     import subprocess
     import sys
     from strainscan_amd import _lib
@@ -337,6 +338,15 @@ def test_queue_overflow_paths(tmp_path):
         "    db = _lib.KmerDB.from_text(kfa, 31, True)\n"
         "    db.scan_flat(flat)\n"
         "    assert np.array_equal(db.counts_rows(), want)\n"
+        "    valid = db.row_valid\n"
+        "    n = want.size\n"
+        "    lists = [np.arange(0, n, 2), np.arange(1, n, 3), np.arange(n)[::-1][: n // 2], np.arange(5)]\n"
+        "    st = _lib.NodeSet(lists).reduce(db)\n"
+        "    for j, rows in enumerate(lists):\n"
+        "        o = orc.match_node(want, valid, rows)\n"
+        "        got = (int(st[j]['length']), int(st[j]['n_pos']), int(st[j]['n_kept']), int(st[j]['sum_kept']), int(st[j]['median2']))\n"
+        "        assert got == (o['length'], o['n_pos'], o['n_kept'], o['sum_kept'], (int(round(2 * o['median'])) if o['n_pos'] else 0)), (got, o)\n"
+        "    assert max(int(x['n_pos']) for x in st) > 64\n"
         "print('tinyq ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, SS_LIB=tiny)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
@@ -389,3 +399,45 @@ def test_tiny_databases(L):
         db.scan_flat(flat)
         assert np.array_equal(db.counts_rows(), want), seed
         db.close()
+
+
+@pytest.mark.gpu
+def test_node_reduce_synthetic_counts(L):
+    """ss_nodes_reduce_dev on hand-made row counts vs the oracle's match_node + del_outlier
+    (identify.py:106-127): empty / all-invalid nodes, odd and even profiles, ties at the median,
+    outliers >= 100 x median, counts >= 65535 and a node with more positive counts than the
+    kernel keeps in LDS (both take its global-memory passes), a two-byte radix select."""
+    import torch
+    from oracle import oracle as orc
+    rs = np.random.RandomState(99)
+    n = 200_000
+    counts = np.zeros(n, np.uint32)
+    valid = (rs.random_sample(n) < 0.97).astype(np.uint8)
+    counts[:60_000] = rs.poisson(20, 60_000)                      # one big covered region
+    counts[60_000:70_000] = rs.randint(0, 3, 10_000)              # many ties, zeros
+    counts[70_000:70_100] = rs.randint(250, 70_000, 100)          # wide range: two radix bytes and >= 65535
+    counts[70_050] = 65_535
+    counts[70_051] = 3_000_000
+    counts[80_000:80_009] = [5, 5, 5, 5, 5, 5, 5, 5, 700]         # outlier cut
+    counts[90_000:90_004] = [1, 2, 3, 4]                          # even length, x.5 median
+    valid[80_000:80_009] = 1
+    valid[90_000:90_004] = 1
+    valid[100_000:100_500] = 0
+    lists = [np.arange(0, 60_000),                                # 58 k positives: beyond the LDS cap
+             np.arange(0, 30_000), np.arange(60_000, 70_000), np.arange(70_000, 70_100),
+             np.arange(80_000, 80_009), np.arange(90_000, 90_004), np.arange(90_000, 90_003),
+             np.arange(100_000, 100_500), np.arange(150_000, 151_000), np.arange(0),
+             rs.choice(n, 25_000, replace=False), np.arange(70_040, 90_004)]
+    ns = L.NodeSet(lists)
+    dc = torch.from_numpy(counts.view(np.int32)).cuda()
+    dv = torch.from_numpy(valid).cuda()
+    st = torch.zeros(len(lists) * L.NODE_STAT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    ns.reduce_dev(dc.data_ptr(), dv.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = st.cpu().numpy().view(L.NODE_STAT_DTYPE)
+    for j, rows in enumerate(lists):
+        o = orc.match_node(counts, valid, rows)
+        want = (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"], int(round(2 * o["median"])) if o["n_pos"] else 0)
+        have = tuple(int(got[j][f]) for f in ("length", "n_pos", "n_kept", "sum_kept", "median2"))
+        assert have == want, (j, have, want)
+    assert got[0]["n_pos"] > 32768 and got[3]["n_pos"] > 0 and got[7]["length"] == 0
