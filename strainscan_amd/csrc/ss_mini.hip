@@ -133,24 +133,24 @@ struct Ent {
 // scan kernel, minimizer layout: dense SIMD for the arithmetic, compacted LDS work queues for
 // the memory probes.
 //
-// Measured on MI355X (profiles/r01b..e): what bounds this kernel is not HBM bytes but the
-// instructions a wave issues per tile (VALU ~58 % busy, waves parked ~60 % of their life at
-// barriers / waitcnt) and the NUMBER of divergent vector-memory instructions.  So per tile of
-// 4080 start positions:
-//   phase 0  coalesced 16-byte loads of the bases (one tile ahead), SWAR 2-bit encode, codes -> LDS
-//   phase 1a every lane keys the 16 m-mers that start in its bases (3 instructions each) and tags
-//            them with their index: packed = (key & ~31) | index, shared through LDS
-//   phase 1b minimizer of the lane's 16 k-mers = suffix/prefix minima over the packed words
-//            (one v_min_u32 per step decides key AND leftmost position); runs of equal
-//            minimizers are pushed to LDS queue q1 through a DPP wave prefix-sum
-//            (one 32-bit entry per run: ~450 per tile instead of 4080 positions)
-//   phase 2  lanes pull runs from q1: the minimizer m-mer is re-read from the codes, ONE 16-byte
-//            directory load per run.  Runs whose minimizer exists go to q2 and are expanded to
-//            per-position items in q3 (rare: ~5 % of the positions of a typical sample)
-//   phase 3  lanes pull items from q3: candidate slot from the run's offset mask -> 64-bit
-//            compare -> atomicAdd
+// Measured on MI355X (profiles/r01b..f): what bounds this kernel is not HBM bytes but the
+// instructions a wave issues per tile (VALU 82 % busy at 8 waves/SIMD) and the latency chains of
+// its three dependent memory probes.  So per tile of 62 x 16 = 992 start positions, ONE wave:
+//   phase 0  coalesced 16-byte loads of the bases, 2-bit encode, codes + invalid flags -> LDS
+//   phase 1a every lane keys the 16 m-mers that start in its bases (one multiply-add each) and tags
+//            them with their index: packed = (key & ~31) | index, kept in registers
+//   phase 1b minimizer of the lane's 16 k-mers = suffix minima over the own packed words, prefix
+//            minima over the next lane's (read through a DPP wave shift; one v_min_u32 per step
+//            decides key AND leftmost position); runs of equal minimizers, merged across lane
+//            boundaries, are pushed to LDS queue q1 through a DPP wave prefix sum
+//            (one 32-bit entry per run: ~94 per tile instead of 992 positions)
+//   phase 2a lanes pull runs from q1: the minimizer m-mer is re-read from the codes, one mix, one
+//            probe of the Bloom filter (L2).  The ~10 % that pass are compacted into q1b
+//   phase 2b ONE 16-byte directory load per surviving run; runs whose minimizer exists go to q2
+//   phase 3  16 lanes per found run, one per position: candidate slot from the run's offset mask
+//            -> 64-bit compare -> atomicAdd
 // ---------------------------------------------------------------------------------------------
-// threads per workgroup of this kernel (a tile = (MT - 1) x 16 start positions)
+// threads per workgroup of this kernel = one wave
 #ifndef SS_NT
 #define SS_NT 64
 #endif
@@ -159,14 +159,15 @@ static_assert(MT == 64, "one wave per workgroup: phase 2 compacts with ballots a
 #ifndef SS_Q1CAP
 #define SS_Q1CAP 160
 #endif
-constexpr int Q1CAP = SS_Q1CAP;    // runs (q1) and found runs (q2) per tile held in LDS (mean ~450 runs); overflow is
-                                   // handled inline.  Test builds shrink it to exercise those paths.
-static_assert(Q1CAP <= 4096, "q2 keeps a q1 index in 12 bits");
+constexpr int Q1CAP = SS_Q1CAP;    // runs (q1), Bloom survivors (q1b) and found runs (q2) per tile held in LDS (random
+                                   // reads: mean 94 runs, max ~110); overflow is handled inline.  With 160 the
+                                   // workgroup needs 4.9 KB: 32 one-wave workgroups per CU.  Test builds shrink it.
+static_assert(Q1CAP <= 4096, "q2 keeps a q1b index in 12 bits");
 // A tile is (MT - 2) x 16 start positions: all MT lanes load 16 bases and key the 16 m-mers that
-// START in them (shared through LDS); lanes 0..MT-3 own 16 k-mers each, whose 17-m-mer windows end in
-// the NEXT lane's m-mers, whose last bases lie in the lane after that.  The last two lanes only
-// feed their neighbours: 3 % of the lanes idle is cheaper than a separate halo load + encode, which
-// costs a full wave instruction stream for one lane.
+// START in them; lanes 0..MT-3 own 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's
+// m-mers, whose last bases lie in the lane after that.  The last two lanes only feed their
+// neighbours: 3 % of the lanes idle is cheaper than a separate halo load + encode, which costs a
+// full wave instruction stream for one lane.
 constexpr int MLANES = MT - 2;
 constexpr int MTILE = MLANES * PPT;
 
@@ -810,7 +811,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
-    n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 255 x 16 positions
+    n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 62 x 16 positions
     // grid-stride over tiles with MANY more blocks than fit the chip: short blocks start at scattered times, so
     // the waves sharing a SIMD stop marching through their ALU and memory phases in step.  Measured with 8 waves
     // per SIMD resident (20 M reads = 3.04 M tiles; blocks = x * 1024): x = 8 (one round of resident blocks)
