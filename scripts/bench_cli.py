@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""identify_cluster() end to end at BASELINE.json configs[1] scale, from files on disk.
+
+Writes a synthetic E. coli-shaped database in the reference's on-disk format (Tree_database/:
+kmer.fa, kmers/<id>, tree_structure.txt, node_length.txt, hclsMap_95_recls.txt ...: 823 leaf
+clusters = 1645 nodes, ~25 M rows) and a paired FASTQ sample (three-strain mix 70/20/10), then times
+library/identify.identify_cluster's mirror on it: first call (kmer.fa text parse, index build,
+image cache written), a second process-cold call (image cache read) and the phases of each
+(database image, FASTQ ingest + scan, tree walk).  Usage: bench_cli.py [n_reads] [n_leaves]"""
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+K = 31
+
+
+def heap_to_id(h, C):
+    """bench.make_db numbers nodes in heap order (0 root, children 2h+1, 2h+2); Build_tree.py numbers leaves
+    1..C, the root C+1 and internal nodes after it, every parent before its internal children."""
+    return C + 1 + h if h < C - 1 else h - (C - 1) + 1
+
+
+def write_db(torch, dev, spec, C, db_dir):
+    tdir = os.path.join(db_dir, "Tree_database")
+    os.makedirs(os.path.join(tdir, "kmers"))
+    os.makedirs(os.path.join(tdir, "overlapping_info"))
+    n_nodes = spec["n_nodes"]
+    sites, seq_off, row_off = spec["sites"], spec["seq_off"], spec["row_off"].astype(np.int64)
+    asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)      # device codes 0..3 -> A C T G
+    ar = torch.arange(K, device=dev)
+    with open(os.path.join(tdir, "kmer.fa"), "wb") as f:
+        for h0 in range(0, n_nodes, 64):                                     # chunks of nodes: bounded memory
+            h1 = min(n_nodes, h0 + 64)
+            ns = sites[h0:h1]
+            node = np.repeat(np.arange(h0, h1), ns)
+            pos = np.arange(int(ns.sum())) - np.repeat(np.concatenate([[0], np.cumsum(ns)[:-1]]), ns)
+            start = torch.from_numpy(seq_off[node] + pos).to(dev)
+            c = spec["codes"][start[:, None] + ar[None, :]]
+            rows = torch.empty((c.shape[0], 2, K + 4), dtype=torch.uint8, device=dev)
+            rows[:, :, 0] = 62; rows[:, :, 1] = 49; rows[:, :, 2] = 10; rows[:, :, K + 3] = 10   # ">1\n" ... "\n"
+            rows[:, 0, 3:K + 3] = asc[c]
+            rows[:, 1, 3:K + 3] = asc[c.flip(1) ^ 2]
+            f.write(rows.cpu().numpy().tobytes())
+    ids = [heap_to_id(h, C) for h in range(n_nodes)]
+    with open(os.path.join(tdir, "tree_structure.txt"), "w") as f, open(os.path.join(tdir, "node_length.txt"), "w") as g:
+        for i in sorted(ids):
+            h = i - (C + 1) if i > C else i - 1 + (C - 1)
+            par = "N" if h == 0 else str(heap_to_id((h - 1) // 2, C))
+            ch = "N" if h >= C - 1 else "%d %d" % tuple(sorted((heap_to_id(2 * h + 1, C), heap_to_id(2 * h + 2, C))))
+            f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, "strain_%d" % i if h >= C - 1 else ""))
+            g.write("%d\t%d\n" % (i, 2 * sites[h]))
+    for h in range(n_nodes):
+        with open(os.path.join(tdir, "kmers", str(heap_to_id(h, C))), "w") as f:
+            f.write(" ".join(map(str, range(int(row_off[h]), int(row_off[h + 1])))) + " ")
+    open(os.path.join(tdir, "reconstructed_nodes.txt"), "w").close()
+    with open(os.path.join(tdir, "hclsMap_95_recls.txt"), "w") as f:
+        for leaf in range(1, C + 1):
+            f.write("%d\t1\tstrain_%d\n" % (leaf, leaf))
+    return tdir
+
+
+def write_fastq(reads_dev, n_reads, path):
+    reads = reads_dev.view(n_reads, 151)[:, :150].cpu().numpy()
+    rec = np.empty((n_reads, 307), np.uint8)
+    rec[:, 0:2] = np.frombuffer(b"@r", np.uint8); rec[:, 2] = 10
+    rec[:, 3:153] = reads
+    rec[:, 153] = 10; rec[:, 154] = ord("+"); rec[:, 155] = 10
+    rec[:, 156:306] = ord("I"); rec[:, 306] = 10
+    rec.tofile(path)
+
+
+def main():
+    import torch
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+    C = int(sys.argv[2]) if len(sys.argv) > 2 else 823
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "ss_cli_%d" % os.getpid())
+    os.makedirs(base)
+    os.environ["SS_IMAGE_CACHE"] = os.path.join(base, "cache")
+    os.environ["STRAINSCAN_QUIET"] = "1"
+    out = dict(n_reads=n_reads, leaves=C, host_threads=os.cpu_count())
+    try:
+        t0 = time.perf_counter()
+        spec = bench.make_db(torch, dev, C, seed=20231013)
+        tdir = write_db(torch, dev, spec, C, base)
+        out["db_rows"] = int(spec["keys"].size)
+        out["db_text_bytes"] = os.path.getsize(os.path.join(tdir, "kmer.fa"))
+        half = n_reads // 2
+        fq = [os.path.join(base, "s_%d.fq" % (i + 1)) for i in range(2)]
+        r = bench.make_reads(torch, dev, spec, n_reads, seed=2, hit_frac=0.05)
+        write_fastq(r[: half * 151], half, fq[0])
+        write_fastq(r[half * 151:], n_reads - half, fq[1])
+        out["fastq_bytes"] = sum(os.path.getsize(p) for p in fq)
+        del r, spec
+        torch.cuda.empty_cache()
+        out["setup_s"] = round(time.perf_counter() - t0, 1)
+
+        from strainscan_amd import cst, db as ssdb, identify
+        for label in ("first_call", "cached_image"):
+            ssdb.clear_cache()
+            ph = {}
+            t0 = time.perf_counter()
+            if os.environ.get("SS_PROFILE") == label:
+                import cProfile, pstats
+                pr = cProfile.Profile()
+                img = pr.runcall(ssdb.tree_image, tdir, True)
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(18)
+            else:
+                img = ssdb.tree_image(tdir, True)
+            ph["database_image_s"] = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            img.scan(fq)
+            ph["ingest_scan_s"] = time.perf_counter() - t1
+            torch.cuda.synchronize()
+            ph["ingest_scan_s"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            if os.environ.get("SS_PROFILE") == label + "_walk":
+                import cProfile, pstats
+                pr = cProfile.Profile()
+                res = pr.runcall(lambda: cst.Walk(cst.ImageProvider(img), tdir, [0.1, 0.4, 1], identify._PARAMS, out=lambda *a: None).run())
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(14)
+            else:
+                res = cst.Walk(cst.ImageProvider(img), tdir, [0.1, 0.4, 1], identify._PARAMS, out=lambda *a: None).run()
+            ph["tree_walk_s"] = time.perf_counter() - t1
+            ph["total_s"] = time.perf_counter() - t0
+            ph["m_reads_per_s_total"] = n_reads / ph["total_s"] / 1e6
+            ph["m_reads_per_s_ingest_scan"] = n_reads / ph["ingest_scan_s"] / 1e6
+            out[label] = {k: round(v, 3) for k, v in ph.items()}
+        # the public entry, everything warm in this process (image on the device, reads resident)
+        t0 = time.perf_counter()
+        res2 = identify.identify_cluster((fq[0], fq[1]), tdir, [0.1, 0.4, 1])
+        out["identify_cluster_warm_s"] = round(time.perf_counter() - t0, 3)
+        assert dict(res2) == dict(res)
+        out["clusters_found"] = {int(k): dict(strain=v["strain"], cls_per=round(float(v["cls_per"]), 4),
+                                              cls_cov=round(float(v["cls_cov"]), 4)) for k, v in res.items()}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -325,6 +325,20 @@ class NodeSet:
         self._h = h
         self.n_nodes = len(row_lists)
 
+    @classmethod
+    def from_sorted(cls, rows, offsets):
+        """Node lists that are already de-duplicated and sorted, back to back: rows u32[offsets[-1]],
+        offsets[n_nodes + 1] (no per-list np.unique: 0.1 s for the 1645 lists of an E. coli database)."""
+        require_gpu()
+        rows = np.ascontiguousarray(rows, np.uint32)
+        offs = np.ascontiguousarray(offsets, np.uint64)
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        check(lib().ss_nodes_create(ptr(rows), ptr(offs), offs.size - 1, C.byref(h)), "ss_nodes_create")
+        self._h = h
+        self.n_nodes = offs.size - 1
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             lib().ss_nodes_destroy(self._h)

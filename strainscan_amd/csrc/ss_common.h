@@ -84,8 +84,9 @@ struct ss_db {
     hipEvent_t stage_free[2] = {nullptr, nullptr};
     std::atomic<uint64_t> launches{0};
     // per-worker resources of the parallel ingest path (allocated on first use, kept for the handle's life)
-    struct Worker { char *h_buf = nullptr; char *d_buf = nullptr; hipStream_t stream = nullptr; uint64_t cap = 0;
-                    char *t_buf = nullptr; uint64_t t_cap = 0; };   // t_buf: private copy of the text chunk being parsed
+    struct Worker { char *h_buf = nullptr; char *d_buf = nullptr; hipEvent_t done = nullptr; uint64_t cap = 0;
+                    char *t_buf = nullptr; uint64_t t_cap = 0; };   // t_buf: private copy of the text chunk being parsed;
+                                                                    // done: this worker's last copy/kernel has finished
     static constexpr int MAX_WORKERS = 64;
     Worker workers[MAX_WORKERS];
     static void free_workers(Worker *w, int n);

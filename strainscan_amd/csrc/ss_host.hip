@@ -2,6 +2,11 @@
 // FASTA/FASTQ -> flat base blocks (what jellyfish's sequence parser hands its counter), revcomp.
 #include "ss_common.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <zlib.h>
 
 #include <algorithm>
@@ -233,9 +238,110 @@ int ss_encode_kmer(const char *kmer, int k, uint64_t *key)
     return SS_OK;
 }
 
+namespace {
+
+// A plain (not gzip) file mapped read-only; ok() is false for gzip input or when it cannot be mapped
+// (the callers then take the gzread path).
+struct PlainMap {
+    const char *p = nullptr;
+    uint64_t n = 0;
+    bool mapped = false;
+    explicit PlainMap(const char *path)
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 2) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                p = (const char *)m;
+                n = (uint64_t)st.st_size;
+                mapped = true;
+                if ((unsigned char)p[0] == 0x1f && (unsigned char)p[1] == 0x8b) release();
+            }
+        }
+        close(fd);
+    }
+    void release() { if (mapped) munmap((void *)p, n); mapped = false; p = nullptr; n = 0; }
+    ~PlainMap() { release(); }
+    bool ok() const { return mapped; }
+};
+
+unsigned host_threads(uint64_t bytes)
+{
+    if (const char *e = getenv("SS_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));   // tests: many chunks of a small file
+    if (bytes < (8u << 20)) return 1;
+    return std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+}
+
+// '\n' count of [a, b) per chunk of a text cut into `T` equal byte ranges
+std::vector<uint64_t> newline_counts(const char *t, uint64_t n, unsigned T)
+{
+    std::vector<uint64_t> cnt(T, 0);
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < T; w++)
+        pool.emplace_back([&, w] {
+            const uint64_t a = n * w / T, b = n * (w + 1) / T;
+            uint64_t c = 0;
+            for (uint64_t i = a; i < b; i++) c += (t[i] == '\n');
+            cnt[w] = c;
+        });
+    for (auto &th : pool) th.join();
+    return cnt;
+}
+
+// rows (the odd lines) of a mapped k-mer FASTA encoded by T threads; returns the number of rows
+uint64_t encode_mapped(const char *t, uint64_t n, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags)
+{
+    const unsigned T = host_threads(n);
+    const std::vector<uint64_t> cnt = newline_counts(t, n, T);
+    std::vector<uint64_t> before(T + 1, 0);                    // '\n's in front of chunk w = index of the line cut by its start
+    for (unsigned w = 0; w < T; w++) before[w + 1] = before[w] + cnt[w];
+    const uint64_t lines = before[T] + ((n && t[n - 1] != '\n') ? 1 : 0);
+    if (lines / 2 != n_rows) return lines / 2;
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < T; w++)
+        pool.emplace_back([&, w] {
+            const uint64_t a = n * w / T, b = n * (w + 1) / T;
+            // first line that STARTS in [a, b)
+            uint64_t pos = a, line = before[w];
+            if (a > 0 && t[a - 1] != '\n') {
+                const void *nl = memchr(t + a, '\n', n - a);
+                if (!nl) return;
+                pos = (uint64_t)((const char *)nl - t) + 1;
+                line++;
+            }
+            for (; pos < b && pos < n; line++) {
+                const void *nl = memchr(t + pos, '\n', n - pos);
+                uint64_t e = nl ? (uint64_t)((const char *)nl - t) : n;
+                const uint64_t next = nl ? e + 1 : n;
+                if (line & 1) {
+                    while (e > pos && (t[e - 1] == ' ' || t[e - 1] == '\r' || t[e - 1] == '\t' || t[e - 1] == '\v' || t[e - 1] == '\f')) e--;
+                    const RowSpan r{pos, e};
+                    if (line / 2 < n_rows) encode_rows(t, &r, 1, k, keys + line / 2, flags + line / 2);
+                }
+                pos = next;
+            }
+        });
+    for (auto &th : pool) th.join();
+    return n_rows;
+}
+
+}  // namespace
+
 int ss_kmerfa_count_rows(const char *path, uint64_t *n_rows)
 {
     if (!path || !n_rows) return SS_EINVAL;
+    {
+        PlainMap m(path);
+        if (m.ok()) {
+            uint64_t nl = 0;
+            for (uint64_t c : newline_counts(m.p, m.n, host_threads(m.n))) nl += c;
+            if (m.n && m.p[m.n - 1] != '\n') nl++;
+            *n_rows = nl / 2;
+            return SS_OK;
+        }
+    }
     std::string t;
     if (!read_whole_file(path, t)) return SS_EIO;
     uint64_t nl = 0;
@@ -260,6 +366,10 @@ int ss_kmerfa_encode(const char *path, int k, uint64_t n_rows, uint64_t *keys, u
 {
     if (!path || (n_rows && (!keys || !flags))) return SS_EINVAL;
     if (k < 1 || k > 31) return SS_ERANGE;
+    if (threads <= 0) {                         // plain file: mapped, cut at arbitrary offsets, every thread finds its lines
+        PlainMap m(path);
+        if (m.ok()) return encode_mapped(m.p, m.n, k, n_rows, keys, flags) == n_rows ? SS_OK : SS_EINVAL;
+    }
     std::string t;
     if (!read_whole_file(path, t)) return SS_EIO;
     std::vector<RowSpan> rows;

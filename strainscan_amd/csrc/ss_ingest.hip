@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -28,7 +29,10 @@
 
 namespace {
 
-constexpr uint64_t CHUNK = 24ull << 20;   // bytes of text per work item
+// bytes of text per work item (SS_INGEST_CHUNK_MB overrides).  4, 8, 12 and 24 MB parse at the same steady rate
+// (230-270 M reads/s with 20 threads); smaller chunks mean less pinned and private buffer memory to set up and
+// touch for the first time in a process (20 x 27 MB at 24 MB chunks)
+const uint64_t CHUNK = (getenv("SS_INGEST_CHUNK_MB") && atoi(getenv("SS_INGEST_CHUNK_MB")) > 0 ? (uint64_t)atoi(getenv("SS_INGEST_CHUNK_MB")) : 8ull) << 20;
 
 struct Line { uint64_t s, e; };   // [s, e) without the '\n'; s == npos when absent
 
@@ -87,6 +91,21 @@ bool head_is_simple(const char *t, uint64_t n, bool &fastq)
 }  // namespace
 
 namespace ss {
+
+// The parse threads share a few process-wide streams: creating a stream costs ~13 ms on this stack (a
+// hardware queue each: 20 of them were 0.26 s of a 0.33 s first load), the runtime multiplexes streams
+// onto four hardware queues anyway, and a worker waits for ITS work through an event, not a stream.
+constexpr int N_INGEST_STREAMS = 4;
+static hipStream_t ingest_stream(unsigned i)
+{
+    static hipStream_t pool[N_INGEST_STREAMS];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (auto &st : pool)
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    });
+    return pool[i % N_INGEST_STREAMS];
+}
 
 // returns SS_OK and *handled = true when the file was scanned here; *handled = false => caller
 // must use the sequential reader for this file
@@ -151,24 +170,30 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     if (use_pread && fd2 < 0) { munmap((void *)t, n); return SS_EIO; }
     int device = 0;
     hipGetDevice(&device);
+    static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     auto worker = [&](unsigned wid) {
         hipSetDevice(device);
+        const double t_dev = since();
         ss_db::Worker &W = workers[wid];
-        if (W.cap < max_chunk + 64) {            // first use (or a larger chunk than ever before)
+        if (W.cap < max_chunk + 64 || (copy && !W.d_buf)) {   // first use (or a larger chunk than ever before)
             if (W.h_buf) hipHostFree(W.h_buf);
             if (W.d_buf) hipFree(W.d_buf);
             W.h_buf = W.d_buf = nullptr;
             W.cap = 0;
             const uint64_t cap = std::max<uint64_t>(max_chunk + 64, CHUNK + CHUNK / 8);
             if (hipHostMalloc((void **)&W.h_buf, cap, hipHostMallocDefault) != hipSuccess ||
-                hipMalloc((void **)&W.d_buf, cap) != hipSuccess)
+                (copy && hipMalloc((void **)&W.d_buf, cap) != hipSuccess))     // a sink that places the block itself needs none
                 err = SS_ENOMEM;
             else
                 W.cap = cap;
         }
-        if (!W.stream && hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking) != hipSuccess) err = SS_EHIP;
+        if (!W.done && hipEventCreateWithFlags(&W.done, hipEventDisableTiming) != hipSuccess) err = SS_EHIP;
         char *h_buf = W.h_buf, *d_buf = W.d_buf;
-        hipStream_t stream = W.stream;
+        hipStream_t stream = ingest_stream(wid);
+        if (!stream) err = SS_EHIP;
+        if (trace) fprintf(stderr, "[ingest] worker %u: device %.4f s, ready %.4f s\n", wid, t_dev, since());
         for (size_t c; err == SS_OK && (c = next.fetch_add(1)) < n_chunks;) {
             if ((int)(c % (size_t)shard_world) != shard_rank) continue;
             uint64_t out_len = 0, nr = 0;
@@ -195,7 +220,7 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
             if (copy && hipMemcpyAsync(d_buf, h_buf, out_len, hipMemcpyHostToDevice, stream) != hipSuccess) { err = SS_EHIP; break; }
             rc = sink(h_buf, d_buf, out_len, stream);
             if (rc != SS_OK) { err = rc; break; }
-            if (hipStreamSynchronize(stream) != hipSuccess) { err = SS_EHIP; break; }   // buffers are reused
+            if (hipEventRecord(W.done, stream) != hipSuccess || hipEventSynchronize(W.done) != hipSuccess) { err = SS_EHIP; break; }   // buffers are reused
             recs += nr;
             bases += out_len;
         }
@@ -203,6 +228,7 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     std::vector<std::thread> pool;
     for (unsigned w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto &th : pool) th.join();
+    if (trace) fprintf(stderr, "[ingest] %s: %zu chunks, %u threads, done %.4f s\n", path, n_chunks, nthreads, since());
     if (fd2 >= 0) close(fd2);
     munmap((void *)t, n);
     if (err != SS_OK) return err;
@@ -219,7 +245,7 @@ void ss_db::free_workers(Worker *w, int n)
     for (int i = 0; i < n; i++) {
         if (w[i].h_buf) hipHostFree(w[i].h_buf);
         if (w[i].d_buf) hipFree(w[i].d_buf);
-        if (w[i].stream) hipStreamDestroy(w[i].stream);
+        if (w[i].done) hipEventDestroy(w[i].done);
         free(w[i].t_buf);
         w[i] = Worker();
     }
@@ -233,13 +259,48 @@ void ss_db::free_workers(Worker *w, int n)
 // shipped over PCIe once; every later scan is a 10 ms kernel over resident blocks.
 // ---------------------------------------------------------------------------------------------
 struct ss_reads {
-    struct Block { char *d = nullptr; uint64_t len = 0; };
-    std::vector<Block> blocks;
+    // Blocks live back to back in a few large device slabs; every block is followed by at least one '\n'
+    // and padded with '\n' to a multiple of 16 bytes, so a slab is itself one flat base block: one scan
+    // launch per slab (one in all for a typical sample) instead of one per 12 MB block, and no device
+    // allocation per block while loading.
+    struct Slab { char *d = nullptr; uint64_t cap = 0, used = 0; };
+    std::vector<Slab> slabs;
     std::mutex mu;
-    uint64_t n_records = 0, n_bases = 0, device_bytes = 0;
+    uint64_t n_records = 0, n_bases = 0, device_bytes = 0, n_blocks = 0;
     bool has_cut_record = false;      // a record longer than a block was cut with a 30-base overlap (k = 31 only)
-    ss_db::Worker workers[ss_db::MAX_WORKERS];
+    uint64_t first_slab = 0;          // size of the first slab (estimate from the file sizes)
+
+    static uint64_t padded(uint64_t len) { return (len + 1 + 15) & ~15ull; }
+    // room for a block of `len` bytes (+ padding); nullptr when the device is out of memory
+    char *reserve(uint64_t len)
+    {
+        const uint64_t need = padded(len);
+        std::lock_guard<std::mutex> g(mu);
+        if (slabs.empty() || slabs.back().used + need > slabs.back().cap) {
+            Slab sl;
+            sl.cap = std::max<uint64_t>(need, slabs.empty() ? std::max<uint64_t>(first_slab, 64ull << 20) : 512ull << 20);
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hipMalloc((void **)&sl.d, sl.cap) != hipSuccess) return nullptr;
+            if (getenv("SS_INGEST_TRACE"))
+                fprintf(stderr, "[ingest] slab of %.0f MB: %.4f s\n", sl.cap / 1e6,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            slabs.push_back(sl);
+        }
+        Slab &sl = slabs.back();
+        char *p = sl.d + sl.used;
+        sl.used += need;
+        device_bytes += need;
+        n_blocks++;
+        return p;
+    }
 };
+
+namespace {
+// pinned buffers and streams of the parse threads, shared by every ss_reads_load of the process (pinning
+// 20 x 27 MB costs more than parsing a small sample); one load at a time
+ss_db::Worker g_read_workers[ss_db::MAX_WORKERS];
+std::mutex g_read_workers_mu;
+}  // namespace
 
 extern "C" {
 
@@ -249,15 +310,24 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     ss_reads *R = new (std::nothrow) ss_reads();
     if (!R) return SS_ENOMEM;
     uint64_t recs = 0, bases = 0;
-    auto keep = [R](const char *, char *d_buf, uint64_t len, hipStream_t stream) -> int {
-        ss_reads::Block b;
-        if (hipMalloc((void **)&b.d, std::max<uint64_t>(16, len)) != hipSuccess) return SS_ENOMEM;
-        b.len = len;
-        if (hipMemcpyAsync(b.d, d_buf, len, hipMemcpyDeviceToDevice, stream) != hipSuccess) { hipFree(b.d); return SS_EHIP; }
-        std::lock_guard<std::mutex> g(R->mu);
-        R->blocks.push_back(b);
-        R->device_bytes += len;
-        return SS_OK;
+    {   // first slab: FASTQ text is a little over 2 bytes per base, this rank's share of it
+        uint64_t text = 0;
+        for (int i = 0; i < n_paths; i++) {
+            struct stat st;
+            if (paths[i] && paths[i][0] && stat(paths[i], &st) == 0) text += (uint64_t)st.st_size;
+        }
+        R->first_slab = text / 2 / (uint64_t)shard_world + text / 50 + (32ull << 20);
+    }
+    std::lock_guard<std::mutex> pool_lock(g_read_workers_mu);
+    const auto t_load = std::chrono::steady_clock::now();
+    auto load_since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load).count(); };
+    // the parse thread's pinned block goes straight to its place in a slab
+    auto keep = [R](const char *h_buf, char *, uint64_t len, hipStream_t stream) -> int {
+        char *dst = R->reserve(len);
+        if (!dst) return SS_ENOMEM;
+        const uint64_t plen = ss_reads::padded(len);
+        memset(const_cast<char *>(h_buf) + len, '\n', plen - len);       // the pinned buffer has 64 bytes of slack
+        return hipMemcpyAsync(dst, h_buf, plen, hipMemcpyHostToDevice, stream) == hipSuccess ? SS_OK : SS_EHIP;
     };
     int rc = SS_OK;
     // plain files: chunked worker-thread path; everything else (gzip, multi-line records, small files)
@@ -268,7 +338,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
         if (!paths[i]) { rc = SS_EINVAL; break; }
         if (!paths[i][0]) continue;
         bool handled = false;
-        rc = ss::parse_file_parallel(R->workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep, true);
+        rc = ss::parse_file_parallel(g_read_workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep, false);
         if (rc == SS_OK && !handled) seq_files.push_back(i);
     }
     if (rc == SS_OK && !seq_files.empty()) {
@@ -283,7 +353,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
             if (r) { err = r; return; }
             ss_reader_set_overlap(rd, 30);
             const uint64_t cap = 32ull << 20;
-            std::vector<char> buf(cap);
+            std::vector<char> buf(cap + 32);
             for (uint64_t blk = 0; err == SS_OK; blk++) {
                 uint64_t len = 0, nr = 0;
                 r = ss_reader_next(rd, buf.data(), cap, &len, &nr);
@@ -291,15 +361,11 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
                 if (len == 0) break;
                 if (buf[len - 1] != '\n') R->has_cut_record = true;
                 if ((int)((blk + (uint64_t)fi) % (uint64_t)shard_world) != shard_rank) continue;
-                ss_reads::Block b;
-                if (hipMalloc((void **)&b.d, std::max<uint64_t>(16, len)) != hipSuccess) { err = SS_ENOMEM; break; }
-                b.len = len;
-                if (hipMemcpy(b.d, buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) { hipFree(b.d); err = SS_EHIP; break; }
-                {
-                    std::lock_guard<std::mutex> g(R->mu);
-                    R->blocks.push_back(b);
-                    R->device_bytes += len;
-                }
+                char *dst = R->reserve(len);
+                if (!dst) { err = SS_ENOMEM; break; }
+                const uint64_t plen = ss_reads::padded(len);
+                memset(buf.data() + len, '\n', plen - len);
+                if (hipMemcpy(dst, buf.data(), plen, hipMemcpyHostToDevice) != hipSuccess) { err = SS_EHIP; break; }
                 srecs += nr;
                 sbases += len;
             }
@@ -312,9 +378,10 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
         recs += srecs;
         bases += sbases;
     }
-    ss_db::free_workers(R->workers, ss_db::MAX_WORKERS);
     if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
+    const double t_parsed = load_since();
     if (hipDeviceSynchronize() != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
+    if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: files done %.4f s, device idle %.4f s\n", t_parsed, load_since());
     R->n_records = recs;
     R->n_bases = bases;
     *out = R;
@@ -324,8 +391,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
 int ss_reads_destroy(ss_reads *R)
 {
     if (!R) return SS_OK;
-    for (auto &b : R->blocks) hipFree(b.d);
-    ss_db::free_workers(R->workers, ss_db::MAX_WORKERS);
+    for (auto &sl : R->slabs) hipFree(sl.d);
     delete R;
     return SS_OK;
 }
@@ -335,7 +401,7 @@ int ss_reads_info(const ss_reads *R, uint64_t *n_records, uint64_t *n_bases, uin
     if (!R) return SS_EINVAL;
     if (n_records) *n_records = R->n_records;
     if (n_bases) *n_bases = R->n_bases;
-    if (n_blocks) *n_blocks = R->blocks.size();
+    if (n_blocks) *n_blocks = R->n_blocks;
     if (device_bytes) *device_bytes = R->device_bytes;
     return SS_OK;
 }
@@ -346,8 +412,9 @@ int ss_scan_reads(ss_db *db, const ss_reads *R, void *stream)
     int k = 0;
     ss_db_info(db, nullptr, nullptr, nullptr, &k);
     if (R->has_cut_record && k != 31) return SS_ERANGE;   // cut records carry a 30-base overlap
-    for (const auto &b : R->blocks) {
-        int rc = ss_scan_flat_dev(db, b.d, b.len, stream);
+    for (const auto &sl : R->slabs) {
+        if (!sl.used) continue;
+        int rc = ss_scan_flat_dev(db, sl.d, sl.used, stream);
         if (rc) return rc;
     }
     return SS_OK;

@@ -105,11 +105,78 @@ def _cache_dir():
     return None if d in ("", "0", "off") else d
 
 
-def load_tree_text(db_dir, k=L1_K):
-    """kmer.fa + kmers/<id> -> (keys u64[n], flags u8[n], node ids, node row lists in FILE order).
-    The text/directory parse (tens of millions of tokens) is done once per database: a binary
-    image (numpy arrays) is kept under SS_IMAGE_CACHE (default ~/.cache/strainscan_amd), keyed by
-    the database path, size and mtime of kmer.fa."""
+class TreeArrays:
+    """kmer.fa + kmers/<id> as arrays.  keys u64[n] / flags u8[n]: the encoded rows of kmer.fa (only needed
+    to BUILD the device index); ids: node ids ascending; lists[i]: rows of node ids[i] in FILE order
+    (adjust_profile indexes them); urows / uoffs: the same lists de-duplicated and sorted, back to back
+    (what the device-side NodeSet holds: set(map(int, ...)) at identify.py:118)."""
+
+    def __init__(self, keys, flags, ids, rows, offs, urows, uoffs):
+        self.keys, self.flags, self.ids = keys, flags, ids
+        self.rows, self.offs, self.urows, self.uoffs = rows, offs, urows, uoffs
+        self.lists = [rows[offs[i]:offs[i + 1]] for i in range(len(ids))]
+
+
+_TREE_MAGIC = b"SSTREE02"
+
+
+def _pad64(n):
+    return (n + 63) & ~63
+
+
+def _write_tree_cache(path, t):
+    """One raw file, arrays at 64-byte aligned offsets (read back through one memory map: no decompression,
+    no checksum pass, and the 8-byte keys are only paged in when the device index has to be rebuilt)."""
+    same = t.urows is t.rows
+    arrays = [np.asarray(t.ids, np.int64), np.asarray(t.offs, np.int64), np.asarray(t.rows, np.uint32),
+              np.asarray(t.uoffs, np.int64), np.zeros(0, np.uint32) if same else np.asarray(t.urows, np.uint32),
+              np.asarray(t.flags, np.uint8), np.asarray(t.keys, np.uint64)]
+    hdr = np.array([t.keys.size, len(t.ids), t.rows.size, 0 if same else t.urows.size, int(same), 0], np.uint64)
+    tmp = path + ".%d.tmp" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(_TREE_MAGIC)
+        f.write(hdr.tobytes())
+        pos = 8 + hdr.nbytes
+        for a in arrays:
+            f.write(b"\0" * (_pad64(pos) - pos))
+            pos = _pad64(pos)
+            f.write(a.tobytes())
+            pos += a.nbytes
+    os.replace(tmp, path)
+
+
+def _read_tree_cache(path):
+    size = os.path.getsize(path)
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    if size < 56 or bytes(mm[:8]) != _TREE_MAGIC:
+        raise ValueError("not a tree cache")
+    n_rows, n_ids, n_total, n_utotal, same, _ = (int(x) for x in np.frombuffer(mm[8:56], np.uint64))
+    pos = [56]
+
+    def take(dtype, n):
+        o = _pad64(pos[0])
+        nb = n * np.dtype(dtype).itemsize
+        if o + nb > size:
+            raise ValueError("truncated tree cache")
+        pos[0] = o + nb
+        return mm[o:o + nb].view(dtype)
+
+    ids = take(np.int64, n_ids).tolist()
+    offs = np.array(take(np.int64, n_ids + 1))
+    rows = take(np.uint32, n_total)
+    uoffs = np.array(take(np.int64, n_ids + 1))
+    urows = take(np.uint32, n_utotal)
+    flags = take(np.uint8, n_rows)
+    keys = take(np.uint64, n_rows)
+    if pos[0] != size or offs[-1] != n_total or uoffs[-1] != (n_total if same else n_utotal):
+        raise ValueError("inconsistent tree cache")
+    return TreeArrays(keys, flags, ids, rows, offs, rows if same else urows, uoffs)
+
+
+def load_tree(db_dir, k=L1_K):
+    """kmer.fa + kmers/<id> -> TreeArrays.  The text/directory parse (tens of millions of tokens) is done
+    once per database: a binary image is kept under SS_IMAGE_CACHE (default ~/.cache/strainscan_amd), keyed
+    by the database path, size and mtime of kmer.fa."""
     import hashlib
     fa = os.path.join(db_dir, "kmer.fa")
     st = os.stat(fa)
@@ -117,16 +184,11 @@ def load_tree_text(db_dir, k=L1_K):
     tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, int(st.st_mtime), k,
                                              int(os.stat(kdir).st_mtime))).encode()).hexdigest()[:20]
     cdir = _cache_dir()
-    path = os.path.join(cdir, "tree_%s.npz" % tag) if cdir else None
+    path = os.path.join(cdir, "tree_%s.bin" % tag) if cdir else None
     if path and os.path.exists(path):
         try:
-            z = np.load(path)
-            ids = z["ids"].tolist()
-            offs = z["offsets"]
-            rows = z["rows"]
-            lists = [rows[offs[i]:offs[i + 1]] for i in range(len(ids))]
-            return z["keys"], z["flags"], ids, lists
-        except Exception:
+            return _read_tree_cache(path)
+        except (ValueError, OSError):
             pass
     n = _lib.C.c_uint64()
     _lib.check(_lib.lib().ss_kmerfa_count_rows(os.fsencode(fa), _lib.C.byref(n)), "ss_kmerfa_count_rows(%s)" % fa)
@@ -139,33 +201,53 @@ def load_tree_text(db_dir, k=L1_K):
     for i in ids:
         with open(os.path.join(kdir, str(i)), "rb") as f:
             first = f.readline()
-        lists.append(np.array(first.split(), dtype=np.int64) if len(first) < 4096 else
-                     np.fromstring(first, dtype=np.int64, sep=" "))
+        r = (np.array(first.split(), dtype=np.int64) if len(first) < 4096 else np.fromstring(first, dtype=np.int64, sep=" "))
+        if r.size and (r.min() < 0 or r.max() >= max(1, n.value)):
+            raise ValueError("%s/kmers/%d lists a row outside kmer.fa" % (db_dir, i))
+        lists.append(r.astype(np.uint32))
+    offs = np.zeros(len(ids) + 1, np.int64)
+    for i, r in enumerate(lists):
+        offs[i + 1] = offs[i] + r.size
+    rows = np.concatenate(lists) if lists else np.zeros(0, np.uint32)
+    # set(map(int, ...)) of identify.py:118: lists that are already strictly increasing (the builder writes them
+    # so) are their own de-duplicated form
+    inc = rows[1:] > rows[:-1] if rows.size > 1 else np.ones(0, bool)
+    if rows.size > 1:
+        inc[offs[1:-1][(offs[1:-1] > 0) & (offs[1:-1] < rows.size)] - 1] = True
+    if inc.all():
+        urows, uoffs = rows, offs
+    else:
+        ul = [np.unique(r) for r in lists]
+        uoffs = np.zeros(len(ids) + 1, np.int64)
+        for i, r in enumerate(ul):
+            uoffs[i + 1] = uoffs[i] + r.size
+        urows = np.concatenate(ul) if ul else np.zeros(0, np.uint32)
+    t = TreeArrays(keys, flags, ids, rows, offs, urows, uoffs)
     if path:
         try:
             os.makedirs(cdir, exist_ok=True)
-            offs = np.zeros(len(ids) + 1, np.int64)
-            for i, r in enumerate(lists):
-                offs[i + 1] = offs[i] + r.size
-            tmp = path + ".%d.tmp.npz" % os.getpid()
-            np.savez(tmp, keys=keys, flags=flags, ids=np.array(ids, np.int64), offsets=offs,
-                     rows=np.concatenate(lists) if lists else np.zeros(0, np.int64))
-            os.replace(tmp, path)
+            _write_tree_cache(path, t)
         except OSError:
             pass
-    return keys, flags, ids, lists
+    return t
+
+
+def load_tree_text(db_dir, k=L1_K):
+    """-> (keys u64[n], flags u8[n], node ids, node row lists in FILE order); see load_tree."""
+    t = load_tree(db_dir, k)
+    return t.keys, t.flags, t.ids, t.lists
 
 
 class TreeImage:
     def __init__(self, db_dir, upper_keys=True):
         self.db_dir = db_dir
         self.upper_keys = upper_keys
-        keys, flags, ids, lists = load_tree_text(db_dir, L1_K)
-        self.kdb = self._index(db_dir, keys, flags, upper_keys)
-        self.node_ids = list(ids)
-        self.node_rows = dict(zip(ids, lists))   # id -> np.int64 rows in FILE order (adjust_profile indexes it)
+        t = load_tree(db_dir, L1_K)
+        self.kdb = self._index(db_dir, t.keys, t.flags, upper_keys)
+        self.node_ids = list(t.ids)
+        self.node_rows = dict(zip(t.ids, t.lists))   # id -> rows in FILE order (adjust_profile indexes it)
         self.node_index = {i: j for j, i in enumerate(self.node_ids)}
-        self.nodes = _lib.NodeSet(lists)
+        self.nodes = _lib.NodeSet.from_sorted(t.urows, t.uoffs)
         self._scanned = None          # key of the inputs whose counts are in the table
         self._counts = None
         self._stats = None

@@ -16,6 +16,8 @@ import numpy as np
 import pytest
 
 from tests import scenarios as sc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from tests import synth
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,6 +72,53 @@ def test_kmer_fasta_rows():
         if ok:
             assert int(k) == sum(code[ch & 0xDF] << (2 * i) for i, ch in enumerate(r))
             assert bool(f & 2) == any(ch >= 97 for ch in r)
+
+
+def test_kmer_fasta_file_parse_threads_and_gz(tmp_path):
+    """ss_kmerfa_count_rows / ss_kmerfa_encode on a file -- mapped and cut into many chunks at arbitrary
+    byte offsets (SS_HOST_THREADS), and through gzip -- equal the single-pass in-memory encoder: ragged
+    rows, CR LF, trailing blanks, lower case, N, empty rows, no final newline."""
+    import ctypes as C
+    import gzip
+    import subprocess
+    import sys
+    from strainscan_amd import _lib
+    rs = np.random.RandomState(5)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rows = []
+    for i in range(5000):
+        r = lut[rs.randint(0, 4, size=31)].tobytes()
+        x = rs.randint(0, 40)
+        if x == 0: r = r[:17]
+        elif x == 1: r = r[:10] + b"N" + r[11:]
+        elif x == 2: r = r.lower()
+        elif x == 3: r = r + b" \t"
+        elif x == 4: r = b""
+        elif x == 5: r = r + b"\r"
+        rows.append(b">" + (b"h" * rs.randint(1, 9)) + b"\n" + r)
+    text = b"\n".join(rows)                              # no newline at the end
+    want_k, want_f = _lib.encode_kmer_fasta(text, 31)
+    assert want_k.size == 5000
+    plain = tmp_path / "kmer.fa"
+    plain.write_bytes(text)
+    gz = tmp_path / "kmer.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(text)
+    code = (
+        "import sys, numpy as np, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "from strainscan_amd import _lib\n"
+        "n = C.c_uint64()\n"
+        "_lib.check(_lib.lib().ss_kmerfa_count_rows(sys.argv[1].encode(), C.byref(n)), 'count')\n"
+        "k = np.empty(n.value, np.uint64); f = np.empty(n.value, np.uint8)\n"
+        "_lib.check(_lib.lib().ss_kmerfa_encode(sys.argv[1].encode(), 31, n.value, _lib.ptr(k), _lib.ptr(f), 0), 'encode')\n"
+        "np.save(sys.argv[2] + '.k.npy', k); np.save(sys.argv[2] + '.f.npy', f)\n" % ROOT)
+    for path, threads in ((plain, "1"), (plain, "7"), (plain, "64"), (gz, "3")):
+        out = str(tmp_path / ("o_%s_%s" % (path.name, threads)))
+        r = subprocess.run([sys.executable, "-c", code, str(path), out], env=dict(os.environ, SS_HOST_THREADS=threads),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert np.array_equal(np.load(out + ".k.npy"), want_k) and np.array_equal(np.load(out + ".f.npy"), want_f), (path, threads)
 
 
 def test_reader_grammar_cuts_and_gz(tmp_path):
