@@ -193,6 +193,12 @@ int ss_rows_reduce(const ss_db *db, const uint32_t *rows, uint64_t n, ss_node_st
 typedef struct ss_l2 ss_l2;
 /* CSR of the K x S binary matrix (scipy.sparse.load_npz of all_strains_re.npz, :200) */
 int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out);
+/* The same matrix as ready-made bit planes: planes[s * W + k / 32] bit k % 32, W = words_per_plane =
+ * ((K + 31) / 32 rounded up to a multiple of 4), bits beyond K zero.  ss_l2_export_planes writes that
+ * array (S * W dwords) from a handle: the host keeps it as a per-cluster image so that later runs skip
+ * decompressing and re-packing all_strains_re.npz. */
+int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **out);
+int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes);
 int ss_l2_destroy(ss_l2 *h);
 int ss_l2_info(const ss_l2 *h, uint64_t *K, uint32_t *S, uint64_t *words_per_plane);
 /* out1[s] = |X_s & A|, out2[s] = |X_s & A & B|; NULL = all ones.  Serves stat_cov/cal_cov_all

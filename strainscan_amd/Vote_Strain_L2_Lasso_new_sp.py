@@ -122,9 +122,9 @@ def cluster_counts(input_fq, fq2, cls_db_dir, ksize):
     """The `jellyfish count -m ksize --if all_kmer.fasta` + dump + load_kmer_count + ordering by
     k-mer id of :354-389, as one device scan.  Row r of all_kmer.fasta is k-mer id r+1
     (Build_kmer_sets_unique_region_lasso_test_allinone_sp.py:397-399,409-410)."""
-    db = _lib.KmerDB.from_fasta(os.path.join(cls_db_dir, "all_kmer.fasta"), int(ksize), upper_keys=2)
+    from .db import fasta_index, scan_into
+    db = fasta_index(os.path.join(cls_db_dir, "all_kmer.fasta"), int(ksize), 2)
     try:
-        from .db import scan_into
         scan_into(db, [input_fq, fq2])       # resident reads: no second parse, no second PCIe trip
         _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")
         return db.counts_rows()

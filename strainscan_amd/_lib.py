@@ -90,6 +90,8 @@ SIGNATURES = {
     "ss_nodes_reduce": (i32, [vp, vp, vp]),
     "ss_rows_reduce": (i32, [vp, vp, u64, P(NodeStat)]),
     "ss_l2_create": (i32, [vp, vp, u64, u32, P(vp)]),
+    "ss_l2_create_planes": (i32, [vp, u64, u32, P(vp)]),
+    "ss_l2_export_planes": (i32, [vp, vp]),
     "ss_l2_destroy": (i32, [vp]),
     "ss_l2_info": (i32, [vp, P(u64), P(u32), P(u64)]),
     "ss_l2_popc2": (i32, [vp, vp, vp, vp, vp]),

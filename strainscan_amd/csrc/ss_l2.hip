@@ -290,6 +290,42 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
     return SS_OK;
 }
 
+int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **out)
+{
+    if (!out || (!planes && K && S)) return SS_EINVAL;
+    ss_l2 *h = new (std::nothrow) ss_l2();
+    if (!h) return SS_ENOMEM;
+    h->K = K;
+    h->S = S;
+    h->W = ((K + 31) / 32 + 3) & ~3ull;
+    if (h->W == 0) h->W = 4;
+    const uint64_t words = (uint64_t)S * h->W, xbytes = std::max<uint64_t>(1, (uint64_t)S) * h->W * 4;
+    // the padding bits of every plane must be zero (popcounts run over whole words)
+    const uint64_t full = K >> 5, rem = K & 31;
+    for (uint32_t s = 0; s < S && K; s++) {
+        const uint32_t *pl = planes + (uint64_t)s * h->W;
+        if (rem && (pl[full] >> rem)) { delete h; return SS_EINVAL; }
+        for (uint64_t w = full + (rem ? 1 : 0); w < h->W; w++)
+            if (pl[w]) { delete h; return SS_EINVAL; }
+    }
+    if (hipMalloc((void **)&h->d_x, xbytes) != hipSuccess) { delete h; return SS_ENOMEM; }
+    if ((K == 0 && hipMemset(h->d_x, 0, xbytes) != hipSuccess) ||
+        (K && words && hipMemcpy(h->d_x, planes, words * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+        hipFree(h->d_x);
+        delete h;
+        return SS_EHIP;
+    }
+    *out = h;
+    return SS_OK;
+}
+
+int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes)
+{
+    if (!h || (!planes && h->S)) return SS_EINVAL;
+    if (h->S) SS_HIP(hipMemcpy(planes, h->d_x, (uint64_t)h->S * h->W * 4, hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
 int ss_l2_destroy(ss_l2 *h)
 {
     if (!h) return SS_OK;

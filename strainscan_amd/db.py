@@ -100,6 +100,35 @@ def scan_into(kdb, paths):
         kdb.scan_files([p for p in paths if p])
 
 
+def fasta_index(path, k, upper_keys):
+    """Device index of a k-mer FASTA (a cluster's all_kmer.fasta): imported from the image cache when there is
+    one for this file (path, size, mtime, k, key convention), else parsed, built and exported.  Only the
+    minimizer layout (k = 31) has an image; other k are built every time."""
+    import hashlib
+    cdir = _cache_dir()
+    img = None
+    if cdir and int(k) == 31:
+        st = os.stat(path)
+        tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, int(st.st_mtime), int(k),
+                                                 int(upper_keys))).encode()).hexdigest()[:20]
+        img = os.path.join(cdir, "index_%s.bin" % tag)
+        if os.path.exists(img):
+            try:
+                return _lib.KmerDB.from_image(img)
+            except RuntimeError:
+                pass
+    kdb = _lib.KmerDB.from_fasta(path, int(k), upper_keys=upper_keys)
+    if img:
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            tmp = img + ".%d.tmp" % os.getpid()
+            kdb.export(tmp)
+            os.replace(tmp, img)
+        except (RuntimeError, OSError):
+            pass
+    return kdb
+
+
 def _cache_dir():
     d = os.environ.get("SS_IMAGE_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "strainscan_amd"))
     return None if d in ("", "0", "off") else d

@@ -154,8 +154,9 @@ def enet_cv_fit(img, cols, py, keep_rows, trace=None, split=None):
 
 
 def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_cls, l2, msn, pmode, emode,
-                trace=None):
-    """detect_strains on in-memory matrices (X: K x S CSR, om: K x n_clusters CSR)."""
+                trace=None, img=None):
+    """detect_strains on in-memory matrices (X: K x S CSR, om: K x n_clusters CSR); `img`: the device image
+    of X when the caller already has one (X is then not looked at)."""
     new_als = [int(a - 1) for a in all_cls]
     ln = np.asarray(om.tocsr()[:, new_als].sum(axis=1)).ravel().astype(np.int64)   # :191-197
     ln[ln > 1] = 0
@@ -170,7 +171,9 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     n_keep = int(drop.size - np.count_nonzero(drop))
     split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, n_keep, CV_NITER, TEST_SIZE, 0) \
         if n_keep >= 200000 else None
-    img = L2.ClusterImage(X)
+    own_img = img is None
+    if own_img:
+        img = L2.ClusterImage(X)
     try:
         out_columns, out_strains, strain_cov, strain_val, final_src, depth = pre_scan(
             img, py, py_u, sid, cutoff, l2, pmode, emode)
@@ -179,7 +182,8 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
         print("Pre-scan finished, now we will start ElasticNet fitting...")
         coef = enet_cv_fit(img, out_columns, py, ~drop, trace, split)
     finally:
-        img.close()
+        if own_img:
+            img.close()
     lasso_coef = np.atleast_1d(coef)
     if not np.sum(lasso_coef) == 0:                                            # :465-471
         coef_norm = lasso_coef / np.sum(lasso_coef)
@@ -190,12 +194,97 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     return res, res2, strain_cov, strain_val, final_src
 
 
+_L2_MAGIC = b"SSL2IM01"
+
+
+def _pad64(n):
+    return (n + 63) & ~63
+
+
+def _l2_cache_path(input_csv, omatrix):
+    """Cluster image cache (SS_IMAGE_CACHE, like the tree image): keyed by path, size and mtime of both files."""
+    import hashlib
+    import os
+    from .db import _cache_dir
+    cdir = _cache_dir()
+    if not cdir:
+        return None
+    st1, st2 = os.stat(input_csv), os.stat(omatrix)
+    tag = hashlib.sha1(("%s|%d|%d|%s|%d|%d" % (os.path.realpath(input_csv), st1.st_size, int(st1.st_mtime),
+                                                os.path.realpath(omatrix), st2.st_size, int(st2.st_mtime))).encode()).hexdigest()[:20]
+    return os.path.join(cdir, "l2_%s.bin" % tag)
+
+
+def _write_l2_cache(path, img, om):
+    import os
+    om = om.tocsr()
+    arrays = [img.planes(), np.asarray(om.indptr, np.int64), np.asarray(om.indices, np.int32), np.asarray(om.data, np.int8)]
+    hdr = np.array([img.K, img.S, img.W, om.shape[1], om.nnz, 0], np.uint64)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = path + ".%d.tmp" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(_L2_MAGIC)
+        f.write(hdr.tobytes())
+        pos = 8 + hdr.nbytes
+        for a in arrays:
+            f.write(b"\0" * (_pad64(pos) - pos))
+            pos = _pad64(pos)
+            f.write(a.tobytes())
+            pos += a.nbytes
+    os.replace(tmp, path)
+
+
+def _read_l2_cache(path):
+    """-> (ClusterImage, overlap CSR) from the raw image: one memory map, no decompression, no bit packing."""
+    import os
+    size = os.path.getsize(path)
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    if size < 56 or bytes(mm[:8]) != _L2_MAGIC:
+        raise ValueError("not a cluster image")
+    K, S, W, ncls, nnz, _ = (int(x) for x in np.frombuffer(mm[8:56], np.uint64))
+    pos = [56]
+
+    def take(dtype, n):
+        o = _pad64(pos[0])
+        nb = n * np.dtype(dtype).itemsize
+        if o + nb > size:
+            raise ValueError("truncated cluster image")
+        pos[0] = o + nb
+        return mm[o:o + nb].view(dtype)
+
+    planes = take(np.uint32, S * W)
+    indptr, indices, data = take(np.int64, K + 1), take(np.int32, nnz), take(np.int8, nnz)
+    if pos[0] != size or (K and int(indptr[K]) != nnz):
+        raise ValueError("inconsistent cluster image")
+    om = sp.csr_matrix((np.array(data), np.array(indices), np.array(indptr)), shape=(K, ncls))
+    return L2.ClusterImage.from_planes(planes, K, S), om
+
+
 def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_cov, omatrix, all_cls, l2, msn, pmode,
                    emode):
     """:177-478.  input_csv = <C>/all_strains_re.npz, ids = <C>/id2strain_re.pkl,
     omatrix = <C>/overlap_matrix.npz, input_y = counts ordered by k-mer id with 1s zeroed."""
-    X = sp.load_npz(input_csv)
-    om = sp.load_npz(omatrix)
     with open(ids, "rb") as f:
         sid = pickle.load(f)
-    return detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_cls, l2, msn, pmode, emode)
+    cache = _l2_cache_path(input_csv, omatrix)
+    img = om = None
+    if cache:
+        try:
+            img, om = _read_l2_cache(cache)
+        except (OSError, ValueError):
+            img = None
+    if img is None:
+        # scipy reads the .npz through zipfile (inflate + CRC: ~7 ms per million non-zeros); done once per
+        # database, the bit planes and the overlap arrays are then kept as a raw image
+        img = L2.ClusterImage(sp.load_npz(input_csv))
+        om = sp.load_npz(omatrix)
+        if cache:
+            try:
+                _write_l2_cache(cache, img, om)
+            except OSError:
+                pass
+    try:
+        return detect_core(None, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_cls, l2, msn, pmode,
+                           emode, img=img)
+    finally:
+        img.close()

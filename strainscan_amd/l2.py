@@ -61,6 +61,29 @@ class ClusterImage:
         _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
         self.W = int(w.value)
 
+    @classmethod
+    def from_planes(cls, planes, K, S):
+        """Bit planes as ss_l2_export_planes wrote them (uint32[S * W])."""
+        _lib.require_gpu()
+        planes = np.ascontiguousarray(planes, np.uint32)
+        self = cls.__new__(cls)
+        self.K, self.S = int(K), int(S)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ss_l2_create_planes(_lib.ptr(planes), self.K, self.S, C.byref(h)), "ss_l2_create_planes")
+        self._h = h
+        w = C.c_uint64()
+        _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
+        self.W = int(w.value)
+        if planes.size != self.S * self.W:
+            self.close()
+            raise ValueError("plane array does not match K, S")
+        return self
+
+    def planes(self):
+        out = np.zeros(self.S * self.W, np.uint32)
+        _lib.check(_lib.lib().ss_l2_export_planes(self._h, _lib.ptr(out)), "ss_l2_export_planes")
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().ss_l2_destroy(self._h)

@@ -151,3 +151,66 @@ def test_detect_core_vs_oracle_medium():
     assert len(names) >= 2
     for nm, c in zip(names, coef / coef.sum()):
         assert abs(float(res[nm]) - c) <= ABUND_TOL
+
+
+@pytest.mark.gpu
+def test_cluster_image_cache(tmp_path, monkeypatch):
+    """detect_strains from the cluster's files: the first call packs all_strains_re.npz and writes the raw
+    cluster image, the second reads it back (no scipy load, no packing), a damaged image is ignored; all
+    equal detect_core on the in-memory matrices.  ss_l2_export_planes / ss_l2_create_planes round trip;
+    planes with bits beyond K are refused."""
+    import pickle
+    import scipy.sparse as sp
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    from strainscan_amd import l2 as L2
+    from strainscan_amd import _lib
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    case = sc.l2_case(sc.L2_CASES[0])
+    d = tmp_path / "C1"
+    d.mkdir()
+    sp.save_npz(str(d / "all_strains_re.npz"), sp.csr_matrix(case["X"]))
+    sp.save_npz(str(d / "overlap_matrix.npz"), sp.csr_matrix(case["O"]))
+    with open(d / "id2strain_re.pkl", "wb") as f:
+        pickle.dump(case["ids"], f)
+
+    def run_files():
+        with contextlib.redirect_stdout(io.StringIO()):
+            return m.detect_strains(str(d / "all_strains_re.npz"), case["y"].copy(), str(d / "id2strain_re.pkl"),
+                                    case["ksize"], case["npp25"], case["npp75"], case["npp_out"], case["cls_cov"],
+                                    str(d / "overlap_matrix.npz"), case["all_cls"], case["l2"], case["msn"],
+                                    case["pmode"], case["emode"])
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        want = m.detect_core(case["X"], case["O"], case["ids"], case["y"].copy(), case["ksize"], case["npp25"],
+                             case["npp75"], case["npp_out"], case["cls_cov"], case["all_cls"], case["l2"], case["msn"],
+                             case["pmode"], case["emode"])
+    first = run_files()
+    imgs = [f for f in os.listdir(tmp_path / "cache") if f.startswith("l2_")]
+    assert len(imgs) == 1
+    calls = []
+    monkeypatch.setattr(sp, "load_npz", lambda *a, **k: calls.append(a) or (_ for _ in ()).throw(AssertionError("cache not used")))
+    second = run_files()
+    assert not calls
+    monkeypatch.undo()
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    path = tmp_path / "cache" / imgs[0]
+    raw = path.read_bytes()
+    path.write_bytes(raw[: len(raw) // 2])              # truncated image: ignored, rebuilt from the .npz files
+    third = run_files()
+    assert path.stat().st_size == len(raw)
+    for got in (first, second, third):
+        assert [dict(x) for x in got] == [dict(x) for x in want]
+    # plane round trip
+    img = L2.ClusterImage(sp.csr_matrix(case["X"]))
+    pl = img.planes()
+    img2 = L2.ClusterImage.from_planes(pl, img.K, img.S)
+    assert np.array_equal(img2.planes(), pl) and (img2.K, img2.S, img2.W) == (img.K, img.S, img.W)
+    a1, b1 = img.popc2(None, None)
+    a2, b2 = img2.popc2(None, None)
+    assert np.array_equal(a1, a2) and np.array_equal(a1, np.asarray(sp.csr_matrix(case["X"]).sum(axis=0)).ravel())
+    if img.K % 32:
+        bad = pl.copy()
+        bad[img.K // 32] |= np.uint32(1 << 31)
+        with pytest.raises(RuntimeError):
+            L2.ClusterImage.from_planes(bad, img.K, img.S)
+    img.close(); img2.close()
