@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <atomic>
 #include <functional>
+#include <vector>
 #include <string.h>
 
 #include "strainscan_hip.h"
@@ -98,7 +99,13 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
 using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
                         uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink, bool copy = true);
+int parse_text_parallel(ss_db::Worker *workers, const char *text, uint64_t n, const char *path, int shard_rank,
+                        int shard_world, uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink,
+                        bool copy = true);
+struct InflatedText { char *p = nullptr; uint64_t n = 0; };
+std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths);
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled);
+int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles);
 }  // namespace ss

@@ -14,6 +14,7 @@
 // multi-line FASTQ, files the boundary rule cannot segment) takes the sequential reader.
 #include "ss_common.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -107,6 +108,116 @@ static hipStream_t ingest_stream(unsigned i)
     return pool[i % N_INGEST_STREAMS];
 }
 
+// ---------------------------------------------------------------------------------------------
+// gzip input.  zlib inflates ~350 MB/s of FASTQ text per thread and a gzip member cannot be cut into
+// independent pieces, so a .gz sample is bound by one inflate thread per file (the reference pipes
+// `zcat` into jellyfish, identify.py:81-84: the same bound at a lower rate).  When libdeflate is on the
+// machine (dlopen: the image ships the runtime library, not its header) a file is inflated WHOLE into
+// memory at 2-3x that rate, all .gz inputs of a call concurrently, and the text is then parsed by the
+// chunked parser above like a plain file.  Otherwise, or when the text would not fit the memory budget
+// (SS_INFLATE_MAX_GB, default a quarter of the physical memory), the zlib reader streams it as before.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Deflate {
+    void *(*alloc)() = nullptr;
+    int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    bool ok = false;
+};
+const Deflate &deflate_lib()
+{
+    static Deflate d;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("SS_NO_LIBDEFLATE")) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        d.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        d.gunzip = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
+        d.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        d.ok = d.alloc && d.gunzip && d.release;
+    });
+    return d;
+}
+}  // namespace
+
+uint64_t inflate_budget_bytes()
+{
+    if (const char *e = getenv("SS_INFLATE_MAX_GB")) return (uint64_t)(atof(e) * 1e9);
+    const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+    return pages > 0 && psz > 0 ? (uint64_t)pages * (uint64_t)psz / 4 : (8ull << 30);
+}
+
+// path -> malloc'ed text of all its gzip members, or false (not gzip, no libdeflate, damaged, over `budget`)
+bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len)
+{
+    const Deflate &L = deflate_lib();
+    if (!L.ok) return false;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) { close(fd); return false; }
+    const uint64_t in_n = (uint64_t)st.st_size;
+    const unsigned char *in = (const unsigned char *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (in == MAP_FAILED) return false;
+    bool ok = in[0] == 0x1f && in[1] == 0x8b;
+    char *out = nullptr;
+    uint64_t cap = 0, opos = 0;
+    if (ok) {
+        // ISIZE (last four bytes) = length of the LAST member mod 2^32: exact for the usual single-member file
+        // below 4 GB of text; k * 2^32 is added while the text would be shorter than the file; a file of many
+        // members (bgzip) gets four times its size; the buffer grows when a member does not fit
+        uint64_t guess = (uint64_t)in[in_n - 4] | (uint64_t)in[in_n - 3] << 8 | (uint64_t)in[in_n - 2] << 16 | (uint64_t)in[in_n - 1] << 24;
+        while (guess < in_n) guess += 1ull << 32;
+        cap = std::max<uint64_t>(guess, std::min<uint64_t>(4 * in_n, guess + (1ull << 32))) + (64 << 10);
+        if (guess <= (1ull << 20)) cap = 4 * in_n + (64 << 10);       // small last member: many members
+        ok = cap <= budget && (out = (char *)malloc(cap)) != nullptr;
+    }
+    void *dec = ok ? L.alloc() : nullptr;
+    ok = ok && dec;
+    uint64_t ipos = 0;
+    while (ok && ipos + 18 <= in_n && in[ipos] == 0x1f && in[ipos + 1] == 0x8b) {
+        size_t ain = 0, aout = 0;
+        const int r = L.gunzip(dec, in + ipos, in_n - ipos, out + opos, cap - opos, &ain, &aout);
+        if (r == 0) { ipos += ain; opos += aout; continue; }
+        if (r != 3) { ok = false; break; }                             // damaged data: let the zlib reader report it
+        const uint64_t ncap = cap + std::max<uint64_t>(cap / 2, 1ull << 32);   // LIBDEFLATE_INSUFFICIENT_SPACE
+        char *no = ncap <= budget ? (char *)realloc(out, ncap) : nullptr;
+        if (!no) { ok = false; break; }
+        out = no;
+        cap = ncap;
+    }
+    if (dec) L.release(dec);
+    munmap((void *)in, in_n);
+    if (!ok || ipos == 0) { free(out); return false; }
+    *text = out;
+    *len = opos;
+    return true;
+}
+
+// All gzip inputs of a call inflated concurrently (one thread per file); entry i stays empty when path i is not
+// gzip or cannot be inflated here.  The caller frees the texts.
+std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths)
+{
+    std::vector<InflatedText> out((size_t)std::max(0, n_paths));
+    if (!deflate_lib().ok) return out;
+    const uint64_t budget = inflate_budget_bytes() / (uint64_t)std::max(1, n_paths);
+    std::vector<std::thread> pool;
+    for (int i = 0; i < n_paths; i++) {
+        if (!paths[i] || !paths[i][0]) continue;
+        unsigned char magic[2] = {0, 0};
+        FILE *f = fopen(paths[i], "rb");
+        if (!f) continue;
+        const bool gz = fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        fclose(f);
+        if (gz) pool.emplace_back([&out, paths, i, budget] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n)) out[i].p = nullptr; });
+    }
+    for (auto &th : pool) th.join();
+    return out;
+}
+
 // returns SS_OK and *handled = true when the file was scanned here; *handled = false => caller
 // must use the sequential reader for this file
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled)
@@ -118,6 +229,14 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
                                [db](const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream) {
                                    return ss_scan_flat_dev(db, zero_copy ? h_buf : d_buf, len, stream);
                                }, !zero_copy);
+}
+
+int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled)
+{
+    return parse_text_parallel(db->workers, text, n, nullptr, 0, 1, n_records, n_bases, handled,
+                               [db](const char *, char *d_buf, uint64_t len, hipStream_t stream) {
+                                   return ss_scan_flat_dev(db, d_buf, len, stream);
+                               }, true);
 }
 
 // Parse `path` with worker threads; each flat block (already copied to the worker's device buffer
@@ -135,9 +254,22 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     const char *t = (const char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (t == MAP_FAILED) return SS_OK;
-    bool fastq = true;
-    if ((unsigned char)t[0] == 0x1f || !head_is_simple(t, n, fastq)) { munmap((void *)t, n); return SS_OK; }
+    if ((unsigned char)t[0] == 0x1f) { munmap((void *)t, n); return SS_OK; }
     madvise((void *)t, n, MADV_SEQUENTIAL);
+    const int rc = parse_text_parallel(workers, t, n, path, shard_rank, shard_world, n_records, n_bases, handled, sink, copy);
+    munmap((void *)t, n);
+    return rc;
+}
+
+// The chunked parse of a text that is in memory: a mapped file (`path` then names it: chunks are pread() from it)
+// or a buffer (path == nullptr: an inflated .gz, parsed where it lies).
+int parse_text_parallel(ss_db::Worker *workers, const char *t, uint64_t n, const char *path, int shard_rank,
+                        int shard_world, uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink,
+                        bool copy)
+{
+    *handled = false;
+    bool fastq = true;
+    if (n < (4u << 20) || !head_is_simple(t, n, fastq)) return SS_OK;
 
     // chunk starts at record boundaries
     std::vector<uint64_t> starts;
@@ -151,7 +283,7 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     const size_t n_chunks = starts.size() - 1;
     uint64_t max_chunk = 0;
     for (size_t c = 0; c < n_chunks; c++) max_chunk = std::max(max_chunk, starts[c + 1] - starts[c]);
-    if (max_chunk > 8 * CHUNK) { munmap((void *)t, n); return SS_OK; }   // a giant record: sequential path
+    if (max_chunk > 8 * CHUNK) return SS_OK;   // a giant record: sequential path
 
     // parse threads: each owns a text buffer, a pinned buffer, a device buffer and a stream.  Measured on
     // the MI355X host (scripts/bench_e2e.py): 21 M reads/s per thread up to ~20 threads (256 M reads/s =
@@ -165,9 +297,9 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     std::atomic<int> err(SS_OK);
     // chunks are pread() into a private buffer before parsing: parsing the mapping directly takes a minor page
     // fault every 4 KB (1.2 M faults per 5 GB) and runs at half the rate.  SS_INGEST_PREAD=0 parses the mapping.
-    const bool use_pread = !(getenv("SS_INGEST_PREAD") && atoi(getenv("SS_INGEST_PREAD")) == 0);
+    const bool use_pread = path && !(getenv("SS_INGEST_PREAD") && atoi(getenv("SS_INGEST_PREAD")) == 0);
     const int fd2 = use_pread ? open(path, O_RDONLY) : -1;
-    if (use_pread && fd2 < 0) { munmap((void *)t, n); return SS_EIO; }
+    if (use_pread && fd2 < 0) return SS_EIO;
     int device = 0;
     hipGetDevice(&device);
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
@@ -228,9 +360,8 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
     std::vector<std::thread> pool;
     for (unsigned w = 0; w < nthreads; w++) pool.emplace_back(worker, w);
     for (auto &th : pool) th.join();
-    if (trace) fprintf(stderr, "[ingest] %s: %zu chunks, %u threads, done %.4f s\n", path, n_chunks, nthreads, since());
+    if (trace) fprintf(stderr, "[ingest] %s: %zu chunks, %u threads, done %.4f s\n", path ? path : "(inflated text)", n_chunks, nthreads, since());
     if (fd2 >= 0) close(fd2);
-    munmap((void *)t, n);
     if (err != SS_OK) return err;
     *n_records += recs;
     *n_bases += bases;
@@ -334,13 +465,21 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     // goes through the sequential reader -- one thread PER FILE, so the two mates of a paired
     // .fastq.gz sample inflate concurrently (zlib is the limiter there)
     std::vector<int> seq_files;
+    std::vector<ss::InflatedText> texts = ss::inflate_gz_inputs(paths, n_paths);     // .gz inputs, inflated concurrently
     for (int i = 0; i < n_paths && rc == SS_OK; i++) {
         if (!paths[i]) { rc = SS_EINVAL; break; }
         if (!paths[i][0]) continue;
         bool handled = false;
-        rc = ss::parse_file_parallel(g_read_workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep, false);
+        if (texts[i].p)
+            rc = ss::parse_text_parallel(g_read_workers, texts[i].p, texts[i].n, nullptr, shard_rank, shard_world, &recs,
+                                         &bases, &handled, keep, false);
+        else
+            rc = ss::parse_file_parallel(g_read_workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep, false);
+        free(texts[i].p);
+        texts[i].p = nullptr;
         if (rc == SS_OK && !handled) seq_files.push_back(i);
     }
+    for (auto &tx : texts) free(tx.p);
     if (rc == SS_OK && !seq_files.empty()) {
         std::atomic<int> err(SS_OK);
         std::atomic<uint64_t> srecs(0), sbases(0);

@@ -427,19 +427,24 @@ int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_
     uint64_t recs = 0, total = 0;
     const char *seq_env = getenv("SS_INGEST");
     const bool allow_parallel = !(seq_env && !strcmp(seq_env, "sequential"));
-    for (int i = 0; i < n_paths; i++) {
+    for (int i = 0; i < n_paths; i++)
         if (!paths[i]) return SS_EINVAL;
+    // .gz inputs are inflated whole (libdeflate, all files at once) and parsed like plain text when possible
+    std::vector<ss::InflatedText> texts;
+    if (allow_parallel) texts = ss::inflate_gz_inputs(paths, n_paths);
+    int rc = SS_OK;
+    for (int i = 0; i < n_paths && rc == SS_OK; i++) {
         if (!paths[i][0]) continue;            // '' = no second file (StrainScan.py:182)
         bool handled = false;
         if (allow_parallel) {
-            int rc = ss::scan_file_parallel(db, paths[i], &recs, &total, &handled);
-            if (rc) return rc;
+            if (!texts.empty() && texts[i].p) rc = ss::scan_text_parallel(db, texts[i].p, texts[i].n, &recs, &total, &handled);
+            else rc = ss::scan_file_parallel(db, paths[i], &recs, &total, &handled);
         }
-        if (!handled) {
-            int rc = scan_files_sequential(db, &paths[i], 1, &recs, &total);
-            if (rc) return rc;
-        }
+        if (!texts.empty()) { free(texts[i].p); texts[i].p = nullptr; }
+        if (rc == SS_OK && !handled) rc = scan_files_sequential(db, &paths[i], 1, &recs, &total);
     }
+    for (auto &tx : texts) free(tx.p);
+    if (rc) return rc;
     if (n_records) *n_records = recs;
     if (n_bases) *n_bases = total;
     return SS_OK;

@@ -441,3 +441,41 @@ def test_node_reduce_synthetic_counts(L):
         have = tuple(int(got[j][f]) for f in ("length", "n_pos", "n_kept", "sum_kept", "median2"))
         assert have == want, (j, have, want)
     assert got[0]["n_pos"] > 32768 and got[3]["n_pos"] > 0 and got[7]["length"] == 0
+
+
+@pytest.mark.gpu
+def test_gz_whole_file_inflate(L, tmp_path):
+    """.gz inputs large enough for the chunked parser (>= 4 MB of text) are inflated whole (libdeflate) and
+    parsed like plain text: single-member, multi-member (two concatenated gzip streams) and a pair of files,
+    through ss_scan_files and through the resident read set, count exactly like the plain files."""
+    import gzip
+    kfa, flat = _random_db_and_reads(77, 80000, 100000)
+    recs = [r for r in flat.split(b"\n") if r]
+    fq = b"".join(b"@r%d\n" % i + r + b"\n+\n" + bytes(33 + (i * 7 + j) % 40 for j in range(len(r))) + b"\n"
+                  for i, r in enumerate(recs))
+    assert len(fq) > (16 << 20)          # each half of the pair is above the 4 MB threshold of the chunked parser
+    half = fq.index(b"\n@r%d\n" % (len(recs) // 2)) + 1
+    plain = tmp_path / "a.fq"
+    plain.write_bytes(fq)
+    one = tmp_path / "one.fq.gz"
+    one.write_bytes(gzip.compress(fq, 1))
+    multi = tmp_path / "multi.fq.gz"
+    multi.write_bytes(gzip.compress(fq[:half], 1) + gzip.compress(fq[half:], 6))
+    p1, p2 = tmp_path / "p_1.fq.gz", tmp_path / "p_2.fq.gz"
+    p1.write_bytes(gzip.compress(fq[:half], 1))
+    p2.write_bytes(gzip.compress(fq[half:], 1))
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_files([str(plain)])
+    want = db.counts_rows().copy()
+    assert want.sum() > 0
+    for paths in ([str(one)], [str(multi)], [str(p1), str(p2)]):
+        db.reset()
+        nrec, _ = db.scan_files(paths)
+        assert nrec == len(recs)
+        assert np.array_equal(db.counts_rows(), want), paths
+        rs = L.ReadSet(paths, 0, 1)
+        assert rs.info()["n_records"] == len(recs)
+        db.reset()
+        rs.scan_into(db)
+        assert np.array_equal(db.counts_rows(), want), paths
+        rs.close()
