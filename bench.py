@@ -290,6 +290,14 @@ def main():
         cpu = dict(value=round(n_s / t_cpu / 1e6, 4), unit="M reads/s", cores=threads, kind="port",
                    sample="first %d reads of the rank-0 batch vs the same %d-row table; oracle/ss_oracle.c "
                           "orc_count_flat (OpenMP), table build excluded" % (n_s, n_rows))
+        # the reference runs jellyfish with a fixed -t 8 (identify.py:82): the same counter on 8 threads, smaller sample
+        if threads > 8:
+            n8 = int(max(20000, min(n_s, n_s * 8.0 / threads * 0.5)))
+            t1 = time.perf_counter()
+            orc.count_flat(db_spec["okeys"], K, flat[: n8 * (READ_LEN + 1)], 8)
+            t8 = time.perf_counter() - t1 - t_build
+            cpu["value_8_threads"] = round(n8 / max(1e-6, t8) / 1e6, 4)
+            cpu["sample_8_threads"] = "first %d reads" % n8
         # and use it as a checker on that sample (never the other way round)
         db.reset(stream)
         db.scan_flat_dev(reads.data_ptr(), n_s * (READ_LEN + 1), stream)
