@@ -60,6 +60,12 @@ int ss_memset_dev(void *dst_dev, int byte, uint64_t bytes, void *stream);
  * table on the GPU for n_seq equal-length sequences stored back to back.
  * ------------------------------------------------------------------------------------------ */
 int ss_revcomp(const char *in, char *out, uint64_t n);
+
+/* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
+ * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,
+ * random_state=0)): bits[i] bit f = row i is in the test set of split f (the first n_test entries of the f-th
+ * numpy.random.RandomState(seed).permutation(n)).  Host only; n < 2^32, n_splits <= 31. */
+int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, uint32_t *bits);
 int ss_revcomp_dev(const char *in_dev, char *out_dev, uint64_t seq_len, uint64_t n_seq, void *stream);
 
 /* --------------------------------------------------------------------------------------------

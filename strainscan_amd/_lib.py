@@ -54,6 +54,7 @@ SIGNATURES = {
     "ss_memcpy_d2h": (i32, [vp, vp, u64, vp]),
     "ss_memset_dev": (i32, [vp, i32, u64, vp]),
     "ss_revcomp": (i32, [cp, cp, u64]),
+    "ss_shuffle_split_bits": (i32, [u64, i32, u64, u32, vp]),
     "ss_revcomp_dev": (i32, [vp, vp, u64, u64, vp]),
     "ss_kmerfa_count_rows": (i32, [cp, P(u64)]),
     "ss_kmerfa_encode": (i32, [cp, i32, u64, vp, vp, i32]),

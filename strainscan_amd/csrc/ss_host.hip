@@ -206,6 +206,100 @@ int ss_memset_dev(void *dst, int byte, uint64_t bytes, void *stream)
     return SS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ShuffleSplit(n_splits, test_size, random_state=seed) of scikit-learn 0.23 (model_selection/_split.py):
+// for every split `rng.permutation(n)[:n_test]` is the test set, rng = numpy.random.RandomState(seed).
+// Restated: MT19937 seeded by init_genrand(seed) (numpy _legacy_seeding for an integer), permutation(n) =
+// Fisher-Yates from the top -- for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j]) -- with
+// random_interval(max) = 32-bit draws masked to the next power of two minus one, redrawn while > max
+// (numpy/random/src/distributions: random_interval; mtrand.pyx: _shuffle_raw).  One thread walks the
+// generator (the splits share ONE stream, in order) and writes the swap partners of a split; worker
+// threads apply the swaps of different splits concurrently (that is where the cache misses are).
+// Pinned against numpy itself in tests/test_abi_and_host.py and against sklearn's ShuffleSplit golden.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct MT19937 {
+    uint32_t mt[624], out[624];
+    int pos;
+    explicit MT19937(uint32_t seed)
+    {
+        mt[0] = seed;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        pos = 624;
+    }
+    void refill()                       // the next 624 words, tempered
+    {
+        auto tw = [](uint32_t u, uint32_t v, uint32_t m) {
+            const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+            return m ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        };
+        int i = 0;
+        for (; i < 624 - 397; i++) mt[i] = tw(mt[i], mt[i + 1], mt[i + 397]);
+        for (; i < 623; i++) mt[i] = tw(mt[i], mt[i + 1], mt[i - (624 - 397)]);
+        mt[623] = tw(mt[623], mt[0], mt[396]);
+        for (i = 0; i < 624; i++) {
+            uint32_t y = mt[i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[i] = y;
+        }
+        pos = 0;
+    }
+    inline uint32_t next()
+    {
+        if (pos == 624) refill();
+        return out[pos++];
+    }
+};
+}  // namespace
+
+int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, uint32_t *bits)
+{
+    if (n_splits < 1 || n_splits > 31 || n_test > n || n > 0xFFFFFFFFull || (n && !bits)) return SS_EINVAL;
+    if (n) memset(bits, 0, n * sizeof(uint32_t));
+    if (n < 2) {
+        for (uint64_t i = 0; i < n_test; i++) bits[i] = (1u << n_splits) - 1u;      // permutation(1) = [0]
+        return SS_OK;
+    }
+    MT19937 rng(seed);
+    const unsigned in_flight = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool((size_t)n_splits);
+    std::atomic<int> err(SS_OK);
+    for (int f = 0; f < n_splits; f++) {
+        if (f >= (int)in_flight) pool[(size_t)f - in_flight].join();                 // bounds the memory: in_flight x 8 n bytes
+        std::vector<uint32_t> *js = new (std::nothrow) std::vector<uint32_t>();
+        if (js) { try { js->resize(n); } catch (...) { delete js; js = nullptr; } }
+        if (!js) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); continue; }
+        uint32_t *J = js->data();
+        for (uint64_t hi = n - 1; hi >= 1;) {                                         // the generator, in stream order
+            // all i in (mask >> 1, hi] share the mask: the next power of two above i, minus one
+            uint32_t mask = (uint32_t)hi;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            const uint64_t lo = (uint64_t)(mask >> 1) + 1;
+            for (uint64_t i = hi; i >= lo; i--) {
+                uint32_t v;
+                while ((v = rng.next() & mask) > (uint32_t)i) {}
+                J[i] = v;
+            }
+            hi = lo - 1;
+        }
+        pool[(size_t)f] = std::thread([js, n, n_test, f, bits, &err] {
+            std::vector<uint32_t> x;
+            try { x.resize(n); } catch (...) { err = SS_ENOMEM; delete js; return; }
+            for (uint64_t i = 0; i < n; i++) x[i] = (uint32_t)i;
+            const uint32_t *J = js->data();
+            for (uint64_t i = n - 1; i >= 1; i--) std::swap(x[i], x[J[i]]);
+            const uint32_t bit = 1u << f;
+            for (uint64_t i = 0; i < n_test; i++) __atomic_fetch_or(&bits[x[i]], bit, __ATOMIC_RELAXED);
+            delete js;
+        });
+    }
+    for (int f = std::max(0, n_splits - (int)in_flight); f < n_splits; f++) pool[(size_t)f].join();
+    return err;
+}
+
 int ss_revcomp(const char *in, char *out, uint64_t n)
 {
     if (n && (!in || !out)) return SS_EINVAL;

@@ -196,8 +196,20 @@ def alpha_grid(q_total, n, l1_ratio=0.5, eps=1e-3, n_alphas=50):
 
 
 def shuffle_split_test_bits(n, n_splits=20, test_size=0.5, seed=0):
-    """ShuffleSplit(n_splits, test_size, random_state=seed) -> uint32[n], bit f = in test of fold f.
-    numpy's legacy RandomState.permutation IS the specification here (sklearn calls it)."""
+    """ShuffleSplit(n_splits, test_size, random_state=seed) -> (uint32[n], n_test): bit f of entry i = row i is in
+    the test set of fold f.  The permutations are numpy's legacy RandomState.permutation (sklearn calls it); the
+    native restatement (ss_shuffle_split_bits) draws the same stream several times faster and is pinned against
+    numpy in the tests."""
+    n = int(n)
+    n_test = int(math.ceil(test_size * n))
+    bits = np.zeros(n, np.uint32)
+    _lib.check(_lib.lib().ss_shuffle_split_bits(n, int(n_splits), n_test, int(seed), _lib.ptr(bits)),
+               "ss_shuffle_split_bits")
+    return bits, n_test
+
+
+def shuffle_split_test_bits_numpy(n, n_splits=20, test_size=0.5, seed=0):
+    """The same through numpy.random.RandomState itself (the specification; used by the tests)."""
     rng = np.random.RandomState(seed)
     n_test = int(math.ceil(test_size * n))
     bits = np.zeros(n, np.uint32)

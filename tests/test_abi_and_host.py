@@ -121,6 +121,24 @@ def test_kmer_fasta_file_parse_threads_and_gz(tmp_path):
         assert np.array_equal(np.load(out + ".k.npy"), want_k) and np.array_equal(np.load(out + ".f.npy"), want_f), (path, threads)
 
 
+def test_shuffle_split_native_equals_numpy():
+    """ss_shuffle_split_bits (MT19937 + masked-rejection Fisher-Yates, restated) draws exactly the test sets of
+    numpy.random.RandomState(seed).permutation -- the specification sklearn's ShuffleSplit calls -- for sizes around
+    every power of two it masks with, several seeds, split counts and test fractions (test_l2_host_helpers checks the
+    same function against the ShuffleSplit indices recorded from scikit-learn itself)."""
+    from strainscan_amd import l2
+    for n in list(range(0, 20)) + [31, 32, 33, 255, 256, 257, 1000, 4095, 4096, 4097, 65535, 65536, 65537, 300001]:
+        for seed in (0, 1, 12345, 2 ** 32 - 1):
+            a, na = l2.shuffle_split_test_bits(n, 20, 0.5, seed)
+            b, nb = l2.shuffle_split_test_bits_numpy(n, 20, 0.5, seed)
+            assert na == nb and np.array_equal(a, b), (n, seed)
+    for splits, frac in ((1, 0.5), (3, 0.1), (31, 0.9), (7, 1.0)):
+        a, _ = l2.shuffle_split_test_bits(5003, splits, frac, 42)
+        b, _ = l2.shuffle_split_test_bits_numpy(5003, splits, frac, 42)
+        assert np.array_equal(a, b), (splits, frac)
+    assert l2._lib.lib().ss_shuffle_split_bits(10, 32, 5, 0, None) != 0          # more than 31 splits: refused
+
+
 def test_reader_grammar_cuts_and_gz(tmp_path):
     from oracle import oracle as orc
     from strainscan_amd import _lib
