@@ -146,7 +146,16 @@ uint64_t inflate_budget_bytes()
 {
     if (const char *e = getenv("SS_INFLATE_MAX_GB")) return (uint64_t)(atof(e) * 1e9);
     const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
-    return pages > 0 && psz > 0 ? (uint64_t)pages * (uint64_t)psz / 4 : (8ull << 30);
+    uint64_t mem = pages > 0 && psz > 0 ? (uint64_t)pages * (uint64_t)psz : (32ull << 30);
+    // a container may be allowed far less than the machine has (cgroup v2, then v1)
+    for (const char *f : {"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"}) {
+        FILE *fp = fopen(f, "r");
+        if (!fp) continue;
+        unsigned long long lim = 0;
+        if (fscanf(fp, "%llu", &lim) == 1 && lim > 0 && lim < mem) mem = lim;      // "max" does not parse: no limit
+        fclose(fp);
+    }
+    return mem / 4;
 }
 
 // path -> malloc'ed text of all its gzip members, or false (not gzip, no libdeflate, damaged, over `budget`)
