@@ -136,6 +136,11 @@ def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on the C stdout of every rank
+    # (flushed at exit): keep the real stdout aside for the JSON line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -317,7 +322,7 @@ def main():
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
                    roofline=roofline, cpu_baseline=cpu,
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum())))
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or self_group:
         dist.destroy_process_group()
 
