@@ -278,10 +278,18 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
             uint32_t mask = (uint32_t)hi;
             mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
             const uint64_t lo = (uint64_t)(mask >> 1) + 1;
-            for (uint64_t i = hi; i >= lo; i--) {
-                uint32_t v;
-                while ((v = rng.next() & mask) > (uint32_t)i) {}
-                J[i] = v;
+            // branch-free rejection: every draw is written to J[i]; i moves on only when the draw is accepted
+            for (uint64_t i = hi; i >= lo;) {
+                if (rng.pos == 624) rng.refill();
+                const int avail = 624 - rng.pos;
+                const uint32_t *o = rng.out + rng.pos;
+                int k = 0;
+                for (; k < avail && i >= lo; k++) {
+                    const uint32_t v = o[k] & mask;
+                    J[i] = v;
+                    i -= (uint64_t)(v <= (uint32_t)i);
+                }
+                rng.pos += k;
             }
             hi = lo - 1;
         }
