@@ -199,8 +199,20 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
             todo.append([input_fq, nd, cls_out, ksize, res[r]["cls_ab"], cls, res[r]["cls_cov"], list(res.keys()), l2,
                          msn, pmode, emode, fq2])
         print("- Parallel strain-level identification ...")
-        for item in todo:
-            vote_strain_L2(item)
+        # clusters are independent (the reference ran them in a Pool(5) at :298-305 before it went serial at
+        # :295-296): a few host threads keep the device busy while another cluster's files are read and its
+        # reports written.  Under torch.distributed the per-cluster all-reduces must be issued in the same order
+        # on every rank, so the loop stays serial there.  SS_L2_THREADS=1 forces the serial loop.
+        from . import dist
+        nthreads = 1 if dist.is_distributed() else max(1, min(len(todo), int(os.environ.get("SS_L2_THREADS", "4"))))
+        if nthreads == 1:
+            for item in todo:
+                vote_strain_L2(item)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="ss-l2") as pool:
+                for fut in [pool.submit(vote_strain_L2, item) for item in todo]:
+                    fut.result()                      # re-raises the first failure, in submission order
         print("- Generate final report ...")
         merge_res(out_dir, res)
 

@@ -14,6 +14,7 @@ ladder of StrainScan.py:196-216 (which calls identify_cluster up to twice) parse
 database once.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -56,6 +57,7 @@ class CountsView:
 
 
 _READS = {}          # one resident read set at a time: key -> _lib.ReadSet
+_READS_LOCK = threading.Lock()
 RESIDENT_LIMIT_BYTES = int(float(os.environ.get("SS_READS_RESIDENT_GB", "160")) * 1e9)
 
 
@@ -74,13 +76,14 @@ def resident_reads(paths):
     if (total * (4 if gz else 1)) / world > RESIDENT_LIMIT_BYTES or RESIDENT_LIMIT_BYTES <= 0:
         return None
     key = _reads_key(paths, rank, world)
-    rs = _READS.get(key)
-    if rs is None:
-        for old in _READS.values():
-            old.close()
-        _READS.clear()
-        rs = _lib.ReadSet([p for p in paths if p], rank, world)
-        _READS[key] = rs
+    with _READS_LOCK:                     # layer 2 asks from several threads; the set is parsed once
+        rs = _READS.get(key)
+        if rs is None:
+            for old in _READS.values():
+                old.close()
+            _READS.clear()
+            rs = _lib.ReadSet([p for p in paths if p], rank, world)
+            _READS[key] = rs
     return rs
 
 

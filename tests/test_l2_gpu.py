@@ -214,3 +214,38 @@ def test_cluster_image_cache(tmp_path, monkeypatch):
         with pytest.raises(RuntimeError):
             L2.ClusterImage.from_planes(bad, img.K, img.S)
     img.close(); img2.close()
+
+
+@pytest.mark.gpu
+def test_l2_batch_threads_equal_serial(tmp_path, monkeypatch):
+    """vote_strain_L2_batch over three multi-strain clusters: the threaded cluster loop (SS_L2_THREADS=4, image
+    cache cold and warm) writes the same StrainVote.report files and final_report.txt as the serial loop."""
+    from strainscan_amd import Vote_Strain_L2_Lasso_new_sp as vote
+    from strainscan_amd import db as ssdb
+    dbd = tmp_path / "db"
+    dbd.mkdir()
+    pres = [[1, 1, 0, 0, 1], [1, 0, 1, 0, 0], [0, 1, 1, 1, 0]]
+    mix = []
+    for cid, seed, depths in ((1, 5, (16.0, 6.0)), (2, 6, (11.0, 5.0)), (3, 7, (9.0, 14.0))):
+        names = ["GCF_%d_%d" % (cid, i) for i in range(3)]
+        info = synth.build_l2_cluster(str(dbd), cid, 4, names, [1500, 1200, 1000, 1400, 900], pres, seed=seed)
+        mix += [(info["strain_extra"][names[0]], depths[0]), (info["strain_extra"][names[2]], depths[1])]
+    fq = tmp_path / "s.fq"
+    fq.write_bytes(synth.simulate_reads(mix, 404))
+    res = {cid: dict(strain=0, cls_ab=20.0 + cid, cls_cov=0.9, cls_per=0.25 * cid, s_ab=0, cls_covered_num=10,
+                     cls_total_num=12) for cid in (1, 2, 3)}
+    res[4] = dict(strain="GCF_single", cls_ab=4.0, cls_cov=0.8, cls_per=0.1, s_ab=4.0, cls_covered_num=8,
+                  cls_total_num=10)
+    outs = {}
+    for label, threads, cache in (("serial", "1", "c0"), ("threads_cold", "4", "c1"), ("threads_warm", "4", "c1")):
+        monkeypatch.setenv("SS_L2_THREADS", threads)
+        monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / cache))
+        ssdb.clear_cache()
+        out = tmp_path / label
+        out.mkdir()
+        with contextlib.redirect_stdout(io.StringIO()):
+            vote.vote_strain_L2_batch(str(fq), "", str(dbd), str(out), 31, dict(res), 0, 40, 0, 0)
+        outs[label] = {p: (out / p).read_text() for p in ("final_report.txt", "C1/StrainVote.report",
+                                                           "C2/StrainVote.report", "C3/StrainVote.report")}
+        assert len(outs[label]["final_report.txt"].strip().split("\n")) >= 6
+    assert outs["threads_cold"] == outs["serial"] and outs["threads_warm"] == outs["serial"]
