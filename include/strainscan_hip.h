@@ -61,6 +61,16 @@ int ss_memset_dev(void *dst_dev, int byte, uint64_t bytes, void *stream);
  * ------------------------------------------------------------------------------------------ */
 int ss_revcomp(const char *in, char *out, uint64_t n);
 
+/* Whole-file gunzip as ss_scan_files / ss_reads_load do it for .gz inputs (the reference pipes `zcat`,
+ * identify.py:81-84).  mode 0: one gzip member is inflated by `threads` threads (0 = all, up to 32) when it is
+ * large enough -- entry points found inside the deflate stream, chunks decoded against an unknown 32 KB window
+ * and resolved afterwards, result verified against the member's CRC-32 and length -- else by libdeflate;
+ * 1: the threaded inflater or nothing; 2: libdeflate only.  SS_ERANGE = not inflated here (not gzip, too small,
+ * several members, over the memory budget, verification failed): stream it with zlib.  *text is released with
+ * ss_gz_free.  Host only. */
+int ss_gz_inflate(const char *path, int threads, int mode, char **text, uint64_t *len);
+void ss_gz_free(char *text);
+
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,
  * random_state=0)): bits[i] bit f = row i is in the test set of split f (the first n_test entries of the f-th

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ss_memset_dev": (i32, [vp, i32, u64, vp]),
     "ss_revcomp": (i32, [cp, cp, u64]),
     "ss_shuffle_split_bits": (i32, [u64, i32, u64, u32, vp]),
+    "ss_gz_inflate": (i32, [cp, i32, i32, P(vp), P(u64)]),
+    "ss_gz_free": (None, [vp]),
     "ss_revcomp_dev": (i32, [vp, vp, u64, u64, vp]),
     "ss_kmerfa_count_rows": (i32, [cp, P(u64)]),
     "ss_kmerfa_encode": (i32, [cp, i32, u64, vp, vp, i32]),
@@ -368,6 +370,19 @@ def rows_reduce(db, rows):
     st = NodeStat()
     check(lib().ss_rows_reduce(db.handle, ptr(rows), rows.size, C.byref(st)), "ss_rows_reduce")
     return dict(length=st.length, n_pos=st.n_pos, n_kept=st.n_kept, sum_kept=st.sum_kept, median2=st.median2)
+
+
+def gz_inflate(path, threads=0, mode=0):
+    """Whole-file gunzip as the ingest does it (ss_gz_inflate): bytes, or None when the file is not inflated this
+    way (see include/strainscan_hip.h).  mode 1 = threaded inflater only, 2 = libdeflate only."""
+    text, n = C.c_void_p(), C.c_uint64()
+    rc = lib().ss_gz_inflate(os.fsencode(path), int(threads), int(mode), C.byref(text), C.byref(n))
+    if rc != SS_OK:
+        return None
+    try:
+        return C.string_at(text, n.value)
+    finally:
+        lib().ss_gz_free(text)
 
 
 def encode_kmer_fasta(text, k=31):

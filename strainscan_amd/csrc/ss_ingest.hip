@@ -109,13 +109,19 @@ static hipStream_t ingest_stream(unsigned i)
 }
 
 // ---------------------------------------------------------------------------------------------
-// gzip input.  zlib inflates ~350 MB/s of FASTQ text per thread and a gzip member cannot be cut into
-// independent pieces, so a .gz sample is bound by one inflate thread per file (the reference pipes
-// `zcat` into jellyfish, identify.py:81-84: the same bound at a lower rate).  When libdeflate is on the
-// machine (dlopen: the image ships the runtime library, not its header) a file is inflated WHOLE into
-// memory at 2-3x that rate, all .gz inputs of a call concurrently, and the text is then parsed by the
-// chunked parser above like a plain file.  Otherwise, or when the text would not fit the memory budget
-// (SS_INFLATE_MAX_GB, default a quarter of the physical memory), the zlib reader streams it as before.
+// gzip input.  zlib inflates ~350 MB/s of FASTQ text per thread and a gzip member has no entry points,
+// so a .gz sample is normally bound by one inflate thread per file (the reference pipes `zcat` into
+// jellyfish, identify.py:81-84: the same bound at a lower rate).  Here a .gz input is inflated WHOLE
+// into memory, all .gz inputs of a call concurrently, and the text is then parsed by the chunked
+// parser above like a plain file:
+//   1. ss_pgz.hip: one member, up to 32 threads (entry points found inside the deflate stream, chunks
+//      decoded against an unknown window, verified against the member's CRC-32 and length): 5-10 GB/s
+//      of text for the decode itself; a sample of two 300 MB files is ready in ~0.35 s, most of it
+//      the kernel handing out ~3 bytes of fresh memory per byte of text (huge pages asked for);
+//   2. libdeflate when it is on the machine (dlopen: the image ships the runtime library, not its
+//      header): one thread per file, ~550 MB/s (files of several members, small files);
+//   3. otherwise, or when the text would not fit the memory budget (SS_INFLATE_MAX_GB, default a
+//      quarter of the memory the process may use), the zlib reader streams the file as before.
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct Deflate {
@@ -142,6 +148,12 @@ const Deflate &deflate_lib()
 }
 }  // namespace
 
+// a text of several hundred MB is released on a background thread (returning its pages takes tens of ms)
+void free_later(char *p)
+{
+    if (p) std::thread([p] { free(p); }).detach();
+}
+
 uint64_t inflate_budget_bytes()
 {
     if (const char *e = getenv("SS_INFLATE_MAX_GB")) return (uint64_t)(atof(e) * 1e9);
@@ -159,10 +171,11 @@ uint64_t inflate_budget_bytes()
 }
 
 // path -> malloc'ed text of all its gzip members, or false (not gzip, no libdeflate, damaged, over `budget`)
-bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len)
+// mode: 0 = parallel inflater when the file is large enough, else libdeflate; 1 = parallel only; 2 = libdeflate only
+bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len, int mode, unsigned threads)
 {
     const Deflate &L = deflate_lib();
-    if (!L.ok) return false;
+    if (!L.ok && mode == 2) return false;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return false;
     struct stat st;
@@ -172,6 +185,14 @@ bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len
     close(fd);
     if (in == MAP_FAILED) return false;
     bool ok = in[0] == 0x1f && in[1] == 0x8b;
+    if (ok && mode != 2 && !getenv("SS_NO_PGZ")) {
+        // many threads on ONE member (ss_pgz.hip); verified against the trailer's CRC-32 and length
+        if (!threads) threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        if (const char *e = getenv("SS_PGZ_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+        threads = (unsigned)std::min<uint64_t>(threads, std::max<uint64_t>(1, in_n >> 21));      // >= 2 MB of input each
+        if (parallel_gunzip(in, in_n, threads, budget, text, len)) { munmap((void *)in, in_n); return true; }
+    }
+    if (mode == 1 || !L.ok) { munmap((void *)in, in_n); return false; }
     char *out = nullptr;
     uint64_t cap = 0, opos = 0;
     if (ok) {
@@ -206,12 +227,26 @@ bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len
     return true;
 }
 
+}  // namespace ss
+
+extern "C" {
+int ss_gz_inflate(const char *path, int threads, int mode, char **text, uint64_t *len)
+{
+    if (!path || !text || !len || mode < 0 || mode > 2 || threads < 0) return SS_EINVAL;
+    *text = nullptr;
+    *len = 0;
+    return ss::inflate_whole(path, ss::inflate_budget_bytes(), text, len, mode, (unsigned)threads) ? SS_OK : SS_ERANGE;
+}
+void ss_gz_free(char *text) { free(text); }
+}
+
+namespace ss {
+
 // All gzip inputs of a call inflated concurrently (one thread per file); entry i stays empty when path i is not
 // gzip or cannot be inflated here.  The caller frees the texts.
 std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths)
 {
     std::vector<InflatedText> out((size_t)std::max(0, n_paths));
-    if (!deflate_lib().ok) return out;
     const uint64_t budget = inflate_budget_bytes() / (uint64_t)std::max(1, n_paths);
     std::vector<std::thread> pool;
     for (int i = 0; i < n_paths; i++) {
@@ -221,7 +256,7 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
         if (!f) continue;
         const bool gz = fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
         fclose(f);
-        if (gz) pool.emplace_back([&out, paths, i, budget] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n)) out[i].p = nullptr; });
+        if (gz) pool.emplace_back([&out, paths, i, budget] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, 0)) out[i].p = nullptr; });
     }
     for (auto &th : pool) th.join();
     return out;
@@ -475,6 +510,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     // .fastq.gz sample inflate concurrently (zlib is the limiter there)
     std::vector<int> seq_files;
     std::vector<ss::InflatedText> texts = ss::inflate_gz_inputs(paths, n_paths);     // .gz inputs, inflated concurrently
+    if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: gz inputs inflated at %.4f s\n", load_since());
     for (int i = 0; i < n_paths && rc == SS_OK; i++) {
         if (!paths[i]) { rc = SS_EINVAL; break; }
         if (!paths[i][0]) continue;
@@ -484,8 +520,9 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
                                          &bases, &handled, keep, false);
         else
             rc = ss::parse_file_parallel(g_read_workers, paths[i], shard_rank, shard_world, &recs, &bases, &handled, keep, false);
-        free(texts[i].p);
+        ss::free_later(texts[i].p);
         texts[i].p = nullptr;
+        if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: file %d parsed at %.4f s\n", i, load_since());
         if (rc == SS_OK && !handled) seq_files.push_back(i);
     }
     for (auto &tx : texts) free(tx.p);

@@ -1,0 +1,501 @@
+// ss_pgz.hip -- a single gzip member inflated by many threads (host code only).
+//
+// The reference pipes `zcat` into jellyfish (library/identify.py:81-84): one inflate thread per file,
+// which is also what zlib and libdeflate give (a deflate stream has no entry points: every block may
+// copy from the 32 KB before it).  This is the two-pass scheme of Kerbiriou & Chikhi ("Parallel
+// decompression of gzip-compressed files and random access to DNA sequences", 2019), restated:
+//   A  every thread takes a byte range of the compressed stream and searches it, bit by bit, for the
+//      first position that parses as the header of a dynamic-Huffman block (complete code-length
+//      code, valid run lengths, complete literal/length code with an end-of-block symbol) and from
+//      which a few blocks decode without an error;
+//   B  every thread inflates from its position to the position of the next thread, not knowing the
+//      32 KB in front of it: the output is 16-bit symbols, a byte or "byte w of the unknown window"
+//      (a copy of a copy keeps the window index: one lookup resolves any symbol);
+//   C  in stream order, the last 32 KB of every chunk are resolved and become the window of the next;
+//   D  every thread turns its symbols into bytes at the chunk's place in the text.
+// The result is accepted only if every chunk stopped exactly where the next one began, the stream
+// ended where the 8-byte gzip trailer begins, and CRC-32 and ISIZE of the trailer match; otherwise
+// the caller inflates the file with libdeflate or zlib.  Stored and fixed-Huffman blocks are decoded
+// but never used as entry points (their headers are too easy to mistake).
+#include "ss_common.h"
+
+#include <sys/mman.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t WSIZE = 32768;
+constexpr uint16_t UNRESOLVED = 0x8000;     // symbol = UNRESOLVED | index into the 32 KB in front of the chunk
+
+struct Bits {
+    const uint8_t *in;
+    uint64_t n;          // bytes
+    uint64_t pos;        // next byte to load
+    uint64_t buf = 0;
+    int cnt = 0;
+    bool over = false;   // read past the end
+
+    Bits(const uint8_t *p, uint64_t len, uint64_t bitpos) : in(p), n(len), pos(bitpos >> 3)
+    {
+        const int skip = (int)(bitpos & 7);
+        if (skip) { need(8); buf >>= skip; cnt -= skip; }
+    }
+    inline void need(int k)      // k <= 32
+    {
+        while (cnt < k) {
+            if (pos + 4 <= n && cnt <= 32) {
+                uint32_t w;
+                memcpy(&w, in + pos, 4);
+                buf |= (uint64_t)w << cnt;
+                pos += 4;
+                cnt += 32;
+            } else if (pos < n) {
+                buf |= (uint64_t)in[pos++] << cnt;
+                cnt += 8;
+            } else {
+                over = true;     // zeros
+                cnt += 8;
+            }
+        }
+    }
+    // at least 56 bits in the buffer (one unaligned 8-byte load) unless the input is about to end
+    inline void refill()
+    {
+        if (pos + 8 <= n) {
+            uint64_t w;
+            memcpy(&w, in + pos, 8);
+            buf |= w << cnt;
+            const int adv = (63 - cnt) >> 3;
+            pos += (uint64_t)adv;
+            cnt += adv * 8;
+        } else {
+            need(32);
+        }
+    }
+    inline uint32_t peek(int k) { need(k); return (uint32_t)(buf & ((1ull << k) - 1)); }
+    inline void drop(int k) { buf >>= k; cnt -= k; }
+    inline uint32_t get(int k) { const uint32_t v = peek(k); drop(k); return v; }
+    uint64_t bitpos() const { return pos * 8 - (uint64_t)cnt; }
+    void align() { drop(cnt & 7); }
+};
+
+// canonical Huffman code, decoded with a PB-bit table and a bit-by-bit walk for longer codes
+template <int PB, int MAXSYM>
+struct Huff {
+    uint16_t tsym[1 << PB];
+    uint8_t tlen[1 << PB];
+    uint16_t count[16], sorted[MAXSYM];
+    int maxlen = 0;
+
+    // 0 ok, 1 incomplete (left > 0), -1 over-subscribed / unusable
+    int build(const uint8_t *lens, int n)
+    {
+        memset(count, 0, sizeof(count));
+        for (int i = 0; i < n; i++) count[lens[i]]++;
+        maxlen = 15;
+        while (maxlen > 0 && count[maxlen] == 0) maxlen--;
+        int left = 1;
+        for (int l = 1; l <= 15; l++) {
+            left <<= 1;
+            left -= count[l];
+            if (left < 0) return -1;
+        }
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+        for (int i = 0; i < n; i++) if (lens[i]) sorted[offs[lens[i]]++] = (uint16_t)i;
+        memset(tlen, 0, sizeof(tlen));
+        // table: every PB-bit pattern whose low bits are the bit-reversed code
+        uint32_t code = 0;
+        int idx = 0;
+        for (int l = 1; l <= 15; l++) {
+            for (int k = 0; k < count[l]; k++, idx++, code++) {
+                if (l > PB) continue;
+                uint32_t r = 0;
+                for (int b = 0; b < l; b++) r |= ((code >> b) & 1u) << (l - 1 - b);
+                for (uint32_t e = r; e < (1u << PB); e += 1u << l) { tsym[e] = sorted[idx]; tlen[e] = (uint8_t)l; }
+            }
+            code <<= 1;
+        }
+        return left > 0 ? 1 : 0;
+    }
+    // -1 on an invalid code
+    inline int decode(Bits &b) const
+    {
+        const uint32_t v = b.peek(15);
+        const int l = tlen[v & ((1u << PB) - 1)];
+        if (l) { b.drop(l); return tsym[v & ((1u << PB) - 1)]; }
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= (int)((v >> (len - 1)) & 1u);
+            const int c = count[len];
+            if (code - c < first) { b.drop(len); return sorted[index + (code - first)]; }
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+
+using LitCode = Huff<11, 288>;
+using DistCode = Huff<8, 32>;
+using ClCode = Huff<7, 19>;
+
+const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Codes {
+    LitCode lit;
+    DistCode dist;
+    bool dist_usable = true;
+};
+
+// header of a dynamic block (the three header bits already consumed); false = not a valid header
+bool read_dynamic(Bits &b, Codes &c)
+{
+    const int hlit = (int)b.get(5) + 257, hdist = (int)b.get(5) + 1, hclen = (int)b.get(4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    uint8_t cl[19] = {0};
+    for (int i = 0; i < hclen; i++) cl[CL_ORDER[i]] = (uint8_t)b.get(3);
+    ClCode clc;
+    if (clc.build(cl, 19) != 0) return false;                      // zlib: the code-length code must be complete
+    uint8_t lens[286 + 30];
+    int i = 0;
+    while (i < hlit + hdist) {
+        const int s = clc.decode(b);
+        if (s < 0 || b.over) return false;
+        if (s < 16) { lens[i++] = (uint8_t)s; continue; }
+        int rep, val = 0;
+        if (s == 16) { if (i == 0) return false; val = lens[i - 1]; rep = 3 + (int)b.get(2); }
+        else if (s == 17) rep = 3 + (int)b.get(3);
+        else rep = 11 + (int)b.get(7);
+        if (i + rep > hlit + hdist) return false;
+        while (rep--) lens[i++] = (uint8_t)val;
+    }
+    if (lens[256] == 0) return false;                                // no end-of-block code
+    const int rl = c.lit.build(lens, hlit);
+    if (rl < 0 || (rl > 0 && c.lit.maxlen != 1)) return false;       // zlib: incomplete only as a single 1-bit code
+    const int rd = c.dist.build(lens + hlit, hdist);
+    if (rd < 0 || (rd > 0 && c.dist.maxlen > 1)) return false;
+    c.dist_usable = c.dist.maxlen > 0;
+    return !b.over;
+}
+
+const Codes &fixed_codes()
+{
+    static Codes c;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        uint8_t l[288];
+        for (int i = 0; i < 144; i++) l[i] = 8;
+        for (int i = 144; i < 256; i++) l[i] = 9;
+        for (int i = 256; i < 280; i++) l[i] = 7;
+        for (int i = 280; i < 288; i++) l[i] = 8;
+        c.lit.build(l, 288);
+        uint8_t d[30];
+        for (int i = 0; i < 30; i++) d[i] = 5;
+        c.dist.build(d, 30);        // incomplete by two codes (30, 31 invalid): the table still decodes 0..29
+    });
+    return c;
+}
+
+struct alignas(128) Out {           // one per thread, written on every symbol: its own cache lines
+    uint16_t *p = nullptr;
+    uint64_t n = 0, cap = 0;
+    bool count_only = false;        // the search only needs to know that decoding works
+    ~Out() { if (p) munmap(p, cap * 2); }
+    // anonymous mappings with transparent huge pages asked for: thirty-two threads touching 4 KB pages of
+    // fresh memory for the first time spend their time in page faults, not in inflate
+    bool room(uint64_t k)
+    {
+        if (count_only || n + k <= cap) return true;
+        uint64_t ncap = std::max<uint64_t>(cap + cap / 2, n + k + (1u << 20));
+        ncap = (ncap * 2 + (2u << 20) - 1) / (2u << 20) * (2u << 20) / 2;        // whole 2 MB pages
+        void *q;
+        if (!p) {
+            q = mmap(nullptr, ncap * 2, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) return false;
+        } else {
+            q = mremap(p, cap * 2, ncap * 2, MREMAP_MAYMOVE);
+            if (q == MAP_FAILED) return false;
+        }
+        if (!getenv("SS_PGZ_NOHUGE")) madvise(q, ncap * 2, MADV_HUGEPAGE);
+        p = (uint16_t *)q;
+        cap = ncap;
+        return true;
+    }
+};
+
+// One block from the current position (BFINAL and BTYPE not yet read).  0 = block done, 1 = final block done,
+// <0 = error.  known_window: references in front of the output are an error (chunk 0 and libdeflate agree).
+int inflate_block(Bits &b, Out &o, bool known_window)
+{
+    const uint32_t bfinal = b.get(1), btype = b.get(2);
+    if (btype == 3) return -1;
+    if (btype == 0) {
+        b.align();
+        const uint32_t len = b.get(16), nlen = b.get(16);
+        if (b.over || (len ^ 0xFFFFu) != nlen) return -2;
+        if (!o.room(len)) return -9;
+        for (uint32_t i = 0; i < len; i++) {
+            const uint32_t v = b.get(8);
+            if (!o.count_only) o.p[o.n] = (uint16_t)v;
+            o.n++;
+        }
+        return b.over ? -3 : (int)bfinal;
+    }
+    Codes dyn;
+    const Codes *c = &dyn;
+    if (btype == 1) c = &fixed_codes();
+    else if (!read_dynamic(b, dyn)) return -4;
+    const LitCode &lit = c->lit;
+    const DistCode &dc = c->dist;
+    const bool counting = o.count_only;
+    uint64_t n = o.n;                                  // kept in registers; written back on every exit
+    uint16_t *out = o.p;
+#define PGZ_RET(v) do { o.n = n; return (v); } while (0)
+    for (;;) {
+        if (!counting && n + 264 > o.cap) {
+            o.n = n;
+            if (!o.room(264)) return -9;
+            out = o.p;
+        }
+        b.refill();
+        int s = lit.decode(b);
+        if (s >= 0 && s < 256) {                      // up to three literals per refill (3 x 15 bits <= 56)
+            if (!counting) out[n] = (uint16_t)s;
+            n++;
+            s = lit.decode(b);
+            if (s >= 0 && s < 256) {
+                if (!counting) out[n] = (uint16_t)s;
+                n++;
+                s = lit.decode(b);
+                if (s >= 0 && s < 256) {
+                    if (!counting) out[n] = (uint16_t)s;
+                    n++;
+                    if (b.over) PGZ_RET(-5);
+                    continue;
+                }
+            }
+        }
+        if (s < 0 || b.over) PGZ_RET(-5);
+        if (s == 256) PGZ_RET((int)bfinal);
+        if (s > 285) PGZ_RET(-6);
+        b.refill();                                   // length extra 5 + distance 15 + distance extra 13 <= 33 bits
+        const int li = s - 257;
+        const uint32_t len = LEN_BASE[li] + b.get(LEN_EXTRA[li]);
+        if (!c->dist_usable) PGZ_RET(-7);
+        const int ds = dc.decode(b);
+        if (ds < 0 || ds > 29) PGZ_RET(-7);
+        const uint32_t dist = DIST_BASE[ds] + b.get(DIST_EXTRA[ds]);
+        if (b.over) PGZ_RET(-5);
+        if (counting) {
+            if (known_window && dist > n) PGZ_RET(-8);
+            n += len;
+            continue;
+        }
+        uint16_t *dst = out + n;
+        if (dist <= n) {
+            const uint16_t *src = dst - dist;
+            if (dist >= len) memcpy(dst, src, (size_t)len * 2);
+            else for (uint32_t i = 0; i < len; i++) dst[i] = src[i];      // overlapping: element by element
+        } else {
+            if (known_window) PGZ_RET(-8);
+            // the first (dist - n) elements come from the unknown window, the rest (if any) from the output
+            const uint64_t from_w = std::min<uint64_t>(len, dist - n);
+            const uint32_t w0 = WSIZE - (uint32_t)(dist - n);
+            for (uint64_t i = 0; i < from_w; i++) dst[i] = (uint16_t)(UNRESOLVED | (w0 + i));
+            for (uint64_t i = from_w; i < len; i++) dst[i] = out[n + i - dist];
+        }
+        n += len;
+    }
+#undef PGZ_RET
+}
+
+// gzip member header -> offset of the deflate data, 0 = not a header this code handles
+uint64_t gzip_header_len(const uint8_t *p, uint64_t n)
+{
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return 0;
+    const uint8_t flg = p[3];
+    if (flg & 0xE0) return 0;
+    uint64_t pos = 10;
+    if (flg & 4) { if (pos + 2 > n) return 0; pos += 2 + ((uint64_t)p[pos] | (uint64_t)p[pos + 1] << 8); }
+    for (int f = 0; f < 2; f++)
+        if (flg & (f == 0 ? 8 : 16)) {
+            while (pos < n && p[pos]) pos++;
+            pos++;
+        }
+    if (flg & 2) pos += 2;
+    return pos + 8 < n ? pos : 0;
+}
+
+}  // namespace
+
+namespace ss {
+
+// Inflate the single-member gzip file image `in` with `threads` threads.  On success *text is a malloc'ed
+// buffer of *len bytes.  false = not applicable or not verified: the caller uses another inflater.
+bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len)
+{
+    static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
+    auto say = [&](const char *what, uint64_t a = 0, uint64_t b = 0) {
+        if (trace) fprintf(stderr, "[pgz] %s (%llu, %llu)\n", what, (unsigned long long)a, (unsigned long long)b);
+        return false;
+    };
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[pgz]   %-12s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    const uint64_t hdr = gzip_header_len(in, in_n);
+    if (!hdr || threads < 2) return say("no gzip header / one thread", hdr, threads);
+    const uint64_t end = in_n - 8;                       // the trailer: CRC-32, ISIZE
+    if (end - hdr < (uint64_t)threads * (1u << 20)) return say("too small", end - hdr, threads);
+    const uint32_t want_crc = (uint32_t)in[end] | (uint32_t)in[end + 1] << 8 | (uint32_t)in[end + 2] << 16 | (uint32_t)in[end + 3] << 24;
+    const uint32_t want_size = (uint32_t)in[end + 4] | (uint32_t)in[end + 5] << 8 | (uint32_t)in[end + 6] << 16 | (uint32_t)in[end + 7] << 24;
+    // memory: 2 bytes per byte of text for the symbols + the text; the text is at least ISIZE
+    uint64_t guess = want_size;
+    while (guess < in_n) guess += 1ull << 32;
+    if (3 * guess > budget) return say("over the memory budget", guess, budget);
+
+    // ---- A: entry points ----------------------------------------------------------------------
+    const uint64_t span = (end - hdr) / threads;
+    std::vector<uint64_t> start(threads, ~0ull);         // bit positions
+    start[0] = hdr * 8;
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++)
+            pool.emplace_back([&, t] {
+                const uint64_t lo = (hdr + span * t) * 8, hi = (t + 1 == threads ? end : hdr + span * (t + 1)) * 8;
+                for (uint64_t bp = lo; bp < hi; bp++) {
+                    // BFINAL = 0, BTYPE = 10 (bits, LSB first: 0, 0, 1)
+                    const uint64_t byte = bp >> 3;
+                    const uint32_t three = (((uint32_t)in[byte] | (uint32_t)in[byte + 1] << 8) >> (bp & 7)) & 7u;
+                    if (three != 4u) continue;
+                    Bits b(in, in_n, bp + 3);
+                    Codes c;
+                    if (!read_dynamic(b, c)) continue;
+                    // decodes?  this block and the next two must come through without an error
+                    Bits b2(in, in_n, bp);
+                    Out o;
+                    o.count_only = true;
+                    int r = 0;
+                    for (int k = 0; k < 3 && r == 0; k++) r = inflate_block(b2, o, false);
+                    if (r < 0) continue;
+                    start[t] = bp;
+                    return;
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    std::vector<uint64_t> entry;
+    for (uint64_t s : start) if (s != ~0ull) entry.push_back(s);
+    const size_t nc = entry.size();
+    lap("A entries");
+    if (nc < 2) return say("no entry points", nc, threads);
+    say("entry points", nc, threads);
+
+    // ---- B: every chunk to the next entry point -----------------------------------------------
+    std::vector<Out> outs(nc);
+    std::atomic<bool> bad(false);
+    {
+        std::vector<std::thread> pool;
+        for (size_t c = 0; c < nc; c++)
+            pool.emplace_back([&, c] {
+                Bits b(in, in_n, entry[c]);           // look-ahead may run into the trailer bytes: harmless
+                Out &o = outs[c];
+                const uint64_t stop = c + 1 < nc ? entry[c + 1] : ~0ull;
+                if (!o.room((guess / nc) + (guess / nc) / 4 + (1u << 20))) { bad = true; return; }
+                for (;;) {
+                    const int r = inflate_block(b, o, c == 0);
+                    if (r < 0 || bad) { bad = true; return; }
+                    const uint64_t bp = b.bitpos();
+                    if (r == 1) {                                           // final block: must be the last chunk, at the trailer
+                        if (c + 1 != nc || ((bp + 7) >> 3) != end) bad = true;
+                        return;
+                    }
+                    if (bp == stop) return;
+                    if (bp > stop) { bad = true; return; }
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    lap("B decoded");
+    if (bad) return say("a chunk failed or overran the next entry point");
+    uint64_t total = 0;
+    std::vector<uint64_t> off(nc + 1, 0);
+    for (size_t c = 0; c < nc; c++) { total += outs[c].n; off[c + 1] = total; }
+    if ((uint32_t)total != want_size) return say("length differs from ISIZE", total, want_size);
+
+    // ---- C: windows, in stream order ----------------------------------------------------------
+    std::vector<std::vector<uint8_t>> window(nc);          // window[c]: the WSIZE bytes in front of chunk c
+    window[0].assign(WSIZE, 0);
+    for (size_t c = 0; c + 1 < nc; c++) {
+        const Out &o = outs[c];
+        std::vector<uint8_t> &w = window[c + 1];
+        w.resize(WSIZE);
+        const uint64_t take = std::min<uint64_t>(WSIZE, o.n);
+        memcpy(w.data(), window[c].data() + take, WSIZE - take);       // what is left of the older window
+        for (uint64_t i = 0; i < take; i++) {
+            const uint16_t s = o.p[o.n - take + i];
+            w[WSIZE - take + i] = (s & UNRESOLVED) ? window[c][s & (WSIZE - 1)] : (uint8_t)s;
+        }
+    }
+
+    lap("C windows");
+    // ---- D: bytes + CRC -----------------------------------------------------------------------
+    // the text: 2 MB aligned so that huge pages back all of it (32 threads write it for the first time below);
+    // released with free() like any other text the ingest holds
+    void *mem = nullptr;
+    const uint64_t text_cap = (std::max<uint64_t>(1, total) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+    if (posix_memalign(&mem, 2u << 20, text_cap) != 0 || !mem) return false;
+    if (!getenv("SS_PGZ_NOHUGE")) madvise(mem, text_cap, MADV_HUGEPAGE);
+    char *out = (char *)mem;
+    std::vector<uint32_t> crc(nc, 0);
+    {
+        std::vector<std::thread> pool;
+        for (size_t c = 0; c < nc; c++)
+            pool.emplace_back([&, c] {
+                const Out &o = outs[c];
+                uint8_t *dst = (uint8_t *)out + off[c];
+                const uint8_t *w = window[c].data();
+                for (uint64_t i = 0; i < o.n; i++) {
+                    const uint16_t s = o.p[i];
+                    dst[i] = (s & UNRESOLVED) ? w[s & (WSIZE - 1)] : (uint8_t)s;
+                }
+                uint32_t k = (uint32_t)crc32(0L, Z_NULL, 0);
+                for (uint64_t a = 0; a < o.n; a += 1u << 30)
+                    k = (uint32_t)crc32(k, dst + a, (uInt)std::min<uint64_t>(1u << 30, o.n - a));
+                crc[c] = k;
+            });
+        for (auto &th : pool) th.join();
+    }
+    lap("D bytes+crc");
+    uint32_t all = crc[0];
+    for (size_t c = 1; c < nc; c++) all = (uint32_t)crc32_combine(all, crc[c], (z_off_t)outs[c].n);
+    if (all != want_crc) { free(out); return say("CRC-32 differs", all, want_crc); }
+    say("ok", total, nc);
+    *text = out;
+    *len = total;
+    // unmapping 2 bytes per byte of text takes tens of milliseconds: not on the caller's time
+    {
+        std::vector<std::pair<void *, uint64_t>> maps;
+        for (auto &o : outs) { if (o.p) maps.emplace_back(o.p, o.cap * 2); o.p = nullptr; }
+        std::thread([maps] { for (auto &m : maps) munmap(m.first, m.second); }).detach();
+    }
+    lap("done");
+    return true;
+}
+
+}  // namespace ss

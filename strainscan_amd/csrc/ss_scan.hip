@@ -440,7 +440,7 @@ int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_
             if (!texts.empty() && texts[i].p) rc = ss::scan_text_parallel(db, texts[i].p, texts[i].n, &recs, &total, &handled);
             else rc = ss::scan_file_parallel(db, paths[i], &recs, &total, &handled);
         }
-        if (!texts.empty()) { free(texts[i].p); texts[i].p = nullptr; }
+        if (!texts.empty()) { ss::free_later(texts[i].p); texts[i].p = nullptr; }
         if (rc == SS_OK && !handled) rc = scan_files_sequential(db, &paths[i], 1, &recs, &total);
     }
     for (auto &tx : texts) free(tx.p);

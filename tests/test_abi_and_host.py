@@ -121,6 +121,73 @@ def test_kmer_fasta_file_parse_threads_and_gz(tmp_path):
         assert np.array_equal(np.load(out + ".k.npy"), want_k) and np.array_equal(np.load(out + ".f.npy"), want_f), (path, threads)
 
 
+def _fastq_like(rs, n_reads, read_len=150):
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rec = np.empty((n_reads, 2 * read_len + 12), np.uint8)
+    rec[:, :8] = np.frombuffer(b"@r/12345", np.uint8)
+    rec[:, 3:8] = 48 + rs.randint(0, 10, size=(n_reads, 5))
+    rec[:, 8] = 10
+    rec[:, 9:9 + read_len] = lut[rs.randint(0, 4, size=(n_reads, read_len))]
+    rec[:, 9 + read_len] = 10
+    rec[:, 10 + read_len] = 43
+    rec[:, 11 + read_len] = 10
+    q = np.clip(38 - np.abs(rs.normal(0, 5, size=(n_reads, read_len))).astype(np.int64), 2, 40) + 33
+    rec[:, 12 + read_len:12 + 2 * read_len - 1] = q[:, :read_len - 1].astype(np.uint8)
+    rec[:, -1] = 10
+    return rec.tobytes()
+
+
+def test_threaded_gunzip_equals_gzip(tmp_path):
+    """ss_gz_inflate (one gzip member inflated by several threads: entry points inside the deflate stream,
+    unknown-window symbols, CRC-checked) returns exactly what Python's gzip returns: FASTQ-like text at levels
+    1/6/9, text with long and overlapping matches at every distance, incompressible stretches (stored blocks)
+    between text; files it must decline (several members, too small) are declined in mode 1 and still inflated
+    in mode 0 (libdeflate) when that library is present."""
+    import zlib
+    from strainscan_amd import _lib
+    rs = np.random.RandomState(11)
+    fq = _fastq_like(rs, 90000)                                  # 28 MB
+    unit = _fastq_like(rs, 300)
+    rep = b"".join(unit[: rs.randint(1, len(unit))] + bytes(rs.randint(65, 70, size=rs.randint(0, 40)).astype(np.uint8))
+                   for _ in range(1500)) + b"A" * 300000 + b"ACGT" * 100000 + unit * 40
+    mixed = b"".join(_fastq_like(rs, 4000) + rs.bytes(300000) for _ in range(12))
+    cases = [("fq1", fq, 1), ("fq6", fq, 6), ("fq9", fq[: len(fq) // 2], 9), ("rep6", rep * 3, 6), ("mixed6", mixed, 6)]
+    have_libdeflate = None
+    for name, data, level in cases:
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(gzip.compress(data, level))
+        size = p.stat().st_size
+        for threads in (2, 3, 8):
+            got = _lib.gz_inflate(str(p), threads, 1)
+            if size >= threads * (2 << 20) and name != "mixed6":
+                assert got is not None, (name, threads, size)
+            if got is not None:
+                assert got == data, (name, threads)
+        auto = _lib.gz_inflate(str(p), 0, 0)
+        if have_libdeflate is None:
+            have_libdeflate = _lib.gz_inflate(str(p), 0, 2) is not None
+        if auto is not None:
+            assert auto == data, name
+        else:
+            assert not have_libdeflate
+    # several members, and a file too small to split: declined by the threaded inflater
+    multi = tmp_path / "multi.gz"
+    multi.write_bytes(gzip.compress(fq[: len(fq) // 2], 6) + gzip.compress(fq[len(fq) // 2:], 6))
+    small = tmp_path / "small.gz"
+    small.write_bytes(gzip.compress(fq[:200000], 6))
+    for p, data in ((multi, fq), (small, fq[:200000])):
+        assert _lib.gz_inflate(str(p), 4, 1) is None
+        got = _lib.gz_inflate(str(p), 4, 0)
+        assert (got == data) if have_libdeflate else (got is None)
+    # a damaged member is never accepted (CRC), a non-gzip file is declined
+    bad = bytearray((tmp_path / "fq6.gz").read_bytes())
+    bad[len(bad) // 2] ^= 0x5A
+    (tmp_path / "bad.gz").write_bytes(bytes(bad))
+    assert _lib.gz_inflate(str(tmp_path / "bad.gz"), 4, 0) is None
+    (tmp_path / "plain.txt").write_bytes(fq[:100000])
+    assert _lib.gz_inflate(str(tmp_path / "plain.txt"), 4, 0) is None
+
+
 def test_shuffle_split_native_equals_numpy():
     """ss_shuffle_split_bits (MT19937 + masked-rejection Fisher-Yates, restated) draws exactly the test sets of
     numpy.random.RandomState(seed).permutation -- the specification sklearn's ShuffleSplit calls -- for sizes around
