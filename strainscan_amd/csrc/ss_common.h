@@ -106,6 +106,7 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
 struct InflatedText { char *p = nullptr; uint64_t n = 0; };
 bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len, int mode, unsigned threads);
 uint64_t inflate_budget_bytes();
+hipStream_t ingest_stream(unsigned i);   // a few process-wide non-blocking streams (creating one costs ~13 ms)
 void free_later(char *p);
 std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths);
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled);

@@ -97,7 +97,7 @@ namespace ss {
 // hardware queue each: 20 of them were 0.26 s of a 0.33 s first load), the runtime multiplexes streams
 // onto four hardware queues anyway, and a worker waits for ITS work through an event, not a stream.
 constexpr int N_INGEST_STREAMS = 4;
-static hipStream_t ingest_stream(unsigned i)
+hipStream_t ingest_stream(unsigned i)
 {
     static hipStream_t pool[N_INGEST_STREAMS];
     static std::once_flag once;

@@ -41,6 +41,10 @@
 #include "ss_common.h"
 #include "ss_scan_dev.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <functional>
@@ -854,16 +858,52 @@ bool write_dev(FILE *f, const void *d, uint64_t bytes)
     return true;
 }
 
-bool read_dev(FILE *f, void *d, uint64_t bytes)
-{
-    std::vector<char> buf(std::min<uint64_t>(bytes, 64ull << 20));
-    for (uint64_t off = 0; off < bytes; off += buf.size()) {
-        const uint64_t n = std::min<uint64_t>(buf.size(), bytes - off);
-        if (fread(buf.data(), 1, n, f) != n) return false;
-        if (hipMemcpy((char *)d + off, buf.data(), n, hipMemcpyHostToDevice) != hipSuccess) return false;
+// A file range straight to device memory: four threads pread() 16 MB pieces into pinned buffers and copy them on
+// the shared ingest streams (one pageable 64 MB bounce buffer moved the 0.54 GB image of an E. coli database in
+// 0.09 s: more than reading the sample).
+struct PinnedReaders {
+    static constexpr int T = 4;
+    static constexpr uint64_t PIECE = 16ull << 20;
+    char *buf[T] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = true;
+    PinnedReaders()
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++) pool.emplace_back([this, t] { if (hipHostMalloc((void **)&buf[t], PIECE, hipHostMallocDefault) != hipSuccess) buf[t] = nullptr; });
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < T; t++) ok = ok && buf[t] && ss::ingest_stream((unsigned)t);
     }
-    return true;
-}
+    ~PinnedReaders() { for (int t = 0; t < T; t++) if (buf[t]) hipHostFree(buf[t]); }
+    bool read(int fd, uint64_t file_off, void *d, uint64_t bytes)
+    {
+        if (!ok) return false;
+        int device = 0;
+        hipGetDevice(&device);
+        std::atomic<bool> good(true);
+        std::atomic<uint64_t> next(0);
+        const uint64_t pieces = (bytes + PIECE - 1) / PIECE;
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T && (uint64_t)t < pieces; t++)
+            pool.emplace_back([&, t] {
+                hipSetDevice(device);
+                hipStream_t st = ss::ingest_stream((unsigned)t);
+                for (uint64_t c; good && (c = next.fetch_add(1)) < pieces;) {
+                    const uint64_t off = c * PIECE, n = std::min<uint64_t>(PIECE, bytes - off);
+                    uint64_t got = 0;
+                    while (got < n) {
+                        const ssize_t r = pread(fd, buf[t] + got, n - got, (off_t)(file_off + off + got));
+                        if (r <= 0) break;
+                        got += (uint64_t)r;
+                    }
+                    if (got != n || hipMemcpyAsync((char *)d + off, buf[t], n, hipMemcpyHostToDevice, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess)
+                        good = false;
+                }
+            });
+        for (auto &th : pool) th.join();
+        return good;
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -894,39 +934,41 @@ int ss_db_export(const ss_db *db, const char *path)
 int ss_db_import(const char *path, ss_db **out)
 {
     if (!path || !out) return SS_EINVAL;
-    FILE *f = fopen(path, "rb");
-    if (!f) return SS_EIO;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return SS_EIO;
     ImageHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SSIDX06", 8) != 0 || h.layout != 1 || h.k != 31 ||
-        h.n_slots == 0 || h.n_dir == 0 || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
-        fclose(f);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX06", 8) != 0 ||
+        h.layout != 1 || h.k != 31 || h.n_slots == 0 || h.n_dir == 0 || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
+        close(fd);
         return SS_EINVAL;
     }
+    const uint64_t nr = std::max<uint64_t>(1, h.n_rows);
+    const uint64_t sizes[5] = {h.n_slots * 8, (uint64_t)h.n_dir * 16, nr * 4, nr, h.bloom_bits ? (1ull << h.bloom_bits) / 8 : 0};
+    uint64_t offs[6] = {sizeof(h), 0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; i++) offs[i + 1] = offs[i] + sizes[i];
+    if ((uint64_t)st.st_size != offs[5]) { close(fd); return SS_EIO; }     // the file must be exactly the image
     ss_db *db = new (std::nothrow) ss_db();
-    if (!db) { fclose(f); return SS_ENOMEM; }
+    if (!db) { close(fd); return SS_ENOMEM; }
     db->k = h.k; db->layout = 1;
     db->n_rows = h.n_rows; db->n_distinct = h.n_distinct; db->n_slots = h.n_slots; db->capacity = h.n_slots;
     db->n_buckets = h.n_buckets; db->n_dir = h.n_dir;
     hipGetDevice(&db->device);
-    const uint64_t nr = std::max<uint64_t>(1, db->n_rows);
-    bool ok = hipMalloc((void **)&db->d_mkeys, db->n_slots * 8) == hipSuccess &&
-              hipMalloc((void **)&db->d_dir, (uint64_t)db->n_dir * 16) == hipSuccess &&
+    bool ok = hipMalloc((void **)&db->d_mkeys, sizes[0]) == hipSuccess && hipMalloc((void **)&db->d_dir, sizes[1]) == hipSuccess &&
               hipMalloc((void **)&db->d_counts, db->n_slots * 4) == hipSuccess &&
-              hipMalloc((void **)&db->d_slot_of_row, nr * 4) == hipSuccess &&
-              hipMalloc((void **)&db->d_row_valid, nr) == hipSuccess;
-    ok = ok && read_dev(f, db->d_mkeys, db->n_slots * 8) && read_dev(f, db->d_dir, (uint64_t)db->n_dir * 16) &&
-         read_dev(f, db->d_slot_of_row, nr * 4) && read_dev(f, db->d_row_valid, nr) &&
-         hipMemset(db->d_counts, 0, db->n_slots * 4) == hipSuccess;
-    if (ok && h.bloom_bits) {
-        db->bloom_bits = h.bloom_bits;
-        ok = hipMalloc((void **)&db->d_bloom, (1ull << h.bloom_bits) / 8) == hipSuccess &&
-             read_dev(f, db->d_bloom, (1ull << h.bloom_bits) / 8);
+              hipMalloc((void **)&db->d_slot_of_row, sizes[2]) == hipSuccess && hipMalloc((void **)&db->d_row_valid, sizes[3]) == hipSuccess &&
+              (!h.bloom_bits || hipMalloc((void **)&db->d_bloom, sizes[4]) == hipSuccess);
+    if (ok) {
+        PinnedReaders rd;
+        ok = rd.read(fd, offs[0], db->d_mkeys, sizes[0]) && rd.read(fd, offs[1], db->d_dir, sizes[1]) &&
+             rd.read(fd, offs[2], db->d_slot_of_row, sizes[2]) && rd.read(fd, offs[3], db->d_row_valid, sizes[3]) &&
+             (!h.bloom_bits || rd.read(fd, offs[4], db->d_bloom, sizes[4])) &&
+             hipMemset(db->d_counts, 0, db->n_slots * 4) == hipSuccess;
     }
-    // the file must end exactly here
-    ok = ok && fgetc(f) == EOF;
-    fclose(f);
+    close(fd);
+    if (ok && h.bloom_bits) db->bloom_bits = h.bloom_bits;
     if (!ok) { ss_db_destroy(db); return SS_EIO; }
-    db->device_bytes = db->n_slots * 12 + (uint64_t)db->n_dir * 16 + nr * 5 + (h.bloom_bits ? (1ull << h.bloom_bits) / 8 : 0);
+    db->device_bytes = db->n_slots * 12 + (uint64_t)db->n_dir * 16 + nr * 5 + sizes[4];
     *out = db;
     return SS_OK;
 }
