@@ -17,8 +17,11 @@
 // ended where the 8-byte gzip trailer begins, and CRC-32 and ISIZE of the trailer match; otherwise
 // the caller inflates the file with libdeflate or zlib.  Stored and fixed-Huffman blocks are decoded
 // but never used as entry points (their headers are too easy to mistake).
-#include "ss_common.h"
-
+// No HIP in this file: tests/pgz_fuzz.cpp compiles it with g++ -fsanitize=address,undefined as well.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <sys/mman.h>
 #include <zlib.h>
 
@@ -344,6 +347,7 @@ uint64_t gzip_header_len(const uint8_t *p, uint64_t n)
 }  // namespace
 
 namespace ss {
+bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len);
 
 // Inflate the single-member gzip file image `in` with `threads` threads.  On success *text is a malloc'ed
 // buffer of *len bytes.  false = not applicable or not verified: the caller uses another inflater.
