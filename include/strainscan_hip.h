@@ -61,6 +61,10 @@ int ss_memset_dev(void *dst_dev, int byte, uint64_t bytes, void *stream);
  * ------------------------------------------------------------------------------------------ */
 int ss_revcomp(const char *in, char *out, uint64_t n);
 
+/* CPUs this process may use: hardware threads capped by the cgroup CPU quota (SS_HOST_CPUS overrides).  The host-side
+ * thread pools (parsers, inflater, index build) size themselves with it. */
+int ss_host_cpus(void);
+
 /* Whole-file gunzip as ss_scan_files / ss_reads_load do it for .gz inputs (the reference pipes `zcat`,
  * identify.py:81-84).  mode 0: one gzip member is inflated by `threads` threads (0 = all, up to 32) when it is
  * large enough -- entry points found inside the deflate stream, chunks decoded against an unknown 32 KB window

@@ -54,6 +54,11 @@ __host__ __device__ __forceinline__ int base_code(unsigned char c)
 
 inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 
+// CPUs this process may really use: hardware threads, capped by the cgroup's CPU quota (v2 cpu.max, v1 cfs quota).
+// A container with 16 CPUs of quota on a 256-thread host runs 64 busy threads SLOWER than 16 (CFS throttles the
+// whole group once the quota of a period is spent).
+unsigned host_cpus();
+
 }  // namespace ss
 
 // The opaque database handle.

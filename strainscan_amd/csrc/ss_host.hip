@@ -264,7 +264,7 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         return SS_OK;
     }
     MT19937 rng(seed);
-    const unsigned in_flight = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned in_flight = std::max(1u, std::min(8u, ss::host_cpus()));
     std::vector<std::thread> pool((size_t)n_splits);
     std::atomic<int> err(SS_OK);
     for (int f = 0; f < n_splits; f++) {
@@ -340,6 +340,8 @@ int ss_encode_kmer(const char *kmer, int k, uint64_t *key)
     return SS_OK;
 }
 
+int ss_host_cpus(void) { return (int)ss::host_cpus(); }
+
 namespace {
 
 // A plain (not gzip) file mapped read-only; ok() is false for gzip input or when it cannot be mapped
@@ -373,7 +375,7 @@ unsigned host_threads(uint64_t bytes)
 {
     if (const char *e = getenv("SS_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));   // tests: many chunks of a small file
     if (bytes < (8u << 20)) return 1;
-    return std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    return std::min<unsigned>(ss::host_cpus(), 32u);
 }
 
 // '\n' count of [a, b) per chunk of a text cut into `T` equal byte ranges

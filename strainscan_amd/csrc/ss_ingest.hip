@@ -92,6 +92,29 @@ bool head_is_simple(const char *t, uint64_t n, bool &fastq)
 }  // namespace
 
 namespace ss {
+unsigned host_cpus()
+{
+    static const unsigned cached = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        if (const char *e = getenv("SS_HOST_CPUS")) return (unsigned)std::max(1, atoi(e));
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+        }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        return n;
+    }();
+    return cached;
+}
+}  // namespace ss
+
+namespace ss {
 
 // The parse threads share a few process-wide streams: creating a stream costs ~13 ms on this stack (a
 // hardware queue each: 20 of them were 0.26 s of a 0.33 s first load), the runtime multiplexes streams
@@ -187,7 +210,7 @@ bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len
     bool ok = in[0] == 0x1f && in[1] == 0x8b;
     if (ok && mode != 2 && !getenv("SS_NO_PGZ")) {
         // many threads on ONE member (ss_pgz.hip); verified against the trailer's CRC-32 and length
-        if (!threads) threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+        if (!threads) threads = std::min<unsigned>(host_cpus(), 32u);
         if (const char *e = getenv("SS_PGZ_THREADS")) threads = (unsigned)std::max(1, atoi(e));
         threads = (unsigned)std::min<uint64_t>(threads, std::max<uint64_t>(1, in_n >> 21));      // >= 2 MB of input each
         if (parallel_gunzip(in, in_n, threads, budget, text, len)) { munmap((void *)in, in_n); return true; }
@@ -248,16 +271,21 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
 {
     std::vector<InflatedText> out((size_t)std::max(0, n_paths));
     const uint64_t budget = inflate_budget_bytes() / (uint64_t)std::max(1, n_paths);
-    std::vector<std::thread> pool;
+    std::vector<int> gz;
     for (int i = 0; i < n_paths; i++) {
         if (!paths[i] || !paths[i][0]) continue;
         unsigned char magic[2] = {0, 0};
         FILE *f = fopen(paths[i], "rb");
         if (!f) continue;
-        const bool gz = fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) gz.push_back(i);
         fclose(f);
-        if (gz) pool.emplace_back([&out, paths, i, budget] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, 0)) out[i].p = nullptr; });
     }
+    if (gz.empty()) return out;
+    // the files inflate concurrently and share the CPUs the process may use (not the machine's hardware threads)
+    const unsigned per_file = std::max(1u, std::min(32u, host_cpus() / (unsigned)gz.size()));
+    std::vector<std::thread> pool;
+    for (int i : gz)
+        pool.emplace_back([&out, paths, i, budget, per_file] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, per_file)) out[i].p = nullptr; });
     for (auto &th : pool) th.join();
     return out;
 }

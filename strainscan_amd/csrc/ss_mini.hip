@@ -612,7 +612,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
 {
     const int k = db->k;
     constexpr int PB = 8, NP = 1 << PB;
-    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    unsigned nthreads = std::min<unsigned>(ss::host_cpus(), 32u);
     // 1. entries of valid rows with their minimizer
     std::vector<uint64_t> pos(n_rows + 1, 0);
     for (uint64_t i = 0; i < n_rows; i++) pos[i + 1] = pos[i] + ((flags[i] & SS_ROW_VALID) ? 1 : 0);

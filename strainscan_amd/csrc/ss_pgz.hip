@@ -349,8 +349,14 @@ uint64_t gzip_header_len(const uint8_t *p, uint64_t n)
 namespace ss {
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len);
 
-// Inflate the single-member gzip file image `in` with `threads` threads.  On success *text is a malloc'ed
-// buffer of *len bytes.  false = not applicable or not verified: the caller uses another inflater.
+// Inflate the single-member gzip file image `in` with `threads` threads.  On success *text is a buffer of *len
+// bytes to be released with free().  false = not applicable or not verified: the caller uses another inflater.
+//
+// Streaming form of the scheme above: the deflate data is cut into many small chunks (~1 MB), handed out IN ORDER
+// to the threads.  A thread finds its chunk's entry point, inflates to the next chunk's entry point into ITS symbol
+// buffer (reused for every chunk it takes: a few MB that stay in cache, instead of 2 bytes of fresh memory per byte
+// of text), then -- as soon as the chunk before it has published them -- takes its place in the text and its window,
+// passes both on to its successor, and writes its bytes.  The text is the only large allocation.
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
@@ -368,137 +374,164 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
     if (end - hdr < (uint64_t)threads * (1u << 20)) return say("too small", end - hdr, threads);
     const uint32_t want_crc = (uint32_t)in[end] | (uint32_t)in[end + 1] << 8 | (uint32_t)in[end + 2] << 16 | (uint32_t)in[end + 3] << 24;
     const uint32_t want_size = (uint32_t)in[end + 4] | (uint32_t)in[end + 5] << 8 | (uint32_t)in[end + 6] << 16 | (uint32_t)in[end + 7] << 24;
-    // memory: 2 bytes per byte of text for the symbols + the text; the text is at least ISIZE
+    // the text is ISIZE + k * 2^32 bytes long; the smallest such length that is not below the file's own size
+    // is right for anything that deflates at all (a wrong k is caught below: the text would not fit, or ISIZE differs)
     uint64_t guess = want_size;
     while (guess < in_n) guess += 1ull << 32;
-    if (3 * guess > budget) return say("over the memory budget", guess, budget);
+    const uint64_t sym_bytes = (uint64_t)threads * (64ull << 20);
+    if (guess + sym_bytes > budget) return say("over the memory budget", guess, budget);
 
-    // ---- A: entry points ----------------------------------------------------------------------
-    const uint64_t span = (end - hdr) / threads;
-    std::vector<uint64_t> start(threads, ~0ull);         // bit positions
-    start[0] = hdr * 8;
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; t++)
-            pool.emplace_back([&, t] {
-                const uint64_t lo = (hdr + span * t) * 8, hi = (t + 1 == threads ? end : hdr + span * (t + 1)) * 8;
-                for (uint64_t bp = lo; bp < hi; bp++) {
-                    // BFINAL = 0, BTYPE = 10 (bits, LSB first: 0, 0, 1)
-                    const uint64_t byte = bp >> 3;
-                    const uint32_t three = (((uint32_t)in[byte] | (uint32_t)in[byte + 1] << 8) >> (bp & 7)) & 7u;
-                    if (three != 4u) continue;
-                    Bits b(in, in_n, bp + 3);
-                    Codes c;
-                    if (!read_dynamic(b, c)) continue;
-                    // decodes?  this block and the next two must come through without an error
-                    Bits b2(in, in_n, bp);
-                    Out o;
-                    o.count_only = true;
-                    int r = 0;
-                    for (int k = 0; k < 3 && r == 0; k++) r = inflate_block(b2, o, false);
-                    if (r < 0) continue;
-                    start[t] = bp;
-                    return;
-                }
-            });
-        for (auto &th : pool) th.join();
-    }
-    std::vector<uint64_t> entry;
-    for (uint64_t s : start) if (s != ~0ull) entry.push_back(s);
-    const size_t nc = entry.size();
-    lap("A entries");
-    if (nc < 2) return say("no entry points", nc, threads);
-    say("entry points", nc, threads);
-
-    // ---- B: every chunk to the next entry point -----------------------------------------------
-    std::vector<Out> outs(nc);
+    const uint64_t CH = std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, (end - hdr) / ((uint64_t)threads * 8)));
+    const uint64_t nch = (end - hdr + CH - 1) / CH;
+    constexpr uint64_t UNKNOWN = ~0ull, NONE = ~0ull - 1;
+    struct alignas(64) Chunk {
+        std::atomic<uint64_t> entry{~0ull};        // bit position, NONE, or UNKNOWN
+        std::atomic<int> entry_state{0};            // 0 nobody looked, 1 being searched, 2 known
+        std::atomic<bool> off_ready{false}, win_ready{false};
+        uint64_t off = 0, n = 0;                    // place and length of the chunk's text
+        uint32_t crc = 0;
+        bool exists = false;
+        uint8_t *window = nullptr;                  // WSIZE bytes in front of the chunk (owned by the chunk)
+    };
+    std::vector<Chunk> ch(nch);
     std::atomic<bool> bad(false);
-    {
-        std::vector<std::thread> pool;
-        for (size_t c = 0; c < nc; c++)
-            pool.emplace_back([&, c] {
-                Bits b(in, in_n, entry[c]);           // look-ahead may run into the trailer bytes: harmless
-                Out &o = outs[c];
-                const uint64_t stop = c + 1 < nc ? entry[c + 1] : ~0ull;
-                if (!o.room((guess / nc) + (guess / nc) / 4 + (1u << 20))) { bad = true; return; }
-                for (;;) {
-                    const int r = inflate_block(b, o, c == 0);
-                    if (r < 0 || bad) { bad = true; return; }
-                    const uint64_t bp = b.bitpos();
-                    if (r == 1) {                                           // final block: must be the last chunk, at the trailer
-                        if (c + 1 != nc || ((bp + 7) >> 3) != end) bad = true;
-                        return;
-                    }
-                    if (bp == stop) return;
-                    if (bp > stop) { bad = true; return; }
-                }
-            });
-        for (auto &th : pool) th.join();
-    }
-    lap("B decoded");
-    if (bad) return say("a chunk failed or overran the next entry point");
-    uint64_t total = 0;
-    std::vector<uint64_t> off(nc + 1, 0);
-    for (size_t c = 0; c < nc; c++) { total += outs[c].n; off[c + 1] = total; }
-    if ((uint32_t)total != want_size) return say("length differs from ISIZE", total, want_size);
+    std::atomic<uint64_t> next(0), total(UNKNOWN);
 
-    // ---- C: windows, in stream order ----------------------------------------------------------
-    std::vector<std::vector<uint8_t>> window(nc);          // window[c]: the WSIZE bytes in front of chunk c
-    window[0].assign(WSIZE, 0);
-    for (size_t c = 0; c + 1 < nc; c++) {
-        const Out &o = outs[c];
-        std::vector<uint8_t> &w = window[c + 1];
-        w.resize(WSIZE);
-        const uint64_t take = std::min<uint64_t>(WSIZE, o.n);
-        memcpy(w.data(), window[c].data() + take, WSIZE - take);       // what is left of the older window
-        for (uint64_t i = 0; i < take; i++) {
-            const uint16_t s = o.p[o.n - take + i];
-            w[WSIZE - take + i] = (s & UNRESOLVED) ? window[c][s & (WSIZE - 1)] : (uint8_t)s;
-        }
-    }
-
-    lap("C windows");
-    // ---- D: bytes + CRC -----------------------------------------------------------------------
-    // the text: 2 MB aligned so that huge pages back all of it (32 threads write it for the first time below);
-    // released with free() like any other text the ingest holds
+    // the text: 2 MB aligned so that huge pages back all of it; released with free()
     void *mem = nullptr;
-    const uint64_t text_cap = (std::max<uint64_t>(1, total) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
-    if (posix_memalign(&mem, 2u << 20, text_cap) != 0 || !mem) return false;
+    const uint64_t text_cap = (std::max<uint64_t>(1, guess) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+    if (posix_memalign(&mem, 2u << 20, text_cap) != 0 || !mem) return say("no memory for the text", text_cap);
     if (!getenv("SS_PGZ_NOHUGE")) madvise(mem, text_cap, MADV_HUGEPAGE);
-    char *out = (char *)mem;
-    std::vector<uint32_t> crc(nc, 0);
+    uint8_t *out = (uint8_t *)mem;
+
+    // entry point of chunk k: the first position in its byte range that parses as a dynamic block and decodes
+    auto find_entry = [&](uint64_t k) -> uint64_t {
+        if (k == 0) return hdr * 8;
+        const uint64_t lo = (hdr + CH * k) * 8, hi = std::min<uint64_t>(end, hdr + CH * (k + 1)) * 8;
+        for (uint64_t bp = lo; bp < hi; bp++) {
+            const uint64_t byte = bp >> 3;      // BFINAL = 0, BTYPE = 10 (LSB first: 0, 0, 1)
+            const uint32_t three = (((uint32_t)in[byte] | (uint32_t)in[byte + 1] << 8) >> (bp & 7)) & 7u;
+            if (three != 4u) continue;
+            Bits b(in, in_n, bp + 3);
+            Codes c;
+            if (!read_dynamic(b, c)) continue;
+            Bits b2(in, in_n, bp);                // this block and the next two must come through without an error
+            Out o;
+            o.count_only = true;
+            int r = 0;
+            for (int q = 0; q < 3 && r == 0; q++) r = inflate_block(b2, o, false);
+            if (r < 0) continue;
+            return bp;
+        }
+        return NONE;
+    };
+    auto ensure_entry = [&](uint64_t k) -> uint64_t {
+        Chunk &c = ch[k];
+        int st = 0;
+        if (c.entry_state.compare_exchange_strong(st, 1)) {
+            c.entry.store(find_entry(k), std::memory_order_relaxed);
+            c.entry_state.store(2, std::memory_order_release);
+        } else {
+            for (unsigned spin = 0; c.entry_state.load(std::memory_order_acquire) != 2; spin++) {
+                if (bad) return NONE;
+                if (spin < 256) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        }
+        return c.entry.load(std::memory_order_relaxed);
+    };
+    auto wait_for = [&](std::atomic<bool> &flag) {
+        for (unsigned spin = 0; !flag.load(std::memory_order_acquire); spin++) {
+            if (bad) return false;
+            if (spin < 256) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        return true;
+    };
+
+    ch[0].window = (uint8_t *)calloc(WSIZE, 1);
+    if (!ch[0].window) { free(mem); return false; }
+    ch[0].off_ready = true;
+    ch[0].win_ready = true;
+
+    auto worker = [&] {
+        Out o;                                           // this thread's symbols, reused chunk after chunk
+        for (uint64_t j; !bad && (j = next.fetch_add(1)) < nch;) {
+            const uint64_t e = ensure_entry(j);
+            if (e == NONE) continue;                     // no entry point in this range: the chunk before runs through it
+            Chunk &c = ch[j];
+            c.exists = true;
+            // the next chunk that has an entry point is where this one stops
+            uint64_t s = j + 1, stop = UNKNOWN;
+            for (; s < nch; s++) {
+                const uint64_t es = ensure_entry(s);
+                if (bad) return;
+                if (es != NONE) { stop = es; break; }
+            }
+            o.n = 0;
+            Bits b(in, in_n, e);
+            bool final_seen = false;
+            for (;;) {
+                const int r = inflate_block(b, o, j == 0);
+                if (r < 0 || bad) { bad = true; return; }
+                const uint64_t bp = b.bitpos();
+                if (r == 1) {                                    // the final block: nothing may follow but the trailer
+                    if (s < nch || ((bp + 7) >> 3) != end) { bad = true; return; }
+                    final_seen = true;
+                    break;
+                }
+                if (bp == stop) break;
+                if (bp > stop) { bad = true; return; }           // ran over the next entry point: it was not a block start
+            }
+            c.n = o.n;
+            // place in the text, handed on to the successor at once
+            if (!wait_for(c.off_ready)) return;
+            if (c.off + c.n > text_cap) { bad = true; return; }
+            if (s < nch) { ch[s].off = c.off + c.n; ch[s].off_ready.store(true, std::memory_order_release); }
+            else if (final_seen) total.store(c.off + c.n, std::memory_order_release);
+            // window of the successor = the last WSIZE bytes of the text up to here
+            if (!wait_for(c.win_ready)) return;
+            const uint8_t *w = c.window;
+            if (s < nch) {
+                uint8_t *nw = (uint8_t *)malloc(WSIZE);
+                if (!nw) { bad = true; return; }
+                const uint64_t take = std::min<uint64_t>(WSIZE, o.n);
+                memcpy(nw, w + take, WSIZE - take);
+                for (uint64_t i = 0; i < take; i++) {
+                    const uint16_t sy = o.p[o.n - take + i];
+                    nw[WSIZE - take + i] = (sy & UNRESOLVED) ? w[sy & (WSIZE - 1)] : (uint8_t)sy;
+                }
+                ch[s].window = nw;
+                ch[s].win_ready.store(true, std::memory_order_release);
+            }
+            // the chunk's bytes and their CRC
+            uint8_t *dst = out + c.off;
+            for (uint64_t i = 0; i < o.n; i++) {
+                const uint16_t sy = o.p[i];
+                dst[i] = (sy & UNRESOLVED) ? w[sy & (WSIZE - 1)] : (uint8_t)sy;
+            }
+            uint32_t k = (uint32_t)crc32(0L, Z_NULL, 0);
+            for (uint64_t a = 0; a < o.n; a += 1u << 30) k = (uint32_t)crc32(k, dst + a, (uInt)std::min<uint64_t>(1u << 30, o.n - a));
+            c.crc = k;
+        }
+    };
     {
         std::vector<std::thread> pool;
-        for (size_t c = 0; c < nc; c++)
-            pool.emplace_back([&, c] {
-                const Out &o = outs[c];
-                uint8_t *dst = (uint8_t *)out + off[c];
-                const uint8_t *w = window[c].data();
-                for (uint64_t i = 0; i < o.n; i++) {
-                    const uint16_t s = o.p[i];
-                    dst[i] = (s & UNRESOLVED) ? w[s & (WSIZE - 1)] : (uint8_t)s;
-                }
-                uint32_t k = (uint32_t)crc32(0L, Z_NULL, 0);
-                for (uint64_t a = 0; a < o.n; a += 1u << 30)
-                    k = (uint32_t)crc32(k, dst + a, (uInt)std::min<uint64_t>(1u << 30, o.n - a));
-                crc[c] = k;
-            });
+        for (unsigned t = 0; t < threads; t++) pool.emplace_back(worker);
         for (auto &th : pool) th.join();
     }
-    lap("D bytes+crc");
-    uint32_t all = crc[0];
-    for (size_t c = 1; c < nc; c++) all = (uint32_t)crc32_combine(all, crc[c], (z_off_t)outs[c].n);
-    if (all != want_crc) { free(out); return say("CRC-32 differs", all, want_crc); }
-    say("ok", total, nc);
-    *text = out;
-    *len = total;
-    // unmapping 2 bytes per byte of text takes tens of milliseconds: not on the caller's time
-    {
-        std::vector<std::pair<void *, uint64_t>> maps;
-        for (auto &o : outs) { if (o.p) maps.emplace_back(o.p, o.cap * 2); o.p = nullptr; }
-        std::thread([maps] { for (auto &m : maps) munmap(m.first, m.second); }).detach();
+    lap("inflated");
+    uint64_t n_exist = 0;
+    uint32_t all = (uint32_t)crc32(0L, Z_NULL, 0);
+    for (auto &c : ch) {
+        free(c.window);
+        if (c.exists && !bad) { all = (uint32_t)crc32_combine(all, c.crc, (z_off_t)c.n); n_exist++; }
     }
-    lap("done");
+    const uint64_t tot = total.load();
+    if (bad || tot == UNKNOWN) { free(mem); return say("a chunk failed, overran the next entry point, or the stream did not end at the trailer"); }
+    if ((uint32_t)tot != want_size) { free(mem); return say("length differs from ISIZE", tot, want_size); }
+    if (all != want_crc) { free(mem); return say("CRC-32 differs", all, want_crc); }
+    say("ok", tot, n_exist);
+    *text = (char *)mem;
+    *len = tot;
     return true;
 }
 
