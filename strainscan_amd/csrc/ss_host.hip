@@ -342,6 +342,8 @@ int ss_encode_kmer(const char *kmer, int k, uint64_t *key)
 
 int ss_host_cpus(void) { return (int)ss::host_cpus(); }
 
+}  // extern "C"
+
 namespace {
 
 // A plain (not gzip) file mapped read-only; ok() is false for gzip input or when it cannot be mapped
@@ -432,6 +434,8 @@ uint64_t encode_mapped(const char *t, uint64_t n, int k, uint64_t n_rows, uint64
 }
 
 }  // namespace
+
+extern "C" {
 
 int ss_kmerfa_count_rows(const char *path, uint64_t *n_rows)
 {
