@@ -99,3 +99,41 @@ def test_cli_flags_b_and_l(golden, l1_dbs, l1_reads, tmp_path):
     names = dict((l.split("\t")[0], l.rstrip("\n").split("\t")[2]) for l in
                  open(os.path.join(info["db_dir"], "Tree_database", "hclsMap_95_recls.txt")))
     assert lines[1].split("\t")[3] == names[str(want[0][0])]
+
+
+@pytest.mark.gpu
+def test_identify_cluster_from_files_cold_and_cached(tmp_path, monkeypatch):
+    """A 23-leaf synthetic Tree_database written in the reference's on-disk format (scripts/bench_cli.py's writer)
+    and a paired FASTQ sample of a 70/20/10 three-strain mix: identify_cluster finds exactly those three leaves with
+    those proportions; the second call (tree cache + index image read back, new process state) returns the same
+    dict; hit counts of the cached index equal those of the freshly built one."""
+    import torch
+    import bench
+    from scripts import bench_cli
+    from strainscan_amd import db as ssdb
+    from strainscan_amd import identify
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    monkeypatch.setenv("STRAINSCAN_QUIET", "1")
+    dev = torch.device("cuda", 0)
+    C, n_reads = 23, 600_000
+    spec = bench.make_db(torch, dev, C, seed=20231013)
+    tdir = bench_cli.write_db(torch, dev, spec, C, str(tmp_path / "db"))
+    r = bench.make_reads(torch, dev, spec, n_reads, seed=2, hit_frac=0.05)
+    half = n_reads // 2
+    fq = [str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")]
+    bench_cli.write_fastq(r[: half * 151], half, fq[0])
+    bench_cli.write_fastq(r[half * 151:], n_reads - half, fq[1])
+    del r
+    ssdb.clear_cache()
+    first = identify.identify_cluster((fq[0], fq[1]), tdir, [0.1, 0.4, 1])
+    counts_first = ssdb.tree_image(tdir, True).counts.copy()
+    assert len(first) == 3
+    per = sorted((float(v["cls_per"]) for v in first.values()), reverse=True)
+    assert abs(per[0] - 0.7) < 0.02 and abs(per[1] - 0.2) < 0.02 and abs(per[2] - 0.1) < 0.02
+    assert all(v["strain"] == "strain_%d" % k and float(v["cls_cov"]) > 0.9 for k, v in first.items())
+    assert {f[:5] for f in os.listdir(tmp_path / "cache")} == {"tree_", "index"}
+    ssdb.clear_cache()
+    second = identify.identify_cluster((fq[0], fq[1]), tdir, [0.1, 0.4, 1])
+    assert dict(second) == dict(first)
+    assert np.array_equal(ssdb.tree_image(tdir, True).counts, counts_first)
+    ssdb.clear_cache()
