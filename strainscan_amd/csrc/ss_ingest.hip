@@ -146,6 +146,7 @@ hipStream_t ingest_stream(unsigned i)
 //   3. otherwise, or when the text would not fit the memory budget (SS_INFLATE_MAX_GB, default a
 //      quarter of the memory the process may use), the zlib reader streams the file as before.
 // ---------------------------------------------------------------------------------------------
+void pgz_set_crc32(uint32_t (*fn)(uint32_t, const void *, size_t));      // ss_pgz.hip
 namespace {
 struct Deflate {
     void *(*alloc)() = nullptr;
@@ -166,6 +167,7 @@ const Deflate &deflate_lib()
         d.gunzip = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(h, "libdeflate_gzip_decompress_ex");
         d.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
         d.ok = d.alloc && d.gunzip && d.release;
+        if (void *c = dlsym(h, "libdeflate_crc32")) pgz_set_crc32((uint32_t (*)(uint32_t, const void *, size_t))c);
     });
     return d;
 }

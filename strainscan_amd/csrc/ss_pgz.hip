@@ -312,8 +312,14 @@ int inflate_block(Bits &b, Out &o, bool known_window)
         uint16_t *dst = out + n;
         if (dist <= n) {
             const uint16_t *src = dst - dist;
-            if (dist >= len) memcpy(dst, src, (size_t)len * 2);
-            else for (uint32_t i = 0; i < len; i++) dst[i] = src[i];      // overlapping: element by element
+            if (dist >= 8) {
+                // blocks of 8 symbols (one 16-byte move each, no call): block k reads symbols that are final already
+                // because dist > 7, also when the match overlaps itself; up to 7 symbols of overrun land in the
+                // 264 symbols of slack and are overwritten by what follows
+                for (uint32_t i = 0; i < len; i += 8) memcpy(dst + i, src + i, 16);
+            } else {
+                for (uint32_t i = 0; i < len; i++) dst[i] = src[i];          // short period: element by element
+            }
         } else {
             if (known_window) PGZ_RET(-8);
             // the first (dist - n) elements come from the unknown window, the rest (if any) from the output
@@ -348,6 +354,32 @@ uint64_t gzip_header_len(const uint8_t *p, uint64_t n)
 
 namespace ss {
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len);
+
+// CRC-32 of a buffer, continuing `crc` (zlib's convention).  zlib's own does ~2 GB/s per thread; the ingest
+// installs libdeflate's carry-less-multiply version (10+ GB/s) when that library is loaded.
+static uint32_t (*g_crc32)(uint32_t, const void *, size_t) = nullptr;
+void pgz_set_crc32(uint32_t (*fn)(uint32_t, const void *, size_t)) { g_crc32 = fn; }
+static inline uint32_t crc_of(const uint8_t *p, uint64_t n)
+{
+    if (g_crc32) return g_crc32(0, p, (size_t)n);
+    uint32_t k = (uint32_t)crc32(0L, Z_NULL, 0);
+    for (uint64_t a = 0; a < n; a += 1u << 30) k = (uint32_t)crc32(k, p + a, (uInt)std::min<uint64_t>(1u << 30, n - a));
+    return k;
+}
+
+// symbols -> bytes: a plain narrowing pass the compiler vectorises, and a second look only at the (rare) groups
+// that hold a window symbol
+static inline void resolve(const uint16_t *sy, uint64_t n, const uint8_t *w, uint8_t *dst)
+{
+    uint64_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        uint16_t any = 0;
+        for (int k = 0; k < 64; k++) { const uint16_t v = sy[i + k]; any |= v; dst[i + k] = (uint8_t)v; }
+        if (any & UNRESOLVED)
+            for (int k = 0; k < 64; k++) { const uint16_t v = sy[i + k]; if (v & UNRESOLVED) dst[i + k] = w[v & (WSIZE - 1)]; }
+    }
+    for (; i < n; i++) { const uint16_t v = sy[i]; dst[i] = (v & UNRESOLVED) ? w[v & (WSIZE - 1)] : (uint8_t)v; }
+}
 
 // Inflate the single-member gzip file image `in` with `threads` threads.  On success *text is a buffer of *len
 // bytes to be released with free().  false = not applicable or not verified: the caller uses another inflater.
@@ -452,9 +484,13 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
     ch[0].off_ready = true;
     ch[0].win_ready = true;
 
+    std::atomic<uint64_t> t_entry(0), t_decode(0), t_wait(0), t_resolve(0), t_crc(0);     // microseconds, all threads (trace)
     auto worker = [&] {
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
         Out o;                                           // this thread's symbols, reused chunk after chunk
         for (uint64_t j; !bad && (j = next.fetch_add(1)) < nch;) {
+            auto t0 = now();
             const uint64_t e = ensure_entry(j);
             if (e == NONE) continue;                     // no entry point in this range: the chunk before runs through it
             Chunk &c = ch[j];
@@ -466,6 +502,7 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
                 if (bad) return;
                 if (es != NONE) { stop = es; break; }
             }
+            auto t1 = now();
             o.n = 0;
             Bits b(in, in_n, e);
             bool final_seen = false;
@@ -482,6 +519,7 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
                 if (bp > stop) { bad = true; return; }           // ran over the next entry point: it was not a block start
             }
             c.n = o.n;
+            auto t2 = now();
             // place in the text, handed on to the successor at once
             if (!wait_for(c.off_ready)) return;
             if (c.off + c.n > text_cap) { bad = true; return; }
@@ -489,28 +527,23 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
             else if (final_seen) total.store(c.off + c.n, std::memory_order_release);
             // window of the successor = the last WSIZE bytes of the text up to here
             if (!wait_for(c.win_ready)) return;
+            auto t3 = now();
             const uint8_t *w = c.window;
             if (s < nch) {
                 uint8_t *nw = (uint8_t *)malloc(WSIZE);
                 if (!nw) { bad = true; return; }
                 const uint64_t take = std::min<uint64_t>(WSIZE, o.n);
                 memcpy(nw, w + take, WSIZE - take);
-                for (uint64_t i = 0; i < take; i++) {
-                    const uint16_t sy = o.p[o.n - take + i];
-                    nw[WSIZE - take + i] = (sy & UNRESOLVED) ? w[sy & (WSIZE - 1)] : (uint8_t)sy;
-                }
+                resolve(o.p + (o.n - take), take, w, nw + (WSIZE - take));
                 ch[s].window = nw;
                 ch[s].win_ready.store(true, std::memory_order_release);
             }
             // the chunk's bytes and their CRC
             uint8_t *dst = out + c.off;
-            for (uint64_t i = 0; i < o.n; i++) {
-                const uint16_t sy = o.p[i];
-                dst[i] = (sy & UNRESOLVED) ? w[sy & (WSIZE - 1)] : (uint8_t)sy;
-            }
-            uint32_t k = (uint32_t)crc32(0L, Z_NULL, 0);
-            for (uint64_t a = 0; a < o.n; a += 1u << 30) k = (uint32_t)crc32(k, dst + a, (uInt)std::min<uint64_t>(1u << 30, o.n - a));
-            c.crc = k;
+            resolve(o.p, o.n, w, dst);
+            auto t4 = now();
+            c.crc = crc_of(dst, o.n);
+            if (trace) { auto t5 = now(); t_entry += us(t0, t1); t_decode += us(t1, t2); t_wait += us(t2, t3); t_resolve += us(t3, t4); t_crc += us(t4, t5); }
         }
     };
     {
@@ -519,6 +552,8 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
         for (auto &th : pool) th.join();
     }
     lap("inflated");
+    if (trace) fprintf(stderr, "[pgz]   thread-seconds: entry search %.3f, decode %.3f, waiting %.3f, resolve %.3f, crc %.3f (%u threads)\n",
+                       t_entry / 1e6, t_decode / 1e6, t_wait / 1e6, t_resolve / 1e6, t_crc / 1e6, threads);
     uint64_t n_exist = 0;
     uint32_t all = (uint32_t)crc32(0L, Z_NULL, 0);
     for (auto &c : ch) {
