@@ -381,14 +381,19 @@ static inline void resolve(const uint16_t *sy, uint64_t n, const uint8_t *w, uin
     for (; i < n; i++) { const uint16_t v = sy[i]; dst[i] = (v & UNRESOLVED) ? w[v & (WSIZE - 1)] : (uint8_t)v; }
 }
 
-// Inflate the single-member gzip file image `in` with `threads` threads.  On success *text is a buffer of *len
-// bytes to be released with free().  false = not applicable or not verified: the caller uses another inflater.
+// Inflate the gzip file image `in` with `threads` threads.  On success *text is a buffer of *len bytes to be
+// released with free().  false = not applicable or not verified: the caller uses another inflater.
 //
-// Streaming form of the scheme above: the deflate data is cut into many small chunks (~1 MB), handed out IN ORDER
+// Streaming form of the scheme above: the deflate data is cut into many small chunks (1-4 MB), handed out IN ORDER
 // to the threads.  A thread finds its chunk's entry point, inflates to the next chunk's entry point into ITS symbol
 // buffer (reused for every chunk it takes: a few MB that stay in cache, instead of 2 bytes of fresh memory per byte
 // of text), then -- as soon as the chunk before it has published them -- takes its place in the text and its window,
 // passes both on to its successor, and writes its bytes.  The text is the only large allocation.
+//
+// Several members (lanes concatenated with `cat a.gz b.gz`): where a member ends is only known when its final
+// block has been decoded.  The chunk that meets it cancels the chunks after it (they were decoding the next
+// member's data ahead of time), the member's trailer is checked, and the pipeline starts again behind it.
+// Files of many small members (bgzip) are left to libdeflate.
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
@@ -400,21 +405,23 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "[pgz]   %-12s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    const uint64_t hdr = gzip_header_len(in, in_n);
-    if (!hdr || threads < 2) return say("no gzip header / one thread", hdr, threads);
-    const uint64_t end = in_n - 8;                       // the trailer: CRC-32, ISIZE
-    if (end - hdr < (uint64_t)threads * (1u << 20)) return say("too small", end - hdr, threads);
-    const uint32_t want_crc = (uint32_t)in[end] | (uint32_t)in[end + 1] << 8 | (uint32_t)in[end + 2] << 16 | (uint32_t)in[end + 3] << 24;
-    const uint32_t want_size = (uint32_t)in[end + 4] | (uint32_t)in[end + 5] << 8 | (uint32_t)in[end + 6] << 16 | (uint32_t)in[end + 7] << 24;
-    // the text is ISIZE + k * 2^32 bytes long; the smallest such length that is not below the file's own size
-    // is right for anything that deflates at all (a wrong k is caught below: the text would not fit, or ISIZE differs)
-    uint64_t guess = want_size;
+    if (!gzip_header_len(in, in_n) || threads < 2) return say("no gzip header / one thread", 0, threads);
+    if (in_n < (uint64_t)threads * (1u << 20) + 64) return say("too small", in_n, threads);
+    const uint64_t lim = in_n - 8;                       // no deflate data at or beyond this byte (the last trailer)
+    // the text: ISIZE of the LAST member + k * 2^32 for a file of one member (the smallest such length that is not
+    // below the file's own size is right for anything that deflates at all); several members: room for 6 x the file
+    // (address space only; pages are touched as the text is written).  Too small a guess is caught: the text would
+    // not fit, and the file goes to the caller's other inflaters.
+    uint64_t guess = (uint32_t)in[lim + 4] | (uint32_t)in[lim + 5] << 8 | (uint32_t)in[lim + 6] << 16 | (uint64_t)in[lim + 7] << 24;
     while (guess < in_n) guess += 1ull << 32;
     const uint64_t sym_bytes = (uint64_t)threads * (64ull << 20);
-    if (guess + sym_bytes > budget) return say("over the memory budget", guess, budget);
+    if (std::max<uint64_t>(guess, 4 * in_n) + sym_bytes > budget) return say("over the memory budget", guess, budget);
+    void *mem = nullptr;
+    const uint64_t text_cap = (std::max<uint64_t>(guess, 6 * in_n) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+    if (posix_memalign(&mem, 2u << 20, text_cap) != 0 || !mem) return say("no memory for the text", text_cap);
+    if (!getenv("SS_PGZ_NOHUGE")) madvise(mem, text_cap, MADV_HUGEPAGE);
+    uint8_t *out = (uint8_t *)mem;
 
-    const uint64_t CH = std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, (end - hdr) / ((uint64_t)threads * 8)));
-    const uint64_t nch = (end - hdr + CH - 1) / CH;
     constexpr uint64_t UNKNOWN = ~0ull, NONE = ~0ull - 1;
     struct alignas(64) Chunk {
         std::atomic<uint64_t> entry{~0ull};        // bit position, NONE, or UNKNOWN
@@ -423,150 +430,177 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
         uint64_t off = 0, n = 0;                    // place and length of the chunk's text
         uint32_t crc = 0;
         bool exists = false;
+        uint64_t end_byte = 0;                      // where the member's trailer starts, if this chunk met the final block
         uint8_t *window = nullptr;                  // WSIZE bytes in front of the chunk (owned by the chunk)
     };
-    std::vector<Chunk> ch(nch);
-    std::atomic<bool> bad(false);
-    std::atomic<uint64_t> next(0), total(UNKNOWN);
+    std::atomic<uint64_t> t_entry(0), t_decode(0), t_wait(0), t_resolve(0), t_crc(0);     // microseconds, all threads (trace)
+    uint64_t text_off = 0, mstart = 0, members = 0;
 
-    // the text: 2 MB aligned so that huge pages back all of it; released with free()
-    void *mem = nullptr;
-    const uint64_t text_cap = (std::max<uint64_t>(1, guess) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
-    if (posix_memalign(&mem, 2u << 20, text_cap) != 0 || !mem) return say("no memory for the text", text_cap);
-    if (!getenv("SS_PGZ_NOHUGE")) madvise(mem, text_cap, MADV_HUGEPAGE);
-    uint8_t *out = (uint8_t *)mem;
-
-    // entry point of chunk k: the first position in its byte range that parses as a dynamic block and decodes
-    auto find_entry = [&](uint64_t k) -> uint64_t {
-        if (k == 0) return hdr * 8;
-        const uint64_t lo = (hdr + CH * k) * 8, hi = std::min<uint64_t>(end, hdr + CH * (k + 1)) * 8;
-        for (uint64_t bp = lo; bp < hi; bp++) {
-            const uint64_t byte = bp >> 3;      // BFINAL = 0, BTYPE = 10 (LSB first: 0, 0, 1)
-            const uint32_t three = (((uint32_t)in[byte] | (uint32_t)in[byte + 1] << 8) >> (bp & 7)) & 7u;
-            if (three != 4u) continue;
-            Bits b(in, in_n, bp + 3);
-            Codes c;
-            if (!read_dynamic(b, c)) continue;
-            Bits b2(in, in_n, bp);                // this block and the next two must come through without an error
-            Out o;
-            o.count_only = true;
-            int r = 0;
-            for (int q = 0; q < 3 && r == 0; q++) r = inflate_block(b2, o, false);
-            if (r < 0) continue;
-            return bp;
+    while (mstart < in_n) {
+        const uint64_t hl = gzip_header_len(in + mstart, in_n - mstart);
+        if (!hl) { free(mem); return say("what follows a member is not a gzip header", mstart, members); }
+        {   // bgzip: an extra field with a 'B','C' subfield; thousands of 64 KB members are not for this pipeline
+            const uint8_t *h = in + mstart;
+            if ((h[3] & 4) && hl >= 18 && h[12] == 'B' && h[13] == 'C') { free(mem); return say("bgzf", mstart); }
         }
-        return NONE;
-    };
-    auto ensure_entry = [&](uint64_t k) -> uint64_t {
-        Chunk &c = ch[k];
-        int st = 0;
-        if (c.entry_state.compare_exchange_strong(st, 1)) {
-            c.entry.store(find_entry(k), std::memory_order_relaxed);
-            c.entry_state.store(2, std::memory_order_release);
-        } else {
-            for (unsigned spin = 0; c.entry_state.load(std::memory_order_acquire) != 2; spin++) {
-                if (bad) return NONE;
+        const uint64_t ds = mstart + hl;                 // first byte of deflate data of this member
+        if (lim - ds < (2u << 20) && members > 0) { free(mem); return say("small trailing member", lim - ds, members); }
+        const uint64_t CH = std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, (lim - ds) / ((uint64_t)threads * 8)));
+        const uint64_t nch = std::max<uint64_t>(1, (lim - ds + CH - 1) / CH);
+        std::vector<Chunk> ch(nch);
+        std::atomic<bool> bad(false);
+        std::atomic<uint64_t> next(0), total(UNKNOWN), cut(UNKNOWN);
+
+        // entry point of chunk k: the first position in its byte range that parses as a dynamic block and decodes
+        auto find_entry = [&](uint64_t k) -> uint64_t {
+            if (k == 0) return ds * 8;
+            const uint64_t lo = (ds + CH * k) * 8, hi = std::min<uint64_t>(lim, ds + CH * (k + 1)) * 8;
+            for (uint64_t bp = lo; bp < hi; bp++) {
+                const uint64_t byte = bp >> 3;      // BFINAL = 0, BTYPE = 10 (LSB first: 0, 0, 1)
+                const uint32_t three = (((uint32_t)in[byte] | (uint32_t)in[byte + 1] << 8) >> (bp & 7)) & 7u;
+                if (three != 4u) continue;
+                Bits b(in, in_n, bp + 3);
+                Codes c;
+                if (!read_dynamic(b, c)) continue;
+                Bits b2(in, in_n, bp);                // this block and the next two must come through without an error
+                Out o;
+                o.count_only = true;
+                int r = 0;
+                for (int q = 0; q < 3 && r == 0; q++) r = inflate_block(b2, o, false);
+                if (r < 0) continue;
+                return bp;
+            }
+            return NONE;
+        };
+        auto ensure_entry = [&](uint64_t k) -> uint64_t {
+            Chunk &c = ch[k];
+            int st = 0;
+            if (c.entry_state.compare_exchange_strong(st, 1)) {
+                c.entry.store(find_entry(k), std::memory_order_relaxed);
+                c.entry_state.store(2, std::memory_order_release);
+            } else {
+                for (unsigned spin = 0; c.entry_state.load(std::memory_order_acquire) != 2; spin++) {
+                    if (bad) return NONE;
+                    if (spin < 256) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
+            }
+            return c.entry.load(std::memory_order_relaxed);
+        };
+        // false: give up (an error somewhere, or chunk j lies behind the member's end)
+        auto wait_for = [&](std::atomic<bool> &flag, uint64_t j) {
+            for (unsigned spin = 0; !flag.load(std::memory_order_acquire); spin++) {
+                if (bad || j > cut.load(std::memory_order_acquire)) return false;
                 if (spin < 256) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
             }
-        }
-        return c.entry.load(std::memory_order_relaxed);
-    };
-    auto wait_for = [&](std::atomic<bool> &flag) {
-        for (unsigned spin = 0; !flag.load(std::memory_order_acquire); spin++) {
-            if (bad) return false;
-            if (spin < 256) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
-        }
-        return true;
-    };
+            return true;
+        };
 
-    ch[0].window = (uint8_t *)calloc(WSIZE, 1);
-    if (!ch[0].window) { free(mem); return false; }
-    ch[0].off_ready = true;
-    ch[0].win_ready = true;
+        ch[0].window = (uint8_t *)calloc(WSIZE, 1);
+        if (!ch[0].window) { free(mem); return false; }
+        ch[0].off = text_off;
+        ch[0].off_ready = true;
+        ch[0].win_ready = true;
 
-    std::atomic<uint64_t> t_entry(0), t_decode(0), t_wait(0), t_resolve(0), t_crc(0);     // microseconds, all threads (trace)
-    auto worker = [&] {
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        Out o;                                           // this thread's symbols, reused chunk after chunk
-        for (uint64_t j; !bad && (j = next.fetch_add(1)) < nch;) {
-            auto t0 = now();
-            const uint64_t e = ensure_entry(j);
-            if (e == NONE) continue;                     // no entry point in this range: the chunk before runs through it
-            Chunk &c = ch[j];
-            c.exists = true;
-            // the next chunk that has an entry point is where this one stops
-            uint64_t s = j + 1, stop = UNKNOWN;
-            for (; s < nch; s++) {
-                const uint64_t es = ensure_entry(s);
-                if (bad) return;
-                if (es != NONE) { stop = es; break; }
-            }
-            auto t1 = now();
-            o.n = 0;
-            Bits b(in, in_n, e);
-            bool final_seen = false;
-            for (;;) {
-                const int r = inflate_block(b, o, j == 0);
-                if (r < 0 || bad) { bad = true; return; }
-                const uint64_t bp = b.bitpos();
-                if (r == 1) {                                    // the final block: nothing may follow but the trailer
-                    if (s < nch || ((bp + 7) >> 3) != end) { bad = true; return; }
-                    final_seen = true;
-                    break;
+        auto worker = [&] {
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+            Out o;                                           // this thread's symbols, reused chunk after chunk
+            for (uint64_t j; !bad && (j = next.fetch_add(1)) < nch && j <= cut.load(std::memory_order_acquire);) {
+                auto t0 = now();
+                const uint64_t e = ensure_entry(j);
+                if (e == NONE) continue;                     // no entry point in this range: the chunk before runs through it
+                Chunk &c = ch[j];
+                // the next chunk that has an entry point is where this one stops
+                uint64_t s = j + 1, stop = UNKNOWN;
+                for (; s < nch; s++) {
+                    const uint64_t es = ensure_entry(s);
+                    if (bad) return;
+                    if (es != NONE) { stop = es; break; }
                 }
-                if (bp == stop) break;
-                if (bp > stop) { bad = true; return; }           // ran over the next entry point: it was not a block start
+                auto t1 = now();
+                o.n = 0;
+                Bits b(in, in_n, e);
+                bool final_seen = false;
+                for (;;) {
+                    const int r = inflate_block(b, o, j == 0);
+                    if (j > cut.load(std::memory_order_acquire)) break;     // this was the next member's data
+                    if (r < 0 || bad) { bad = true; return; }
+                    const uint64_t bp = b.bitpos();
+                    if (r == 1) {                                    // the member's final block: its trailer follows
+                        const uint64_t eb = (bp + 7) >> 3;
+                        if (eb > lim) { bad = true; return; }
+                        c.end_byte = eb;
+                        // chunks behind this one are not part of the member.  A chunk that was decoding the NEXT member
+                        // ahead of time may get here first with that member's final block: the smallest index wins
+                        uint64_t cur = cut.load(std::memory_order_acquire);
+                        while (j < cur && !cut.compare_exchange_weak(cur, j, std::memory_order_acq_rel)) {}
+                        final_seen = true;
+                        break;
+                    }
+                    if (bp == stop) break;
+                    if (bp > stop) { bad = true; return; }           // ran over the next entry point: it was not a block start
+                }
+                if (j > cut.load(std::memory_order_acquire)) continue;
+                c.exists = true;
+                c.n = o.n;
+                auto t2 = now();
+                // place in the text, handed on to the successor at once
+                if (!wait_for(c.off_ready, j)) return;
+                if (c.off + c.n > text_cap) { bad = true; return; }
+                if (final_seen) total.store(c.off + c.n, std::memory_order_release);
+                else if (s < nch) { ch[s].off = c.off + c.n; ch[s].off_ready.store(true, std::memory_order_release); }
+                // window of the successor = the last WSIZE bytes of the text up to here
+                if (!wait_for(c.win_ready, j)) return;
+                auto t3 = now();
+                const uint8_t *w = c.window;
+                if (!final_seen && s < nch) {
+                    uint8_t *nw = (uint8_t *)malloc(WSIZE);
+                    if (!nw) { bad = true; return; }
+                    const uint64_t take = std::min<uint64_t>(WSIZE, o.n);
+                    memcpy(nw, w + take, WSIZE - take);
+                    resolve(o.p + (o.n - take), take, w, nw + (WSIZE - take));
+                    ch[s].window = nw;
+                    ch[s].win_ready.store(true, std::memory_order_release);
+                }
+                // the chunk's bytes and their CRC
+                uint8_t *dst = out + c.off;
+                resolve(o.p, o.n, w, dst);
+                auto t4 = now();
+                c.crc = crc_of(dst, o.n);
+                if (trace) { auto t5 = now(); t_entry += us(t0, t1); t_decode += us(t1, t2); t_wait += us(t2, t3); t_resolve += us(t3, t4); t_crc += us(t4, t5); }
             }
-            c.n = o.n;
-            auto t2 = now();
-            // place in the text, handed on to the successor at once
-            if (!wait_for(c.off_ready)) return;
-            if (c.off + c.n > text_cap) { bad = true; return; }
-            if (s < nch) { ch[s].off = c.off + c.n; ch[s].off_ready.store(true, std::memory_order_release); }
-            else if (final_seen) total.store(c.off + c.n, std::memory_order_release);
-            // window of the successor = the last WSIZE bytes of the text up to here
-            if (!wait_for(c.win_ready)) return;
-            auto t3 = now();
-            const uint8_t *w = c.window;
-            if (s < nch) {
-                uint8_t *nw = (uint8_t *)malloc(WSIZE);
-                if (!nw) { bad = true; return; }
-                const uint64_t take = std::min<uint64_t>(WSIZE, o.n);
-                memcpy(nw, w + take, WSIZE - take);
-                resolve(o.p + (o.n - take), take, w, nw + (WSIZE - take));
-                ch[s].window = nw;
-                ch[s].win_ready.store(true, std::memory_order_release);
-            }
-            // the chunk's bytes and their CRC
-            uint8_t *dst = out + c.off;
-            resolve(o.p, o.n, w, dst);
-            auto t4 = now();
-            c.crc = crc_of(dst, o.n);
-            if (trace) { auto t5 = now(); t_entry += us(t0, t1); t_decode += us(t1, t2); t_wait += us(t2, t3); t_resolve += us(t3, t4); t_crc += us(t4, t5); }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < threads; t++) pool.emplace_back(worker);
+            for (auto &th : pool) th.join();
         }
-    };
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; t++) pool.emplace_back(worker);
-        for (auto &th : pool) th.join();
+        const uint64_t last = cut.load(), tot = total.load();
+        const uint64_t eb = last != UNKNOWN ? ch[last].end_byte : UNKNOWN;
+        uint32_t all = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (uint64_t k = 0; k < nch; k++) {
+            free(ch[k].window);
+            if (ch[k].exists && k <= last && !bad) all = (uint32_t)crc32_combine(all, ch[k].crc, (z_off_t)ch[k].n);
+        }
+        if (bad || last == UNKNOWN || tot == UNKNOWN || !ch[last].exists) {
+            free(mem);
+            return say("a chunk failed, overran the next entry point, or no final block was found", members);
+        }
+        const uint32_t want_crc = (uint32_t)in[eb] | (uint32_t)in[eb + 1] << 8 | (uint32_t)in[eb + 2] << 16 | (uint32_t)in[eb + 3] << 24;
+        const uint32_t want_size = (uint32_t)in[eb + 4] | (uint32_t)in[eb + 5] << 8 | (uint32_t)in[eb + 6] << 16 | (uint32_t)in[eb + 7] << 24;
+        if ((uint32_t)(tot - text_off) != want_size) { free(mem); return say("length differs from ISIZE", tot - text_off, want_size); }
+        if (all != want_crc) { free(mem); return say("CRC-32 differs", all, want_crc); }
+        members++;
+        text_off = tot;
+        mstart = eb + 8;
+        lap("member done");
+        if (mstart < in_n && (eb - ds) < (2u << 20)) { free(mem); return say("small members", eb - ds, members); }
     }
-    lap("inflated");
     if (trace) fprintf(stderr, "[pgz]   thread-seconds: entry search %.3f, decode %.3f, waiting %.3f, resolve %.3f, crc %.3f (%u threads)\n",
                        t_entry / 1e6, t_decode / 1e6, t_wait / 1e6, t_resolve / 1e6, t_crc / 1e6, threads);
-    uint64_t n_exist = 0;
-    uint32_t all = (uint32_t)crc32(0L, Z_NULL, 0);
-    for (auto &c : ch) {
-        free(c.window);
-        if (c.exists && !bad) { all = (uint32_t)crc32_combine(all, c.crc, (z_off_t)c.n); n_exist++; }
-    }
-    const uint64_t tot = total.load();
-    if (bad || tot == UNKNOWN) { free(mem); return say("a chunk failed, overran the next entry point, or the stream did not end at the trailer"); }
-    if ((uint32_t)tot != want_size) { free(mem); return say("length differs from ISIZE", tot, want_size); }
-    if (all != want_crc) { free(mem); return say("CRC-32 differs", all, want_crc); }
-    say("ok", tot, n_exist);
+    say("ok", text_off, members);
     *text = (char *)mem;
-    *len = tot;
+    *len = text_off;
     return true;
 }
 

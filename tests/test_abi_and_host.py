@@ -170,13 +170,22 @@ def test_threaded_gunzip_equals_gzip(tmp_path):
             assert auto == data, name
         else:
             assert not have_libdeflate
-    # several members, and a file too small to split: declined by the threaded inflater
+    # several large members (lanes concatenated with cat): member ends are discovered, every trailer is checked
+    third = len(fq) // 3
     multi = tmp_path / "multi.gz"
-    multi.write_bytes(gzip.compress(fq[: len(fq) // 2], 6) + gzip.compress(fq[len(fq) // 2:], 6))
+    multi.write_bytes(gzip.compress(fq[:third], 6) + gzip.compress(fq[third:2 * third], 1) + gzip.compress(fq[2 * third:], 9))
+    for threads in (2, 3, 5):
+        assert _lib.gz_inflate(str(multi), threads, 1) == fq, threads
+    # many small members (bgzip-like), a small trailing member, a file too small to split: declined by the threaded
+    # inflater, inflated by libdeflate in mode 0
+    tiny = tmp_path / "tiny_members.gz"
+    tiny.write_bytes(b"".join(gzip.compress(fq[a:a + 60000], 6) for a in range(0, 6000000, 60000)))
+    tail = tmp_path / "tail.gz"
+    tail.write_bytes(gzip.compress(fq, 6) + gzip.compress(b"@r\nACGT\n+\nIIII\n", 6))
     small = tmp_path / "small.gz"
     small.write_bytes(gzip.compress(fq[:200000], 6))
-    for p, data in ((multi, fq), (small, fq[:200000])):
-        assert _lib.gz_inflate(str(p), 4, 1) is None
+    for p, data in ((tiny, fq[:6000000]), (tail, fq + b"@r\nACGT\n+\nIIII\n"), (small, fq[:200000])):
+        assert _lib.gz_inflate(str(p), 4, 1) is None, p
         got = _lib.gz_inflate(str(p), 4, 0)
         assert (got == data) if have_libdeflate else (got is None)
     # a damaged member is never accepted (CRC), a non-gzip file is declined
@@ -206,9 +215,15 @@ def test_threaded_gunzip_fuzz_sanitized(tmp_path):
     (tmp_path / "want.txt").write_bytes(data)
     (tmp_path / "in.gz").write_bytes(gzip.compress(data, 6))
     assert (tmp_path / "in.gz").stat().st_size > (5 << 20)
-    r = subprocess.run([str(exe), str(tmp_path / "in.gz"), str(tmp_path / "want.txt"), "250"], capture_output=True, text=True,
-                       timeout=1500, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
-    assert r.returncode == 0 and "pgz_fuzz ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    # ... and a file of two members (the member loop: discovered end, cancelled look-ahead chunks, second pipeline)
+    data2 = _fastq_like(rs, 50000)
+    cut = len(data2) * 3 // 5
+    (tmp_path / "want2.txt").write_bytes(data2)
+    (tmp_path / "in2.gz").write_bytes(gzip.compress(data2[:cut], 6) + gzip.compress(data2[cut:], 1))
+    for gz, want, iters in (("in.gz", "want.txt", "120"), ("in2.gz", "want2.txt", "80")):
+        r = subprocess.run([str(exe), str(tmp_path / gz), str(tmp_path / want), iters], capture_output=True, text=True,
+                           timeout=1500, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0 and "pgz_fuzz ok" in r.stdout, (gz, r.stdout[-500:], r.stderr[-3000:])
 
 
 def test_shuffle_split_native_equals_numpy():
