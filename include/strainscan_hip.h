@@ -74,6 +74,9 @@ int ss_host_cpus(void);
  * ss_gz_free.  Host only. */
 int ss_gz_inflate(const char *path, int threads, int mode, char **text, uint64_t *len);
 void ss_gz_free(char *text);
+/* The same text written to out_path (the threaded inflater writes through a shared mapping of the file): the ranks
+ * of one node inflate a .gz sample ONCE into /dev/shm and each parses its share of the plain text. */
+int ss_gz_inflate_to_file(const char *path, const char *out_path, int threads, uint64_t *len);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,

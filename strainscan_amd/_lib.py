@@ -57,6 +57,7 @@ SIGNATURES = {
     "ss_shuffle_split_bits": (i32, [u64, i32, u64, u32, vp]),
     "ss_gz_inflate": (i32, [cp, i32, i32, P(vp), P(u64)]),
     "ss_gz_free": (None, [vp]),
+    "ss_gz_inflate_to_file": (i32, [cp, cp, i32, P(u64)]),
     "ss_host_cpus": (i32, []),
     "ss_revcomp_dev": (i32, [vp, vp, u64, u64, vp]),
     "ss_kmerfa_count_rows": (i32, [cp, P(u64)]),

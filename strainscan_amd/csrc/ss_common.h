@@ -107,7 +107,6 @@ int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank
 int parse_text_parallel(ss_db::Worker *workers, const char *text, uint64_t n, const char *path, int shard_rank,
                         int shard_world, uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink,
                         bool copy = true);
-bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len);
 struct InflatedText { char *p = nullptr; uint64_t n = 0; };
 bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len, int mode, unsigned threads);
 uint64_t inflate_budget_bytes();

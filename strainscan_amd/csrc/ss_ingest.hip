@@ -147,6 +147,13 @@ hipStream_t ingest_stream(unsigned i)
 //      quarter of the memory the process may use), the zlib reader streams the file as before.
 // ---------------------------------------------------------------------------------------------
 void pgz_set_crc32(uint32_t (*fn)(uint32_t, const void *, size_t));      // ss_pgz.hip
+struct TextAlloc {                                                          // ss_pgz.hip
+    void *(*alloc)(uint64_t cap, void *ctx) = nullptr;
+    void (*release)(void *p, uint64_t cap, void *ctx) = nullptr;
+    void *ctx = nullptr;
+};
+bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len,
+                     const TextAlloc *ta);
 namespace {
 struct Deflate {
     void *(*alloc)() = nullptr;
@@ -215,7 +222,7 @@ bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len
         if (!threads) threads = std::min<unsigned>(host_cpus(), 32u);
         if (const char *e = getenv("SS_PGZ_THREADS")) threads = (unsigned)std::max(1, atoi(e));
         threads = (unsigned)std::min<uint64_t>(threads, std::max<uint64_t>(1, in_n >> 21));      // >= 2 MB of input each
-        if (parallel_gunzip(in, in_n, threads, budget, text, len)) { munmap((void *)in, in_n); return true; }
+        if (parallel_gunzip(in, in_n, threads, budget, text, len, nullptr)) { munmap((void *)in, in_n); return true; }
     }
     if (mode == 1 || !L.ok) { munmap((void *)in, in_n); return false; }
     char *out = nullptr;
@@ -263,6 +270,65 @@ int ss_gz_inflate(const char *path, int threads, int mode, char **text, uint64_t
     return ss::inflate_whole(path, ss::inflate_budget_bytes(), text, len, mode, (unsigned)threads) ? SS_OK : SS_ERANGE;
 }
 void ss_gz_free(char *text) { free(text); }
+
+// The text of a .gz file written to `out_path` (a file on tmpfs, so that the ranks of one node share ONE inflate:
+// strainscan_amd/dist.py).  The threaded inflater writes straight into a shared mapping of the file; otherwise
+// libdeflate inflates to memory and the text is written out.
+int ss_gz_inflate_to_file(const char *path, const char *out_path, int threads, uint64_t *len)
+{
+    if (!path || !out_path || !len || threads < 0) return SS_EINVAL;
+    *len = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return SS_EIO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) { close(fd); return SS_ERANGE; }
+    const uint64_t in_n = (uint64_t)st.st_size;
+    const uint8_t *in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (in == MAP_FAILED) return SS_EIO;
+    struct Ctx { const char *out_path; int fd; } ctx{out_path, -1};
+    ss::TextAlloc ta;
+    ta.ctx = &ctx;
+    ta.alloc = [](uint64_t cap, void *c) -> void * {
+        Ctx *x = (Ctx *)c;
+        x->fd = open(x->out_path, O_RDWR | O_CREAT | O_TRUNC, 0600);
+        if (x->fd < 0 || ftruncate(x->fd, (off_t)cap) != 0) return nullptr;          // sparse: pages come as they are written
+        void *m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
+        return m == MAP_FAILED ? nullptr : m;
+    };
+    ta.release = [](void *p, uint64_t cap, void *c) {
+        Ctx *x = (Ctx *)c;
+        munmap(p, cap);
+        if (x->fd >= 0) { close(x->fd); x->fd = -1; }
+        unlink(x->out_path);
+    };
+    unsigned t = threads ? (unsigned)threads : std::min<unsigned>(ss::host_cpus(), 32u);
+    t = (unsigned)std::min<uint64_t>(t, std::max<uint64_t>(1, in_n >> 21));
+    char *text = nullptr;
+    uint64_t n = 0;
+    int rc = SS_ERANGE;
+    if (!getenv("SS_NO_PGZ") && ss::parallel_gunzip(in, in_n, t, ss::inflate_budget_bytes(), &text, &n, &ta)) {
+        // the mapping's capacity was an upper bound: cut the file to the text
+        struct stat so;
+        const uint64_t cap = fstat(ctx.fd, &so) == 0 ? (uint64_t)so.st_size : n;
+        munmap(text, cap);
+        rc = ftruncate(ctx.fd, (off_t)n) == 0 ? SS_OK : SS_EIO;
+        close(ctx.fd);
+        if (rc != SS_OK) unlink(out_path);
+    } else {
+        if (ctx.fd >= 0) { close(ctx.fd); unlink(out_path); }
+        if (ss::inflate_whole(path, ss::inflate_budget_bytes(), &text, &n, 2, 0)) {
+            FILE *f = fopen(out_path, "wb");
+            rc = (f && fwrite(text, 1, n, f) == n) ? SS_OK : SS_EIO;
+            if (f && fclose(f) != 0) rc = SS_EIO;
+            if (rc != SS_OK) unlink(out_path);
+            free(text);
+        }
+    }
+    munmap((void *)in, in_n);
+    if (rc == SS_OK) *len = n;
+    return rc;
+}
 }
 
 namespace ss {

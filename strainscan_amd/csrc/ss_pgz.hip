@@ -353,7 +353,14 @@ uint64_t gzip_header_len(const uint8_t *p, uint64_t n)
 }  // namespace
 
 namespace ss {
-bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len);
+// where the text goes: by default 2 MB aligned heap memory released with free(); ss_gz_inflate_to_file maps a file
+struct TextAlloc {
+    void *(*alloc)(uint64_t cap, void *ctx) = nullptr;
+    void (*release)(void *p, uint64_t cap, void *ctx) = nullptr;
+    void *ctx = nullptr;
+};
+bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len,
+                     const TextAlloc *ta = nullptr);
 
 // CRC-32 of a buffer, continuing `crc` (zlib's convention).  zlib's own does ~2 GB/s per thread; the ingest
 // installs libdeflate's carry-less-multiply version (10+ GB/s) when that library is loaded.
@@ -394,7 +401,8 @@ static inline void resolve(const uint16_t *sy, uint64_t n, const uint8_t *w, uin
 // block has been decoded.  The chunk that meets it cancels the chunks after it (they were decoding the next
 // member's data ahead of time), the member's trailer is checked, and the pipeline starts again behind it.
 // Files of many small members (bgzip) are left to libdeflate.
-bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len)
+bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len,
+                     const TextAlloc *ta)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     auto say = [&](const char *what, uint64_t a = 0, uint64_t b = 0) {
@@ -418,9 +426,12 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
     if (std::max<uint64_t>(guess, 4 * in_n) + sym_bytes > budget) return say("over the memory budget", guess, budget);
     void *mem = nullptr;
     const uint64_t text_cap = (std::max<uint64_t>(guess, 6 * in_n) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
-    if (posix_memalign(&mem, 2u << 20, text_cap) != 0 || !mem) return say("no memory for the text", text_cap);
+    if (ta && ta->alloc) mem = ta->alloc(text_cap, ta->ctx);
+    else if (posix_memalign(&mem, 2u << 20, text_cap) != 0) mem = nullptr;
+    if (!mem) return say("no memory for the text", text_cap);
     if (!getenv("SS_PGZ_NOHUGE")) madvise(mem, text_cap, MADV_HUGEPAGE);
     uint8_t *out = (uint8_t *)mem;
+    auto drop_text = [&] { if (ta && ta->release) ta->release(mem, text_cap, ta->ctx); else free(mem); };
 
     constexpr uint64_t UNKNOWN = ~0ull, NONE = ~0ull - 1;
     struct alignas(64) Chunk {
@@ -438,13 +449,13 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
 
     while (mstart < in_n) {
         const uint64_t hl = gzip_header_len(in + mstart, in_n - mstart);
-        if (!hl) { free(mem); return say("what follows a member is not a gzip header", mstart, members); }
+        if (!hl) { drop_text(); return say("what follows a member is not a gzip header", mstart, members); }
         {   // bgzip: an extra field with a 'B','C' subfield; thousands of 64 KB members are not for this pipeline
             const uint8_t *h = in + mstart;
-            if ((h[3] & 4) && hl >= 18 && h[12] == 'B' && h[13] == 'C') { free(mem); return say("bgzf", mstart); }
+            if ((h[3] & 4) && hl >= 18 && h[12] == 'B' && h[13] == 'C') { drop_text(); return say("bgzf", mstart); }
         }
         const uint64_t ds = mstart + hl;                 // first byte of deflate data of this member
-        if (lim - ds < (2u << 20) && members > 0) { free(mem); return say("small trailing member", lim - ds, members); }
+        if (lim - ds < (2u << 20) && members > 0) { drop_text(); return say("small trailing member", lim - ds, members); }
         const uint64_t CH = std::min<uint64_t>(4u << 20, std::max<uint64_t>(1u << 20, (lim - ds) / ((uint64_t)threads * 8)));
         const uint64_t nch = std::max<uint64_t>(1, (lim - ds + CH - 1) / CH);
         std::vector<Chunk> ch(nch);
@@ -496,7 +507,7 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
         };
 
         ch[0].window = (uint8_t *)calloc(WSIZE, 1);
-        if (!ch[0].window) { free(mem); return false; }
+        if (!ch[0].window) { drop_text(); return false; }
         ch[0].off = text_off;
         ch[0].off_ready = true;
         ch[0].win_ready = true;
@@ -583,18 +594,18 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
             if (ch[k].exists && k <= last && !bad) all = (uint32_t)crc32_combine(all, ch[k].crc, (z_off_t)ch[k].n);
         }
         if (bad || last == UNKNOWN || tot == UNKNOWN || !ch[last].exists) {
-            free(mem);
+            drop_text();
             return say("a chunk failed, overran the next entry point, or no final block was found", members);
         }
         const uint32_t want_crc = (uint32_t)in[eb] | (uint32_t)in[eb + 1] << 8 | (uint32_t)in[eb + 2] << 16 | (uint32_t)in[eb + 3] << 24;
         const uint32_t want_size = (uint32_t)in[eb + 4] | (uint32_t)in[eb + 5] << 8 | (uint32_t)in[eb + 6] << 16 | (uint32_t)in[eb + 7] << 24;
-        if ((uint32_t)(tot - text_off) != want_size) { free(mem); return say("length differs from ISIZE", tot - text_off, want_size); }
-        if (all != want_crc) { free(mem); return say("CRC-32 differs", all, want_crc); }
+        if ((uint32_t)(tot - text_off) != want_size) { drop_text(); return say("length differs from ISIZE", tot - text_off, want_size); }
+        if (all != want_crc) { drop_text(); return say("CRC-32 differs", all, want_crc); }
         members++;
         text_off = tot;
         mstart = eb + 8;
         lap("member done");
-        if (mstart < in_n && (eb - ds) < (2u << 20)) { free(mem); return say("small members", eb - ds, members); }
+        if (mstart < in_n && (eb - ds) < (2u << 20)) { drop_text(); return say("small members", eb - ds, members); }
     }
     if (trace) fprintf(stderr, "[pgz]   thread-seconds: entry search %.3f, decode %.3f, waiting %.3f, resolve %.3f, crc %.3f (%u threads)\n",
                        t_entry / 1e6, t_decode / 1e6, t_wait / 1e6, t_resolve / 1e6, t_crc / 1e6, threads);

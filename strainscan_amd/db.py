@@ -82,7 +82,11 @@ def resident_reads(paths):
             for old in _READS.values():
                 old.close()
             _READS.clear()
-            rs = _lib.ReadSet([p for p in paths if p], rank, world)
+            use, cleanup = dist.share_inflated([p for p in paths if p])    # .gz under torch.distributed: one inflate per node
+            try:
+                rs = _lib.ReadSet(use, rank, world)
+            finally:
+                cleanup()
             _READS[key] = rs
     return rs
 

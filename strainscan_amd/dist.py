@@ -84,6 +84,56 @@ def scan_files_sharded(kdb, paths, cap=32 << 20):
     return nrec, nb
 
 
+def share_inflated(paths, shm_dir="/dev/shm"):
+    """.gz inputs under torch.distributed on ONE node: rank 0 inflates each of them once into a plain file on tmpfs
+    (ss_gz_inflate_to_file: the threaded inflater writes through a shared mapping), the names are broadcast, every
+    rank then parses only its share of the plain text -- instead of every rank inflating the whole file before it
+    can pick its share (a gzip member has no entry points).  -> (paths to read, cleanup): call cleanup() when the
+    reads are loaded (a barrier, then rank 0 removes the files).  Not distributed, several nodes, SS_GZ_SHARE=0,
+    no room on tmpfs, or an input that cannot be inflated whole: the original paths come back."""
+    import ctypes as C
+    paths = list(paths)
+    if not is_distributed() or os.environ.get("SS_GZ_SHARE", "1") == "0":
+        return paths, (lambda: None)
+    import torch.distributed as dist
+    rank, world = rank_world()
+    if int(os.environ.get("LOCAL_WORLD_SIZE", world)) != world or not os.path.isdir(shm_dir):
+        return paths, (lambda: None)
+    names = [None] * len(paths)
+    if rank == 0:
+        for i, p in enumerate(paths):
+            try:
+                if not p:
+                    continue
+                with open(p, "rb") as f:
+                    if f.read(2) != b"\x1f\x8b":
+                        continue
+                fs = os.statvfs(shm_dir)
+                if fs.f_bavail * fs.f_frsize < 8 * os.path.getsize(p):
+                    continue
+                out = os.path.join(shm_dir, "ss_inflate_%d_%d_%s.txt" % (os.getpid(), i, os.path.basename(p)))
+                n = C.c_uint64()
+                if _lib.lib().ss_gz_inflate_to_file(os.fsencode(p), os.fsencode(out), 0, C.byref(n)) == _lib.SS_OK:
+                    names[i] = out
+            except OSError:
+                pass
+    box = [names]
+    dist.broadcast_object_list(box, src=0)
+    names = box[0]
+
+    def cleanup():
+        dist.barrier()
+        if rank == 0:
+            for q in names:
+                if q:
+                    try:
+                        os.unlink(q)
+                    except OSError:
+                        pass
+
+    return [names[i] or p for i, p in enumerate(paths)], cleanup
+
+
 def init_from_env():
     """torchrun environment -> process group on this rank's GPU (no-op for a single process)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
