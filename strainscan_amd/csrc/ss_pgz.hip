@@ -388,6 +388,72 @@ static inline void resolve(const uint16_t *sy, uint64_t n, const uint8_t *w, uin
     for (; i < n; i++) { const uint16_t v = sy[i]; dst[i] = (v & UNRESOLVED) ? w[v & (WSIZE - 1)] : (uint8_t)v; }
 }
 
+// bgzip (BGZF) files: every member says how long it is (extra subfield 'B','C': BSIZE = member bytes - 1) and holds
+// at most 64 KB of text, so the members are independent work items with known places in the text.  zlib's raw
+// inflate per member, CRC-32 and ISIZE of every member checked.
+static bool bgzf_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len)
+{
+    struct Mem { uint64_t off, hdr, size, out_off; uint32_t isize, crc; };
+    std::vector<Mem> ms;
+    uint64_t pos = 0, total = 0;
+    while (pos < in_n) {
+        if (in_n - pos < 28) return false;
+        const uint8_t *h = in + pos;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+        const uint64_t xlen = (uint64_t)h[10] | (uint64_t)h[11] << 8;
+        if (12 + xlen > in_n - pos) return false;
+        uint64_t bsize = 0;
+        for (uint64_t x = 12; x + 4 <= 12 + xlen;) {          // subfields: SI1 SI2 SLEN(2) data
+            const uint64_t slen = (uint64_t)h[x + 2] | (uint64_t)h[x + 3] << 8;
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = ((uint64_t)h[x + 4] | (uint64_t)h[x + 5] << 8) + 1;
+            x += 4 + slen;
+        }
+        const uint64_t hl = gzip_header_len(h, in_n - pos);
+        if (!bsize || !hl || bsize < hl + 8 || bsize > in_n - pos) return false;
+        const uint8_t *t = h + bsize - 8;
+        Mem m;
+        m.off = pos; m.hdr = hl; m.size = bsize; m.out_off = total;
+        m.crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        m.isize = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        if (m.isize > (1u << 16)) return false;                 // BGZF blocks hold at most 64 KB
+        total += m.isize;
+        ms.push_back(m);
+        pos += bsize;
+    }
+    if (ms.empty() || total > budget) return false;
+    void *mem = nullptr;
+    const uint64_t cap = (std::max<uint64_t>(1, total) + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+    if (posix_memalign(&mem, 2u << 20, cap) != 0 || !mem) return false;
+    madvise(mem, cap, MADV_HUGEPAGE);
+    std::atomic<uint64_t> next(0);
+    std::atomic<bool> bad(false);
+    auto worker = [&] {
+        z_stream z;
+        memset(&z, 0, sizeof(z));
+        if (inflateInit2(&z, -15) != Z_OK) { bad = true; return; }
+        for (uint64_t i0; !bad && (i0 = next.fetch_add(64)) < ms.size();)
+            for (uint64_t i = i0; i < std::min<uint64_t>(ms.size(), i0 + 64); i++) {
+                const Mem &m = ms[i];
+                uint8_t *dst = (uint8_t *)mem + m.out_off;
+                inflateReset(&z);
+                z.next_in = const_cast<Bytef *>(in + m.off + m.hdr);
+                z.avail_in = (uInt)(m.size - m.hdr - 8);
+                z.next_out = dst;
+                z.avail_out = m.isize;
+                const int r = inflate(&z, Z_FINISH);
+                if ((r != Z_STREAM_END) || z.avail_out != 0 || z.avail_in != 0 || crc_of(dst, m.isize) != m.crc) { bad = true; break; }
+            }
+        inflateEnd(&z);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < std::max(1u, threads); t++) pool.emplace_back(worker);
+    for (auto &th : pool) th.join();
+    if (bad) { free(mem); return false; }
+    *text = (char *)mem;
+    *len = total;
+    return true;
+}
+
 // Inflate the gzip file image `in` with `threads` threads.  On success *text is a buffer of *len bytes to be
 // released with free().  false = not applicable or not verified: the caller uses another inflater.
 //
@@ -400,7 +466,7 @@ static inline void resolve(const uint16_t *sy, uint64_t n, const uint8_t *w, uin
 // Several members (lanes concatenated with `cat a.gz b.gz`): where a member ends is only known when its final
 // block has been decoded.  The chunk that meets it cancels the chunks after it (they were decoding the next
 // member's data ahead of time), the member's trailer is checked, and the pipeline starts again behind it.
-// Files of many small members (bgzip) are left to libdeflate.
+// bgzip (BGZF) files, thousands of <= 64 KB members with their size in the header, take bgzf_gunzip above.
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len,
                      const TextAlloc *ta)
 {
@@ -452,7 +518,11 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
         if (!hl) { drop_text(); return say("what follows a member is not a gzip header", mstart, members); }
         {   // bgzip: an extra field with a 'B','C' subfield; thousands of 64 KB members are not for this pipeline
             const uint8_t *h = in + mstart;
-            if ((h[3] & 4) && hl >= 18 && h[12] == 'B' && h[13] == 'C') { drop_text(); return say("bgzf", mstart); }
+            if ((h[3] & 4) && hl >= 18 && h[12] == 'B' && h[13] == 'C') {
+                drop_text();
+                if (mstart == 0 && !ta && bgzf_gunzip(in, in_n, threads, budget, text, len)) { say("ok, bgzf", *len); return true; }
+                return say("bgzf, not taken", mstart);
+            }
         }
         const uint64_t ds = mstart + hl;                 // first byte of deflate data of this member
         if (lim - ds < (2u << 20) && members > 0) { drop_text(); return say("small trailing member", lim - ds, members); }

@@ -188,6 +188,27 @@ def test_threaded_gunzip_equals_gzip(tmp_path):
         assert _lib.gz_inflate(str(p), 4, 1) is None, p
         got = _lib.gz_inflate(str(p), 4, 0)
         assert (got == data) if have_libdeflate else (got is None)
+    # bgzip (BGZF): members of <= 64 KB with their size in an extra field, an empty member at the end: inflated member
+    # by member in parallel; a block with a wrong CRC makes the file go elsewhere
+    def bgzf(data, level=6):
+        import struct
+        out = []
+        for a in list(range(0, len(data), 65280)) + [len(data)]:
+            blk = data[a:a + 65280] if a < len(data) else b""
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            raw = c.compress(blk) + c.flush()
+            out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(raw) + 25) + raw +
+                       struct.pack("<II", zlib.crc32(blk), len(blk)))
+        return b"".join(out)
+    bg = tmp_path / "reads.bgzf.gz"
+    bg.write_bytes(bgzf(fq))
+    assert gzip.decompress(bg.read_bytes()) == fq          # the writer above makes valid gzip
+    for threads in (2, 3):
+        assert _lib.gz_inflate(str(bg), threads, 1) == fq, threads
+    raw = bytearray(bg.read_bytes())
+    raw[len(raw) // 2] ^= 0x10
+    (tmp_path / "bad.bgzf.gz").write_bytes(bytes(raw))
+    assert _lib.gz_inflate(str(tmp_path / "bad.bgzf.gz"), 3, 1) is None
     # a damaged member is never accepted (CRC), a non-gzip file is declined
     bad = bytearray((tmp_path / "fq6.gz").read_bytes())
     bad[len(bad) // 2] ^= 0x5A
