@@ -39,7 +39,11 @@ __device__ __forceinline__ void load16(const uint8_t *__restrict__ bases, uint64
                                        uint32_t w[4])
 {
     if (ALIGNED && off + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(bases + off);
+        // non-temporal: the base stream is read exactly once, and 3 GB of it must not push the 4 MB Bloom filter (and the
+        // directory / bucket sectors, which do get re-used) out of L2: 3.45 vs 3.50 ms for 20 M reads
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(bases + off));
+        const uint4 v = make_uint4(q.x, q.y, q.z, q.w);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
     } else {
 #pragma unroll
