@@ -18,9 +18,12 @@ CHUNK = 1 << 26      # elements per all-reduce call (256 MiB of int32): bounded 
 
 
 def is_distributed():
-    try:
-        import torch.distributed as dist
-    except ImportError:
+    """A process group exists and has more than one rank.  A group can only have been created through
+    torch.distributed, so if that module is not loaded the answer is no -- WITHOUT importing torch (2.7 s in a
+    process whose whole identification takes 0.13 s)."""
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is None:
         return False
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 

@@ -12,7 +12,6 @@ import pickle
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
-import scipy.sparse as sp
 
 from . import l2 as L2
 
@@ -256,6 +255,7 @@ def _read_l2_cache(path):
     indptr, indices, data = take(np.int64, K + 1), take(np.int32, nnz), take(np.int8, nnz)
     if pos[0] != size or (K and int(indptr[K]) != nnz):
         raise ValueError("inconsistent cluster image")
+    import scipy.sparse as sp          # here, not at module load: a run without layer-2 clusters never pays for it
     om = sp.csr_matrix((np.array(data), np.array(indices), np.array(indptr)), shape=(K, ncls))
     return L2.ClusterImage.from_planes(planes, K, S), om
 
@@ -276,6 +276,7 @@ def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_co
     if img is None:
         # scipy reads the .npz through zipfile (inflate + CRC: ~7 ms per million non-zeros); done once per
         # database, the bit planes and the overlap arrays are then kept as a raw image
+        import scipy.sparse as sp
         img = L2.ClusterImage(sp.load_npz(input_csv))
         om = sp.load_npz(omatrix)
         if cache:

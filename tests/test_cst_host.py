@@ -5,6 +5,7 @@ the same code the GPU path runs, only its provider differs."""
 import json
 import os
 
+import numpy as np
 import pytest
 
 from tests import hostlogic as hl
@@ -70,3 +71,39 @@ def test_low_depth_ranks(sname, golden, l1_dbs, l1_reads):
     assert [a for a, _ in got] == [a for a, _ in want["result"]]
     for (a, b), (_, wb) in zip(got, want["result"]):
         assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+
+
+def test_binom_sf_without_scipy(golden_dir):
+    """cst.binom_sf (a direct sum in numpy, no scipy in the product path) against the table recorded from
+    scipy.stats.binom.sf and against scipy.stats itself: values within 1e-11, the same `1 - sf < 0.05` decision for
+    every pair of depths tried (all pairs up to 400, a random sample up to 200000), and -- from scipy's own values
+    over ALL pairs up to 3000 -- no pair closer to the threshold than 1e-9, ten thousand times the error bound."""
+    import scipy.stats as st
+    from strainscan_amd import cst
+    t = np.load(os.path.join(golden_dir, "binom_table.npz"))
+    tab = t["table"]
+    for x in range(61):
+        for y in range(61):
+            assert abs((1 - cst.binom_sf(max(x, y), x + y, 0.995)) - tab[x, y]) < 1e-12
+    for x, y, v in t["big"]:
+        assert abs((1 - cst.binom_sf(max(int(x), int(y)), int(x + y), 0.995)) - v) < 1e-11
+    assert cst.binom_sf(-1, 5, 0.995) == 1.0 == st.binom.sf(-1, 5, 0.995)
+    assert cst.binom_sf(5, 5, 0.995) == 0.0 == st.binom.sf(5, 5, 0.995)
+    assert cst.binom_sf(0, 0, 0.995) == 0.0 == st.binom.sf(0, 0, 0.995)
+    rs = np.random.RandomState(8)
+    pairs = [(x, y) for x in range(0, 401) for y in range(0, x + 1, 3)]
+    big_x = rs.randint(0, 200000, size=4000)
+    pairs += [(int(x), int(rs.randint(0, min(x, 4000) + 1))) for x in big_x]
+    pairs += [(1000000, 4800), (1000000, 5200), (50000, 50000), (7, 0), (0, 0)]
+    for x, y in pairs:
+        a = 1.0 - cst.binom_sf(max(x, y), x + y, 0.995)
+        b = 1.0 - float(st.binom.sf(max(x, y), x + y, 0.995))
+        assert abs(a - b) < 1e-11, (x, y, a, b)
+        assert (a < 0.05) == (b < 0.05), (x, y)
+    xs = np.arange(0, 3001)
+    worst = 1.0
+    for y in range(0, 3001):
+        x = xs[y:]
+        b = 1.0 - st.binom.sf(x, x + y, 0.995)
+        worst = min(worst, float(np.abs(b - 0.05).min()))
+    assert worst > 1e-9, worst
