@@ -125,8 +125,15 @@ hipStream_t ingest_stream(unsigned i)
     static hipStream_t pool[N_INGEST_STREAMS];
     static std::once_flag once;
     std::call_once(once, [] {
+        int device = 0;
+        hipGetDevice(&device);
+        std::vector<std::thread> th;                      // ~13 ms each: at the same time rather than one after another
         for (auto &st : pool)
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+            th.emplace_back([&st, device] {
+                hipSetDevice(device);
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+            });
+        for (auto &t : th) t.join();
     });
     return pool[i % N_INGEST_STREAMS];
 }
