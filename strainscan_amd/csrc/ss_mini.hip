@@ -47,6 +47,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -611,6 +612,11 @@ namespace ss {
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys)
 {
     const int k = db->k;
+    static const bool trace = getenv("SS_BUILD_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[build] %-28s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     constexpr int PB = 8, NP = 1 << PB;
     unsigned nthreads = std::min<unsigned>(ss::host_cpus(), 32u);
     // 1. entries of valid rows with their minimizer
@@ -626,6 +632,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
                 ents[pos[i]] = Ent{mx, (uint32_t)i, keys[i], o, dir_mix(mx) >> (32 - PB)};
             }
     });
+    lap("1 minimizers");
     // 2. counting partition on 8 mixed bits of the minimizer, then per-partition sort
     std::vector<uint64_t> pcount(NP + 1, 0);
     for (uint64_t i = 0; i < nv; i++) pcount[ents[i].part + 1]++;
@@ -651,53 +658,85 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
             });
         for (auto &th : pool) th.join();
     }
+    lap("2 partition + sort");
     // 3. distinct k-mers, buckets (header + entries), row bookkeeping (dict overwrite: the last
-    //    allowed row owns the count)
-    std::vector<uint64_t> mkeys;
-    mkeys.reserve(nv + nv / 4 + 2);
+    //    allowed row owns the count).  A minimizer lives in one partition, so the partitions are independent:
+    //    count their slots and buckets, prefix-sum, fill in parallel (same order as a serial walk: the image
+    //    does not depend on the thread count)
+    struct Bkt { uint32_t first, second, hdr; };         // minimizer (m-mer), header slot, offset mask | multi
+    std::vector<uint64_t> p_slots(NP + 1, 0), p_bkts(NP + 1, 0);
+    auto for_partitions = [&](const std::function<void(int)> &fn) {
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nthreads; w++)
+            pool.emplace_back([&] { for (int p; (p = next.fetch_add(1)) < NP;) fn(p); });
+        for (auto &th : pool) th.join();
+    };
+    for_partitions([&](int p) {
+        uint64_t nb = 0, nd = 0;
+        for (uint64_t i = pcount[p]; i < pcount[p + 1];) {
+            uint64_t e = i;
+            while (e < pcount[p + 1] && sorted[e].mini == sorted[i].mini) e++;
+            nb++;
+            for (uint64_t a2 = i; a2 < e;) {
+                uint64_t b2 = a2;
+                while (b2 < e && sorted[b2].key == sorted[a2].key) b2++;
+                nd++;
+                a2 = b2;
+            }
+            i = e;
+        }
+        p_slots[p + 1] = nd + nb;
+        p_bkts[p + 1] = nb;
+    });
+    for (int p = 0; p < NP; p++) { p_slots[p + 1] += p_slots[p]; p_bkts[p + 1] += p_bkts[p]; }
+    if (p_slots[NP] >= 0x7FFFFFF0ull) return SS_ERANGE;
+    std::vector<uint64_t> mkeys(p_slots[NP]);
+    std::vector<Bkt> buckets(p_bkts[NP]);
     std::vector<uint32_t> slot_of_row(std::max<uint64_t>(1, n_rows), SS_NO_SLOT);
     std::vector<uint8_t> row_valid(std::max<uint64_t>(1, n_rows), 0);
-    struct Bkt { uint32_t first, second, hdr; };         // minimizer (m-mer), header slot, offset mask | multi
-    std::vector<Bkt> buckets;
-    uint64_t orphans = 0, n_distinct = 0;
-    for (uint64_t i = 0; i < nv;) {
-        // one bucket = all entries with this minimizer
-        uint64_t e = i;
-        while (e < nv && sorted[e].mini == sorted[i].mini) e++;
-        const uint32_t hslot = (uint32_t)mkeys.size();
-        buckets.push_back(Bkt{sorted[i].mini, hslot, 0});
-        mkeys.push_back(0);
-        uint32_t mask = 0, multi = 0, cnt = 0;
-        for (uint64_t a = i; a < e;) {
-            uint64_t b = a;
-            int64_t owner = -1;
-            while (b < e && sorted[b].key == sorted[a].key) {
-                const uint32_t r = sorted[b].row;
-                if (upper_keys == 1 || !(flags[r] & SS_ROW_LOWER)) owner = r;   // rows ascend within equal k-mers
-                b++;
+    std::atomic<uint64_t> orphans_a(0);
+    for_partitions([&](int p) {
+        uint64_t ms = p_slots[p], bi = p_bkts[p], orph = 0;
+        for (uint64_t i = pcount[p]; i < pcount[p + 1];) {
+            // one bucket = all entries with this minimizer
+            uint64_t e = i;
+            while (e < pcount[p + 1] && sorted[e].mini == sorted[i].mini) e++;
+            const uint32_t hslot = (uint32_t)ms++;
+            uint32_t mask = 0, multi = 0, cnt = 0;
+            for (uint64_t a2 = i; a2 < e;) {
+                uint64_t b2 = a2;
+                int64_t owner = -1;
+                while (b2 < e && sorted[b2].key == sorted[a2].key) {
+                    const uint32_t r = sorted[b2].row;
+                    if (upper_keys == 1 || !(flags[r] & SS_ROW_LOWER)) owner = r;   // rows ascend within equal k-mers
+                    b2++;
+                }
+                const uint32_t o = sorted[a2].off;
+                if ((mask >> o) & 1u) multi = HDR_MULTI;
+                mask |= 1u << o;
+                const uint32_t slot = (uint32_t)ms;
+                mkeys[ms++] = sorted[a2].key;
+                for (uint64_t q = a2; q < b2; q++) slot_of_row[sorted[q].row] = slot;
+                if (owner >= 0) row_valid[owner] = 1;
+                else orph++;
+                cnt++;
+                a2 = b2;
             }
-            const uint32_t o = sorted[a].off;
-            if ((mask >> o) & 1u) multi = HDR_MULTI;
-            mask |= 1u << o;
-            const uint32_t slot = (uint32_t)mkeys.size();
-            mkeys.push_back(sorted[a].key);
-            for (uint64_t q = a; q < b; q++) slot_of_row[sorted[q].row] = slot;
-            if (owner >= 0) row_valid[owner] = 1;
-            else orphans++;
-            cnt++;
-            n_distinct++;
-            a = b;
+            mkeys[hslot] = ((uint64_t)cnt << 32) | multi | mask;
+            buckets[bi++] = Bkt{sorted[i].mini, hslot, multi | mask};
+            i = e;
         }
-        mkeys[hslot] = ((uint64_t)cnt << 32) | multi | mask;
-        buckets.back().hdr = multi | mask;
-        i = e;
-    }
+        orphans_a += orph;
+    });
+    const uint64_t orphans = orphans_a.load(), n_distinct = p_slots[NP] - p_bkts[NP];
     sorted.clear();
     sorted.shrink_to_fit();
     if (orphans && upper_keys == 0) return SS_EKEY;
     if (mkeys.size() >= 0xFFFFFFF0ull) return SS_ERANGE;
     db->n_distinct = n_distinct;
     db->n_slots = std::max<uint64_t>(1, mkeys.size());
+    lap("3 buckets");
     // cuckoo directory of 2-entry buckets, ~0.67 keys per bucket (1/3 load).  Keys prefer their first
     // bucket; a key that ends up in its second bucket sets DIR_MOVED on its first one.
     if (mkeys.size() >= 0x7FFFFFF0ull) return SS_ERANGE;
@@ -744,6 +783,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     db->dirbits = dirbits;
     db->n_buckets = buckets.size();
     db->capacity = db->n_slots;
+    lap("cuckoo directory");
     // 4. upload
     const uint64_t nr = std::max<uint64_t>(1, n_rows);
     SS_HIP(hipMalloc((void **)&db->d_mkeys, db->n_slots * sizeof(uint64_t)));
@@ -779,6 +819,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     }
     SS_HIP(hipMemcpy(db->d_slot_of_row, slot_of_row.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
     SS_HIP(hipMemcpy(db->d_row_valid, row_valid.data(), nr, hipMemcpyHostToDevice));
+    lap("4 bloom + upload");
     return SS_OK;
 }
 
