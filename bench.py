@@ -42,43 +42,91 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_db(torch, dev, n_leaves, seed, lo_sites=500, hi_sites=15000):
-    """Node-private random sequences -> k-mer rows (forward, reverse complement adjacent).
-    Returns keys (device-convention uint64, numpy), oracle-convention keys, node row lists
-    (offsets), the per-node code tensors and the tree parent array."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    n_nodes = 2 * n_leaves - 1
-    rs = np.random.RandomState(seed)
-    sites = rs.randint(lo_sites, hi_sites + 1, size=n_nodes).astype(np.int64)
-    seq_len = sites + K - 1
-    seq_off = np.concatenate([[0], np.cumsum(seq_len)])
-    total = int(seq_off[-1])
-    codes = torch.randint(0, 4, (total,), generator=g, device=dev, dtype=torch.int64)
-    n_sites = int(sites.sum())
-    # start offsets of every site in the concatenated code stream
-    site_node = np.repeat(np.arange(n_nodes), sites)
-    site_pos = np.arange(n_sites) - np.repeat(np.concatenate([[0], np.cumsum(sites)[:-1]]), sites)
-    start = torch.from_numpy(seq_off[site_node] + site_pos).to(dev)
-    key = torch.zeros(n_sites, dtype=torch.int64, device=dev)
-    rc = torch.zeros(n_sites, dtype=torch.int64, device=dev)
-    okey = torch.zeros(n_sites, dtype=torch.int64, device=dev)   # oracle convention
-    orc_ = torch.zeros(n_sites, dtype=torch.int64, device=dev)
-    # device code: A0 C1 T2 G3 (first base LSB); oracle code: A0 C1 G2 T3 (first base MSB)
+def _kmer_keys(torch, codes, start, dev):
+    """device-convention keys (A0 C1 T2 G3, first base LSB) and oracle-convention keys (A0 C1 G2 T3, first base
+    MSB) of the k-mers starting at `start`, and of their reverse complements"""
+    n = start.numel()
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    rc = torch.zeros(n, dtype=torch.int64, device=dev)
+    okey = torch.zeros(n, dtype=torch.int64, device=dev)
+    orc_ = torch.zeros(n, dtype=torch.int64, device=dev)
     to_or = torch.tensor([0, 1, 3, 2], device=dev, dtype=torch.int64)
     for j in range(K):
-        cj = codes[start + j]
+        cj = codes[start + j].to(torch.int64)
         key |= cj << (2 * j)
         rc |= (cj ^ 2) << (2 * (K - 1 - j))
         oj = to_or[cj]
         okey |= oj << (2 * (K - 1 - j))
         orc_ |= (3 - oj) << (2 * j)
-    keys = torch.stack([key, rc], 1).reshape(-1).cpu().numpy().view(np.uint64)
-    okeys = torch.stack([okey, orc_], 1).reshape(-1).cpu().numpy().view(np.uint64)
-    row_off = np.concatenate([[0], np.cumsum(2 * sites)]).astype(np.uint64)
+    return key, rc, okey, orc_
+
+
+def make_db(torch, dev, n_leaves, seed, lo_sites=500, hi_sites=15000, shape="contiguous", hit_frac=0.05):
+    """Node-private random sequences -> k-mer rows.  Two shapes of the node sets:
+
+    contiguous  every k-mer of the node's stretch, forward and reverse complement adjacent in kmer.fa (a node
+                whose unique set is below the builder's cap keeps all of it: Build_tree.py:586-596)
+    sampled     what the builder writes for a node ABOVE its cap (Build_tree.py:590-591:
+                `kmer_t = set(random.sample(kmer_t, maxsize))`): a uniform random subset -- density 1-10 % --
+                of the (k-mer, orientation) entries of a stretch 10-100x longer; forward and reverse-complement
+                entries are separate ids there (Build_tree.py:101-110) and are drawn independently; kmer.fa
+                is written in set order (Build_tree.py:677-684), so a node's rows are scattered over the file.
+
+    Returns keys (device-convention uint64, numpy), oracle-convention keys, node row lists (rows, row_off),
+    the stretch code tensor + offsets (the reads are cut from them) and the node count."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n_nodes = 2 * n_leaves - 1
+    rs = np.random.RandomState(seed)
+    sites = rs.randint(lo_sites, hi_sites + 1, size=n_nodes).astype(np.int64)   # rows per orientation
+    if shape == "contiguous":
+        stretch = sites
+    else:
+        dens = np.minimum(1.0, rs.uniform(0.3, 2.0, size=n_nodes) * max(hit_frac, 0.025))
+        stretch = np.ceil(sites / dens).astype(np.int64)
+    seq_len = stretch + K - 1
+    seq_off = np.concatenate([[0], np.cumsum(seq_len)])
+    total = int(seq_off[-1])
+    codes = torch.randint(0, 4, (total,), generator=g, device=dev, dtype=torch.uint8)
+    st_off = np.concatenate([[0], np.cumsum(stretch)])
+    n_st = int(st_off[-1])
+    if shape == "contiguous":
+        site_node = np.repeat(np.arange(n_nodes), sites)
+        site_pos = np.arange(n_st) - np.repeat(st_off[:-1], sites)
+        start = torch.from_numpy(seq_off[site_node] + site_pos).to(dev)
+        key, rc, okey, orc_ = _kmer_keys(torch, codes, start, dev)
+        keys = torch.stack([key, rc], 1).reshape(-1).cpu().numpy().view(np.uint64)
+        okeys = torch.stack([okey, orc_], 1).reshape(-1).cpu().numpy().view(np.uint64)
+        row_off = np.concatenate([[0], np.cumsum(2 * sites)]).astype(np.uint64)
+        rows = np.arange(keys.size, dtype=np.uint32)
+    else:
+        # Bernoulli(density) per (site, orientation): a uniform random subset, ~sites[i] rows per orientation
+        node_of_site = torch.from_numpy(np.repeat(np.arange(n_nodes), stretch)).to(dev)
+        d_site = torch.from_numpy(dens.astype(np.float32)).to(dev)[node_of_site]
+        base = torch.from_numpy(seq_off[:-1] - st_off[:-1]).to(dev)[node_of_site] + torch.arange(n_st, device=dev)
+        parts_k, parts_o, parts_n = [], [], []
+        for orient in (0, 1):
+            sel = torch.nonzero(torch.rand(n_st, generator=g, device=dev) < d_site).squeeze(1)
+            key, rc, okey, orc_ = _kmer_keys(torch, codes, base[sel], dev)
+            parts_k.append(rc if orient else key)
+            parts_o.append(orc_ if orient else okey)
+            parts_n.append(node_of_site[sel])
+        k_all, o_all, n_all = torch.cat(parts_k), torch.cat(parts_o), torch.cat(parts_n)
+        order = torch.argsort(n_all, stable=True)                       # node-major
+        perm = torch.randperm(k_all.numel(), generator=g, device=dev)   # node-major position -> kmer.fa row
+        keys_t = torch.empty_like(k_all)
+        okeys_t = torch.empty_like(o_all)
+        keys_t[perm] = k_all[order]
+        okeys_t[perm] = o_all[order]
+        keys = keys_t.cpu().numpy().view(np.uint64)
+        okeys = okeys_t.cpu().numpy().view(np.uint64)
+        rows = perm.cpu().numpy().astype(np.uint32)
+        per_node = np.bincount(n_all.cpu().numpy(), minlength=n_nodes)
+        row_off = np.concatenate([[0], np.cumsum(per_node)]).astype(np.uint64)
+        del node_of_site, d_site, base, k_all, o_all, n_all, keys_t, okeys_t
     # balanced binary tree in heap order: node 0 root, children 2i+1, 2i+2; leaves are the last n_leaves
-    return dict(keys=keys, okeys=okeys, row_off=row_off, sites=sites, seq_off=seq_off, codes=codes,
-                n_nodes=n_nodes)
+    return dict(keys=keys, okeys=okeys, rows=rows, row_off=row_off, sites=sites, seq_off=seq_off, codes=codes,
+                n_nodes=n_nodes, shape=shape)
 
 
 def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
@@ -101,8 +149,9 @@ def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
             i = (i - 1) // 2
         parts = [db["codes"][int(db["seq_off"][p]):int(db["seq_off"][p + 1])] for p in path[::-1]]
         core = torch.cat(parts)
-        filler = torch.randint(0, 4, (int(core.numel() * (1.0 / hit_frac - 1.0)),), generator=g, device=dev,
-                               dtype=torch.int64)
+        n_db = sum(int(db["sites"][p]) for p in path)                 # database k-mers per orientation on the path
+        n_fill = max(0, int(n_db / hit_frac) - int(core.numel()))
+        filler = torch.randint(0, 4, (n_fill,), generator=g, device=dev, dtype=torch.uint8)
         # interleave core pieces into the filler so hits are spread over the genome
         chunks = list(torch.tensor_split(filler, len(parts)))
         genomes.append(torch.cat([x for pair in zip(chunks, parts) for x in pair]))
@@ -122,10 +171,10 @@ def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
             st = torch.randint(0, gen.numel() - READ_LEN, (m,), generator=g, device=dev)
             c = gen[st[:, None] + ar[None, :]]
             err = torch.rand((m, READ_LEN), generator=g, device=dev) < 0.005
-            c = torch.where(err, torch.randint(0, 4, (m, READ_LEN), generator=g, device=dev), c)
+            c = torch.where(err, torch.randint(0, 4, (m, READ_LEN), generator=g, device=dev, dtype=torch.uint8), c)
             rev = torch.rand((m,), generator=g, device=dev) < 0.5
             c = torch.where(rev[:, None], c.flip(1) ^ 2, c)
-            view[row:row + m, :READ_LEN] = asc[c]
+            view[row:row + m, :READ_LEN] = asc[c.long()]
             row += m
             done += m
     view[:, READ_LEN] = 10
@@ -135,12 +184,7 @@ def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
     return out
 
 
-def main():
-    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on the C stdout of every rank
-    # (flushed at exit): keep the real stdout aside for the JSON line and point fd 1 at stderr for everything else.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -148,19 +192,65 @@ def main():
     ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU (10 M pairs)")
     ap.add_argument("--leaves", type=int, default=823)
     ap.add_argument("--hit-frac", type=float, default=0.05)
+    ap.add_argument("--db-shape", choices=("sampled", "contiguous"), default="sampled",
+                    help="node k-mer sets: a random 1-10 %% sample of a longer stretch, rows scattered over kmer.fa "
+                         "(what Build_tree.py:590-591 writes for a node above its cap) or every k-mer of a stretch")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phases", action="store_true", help="skip the untimed phase breakdown (text -> HBM, walk)")
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL
+    rendezvous on 127.0.0.1) BEFORE this process has touched torch or HIP, relay rank 0's JSON line and
+    exit with the worst return code.  Nothing is exec'ed: the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, argv))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner on the C stdout of every rank
+    # (flushed at exit): keep the real stdout aside for the JSON line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("SS_BENCH_WORKER_STUB"):     # tests/test_abi_and_host.py: argument handling up to here, no GPU
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(dict(stub=True, n_gpus=world, rank=rank, local_rank=local,
+                                                   master=os.environ.get("MASTER_ADDR"), argv=list(argv))) + "\n").encode())
+        return
 
     import torch
     import torch.distributed as dist
     from strainscan_amd import _lib
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to time")
     torch.cuda.set_device(local)
@@ -173,13 +263,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        world = dist.get_world_size()
 
     t0 = time.time()
-    db_spec = make_db(torch, dev, args.leaves, seed=20231013)
+    db_spec = make_db(torch, dev, args.leaves, seed=20231013, shape=args.db_shape, hit_frac=args.hit_frac)
     n_rows = db_spec["keys"].size
     db = _lib.KmerDB(db_spec["keys"], np.ones(n_rows, np.uint8), K, True)
     info = db.info()
-    rows = np.arange(n_rows, dtype=np.uint32)
+    rows = db_spec["rows"]
     nodes = _lib.NodeSet.__new__(_lib.NodeSet)
     import ctypes as C
     h = C.c_void_p()
@@ -320,7 +413,8 @@ def main():
                    dtype="u64", data="synthetic",
                    config=dict(workload="E. coli 1433-strain/823-cluster DB, 10M synthetic 150 bp PE reads (20M reads) per GPU",
                                db_rows=int(n_rows), tree_nodes=int(db_spec["n_nodes"]), reads_per_gpu=args.reads,
-                               read_len=READ_LEN, k=K, hit_frac=args.hit_frac, table_slots=int(info["capacity"]),
+                               read_len=READ_LEN, k=K, hit_frac=args.hit_frac, db_shape=args.db_shape,
+                               table_slots=int(info["capacity"]), minimizer_buckets=int(info.get("n_buckets", 0)),
                                table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
                    roofline=roofline, cpu_baseline=cpu,

@@ -125,6 +125,10 @@ int ss_db_import(const char *path, ss_db **out);
 int ss_db_row_valid(const ss_db *db, uint8_t *row_valid);
 const uint8_t *ss_db_row_valid_dev(const ss_db *db);
 uint64_t ss_db_device_bytes(const ss_db *db);
+/* Shape of the built index, for benchmarks and logs (no reference counterpart: jellyfish prints nothing):
+ * out[0] layout (0 flat table, 1 minimizer buckets), [1] count slots, [2] minimizer buckets,
+ * [3] directory buckets, [4] log2 of the filter size in bits (0 = none), [5] distinct k-mers, [6..7] 0. */
+int ss_db_index_info(const ss_db *db, uint64_t out[8]);
 
 /* --------------------------------------------------------------------------------------------
  * The scan  (the `jellyfish count` + `dump -c` pair of identify.py:82-87,

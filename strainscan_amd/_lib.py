@@ -72,6 +72,7 @@ SIGNATURES = {
     "ss_db_row_valid": (i32, [vp, vp]),
     "ss_db_row_valid_dev": (vp, [vp]),
     "ss_db_device_bytes": (u64, [vp]),
+    "ss_db_index_info": (i32, [vp, vp]),
     "ss_scan_reset": (i32, [vp, vp]),
     "ss_scan_flat_dev": (i32, [vp, vp, u64, vp]),
     "ss_scan_flat_host": (i32, [vp, cp, u64]),
@@ -239,8 +240,11 @@ class KmerDB:
     def info(self):
         a, b, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
         check(lib().ss_db_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(k)), "ss_db_info")
+        ix = np.zeros(8, np.uint64)
+        check(lib().ss_db_index_info(self._h, ptr(ix)), "ss_db_index_info")
         return dict(n_rows=a.value, n_distinct=b.value, capacity=c.value, k=k.value,
-                    device_bytes=int(lib().ss_db_device_bytes(self._h)))
+                    device_bytes=int(lib().ss_db_device_bytes(self._h)), layout=int(ix[0]), n_slots=int(ix[1]),
+                    n_buckets=int(ix[2]), n_dir=int(ix[3]), filter_bits=int(ix[4]))
 
     @property
     def row_valid(self):
