@@ -104,10 +104,14 @@ def read_tree_structure(db_dir):
     with open(os.path.join(db_dir, "tree_structure.txt"), "r") as f:
         lines = f.readlines()
     if len(lines) == 1:
-        # identify.py:19-21 unpickles a treelib.Tree from tree.pkl here; treelib is a third-party
-        # dependency of the reference that this package does not carry.
-        raise NotImplementedError(
-            "single-cluster database (%s/tree.pkl is a pickled treelib.Tree): not supported" % db_dir)
+        # single-cluster database (Build_tree.py:283-334): identify.py:19-21 unpickles a treelib.Tree from
+        # tree.pkl and returns it with an empty GCF
+        pkl = os.path.join(db_dir, "tree.pkl")
+        if os.path.exists(pkl):
+            return load_tree_pkl(pkl), GCF
+        tree = Tree()                     # the file the builder pickled holds exactly this node (Build_tree.py:284-286)
+        tree.create_node(int(lines[0].split("\t")[0]))
+        return tree, GCF
     tree = Tree()
     if lines[-1].split("\t")[1] != "N":
         i = 0
@@ -126,3 +130,97 @@ def read_tree_structure(db_dir):
         if len(t) == 4:
             GCF[tree.get_node(int(t[0]))] = t[3]
     return tree, GCF
+
+
+class _PickledObject:
+    """Stands in for treelib.tree.Tree / treelib.node.Node while tree.pkl is read: keeps the pickled
+    attribute dict, nothing else."""
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2:            # (dict state, slots state)
+            state = dict(state[0] or {}, **(state[1] or {}))
+        self.state = dict(state)
+
+
+class _PickledTree(_PickledObject):
+    pass
+
+
+class _PickledNode(_PickledObject):
+    pass
+
+
+def load_tree_pkl(path):
+    """tree.pkl of a single-cluster database: `pkl.dump(tree, ...)` of a treelib.Tree (Build_tree.py:329),
+    read back by identify.py:19-21.  treelib is a dependency of the reference that this package does not
+    carry, so the pickle is read with a restricted Unpickler -- only treelib's Tree and Node classes
+    (mapped onto attribute bags) and collections.defaultdict / OrderedDict are admitted, nothing else in the
+    file can name a callable -- and turned into this module's Tree: nodes in the pickled dict's order
+    (= creation order), children in the order of the successor lists.  Understands the attribute layout of
+    treelib >= 1.6 (_predecessor / _successors keyed by tree id; the reference pins 1.6.1) and of treelib
+    <= 1.5 (_bpointer / _fpointer)."""
+    import collections
+    import pickle
+
+    class _Restricted(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] == "treelib" and name == "Tree":
+                return _PickledTree
+            if module.split(".")[0] == "treelib" and name == "Node":
+                return _PickledNode
+            if module == "collections" and name in ("defaultdict", "OrderedDict"):
+                return getattr(collections, name)
+            if module in ("builtins", "__builtin__") and name in ("list", "dict", "set", "int", "str", "object"):
+                return {"list": list, "dict": dict, "set": set, "int": int, "str": str, "object": object}[name]
+            if module in ("copy_reg", "copyreg") and name == "_reconstructor":
+                import copyreg
+                return copyreg._reconstructor
+            raise pickle.UnpicklingError("tree.pkl: %s.%s is not part of a pickled treelib.Tree" % (module, name))
+
+    with open(path, "rb") as f:
+        obj = _Restricted(f).load()
+    if not isinstance(obj, _PickledTree) or "_nodes" not in obj.state:
+        raise ValueError("%s does not hold a treelib.Tree" % path)
+    tid = obj.state.get("_identifier")
+    raw = obj.state["_nodes"]
+
+    def links(st):
+        if "_successors" in st:                                     # treelib >= 1.6
+            succ = st["_successors"]
+            pred = st.get("_predecessor", {})
+            ch = succ.get(tid) if tid in succ else (list(succ.values())[0] if len(succ) == 1 else [])
+            par = pred.get(tid) if tid in pred else (list(pred.values())[0] if len(pred) == 1 else None)
+            return par, list(ch or [])
+        return st.get("_bpointer"), list(st.get("_fpointer") or [])  # treelib <= 1.5
+
+    info = {}
+    for nid, n in raw.items():
+        if not isinstance(n, _PickledNode):
+            raise ValueError("%s: node %r is not a treelib.Node" % (path, nid))
+        info[nid] = links(n.state)
+    tree = Tree()
+    root = obj.state.get("root")
+    order = list(raw)
+    if root in info and order and order[0] != root:                  # parents are created before their children
+        order.remove(root)
+        order.insert(0, root)
+    pending = list(order)
+    while pending:
+        rest = []
+        for nid in pending:
+            par = info[nid][0]
+            if nid == root or par is None:
+                tree.create_node(nid)
+            elif tree.get_node(par) is not None:
+                tree.create_node(nid, parent=par)
+            else:
+                rest.append(nid)
+        if len(rest) == len(pending):
+            raise ValueError("%s: nodes without a path to the root: %r" % (path, rest))
+        pending = rest
+    for nid, (_, ch) in info.items():                                # children in the successor lists' order
+        node = tree[nid]
+        by_id = {c.identifier: c for c in node.children}
+        if sorted(by_id, key=repr) == sorted(ch, key=repr):
+            node.children = [by_id[c] for c in ch]
+    return tree

@@ -73,6 +73,10 @@ L1_DBS = {
     # two-leaf tree: root is the LAST line of tree_structure.txt -> reversed() creation order
     "C": dict(parent={1: 3, 2: 3, 3: None}, sites={1: 1600, 2: 1700, 3: 1500}, seed=13,
               singleton={1: "GCF_ONLY1"}, clusters={2: ["GCF_T1", "GCF_T2"]}, reconstructed=[], overlaps=[]),
+    # single-cluster database (Build_tree.py:283-375): tree_structure.txt is "<id>\t" and the tree is in tree.pkl
+    # (a pickled treelib.Tree, identify.py:19-21); the one node is root and leaf at once
+    "D": dict(parent={1: None}, sites={1: 2600}, seed=14, singleton={}, clusters={1: ["GCF_U1", "GCF_U2", "GCF_U3"]},
+              reconstructed=[], overlaps=[], single_cluster=True),
 }
 
 # samples: name -> (db, [(leaf or ('path', node) or ('random', length), depth)], read seed)
@@ -86,6 +90,9 @@ L1_SAMPLES = {
     "A_novel": ("A", [(("path", 9), 15.0)], 207),
     "B_mix": ("B", [(3, 12.0), (4, 6.0), (2, 9.0), (5, 4.0)], 211),
     "C_two": ("C", [(1, 10.0), (2, 3.0)], 221),
+    "D_one": ("D", [(1, 9.0)], 231),
+    "D_low": ("D", [(1, 0.5)], 232),
+    "D_none": ("D", [(("random", 40000), 5.0)], 233),
 }
 
 CUTOFFS = [[0.1, 0.4, 1], [0.05, 0.05, 1], [0.01, 0.05, 1], [0.005, 0.01, 1]]   # StrainScan.py:196-216
@@ -96,7 +103,8 @@ def build_l1(name, root_dir):
     spec = L1_DBS[name]
     db_dir = os.path.join(root_dir, "DB_" + name)
     info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["seed"], spec.get("singleton"),
-                             spec.get("clusters"), spec.get("reconstructed", ()), spec.get("overlaps", ()))
+                             spec.get("clusters"), spec.get("reconstructed", ()), spec.get("overlaps", ()),
+                             single_cluster=spec.get("single_cluster", False))
     info["db_dir"] = db_dir
     return info
 

@@ -60,8 +60,46 @@ class Tree:
         return p[::-1]
 
 
+def treelib_pickle(parent, protocol=None):
+    """Bytes of `pickle.dump(tree)` for a treelib 1.6.1 Tree with the given parent map, written WITHOUT treelib
+    (absent from the image): classes named treelib.tree.Tree / treelib.node.Node carrying 1.6.1's attribute
+    layout (tests/golden/_standin/treelib mirrors the same layout, so the reference run under the stand-in
+    reads these bytes too).  Build_tree.py:283-329 pickles a one-node tree for a single-cluster database."""
+    import sys
+    import types
+    from collections import defaultdict
+    mods = {n: types.ModuleType(n) for n in ("treelib", "treelib.tree", "treelib.node")}
+    Node = type("Node", (object,), {"__module__": "treelib.node"})
+    TreeC = type("Tree", (object,), {"__module__": "treelib.tree"})
+    mods["treelib.node"].Node = Node
+    mods["treelib.tree"].Tree = TreeC
+    tid = "8a4d5e6e-5f7d-11ee-b3a1-0242ac110002"          # uuid1 string in treelib; any hashable works
+    ids = sorted(parent, key=lambda i: (parent[i] is not None, i))
+    nodes = {}
+    for i in ids:
+        n = Node()
+        n.__dict__.update(_identifier=i, _tag=i, expanded=True, _predecessor={tid: parent[i]},
+                          _successors=defaultdict(list), data=None, _initial_tree_id=tid)
+        nodes[i] = n
+    for i in ids:
+        if parent[i] is not None:
+            nodes[parent[i]]._successors[tid].append(i)
+    t = TreeC()
+    t.__dict__.update(_identifier=tid, _nodes=nodes, root=[i for i in ids if parent[i] is None][0])
+    saved = {n: sys.modules.get(n) for n in mods}
+    sys.modules.update(mods)
+    try:
+        return pickle.dumps(t, protocol) if protocol is not None else pickle.dumps(t)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                del sys.modules[n]
+            else:
+                sys.modules[n] = m
+
+
 def build_l1_db(db_dir, parent, sites, seed, singleton=None, clusters=None, reconstructed=(),
-                overlaps=(), extra_rows=()):
+                overlaps=(), extra_rows=(), single_cluster=False):
     """Write <db_dir>/Tree_database.  Returns dict(tree, node_seq, leaf_genome, row_of_node).
 
     parent        {id: parent or None}; leaves must be 1..C, the root C+1, internal ids so that
@@ -111,10 +149,16 @@ def build_l1_db(db_dir, parent, sites, seed, singleton=None, clusters=None, reco
     with open(os.path.join(tdir, "kmer.fa"), "wb") as f:
         f.write(b"".join(b">1\n" + km + b"\n" for km in rows))
     with open(os.path.join(tdir, "tree_structure.txt"), "w") as f:
-        for i in T.ids:
-            par = "N" if parent[i] is None else str(parent[i])
-            ch = "N" if not T.children[i] else " ".join(map(str, T.children[i]))
-            f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, singleton.get(i, "")))
+        if single_cluster:                              # Build_tree.py:329-334: "<id>\t", no newline, + tree.pkl
+            assert len(T.ids) == 1
+            f.write("%d\t" % T.ids[0])
+            with open(os.path.join(tdir, "tree.pkl"), "wb") as fp:
+                fp.write(treelib_pickle(parent))
+        else:
+            for i in T.ids:
+                par = "N" if parent[i] is None else str(parent[i])
+                ch = "N" if not T.children[i] else " ".join(map(str, T.children[i]))
+                f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, singleton.get(i, "")))
     with open(os.path.join(tdir, "node_length.txt"), "w") as f:
         for i in T.ids:
             f.write("%d\t%d\n" % (i, len(row_of_node[i])))

@@ -366,3 +366,46 @@ def test_tree_image_cache_roundtrip(l1_dbs, tmp_path, monkeypatch):
     monkeypatch.setenv("SS_IMAGE_CACHE", "off")
     k3, _, _, _ = sdb.load_tree_text(tdb)
     assert np.array_equal(k1, k3)
+
+
+def test_revcomp_host_vs_golden(golden_dir):
+    """library/seqpy.c:5-36 (IUPAC table, case kept, other bytes unchanged) -- host forms of the product:
+    ss_revcomp through ctypes and the seqpy drop-in module.  Golden pairs come from the reference's own
+    seqpy.c compiled in the build container (tests/golden/make_golden.py)."""
+    from strainscan_amd import _lib, seqpy
+    with open(os.path.join(golden_dir, "revcomp.json")) as f:
+        pairs = json.load(f)
+    assert len(pairs) >= 8
+    for s, want in pairs:
+        assert seqpy.revcomp(s) == want
+        assert _lib.revcomp(s.encode()) == want.encode()
+        out = ctypes.create_string_buffer(max(1, len(s)))
+        assert _lib.lib().ss_revcomp(s.encode(), out, len(s)) == 0
+        assert out.raw[:len(s)] == want.encode()
+
+
+def test_bench_gpus_argument_handling():
+    """`python bench.py --gpus 2` without a launcher spawns two fresh rank processes (RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 set) before anything touches torch, and relays rank 0's line; under a launcher
+    a --gpus that disagrees with WORLD_SIZE is an error.  SS_BENCH_WORKER_STUB stops the worker before
+    the GPU work."""
+    import subprocess
+    import sys
+    bench = os.path.join(REPO, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SS_BENCH_WORKER_STUB"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3"], env=env, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rank"] == 0 and d["master"] == "127.0.0.1" and d["argv"] == ["--gpus", "2", "--steps", "3"]
+    # one process, no launcher: world 1
+    r = subprocess.run([sys.executable, bench], env=env, capture_output=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.decode())["n_gpus"] == 1
+    # launcher started 2 ranks but --gpus says 4: refuse
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"], env=env2, capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"--gpus 4" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env2, capture_output=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.decode())["n_gpus"] == 2

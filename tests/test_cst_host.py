@@ -107,3 +107,35 @@ def test_binom_sf_without_scipy(golden_dir):
         b = 1.0 - st.binom.sf(x, x + y, 0.995)
         worst = min(worst, float(np.abs(b - 0.05).min()))
     assert worst > 1e-9, worst
+
+
+def test_single_cluster_tree_pkl(tmp_path):
+    """identify.py:19-21: a one-line tree_structure.txt means the tree is in tree.pkl (a pickled treelib.Tree,
+    Build_tree.py:283-334).  The product reads it with a restricted Unpickler: same node / children order as
+    treelib, other treelib layouts understood, anything that is not a treelib tree refused."""
+    import pickle
+    from strainscan_amd import tree as T
+    from tests import scenarios as sc, synth
+    info = sc.build_l1("D", str(tmp_path))
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    assert open(os.path.join(tdb, "tree_structure.txt")).read() == "1\t"
+    t, gcf = T.read_tree_structure(tdb)
+    assert gcf == {} and [n.identifier for n in t.all_nodes()] == [1] and t.children(1) == [] and t.root.identifier == 1
+    os.remove(os.path.join(tdb, "tree.pkl"))                      # the line alone names the node
+    t, gcf = T.read_tree_structure(tdb)
+    assert [n.identifier for n in t.all_nodes()] == [1] and gcf == {}
+    # a full tree in the 1.6.1 layout, every pickle protocol: creation order root first, children in list order
+    for proto in (0, 1, 2, 3, 4):
+        p = tmp_path / ("t%d.pkl" % proto)
+        p.write_bytes(synth.treelib_pickle(sc.PARENT_T11, proto))
+        t = T.load_tree_pkl(str(p))
+        assert [n.identifier for n in t.all_nodes()] == [7, 8, 9, 10, 11, 1, 2, 3, 4, 5, 6]
+        assert [c.identifier for c in t.children(8)] == [3, 9] and t.parent(9).identifier == 8
+        assert sorted(n.identifier for n in t.leaves()) == [1, 2, 3, 4, 5, 6]
+    p = tmp_path / "bad.pkl"
+    p.write_bytes(pickle.dumps(os.getcwd))
+    with pytest.raises(pickle.UnpicklingError):
+        T.load_tree_pkl(str(p))
+    p.write_bytes(pickle.dumps({"_nodes": {}}))
+    with pytest.raises(ValueError):
+        T.load_tree_pkl(str(p))

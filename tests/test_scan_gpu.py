@@ -479,3 +479,39 @@ def test_gz_whole_file_inflate(L, tmp_path):
         rs.scan_into(db)
         assert np.array_equal(db.counts_rows(), want), paths
         rs.close()
+
+
+def test_revcomp_device_and_host_vs_golden(L, golden_dir):
+    """library/seqpy.c:5-36: the product's three forms -- ss_revcomp (host), strainscan_amd.seqpy.revcomp and the
+    device batch form ss_revcomp_dev -- against pairs produced by the reference's own seqpy.c (golden/revcomp.json):
+    IUPAC codes, case kept, every other byte unchanged; and on random bytes of all 256 values (device == host)."""
+    import ctypes as C
+    from strainscan_amd import seqpy
+    pairs = _golden(golden_dir, "revcomp.json")
+    lib = L.lib()
+
+    def dev_revcomp(seqs):     # equal-length batch
+        n, ln = len(seqs), len(seqs[0])
+        buf = b"".join(seqs)
+        if not buf:
+            assert lib.ss_revcomp_dev(None, None, 0, n, None) == 0
+            return [b""] * n
+        din, dout = C.c_void_p(), C.c_void_p()
+        L.check(lib.ss_dev_alloc(C.byref(din), len(buf)), "alloc")
+        L.check(lib.ss_dev_alloc(C.byref(dout), len(buf)), "alloc")
+        L.check(lib.ss_memcpy_h2d(din, buf, len(buf), None), "h2d")
+        L.check(lib.ss_revcomp_dev(din, dout, ln, n, None), "ss_revcomp_dev")
+        out = C.create_string_buffer(len(buf))
+        L.check(lib.ss_memcpy_d2h(out, dout, len(buf), None), "d2h")
+        L.check(lib.ss_device_sync(), "sync")
+        lib.ss_dev_free(din), lib.ss_dev_free(dout)
+        return [out.raw[i * ln:(i + 1) * ln] for i in range(n)]
+
+    for s, want in pairs:
+        assert seqpy.revcomp(s) == want
+        assert L.revcomp(s.encode()) == want.encode()
+        assert dev_revcomp([s.encode()] * 3) == [want.encode()] * 3
+    rs = np.random.RandomState(5)
+    for ln in (1, 31, 150, 1000):
+        seqs = [rs.randint(0, 256, size=ln).astype(np.uint8).tobytes() for _ in range(257)]
+        assert dev_revcomp(seqs) == [L.revcomp(x) for x in seqs]
