@@ -70,12 +70,13 @@ struct ss_db {
     uint32_t log2cap = 0;
     uint64_t capacity = 0;
     int layout = 0;                    // 0 = flat open-address table, 1 = minimizer buckets (k = 31)
-    uint64_t n_slots = 0;              // length of d_counts: capacity (flat) or n_distinct (buckets)
+    uint64_t n_slots = 0;              // length of d_counts: capacity (flat) or n_mslots + 8 * n_dir (pages)
+    uint64_t n_mslots = 0;             // pages: length of d_mkeys (bucket headers + k-mers)
     uint64_t *d_keys = nullptr;        // flat: [capacity] table keys, EMPTY_KEY where free
-    uint64_t *d_mkeys = nullptr;       // buckets: [n_distinct] k-mers grouped by minimizer, bit 63 = last of bucket
-    uint64_t *d_dir = nullptr;         // buckets: [2^dirbits] (minimizer hash << 32) | bucket start
+    uint64_t *d_mkeys = nullptr;       // pages: [n_mslots] buckets of the minimizers with many k-mers (ss_mini.hip)
+    uint64_t *d_dir = nullptr;         // pages: [n_dir][8] 64-byte pages of slots (inline k-mers, bucket references)
     uint32_t dirbits = 0;
-    uint32_t n_dir = 0;                // buckets: number of 16-byte directory buckets
+    uint32_t n_dir = 0;                // pages: number of 64-byte pages
     uint32_t *d_bloom = nullptr;       // buckets: one-probe Bloom filter over the minimizers (L2 resident), or null
     uint32_t bloom_bits = 0;           // log2 of its size in bits
     uint64_t n_buckets = 0;

@@ -1,43 +1,51 @@
-// ss_mini.hip -- minimizer-bucketed k-mer index and its scan kernel (k = 31).
+// ss_mini.hip -- minimizer-paged k-mer index and its scan kernel (k = 31).
 //
 // Why: with the flat open-address table (ss_scan.hip) every one of the 120 k-mers of a 150-bp
 // read costs a random 64-byte HBM sector although ~95 % of them are not in the database
 // (profiles/r01a: 213 GB fetched per 22 GB of algorithmic bytes).  Consecutive k-mers of a read
 // share their minimizer (the 15-mer with the smallest ordering key inside the k-mer) for ~9 positions
-// on average, so:
-//   * database k-mers are stored grouped by minimizer ("buckets"), contiguous in HBM;
-//   * a one-probe Bloom filter (<= 4 MB: L2 resident) and behind it a small exact directory
-//     minimizer -> bucket (tens of MB) answer "no database k-mer has this minimizer" for most
-//     read windows;
-//   * a lane probes the directory once per run of equal minimizers (~13 per read instead of
-//     120) and touches a bucket only when the minimizer exists.
-// Counting semantics are unchanged and exact: a k-mer is looked up in the bucket of ITS OWN
-// minimizer, which is a function of the k-mer alone, on the database side and on the read side.
+// on average, so a lane probes the index once per RUN of equal minimizers (~13 per read instead of
+// 120).  Counting semantics are unchanged and exact: a k-mer is looked up under ITS OWN minimizer,
+// which is a function of the k-mer alone, on the database side and on the read side.
+//
+// What bounds the lookups (scripts/micro/randsec.hip on MI355X): random 64-byte sectors come at
+// ~55 G/s = 3.5 TB/s from anything larger than the L2 (the 256 MB Infinity Cache does not help), at
+// 250 G/s out of the 4 MB L2 of an XCD, and reading all 64 bytes of a sector costs the same as
+// reading 16.  So one run = ONE sector, and that sector answers as much as possible:
 //
 // Layout in HBM
-//   d_mkeys[n_slots] u64  buckets back to back.  A bucket = 1 header word + its k-mers sorted by
+//   d_pages[n_pages]  64 B  hash-addressed pages of eight 8-byte slots.  A minimizer (the 30-bit m-mer x)
+//                         lives in page floor(h * n_pages / 2^30), h = mix30(x) a BIJECTION of the 30 bits, or,
+//                         when that page was full at build time, in the next one(s): a lookup goes on to
+//                         the next page only if the page it read is full (slot 7 occupied), which at the
+//                         build's load (two items per page on average) is one lookup in a thousand.
+//                         slot, inline k-mer:  0 | tag20 | e5 | 6 spare || flank32
+//                              the database k-mer itself: tag20 = low 20 bits of h (with the page number they
+//                              determine h, hence x, exactly: two minimizers that agree in the low 20 bits of h
+//                              lie >= 2^20 apart, i.e. in different pages, for n_pages >= 2^11); e = 16 - o, o =
+//                              offset of the minimizer inside the k-mer; flank32 = the other 16 bases (those
+//                              behind the minimizer in the low bits, then those in front of it).  A read k-mer
+//                              equals it iff tag, offset and flank agree: no second load, no key array.  Its
+//                              counter is d_counts[n_mslots + 8 * page + slot].
+//                         slot, bucket reference:  1 | tag14 | mask17 || multi | spare | start30
+//                              minimizers with more than SS_INLINE_MAX database k-mers keep them in a bucket of
+//                              d_mkeys (below); the bucket's header travels in the slot.  tag14 is only a
+//                              filter: candidates are compared in full.
+//                         empty slot = 0x7FFFFFFF'FFFFFFFF (an inline slot with the impossible e = 31)
+//   d_mkeys[n_mslots] u64 buckets back to back.  A bucket = 1 header word + its k-mers sorted by
 //                         (offset of the minimizer inside the k-mer, rest):
 //                           header: bits 0..16 = which offsets occur, bit 17 = some offset occurs more
 //                                   than once ("multi"), bits 32..63 = number of k-mers
 //                           k-mer : the 62-bit key
 //                         With one k-mer per offset (the normal case: a bucket is one super-k-mer)
-//                         the k-mer with offset o sits at header + 1 + popcount(mask & ((1 << o) - 1)):
-//                         a hit costs two dependent loads, a miss inside an existing bucket one.
-//   d_counts[n_slots] u32 occurrences per slot (same index; header slots unused)
-//   d_dir[n_dir][2]   u64 cuckoo directory of 16-byte buckets (two entries each, two hash functions).
-//                         keyed by the minimizer itself (the 30-bit m-mer).
-//                         entry = 14-bit fingerprint (never 0x3FFF) << 50 | multi << 49 |
-//                                 offset mask (17 bits) << 32 | moved flag << 31 | bucket start (31 bits)
-//                         i.e. the bucket's header travels with the directory entry: a found run goes
-//                         straight to its candidate k-mers (dir -> candidate: two dependent round trips
-//                         per tile instead of three).  A fingerprint false positive (2^-14) only costs a
-//                         candidate compare that fails: k-mers are compared in full, and a k-mer lives in
-//                         exactly one bucket, so every fingerprint match is simply tried.  A key lives
-//                         in its FIRST bucket unless that was full when it arrived; "moved" on a first
-//                         bucket's entry 0 means a key of that bucket lives in its second bucket, which is
-//                         then read too (a few % of the lookups; the second bucket is never the first
-//                         one again).  EMPTY = ~0.
-//   d_bloom[2^b/32]   u32 bit dir_mix(minimizer) >> (32 - b) set for every bucket
+//                         the k-mer with offset o sits at header + 1 + popcount(mask & ((1 << o) - 1)).
+//   d_counts[n_slots] u32 occurrences: [0, n_mslots) parallel to d_mkeys, [n_mslots, n_mslots + 8 n_pages)
+//                         parallel to the page slots
+//   d_bloom[2^b/32]   u32 bit h >> (30 - b) set for every minimizer -- only built when it is worth its L2
+//                         round trip: >= 4 bits per minimizer within 2^25 bits (the 4 MB L2 of an XCD).  A database
+//                         of dense node sets (few minimizers, ~9 k-mers each) gets one; a database of sampled
+//                         node sets (Build_tree.py:590-591: nearly one minimizer per k-mer) does not -- there
+//                         half of a sample's runs find their minimizer anyway.
 #include "ss_common.h"
 #include "ss_scan_dev.h"
 
@@ -74,8 +82,8 @@ __host__ __device__ __forceinline__ uint32_t mmkey(uint32_t x)
 }
 constexpr uint32_t KEY_MASK = ~31u;
 
-// the two directory buckets of a minimizer (the 30-bit m-mer): 32-bit mixes reduced to [0, n_dir)
-// by the high half of a 32x32 product (any table size, no power-of-two rounding).  Once per RUN.
+// Once per RUN: h = mix30(minimizer), a bijection of the 30 bits (odd multipliers modulo 2^30, xor-shifts).
+// Page = high half of (h << 2) x n_pages (any table size, no power-of-two rounding); tags = low bits of h.
 __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -84,27 +92,35 @@ __host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b)
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
-__host__ __device__ __forceinline__ uint32_t dir_mix(uint32_t mini)
+__host__ __device__ __forceinline__ uint32_t mix30(uint32_t x)
 {
-    uint32_t h = mini * 0x9E3779B1u;
-    return h ^ (h >> 15);
+    uint32_t h = (x * 0x9E3779B1u) & M30;
+    h ^= h >> 15;
+    h = (h * 0x2C1B3C6Du) & M30;
+    h ^= h >> 14;
+    return h;
 }
-__host__ __device__ __forceinline__ uint32_t dir_bucket1(uint32_t mini, uint32_t n_dir)
+__host__ __device__ __forceinline__ uint32_t page_of(uint32_t h, uint32_t n_pages) { return mulhi32(h << 2, n_pages); }
+constexpr uint32_t PG_SLOTS = 8;                          // slots per 64-byte page
+constexpr uint32_t PG_MIN_PAGES = 4096;                   // >= 2^11: (page, low 20 bits of h) determines h
+// A page, structure of arrays, so that ONE 16-byte load decides almost every lookup:
+//   bytes  0.. 7  tag8[8]   h & 0xFF of the slot's minimizer                         (0xFF when empty)
+//   bytes  8..15  hi8[8]    inline k-mer: e = 16 - offset (5 bits); bucket reference: 0x80 | mask bit 16 << 6 | h[13:8]
+//                           (0x7F when empty: an inline slot with the impossible e = 31)
+//   bytes 16..47  lo32[8]   inline: flank32; reference: multi << 31 | bucket start
+//   bytes 48..63  mid16[8]  inline: h[19:8] << 4; reference: mask bits 0..15
+// Only slots whose tag8 (and e range / reference filter bits) match have their lo32 / mid16 read, from the sector the
+// first load has just brought into the L1.
+constexpr uint8_t PG_EMPTY_TAG = 0xFF, PG_EMPTY_HI = 0x7F;
+constexpr uint32_t START_MASK = 0x3FFFFFFFu;
+// the 16 bases of a k-mer that are not its minimizer: rotate the 62-bit key right by 2 * offset (the minimizer
+// comes to stand in bits 0..29), the upper 32 bits = bases behind the minimizer, then the bases in front of it
+__host__ __device__ __forceinline__ uint32_t flank_of_key(uint64_t key, uint32_t off)
 {
-    return mulhi32(dir_mix(mini), n_dir);
+    const uint64_t M62 = (1ull << 62) - 1;
+    const uint64_t r = off ? (((key >> (2 * off)) | (key << (62 - 2 * off))) & M62) : key;
+    return (uint32_t)(r >> 30);
 }
-// never the first bucket again (an entry reachable through both would be counted twice): n_dir >= 16
-__host__ __device__ __forceinline__ uint32_t dir_bucket2(uint32_t mini, uint32_t n_dir)
-{
-    const uint32_t b = dir_bucket1(mini, n_dir) + 1u + mulhi32((mini ^ 0x5bd1e995u) * 0x85EBCA6Bu, n_dir - 1u);
-    return b >= n_dir ? b - n_dir : b;
-}
-// 14-bit fingerprint: the LOW bits of the mix (the bucket index uses its high bits), never 0x3FFF so that
-// an empty entry (all ones) matches nothing
-__host__ __device__ __forceinline__ uint32_t dir_fp_of_mix(uint32_t h) { const uint32_t f = h & 0x3FFFu; return f < 0x3FFEu ? f : 0x3FFEu; }
-__host__ __device__ __forceinline__ uint32_t dir_fp(uint32_t mini) { return dir_fp_of_mix(dir_mix(mini)); }
-constexpr uint64_t DIR_MOVED = 1ull << 31;        // flag in entry 0 of a first bucket
-constexpr uint32_t START_MASK = 0x7FFFFFFFu;
 
 // minimizer (the m-mer itself) of a k-mer and its LEFTMOST offset inside the k-mer
 static inline uint32_t mini_of_key(uint64_t key, int k, uint32_t *offset)
@@ -177,12 +193,14 @@ constexpr int MLANES = MT - 2;
 constexpr int MTILE = MLANES * PPT;
 
 struct QShared {
-    uint32_t code[MT + 2];
+    uint32_t code_[MT + 3];            // code_[1 + i] = bases 16 i .. 16 i + 15 of the tile; one word of slack in front (the
+                                       // window of 16 bases BEFORE a minimizer near the tile start) and two behind
     uint16_t inv[MT + 2];
     uint32_t q1[Q1CAP + 64];           // run:   len << 12 | tile position of its first k-mer (+64 dump slots)
     alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
-    uint64_t q1b[Q1CAP];               // run that passed the Bloom filter: mix << 32 | minimizer offset in the first k-mer << 17 | q1 entry
-    uint64_t q2[Q1CAP];                // found: bucket start << 32 | multi << 31 | aligned offset mask << 12 | q1b index
+    uint64_t q1b[Q1CAP];               // run that passed the Bloom filter: h << 32 | minimizer offset in the first k-mer << 17 | q1 entry
+    uint64_t q2[Q1CAP];                // found bucket: bucket start << 32 | multi << 31 | aligned offset mask << 12 | run index (q1b with a
+                                       // Bloom filter, q1 without)
     uint32_t cnt[4];                   // [1] = found runs
 #ifdef SS_LDS_PAD
     uint32_t pad[SS_LDS_PAD / 4];      // occupancy experiments only
@@ -193,7 +211,7 @@ struct QShared {
 __device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t &lo, uint32_t &hi)
 {
     const uint32_t w = pos >> 4, sh = 2 * (pos & 15);
-    const uint32_t a = S.code[w], b = S.code[w + 1], c = S.code[w + 2];
+    const uint32_t a = S.code_[w + 1], b = S.code_[w + 2], c = S.code_[w + 3];
     lo = __builtin_amdgcn_alignbit(b, a, sh);
     hi = __builtin_amdgcn_alignbit(c, b, sh) & 0x3FFFFFFFu;
 }
@@ -202,7 +220,13 @@ __device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t
 __device__ __forceinline__ uint32_t mmer_at(const QShared &S, uint32_t p)
 {
     const uint32_t w = p >> 4;
-    return __builtin_amdgcn_alignbit(S.code[w + 1], S.code[w], 2 * (p & 15)) & ss::M30;
+    return __builtin_amdgcn_alignbit(S.code_[w + 2], S.code_[w + 1], 2 * (p & 15)) & ss::M30;
+}
+// the 16 bases starting at tile position p (p >= -16)
+__device__ __forceinline__ uint32_t win16_at(const QShared &S, int32_t p)
+{
+    const int32_t w = (p >> 4) + 1;
+    return __builtin_amdgcn_alignbit(S.code_[w + 1], S.code_[w], 2 * (p & 15));
 }
 
 // A found run carries the bucket's offset mask shifted so that the offset of the run's FIRST k-mer
@@ -294,17 +318,16 @@ __device__ unsigned long long ss_timing[32];
 #ifndef SS_NUM_SGPR
 #define SS_NUM_SGPR 80
 #endif
-template <bool ALIGNED, int WAVES_PER_SIMD>
+template <bool ALIGNED, bool BLOOM, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(SS_NUM_SGPR))) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
-    const uint64_t *__restrict__ dir, uint32_t n_dir, uint32_t *__restrict__ counts,
+    const uint4 *__restrict__ pages, uint32_t n_pages, uint32_t *__restrict__ counts, uint32_t cbase,
     const uint32_t *__restrict__ bloom, uint32_t bloom_shift)
 {
     constexpr int K = 31;                            // 17 m-mers of length 15 per k-mer
     static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
     const int t = threadIdx.x;
-    const ulonglong2 *dir2 = reinterpret_cast<const ulonglong2 *>(dir);
     const uint32_t vc1 = ss::MMK_C1;
 
     // the 16 bases of this lane are fetched one tile AHEAD: the HBM
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         {
             uint32_t code, inv;
             encode16(wn, code, inv);
-            S.code[t] = code;
+            S.code_[t + 1] = code;
             S.inv[t] = (uint16_t)inv;
             if (t == 1) S.cnt[1] = 0;
 #ifdef SS_LDS_PAD
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         // ---- phase 1a: key the 16 m-mers that start in this lane's 16 bases -----------------------
         uint32_t hm[PPT];
         {
-            const uint32_t c0 = S.code[t], c1 = S.code[t + 1];
+            const uint32_t c0 = S.code_[t + 1], c1 = S.code_[t + 2];
             // low 24 bits of the m-mers 0..15 (bits 2i.. of c1:c0): 15 funnel shifts, then one multiply-add
             // per m-mer; the "+ i" of the packed word rides in the additive constant
             hm[0] = mad24s(c0, vc1, ss::MMK_C0);
@@ -451,17 +474,22 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         SS_T(2);
         SS_STOP(2)
 
-        // every directory entry whose fingerprint matches becomes a found run in q2 (phase 3 gives it
-        // 16 lanes, one per position).  meta = minimizer offset in the first k-mer << 17 | len << 12 | position
-        auto push_found = [&](uint64_t de, uint32_t meta, uint32_t ib, bool queued) {
-            const uint32_t bstart = (uint32_t)de & ss::START_MASK, hdr = (uint32_t)(de >> 32) & 0x3FFFFu;
-            const uint32_t amask = aligned_mask(hdr, (meta >> 17) & 31u), multi = (hdr >> 17) & 1u;
+        // minimizer offset (in the run's first k-mer) from the index byte of the run's first position:
+        // meta = offset << 17 | len << 12 | position
+        auto run_meta = [&](uint32_t e) {
+            const uint32_t rpos = e & 0xFFFu;
+            return e | ((((uint32_t)S.ib[rpos] & 31u) - (rpos & 15u)) << 17);
+        };
+        // a bucket reference whose tag bits match becomes a found run in q2 (phase 3 gives it 16 lanes, one per position)
+        auto push_found = [&](uint32_t lo, uint32_t mask17, uint32_t meta, uint32_t ridx, bool queued) {
+            const uint32_t bstart = lo & ss::START_MASK, multi = lo >> 31;
+            const uint32_t amask = aligned_mask(mask17, (meta >> 17) & 31u);
             uint32_t i2 = Q1CAP;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
             if (i2 < Q1CAP) {
-                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | ib;
+                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | ridx;
             } else {
-                // the queue is full (only with floods of fingerprint collisions), or phase 3 is already
+                // the queue is full (only with floods of tag collisions), or phase 3 is already
                 // over (runs that overflowed q1): settle this run here, so that no k-mer is ever dropped
                 const uint32_t rpos = meta & 0xFFFu, len = (meta >> 12) & 31u;
                 for (uint32_t q = 0; q < len; q++) {
@@ -470,38 +498,62 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 }
             }
         };
-        // the directory entries (first bucket b1, second bucket behind the "moved" flag) that match the run
-        auto lookup_found = [&](const ulonglong2 &b1, uint32_t h, uint32_t meta, uint32_t ib, bool queued) {
-            const uint32_t fp = ss::dir_fp_of_mix(h);
-            // matching entries as a bit mask + selects (an indexed local array would live in scratch memory);
-            // 32-bit compares on the upper halves: a fingerprint is never 0x3FFF, so empty entries match nothing
-            ulonglong2 b2 = make_ulonglong2(ss::EMPTY_KEY, ss::EMPTY_KEY);
-            if (((uint32_t)b1.x & (uint32_t)ss::DIR_MOVED) && (uint32_t)(b1.x >> 32) != 0xFFFFFFFFu)   // a key of this bucket moved
-                b2 = dir2[ss::dir_bucket2(mmer_at(S, (meta & 0xFFFu) + ((meta >> 17) & 31u)), n_dir)];
-            uint32_t hits = (uint32_t)(((uint32_t)(b1.x >> 32) >> 18) == fp) | (uint32_t)(((uint32_t)(b1.y >> 32) >> 18) == fp) << 1 |
-                            (uint32_t)(((uint32_t)(b2.x >> 32) >> 18) == fp) << 2 | (uint32_t)(((uint32_t)(b2.y >> 32) >> 18) == fp) << 3;
-            while (hits) {
-                const uint32_t d = (uint32_t)__ffs(hits) - 1u;
-                hits &= hits - 1u;
-                push_found(d == 0 ? b1.x : d == 1 ? b1.y : d == 2 ? b2.x : b2.y, meta, ib, queued);
+        // One page against one run; tg = the page's first 16 bytes (tag8[8], hi8[8]).  Inline slots are whole database
+        // k-mers: the k-mer of the run with minimizer offset o = 16 - e (if the run has one) equals the slot iff the
+        // remaining tag bits and the flank agree -- the flank of EVERY k-mer of the run is a bit-select between the 16
+        // bases behind the minimizer (fa) and the 16 in front of it (fb).  Returns true when the page is full (the
+        // minimizer's slots may go on in the next page).
+        auto scan_page = [&](const uint4 tg, uint32_t page, uint32_t meta, uint32_t h, uint32_t ridx, bool queued) -> bool {
+            const uint32_t tt = (h & 0xFFu) * 0x01010101u;
+            const uint32_t x0 = tg.x ^ tt, x1 = tg.y ^ tt;                      // zero byte = tag8 matches
+            const uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u;
+            const uint32_t z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
+            uint32_t hit = (z0 >> 7) | (z1 >> 3);                               // slot s at bit 8 (s & 3) + 4 (s >> 2)
+            if (hit) {
+                const uint32_t o0 = (meta >> 17) & 31u, len = (meta >> 12) & 31u;
+                const char *pb = reinterpret_cast<const char *>(pages) + (uint64_t)page * 64u;
+                do {
+                    const uint32_t b = (uint32_t)__ffs(hit) - 1u, sl = (b >> 3) + (b & 4u);
+                    hit &= hit - 1u;
+                    const uint32_t hi8 = (((b & 4u) ? tg.w : tg.z) >> (b & 24u)) & 0xFFu;
+                    const bool ref = hi8 & 0x80u;
+                    const uint32_t e = hi8 & 31u, j = o0 + e - 16u;             // inline: k-mer j of the run has offset o0 - j
+                    if (ref ? ((hi8 ^ (h >> 8)) & 0x3Fu) == 0u : j < len) {
+                        const uint32_t lo = reinterpret_cast<const uint32_t *>(pb + 16)[sl];
+                        const uint32_t mid = reinterpret_cast<const uint16_t *>(pb + 48)[sl];
+                        if (ref) {
+                            push_found(lo, mid | ((hi8 & 0x40u) << 10), meta, ridx, queued);
+                        } else if ((mid >> 4) == ((h >> 8) & 0xFFFu)) {
+                            const int32_t q = (int32_t)((meta & 0xFFFu) + o0);  // tile position of the minimizer
+                            const uint32_t fa = win16_at(S, q + ss::MINI_M), fb = win16_at(S, q - 16);
+                            const uint32_t m = ((1u << e) << e) - 1u;           // low 2 e bits (e = 16: all)
+                            if (((fa & m) | (fb & ~m)) == lo) atomicAdd(&counts[cbase + page * 8u + sl], 1u);
+                        }
+                    }
+                } while (hit);
             }
+            return (tg.w >> 24) != (uint32_t)ss::PG_EMPTY_HI;
         };
-        // minimizer offset (in the run's first k-mer) from the index byte of the run's first position
-        auto run_meta = [&](uint32_t e) {
-            const uint32_t rpos = e & 0xFFFu;
-            return e | ((((uint32_t)S.ib[rpos] & 31u) - (rpos & 15u)) << 17);
+        // the rare continuation: the page was full, the minimizer's slots may go on in the next one(s)
+        auto scan_more = [&](uint32_t page, uint32_t meta, uint32_t h, uint32_t ridx, bool queued) {
+            uint4 tg;
+            do {
+                page = page + 1u == n_pages ? 0u : page + 1u;
+                tg = pages[(uint64_t)page * 4u];
+            } while (scan_page(tg, page, meta, h, ridx, queued));
         };
 
         SS_T(7);
-        // ---- phase 2a: Bloom filter, all lanes busy: one probe of an L2-resident bit array kills most of
+        // ---- phase 2a (databases with a Bloom filter): one probe of an L2-resident bit array kills most of
         // the ~90 % of the runs whose minimizer is not in the database before they cost a random HBM
         // sector each.  Survivors are compacted into q1b (ballot + lane count: one wave per workgroup)
-        uint32_t ns = 0;
-        {
+        uint32_t ns = n1;
 #ifndef SS_RPL
 #define SS_RPL 2
 #endif
-            constexpr int RPL = SS_RPL;
+        constexpr int RPL = SS_RPL;
+        if (BLOOM) {
+            ns = 0;
             for (uint32_t r0 = 0; r0 < n1; r0 += RPL * MT) {
                 uint32_t meta[RPL], hs[RPL], bw[RPL];
                 bool ok[RPL];
@@ -510,14 +562,12 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     const uint32_t r = r0 + u * MT + t;
                     ok[u] = r < n1;
                     meta[u] = run_meta(S.q1[ok[u] ? r : 0u]);
-                    hs[u] = ss::dir_mix(mmer_at(S, (meta[u] & 0xFFFu) + (meta[u] >> 17)));   // one mix per run: Bloom bit, bucket, fingerprint
+                    hs[u] = ss::mix30(mmer_at(S, (meta[u] & 0xFFFu) + (meta[u] >> 17)));   // one mix per run: Bloom bit, page, tags
                 }
-                if (bloom) {
 #pragma unroll
-                    for (int u = 0; u < RPL; u++) bw[u] = bloom[hs[u] >> (bloom_shift + 5)];
+                for (int u = 0; u < RPL; u++) bw[u] = bloom[hs[u] >> (bloom_shift + 5)];
 #pragma unroll
-                    for (int u = 0; u < RPL; u++) ok[u] = ok[u] && ((bw[u] >> ((hs[u] >> bloom_shift) & 31u)) & 1u);
-                }
+                for (int u = 0; u < RPL; u++) ok[u] = ok[u] && ((bw[u] >> ((hs[u] >> bloom_shift) & 31u)) & 1u);
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     const uint64_t pass = __ballot(ok[u]);
@@ -526,16 +576,35 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     ns += (uint32_t)__popcll(pass);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        // ---- phase 2b: one 16-byte directory load per surviving run (about a tenth of the runs) ----
-        for (uint32_t i0 = 0; i0 < ns; i0 += MT) {
-            const uint32_t i = i0 + t;
-            if (i < ns) {
-                const uint64_t sv = S.q1b[i];
-                const uint32_t h = (uint32_t)(sv >> 32);
-                lookup_found(dir2[ss::mulhi32(h, n_dir)], h, (uint32_t)sv, i, true);
+        // ---- phase 2b: ONE sector per run (all runs, or the Bloom survivors), RPL2 page heads in flight per lane ----
+#ifndef SS_RPL2
+#define SS_RPL2 1
+#endif
+        constexpr int RPL2 = SS_RPL2;
+        for (uint32_t i0 = 0; i0 < ns; i0 += RPL2 * MT) {
+            uint32_t meta[RPL2], hs[RPL2], pgi[RPL2];
+            uint4 tg[RPL2];
+            bool ok[RPL2];
+#pragma unroll
+            for (int u = 0; u < RPL2; u++) {
+                const uint32_t i = i0 + u * MT + t;
+                ok[u] = i < ns;
+                if (BLOOM) {
+                    const uint64_t sv = S.q1b[ok[u] ? i : 0u];
+                    meta[u] = (uint32_t)sv;
+                    hs[u] = (uint32_t)(sv >> 32);
+                } else {
+                    meta[u] = run_meta(S.q1[ok[u] ? i : 0u]);
+                    hs[u] = ss::mix30(mmer_at(S, (meta[u] & 0xFFFu) + (meta[u] >> 17)));
+                }
+                pgi[u] = ss::page_of(hs[u], n_pages);
+                if (ok[u]) tg[u] = pages[(uint64_t)pgi[u] * 4u];
             }
+#pragma unroll
+            for (int u = 0; u < RPL2; u++)
+                if (ok[u] && scan_page(tg[u], pgi[u], meta[u], hs[u], i0 + u * MT + t, true)) scan_more(pgi[u], meta[u], hs[u], i0 + u * MT + t, true);
         }
         __syncthreads();
         SS_T(3);
@@ -558,7 +627,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
                     const bool v = (g >> 4) < n2;
                     const uint64_t r = S.q2[v ? (g >> 4) : 0u];
-                    const uint32_t run = (uint32_t)S.q1b[(uint32_t)r & 0xFFFu];
+                    const uint32_t run = BLOOM ? (uint32_t)S.q1b[(uint32_t)r & 0xFFFu] : S.q1[(uint32_t)r & 0xFFFu];
                     pos[u] = (run & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32);
                     mul[u] = (uint32_t)r >> 31;
@@ -576,8 +645,9 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 if (!((ovf >> j) & 1u)) continue;
                 const uint32_t len12 = ((uint32_t)__ffs(stop >> (j + 1)) << 12) + ((need >> (j + 1)) ? 0u : ext12);
                 const uint32_t meta = run_meta(len12 + (uint32_t)(t * PPT + j));
-                const uint32_t x = mmer_at(S, (meta & 0xFFFu) + (meta >> 17));
-                lookup_found(dir2[ss::dir_bucket1(x, n_dir)], ss::dir_mix(x), meta, 0u, false);
+                const uint32_t h = ss::mix30(mmer_at(S, (meta & 0xFFFu) + (meta >> 17)));
+                const uint32_t page = ss::page_of(h, n_pages);
+                if (scan_page(pages[(uint64_t)page * 4u], page, meta, h, 0u, false)) scan_more(page, meta, h, 0u, false);
             }
         }
         SS_T(4);
@@ -619,6 +689,10 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     };
     constexpr int PB = 8, NP = 1 << PB;
     unsigned nthreads = std::min<unsigned>(ss::host_cpus(), 32u);
+    uint32_t inline_max = 2;                        // minimizers with at most this many database k-mers keep them in page slots
+    if (const char *e = getenv("SS_INLINE_MAX")) inline_max = (uint32_t)std::max(0, std::min(8, atoi(e)));
+    double lambda = 2.0;                            // page items per page on average (eight slots: one page in a thousand full)
+    if (const char *e = getenv("SS_PAGE_LAMBDA")) lambda = std::max(0.25, std::min(6.0, atof(e)));
     // 1. entries of valid rows with their minimizer
     std::vector<uint64_t> pos(n_rows + 1, 0);
     for (uint64_t i = 0; i < n_rows; i++) pos[i + 1] = pos[i] + ((flags[i] & SS_ROW_VALID) ? 1 : 0);
@@ -629,11 +703,11 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
             if (flags[i] & SS_ROW_VALID) {
                 uint32_t o;
                 const uint32_t mx = mini_of_key(keys[i], k, &o);
-                ents[pos[i]] = Ent{mx, (uint32_t)i, keys[i], o, dir_mix(mx) >> (32 - PB)};
+                ents[pos[i]] = Ent{mx, (uint32_t)i, keys[i], o, mix30(mx) >> (30 - PB)};
             }
     });
     lap("1 minimizers");
-    // 2. counting partition on 8 mixed bits of the minimizer, then per-partition sort
+    // 2. counting partition on the top 8 bits of h = mix30(minimizer) -- the page order --, then per-partition sort
     std::vector<uint64_t> pcount(NP + 1, 0);
     for (uint64_t i = 0; i < nv; i++) pcount[ents[i].part + 1]++;
     for (int p = 0; p < NP; p++) pcount[p + 1] += pcount[p];
@@ -643,28 +717,6 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     }
     ents.clear();
     ents.shrink_to_fit();
-    {
-        std::atomic<int> next(0);
-        std::vector<std::thread> pool;
-        for (unsigned w = 0; w < nthreads; w++)
-            pool.emplace_back([&] {
-                for (int p; (p = next.fetch_add(1)) < NP;)
-                    std::sort(sorted.begin() + pcount[p], sorted.begin() + pcount[p + 1], [](const Ent &a, const Ent &b) {
-                        if (a.mini != b.mini) return a.mini < b.mini;
-                        if (a.off != b.off) return a.off < b.off;
-                        if (a.key != b.key) return a.key < b.key;
-                        return a.row < b.row;
-                    });
-            });
-        for (auto &th : pool) th.join();
-    }
-    lap("2 partition + sort");
-    // 3. distinct k-mers, buckets (header + entries), row bookkeeping (dict overwrite: the last
-    //    allowed row owns the count).  A minimizer lives in one partition, so the partitions are independent:
-    //    count their slots and buckets, prefix-sum, fill in parallel (same order as a serial walk: the image
-    //    does not depend on the thread count)
-    struct Bkt { uint32_t first, second, hdr; };         // minimizer (m-mer), header slot, offset mask | multi
-    std::vector<uint64_t> p_slots(NP + 1, 0), p_bkts(NP + 1, 0);
     auto for_partitions = [&](const std::function<void(int)> &fn) {
         std::atomic<int> next(0);
         std::vector<std::thread> pool;
@@ -673,37 +725,60 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
         for (auto &th : pool) th.join();
     };
     for_partitions([&](int p) {
-        uint64_t nb = 0, nd = 0;
+        std::sort(sorted.begin() + pcount[p], sorted.begin() + pcount[p + 1], [](const Ent &a, const Ent &b) {
+            if (a.mini != b.mini) return a.mini < b.mini;
+            if (a.off != b.off) return a.off < b.off;
+            if (a.key != b.key) return a.key < b.key;
+            return a.row < b.row;
+        });
+    });
+    lap("2 partition + sort");
+    // 3. distinct k-mers per minimizer.  Small sets become inline page items (one per k-mer), larger ones a bucket
+    //    of d_mkeys (header + k-mers) plus ONE page item, the reference.  Row bookkeeping: dict overwrite, the last
+    //    allowed row owns the count.  A minimizer lives in one partition, so the partitions are independent: count,
+    //    prefix-sum, fill in parallel (same order as a serial walk: the image does not depend on the thread count).
+    struct Item { uint32_t h, lo; uint16_t mid; uint8_t hi8; uint64_t e0, e1; };   // page item; [e0, e1) = its rows in `sorted` (inline items)
+    std::vector<uint64_t> p_slots(NP + 1, 0), p_items(NP + 1, 0), p_minis(NP + 1, 0);
+    auto walk = [&](int p, const std::function<void(uint64_t, uint64_t, uint32_t)> &bucket) {   // [i, e) = one minimizer, nd distinct k-mers
         for (uint64_t i = pcount[p]; i < pcount[p + 1];) {
             uint64_t e = i;
-            while (e < pcount[p + 1] && sorted[e].mini == sorted[i].mini) e++;
-            nb++;
-            for (uint64_t a2 = i; a2 < e;) {
-                uint64_t b2 = a2;
-                while (b2 < e && sorted[b2].key == sorted[a2].key) b2++;
-                nd++;
-                a2 = b2;
+            uint32_t nd = 0;
+            uint64_t last = ~0ull;
+            while (e < pcount[p + 1] && sorted[e].mini == sorted[i].mini) {
+                if (sorted[e].key != last) { nd++; last = sorted[e].key; }
+                e++;
             }
+            bucket(i, e, nd);
             i = e;
         }
-        p_slots[p + 1] = nd + nb;
-        p_bkts[p + 1] = nb;
+    };
+    for_partitions([&](int p) {
+        uint64_t ns_ = 0, ni = 0, nm = 0;
+        walk(p, [&](uint64_t, uint64_t, uint32_t nd) {
+            nm++;
+            if (nd <= inline_max) ni += nd;
+            else { ni++; ns_ += 1 + nd; }
+        });
+        p_slots[p + 1] = ns_; p_items[p + 1] = ni; p_minis[p + 1] = nm;
     });
-    for (int p = 0; p < NP; p++) { p_slots[p + 1] += p_slots[p]; p_bkts[p + 1] += p_bkts[p]; }
-    if (p_slots[NP] >= 0x7FFFFFF0ull) return SS_ERANGE;
-    std::vector<uint64_t> mkeys(p_slots[NP]);
-    std::vector<Bkt> buckets(p_bkts[NP]);
+    for (int p = 0; p < NP; p++) { p_slots[p + 1] += p_slots[p]; p_items[p + 1] += p_items[p]; p_minis[p + 1] += p_minis[p]; }
+    const uint64_t n_mslots = std::max<uint64_t>(1, p_slots[NP]), n_items = p_items[NP], n_minis = p_minis[NP];
+    if (n_mslots >= (uint64_t)START_MASK) return SS_ERANGE;
+    uint64_t n_pages = std::max<uint64_t>(PG_MIN_PAGES, (uint64_t)((double)n_items / lambda) + 1);
+    if (n_mslots + n_pages * PG_SLOTS >= 0xFFFFFFF0ull) return SS_ERANGE;     // counter indices are 32 bits
+    std::vector<uint64_t> mkeys(n_mslots, 0);
+    std::vector<Item> items(n_items);
     std::vector<uint32_t> slot_of_row(std::max<uint64_t>(1, n_rows), SS_NO_SLOT);
     std::vector<uint8_t> row_valid(std::max<uint64_t>(1, n_rows), 0);
-    std::atomic<uint64_t> orphans_a(0);
+    std::atomic<uint64_t> orphans_a(0), n_distinct_a(0);
     for_partitions([&](int p) {
-        uint64_t ms = p_slots[p], bi = p_bkts[p], orph = 0;
-        for (uint64_t i = pcount[p]; i < pcount[p + 1];) {
-            // one bucket = all entries with this minimizer
-            uint64_t e = i;
-            while (e < pcount[p + 1] && sorted[e].mini == sorted[i].mini) e++;
-            const uint32_t hslot = (uint32_t)ms++;
-            uint32_t mask = 0, multi = 0, cnt = 0;
+        uint64_t ms = p_slots[p], it = p_items[p], orph = 0, ndist = 0;
+        walk(p, [&](uint64_t i, uint64_t e, uint32_t nd) {
+            const uint32_t h = mix30(sorted[i].mini);
+            const bool inl = nd <= inline_max;
+            const uint32_t hslot = (uint32_t)ms;
+            if (!inl) ms++;
+            uint32_t mask = 0, multi = 0;
             for (uint64_t a2 = i; a2 < e;) {
                 uint64_t b2 = a2;
                 int64_t owner = -1;
@@ -713,103 +788,95 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
                     b2++;
                 }
                 const uint32_t o = sorted[a2].off;
-                if ((mask >> o) & 1u) multi = HDR_MULTI;
-                mask |= 1u << o;
-                const uint32_t slot = (uint32_t)ms;
-                mkeys[ms++] = sorted[a2].key;
-                for (uint64_t q = a2; q < b2; q++) slot_of_row[sorted[q].row] = slot;
+                if (inl) {
+                    items[it++] = Item{h, flank_of_key(sorted[a2].key, o), (uint16_t)(((h >> 8) & 0xFFFu) << 4), (uint8_t)(16u - o), a2, b2};
+                } else {
+                    if ((mask >> o) & 1u) multi = 1u;
+                    mask |= 1u << o;
+                    const uint32_t slot = (uint32_t)ms;
+                    mkeys[ms++] = sorted[a2].key;
+                    for (uint64_t q = a2; q < b2; q++) slot_of_row[sorted[q].row] = slot;
+                }
                 if (owner >= 0) row_valid[owner] = 1;
                 else orph++;
-                cnt++;
+                ndist++;
                 a2 = b2;
             }
-            mkeys[hslot] = ((uint64_t)cnt << 32) | multi | mask;
-            buckets[bi++] = Bkt{sorted[i].mini, hslot, multi | mask};
-            i = e;
-        }
+            if (!inl) {
+                mkeys[hslot] = ((uint64_t)nd << 32) | (multi ? HDR_MULTI : 0u) | mask;
+                items[it++] = Item{h, (multi << 31) | hslot, (uint16_t)(mask & 0xFFFFu), (uint8_t)(0x80u | ((mask >> 16) << 6) | ((h >> 8) & 0x3Fu)), 0, 0};
+            }
+        });
+        // page order inside the partition (the partitions themselves are h ranges); stable: a minimizer's items stay together
+        std::stable_sort(items.begin() + p_items[p], items.begin() + p_items[p + 1], [](const Item &a, const Item &b) { return a.h < b.h; });
         orphans_a += orph;
+        n_distinct_a += ndist;
     });
-    const uint64_t orphans = orphans_a.load(), n_distinct = p_slots[NP] - p_bkts[NP];
+    const uint64_t orphans = orphans_a.load();
+    if (orphans && upper_keys == 0) return SS_EKEY;
+    db->n_distinct = n_distinct_a.load();
+    lap("3 buckets + items");
+    // 4. place the items: home page = page_of(h), or the first page behind it that is not full (a lookup reads on while
+    //    the page it sees is full).  Serial in h order: ~20 ns per item.
+    std::vector<uint8_t> pages(n_pages * 64, 0);
+    {
+        std::vector<uint8_t> fill(n_pages, 0);
+        for (uint64_t pg = 0; pg < n_pages; pg++) {
+            memset(&pages[pg * 64], PG_EMPTY_TAG, 8);
+            memset(&pages[pg * 64 + 8], PG_EMPTY_HI, 8);
+        }
+        for (uint64_t i = 0; i < n_items; i++) {
+            const Item &it = items[i];
+            uint64_t pg = page_of(it.h, (uint32_t)n_pages);
+            while (fill[pg] == PG_SLOTS) pg = pg + 1 == n_pages ? 0 : pg + 1;
+            const uint32_t sl = fill[pg]++;
+            uint8_t *pp = &pages[pg * 64];
+            pp[sl] = (uint8_t)(it.h & 0xFFu);
+            pp[8 + sl] = it.hi8;
+            memcpy(pp + 16 + 4 * sl, &it.lo, 4);
+            memcpy(pp + 48 + 2 * sl, &it.mid, 2);
+            for (uint64_t q = it.e0; q < it.e1; q++) slot_of_row[sorted[q].row] = (uint32_t)(n_mslots + pg * PG_SLOTS + sl);
+        }
+    }
     sorted.clear();
     sorted.shrink_to_fit();
-    if (orphans && upper_keys == 0) return SS_EKEY;
-    if (mkeys.size() >= 0xFFFFFFF0ull) return SS_ERANGE;
-    db->n_distinct = n_distinct;
-    db->n_slots = std::max<uint64_t>(1, mkeys.size());
-    lap("3 buckets");
-    // cuckoo directory of 2-entry buckets, ~0.67 keys per bucket (1/3 load).  Keys prefer their first
-    // bucket; a key that ends up in its second bucket sets DIR_MOVED on its first one.
-    if (mkeys.size() >= 0x7FFFFFF0ull) return SS_ERANGE;
-    uint64_t n_dir = std::max<uint64_t>(16, buckets.size() + buckets.size() / 2);
-    std::vector<uint64_t> dir;
-    std::vector<uint32_t> dir_h;      // minimizer of each occupied slot (needed to re-place evicted keys)
-    std::vector<uint8_t> moved;
-    for (;; n_dir += n_dir / 4) {
-        if (n_dir >= 0xFFFFFFF0ull) return SS_ERANGE;
-        dir.assign(2 * n_dir, EMPTY_KEY);
-        dir_h.assign(2 * n_dir, 0);
-        moved.assign(n_dir, 0);
-        bool ok = true;
-        uint64_t rng = 0x9E3779B97F4A7C15ull;
-        auto place = [&](uint64_t cur, uint32_t h) -> bool {
-            for (int kicks = 0; kicks < 1000; kicks++) {
-                const uint32_t b1 = dir_bucket1(h, (uint32_t)n_dir), b2 = dir_bucket2(h, (uint32_t)n_dir);
-                for (uint64_t sl : {2 * (uint64_t)b1, 2 * (uint64_t)b1 + 1})
-                    if (dir[sl] == EMPTY_KEY) { dir[sl] = cur; dir_h[sl] = h; return true; }
-                moved[b1] = 1;                                     // from now on look in b2 as well
-                for (uint64_t sl : {2 * (uint64_t)b2, 2 * (uint64_t)b2 + 1})
-                    if (dir[sl] == EMPTY_KEY) { dir[sl] = cur; dir_h[sl] = h; return true; }
-                rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
-                const uint64_t victim = 2 * (uint64_t)((rng & 2) ? b1 : b2) + (rng & 1);
-                std::swap(cur, dir[victim]);                       // evict; the victim is re-placed next round
-                std::swap(h, dir_h[victim]);
-            }
-            return false;
-        };
-        for (const auto &b : buckets) {
-            const uint64_t e = ((uint64_t)dir_fp(b.first) << 50) | ((uint64_t)b.hdr << 32) | b.second;
-            if (!place(e, b.first)) { ok = false; break; }
-        }
-        if (ok) break;
-    }
-    for (uint64_t b = 0; b < n_dir; b++)
-        if (moved[b]) {
-            if (dir[2 * b] == EMPTY_KEY) std::swap(dir[2 * b], dir[2 * b + 1]);   // keep the flag carrier in entry 0
-            if (dir[2 * b] != EMPTY_KEY) dir[2 * b] |= DIR_MOVED;
-            // a flagged bucket cannot be empty: keys only move on from FULL buckets and evictions swap
-        }
-    const uint32_t dirbits = 0;
-    db->n_dir = (uint32_t)n_dir;
-    db->dirbits = dirbits;
-    db->n_buckets = buckets.size();
+    db->n_mslots = n_mslots;
+    db->n_slots = n_mslots + n_pages * PG_SLOTS;
+    db->n_dir = (uint32_t)n_pages;
+    db->dirbits = 0;
+    db->n_buckets = n_minis;
     db->capacity = db->n_slots;
-    lap("cuckoo directory");
-    // 4. upload
+    lap("4 pages");
+    // 5. upload
     const uint64_t nr = std::max<uint64_t>(1, n_rows);
-    SS_HIP(hipMalloc((void **)&db->d_mkeys, db->n_slots * sizeof(uint64_t)));
-    SS_HIP(hipMalloc((void **)&db->d_dir, dir.size() * sizeof(uint64_t)));
+    SS_HIP(hipMalloc((void **)&db->d_mkeys, n_mslots * sizeof(uint64_t)));
+    SS_HIP(hipMalloc((void **)&db->d_dir, pages.size()));
     SS_HIP(hipMalloc((void **)&db->d_counts, db->n_slots * sizeof(uint32_t)));
     SS_HIP(hipMalloc((void **)&db->d_slot_of_row, nr * sizeof(uint32_t)));
     SS_HIP(hipMalloc((void **)&db->d_row_valid, nr));
-    db->device_bytes = db->n_slots * 12 + dir.size() * 8 + nr * 5;
-    if (!mkeys.empty())
-        SS_HIP(hipMemcpy(db->d_mkeys, mkeys.data(), mkeys.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    else
-        SS_HIP(hipMemset(db->d_mkeys, 0xFF, sizeof(uint64_t)));
-    SS_HIP(hipMemcpy(db->d_dir, dir.data(), dir.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    db->device_bytes = n_mslots * 8 + db->n_slots * 4 + pages.size() + nr * 5;
+    SS_HIP(hipMemcpy(db->d_mkeys, mkeys.data(), n_mslots * sizeof(uint64_t), hipMemcpyHostToDevice));
+    SS_HIP(hipMemcpy(db->d_dir, pages.data(), pages.size(), hipMemcpyHostToDevice));
     SS_HIP(hipMemset(db->d_counts, 0, db->n_slots * sizeof(uint32_t)));
     {
-        // about 8 bits per minimizer, at most 2^25 bits = 4 MB (the L2 of one XCD): measured on the
-        // 25 M-row table 2^23: 4.71 ms, 2^25: 4.60 ms, 2^27: 5.29 ms, none: 6.0 ms.  SS_BLOOM_BITS=0 disables.
+        // Bloom filter over the minimizers, at most 2^25 bits = 4 MB (the L2 of one XCD; measured on a 25 M-row table of
+        // dense node sets -- 2.8 M minimizers -- 2^23: 4.71 ms, 2^25: 4.60 ms, 2^27: 5.29 ms, none: 6.0 ms), and only
+        // with >= 4 bits per minimizer: on a table of SAMPLED node sets (17 M minimizers) the filter passes 40 % of the
+        // absent minimizers, half of the runs find theirs anyway, and the scan is 7 % faster without it (7.73 -> 7.18 ms).
+        // SS_BLOOM_BITS=0 disables, = n forces 2^n bits.
         int bits = 10;
-        while (bits < 25 && (1ull << bits) < 8 * (uint64_t)buckets.size()) bits++;
+        while (bits < 25 && (1ull << bits) < 8 * n_minis) bits++;
+        if ((1ull << bits) < 4 * n_minis) bits = 0;
         const char *bb = getenv("SS_BLOOM_BITS");
         if (bb) bits = atoi(bb);
         if (bits >= 10 && bits <= 30) {
             std::vector<uint32_t> bloom((size_t)1 << (bits - 5), 0);
-            for (const auto &b : buckets) {
-                const uint32_t h = dir_mix(b.first) >> (32 - bits);
-                bloom[h >> 5] |= 1u << (h & 31u);
+            uint32_t last = ~0u;
+            for (const auto &it : items) {
+                if (it.h == last) continue;
+                last = it.h;
+                const uint32_t hb = it.h >> (30 - bits);
+                bloom[hb >> 5] |= 1u << (hb & 31u);
             }
             SS_HIP(hipMalloc((void **)&db->d_bloom, bloom.size() * 4));
             SS_HIP(hipMemcpy(db->d_bloom, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
@@ -819,7 +886,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     }
     SS_HIP(hipMemcpy(db->d_slot_of_row, slot_of_row.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
     SS_HIP(hipMemcpy(db->d_row_valid, row_valid.data(), nr, hipMemcpyHostToDevice));
-    lap("4 bloom + upload");
+    lap("5 bloom + upload");
     return SS_OK;
 }
 
@@ -827,12 +894,13 @@ template <int LB>
 static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const uint8_t *bases, uint64_t n,
                       uint64_t n_tiles, ss_db *db)
 {
-    if (aligned)
-        hipLaunchKernelGGL((scan_mini_kernel<true, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,
-                           db->d_mkeys, db->d_dir, db->n_dir, db->d_counts, db->d_bloom, 32u - db->bloom_bits);
-    else
-        hipLaunchKernelGGL((scan_mini_kernel<false, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,
-                           db->d_mkeys, db->d_dir, db->n_dir, db->d_counts, db->d_bloom, 32u - db->bloom_bits);
+    const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
+    const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
+#define SS_LAUNCH(A, B) hipLaunchKernelGGL((scan_mini_kernel<A, B, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
+                                           db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift)
+    if (db->d_bloom) { if (aligned) SS_LAUNCH(true, true); else SS_LAUNCH(false, true); }
+    else             { if (aligned) SS_LAUNCH(true, false); else SS_LAUNCH(false, false); }
+#undef SS_LAUNCH
 }
 
 #ifdef SS_TIMING
@@ -852,7 +920,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     static int lb = -1, bpc = 0;
     if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
         const char *e = getenv("SS_MINI_LB");
-        lb = e ? atoi(e) : 4;
+        lb = e ? atoi(e) : 8;
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
@@ -865,10 +933,9 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    case 5: launch_lb<5>(aligned, blocks, stream, b, n, n_tiles, db); break;
     case 6: launch_lb<6>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    case 7: launch_lb<7>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    default: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    case 4: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    default: launch_lb<8>(aligned, blocks, stream, b, n, n_tiles, db); break;
     }
     SS_HIP(hipGetLastError());
     return SS_OK;
@@ -882,9 +949,9 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct ImageHeader {
-    char magic[8];          // "SSIDX06\0"
+    char magic[8];          // "SSIDX07\0"
     int32_t k, layout;
-    uint64_t n_rows, n_distinct, n_slots, n_buckets;
+    uint64_t n_rows, n_distinct, n_slots, n_buckets, n_mslots;
     uint32_t n_dir, bloom_bits;
 };
 
@@ -957,14 +1024,15 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX06", 8);
+    memcpy(h.magic, "SSIDX07", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
+    h.n_mslots = db->n_mslots;
     h.n_dir = db->n_dir;
     h.bloom_bits = db->d_bloom ? db->bloom_bits : 0;
     const uint64_t nr = std::max<uint64_t>(1, db->n_rows);
-    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && write_dev(f, db->d_mkeys, db->n_slots * 8) &&
-              write_dev(f, db->d_dir, (uint64_t)db->n_dir * 16) && write_dev(f, db->d_slot_of_row, nr * 4) &&
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && write_dev(f, db->d_mkeys, db->n_mslots * 8) &&
+              write_dev(f, db->d_dir, (uint64_t)db->n_dir * 64) && write_dev(f, db->d_slot_of_row, nr * 4) &&
               write_dev(f, db->d_row_valid, nr) &&
               (!h.bloom_bits || write_dev(f, db->d_bloom, (1ull << h.bloom_bits) / 8));
     ok = (fclose(f) == 0) && ok;
@@ -979,13 +1047,14 @@ int ss_db_import(const char *path, ss_db **out)
     if (fd < 0) return SS_EIO;
     ImageHeader h;
     struct stat st;
-    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX06", 8) != 0 ||
-        h.layout != 1 || h.k != 31 || h.n_slots == 0 || h.n_dir == 0 || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
+    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX07", 8) != 0 ||
+        h.layout != 1 || h.k != 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_slots != h.n_mslots + (uint64_t)h.n_dir * 8 ||
+        h.n_slots >= 0xFFFFFFF0ull || h.n_mslots >= (uint64_t)ss::START_MASK || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         close(fd);
         return SS_EINVAL;
     }
     const uint64_t nr = std::max<uint64_t>(1, h.n_rows);
-    const uint64_t sizes[5] = {h.n_slots * 8, (uint64_t)h.n_dir * 16, nr * 4, nr, h.bloom_bits ? (1ull << h.bloom_bits) / 8 : 0};
+    const uint64_t sizes[5] = {h.n_mslots * 8, (uint64_t)h.n_dir * 64, nr * 4, nr, h.bloom_bits ? (1ull << h.bloom_bits) / 8 : 0};
     uint64_t offs[6] = {sizeof(h), 0, 0, 0, 0, 0};
     for (int i = 0; i < 5; i++) offs[i + 1] = offs[i] + sizes[i];
     if ((uint64_t)st.st_size != offs[5]) { close(fd); return SS_EIO; }     // the file must be exactly the image
@@ -993,6 +1062,7 @@ int ss_db_import(const char *path, ss_db **out)
     if (!db) { close(fd); return SS_ENOMEM; }
     db->k = h.k; db->layout = 1;
     db->n_rows = h.n_rows; db->n_distinct = h.n_distinct; db->n_slots = h.n_slots; db->capacity = h.n_slots;
+    db->n_mslots = h.n_mslots;
     db->n_buckets = h.n_buckets; db->n_dir = h.n_dir;
     hipGetDevice(&db->device);
     bool ok = hipMalloc((void **)&db->d_mkeys, sizes[0]) == hipSuccess && hipMalloc((void **)&db->d_dir, sizes[1]) == hipSuccess &&
@@ -1009,7 +1079,7 @@ int ss_db_import(const char *path, ss_db **out)
     close(fd);
     if (ok && h.bloom_bits) db->bloom_bits = h.bloom_bits;
     if (!ok) { ss_db_destroy(db); return SS_EIO; }
-    db->device_bytes = db->n_slots * 12 + (uint64_t)db->n_dir * 16 + nr * 5 + sizes[4];
+    db->device_bytes = db->n_mslots * 8 + db->n_slots * 4 + (uint64_t)db->n_dir * 64 + nr * 5 + sizes[4];
     *out = db;
     return SS_OK;
 }

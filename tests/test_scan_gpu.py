@@ -515,3 +515,109 @@ def test_revcomp_device_and_host_vs_golden(L, golden_dir):
     for ln in (1, 31, 150, 1000):
         seqs = [rs.randint(0, 256, size=ln).astype(np.uint8).tobytes() for _ in range(257)]
         assert dev_revcomp(seqs) == [L.revcomp(x) for x in seqs]
+
+
+def _sampled_db_and_reads(seed, n_genome, density, n_reads, read_len=150, k=31):
+    """A database as Build_tree.py:590-591 writes it for a node above its cap: a uniform random subset of the
+    (k-mer, orientation) entries of a genome -- forward and reverse complement drawn independently --, rows in
+    shuffled order; reads from the same genome (both strands, 0.5 % substitutions, a few N, ragged lengths).
+    Returns (device keys, oracle keys, flat read block)."""
+    rs = np.random.RandomState(seed)
+    codes = rs.randint(0, 4, size=n_genome).astype(np.uint64)             # device code: A0 C1 T2 G3
+    n_sites = n_genome - k + 1
+    dev = np.zeros(n_sites, np.uint64)
+    rc = np.zeros(n_sites, np.uint64)
+    okey = np.zeros(n_sites, np.uint64)
+    orc_ = np.zeros(n_sites, np.uint64)
+    to_or = np.array([0, 1, 3, 2], np.uint64)
+    for j in range(k):
+        cj = codes[j:j + n_sites]
+        dev |= cj << np.uint64(2 * j)
+        rc |= (cj ^ np.uint64(2)) << np.uint64(2 * (k - 1 - j))
+        oj = to_or[cj]
+        okey |= oj << np.uint64(2 * (k - 1 - j))
+        orc_ |= (np.uint64(3) - oj) << np.uint64(2 * j)
+    f = np.nonzero(rs.random_sample(n_sites) < density)[0]
+    r = np.nonzero(rs.random_sample(n_sites) < density)[0]
+    keys = np.concatenate([dev[f], rc[r]])
+    okeys = np.concatenate([okey[f], orc_[r]])
+    perm = rs.permutation(keys.size)
+    asc = np.frombuffer(b"ACTG", np.uint8)[codes.astype(np.int64)]
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGTN")] = list(b"TGCAN")
+    starts = rs.randint(0, n_genome - read_len, size=n_reads)
+    lens = np.where(rs.random_sample(n_reads) < 0.9, read_len, rs.randint(20, read_len + 1, size=n_reads))
+    recs = []
+    for s, ln in zip(starts, lens):
+        x = asc[s:s + ln].copy()
+        m = rs.random_sample(ln) < 0.005
+        x[m] = np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=int(m.sum()))]
+        if rs.random_sample() < 0.03:
+            x[rs.randint(0, ln)] = ord("N")
+        if rs.random_sample() < 0.5:
+            x = comp[x][::-1]
+        recs.append(x.tobytes())
+    return keys[perm].copy(), okeys[perm].copy(), b"\n".join(recs) + b"\n"
+
+
+def _check_sampled(L, keys, okeys, flat, env):
+    from oracle import oracle as orc
+    old = {k_: os.environ.get(k_) for k_ in env}
+    os.environ.update(env)
+    try:
+        db = L.KmerDB(keys, np.ones(keys.size, np.uint8), 31, True)
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    want = orc.count_flat(okeys, 31, np.frombuffer(flat, np.uint8), 4)
+    info = db.info()
+    db.scan_flat(flat)
+    got = db.counts_rows()
+    assert np.array_equal(got, want), (env, int((got != want).sum()))
+    assert int(want.sum()) > 100000
+    db.close()
+    return info
+
+
+def test_sampled_database_vs_oracle(L):
+    """The database shape the reference's builder writes for large nodes (Build_tree.py:590-591): nearly every
+    k-mer alone under its minimizer.  1.2 M rows, checked bit for bit against the oracle with the index built five
+    ways: default (k-mers of small minimizer sets inline in the pages, no Bloom filter), everything by bucket
+    reference, everything up to 8 k-mers inline, pages packed until most are full (lookups read on into the next
+    pages), and with a forced Bloom filter."""
+    keys, okeys, flat = _sampled_db_and_reads(77, 8_000_000, 0.075, 40000)
+    assert keys.size > 1_000_000
+    info = _check_sampled(L, keys, okeys, flat, {})                               # small table: Bloom filter built
+    assert info["n_buckets"] > 0.6 * keys.size and info["filter_bits"] > 0       # sampled: ~one minimizer per k-mer
+    info = _check_sampled(L, keys, okeys, flat, {"SS_BLOOM_BITS": "0"})           # as for a 25 M-row sampled table
+    assert info["filter_bits"] == 0
+    _check_sampled(L, keys, okeys, flat, {"SS_BLOOM_BITS": "0", "SS_INLINE_MAX": "0"})
+    _check_sampled(L, keys, okeys, flat, {"SS_BLOOM_BITS": "0", "SS_INLINE_MAX": "8"})
+    _check_sampled(L, keys, okeys, flat, {"SS_BLOOM_BITS": "0", "SS_PAGE_LAMBDA": "6.0"})
+    _check_sampled(L, keys, okeys, flat, {"SS_PAGE_LAMBDA": "6.0", "SS_INLINE_MAX": "8", "SS_BLOOM_BITS": "22"})
+
+
+def test_sampled_database_tiny_queues():
+    """... and against the build with 64-entry LDS queues (every tile overflows them: the inline paths settle the runs)."""
+    import subprocess
+    import sys
+    from strainscan_amd import _lib
+    tiny = os.path.join(os.path.dirname(_lib.LIB_PATH), "libstrainscan_hip_tinyq.so")
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from strainscan_amd import _lib\n"
+        "from tests.test_scan_gpu import _sampled_db_and_reads, _check_sampled\n"
+        "assert _lib.LIB_PATH.endswith('tinyq.so')\n"
+        "keys, okeys, flat = _sampled_db_and_reads(78, 3_000_000, 0.08, 20000)\n"
+        "_check_sampled(_lib, keys, okeys, flat, {})\n"
+        "_check_sampled(_lib, keys, okeys, flat, {'SS_BLOOM_BITS': '0'})\n"
+        "_check_sampled(_lib, keys, okeys, flat, {'SS_PAGE_LAMBDA': '6.0', 'SS_BLOOM_BITS': '0', 'SS_INLINE_MAX': '8'})\n"
+        "_check_sampled(_lib, keys, okeys, flat, {'SS_PAGE_LAMBDA': '6.0', 'SS_BLOOM_BITS': '20'})\n"
+        "print('tinyq sampled ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, SS_LIB=tiny)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "tinyq sampled ok" in out.stdout, out.stderr[-2000:]
