@@ -6,12 +6,17 @@ Workload (BASELINE.json configs[1]): synthetic E. coli-shaped database -- 823 le
 about 25 M rows in all -- and 10 M pairs = 20 M synthetic 150-bp reads of a 70/20/10 three-strain
 mix (strand 50/50, 0.5 % substitutions), all resident in HBM before the timed region.
 
+--db-shape sampled (default) draws every node's rows as a random 1.5-10 % sample of a longer stretch, both
+orientations independently, rows scattered over kmer.fa -- what the reference's builder writes for a
+node above its cap (Build_tree.py:590-591); --db-shape contiguous keeps every k-mer of a stretch.
+
 One step = one pass of the hot path over the whole read batch on each GPU:
-    reset counters -> encode+probe+count kernel over the flat base block -> gather slot counts
-    to kmer.fa rows -> [N > 1: RCCL all-reduce of the uint32 row counts] -> per-node reductions
-    (length / covered / outlier-cut sums for all 1645 nodes).
+    reset counters -> encode+probe+count kernel over the flat base block -> harvest (non-zero
+    counters to their node-list positions) -> [N > 1: RCCL exchange of the touched nodes' counts]
+    -> per-node reductions (length / covered / outlier-cut sums for all 1645 nodes).
 `value` = reads of all ranks / max-over-ranks step time.  Weak scaling: every rank scans its
-own 20 M-read shard (reads shard, the table is replicated).
+own 20 M-read shard (reads shard, the table is replicated).  `python bench.py --gpus N` starts the
+N ranks itself; under torchrun it checks WORLD_SIZE == N.
 
 Extra objects on the JSON line:
   roofline     -- the scan kernel against the HBM roof: algorithmic bytes per launch
@@ -256,9 +261,9 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.check(_lib.lib().ss_set_device(local), "ss_set_device")
-    # SS_BENCH_FORCE_PIPELINE=2: run the N > 1 code path (async RCCL all-reduce + deferred node reduction) in a
-    # one-rank group, to test it on a single-GPU box
-    self_group = world == 1 and os.environ.get("SS_BENCH_FORCE_PIPELINE") == "2"
+    # SS_BENCH_FORCE_EXCHANGE=1: run the N > 1 code path (RCCL exchange of the touched nodes) in a one-rank group, to
+    # test it on a single-GPU box
+    self_group = world == 1 and bool(os.environ.get("SS_BENCH_FORCE_EXCHANGE") or os.environ.get("SS_BENCH_FORCE_PIPELINE"))
     if world > 1 or self_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -290,55 +295,42 @@ def main(argv=None):
     log("[bench] reads: %d x %d bp = %.2f GB in HBM (%.1f s)" % (args.reads, READ_LEN, reads.numel() / 1e9,
                                                                  time.time() - t0))
 
-    # two row-count buffers: with N > 1 the all-reduce of batch i runs on RCCL's stream while batch i + 1
-    # is being scanned (the per-node reduction of batch i is enqueued one step later, after the collective)
-    bufs = [torch.zeros(n_rows, dtype=torch.int32, device=dev) for _ in range(2)]
+    # One step = reset the counters -> scan kernel -> harvest (one streaming pass over the counters: the non-zero ones
+    # go to their node-list positions, their nodes are flagged) -> [N > 1: RCCL exchange of the touched nodes: flags
+    # MAX-all-reduced, their segments packed, SUM-all-reduced, unpacked] -> per-node reductions.
+    from strainscan_amd import dist as ssdist
+    nodes.bind(db)
     stats = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    pipelined = world > 1 or bool(os.environ.get("SS_BENCH_FORCE_PIPELINE"))
-    state = dict(k=0, pending=None, last=bufs[0])
-
-    def finish(work, buf):
-        if work is not None:
-            work.wait()                        # the compute stream waits for the collective
-        nodes.reduce_dev(buf.data_ptr(), db.row_valid_dev, stats.data_ptr(), stream)
-        state["last"] = buf
-
-    def drain():
-        if state["pending"] is not None:
-            finish(*state["pending"])
-            state["pending"] = None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    exchange = world > 1 or self_group
+    packed = dict(n=0)
 
     def step(i=None):
-        buf = bufs[state["k"] % 2]
-        state["k"] += 1
         db.reset(stream)
         if i is not None:
             ev[i][0].record()
         db.scan_flat_dev(reads.data_ptr(), reads.numel(), stream)
         if i is not None:
             ev[i][1].record()
-        db.counts_rows_dev(buf.data_ptr(), stream)
-        if not pipelined:
-            finish(None, buf)
-            return
-        # RCCL sum of the per-GPU hit-count vectors (int32 view of uint32: two's-complement add)
-        work = dist.all_reduce(buf, async_op=True) if (world > 1 or self_group) else None
-        drain()                                # batch i - 1: wait for its collective, reduce its nodes
-        state["pending"] = (work, buf)
+        nodes.harvest_dev(db, stream)
+        if i is not None:
+            ev[i][2].record()
+        if exchange:
+            packed["n"] = ssdist.exchange_touched(nodes, stream=stream)
+        nodes.reduce_touched_dev(stats.data_ptr(), stream)
+        if i is not None:
+            ev[i][3].record()
 
     for _ in range(args.warmup):
         step()
-    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -348,12 +340,23 @@ def main(argv=None):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    counts_rows = state["last"]
     ms_per_step = dt / args.steps * 1e3
     reads_per_s = args.reads * world * args.steps / dt
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    hits = int(counts_rows.to(torch.int64).sum().item())
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    harvest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    tail_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))     # [exchange +] node reductions
     st_np = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
+    # the counters of the last step are still in the table (a step resets them at its start): whole-table checksum,
+    # and the harvest path against the row-gather path it replaces (ss_counts_rows_dev + ss_nodes_reduce_dev)
+    counts_rows = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    db.counts_rows_dev(counts_rows.data_ptr(), stream)
+    hits = int(counts_rows.to(torch.int64).sum().item())
+    stats2 = torch.zeros_like(stats)
+    if exchange:
+        ssdist.allreduce_counts(counts_rows)
+    nodes.reduce_dev(counts_rows.data_ptr(), db.row_valid_dev, stats2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    harvest_equals_gather = bool(torch.equal(stats, stats2))
 
     achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
     traffic = None
@@ -418,7 +421,10 @@ def main(argv=None):
                                table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
                    roofline=roofline, cpu_baseline=cpu,
-                   check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum())))
+                   check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
+                              harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"]),
+                   step_breakdown_ms=dict(scan_kernel=round(kern_ms, 3), harvest=round(harvest_ms, 3),
+                                          exchange_and_node_reduce=round(tail_ms, 3)))
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or self_group:
         dist.destroy_process_group()

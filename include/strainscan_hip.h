@@ -207,6 +207,22 @@ int ss_nodes_destroy(ss_nodes *ns);
 int ss_nodes_reduce_dev(const ss_nodes *ns, const uint32_t *counts_rows_dev, const uint8_t *row_valid_dev,
                         ss_node_stat *stats_dev, void *stream);
 int ss_nodes_reduce(const ss_nodes *ns, const ss_db *db, ss_node_stat *stats /* host, n_nodes */);
+/* Harvest path: the same statistics without touching every row of every node (ss_nodes.hip).  match_node reads
+ * <db>/kmers/<id> and looks every row up in the dump (identify.py:116-124) for each visited node; a sample has
+ * hits in a few dozen of an E. coli database's 1645 nodes.
+ *   ss_nodes_bind               once per (node set, database): (counter, list position) pairs sorted by counter
+ *   ss_nodes_harvest_dev        after a scan: one streaming pass moves the non-zero counters to their list positions
+ *                               in a node-major buffer and flags their nodes
+ *   ss_nodes_reduce_touched_dev statistics of all nodes (untouched ones: length, zeros), buffer and flags cleared
+ * Several GPUs, between the two (dist.py): touched flags MAX-all-reduced (get/set), the touched nodes' segments packed
+ * (ss_nodes_pack_dev; packed_dev = NULL only returns the size; needs a host sync for that size), summed, unpacked. */
+int ss_nodes_bind(ss_nodes *ns, const ss_db *db);
+int ss_nodes_harvest_dev(ss_nodes *ns, const ss_db *db, void *stream);
+int ss_nodes_reduce_touched_dev(ss_nodes *ns, ss_node_stat *stats_dev, void *stream);
+int ss_nodes_touched_get_dev(const ss_nodes *ns, uint32_t *flags_dev, void *stream);
+int ss_nodes_touched_set_dev(ss_nodes *ns, const uint32_t *flags_dev, void *stream);
+int ss_nodes_pack_dev(ss_nodes *ns, uint32_t *packed_dev, uint64_t cap, uint64_t *n_packed, void *stream);
+int ss_nodes_unpack_dev(ss_nodes *ns, const uint32_t *packed_dev, void *stream);
 /* one ad-hoc row list (adjust_profile's `remain` set, identify.py:181-189) */
 int ss_rows_reduce(const ss_db *db, const uint32_t *rows, uint64_t n, ss_node_stat *stat);
 

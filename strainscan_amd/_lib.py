@@ -94,6 +94,13 @@ SIGNATURES = {
     "ss_nodes_destroy": (i32, [vp]),
     "ss_nodes_reduce_dev": (i32, [vp, vp, vp, vp, vp]),
     "ss_nodes_reduce": (i32, [vp, vp, vp]),
+    "ss_nodes_bind": (i32, [vp, vp]),
+    "ss_nodes_harvest_dev": (i32, [vp, vp, vp]),
+    "ss_nodes_reduce_touched_dev": (i32, [vp, vp, vp]),
+    "ss_nodes_touched_get_dev": (i32, [vp, vp, vp]),
+    "ss_nodes_touched_set_dev": (i32, [vp, vp, vp]),
+    "ss_nodes_pack_dev": (i32, [vp, vp, u64, P(u64), vp]),
+    "ss_nodes_unpack_dev": (i32, [vp, vp, vp]),
     "ss_rows_reduce": (i32, [vp, vp, u64, P(NodeStat)]),
     "ss_l2_create": (i32, [vp, vp, u64, u32, P(vp)]),
     "ss_l2_create_planes": (i32, [vp, u64, u32, P(vp)]),
@@ -364,6 +371,39 @@ class NodeSet:
     def reduce(self, db):
         st = np.zeros(self.n_nodes, NODE_STAT_DTYPE)
         check(lib().ss_nodes_reduce(self._h, db.handle, ptr(st)), "ss_nodes_reduce")
+        return st
+
+    # -- harvest path (ss_nodes.hip): bind once per database, then per scan harvest + reduce over the touched nodes
+    def bind(self, db):
+        check(lib().ss_nodes_bind(self._h, db.handle), "ss_nodes_bind")
+        self._bound = db
+        return self
+
+    def harvest_dev(self, db, stream=None):
+        check(lib().ss_nodes_harvest_dev(self._h, db.handle, stream), "ss_nodes_harvest_dev")
+
+    def reduce_touched_dev(self, stats_dptr, stream=None):
+        check(lib().ss_nodes_reduce_touched_dev(self._h, stats_dptr, stream), "ss_nodes_reduce_touched_dev")
+
+    def harvest(self, db, between=None):
+        """Statistics of all nodes from the counters of `db` (bound): harvest, [between(self): the multi-GPU
+        exchange], reduce over the touched nodes."""
+        if getattr(self, "_bound", None) is not db:
+            self.bind(db)
+        dst = C.c_void_p()
+        nbytes = max(1, self.n_nodes) * NODE_STAT_DTYPE.itemsize
+        check(lib().ss_dev_alloc(C.byref(dst), nbytes), "ss_dev_alloc")
+        try:
+            self.harvest_dev(db)
+            if between is not None:
+                between(self)
+            self.reduce_touched_dev(dst)
+            st = np.zeros(self.n_nodes, NODE_STAT_DTYPE)
+            if self.n_nodes:
+                check(lib().ss_memcpy_d2h(ptr(st), dst, self.n_nodes * NODE_STAT_DTYPE.itemsize, None), "ss_memcpy_d2h")
+            check(lib().ss_device_sync(), "ss_device_sync")
+        finally:
+            lib().ss_dev_free(dst)
         return st
 
     def reduce_dev(self, counts_rows_dptr, row_valid_dptr, stats_dptr, stream=None):

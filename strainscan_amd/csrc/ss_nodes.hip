@@ -14,7 +14,18 @@
 // Positive counts are kept as 16-bit values (32768 of them); a node with more, or with a count >= 65535,
 // falls back to those passes over global memory.
 // Algorithmic bytes: 4 B row index + 4 B count + 1 B valid flag per node k-mer.
+//
+// Harvest path (ss_nodes_bind + ss_nodes_harvest_dev + ss_nodes_reduce_touched_dev): the gather above touches every
+// row of every node -- 25 M random counter reads for an E. coli table whose rows lie scattered over the index -- although
+// a sample has hits in a few dozen of the 1645 nodes.  Binding a node set to a database sorts the (counter, list position)
+// pairs of all nodes by counter once; after a scan ONE streaming pass over that sorted list reads the counters in
+// ascending order (sectors of the counter array, no gathers), writes the non-zero ones to their list positions in a
+// dense node-major buffer and flags their nodes; the reduction then runs over the flagged nodes only, from contiguous
+// memory, and clears what it read.  Several GPUs: flags MAX-all-reduced, the flagged segments packed, summed (RCCL),
+// unpacked -- a few MB instead of 4 bytes per database row (dist.py).
 #include "ss_common.h"
+
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -27,6 +38,16 @@ struct ss_nodes {
     ss_node_stat *d_stats = nullptr;
     uint32_t *d_counts_rows = nullptr;  // scratch for the single-GPU convenience entry point
     uint64_t counts_rows_cap = 0;
+    // bound to one database (harvest path)
+    const ss_db *bound = nullptr;
+    uint64_t n_used = 0;                // list positions whose row is valid
+    uint32_t *d_pkeys = nullptr;        // [n_used] counter index, ascending
+    uint32_t *d_ppos = nullptr;         // [n_used] list position of that entry
+    uint32_t *d_pnode = nullptr;        // [n_used] node of that list position
+    uint32_t *d_len = nullptr;          // [n_nodes] valid rows per node (the `length` of match_node: static)
+    uint32_t *d_val = nullptr;          // [n_rows_total] counts by list position, zero outside a harvest..reduce window
+    uint32_t *d_touched = nullptr;      // [n_nodes] 1 = the node has a non-zero count
+    uint64_t *d_packoff = nullptr;      // [n_nodes + 1] offsets of the touched nodes' segments in the packed buffer
 };
 
 namespace {
@@ -65,11 +86,16 @@ __device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *s_red)
     return r;
 }
 
+// DENSE: counts = the node-major buffer of the harvest path (entry i = list position i, invalid rows and rows without
+// hits hold 0), rows unused, valid = nullptr, len_static / touched given; the kernel clears what it read.
+template <bool DENSE>
 __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restrict__ rows,
                                                          const uint64_t *__restrict__ offsets,
-                                                         const uint32_t *__restrict__ counts,
+                                                         uint32_t *__restrict__ counts,
                                                          const uint8_t *__restrict__ valid,
-                                                         ss_node_stat *__restrict__ stats)
+                                                         ss_node_stat *__restrict__ stats,
+                                                         const uint32_t *__restrict__ len_static,
+                                                         uint32_t *__restrict__ touched)
 {
     __shared__ uint16_t s_val[CAP];
     __shared__ uint32_t s_hist[256];
@@ -81,6 +107,14 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
     const uint32_t node = blockIdx.x;
     const uint64_t lo = offsets[node], hi = offsets[node + 1];
     const int t = threadIdx.x;
+    if (DENSE && !touched[node]) {           // no hits in this node (most nodes of a sample)
+        if (t == 0) {
+            ss_node_stat st;
+            st.length = len_static[node]; st.n_pos = 0; st.n_kept = 0; st.reserved = 0; st.sum_kept = 0; st.median2 = 0;
+            stats[node] = st;
+        }
+        return;
+    }
     if (t == 0) s_n = 0;
     __syncthreads();
 
@@ -102,8 +136,12 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
     {
         uint64_t i = lo + t;
         for (; i + 3 * NT < hi; i += 4 * NT) {
-            const uint32_t r0 = rows[i], r1 = rows[i + NT], r2 = rows[i + 2 * NT], r3 = rows[i + 3 * NT];
-            const uint32_t v0 = valid[r0], v1 = valid[r1], v2 = valid[r2], v3 = valid[r3];
+            uint32_t r0, r1, r2, r3, v0 = 1, v1 = 1, v2 = 1, v3 = 1;
+            if (DENSE) { r0 = (uint32_t)i; r1 = r0 + NT; r2 = r0 + 2 * NT; r3 = r0 + 3 * NT; }
+            else {
+                r0 = rows[i]; r1 = rows[i + NT]; r2 = rows[i + 2 * NT]; r3 = rows[i + 3 * NT];
+                v0 = valid[r0]; v1 = valid[r1]; v2 = valid[r2]; v3 = valid[r3];
+            }
             const uint32_t c0 = counts[r0], c1 = counts[r1], c2 = counts[r2], c3 = counts[r3];
             len += (v0 != 0) + (v1 != 0) + (v2 != 0) + (v3 != 0);
             keep(v0 && c0, c0); keep(v1 && c1, c1); keep(v2 && c2, c2); keep(v3 && c3, c3);
@@ -114,8 +152,8 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
             const uint64_t j = i0 + t;
             uint32_t v = 0, c = 0;
             if (j < hi) {
-                const uint32_t r = rows[j];
-                v = valid[r];
+                const uint32_t r = DENSE ? (uint32_t)j : rows[j];
+                v = DENSE ? 1u : valid[r];
                 c = counts[r];
             }
             len += (v != 0);
@@ -134,8 +172,8 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
             for (uint32_t i = (uint32_t)t; i < (uint32_t)npos; i += NT) f(s_val[i]);
         } else {
             for (uint64_t i = lo + t; i < hi; i += NT) {
-                const uint32_t r = rows[i];
-                if (!valid[r]) continue;
+                const uint32_t r = DENSE ? (uint32_t)i : rows[i];
+                if (!DENSE && !valid[r]) continue;
                 const uint32_t c = counts[r];
                 if (c) f(c);
             }
@@ -194,6 +232,11 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
         });
     nk = block_sum(nk, s_red64);
     sk = block_sum(sk, s_red64);
+    if (DENSE) {                              // leave the buffer and the flag clean for the next scan
+        for (uint64_t i = lo + t; i < hi; i += NT) counts[i] = 0;
+        if (t == 0) touched[node] = 0;
+        len = len_static[node];
+    }
     if (t == 0) {
         ss_node_stat st;
         st.length = (uint32_t)len;
@@ -203,6 +246,114 @@ __global__ __launch_bounds__(NT) void node_reduce_kernel(const uint32_t *__restr
         st.sum_kept = sk;
         st.median2 = med2;
         stats[node] = st;
+    }
+}
+
+// ---- harvest path ---------------------------------------------------------------------------------
+__global__ void bind_cslot_kernel(const uint32_t *__restrict__ rows, uint64_t n, const uint32_t *__restrict__ slot_of_row,
+                                  const uint8_t *__restrict__ valid, uint64_t n_db_rows, uint32_t *__restrict__ keys,
+                                  uint32_t *__restrict__ pos)
+{
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = rows[p];
+        keys[p] = (r < n_db_rows && valid[r]) ? slot_of_row[r] : SS_NO_SLOT;
+        pos[p] = (uint32_t)p;
+    }
+}
+
+// node of a list position: the last offset <= p
+__device__ __forceinline__ uint32_t node_of_pos(const uint64_t *__restrict__ offsets, uint32_t n_nodes, uint64_t p)
+{
+    uint32_t lo = 0, hi = n_nodes;             // offsets[lo] <= p < offsets[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void bind_node_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ pos, uint64_t n,
+                                 const uint64_t *__restrict__ offsets, uint32_t n_nodes, uint32_t *__restrict__ pnode)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (keys[i] == SS_NO_SLOT) continue;    // sorted: the invalid positions are the tail
+        pnode[i] = node_of_pos(offsets, n_nodes, pos[i]);
+    }
+}
+
+// valid rows per node (keys in list order, before the sort): one block per node
+__global__ __launch_bounds__(256) void bind_len_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ offsets,
+                                                       uint32_t *__restrict__ len)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t c = 0;
+    for (uint64_t i = offsets[blockIdx.x] + threadIdx.x; i < offsets[blockIdx.x + 1]; i += 256) c += keys[i] != SS_NO_SLOT;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) len[blockIdx.x] = s_cnt;
+}
+
+// one streaming pass: counters in ascending order -> list positions of the dense buffer, node flags
+__global__ __launch_bounds__(256) void harvest_kernel(const uint32_t *__restrict__ pkeys, const uint32_t *__restrict__ ppos,
+                                                      const uint32_t *__restrict__ pnode, uint64_t n_used,
+                                                      const uint32_t *__restrict__ counts, uint32_t *__restrict__ val,
+                                                      uint32_t *__restrict__ touched)
+{
+    const uint64_t n4 = n_used >> 2;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 k = reinterpret_cast<const uint4 *>(pkeys)[q];
+        const uint32_t c0 = counts[k.x], c1 = counts[k.y], c2 = counts[k.z], c3 = counts[k.w];
+        if (c0 | c1 | c2 | c3) {
+            const uint64_t i = q << 2;
+            if (c0) { val[ppos[i]] = c0; touched[pnode[i]] = 1u; }
+            if (c1) { val[ppos[i + 1]] = c1; touched[pnode[i + 1]] = 1u; }
+            if (c2) { val[ppos[i + 2]] = c2; touched[pnode[i + 2]] = 1u; }
+            if (c3) { val[ppos[i + 3]] = c3; touched[pnode[i + 3]] = 1u; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_used & 3)) {
+        const uint64_t i = (n4 << 2) + threadIdx.x;
+        const uint32_t c = counts[pkeys[i]];
+        if (c) { val[ppos[i]] = c; touched[pnode[i]] = 1u; }
+    }
+}
+
+// offsets of the touched nodes' segments in a packed buffer (one block; n_nodes is a few thousand)
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const uint32_t *__restrict__ touched, const uint64_t *__restrict__ offsets,
+                                                            uint32_t n_nodes, uint64_t *__restrict__ packoff)
+{
+    __shared__ uint64_t s_part[1024];
+    const int t = threadIdx.x;
+    const uint32_t per = (n_nodes + 1023u) / 1024u, a = min(n_nodes, (uint32_t)t * per), b = min(n_nodes, a + per);
+    uint64_t sum = 0;
+    for (uint32_t i = a; i < b; i++) sum += touched[i] ? offsets[i + 1] - offsets[i] : 0;
+    s_part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; i++) { const uint64_t v = s_part[i]; s_part[i] = run; run += v; }
+        packoff[n_nodes] = run;
+    }
+    __syncthreads();
+    uint64_t run = s_part[t];
+    for (uint32_t i = a; i < b; i++) { packoff[i] = run; run += touched[i] ? offsets[i + 1] - offsets[i] : 0; }
+}
+
+// PACK: packed <- val segments of the touched nodes; else the other way round
+template <bool PACK>
+__global__ __launch_bounds__(256) void pack_copy_kernel(const uint32_t *__restrict__ touched, const uint64_t *__restrict__ offsets,
+                                                        const uint64_t *__restrict__ packoff, uint32_t *__restrict__ val,
+                                                        uint32_t *__restrict__ packed)
+{
+    const uint32_t node = blockIdx.x;
+    if (!touched[node]) return;
+    const uint64_t lo = offsets[node], n = offsets[node + 1] - lo, po = packoff[node];
+    for (uint64_t i = threadIdx.x; i < n; i += 256) {
+        if (PACK) packed[po + i] = val[lo + i];
+        else val[lo + i] = packed[po + i];
     }
 }
 
@@ -239,7 +390,120 @@ int ss_nodes_destroy(ss_nodes *ns)
     hipFree(ns->d_offsets);
     hipFree(ns->d_stats);
     hipFree(ns->d_counts_rows);
+    hipFree(ns->d_pkeys); hipFree(ns->d_ppos); hipFree(ns->d_pnode); hipFree(ns->d_len); hipFree(ns->d_val);
+    hipFree(ns->d_touched); hipFree(ns->d_packoff);
     delete ns;
+    return SS_OK;
+}
+
+int ss_nodes_bind(ss_nodes *ns, const ss_db *db)
+{
+    if (!ns || !db) return SS_EINVAL;
+    if (ns->bound == db) return SS_OK;
+    hipFree(ns->d_pkeys); hipFree(ns->d_ppos); hipFree(ns->d_pnode); hipFree(ns->d_len); hipFree(ns->d_val);
+    hipFree(ns->d_touched); hipFree(ns->d_packoff);
+    ns->d_pkeys = ns->d_ppos = ns->d_pnode = ns->d_len = ns->d_val = ns->d_touched = nullptr;
+    ns->d_packoff = nullptr;
+    ns->bound = nullptr;
+    const uint64_t n = ns->n_rows_total, n1 = std::max<uint64_t>(1, n), nn = std::max<uint32_t>(1, ns->n_nodes);
+    if (n >= 0xFFFFFFF0ull) return SS_ERANGE;
+    uint32_t *k_in = nullptr, *p_in = nullptr;
+    void *tmp = nullptr;
+    auto cleanup = [&] { hipFree(k_in); hipFree(p_in); hipFree(tmp); };
+#define SS_B(call) do { if ((call) != hipSuccess) { cleanup(); ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); return SS_EHIP; } } while (0)
+    SS_B(hipMalloc((void **)&k_in, n1 * 4)); SS_B(hipMalloc((void **)&p_in, n1 * 4));
+    SS_B(hipMalloc((void **)&ns->d_pkeys, n1 * 4)); SS_B(hipMalloc((void **)&ns->d_ppos, n1 * 4));
+    SS_B(hipMalloc((void **)&ns->d_pnode, n1 * 4)); SS_B(hipMalloc((void **)&ns->d_val, n1 * 4));
+    SS_B(hipMalloc((void **)&ns->d_len, nn * 4)); SS_B(hipMalloc((void **)&ns->d_touched, nn * 4));
+    SS_B(hipMalloc((void **)&ns->d_packoff, ((uint64_t)nn + 1) * 8));
+    SS_B(hipMemset(ns->d_val, 0, n1 * 4)); SS_B(hipMemset(ns->d_len, 0, nn * 4)); SS_B(hipMemset(ns->d_touched, 0, nn * 4));
+    if (n) {
+        uint64_t n_db_rows = 0;
+        ss_db_info(db, &n_db_rows, nullptr, nullptr, nullptr);
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 65536);
+        hipLaunchKernelGGL(bind_cslot_kernel, dim3(blocks), dim3(256), 0, 0, ns->d_rows, n, db->d_slot_of_row, db->d_row_valid,
+                           n_db_rows, k_in, p_in);
+        hipLaunchKernelGGL(bind_len_kernel, dim3(ns->n_nodes), dim3(256), 0, 0, k_in, ns->d_offsets, ns->d_len);
+        size_t tmp_bytes = 0;
+        SS_B(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, ns->d_pkeys, p_in, ns->d_ppos, (int)n));
+        SS_B(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        SS_B(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k_in, ns->d_pkeys, p_in, ns->d_ppos, (int)n));
+        hipLaunchKernelGGL(bind_node_kernel, dim3(blocks), dim3(256), 0, 0, ns->d_pkeys, ns->d_ppos, n, ns->d_offsets, ns->n_nodes,
+                           ns->d_pnode);
+        SS_B(hipGetLastError());
+    }
+    std::vector<uint32_t> len(nn, 0);
+    SS_B(hipMemcpy(len.data(), ns->d_len, (uint64_t)nn * 4, hipMemcpyDeviceToHost));
+#undef SS_B
+    cleanup();
+    uint64_t used = 0;
+    for (uint32_t i = 0; i < ns->n_nodes; i++) used += len[i];
+    ns->n_used = used;
+    ns->bound = db;
+    return SS_OK;
+}
+
+int ss_nodes_harvest_dev(ss_nodes *ns, const ss_db *db, void *stream)
+{
+    if (!ns || !db || ns->bound != db) return SS_EINVAL;
+    if (!ns->n_used) return SS_OK;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((ns->n_used >> 2) + 255) / 256 + 1, 256 * 32);
+    hipLaunchKernelGGL(harvest_kernel, dim3(blocks), dim3(256), 0, ss::as_stream(stream), ns->d_pkeys, ns->d_ppos, ns->d_pnode,
+                       ns->n_used, db->d_counts, ns->d_val, ns->d_touched);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_nodes_reduce_touched_dev(ss_nodes *ns, ss_node_stat *stats_dev, void *stream)
+{
+    if (!ns || !ns->bound || !stats_dev) return SS_EINVAL;
+    if (!ns->n_nodes) return SS_OK;
+    hipLaunchKernelGGL((node_reduce_kernel<true>), dim3(ns->n_nodes), dim3(NT), 0, ss::as_stream(stream), (const uint32_t *)nullptr,
+                       ns->d_offsets, ns->d_val, (const uint8_t *)nullptr, stats_dev, ns->d_len, ns->d_touched);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_nodes_touched_get_dev(const ss_nodes *ns, uint32_t *flags_dev, void *stream)
+{
+    if (!ns || !ns->bound || !flags_dev) return SS_EINVAL;
+    SS_HIP(hipMemcpyAsync(flags_dev, ns->d_touched, (uint64_t)ns->n_nodes * 4, hipMemcpyDeviceToDevice, ss::as_stream(stream)));
+    return SS_OK;
+}
+
+int ss_nodes_touched_set_dev(ss_nodes *ns, const uint32_t *flags_dev, void *stream)
+{
+    if (!ns || !ns->bound || !flags_dev) return SS_EINVAL;
+    SS_HIP(hipMemcpyAsync(ns->d_touched, flags_dev, (uint64_t)ns->n_nodes * 4, hipMemcpyDeviceToDevice, ss::as_stream(stream)));
+    return SS_OK;
+}
+
+int ss_nodes_pack_dev(ss_nodes *ns, uint32_t *packed_dev, uint64_t cap, uint64_t *n_packed, void *stream)
+{
+    if (!ns || !ns->bound || !n_packed) return SS_EINVAL;
+    *n_packed = 0;
+    if (!ns->n_nodes) return SS_OK;
+    hipStream_t st = ss::as_stream(stream);
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, st, ns->d_touched, ns->d_offsets, ns->n_nodes, ns->d_packoff);
+    uint64_t total = 0;
+    SS_HIP(hipMemcpyAsync(&total, ns->d_packoff + ns->n_nodes, 8, hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    *n_packed = total;
+    if (!packed_dev) return SS_OK;              // size query
+    if (total > cap) return SS_ERANGE;
+    hipLaunchKernelGGL((pack_copy_kernel<true>), dim3(ns->n_nodes), dim3(256), 0, st, ns->d_touched, ns->d_offsets, ns->d_packoff,
+                       ns->d_val, packed_dev);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_nodes_unpack_dev(ss_nodes *ns, const uint32_t *packed_dev, void *stream)
+{
+    if (!ns || !ns->bound || !packed_dev) return SS_EINVAL;
+    if (!ns->n_nodes) return SS_OK;
+    hipLaunchKernelGGL((pack_copy_kernel<false>), dim3(ns->n_nodes), dim3(256), 0, ss::as_stream(stream), ns->d_touched, ns->d_offsets,
+                       ns->d_packoff, ns->d_val, const_cast<uint32_t *>(packed_dev));
+    SS_HIP(hipGetLastError());
     return SS_OK;
 }
 
@@ -248,8 +512,9 @@ int ss_nodes_reduce_dev(const ss_nodes *ns, const uint32_t *counts_rows_dev, con
 {
     if (!ns || !counts_rows_dev || !row_valid_dev || !stats_dev) return SS_EINVAL;
     if (!ns->n_nodes) return SS_OK;
-    hipLaunchKernelGGL(node_reduce_kernel, dim3(ns->n_nodes), dim3(NT), 0, ss::as_stream(stream), ns->d_rows,
-                       ns->d_offsets, counts_rows_dev, row_valid_dev, stats_dev);
+    hipLaunchKernelGGL((node_reduce_kernel<false>), dim3(ns->n_nodes), dim3(NT), 0, ss::as_stream(stream), ns->d_rows,
+                       ns->d_offsets, const_cast<uint32_t *>(counts_rows_dev), row_valid_dev, stats_dev, (const uint32_t *)nullptr,
+                       (uint32_t *)nullptr);
     SS_HIP(hipGetLastError());
     return SS_OK;
 }

@@ -57,6 +57,64 @@ def allreduce_counts(t, group=None):
     return t
 
 
+class _NodeExchange:
+    """What exchange_touched needs from a node set: the touched flags out and in, the touched nodes' segments packed
+    and unpacked (device pointers; strainscan_amd._lib.NodeSet over ss_nodes_*; tests substitute a numpy double)."""
+
+    def __init__(self, nodes):
+        self.nodes = nodes
+        self.n_nodes = nodes.n_nodes
+
+    def flags_get(self, t, stream):
+        _lib.check(_lib.lib().ss_nodes_touched_get_dev(self.nodes._h, t.data_ptr(), stream), "ss_nodes_touched_get_dev")
+
+    def flags_set(self, t, stream):
+        _lib.check(_lib.lib().ss_nodes_touched_set_dev(self.nodes._h, t.data_ptr(), stream), "ss_nodes_touched_set_dev")
+
+    def pack(self, t, stream):
+        import ctypes as C
+        n = C.c_uint64()
+        _lib.check(_lib.lib().ss_nodes_pack_dev(self.nodes._h, t.data_ptr() if t is not None else None,
+                                                t.numel() if t is not None else 0, C.byref(n), stream), "ss_nodes_pack_dev")
+        return int(n.value)
+
+    def unpack(self, t, stream):
+        _lib.check(_lib.lib().ss_nodes_unpack_dev(self.nodes._h, t.data_ptr(), stream), "ss_nodes_unpack_dev")
+
+
+_PACK_BUF = {}
+
+
+def exchange_touched(nodes, group=None, device="cuda", stream=None, ex=None):
+    """The collective of a sharded tree scan, between ss_nodes_harvest_dev and ss_nodes_reduce_touched_dev: every rank
+    has harvested ITS reads' counts into the node-major buffer.  (1) MAX-all-reduce of the touched flags (4 bytes per
+    node) -> every rank knows the union of the nodes with hits; (2) the segments of those nodes, packed in node order
+    (same layout on every rank), are SUM-all-reduced and unpacked.  Bytes per rank per scan: 4 * n_nodes + 4 * (rows
+    of the touched nodes) -- ~2.5 MB for a three-strain sample against an E. coli tree of 25 M rows, where the full
+    row vector is 100 MB.  Integer sums: bit-identical to a single-GPU scan.  Returns the packed length."""
+    import torch
+    import torch.distributed as dist
+    ex = ex or _NodeExchange(nodes)
+    if stream is None and device != "cpu":
+        stream = torch.cuda.current_stream().cuda_stream
+    flags = torch.empty(max(1, ex.n_nodes), dtype=torch.int32, device=device)
+    ex.flags_get(flags, stream)
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    ex.flags_set(flags, stream)
+    n = ex.pack(None, stream)
+    if n == 0:
+        return 0
+    buf = _PACK_BUF.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 20), dtype=torch.int32, device=device)
+        _PACK_BUF.clear()
+        _PACK_BUF[device] = buf
+    ex.pack(buf, stream)
+    allreduce_counts(buf[:n], group)
+    ex.unpack(buf, stream)
+    return n
+
+
 def allreduce_table(kdb):
     """Sum the per-rank hit counts of `kdb` over all ranks and load the global vector back."""
     import torch

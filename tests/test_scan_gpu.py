@@ -621,3 +621,58 @@ def test_sampled_database_tiny_queues():
     env = dict(os.environ, SS_LIB=tiny)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "tinyq sampled ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_harvest_path_equals_row_gather(L):
+    """ss_nodes_bind + ss_nodes_harvest_dev + ss_nodes_reduce_touched_dev against the row-gather path
+    (ss_counts_rows_dev + ss_nodes_reduce_dev) and the oracle's match_node: node lists that overlap, contain invalid
+    rows (N rows, duplicates whose owner is another row) and rows without hits; nodes without any hit; repeated scans
+    (the harvest buffer and the flags must come back clean); accumulating scans; a sampled (scattered) table."""
+    from oracle import oracle as orc
+    kfa, flat = _random_db_and_reads(99, 90000, 15000)
+    rows_txt = kfa.split(b"\n")[1::2]
+    # splice invalid / duplicate rows in
+    extra = [rows_txt[10], rows_txt[11][:12] + b"N" + rows_txt[11][13:], rows_txt[500], rows_txt[501].lower()]
+    kfa2 = kfa + b"".join(b">1\n" + r + b"\n" for r in extra)
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+    want, want_valid = orc.jellyfish_count(kfa2, [fq], k=31, upper=True)
+    n = want.size
+    db = L.KmerDB.from_text(kfa2, 31, True)
+    rs = np.random.RandomState(3)
+    lists = [np.arange(0, n, 2), np.arange(1, n, 3), np.arange(n)[::-1][: n // 2], np.arange(5), np.arange(n - 8, n),
+             np.array([10, n - 4, 500, n - 2]), rs.choice(n, size=4000, replace=False), np.zeros(0, np.int64)]
+    # a node whose rows never occur in the reads
+    lists.append(np.nonzero(want == 0)[0][:700])
+    ns = L.NodeSet(lists)
+
+    def check(scale):
+        a = ns.reduce(db)
+        b = ns.harvest(db)
+        assert a.tobytes() == b.tobytes()
+        for j, rows in enumerate(lists):
+            o = orc.match_node(want * scale, want_valid, np.asarray(rows))
+            got = (int(b[j]["length"]), int(b[j]["n_pos"]), int(b[j]["n_kept"]), int(b[j]["sum_kept"]), int(b[j]["median2"]))
+            assert got == (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"], int(round(2 * o["median"])) if o["n_pos"] else 0), (j, got, o)
+
+    db.scan_flat(flat)
+    check(1)
+    check(1)                       # the second harvest sees a clean buffer
+    db.scan_flat(flat)             # accumulate
+    check(2)
+    db.reset()
+    L.check(L.lib().ss_device_sync(), "sync")
+    st = ns.harvest(db)
+    assert not st["n_pos"].any() and int(st[0]["length"]) == int(want_valid[lists[0]].sum())
+    db.scan_flat(flat)
+    check(1)
+    ns.close()
+    db.close()
+    # sampled table: rows scattered over the index pages
+    keys, okeys, fl = _sampled_db_and_reads(5, 2_000_000, 0.08, 8000)
+    db = L.KmerDB(keys, np.ones(keys.size, np.uint8), 31, True)
+    db.scan_flat(fl)
+    nn = keys.size
+    lists = [np.arange(i, nn, 7) for i in range(7)] + [np.arange(100)]
+    ns = L.NodeSet(lists)
+    a, b = ns.reduce(db), ns.harvest(db)
+    assert a.tobytes() == b.tobytes() and int(b["n_pos"].sum()) > 1000
