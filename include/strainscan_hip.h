@@ -144,6 +144,11 @@ int ss_scan_reset(ss_db *db, void *stream);
 int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream);
 int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n);
 int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records, uint64_t *n_bases);
+/* The same for one rank of a sharded scan (reads shard across GPUs): only the chunks c of the input with
+ * c % shard_world == shard_rank are parsed, copied and scanned (the sequential reader, where a file needs it, walks
+ * everything and keeps every shard_world-th block).  n_records / n_bases: this rank's share for chunk-parsed files. */
+int ss_scan_files_shard(ss_db *db, const char *const *paths, int n_paths, int shard_rank, int shard_world,
+                        uint64_t *n_records, uint64_t *n_bases);
 /* counts per ROW (match_results as an array; 0 for rows that are not valid) */
 int ss_counts_rows_dev(const ss_db *db, uint32_t *counts_rows_dev, void *stream);
 int ss_counts_rows(const ss_db *db, uint32_t *counts_rows);

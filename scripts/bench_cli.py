@@ -43,7 +43,7 @@ def write_db(torch, dev, spec, C, db_dir):
             node = np.repeat(np.arange(h0, h1), ns)
             pos = np.arange(int(ns.sum())) - np.repeat(np.concatenate([[0], np.cumsum(ns)[:-1]]), ns)
             start = torch.from_numpy(seq_off[node] + pos).to(dev)
-            c = spec["codes"][start[:, None] + ar[None, :]]
+            c = spec["codes"][start[:, None] + ar[None, :]].long()
             rows = torch.empty((c.shape[0], 2, K + 4), dtype=torch.uint8, device=dev)
             rows[:, :, 0] = 62; rows[:, :, 1] = 49; rows[:, :, 2] = 10; rows[:, :, K + 3] = 10   # ">1\n" ... "\n"
             rows[:, 0, 3:K + 3] = asc[c]

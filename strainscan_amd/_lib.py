@@ -77,6 +77,7 @@ SIGNATURES = {
     "ss_scan_flat_dev": (i32, [vp, vp, u64, vp]),
     "ss_scan_flat_host": (i32, [vp, cp, u64]),
     "ss_scan_files": (i32, [vp, P(cp), i32, P(u64), P(u64)]),
+    "ss_scan_files_shard": (i32, [vp, P(cp), i32, i32, i32, P(u64), P(u64)]),
     "ss_counts_rows_dev": (i32, [vp, vp, vp]),
     "ss_counts_rows": (i32, [vp, vp]),
     "ss_counts_load_rows_dev": (i32, [vp, vp, vp]),
@@ -275,11 +276,13 @@ class KmerDB:
         b = bytes(bases) if not isinstance(bases, bytes) else bases
         check(lib().ss_scan_flat_host(self._h, b, len(b)), "ss_scan_flat_host")
 
-    def scan_files(self, paths):
+    def scan_files(self, paths, shard_rank=0, shard_world=1):
+        """Count in the reads of the files; with shard_world > 1 only this rank's share of them (parsed, copied, scanned)."""
         paths = [os.fsencode(p) for p in paths if p]
         arr = (C.c_char_p * len(paths))(*paths)
         nrec, nb = C.c_uint64(), C.c_uint64()
-        check(lib().ss_scan_files(self._h, arr, len(paths), C.byref(nrec), C.byref(nb)), "ss_scan_files")
+        check(lib().ss_scan_files_shard(self._h, arr, len(paths), int(shard_rank), int(shard_world), C.byref(nrec), C.byref(nb)),
+              "ss_scan_files_shard")
         return nrec.value, nb.value
 
     def counts_rows(self):

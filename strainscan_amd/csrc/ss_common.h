@@ -114,8 +114,10 @@ uint64_t inflate_budget_bytes();
 hipStream_t ingest_stream(unsigned i);   // a few process-wide non-blocking streams (creating one costs ~13 ms)
 void free_later(char *p);
 std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths);
-int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled);
-int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled);
+int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled, int shard_rank = 0,
+                       int shard_world = 1);
+int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled,
+                       int shard_rank = 0, int shard_world = 1);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles);
 }  // namespace ss

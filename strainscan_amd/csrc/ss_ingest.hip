@@ -367,20 +367,22 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
 
 // returns SS_OK and *handled = true when the file was scanned here; *handled = false => caller
 // must use the sequential reader for this file
-int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled)
+int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled, int shard_rank,
+                       int shard_world)
 {
     // SS_INGEST_ZEROCOPY=1: the kernel streams the flat block straight out of the pinned host buffer
     // (every base is read once, with 16-byte loads) instead of waiting for a DMA copy of it
     static const bool zero_copy = getenv("SS_INGEST_ZEROCOPY") && atoi(getenv("SS_INGEST_ZEROCOPY")) != 0;
-    return parse_file_parallel(db->workers, path, 0, 1, n_records, n_bases, handled,
+    return parse_file_parallel(db->workers, path, shard_rank, shard_world, n_records, n_bases, handled,
                                [db](const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream) {
                                    return ss_scan_flat_dev(db, zero_copy ? h_buf : d_buf, len, stream);
                                }, !zero_copy);
 }
 
-int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled)
+int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled,
+                       int shard_rank, int shard_world)
 {
-    return parse_text_parallel(db->workers, text, n, nullptr, 0, 1, n_records, n_bases, handled,
+    return parse_text_parallel(db->workers, text, n, nullptr, shard_rank, shard_world, n_records, n_bases, handled,
                                [db](const char *, char *d_buf, uint64_t len, hipStream_t stream) {
                                    return ss_scan_flat_dev(db, d_buf, len, stream);
                                }, true);

@@ -948,6 +948,33 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
 // database is indexed once, not at every run (device image cache).
 // ---------------------------------------------------------------------------------------------
 namespace {
+// An imported image is checked before it is used: every index that the scan or gather kernels will follow must stay
+// inside its array (a truncated-and-padded or overwritten cache file must fail here, not read out of bounds later).
+__global__ void validate_image_kernel(const uint32_t *__restrict__ slot_of_row, uint64_t n_rows, uint64_t n_slots,
+                                      const uint8_t *__restrict__ pages, uint64_t n_pages, const uint64_t *__restrict__ mkeys,
+                                      uint64_t n_mslots, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) {
+        const uint32_t sl = slot_of_row[i];
+        if (sl != SS_NO_SLOT && sl >= n_slots) atomicAdd(bad, 1u);
+    }
+    if (i < n_pages * 8) {
+        const uint8_t *pp = pages + (i >> 3) * 64;
+        const uint32_t sl = (uint32_t)(i & 7), hi8 = pp[8 + sl];
+        if (hi8 & 0x80u) {                       // bucket reference: header + candidates inside d_mkeys
+            uint32_t lo;
+            memcpy(&lo, pp + 16 + 4 * sl, 4);
+            const uint64_t start = lo & ss::START_MASK;
+            if (start + 1 >= n_mslots) atomicAdd(bad, 1u);
+            else {
+                const uint64_t cnt = mkeys[start] >> 32;          // header at start, k-mers at start + 1 .. start + cnt
+                if (cnt < 1 || cnt > n_mslots || start + cnt >= n_mslots) atomicAdd(bad, 1u);
+            }
+        } else if (hi8 != ss::PG_EMPTY_HI && (hi8 & 31u) > 16u) atomicAdd(bad, 1u);
+    }
+}
+
 struct ImageHeader {
     char magic[8];          // "SSIDX07\0"
     int32_t k, layout;
@@ -1077,6 +1104,17 @@ int ss_db_import(const char *path, ss_db **out)
              hipMemset(db->d_counts, 0, db->n_slots * 4) == hipSuccess;
     }
     close(fd);
+    if (ok) {
+        uint32_t *d_bad = nullptr, bad = 1;
+        const uint64_t nchk = std::max<uint64_t>(h.n_rows, (uint64_t)h.n_dir * 8);
+        ok = hipMalloc((void **)&d_bad, 4) == hipSuccess && hipMemset(d_bad, 0, 4) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(validate_image_kernel, dim3((unsigned)((nchk + 255) / 256)), dim3(256), 0, 0, db->d_slot_of_row, h.n_rows,
+                               h.n_slots, (const uint8_t *)db->d_dir, (uint64_t)h.n_dir, db->d_mkeys, h.n_mslots, d_bad);
+            ok = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+        }
+        hipFree(d_bad);
+    }
     if (ok && h.bloom_bits) db->bloom_bits = h.bloom_bits;
     if (!ok) { ss_db_destroy(db); return SS_EIO; }
     db->device_bytes = db->n_mslots * 8 + db->n_slots * 4 + (uint64_t)db->n_dir * 64 + nr * 5 + sizes[4];

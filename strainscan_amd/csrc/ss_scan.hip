@@ -389,8 +389,10 @@ int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n)
     return SS_OK;
 }
 
+// shard_world > 1: the reader still walks the whole input (a record grammar has no entry points), but only every
+// shard_world-th block is copied and scanned
 static int scan_files_sequential(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records,
-                                 uint64_t *n_bases)
+                                 uint64_t *n_bases, int shard_rank = 0, int shard_world = 1)
 {
     int rc = ensure_staging(db);
     if (rc) return rc;
@@ -398,7 +400,7 @@ static int scan_files_sequential(ss_db *db, const char *const *paths, int n_path
     rc = ss_reader_open(paths, n_paths, &rd);
     if (rc) return rc;
     ss_reader_set_overlap(rd, db->k - 1);
-    uint64_t recs = 0, total = 0;
+    uint64_t recs = 0, total = 0, blk = 0;
     int b = 0;
     bool used[2] = {false, false};
     for (;;) {
@@ -412,6 +414,7 @@ static int scan_files_sequential(ss_db *db, const char *const *paths, int n_path
         if (len == 0) break;
         recs += nr;
         total += len;
+        if ((int)(blk++ % (uint64_t)shard_world) != shard_rank) continue;
         hipError_t e = hipMemcpyAsync(db->d_stage[b], db->h_stage[b], len, hipMemcpyHostToDevice, db->streams[b]);
         if (e != hipSuccess) { ss_reader_close(rd); ss::set_last_error("hipMemcpyAsync", __FILE__, __LINE__, e); return SS_EHIP; }
         rc = ss_scan_flat_dev(db, db->d_stage[b], len, db->streams[b]);
@@ -430,7 +433,13 @@ static int scan_files_sequential(ss_db *db, const char *const *paths, int n_path
 
 int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_records, uint64_t *n_bases)
 {
-    if (!db || !paths || n_paths < 1) return SS_EINVAL;
+    return ss_scan_files_shard(db, paths, n_paths, 0, 1, n_records, n_bases);
+}
+
+int ss_scan_files_shard(ss_db *db, const char *const *paths, int n_paths, int shard_rank, int shard_world, uint64_t *n_records,
+                        uint64_t *n_bases)
+{
+    if (!db || !paths || n_paths < 1 || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return SS_EINVAL;
     uint64_t recs = 0, total = 0;
     const char *seq_env = getenv("SS_INGEST");
     const bool allow_parallel = !(seq_env && !strcmp(seq_env, "sequential"));
@@ -444,11 +453,11 @@ int ss_scan_files(ss_db *db, const char *const *paths, int n_paths, uint64_t *n_
         if (!paths[i][0]) continue;            // '' = no second file (StrainScan.py:182)
         bool handled = false;
         if (allow_parallel) {
-            if (!texts.empty() && texts[i].p) rc = ss::scan_text_parallel(db, texts[i].p, texts[i].n, &recs, &total, &handled);
-            else rc = ss::scan_file_parallel(db, paths[i], &recs, &total, &handled);
+            if (!texts.empty() && texts[i].p) rc = ss::scan_text_parallel(db, texts[i].p, texts[i].n, &recs, &total, &handled, shard_rank, shard_world);
+            else rc = ss::scan_file_parallel(db, paths[i], &recs, &total, &handled, shard_rank, shard_world);
         }
         if (!texts.empty()) { ss::free_later(texts[i].p); texts[i].p = nullptr; }
-        if (rc == SS_OK && !handled) rc = scan_files_sequential(db, &paths[i], 1, &recs, &total);
+        if (rc == SS_OK && !handled) rc = scan_files_sequential(db, &paths[i], 1, &recs, &total, shard_rank, shard_world);
     }
     for (auto &tx : texts) free(tx.p);
     if (rc) return rc;

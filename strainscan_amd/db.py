@@ -91,18 +91,20 @@ def resident_reads(paths):
     return rs
 
 
-def scan_into(kdb, paths):
+def scan_into(kdb, paths, allreduce=True):
     """Count kdb's k-mers in the reads of `paths`: resident blocks when possible, streaming
-    otherwise; under torch.distributed the per-rank counts are all-reduced (RCCL) and loaded back."""
+    otherwise.  Under torch.distributed every rank scans its share of the reads; with `allreduce` the row counts are
+    then summed over the ranks (RCCL) and loaded back, without it the table keeps this rank's counts (the tree scan:
+    TreeImage exchanges the touched nodes' counts instead, dist.exchange_touched)."""
     from . import dist
     kdb.reset()
     rs = resident_reads(paths)
     if rs is not None:
         rs.scan_into(kdb)
-        if dist.is_distributed():
+        if allreduce and dist.is_distributed():
             dist.allreduce_table(kdb)
     elif dist.is_distributed():
-        dist.scan_files_sharded(kdb, paths)
+        dist.scan_files_sharded(kdb, paths, allreduce=allreduce)
     else:
         kdb.scan_files([p for p in paths if p])
 
@@ -116,7 +118,7 @@ def fasta_index(path, k, upper_keys):
     img = None
     if cdir and int(k) == 31:
         st = os.stat(path)
-        tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, int(st.st_mtime), int(k),
+        tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, st.st_mtime_ns, int(k),
                                                  int(upper_keys))).encode()).hexdigest()[:20]
         img = os.path.join(cdir, "index_%s.bin" % tag)
         if os.path.exists(img):
@@ -217,8 +219,8 @@ def load_tree(db_dir, k=L1_K):
     fa = os.path.join(db_dir, "kmer.fa")
     st = os.stat(fa)
     kdir = os.path.join(db_dir, "kmers")
-    tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, int(st.st_mtime), k,
-                                             int(os.stat(kdir).st_mtime))).encode()).hexdigest()[:20]
+    tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, st.st_mtime_ns, k,
+                                             os.stat(kdir).st_mtime_ns)).encode()).hexdigest()[:20]
     cdir = _cache_dir()
     path = os.path.join(cdir, "tree_%s.bin" % tag) if cdir else None
     if path and os.path.exists(path):
@@ -287,6 +289,7 @@ class TreeImage:
         self._scanned = None          # key of the inputs whose counts are in the table
         self._counts = None
         self._stats = None
+        self._rows_global = True      # False: several ranks, the table holds THIS rank's counts only
 
     @staticmethod
     def _index(db_dir, keys, flags, upper_keys):
@@ -296,7 +299,7 @@ class TreeImage:
         path = None
         if cdir:
             st = os.stat(os.path.join(db_dir, "kmer.fa"))
-            tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, int(st.st_mtime), L1_K,
+            tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, st.st_mtime_ns, L1_K,
                                                      int(upper_keys))).encode()).hexdigest()[:20]
             path = os.path.join(cdir, "index_%s.bin" % tag)
             if os.path.exists(path):
@@ -325,7 +328,9 @@ class TreeImage:
         key = tuple((os.path.abspath(p), os.path.getmtime(p), os.path.getsize(p)) for p in paths if p)
         if self._scanned == key:
             return
-        scan_into(self.kdb, paths)
+        from . import dist
+        scan_into(self.kdb, paths, allreduce=False)
+        self._rows_global = not dist.is_distributed()
         self._scanned = key
         self._counts = None
         self._stats = None
@@ -336,14 +341,26 @@ class TreeImage:
         self._scanned = ("external", tag)
         self._counts = None
         self._stats = None
+        self._rows_global = True
 
     @property
     def is_external(self):
         return bool(self._scanned) and self._scanned[0] == "external"
 
+    def _global_rows(self):
+        """Several ranks: single rows are asked for (adjust_profile's Poisson branch, identify.py:203-218; the `remain`
+        set, :181-189) -> now the whole row vector is summed over the ranks and loaded back.  A collective: every rank
+        runs the same walk on the same node statistics, so all of them get here at the same point."""
+        if not self._rows_global:
+            from . import dist
+            self.node_stats()                     # while the table still holds this rank's own counts
+            dist.allreduce_table(self.kdb)
+            self._rows_global = True
+
     @property
     def counts(self):
         if self._counts is None:
+            self._global_rows()
             self._counts = self.kdb.counts_rows()
         return self._counts
 
@@ -357,11 +374,18 @@ class TreeImage:
     def node_stats(self):
         """match_node + del_outlier for every node in one launch (identify.py:106-127)."""
         if self._stats is None:
-            self._stats = self.nodes.reduce(self.kdb)
+            # harvest path (ss_nodes.hip): one streaming pass over the counters, reductions over the nodes with hits;
+            # several ranks: their counts are exchanged in between (a few MB instead of the row vector)
+            from . import dist
+            between = None
+            if not self._rows_global:
+                between = lambda ns: dist.exchange_touched(ns, device=dist.exchange_device())    # noqa: E731
+            self._stats = self.nodes.harvest(self.kdb, between)
         return self._stats
 
     def rows_stat(self, rows):
         """Ad-hoc row set (adjust_profile's `remain`, identify.py:181-189)."""
+        self._global_rows()
         return _lib.rows_reduce(self.kdb, rows)
 
 

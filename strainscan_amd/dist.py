@@ -2,11 +2,13 @@
 
 One process per GPU (torchrun / torch.distributed, backend "nccl" = RCCL over xGMI).  k-mers never
 span reads, so the scan partitions by read block with no data-path exchange; the
-only collective is ONE sum-all-reduce of the uint32[n_rows] hit-count vector per scan
-(<= 4 * N_db bytes, ~100 MB for the E. coli table).  Integer sums commute, so the reduced
-counts are bit-identical to a single-GPU scan whatever the block-to-rank assignment.  After the
-all-reduce every rank loads the global vector back into its table and runs the (tiny, sequential)
-tree walk redundantly; rank 0 writes the reports.  Layer 2 scans shard the same way.
+collectives sum hit counts.  Tree scan: the counts of the nodes WITH hits only (exchange_touched:
+touched flags MAX-all-reduced, those nodes' segments packed and SUM-all-reduced -- ~1-3 MB where the
+uint32[n_rows] vector of an E. coli table is 100 MB); the full row vector is all-reduced only when the
+walk asks for single rows (adjust_profile's Poisson branch, identify.py:203-218) and for layer-2 scans,
+whose y vector is every row of a (much smaller) cluster table.  Integer sums commute, so the results are
+bit-identical to a single-GPU scan whatever the block-to-rank assignment.  Every rank runs the (tiny,
+sequential) tree walk redundantly; rank 0 writes the reports.
 """
 import os
 
@@ -85,6 +87,11 @@ class _NodeExchange:
 _PACK_BUF = {}
 
 
+def exchange_device():
+    """Tensors of the exchange live on the GPU (RCCL; gloo takes GPU tensors too and stages them itself)."""
+    return "cuda"
+
+
 def exchange_touched(nodes, group=None, device="cuda", stream=None, ex=None):
     """The collective of a sharded tree scan, between ss_nodes_harvest_dev and ss_nodes_reduce_touched_dev: every rank
     has harvested ITS reads' counts into the node-major buffer.  (1) MAX-all-reduce of the touched flags (4 bytes per
@@ -127,20 +134,19 @@ def allreduce_table(kdb):
     torch.cuda.synchronize()
 
 
-def scan_files_sharded(kdb, paths, cap=32 << 20):
-    """Scan this rank's share of the reads into `kdb`, all-reduce, load the global counts back.
-    Every rank parses the input (the flat-block reader is deterministic) and keeps blocks
-    i % world == rank.  Returns (n_records, n_bases) of the whole input."""
+def scan_files_sharded(kdb, paths, allreduce=True):
+    """Scan this rank's share of the reads into `kdb` (ss_scan_files_shard: a rank parses, copies and scans only the
+    chunks c % world == rank of every file; .gz inputs are inflated once per node, share_inflated); with `allreduce`
+    the row counts are then summed over the ranks and loaded back (layer-2 scans need every row; the tree scan
+    exchanges the touched nodes instead, exchange_touched).  Returns this rank's (n_records, n_bases)."""
     rank, world = rank_world()
     kdb.reset()
-    nrec = nb = 0
-    blocks = _lib.read_flat_blocks([p for p in paths if p], cap=cap, overlap=kdb.k - 1)
-    for i, (blk, nr) in enumerate(blocks):
-        nrec += nr
-        nb += len(blk)
-        if i % world == rank:
-            kdb.scan_flat(blk)
-    if world > 1:
+    use, cleanup = share_inflated([p for p in paths if p])
+    try:
+        nrec, nb = kdb.scan_files(use, rank, world)
+    finally:
+        cleanup()
+    if world > 1 and allreduce:
         allreduce_table(kdb)
     return nrec, nb
 
@@ -161,9 +167,11 @@ def share_inflated(paths, shm_dir="/dev/shm"):
     if int(os.environ.get("LOCAL_WORLD_SIZE", world)) != world or not os.path.isdir(shm_dir):
         return paths, (lambda: None)
     names = [None] * len(paths)
+    job_dir = None
     if rank == 0:
-        for i, p in enumerate(paths):
-            try:
+        import tempfile
+        try:
+            for i, p in enumerate(paths):
                 if not p:
                     continue
                 with open(p, "rb") as f:
@@ -172,25 +180,26 @@ def share_inflated(paths, shm_dir="/dev/shm"):
                 fs = os.statvfs(shm_dir)
                 if fs.f_bavail * fs.f_frsize < 8 * os.path.getsize(p):
                     continue
-                out = os.path.join(shm_dir, "ss_inflate_%d_%d_%s.txt" % (os.getpid(), i, os.path.basename(p)))
+                if job_dir is None:
+                    job_dir = tempfile.mkdtemp(prefix="ss_inflate_", dir=shm_dir)       # 0700, unpredictable name
+                out = os.path.join(job_dir, "%d_%s.txt" % (i, os.path.basename(p)))
                 n = C.c_uint64()
                 if _lib.lib().ss_gz_inflate_to_file(os.fsencode(p), os.fsencode(out), 0, C.byref(n)) == _lib.SS_OK:
+                    os.chmod(out, 0o644)
                     names[i] = out
-            except OSError:
-                pass
-    box = [names]
+            if job_dir is not None:
+                os.chmod(job_dir, 0o755)          # the other ranks of the job read the files
+        except Exception:                         # whatever happens on rank 0, the broadcast below must take place
+            names = [None] * len(paths)
+    box = [names, job_dir]
     dist.broadcast_object_list(box, src=0)
-    names = box[0]
+    names, job_dir = box
 
     def cleanup():
         dist.barrier()
-        if rank == 0:
-            for q in names:
-                if q:
-                    try:
-                        os.unlink(q)
-                    except OSError:
-                        pass
+        if rank == 0 and job_dir:
+            import shutil
+            shutil.rmtree(job_dir, ignore_errors=True)
 
     return [names[i] or p for i, p in enumerate(paths)], cleanup
 

@@ -209,8 +209,8 @@ def _l2_cache_path(input_csv, omatrix):
     if not cdir:
         return None
     st1, st2 = os.stat(input_csv), os.stat(omatrix)
-    tag = hashlib.sha1(("%s|%d|%d|%s|%d|%d" % (os.path.realpath(input_csv), st1.st_size, int(st1.st_mtime),
-                                                os.path.realpath(omatrix), st2.st_size, int(st2.st_mtime))).encode()).hexdigest()[:20]
+    tag = hashlib.sha1(("%s|%d|%d|%s|%d|%d" % (os.path.realpath(input_csv), st1.st_size, st1.st_mtime_ns,
+                                                os.path.realpath(omatrix), st2.st_size, st2.st_mtime_ns)).encode()).hexdigest()[:20]
     return os.path.join(cdir, "l2_%s.bin" % tag)
 
 

@@ -98,3 +98,96 @@ def test_two_ranks_share_one_inflate(tmp_path):
     a = (tmp_path / "share0.txt").read_text().split()
     b = (tmp_path / "share1.txt").read_text().split()
     assert a == b and int(a[1]) == len(text) and int(a[2]) == zlib.crc32(text)
+
+
+class _NumpyNodes:
+    """What ss_nodes_* gives dist.exchange_touched, on numpy arrays: a dense node-major buffer, touched flags, packing of
+    the touched nodes' segments in node order.  The semantics of ss_nodes.hip (pack_offsets_kernel / pack_copy_kernel)."""
+
+    def __init__(self, offsets, val):
+        self.offsets = np.asarray(offsets, np.int64)
+        self.n_nodes = self.offsets.size - 1
+        self.val = val
+        self.touched = np.zeros(self.n_nodes, np.int32)
+        for j in range(self.n_nodes):
+            self.touched[j] = int(val[self.offsets[j]:self.offsets[j + 1]].any())
+
+    def flags_get(self, t, stream):
+        t[:self.n_nodes] = torch.from_numpy(self.touched)
+
+    def flags_set(self, t, stream):
+        self.touched = t[:self.n_nodes].numpy().copy()
+
+    def _segments(self):
+        return [(int(self.offsets[j]), int(self.offsets[j + 1])) for j in range(self.n_nodes) if self.touched[j]]
+
+    def pack(self, t, stream):
+        seg = self._segments()
+        n = sum(b - a for a, b in seg)
+        if t is not None:
+            assert t.numel() >= n
+            o = 0
+            for a, b in seg:
+                t[o:o + b - a] = torch.from_numpy(self.val[a:b].view(np.int32))
+                o += b - a
+        return n
+
+    def unpack(self, t, stream):
+        o = 0
+        for a, b in self._segments():
+            self.val[a:b] = t[o:o + b - a].numpy().view(np.uint32)
+            o += b - a
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from strainscan_amd import dist as sdist
+    rs = np.random.RandomState(7)                            # the same tree on every rank ...
+    lens = rs.randint(0, 400, size=40)
+    lens[[3, 17]] = 0                                        # ... with empty nodes
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    rr = np.random.RandomState(100 + rank)                   # ... different hits per rank
+    val = np.zeros(int(offsets[-1]), np.uint32)
+    hot = rr.choice(40, size=6, replace=False)               # this rank has hits in six nodes
+    for j in hot:
+        a, b = offsets[j], offsets[j + 1]
+        if b > a:
+            idx = rr.randint(a, b, size=max(1, (b - a) // 3))
+            val[idx] += rr.randint(1, 50, size=idx.size).astype(np.uint32)
+    if offsets[1] > 0:
+        val[0] += np.uint32(0x90000000)                      # unsigned wrap across ranks
+    np.save(os.path.join(out_dir, "val%d.npy" % rank), val)
+    ex = _NumpyNodes(offsets, val.copy())
+    n = sdist.exchange_touched(None, device="cpu", ex=ex)
+    np.save(os.path.join(out_dir, "sum%d.npy" % rank), ex.val)
+    np.save(os.path.join(out_dir, "flags%d.npy" % rank), ex.touched)
+    with open(os.path.join(out_dir, "n%d.txt" % rank), "w") as f:
+        f.write(str(n))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_touched_sums_the_union(tmp_path, world):
+    """dist.exchange_touched (the collective of a sharded tree scan): flags MAX-all-reduced, the union's segments packed,
+    SUM-all-reduced (uint32 wrap included), unpacked -- every rank ends with the global counts in every node any rank
+    touched, and only those nodes travel."""
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    vals = [np.load(tmp_path / ("val%d.npy" % r)) for r in range(world)]
+    want = np.zeros_like(vals[0])
+    for v in vals:
+        want = want + v                                      # uint32 arithmetic wraps
+    rs = np.random.RandomState(7)
+    lens = rs.randint(0, 400, size=40)
+    lens[[3, 17]] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    union = np.array([int(any(v[offsets[j]:offsets[j + 1]].any() for v in vals)) for j in range(40)])
+    n_want = int(sum(lens[j] for j in range(40) if union[j]))
+    assert 0 < n_want < offsets[-1]
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("sum%d.npy" % r)), want)
+        assert np.array_equal(np.load(tmp_path / ("flags%d.npy" % r)), union)
+        assert int((tmp_path / ("n%d.txt" % r)).read_text()) == n_want

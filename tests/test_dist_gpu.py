@@ -1,0 +1,146 @@
+"""The sharded identification path on the device, several ranks on ONE GPU: every rank is a separate process with its
+own torch.distributed rank (backend gloo -- RCCL refuses two ranks on one device; gloo stages the GPU tensors itself),
+parses and scans only ITS share of the reads (ss_reads_load / ss_scan_files_shard with shard_rank, shard_world) and
+the product's collectives -- dist.exchange_touched for the tree's node statistics, dist.allreduce_table where single
+rows are needed -- must reproduce the reference's golden results (tests/golden/l1_search.json) bit for bit, as the
+single-process run does.  This is BASELINE.json configs[2]'s code path at world sizes 2 and 3."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import contextlib, io, json, os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+import torch
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from strainscan_amd import identify, identify_low_mem, identify_low_depth, db as ssdb, dist as sdist, _lib
+assert sdist.is_distributed() and sdist.rank_world() == (rank, world)
+jobs = json.load(open(%(jobs)r))
+out = []
+for job in jobs:
+    mod = {"identify": identify, "identify_low_mem": identify_low_mem}[job["module"]]
+    np.random.seed(job["seed"])
+    if job.get("stream"):
+        ssdb.RESIDENT_LIMIT_BYTES = 0            # no resident read set: ss_scan_files_shard streams this rank's chunks
+    else:
+        ssdb.RESIDENT_LIMIT_BYTES = 1 << 40
+    ssdb.clear_cache()
+    buf = io.StringIO()
+    err = res = None
+    with contextlib.redirect_stdout(buf):
+        try:
+            res = mod.identify_cluster(tuple(job["fq"]), job["tdb"], list(job["cutoff"]))
+        except BaseException as e:
+            err = type(e).__name__
+    img = ssdb.tree_image(job["tdb"], job["module"] == "identify")
+    st = img.node_stats()
+    rec = dict(error=err, result=None if res is None else {str(k): {a: (b if isinstance(b, (int, str)) else float(b)) for a, b in v.items()} for k, v in res.items()},
+               stats=[[int(x) for x in (s["length"], s["n_pos"], s["n_kept"], s["sum_kept"], s["median2"])] for s in st],
+               rows_global=bool(img._rows_global), text=buf.getvalue())
+    if job.get("ranks"):
+        r, e2, _ = None, None, None
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = identify_low_depth.identify_ranks(tuple(job["fq"]), job["tdb"])
+        except BaseException as e:
+            e2 = type(e).__name__
+        rec["ranks"] = dict(error=e2, result=None if r is None else [[int(a), float(b)] for a, b in r])
+    out.append(rec)
+json.dump(out, open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _spawn(world, jobs, tmp_path):
+    import socket
+    jp = tmp_path / "jobs.json"
+    jp.write_text(json.dumps(jobs))
+    code = WORKER % dict(repo=REPO, jobs=str(jp), out=str(tmp_path))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SS_IMAGE_CACHE=str(tmp_path / ("cache%d" % r)))
+        env.pop("STRAINSCAN_QUIET", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
+    errs = [p.communicate(timeout=900)[1].decode()[-3000:] for p in procs]
+    assert all(p.returncode == 0 for p in procs), errs
+    return [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_identify_equals_golden(world, golden_dir, l1_dbs, l1_reads, tmp_path):
+    from tests import hostlogic as hl
+    from oracle import oracle as orc
+    with open(os.path.join(golden_dir, "l1_search.json")) as f:
+        golden = json.load(f)
+    jobs, wants = [], []
+    for sname in ("A_mix3", "B_mix", "A_leaf6_single", "A_none", "D_one"):
+        dbn = sc.L1_SAMPLES[sname][0]
+        tdb = os.path.join(l1_dbs[dbn]["db_dir"], "Tree_database")
+        for run in golden[sname]["runs"]:
+            if run["cutoff"] != [0.1, 0.4, 1] and sname != "B_mix":
+                continue
+            jobs.append(dict(module=run["module"], seed=sc.POISSON_SEED, fq=[l1_reads[sname][0], ""], tdb=tdb, cutoff=run["cutoff"],
+                             stream=(len(jobs) % 3 == 1), ranks=(len(jobs) % 4 == 0)))
+            wants.append((sname, run))
+    # a paired / gz input: this rank's share of two files, one of them inflated once per node
+    import gzip
+    fq, data = l1_reads["A_mix3"]
+    recs = data.split(b"@r")[1:]
+    half = len(recs) // 2
+    p1, p2 = tmp_path / "a_1.fq", tmp_path / "a_2.fq.gz"
+    p1.write_bytes(b"".join(b"@r" + r for r in recs[:half]))
+    with gzip.open(p2, "wb") as f:
+        f.write(b"".join(b"@r" + r for r in recs[half:]))
+    run0 = [r for r in golden["A_mix3"]["runs"] if r["module"] == "identify" and r["cutoff"] == [0.1, 0.4, 1]][0]
+    tdbA = os.path.join(l1_dbs["A"]["db_dir"], "Tree_database")
+    jobs.append(dict(module="identify", seed=sc.POISSON_SEED, fq=[str(p1), str(p2)], tdb=tdbA, cutoff=[0.1, 0.4, 1]))
+    wants.append(("A_mix3", run0))
+    outs = _spawn(world, jobs, tmp_path)
+    any_rows = False
+    for ji, (sname, run) in enumerate(wants):
+        recs_ = [o[ji] for o in outs]
+        for r in recs_[1:]:                                  # every rank holds the same global answer
+            assert r["result"] == recs_[0]["result"] and r["stats"] == recs_[0]["stats"] and r["error"] == recs_[0]["error"]
+        got = recs_[0]
+        tag = (world, sname, run["module"], run["cutoff"])
+        assert got["error"] == run["error"], (tag, got["text"][-300:])
+        if got["error"] is None:
+            hl.assert_result_equal({int(k): v for k, v in got["result"].items()}, run["result"], tag)
+        assert [g[0] for g in hl.parse_trace(got["text"])] == [w[0] for w in run["trace"]], tag
+        any_rows = any_rows or got["rows_global"]
+        # node statistics = the oracle's match_node on the golden counts of the WHOLE sample
+        info = l1_dbs[sc.L1_SAMPLES[sname][0]]
+        kfa = open(os.path.join(info["db_dir"], "Tree_database", "kmer.fa"), "rb").read()
+        want_c, want_v = orc.jellyfish_count(kfa, [l1_reads[sname][1]], k=31, upper=(run["module"] == "identify"))
+        from strainscan_amd import db as ssdb
+        ids = ssdb.load_tree(os.path.join(info["db_dir"], "Tree_database"), 31).ids
+        for j, nid in enumerate(ids):
+            o = orc.match_node(want_c, want_v, np.array(info["row_of_node"][nid]))
+            assert got["stats"][j] == [o["length"], o["n_pos"], o["n_kept"], o["sum_kept"], int(round(2 * o["median"])) if o["n_pos"] else 0], (tag, nid)
+        if "ranks" in got:
+            want_r = golden[sname]["ranks"]
+            assert got["ranks"]["error"] == want_r["error"]
+            if want_r["result"] is not None:
+                assert [a for a, _ in got["ranks"]["result"]] == [a for a, _ in want_r["result"]]
+                for (_, b), (_, wb) in zip(got["ranks"]["result"], want_r["result"]):
+                    assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+    assert any_rows            # B_mix's Poisson branch asked for single rows: the full row vector was all-reduced there

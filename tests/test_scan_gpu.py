@@ -380,6 +380,27 @@ def test_index_image_roundtrip(L, tmp_path):
             L.KmerDB.from_image(p)
     with pytest.raises(L.SSError):
         L.KmerDB.from_image(str(tmp_path / "missing"))
+    # right size, damaged content: an out-of-range slot index in the row map / a bucket reference beyond the bucket array
+    info = db.info()
+    hdr = len(raw) - (info["n_slots"] - 8 * info["n_dir"]) * 8 - info["n_dir"] * 64 - db.n_rows * 5 - (1 << info["filter_bits"]) // 8 * (info["filter_bits"] > 0)
+    assert 0 < hdr < 256
+    off_pages = hdr + (info["n_slots"] - 8 * info["n_dir"]) * 8
+    off_rows = off_pages + info["n_dir"] * 64
+    bad = bytearray(raw)
+    bad[off_rows + 4 * 7: off_rows + 4 * 7 + 4] = (0xFFFFFF00).to_bytes(4, "little")
+    open(str(tmp_path / "badrow"), "wb").write(bytes(bad))
+    with pytest.raises(L.SSError):
+        L.KmerDB.from_image(str(tmp_path / "badrow"))
+    pages = np.frombuffer(raw, np.uint8, info["n_dir"] * 64, off_pages).reshape(-1, 64)
+    refs = np.argwhere((pages[:, 8:16] & 0x80) != 0)
+    assert len(refs)                                     # this table has multi-k-mer minimizers
+    pg, sl = (int(v) for v in refs[0])
+    bad = bytearray(raw)
+    o = off_pages + pg * 64 + 16 + 4 * sl
+    bad[o:o + 4] = (0x3FFFFFF0).to_bytes(4, "little")
+    open(str(tmp_path / "badref"), "wb").write(bytes(bad))
+    with pytest.raises(L.SSError):
+        L.KmerDB.from_image(str(tmp_path / "badref"))
     # the flat layout (k != 31) is not exported
     kfa5, _ = _random_db_and_reads(5, 300, 10, k=21)
     with pytest.raises(L.SSError):
