@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+RANDOM_SECTOR_PEAK_G = 55.0    # measured: random 64-byte sector reads, G/s, footprint >= 64 MB (scripts/micro/randsec.hip)
 READ_LEN = 150
 K = 31
 BYTES_PER_READ = READ_LEN + (READ_LEN - K + 1) * 8   # 1110 B algorithmic
@@ -189,6 +190,109 @@ def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
     return out
 
 
+def heap_to_id(h, C):
+    """make_db numbers nodes in heap order (0 root, children 2h+1, 2h+2); Build_tree.py numbers leaves
+    1..C, the root C+1 and internal nodes after it, every parent before its internal children."""
+    return C + 1 + h if h < C - 1 else h - (C - 1) + 1
+
+
+def write_tree_files(db_spec, C, tdir):
+    """The small text files of a Tree_database (tree_structure.txt, node_length.txt, reconstructed_nodes.txt,
+    hclsMap_95_recls.txt; Build_tree.py:494-526,664-673) for the synthetic tree -- what the host walk reads."""
+    os.makedirs(os.path.join(tdir, "overlapping_info"), exist_ok=True)
+    n_nodes = db_spec["n_nodes"]
+    per_node = np.diff(db_spec["row_off"].astype(np.int64))
+    ids = [heap_to_id(h, C) for h in range(n_nodes)]
+    with open(os.path.join(tdir, "tree_structure.txt"), "w") as f, open(os.path.join(tdir, "node_length.txt"), "w") as g:
+        for i in sorted(ids):
+            h = i - (C + 1) if i > C else i - 1 + (C - 1)
+            par = "N" if h == 0 else str(heap_to_id((h - 1) // 2, C))
+            ch = "N" if h >= C - 1 else "%d %d" % tuple(sorted((heap_to_id(2 * h + 1, C), heap_to_id(2 * h + 2, C))))
+            f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, "strain_%d" % i if h >= C - 1 else ""))
+            g.write("%d\t%d\n" % (i, int(per_node[h])))
+    open(os.path.join(tdir, "reconstructed_nodes.txt"), "w").close()
+    with open(os.path.join(tdir, "hclsMap_95_recls.txt"), "w") as f:
+        for leaf in range(1, C + 1):
+            f.write("%d\t1\tstrain_%d\n" % (leaf, leaf))
+
+
+def write_fastq(reads_dev, n_reads, path):
+    reads = reads_dev.view(n_reads, READ_LEN + 1)[:, :READ_LEN].cpu().numpy()
+    rec = np.empty((n_reads, 2 * READ_LEN + 7), np.uint8)
+    rec[:, 0:2] = np.frombuffer(b"@r", np.uint8); rec[:, 2] = 10
+    rec[:, 3:3 + READ_LEN] = reads
+    rec[:, 3 + READ_LEN] = 10; rec[:, 4 + READ_LEN] = ord("+"); rec[:, 5 + READ_LEN] = 10
+    rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I"); rec[:, 6 + 2 * READ_LEN] = 10
+    rec.tofile(path)
+
+
+class _StatsProvider:
+    """What the host walk (strainscan_amd.cst.Walk) asks of the device, answered from the bench's node statistics."""
+
+    def __init__(self, st_np, C):
+        self.st, self.C = st_np, C
+
+    def node_stat(self, node_id):
+        h = node_id - (self.C + 1) if node_id > self.C else node_id - 1 + (self.C - 1)
+        s = self.st[h]
+        return int(s["length"]), int(s["n_kept"]), int(s["sum_kept"])
+
+
+def measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, harvest_ms, reduce_ms, stream):
+    """SURVEY 8(d)'s phases, OUTSIDE the timed region of `value` (rank 0, one GPU): FASTQ text -> HBM of a bounded
+    sample (the product's ingest: parse threads || PCIe), the same bytes as one pinned host-to-device copy, the device
+    phases from the timed steps, the host tree walk on the step's node statistics; end-to-end reads/s from text."""
+    import shutil
+    import tempfile
+    from strainscan_amd import _lib, cst, identify
+    n_s = int(min(args.reads, args.phase_reads))
+    base = tempfile.mkdtemp(prefix="ss_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    ph = {}
+    try:
+        fq = os.path.join(base, "sample.fq")
+        write_fastq(reads[: n_s * (READ_LEN + 1)], n_s, fq)
+        text_bytes = os.path.getsize(fq)
+        _lib.ReadSet([fq]).close()                               # first touch of the pinned buffers, page cache
+        t0 = time.perf_counter()
+        rs = _lib.ReadSet([fq])
+        _lib.check(_lib.lib().ss_device_sync(), "sync")
+        ingest_s = time.perf_counter() - t0
+        db.reset(stream)
+        t0 = time.perf_counter()
+        rs.scan_into(db, stream)
+        torch.cuda.synchronize()
+        scan_sample_s = time.perf_counter() - t0
+        rs.close()
+        flat = torch.empty(n_s * (READ_LEN + 1), dtype=torch.uint8).pin_memory()
+        dst = torch.empty_like(flat, device=dev)
+        dst.copy_(flat, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(flat, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_s = time.perf_counter() - t0
+        tdir = os.path.join(base, "Tree_database")
+        write_tree_files(db_spec, args.leaves, tdir)
+        for _ in range(2):                                       # second run: modules imported, files in the page cache
+            t0 = time.perf_counter()
+            res = cst.Walk(_StatsProvider(st_np, args.leaves), tdir, [0.1, 0.4, 1], identify._PARAMS, out=lambda *a: None).run()
+            walk_s = time.perf_counter() - t0
+        scale = n_s / float(args.reads)
+        dev_ms = (kern_ms + harvest_ms + reduce_ms) * scale
+        ph = dict(sample_reads=n_s, fastq_text_gb=round(text_bytes / 1e9, 3),
+                  parse_and_h2d_ms=round(ingest_s * 1e3, 2), h2d_ms=round(h2d_s * 1e3, 2),
+                  parse_note="the product's ingest parses on host threads while earlier chunks cross PCIe: parse_and_h2d_ms is "
+                             "their union; h2d_ms = the same flat bytes as one pinned copy",
+                  kernel_ms=round(kern_ms, 3), gather_ms=round(harvest_ms, 3), node_reduce_ms=round(reduce_ms, 3),
+                  allreduce_ms=None, l1_host_ms=round(walk_s * 1e3, 2), scan_of_sample_ms=round(scan_sample_s * 1e3, 3),
+                  clusters_found=len(res),
+                  e2e_reads_per_s=round(n_s / (ingest_s + dev_ms * 1e-3 + walk_s), 1),
+                  e2e_note="sample_reads / (text -> HBM + device phases scaled to the sample + host walk), one GPU, page cache warm")
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return ph
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +307,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the untimed phase breakdown (text -> HBM, walk)")
+    ap.add_argument("--phase-reads", type=int, default=4_000_000, help="reads of the FASTQ sample written for the phase breakdown")
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
     return ap.parse_args(argv)
@@ -359,17 +464,34 @@ def main(argv=None):
     harvest_equals_gather = bool(torch.equal(stats, stats2))
 
     achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")    # written from rocprofv3 --pmc passes of THIS command
-    if os.path.exists(pmc_path) and args.reads == 20_000_000 and args.leaves == 823 and args.hit_frac == 0.05:
+    # Counter-derived figures come from separate rocprofv3 --pmc passes of THIS command (scripts/gpu_round.sh writes
+    # profiles/pmc_traffic.json, one entry per database shape and hit fraction, with the commit they were taken at):
+    # PMC collection serialises kernels and cannot run inside the timed region.
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_key = "%s:%s:%g" % (layout, args.db_shape, args.hit_frac)
+    if os.path.exists(pmc_path) and args.reads == 20_000_000 and args.leaves == 823:
         with open(pmc_path) as f:
-            traffic = json.load(f).get(layout, {}).get("traffic_gb_per_launch")
+            pmc = json.load(f).get(pmc_key, {})
+    traffic = pmc.get("traffic_gb_per_launch")
+    compulsory_gb = (reads.numel() + 8.0 * hits) / 1e9          # every base once + 4 B read + 4 B write per hit
     roofline = dict(bound="hbm", kernel="scan_mini_kernel" if layout == "mini" else "scan_kernel",
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_unit="GB per launch",
-                    kernel_ms=round(kern_ms, 3),
-                    bytes_per_read=BYTES_PER_READ,
-                    sector_gbs=round(args.reads * (READ_LEN + 120 * 64) / (kern_ms * 1e-3) / 1e9, 1))
+                    kernel_ms=round(kern_ms, 3), bytes_per_read=BYTES_PER_READ,
+                    frac_algorithmic=round(achieved / HBM_PEAK_GBS, 5),
+                    hbm_frac_measured=(round(traffic / (kern_ms * 1e-3) / HBM_PEAK_GBS, 4) if traffic else None),
+                    compulsory_gb=round(compulsory_gb, 3),
+                    traffic_over_compulsory=(round(traffic / compulsory_gb, 2) if traffic else None),
+                    valu_busy=pmc.get("valu_busy"),
+                    random_sectors=dict(
+                        note="what bounds the lookups: random 64-byte sectors, ~55 G/s on this chip from any footprint beyond "
+                             "the L2 (scripts/micro/randsec.hip, profiles/r02_randsec.txt)",
+                        peak_gsectors_s=RANDOM_SECTOR_PEAK_G,
+                        read_requests_per_launch=pmc.get("rdreq_per_launch"),
+                        achieved_gsectors_s=(round(pmc["rdreq_per_launch"] / (kern_ms * 1e-3) / 1e9, 1) if pmc.get("rdreq_per_launch") else None)),
+                    traffic_source=(dict(file="profiles/pmc_traffic.json", key=pmc_key, summary=pmc.get("source"),
+                                         commit=pmc.get("commit")) if pmc else None))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
@@ -409,6 +531,12 @@ def main(argv=None):
         chk = db.counts_rows()
         cpu["parity_on_sample"] = bool(np.array_equal(chk, got))
 
+    phases = None
+    if rank == 0 and world == 1 and not args.no_phases and not args.calib_stream:
+        phases = measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, harvest_ms, tail_ms, stream)
+    elif rank == 0:
+        phases = dict(kernel_ms=round(kern_ms, 3), gather_ms=round(harvest_ms, 3),
+                      allreduce_and_node_reduce_ms=round(tail_ms, 3), exchanged_counts=packed["n"])
     if rank == 0:
         out = dict(metric="M reads/sec vs 1433-strain E. coli DB", value=round(reads_per_s / 1e6, 3),
                    unit="M reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -420,7 +548,8 @@ def main(argv=None):
                                table_slots=int(info["capacity"]), minimizer_buckets=int(info.get("n_buckets", 0)),
                                table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
-                   roofline=roofline, cpu_baseline=cpu,
+                   roofline=roofline, cpu_baseline=cpu, phases=phases,
+                   e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
                               harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"]),
                    step_breakdown_ms=dict(scan_kernel=round(kern_ms, 3), harvest=round(harvest_ms, 3),

@@ -22,16 +22,12 @@ import bench  # noqa: E402
 K = 31
 
 
-def heap_to_id(h, C):
-    """bench.make_db numbers nodes in heap order (0 root, children 2h+1, 2h+2); Build_tree.py numbers leaves
-    1..C, the root C+1 and internal nodes after it, every parent before its internal children."""
-    return C + 1 + h if h < C - 1 else h - (C - 1) + 1
+heap_to_id = bench.heap_to_id
 
 
 def write_db(torch, dev, spec, C, db_dir):
     tdir = os.path.join(db_dir, "Tree_database")
     os.makedirs(os.path.join(tdir, "kmers"))
-    os.makedirs(os.path.join(tdir, "overlapping_info"))
     n_nodes = spec["n_nodes"]
     sites, seq_off, row_off = spec["sites"], spec["seq_off"], spec["row_off"].astype(np.int64)
     asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)      # device codes 0..3 -> A C T G
@@ -49,32 +45,14 @@ def write_db(torch, dev, spec, C, db_dir):
             rows[:, 0, 3:K + 3] = asc[c]
             rows[:, 1, 3:K + 3] = asc[c.flip(1) ^ 2]
             f.write(rows.cpu().numpy().tobytes())
-    ids = [heap_to_id(h, C) for h in range(n_nodes)]
-    with open(os.path.join(tdir, "tree_structure.txt"), "w") as f, open(os.path.join(tdir, "node_length.txt"), "w") as g:
-        for i in sorted(ids):
-            h = i - (C + 1) if i > C else i - 1 + (C - 1)
-            par = "N" if h == 0 else str(heap_to_id((h - 1) // 2, C))
-            ch = "N" if h >= C - 1 else "%d %d" % tuple(sorted((heap_to_id(2 * h + 1, C), heap_to_id(2 * h + 2, C))))
-            f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, "strain_%d" % i if h >= C - 1 else ""))
-            g.write("%d\t%d\n" % (i, 2 * sites[h]))
+    bench.write_tree_files(spec, C, tdir)
     for h in range(n_nodes):
         with open(os.path.join(tdir, "kmers", str(heap_to_id(h, C))), "w") as f:
             f.write(" ".join(map(str, range(int(row_off[h]), int(row_off[h + 1])))) + " ")
-    open(os.path.join(tdir, "reconstructed_nodes.txt"), "w").close()
-    with open(os.path.join(tdir, "hclsMap_95_recls.txt"), "w") as f:
-        for leaf in range(1, C + 1):
-            f.write("%d\t1\tstrain_%d\n" % (leaf, leaf))
     return tdir
 
 
-def write_fastq(reads_dev, n_reads, path):
-    reads = reads_dev.view(n_reads, 151)[:, :150].cpu().numpy()
-    rec = np.empty((n_reads, 307), np.uint8)
-    rec[:, 0:2] = np.frombuffer(b"@r", np.uint8); rec[:, 2] = 10
-    rec[:, 3:153] = reads
-    rec[:, 153] = 10; rec[:, 154] = ord("+"); rec[:, 155] = 10
-    rec[:, 156:306] = ord("I"); rec[:, 306] = 10
-    rec.tofile(path)
+write_fastq = bench.write_fastq
 
 
 def main():
