@@ -231,6 +231,106 @@ def prescan(pX, py, py_u, sid, cutoff, l2, pmode=0, emode=0):
     return out_columns, out_strain, strain_cov, strain_val, final_src, depth
 
 
+def prescan_packed(X, py, py_u, sid, cutoff, l2, pmode=0, emode=0):
+    """prescan() for inputs of BASELINE configs[3] size (K of millions x S of hundreds), where its dense int64
+    K x S temporaries (8 K S bytes each) no longer fit a test's time: the same quantities from bit-packed columns.
+    X is 0/1 (all_strains_re.npz holds int8 ones: Recls_withR_new.py:110-112), so `X[:, i] * v > 1` is `X[:, i] and
+    v > 1`, a column AND a row mask, and the counts are popcounts.  Percentiles still see the actual values.
+    Pinned to prescan() itself on the golden cases and on random ones (tests/test_oracle_golden.py).
+    X: scipy sparse (any format) or dense, K x S."""
+    import scipy.sparse as sp
+    Xc = sp.csc_matrix(X)
+    Xc.sum_duplicates()
+    K, S = Xc.shape
+    py = np.asarray(py, np.int64)
+    py_u = np.asarray(py_u, np.int64)
+    cols = [Xc.indices[Xc.indptr[i]:Xc.indptr[i + 1]][Xc.data[Xc.indptr[i]:Xc.indptr[i + 1]] != 0] for i in range(S)]
+
+    def pack(rows_or_mask, is_mask=False):
+        if is_mask:
+            m = rows_or_mask
+        else:
+            m = np.zeros(K, bool)
+            m[rows_or_mask] = True
+        return np.packbits(m)
+
+    P = [pack(c) for c in cols]
+    popc = lambda a: int(np.bitwise_count(a).sum())          # noqa: E731
+    y_gt1 = pack((py > 1) | (py < 0), True)
+    total = [len(c) for c in cols]
+    valid = [popc(P[i] & y_gt1) for i in range(S)]
+    cov_arr = np.array([(valid[i] / total[i]) if total[i] else 0 for i in range(S)], dtype=float)
+    default_cov = 0 if (pmode == 1 or emode == 1) else 0.7
+    zero = np.zeros_like(P[0])
+    if cov_arr.max() > default_cov:
+        keep = cov_arr > default_cov
+        cov_arr = keep.astype(float)
+        Pt = [P[i] if keep[i] else zero for i in range(S)]
+    else:
+        Pt = P
+        if cov_arr.max() < 0.01:
+            l2 = 2
+    yy = py_u if py_u.sum() > 0 else py
+    if l2 == 2:
+        dom = int(np.where(cov_arr == cov_arr.max())[0][0])
+    else:
+        res = []
+        for c in range(S):
+            da = yy[cols[c]]
+            nz = da[da != 0]
+            if nz.size < 1 or nz.sum() == 0:
+                res.append(0)
+                continue
+            lo = percentile_nearest(nz, 5)
+            hi = percentile_nearest(nz, 95)
+            t = da.copy()
+            t[t < lo] = 0
+            t[t > hi] = 0
+            res.append(int(t.sum()))
+        res = np.array(res)
+        dom = int(np.where(res == res.max())[0][0])
+    do = yy[cols[dom]].copy()
+    do[do == 1] = 0
+    nz = do[do != 0]
+    f25 = percentile_nearest(nz, 25)
+    f75 = percentile_nearest(nz, 75)
+    nz = nz.copy()
+    nz[nz < f25] = 0
+    nz[nz > f75] = 0
+    depth = float(np.mean(nz[nz != 0]))
+    strain_cov, strain_val, strain_remainc, final_src = {}, {}, {}, {}
+    out_columns, out_strain = [dom], [sid[dom]]
+    sc = lambda i: [float(valid[i] / total[i]) if total[i] else 0, valid[i], total[i]]   # noqa: E731
+    strain_cov[sid[dom]] = sc(dom)
+    strain_val[sid[dom]] = strain_cov[sid[dom]][1]
+    final_src[sid[dom]] = strain_cov[sid[dom]][0]
+    used = P[dom].copy()
+    yu_gt1 = pack(py_u > 1, True)
+    yy_gt1 = pack(yy > 1, True)
+    for i in range(S):
+        if i == dom:
+            continue
+        free = Pt[i] & ~used
+        all_k = popc(free)
+        strain_remainc[i] = 0 if all_k == 0 else popc(free & yu_gt1) / all_k
+    for _ in range(15):
+        checks = [popc(Pt[i] & ~used & yy_gt1) for i in range(S)]
+        cand = int(np.argmax(checks))
+        check = checks[cand]
+        rc, cc = (0, 5000) if emode == 1 else (0.2, cutoff)
+        if check >= cc:
+            if strain_remainc.get(cand, strain_remainc.get(sid[cand])) > rc:
+                out_columns.append(cand)
+                out_strain.append(sid[cand])
+                strain_cov[sid[cand]] = sc(cand)
+                strain_val[sid[cand]] = check
+                final_src[sid[cand]] = strain_remainc[cand]
+            used = used | P[cand]
+        else:
+            break
+    return out_columns, out_strain, strain_cov, strain_val, final_src, depth
+
+
 # ---------------------------------------------------------------------------------------------
 # a14-a16: ElasticNetCV -> lasso_mpm -> ElasticNet (identify_strains...:14-31,433-456)
 # restated per SURVEY Appendix C (scikit-learn 0.23/0.24 semantics)
@@ -286,6 +386,7 @@ def enet_cv(X, y, l1_ratio=0.5, n_alphas=50, n_splits=20, max_iter=5000, tol=1e-
             Q = Xt.T @ Xt
             q = Xt.T @ yt
             yy = float(yt @ yt)
+        Xe, ye = X[te], y[te]          # (the test rows are the same for every alpha: gathered once per fold)
         for a, alpha in enumerate(alphas):
             l1 = alpha * l1_ratio * len(tr)
             l2 = alpha * (1.0 - l1_ratio) * len(tr)
@@ -293,7 +394,7 @@ def enet_cv(X, y, l1_ratio=0.5, n_alphas=50, n_splits=20, max_iter=5000, tol=1e-
                 w, _, _ = enet_cd_gram(w, l1, l2, Q, q, yy, max_iter, tol)
             else:
                 w, _, _ = enet_cd(w, l1, l2, Xt, yt, max_iter, tol)
-            r = X[te] @ w - y[te]
+            r = Xe @ w - ye
             mse[a, f] = np.mean(r ** 2)
     return alphas, mse
 

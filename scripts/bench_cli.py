@@ -26,29 +26,27 @@ heap_to_id = bench.heap_to_id
 
 
 def write_db(torch, dev, spec, C, db_dir):
+    """The synthetic database of bench.make_db (either shape) in the reference's on-disk format: kmer.fa rows decoded
+    from the keys, kmers/<id> = the node's row numbers, the tree text files."""
     tdir = os.path.join(db_dir, "Tree_database")
     os.makedirs(os.path.join(tdir, "kmers"))
     n_nodes = spec["n_nodes"]
-    sites, seq_off, row_off = spec["sites"], spec["seq_off"], spec["row_off"].astype(np.int64)
+    row_off = spec["row_off"].astype(np.int64)
     asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)      # device codes 0..3 -> A C T G
-    ar = torch.arange(K, device=dev)
+    keys = torch.from_numpy(spec["keys"].view(np.int64))
+    sh = 2 * torch.arange(K, device=dev, dtype=torch.int64)
     with open(os.path.join(tdir, "kmer.fa"), "wb") as f:
-        for h0 in range(0, n_nodes, 64):                                     # chunks of nodes: bounded memory
-            h1 = min(n_nodes, h0 + 64)
-            ns = sites[h0:h1]
-            node = np.repeat(np.arange(h0, h1), ns)
-            pos = np.arange(int(ns.sum())) - np.repeat(np.concatenate([[0], np.cumsum(ns)[:-1]]), ns)
-            start = torch.from_numpy(seq_off[node] + pos).to(dev)
-            c = spec["codes"][start[:, None] + ar[None, :]].long()
-            rows = torch.empty((c.shape[0], 2, K + 4), dtype=torch.uint8, device=dev)
-            rows[:, :, 0] = 62; rows[:, :, 1] = 49; rows[:, :, 2] = 10; rows[:, :, K + 3] = 10   # ">1\n" ... "\n"
-            rows[:, 0, 3:K + 3] = asc[c]
-            rows[:, 1, 3:K + 3] = asc[c.flip(1) ^ 2]
+        for r0 in range(0, keys.numel(), 1 << 21):                           # bounded memory
+            kk = keys[r0:r0 + (1 << 21)].to(dev)
+            rows = torch.empty((kk.numel(), K + 4), dtype=torch.uint8, device=dev)
+            rows[:, 0] = 62; rows[:, 1] = 49; rows[:, 2] = 10; rows[:, K + 3] = 10   # ">1\n" ... "\n"
+            rows[:, 3:K + 3] = asc[(kk[:, None] >> sh[None, :]) & 3]
             f.write(rows.cpu().numpy().tobytes())
     bench.write_tree_files(spec, C, tdir)
+    rows_np = spec["rows"]
     for h in range(n_nodes):
         with open(os.path.join(tdir, "kmers", str(heap_to_id(h, C))), "w") as f:
-            f.write(" ".join(map(str, range(int(row_off[h]), int(row_off[h + 1])))) + " ")
+            f.write(" ".join(map(str, rows_np[int(row_off[h]):int(row_off[h + 1])].tolist())) + " ")
     return tdir
 
 

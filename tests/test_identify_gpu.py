@@ -137,3 +137,85 @@ def test_identify_cluster_from_files_cold_and_cached(tmp_path, monkeypatch):
     assert dict(second) == dict(first)
     assert np.array_equal(ssdb.tree_image(tdir, True).counts, counts_first)
     ssdb.clear_cache()
+
+
+def _rank_paths_restated(parent_of, leaves, frac):
+    """identify_low_depth.py:134-151 restated for the test: geometric mean over the root path of
+    x = 1 if frac > 0.05 else log(180 frac + 1, 10); nodes with frac == -1 are skipped; zero scores dropped."""
+    from math import log
+    out = {}
+    for leaf in leaves:
+        path, n = [], leaf
+        while n is not None:
+            path.append(n)
+            n = parent_of[n]
+        path = path[::-1]
+        N = len([i for i in path if frac[i] != -1])
+        score = 1
+        for i in path:
+            if frac[i] == -1:
+                continue
+            x = 1 if frac[i] > 0.05 else log(180 * frac[i] + 1, 10)
+            score = score * pow(x, 1 / N)
+        if score != 0:
+            out[leaf] = score
+    return sorted(out.items(), key=lambda kv: kv[1], reverse=True)
+
+
+@pytest.mark.parametrize("shape", ["sampled", "contiguous"])
+def test_config4_low_depth_cli(shape, tmp_path, monkeypatch):
+    """BASELINE configs[4]: low-depth mode (-b 1) on an M. tuberculosis-shaped tree (25 clusters = 49 nodes), a mixed
+    sample of two strains 80/20 at 0.5x coverage, through the CLI entry (StrainScan.main, StrainScan.py:98-111,186-191).
+    strain_prob.txt must carry the scores the reference's formula gives on the ORACLE's counts of the same files
+    (identify_low_depth.py:104-156), to 1e-12, in the same order; the two true clusters lead the ranking."""
+    import torch
+    import bench
+    from oracle import oracle as orc
+    from scripts import bench_cli
+    from strainscan_amd import StrainScan, db as ssdb
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    dev = torch.device("cuda", 0)
+    C = 25
+    spec = bench.make_db(torch, dev, C, seed=4242, shape=shape, hit_frac=0.05)
+    dbdir = str(tmp_path / "db")
+    tdir = bench_cli.write_db(torch, dev, spec, C, dbdir)
+    # genome of a leaf = its root path's stretches + filler (bench.make_reads); 0.5x of a ~5 path-nodes genome
+    n_db = int(spec["sites"].mean() * 5)
+    genome_len = int(n_db / 0.05)
+    n_reads = int(0.5 * genome_len / 150 / 0.8)           # the dominant strain (80 %) at ~0.5x
+    r = bench.make_reads(torch, dev, spec, n_reads, seed=9, hit_frac=0.05, mix=(0.8, 0.2))
+    half = n_reads // 2
+    fq = [str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")]
+    bench.write_fastq(r[: half * 151], half, fq[0])
+    bench.write_fastq(r[half * 151:], n_reads - half, fq[1])
+    ssdb.clear_cache()
+    out = tmp_path / "o"
+    with contextlib.redirect_stdout(io.StringIO()):
+        try:
+            StrainScan.main(["-i", fq[0], "-j", fq[1], "-d", dbdir, "-o", str(out), "-b", "1"])
+        except (SystemExit, FileNotFoundError, RuntimeError):
+            pass        # no Kmer_Sets_L2 in this synthetic database: layer 1 and the -b report are what is checked
+    lines = (out / "strain_prob.txt").read_text().strip().split("\n")
+    assert lines[0] == "Cluster_ID\tProbability\tNumber_of_strains\tStrains_in_the_cluster"
+    # expectation from the oracle's counts of the same two files
+    kfa = open(os.path.join(tdir, "kmer.fa"), "rb").read()
+    counts, valid = orc.jellyfish_count(kfa, [open(fq[0], "rb").read(), open(fq[1], "rb").read()], k=31, upper=False)
+    ids = [bench.heap_to_id(h, C) for h in range(spec["n_nodes"])]
+    parent_of = {bench.heap_to_id(h, C): (None if h == 0 else bench.heap_to_id((h - 1) // 2, C)) for h in range(spec["n_nodes"])}
+    row_off = spec["row_off"].astype(np.int64)
+    frac = {}
+    for h, nid in enumerate(ids):
+        o = orc.match_node(counts, valid, spec["rows"][int(row_off[h]):int(row_off[h + 1])].astype(np.int64))
+        frac[nid] = -1 if o["length"] < 1000 else o["n_kept"] / o["length"]
+    want = _rank_paths_restated(parent_of, list(range(1, C + 1)), frac)
+    assert len(lines) - 1 == len(want) and len(want) >= 2
+    got = [(int(ln.split("\t")[0][1:]), float(ln.split("\t")[1])) for ln in lines[1:]]
+    assert sorted(a for a, _ in got) == sorted(a for a, _ in want)
+    for (a, b), (wa, wb) in zip(got, want):
+        assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+        assert a == wa or abs(b - dict(want)[a]) <= 1e-12      # equal scores may swap
+    # the strains the reads came from: make_reads draws its leaves with RandomState(seed)
+    rs = np.random.RandomState(9)
+    true_leaves = {bench.heap_to_id(int(h), C) for h in rs.choice(np.arange(spec["n_nodes"] // 2, spec["n_nodes"]), size=2, replace=False)}
+    assert {a for a, _ in got[:2]} == true_leaves
+    ssdb.clear_cache()

@@ -249,3 +249,76 @@ def test_l2_batch_threads_equal_serial(tmp_path, monkeypatch):
                                                            "C2/StrainVote.report", "C3/StrainVote.report")}
         assert len(outs[label]["final_report.txt"].strip().split("\n")) >= 6
     assert outs["threads_cold"] == outs["serial"] and outs["threads_warm"] == outs["serial"]
+
+
+def _big_cluster(K, S, depths, seed, near_dup=None, density=0.35, G=64):
+    """One large cluster as BASELINE configs[3] has them: K k-mers x S strains (CSC built column by column -- no dense
+    K x S array), G segments with a presence pattern over the strains, Poisson depths for the strains present.
+    near_dup = (a, b, n_flip): strain b's pattern = strain a's with n_flip segments flipped (near-duplicate strains:
+    two almost collinear columns in the regression)."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(seed)
+    pres = rs.random_sample((S, G)) < density
+    if near_dup:
+        a, b, nf = near_dup
+        pres[b] = pres[a]
+        flip = rs.choice(G, size=nf, replace=False)
+        pres[b, flip] = ~pres[b, flip]
+    seg = rs.randint(0, G, size=K)
+    indptr, indices = [0], []
+    for s in range(S):
+        r = np.nonzero(pres[s][seg])[0]
+        indices.append(r.astype(np.int32))
+        indptr.append(indptr[-1] + r.size)
+    indices = np.concatenate(indices)
+    X = sp.csc_matrix((np.ones(indices.size, np.int8), indices, np.array(indptr, np.int64)), shape=(K, S))
+    lam = np.zeros(K)
+    for s, d in depths.items():
+        lam += pres[s, seg] * d
+    y = rs.poisson(lam).astype(np.int64)
+    y[y == 1] = 0
+    O = sp.csr_matrix(np.ones((K, 1), np.int8))
+    return X, O, ["S%03d" % i for i in range(S)], y
+
+
+@pytest.mark.parametrize("case", ["three_strains", "near_duplicates"])
+def test_detect_core_at_config3_size(case):
+    """BASELINE configs[3] scale: one cluster of K = 2 M k-mers x S = 200 strains (140 M non-zeros).  detect_core against
+    the oracle on the same inputs: every pre-scan integer bit-exact (oracle.prescan_packed = prescan on packed columns,
+    pinned to prescan in the CPU tests), alpha grid and chosen alpha to 1e-12, abundances within 1e-5 -- also with two
+    near-duplicate strains both present (60 of 64 segments shared: the design matrix of the regression is close to
+    collinear, which is where the refit's Gram form could drift from sklearn's residual form)."""
+    from oracle import oracle as orc
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    K, S = 2_000_000, 200
+    if case == "three_strains":
+        X, O, ids, y = _big_cluster(K, S, {3: 30.0, 57: 11.0, 120: 5.0}, seed=5)
+    else:
+        X, O, ids, y = _big_cluster(K, S, {3: 24.0, 57: 9.0, 120: 5.0}, seed=6, near_dup=(3, 57, 4))
+    nz = y[y != 0]
+    npp = float(np.median(nz) * 1000)
+    trace = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        res, res2, scov, sval, fsrc = m.detect_core(X.tocsr(), O, ids, y.copy(), 31, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=trace)
+    cols, names, o_cov, o_val, o_src, depth = orc.prescan_packed(X, y, y, ids, 40 * 31, 0, 0, 0)
+    assert list(scov.keys()) == names and len(names) >= 3
+    assert {k: list(v) for k, v in scov.items()} == {k: list(v) for k, v in o_cov.items()}
+    assert {k: int(v) for k, v in sval.items()} == {k: int(v) for k, v in o_val.items()}
+    for k, v in o_src.items():
+        assert abs(fsrc[k] - v) < 1e-12
+    keep = (y >= 0) & (y <= npp)
+    Xs = X[:, cols].toarray()[keep]
+    al, mse = orc.enet_cv(Xs, y[keep])
+    a, _, _ = orc.lasso_mpm(al, mse)
+    coef = orc.enet_fit(Xs, y[keep], a)
+    assert trace["n_rows"] == int(keep.sum()) and trace["p"] == len(cols)
+    assert np.allclose(trace["alphas_"], al, rtol=1e-12, atol=0)
+    assert np.allclose(trace["mse_path_"], mse, rtol=1e-7, atol=1e-9)
+    assert abs(trace["alpha"] - a) <= 1e-12 * max(1.0, abs(a))
+    assert np.allclose(trace["coef_"], coef, rtol=0, atol=ABUND_TOL), (trace["coef_"], coef)
+    rel = coef / coef.sum()
+    for n_, r_ in zip(names, rel):
+        if r_ > 0 or n_ in res:
+            assert abs(float(res.get(n_, 0.0)) - r_) <= ABUND_TOL, (case, n_, res.get(n_), r_)
+    if case == "near_duplicates":
+        assert "S003" in res and "S057" in res          # both near-duplicates are reported

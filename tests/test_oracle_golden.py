@@ -152,3 +152,28 @@ def test_binom_table_matches_scipy(golden_dir):
 def test_revcomp(golden_dir):
     for s, want in _load(golden_dir, "revcomp.json"):
         assert orc.revcomp(s.encode()).decode() == want
+
+
+def test_prescan_packed_equals_prescan():
+    """oracle.prescan_packed (bit-packed columns, for configs[3]-size inputs) against oracle.prescan (the literal
+    restatement, pinned above to the reference's golden outputs): every golden scenario and random clusters, all
+    modes."""
+    from scripts.bench_l2 import make_case
+    for name in sc.L2_CASES:
+        c = sc.l2_case(name)
+        X, y = c["X"].toarray(), c["y"]
+        ln = c["O"].toarray()[:, [i - 1 for i in c["all_cls"]]].sum(1)
+        ln[ln > 1] = 0
+        yu = y * ln
+        a = orc.prescan(X, y, yu, c["ids"], 40 * 31, c["l2"], c["pmode"], c["emode"])
+        b = orc.prescan_packed(c["X"], y, yu, c["ids"], 40 * 31, c["l2"], c["pmode"], c["emode"])
+        assert a == b, name
+    rs = np.random.RandomState(1)
+    for t in range(4):
+        K, S = int(rs.randint(2000, 12000)), int(rs.randint(3, 24))
+        X, O, ids, y = make_case(K, S, {0: 25.0, 1 % S: 9.0, 2 % S: float(rs.choice([0, 4.0]))}, seed=t,
+                                 density=float(rs.uniform(0.2, 0.6)))
+        yu = y.copy()
+        yu[rs.random_sample(K) < 0.2] = 0
+        for l2, pm, em in ((0, 0, 0), (1, 0, 0), (0, 0, 1), (0, 1, 0)):
+            assert orc.prescan(X.toarray(), y, yu, ids, 1240, l2, pm, em) == orc.prescan_packed(X, y, yu, ids, 1240, l2, pm, em)

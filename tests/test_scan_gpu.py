@@ -697,3 +697,55 @@ def test_harvest_path_equals_row_gather(L):
     ns = L.NodeSet(lists)
     a, b = ns.reduce(db), ns.harvest(db)
     assert a.tobytes() == b.tobytes() and int(b["n_pos"].sum()) > 1000
+
+
+@pytest.mark.parametrize("shape", ["sampled", "contiguous"])
+def test_full_size_config1(L, shape):
+    """BASELINE configs[1] at full size, the workload bench.py times: the E. coli-shaped table (823 clusters = 1645 nodes,
+    25.4 M rows, node sets sampled as Build_tree.py:590-591 writes them, or contiguous) and 20 M reads.  The first
+    2.5 M reads against the oracle, bit for bit; then shard additivity over the rest (counts of the whole batch = counts
+    of the sample + counts of the remainder: integer sums, the property the multi-GPU split relies on); node statistics of
+    all 1645 nodes: harvest path = row-gather path = the oracle's match_node on the nodes with hits."""
+    import ctypes as C
+    import torch
+    import bench
+    from oracle import oracle as orc
+    dev = torch.device("cuda", 0)
+    spec = bench.make_db(torch, dev, 823, seed=20231013, shape=shape, hit_frac=0.05)
+    n_rows = spec["keys"].size
+    assert spec["n_nodes"] == 1645 and n_rows > 25_000_000
+    db = L.KmerDB(spec["keys"], np.ones(n_rows, np.uint8), 31, True)
+    n_reads, n_a = 20_000_000, 2_500_000
+    reads = bench.make_reads(torch, dev, spec, n_reads, seed=2, hit_frac=0.05)
+    torch.cuda.synchronize()
+    cut = n_a * 151
+    db.scan_flat_dev(reads.data_ptr(), cut)
+    L.check(L.lib().ss_device_sync(), "sync")
+    c_a = db.counts_rows()
+    want = orc.count_flat(spec["okeys"], 31, reads[:cut].cpu().numpy(), 8)
+    assert np.array_equal(c_a, want) and int(want.sum()) > 5_000_000
+    db.reset()
+    db.scan_flat_dev(reads.data_ptr() + cut, reads.numel() - cut)
+    L.check(L.lib().ss_device_sync(), "sync")
+    c_b = db.counts_rows()
+    db.reset()
+    db.scan_flat_dev(reads.data_ptr(), reads.numel())
+    L.check(L.lib().ss_device_sync(), "sync")
+    c_all = db.counts_rows()
+    assert np.array_equal(c_all, c_a + c_b)
+    h = C.c_void_p()
+    L.check(L.lib().ss_nodes_create(L.ptr(spec["rows"]), L.ptr(spec["row_off"]), spec["n_nodes"], C.byref(h)), "ss_nodes_create")
+    ns = L.NodeSet.__new__(L.NodeSet)
+    ns._h, ns.n_nodes = h, spec["n_nodes"]
+    a, b = ns.reduce(db), ns.harvest(db)
+    assert a.tobytes() == b.tobytes()
+    hot = np.nonzero(b["n_pos"])[0]
+    assert 10 <= hot.size <= 40
+    valid = np.ones(n_rows, np.uint8)
+    off = spec["row_off"].astype(np.int64)
+    for j in list(hot) + [0, 1644, 7]:
+        o = orc.match_node(c_all, valid, spec["rows"][off[j]:off[j + 1]].astype(np.int64))
+        got = (int(b[j]["length"]), int(b[j]["n_pos"]), int(b[j]["n_kept"]), int(b[j]["sum_kept"]), int(b[j]["median2"]))
+        assert got == (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"], int(round(2 * o["median"])) if o["n_pos"] else 0), (j, got, o)
+    ns.close()
+    db.close()
