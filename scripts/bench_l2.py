@@ -15,11 +15,18 @@ sys.path.insert(0, ROOT)
 
 
 def make_case(K, S, depths, seed=5, density=0.35):
+    """K k-mers x S strains, CSC built column by column (no dense K x S array: 1.5 GB at K = 5 M, S = 300)."""
     rs = np.random.RandomState(seed)
     G = 64                                     # segments with a presence pattern over strains
     pres = rs.random_sample((S, G)) < density
     seg = rs.randint(0, G, size=K)
-    X = sp.csr_matrix(pres[:, seg].T.astype(np.int8))
+    indptr, indices = [0], []
+    for s in range(S):
+        r = np.nonzero(pres[s][seg])[0]
+        indices.append(r.astype(np.int32))
+        indptr.append(indptr[-1] + r.size)
+    indices = np.concatenate(indices)
+    X = sp.csc_matrix((np.ones(indices.size, np.int8), indices, np.array(indptr, np.int64)), shape=(K, S)).tocsr()
     lam = np.zeros(K)
     for s, d in depths.items():
         lam += pres[s, seg] * d
@@ -46,7 +53,11 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             res = m.detect_core(X, O, ids, y.copy(), 31, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=trace)
         ts.append(time.perf_counter() - t0)
+    # SURVEY 8(d) algorithmic bytes: a pre-scan pass reads the bit-packed matrix once, S * K / 8 B (+ K / 8 per mask);
+    # the pattern statistics read the p selected bit planes + y once per fold: (p * K / 8 + 8 K) * 21
     out = dict(K=K, S=S, nnz=int(X.nnz), seconds=round(min(ts), 4), selected=list(res[0].keys()),
+               algorithmic_bytes=dict(prescan_pass=S * K // 8 + K // 8,
+                                      pattern_stats=(len(res[2]) * K // 8 + 8 * K) * 21),
                rel=[round(float(v), 6) for v in res[0].values()], n_rows=trace.get("n_rows"), p=trace.get("p"))
     if check:
         from oracle import oracle as orc
