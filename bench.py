@@ -546,6 +546,8 @@ def main(argv=None):
                                db_rows=int(n_rows), tree_nodes=int(db_spec["n_nodes"]), reads_per_gpu=args.reads,
                                read_len=READ_LEN, k=K, hit_frac=args.hit_frac, db_shape=args.db_shape,
                                table_slots=int(info["capacity"]), minimizer_buckets=int(info.get("n_buckets", 0)),
+                               index=dict(pages=info.get("n_dir"), bucket_slots=info.get("n_mslots"), inline_kmers=info.get("n_inline"),
+                                          filter_bits=info.get("filter_bits"), device_gb=round(info["device_bytes"] / 1e9, 3)),
                                table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
                    roofline=roofline, cpu_baseline=cpu, phases=phases,

@@ -126,8 +126,8 @@ int ss_db_row_valid(const ss_db *db, uint8_t *row_valid);
 const uint8_t *ss_db_row_valid_dev(const ss_db *db);
 uint64_t ss_db_device_bytes(const ss_db *db);
 /* Shape of the built index, for benchmarks and logs (no reference counterpart: jellyfish prints nothing):
- * out[0] layout (0 flat table, 1 minimizer buckets), [1] count slots, [2] minimizer buckets,
- * [3] directory buckets, [4] log2 of the filter size in bits (0 = none), [5] distinct k-mers, [6..7] 0. */
+ * out[0] layout (0 flat table, 1 minimizer pages), [1] counters, [2] minimizers, [3] 64-byte pages,
+ * [4] log2 of the filter size in bits (0 = none), [5] distinct k-mers, [6] bucket-array slots, [7] k-mers inline in pages. */
 int ss_db_index_info(const ss_db *db, uint64_t out[8]);
 
 /* --------------------------------------------------------------------------------------------

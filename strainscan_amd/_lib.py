@@ -252,7 +252,7 @@ class KmerDB:
         check(lib().ss_db_index_info(self._h, ptr(ix)), "ss_db_index_info")
         return dict(n_rows=a.value, n_distinct=b.value, capacity=c.value, k=k.value,
                     device_bytes=int(lib().ss_db_device_bytes(self._h)), layout=int(ix[0]), n_slots=int(ix[1]),
-                    n_buckets=int(ix[2]), n_dir=int(ix[3]), filter_bits=int(ix[4]))
+                    n_buckets=int(ix[2]), n_dir=int(ix[3]), filter_bits=int(ix[4]), n_mslots=int(ix[6]), n_inline=int(ix[7]))
 
     @property
     def row_valid(self):

@@ -72,6 +72,7 @@ struct ss_db {
     int layout = 0;                    // 0 = flat open-address table, 1 = minimizer buckets (k = 31)
     uint64_t n_slots = 0;              // length of d_counts: capacity (flat) or n_mslots + 8 * n_dir (pages)
     uint64_t n_mslots = 0;             // pages: length of d_mkeys (bucket headers + k-mers)
+    uint64_t n_inline = 0;             // pages: database k-mers held inline in page slots
     uint64_t *d_keys = nullptr;        // flat: [capacity] table keys, EMPTY_KEY where free
     uint64_t *d_mkeys = nullptr;       // pages: [n_mslots] buckets of the minimizers with many k-mers (ss_mini.hip)
     uint64_t *d_dir = nullptr;         // pages: [n_dir][8] 64-byte pages of slots (inline k-mers, bucket references)

@@ -841,6 +841,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     sorted.clear();
     sorted.shrink_to_fit();
     db->n_mslots = n_mslots;
+    db->n_inline = (db->n_distinct + n_items - p_slots[NP]) / 2;   // items = inline k-mers + references; bucket slots = references + their k-mers
     db->n_slots = n_mslots + n_pages * PG_SLOTS;
     db->n_dir = (uint32_t)n_pages;
     db->dirbits = 0;
@@ -976,9 +977,9 @@ __global__ void validate_image_kernel(const uint32_t *__restrict__ slot_of_row, 
 }
 
 struct ImageHeader {
-    char magic[8];          // "SSIDX07\0"
+    char magic[8];          // "SSIDX08\0"
     int32_t k, layout;
-    uint64_t n_rows, n_distinct, n_slots, n_buckets, n_mslots;
+    uint64_t n_rows, n_distinct, n_slots, n_buckets, n_mslots, n_inline;
     uint32_t n_dir, bloom_bits;
 };
 
@@ -1051,10 +1052,10 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX07", 8);
+    memcpy(h.magic, "SSIDX08", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
-    h.n_mslots = db->n_mslots;
+    h.n_mslots = db->n_mslots; h.n_inline = db->n_inline;
     h.n_dir = db->n_dir;
     h.bloom_bits = db->d_bloom ? db->bloom_bits : 0;
     const uint64_t nr = std::max<uint64_t>(1, db->n_rows);
@@ -1074,7 +1075,7 @@ int ss_db_import(const char *path, ss_db **out)
     if (fd < 0) return SS_EIO;
     ImageHeader h;
     struct stat st;
-    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX07", 8) != 0 ||
+    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX08", 8) != 0 ||
         h.layout != 1 || h.k != 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_slots != h.n_mslots + (uint64_t)h.n_dir * 8 ||
         h.n_slots >= 0xFFFFFFF0ull || h.n_mslots >= (uint64_t)ss::START_MASK || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         close(fd);
@@ -1089,7 +1090,7 @@ int ss_db_import(const char *path, ss_db **out)
     if (!db) { close(fd); return SS_ENOMEM; }
     db->k = h.k; db->layout = 1;
     db->n_rows = h.n_rows; db->n_distinct = h.n_distinct; db->n_slots = h.n_slots; db->capacity = h.n_slots;
-    db->n_mslots = h.n_mslots;
+    db->n_mslots = h.n_mslots; db->n_inline = h.n_inline;
     db->n_buckets = h.n_buckets; db->n_dir = h.n_dir;
     hipGetDevice(&db->device);
     bool ok = hipMalloc((void **)&db->d_mkeys, sizes[0]) == hipSuccess && hipMalloc((void **)&db->d_dir, sizes[1]) == hipSuccess &&

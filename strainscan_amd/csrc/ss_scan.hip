@@ -324,7 +324,7 @@ int ss_db_index_info(const ss_db *db, uint64_t out[8])
 {
     if (!db || !out) return SS_EINVAL;
     out[0] = (uint64_t)db->layout; out[1] = db->n_slots; out[2] = db->n_buckets; out[3] = db->n_dir;
-    out[4] = db->d_bloom ? db->bloom_bits : 0; out[5] = db->n_distinct; out[6] = 0; out[7] = 0;
+    out[4] = db->d_bloom ? db->bloom_bits : 0; out[5] = db->n_distinct; out[6] = db->n_mslots; out[7] = db->n_inline;
     return SS_OK;
 }
 uint64_t ss_scan_kernel_launches(const ss_db *db) { return db ? db->launches.load() : (uint64_t)0; }
