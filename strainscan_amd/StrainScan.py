@@ -106,8 +106,11 @@ def main(argv=None):
     from . import dist
     rank, world = dist.init_from_env()      # torchrun: one process per GPU, reads shard across ranks
     if rank != 0:                           # every rank computes; rank 0 owns the output directory
+        import atexit
+        import shutil
         import tempfile
         out_dir = tempfile.mkdtemp(prefix="strainscan_rank%d_" % rank)
+        atexit.register(shutil.rmtree, out_dir, True)      # the other ranks' reports are scratch
     in_fq = (fq_dir, fq2)
     tdb = db_dir + "/Tree_database"
     if sprob == 1:
