@@ -749,3 +749,35 @@ def test_full_size_config1(L, shape):
         assert got == (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"], int(round(2 * o["median"])) if o["n_pos"] else 0), (j, got, o)
     ns.close()
     db.close()
+
+
+def test_bench_line_contract_and_exchange_path():
+    """bench.py on a small configuration: the JSON line carries the contract's fields (roofline, cpu_baseline with
+    parity_on_sample, phases, e2e_reads_per_s); and the N > 1 code path -- RCCL exchange of the touched nodes between
+    harvest and node reductions -- run in a one-rank process group (SS_BENCH_FORCE_EXCHANGE=1), its node statistics
+    equal to the row-gather path's."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(repo, "bench.py"), "--reads", "300000", "--leaves", "23", "--steps", "2", "--warmup", "1",
+            "--phase-reads", "100000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for shape in ("sampled", "contiguous"):
+        r = subprocess.run(base + ["--db-shape", shape], env=env, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline", "cpu_baseline", "phases", "e2e_reads_per_s"):
+            assert key in d, key
+        assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["db_shape"] == shape and d["vs_baseline"] is None
+        rf = d["roofline"]
+        assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0
+        assert d["cpu_baseline"]["parity_on_sample"] is True and d["cpu_baseline"]["kind"] == "port"
+        assert d["check"]["harvest_equals_gather"] is True and d["check"]["total_hits"] > 0
+        assert d["phases"]["clusters_found"] == 3 and d["phases"]["l1_host_ms"] > 0 and d["e2e_reads_per_s"] > 0
+    r = subprocess.run(base + ["--no-cpu-baseline", "--no-phases"], env=dict(env, SS_BENCH_FORCE_EXCHANGE="1"), capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][-1])
+    assert d["check"]["harvest_equals_gather"] is True and d["check"]["exchanged_counts"] > 0 and d["n_gpus"] == 1
