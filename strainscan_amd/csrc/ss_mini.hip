@@ -154,9 +154,10 @@ struct Ent {
 // scan kernel, minimizer layout: dense SIMD for the arithmetic, compacted LDS work queues for
 // the memory probes.
 //
-// Measured on MI355X (profiles/r01b..f): what bounds this kernel is not HBM bytes but the
-// instructions a wave issues per tile (VALU 82 % busy at 8 waves/SIMD) and the latency chains of
-// its three dependent memory probes.  So per tile of 62 x 16 = 992 start positions, ONE wave:
+// Measured on MI355X (profiles/): what bounds this kernel is not HBM bytes but, depending on the
+// database, the instructions a wave issues per tile (dense node sets: VALU 100 % busy at 8 waves/SIMD) or the
+// number of random 64-byte sectors it asks of the memory system (sampled node sets: 54 G/s, all there is).
+// So per tile of 62 x 16 = 992 start positions, ONE wave, no barriers that wait for another wave:
 //   phase 0  coalesced 16-byte loads of the bases, 2-bit encode, codes + invalid flags -> LDS
 //   phase 1a every lane keys the 16 m-mers that start in its bases (one multiply-add each) and tags
 //            them with their index: packed = (key & ~31) | index, kept in registers
@@ -165,10 +166,12 @@ struct Ent {
 //            decides key AND leftmost position); runs of equal minimizers, merged across lane
 //            boundaries, are pushed to LDS queue q1 through a DPP wave prefix sum
 //            (one 32-bit entry per run: ~94 per tile instead of 992 positions)
-//   phase 2a lanes pull runs from q1: the minimizer m-mer is re-read from the codes, one mix, one
-//            probe of the Bloom filter (L2).  The ~10 % that pass are compacted into q1b
-//   phase 2b ONE 16-byte directory load per surviving run; runs whose minimizer exists go to q2
-//   phase 3  16 lanes per found run, one per position: candidate slot from the run's offset mask
+//   phase 2a (databases with a Bloom filter) lanes pull runs from q1: the minimizer m-mer is re-read from the
+//            codes, one mix, one probe of the Bloom filter (L2).  The ~10 % that pass are compacted into q1b
+//   phase 2b ONE 16-byte load per run (all runs, or the Bloom survivors): the head of the minimizer's page.
+//            Inline k-mers are settled here (tag + offset + flank = the whole k-mer -> atomicAdd); bucket
+//            references go to q2
+//   phase 3  16 lanes per found bucket, one per position: candidate slot from the run's offset mask
 //            -> 64-bit compare -> atomicAdd
 // ---------------------------------------------------------------------------------------------
 // threads per workgroup of this kernel = one wave
@@ -304,7 +307,7 @@ __device__ unsigned long long ss_timing[32];
 #else
 #define SS_T(i) asm volatile("; SSMARK " #i)
 #endif
-// debug builds -DSS_STOP_AFTER=n end every tile after phase n (1 = m-mer keys, 2 = runs queued, 3 = directory):
+// debug builds -DSS_STOP_AFTER=n end every tile after phase n (1 = m-mer keys, 2 = runs queued, 3 = page lookups):
 // dynamic instruction counts and times per phase (scripts/gpu_stop.sh); results are then of course wrong
 #ifdef SS_STOP_AFTER
 #define SS_STOP(n) if (SS_STOP_AFTER == (n)) { __syncthreads(); continue; }
@@ -692,7 +695,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     uint32_t inline_max = 2;                        // minimizers with at most this many database k-mers keep them in page slots
     if (const char *e = getenv("SS_INLINE_MAX")) inline_max = (uint32_t)std::max(0, std::min(8, atoi(e)));
     double lambda = 2.0;                            // page items per page on average (eight slots: one page in a thousand full)
-    if (const char *e = getenv("SS_PAGE_LAMBDA")) lambda = std::max(0.25, std::min(6.0, atof(e)));
+    if (const char *e = getenv("SS_PAGE_LAMBDA")) lambda = std::max(0.25, std::min(7.8, atof(e)));   // < 8: the pages must hold all items
     // 1. entries of valid rows with their minimizer
     std::vector<uint64_t> pos(n_rows + 1, 0);
     for (uint64_t i = 0; i < n_rows; i++) pos[i + 1] = pos[i] + ((flags[i] & SS_ROW_VALID) ? 1 : 0);
