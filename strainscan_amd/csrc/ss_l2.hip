@@ -44,6 +44,34 @@ __global__ void pack_csr_kernel(const int64_t *__restrict__ indptr, const int32_
     }
 }
 
+// The same without atomics for rows whose column indices ascend (scipy's canonical CSR): one lane per row, the wave
+// walks the S columns together -- ballot(lane's next index == s) IS the two 32-bit words of column s for these 64
+// rows.  513 M atomicOr (16 ms at K = 5 M, S = 300) become 23 M 8-byte stores.  A row whose list is not consumed by
+// the walk (unsorted or out-of-range indices) raises *redo: the caller runs pack_csr_kernel.
+__global__ __launch_bounds__(256) void pack_csr_sorted_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                              uint64_t K, uint32_t S, uint64_t W, uint32_t *x, int *redo)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t p = 0, e = 0;
+    if (k < K) { p = indptr[k]; e = indptr[k + 1]; }
+    int32_t nxt = p < e ? indices[p] : 0x7FFFFFFF;
+    const uint64_t w0 = (k & ~63ull) >> 5;                   // first of the wave's two words
+    const bool writer = (threadIdx.x & 63) == 0;
+    for (uint32_t s = 0; s < S; s++) {
+        const bool has = nxt == (int32_t)s;
+        const uint64_t m = __ballot(has);
+        if (has) {
+            do { p++; nxt = p < e ? indices[p] : 0x7FFFFFFF; } while (nxt == (int32_t)s);   // duplicates collapse
+        }
+        if (writer && m && w0 < W) {
+            uint32_t *dst = x + (uint64_t)s * W + w0;
+            dst[0] = (uint32_t)m;
+            if (w0 + 1 < W) dst[1] = (uint32_t)(m >> 32);
+        }
+    }
+    if (p < e) *redo = 1;
+}
+
 // out1[s] = popc(X_s & A), out2[s] = popc(X_s & A & B); A or B may be null (= all ones)
 __global__ __launch_bounds__(NT) void popc2_kernel(const uint32_t *__restrict__ x, uint64_t W,
                                                    const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
@@ -78,6 +106,14 @@ __global__ void andnot_col_kernel(const uint32_t *__restrict__ x, uint64_t W, ui
         nu[i] &= ~x[(uint64_t)col * W + i];
 }
 
+__global__ void max_u32_kernel(const uint32_t *__restrict__ y, uint64_t n, uint32_t *out)
+{
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = max(m, y[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // ---- masked order statistics: per listed column, values y[k] over rows with X bit set and
 // y[k] != 0; two ranks per column are selected together (8-bit radix passes) ------------------
 struct SelState {
@@ -89,7 +125,7 @@ struct SelState {
 
 __global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
                                                       const uint32_t *__restrict__ y,
-                                                      const uint32_t *__restrict__ cols, int shift,
+                                                      const uint32_t *__restrict__ cols, int shift, int first,
                                                       const SelState *__restrict__ st, uint32_t *hist /*[ncols][2][256]*/)
 {
     __shared__ uint32_t h[2][256];
@@ -109,7 +145,7 @@ __global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict
             const uint32_t v = y[k];
             if (v == 0) continue;
             const uint32_t d = (v >> shift) & 255u;
-            if (shift == 24) {
+            if (first) {                          // no prefix yet (the bytes above `shift` are zero in every value)
                 atomicAdd(&h[0][d], 1u);
             } else {
                 const uint32_t hi = v >> (shift + 8);
@@ -121,7 +157,7 @@ __global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict
     __syncthreads();
     uint32_t *g = hist + (uint64_t)c * 512;
     if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
-    if (shift != 24 && h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
+    if (!first && h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
 }
 
 // numpy.percentile(..., interpolation='nearest'): index = around(q/100 * (n-1)), half to even
@@ -130,13 +166,13 @@ __device__ __forceinline__ unsigned long long nearest_rank(double q, unsigned lo
     return (unsigned long long)rint((q / 100.0) * (double)(n - 1));
 }
 
-__global__ void sel_pick_kernel(int shift, double q_lo, double q_hi, SelState *st, uint32_t *hist, uint32_t ncols)
+__global__ void sel_pick_kernel(int first, double q_lo, double q_hi, SelState *st, uint32_t *hist, uint32_t ncols)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     uint32_t *g = hist + (uint64_t)c * 512;
     SelState s = st[c];
-    if (shift == 24) {
+    if (first) {
         unsigned long long n = 0;
         for (int b = 0; b < 256; b++) n += g[b];
         s.n = n;
@@ -146,7 +182,7 @@ __global__ void sel_pick_kernel(int shift, double q_lo, double q_hi, SelState *s
     }
     if (s.n) {
         for (int t = 0; t < 2; t++) {
-            const uint32_t *h = (shift == 24) ? g : g + 256 * t;
+            const uint32_t *h = first ? g : g + 256 * t;
             unsigned long long cum = 0;
             int b = 0;
             for (; b < 255; b++) {
@@ -279,10 +315,21 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
                (nnz && hipMemcpy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
         rc = SS_EHIP;
     } else if (K) {
-        hipLaunchKernelGGL(pack_csr_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
-                           h->W, h->d_x, d_bad);
-        if (hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
-        else if (bad) rc = SS_EINVAL;
+        static const bool force_atomic = getenv("SS_L2_PACK_ATOMIC") != nullptr;          // tests: the general kernel
+        int redo = 1;
+        if (!force_atomic) {
+            hipLaunchKernelGGL(pack_csr_sorted_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
+                               h->W, h->d_x, d_bad);
+            if (hipMemcpy(&redo, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+        }
+        if (!rc && redo) {
+            hipMemset(d_bad, 0, 4);
+            hipMemset(h->d_x, 0, xbytes);
+            hipLaunchKernelGGL(pack_csr_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
+                               h->W, h->d_x, d_bad);
+            if (hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            else if (bad) rc = SS_EINVAL;
+        }
     }
     hipFree(d_ptr); hipFree(d_idx); hipFree(d_bad);
     if (rc) { hipFree(h->d_x); delete h; return rc; }
@@ -389,9 +436,16 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
         hipMemset(d_st, 0, ncols * sizeof(SelState));
         hipMemset(d_out, 0, (uint64_t)ncols * 16);
         const dim3 grid(grid_for(h->W, ncols), ncols);
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            hipLaunchKernelGGL(sel_hist_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, shift, d_st, d_hist);
-            hipLaunchKernelGGL(sel_pick_kernel, dim3((ncols + 63) / 64), dim3(64), 0, 0, shift, q_lo, q_hi, d_st, d_hist, ncols);
+        // the radix passes start at the highest byte that is non-zero in any value (k-mer counts are small numbers:
+        // usually ONE pass instead of four, each of which reads the bit planes and gathers y for every set bit)
+        uint32_t *d_max = reinterpret_cast<uint32_t *>(d_out), ymax = 0;       // d_out is zero and unused until sel_sum_kernel
+        hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)std::min<uint64_t>((h->K + 1023) / 1024, 4096)), dim3(256), 0, 0, y_dev, h->K, d_max);
+        hipMemcpy(&ymax, d_max, 4, hipMemcpyDeviceToHost);
+        hipMemset(d_max, 0, 4);
+        const int top = ymax >> 24 ? 24 : ymax >> 16 ? 16 : ymax >> 8 ? 8 : 0;
+        for (int shift = top; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(sel_hist_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, shift, (int)(shift == top), d_st, d_hist);
+            hipLaunchKernelGGL(sel_pick_kernel, dim3((ncols + 63) / 64), dim3(64), 0, 0, (int)(shift == top), q_lo, q_hi, d_st, d_hist, ncols);
         }
         hipLaunchKernelGGL(sel_sum_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, d_st, d_out);
         std::vector<SelState> st(ncols);

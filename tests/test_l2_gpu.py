@@ -322,3 +322,54 @@ def test_detect_core_at_config3_size(case):
             assert abs(float(res.get(n_, 0.0)) - r_) <= ABUND_TOL, (case, n_, res.get(n_), r_)
     if case == "near_duplicates":
         assert "S003" in res and "S057" in res          # both near-duplicates are reported
+
+
+def test_csr_pack_and_quantiles_edge_inputs():
+    """ss_l2_create: canonical CSR takes the atomic-free pack kernel, rows with unsorted or repeated column indices fall
+    back to the atomicOr kernel -- same bit planes; out-of-range indices are refused.  ss_l2_quantile_sums starts its
+    radix passes at the highest non-zero byte of y: counts below 256, below 65536 and up to 2^31 against
+    numpy.percentile(..., 'nearest') semantics (oracle.percentile_nearest)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from oracle import oracle as orc
+    from strainscan_amd import _lib, l2
+    rs = np.random.RandomState(12)
+    K, S = 70_001, 7
+    X = sp.csr_matrix((rs.random_sample((K, S)) < 0.4).astype(np.int8))
+    img = l2.ClusterImage(X)
+    want = img.planes()
+    # the same matrix with every row's indices reversed and some entries repeated
+    indptr, indices = [0], []
+    for k in range(K):
+        r = X.indices[X.indptr[k]:X.indptr[k + 1]][::-1].tolist()
+        if r and k % 5 == 0:
+            r.append(r[0])
+        indices.extend(r)
+        indptr.append(len(indices))
+    ip, ix = np.array(indptr, np.int64), np.array(indices, np.int32)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().ss_l2_create(_lib.ptr(ip), _lib.ptr(ix), K, S, C.byref(h)), "ss_l2_create")
+    got = np.zeros_like(want)
+    _lib.check(_lib.lib().ss_l2_export_planes(h, _lib.ptr(got)), "export")
+    _lib.lib().ss_l2_destroy(h)
+    assert np.array_equal(got, want)
+    ix_bad = ix.copy()
+    ix_bad[3] = S
+    assert _lib.lib().ss_l2_create(_lib.ptr(ip), _lib.ptr(ix_bad), K, S, C.byref(h)) == _lib.SS_EINVAL
+    Xd = X.toarray().astype(bool)
+    for top in (200, 60_000, 2**31 - 1, 1):
+        y = rs.randint(0, top + 1, size=K).astype(np.int64)
+        y[rs.random_sample(K) < 0.3] = 0
+        if top == 1:
+            y[:] = 0                                               # nothing non-zero at all
+        yd = img.u32(y)
+        q = img.quantile_sums(yd, np.arange(S), 5, 95)
+        for s_ in range(S):
+            nz = y[Xd[:, s_] & (y != 0)]
+            assert int(q["n_nz"][s_]) == nz.size
+            if nz.size:
+                lo, hi = orc.percentile_nearest(nz, 5), orc.percentile_nearest(nz, 95)
+                assert (int(q["v_lo"][s_]), int(q["v_hi"][s_])) == (int(lo), int(hi)), (top, s_)
+                inside = nz[(nz >= lo) & (nz <= hi)]
+                assert int(q["cnt_in"][s_]) == inside.size and int(q["sum_in"][s_]) == int(inside.sum())
+    img.close()
