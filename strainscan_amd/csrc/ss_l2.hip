@@ -439,7 +439,7 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
         // the radix passes start at the highest byte that is non-zero in any value (k-mer counts are small numbers:
         // usually ONE pass instead of four, each of which reads the bit planes and gathers y for every set bit)
         uint32_t *d_max = reinterpret_cast<uint32_t *>(d_out), ymax = 0;       // d_out is zero and unused until sel_sum_kernel
-        hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)std::min<uint64_t>((h->K + 1023) / 1024, 4096)), dim3(256), 0, 0, y_dev, h->K, d_max);
+        hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)std::min<uint64_t>((h->K + 1023) / 1024, 512)), dim3(256), 0, 0, y_dev, h->K, d_max);
         hipMemcpy(&ymax, d_max, 4, hipMemcpyDeviceToHost);
         hipMemset(d_max, 0, 4);
         const int top = ymax >> 24 ? 24 : ymax >> 16 ? 16 : ymax >> 8 ? 8 : 0;
