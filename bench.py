@@ -363,6 +363,11 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to time")
+    # SS_BENCH_SHARE_GPU=1 (tests on a one-GPU box): every rank uses device 0 and the group runs over gloo, which stages
+    # GPU tensors itself (RCCL refuses two ranks on one device)
+    share_gpu = bool(os.environ.get("SS_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.check(_lib.lib().ss_set_device(local), "ss_set_device")
@@ -372,7 +377,10 @@ def main(argv=None):
     if world > 1 or self_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
         world = dist.get_world_size()

@@ -786,3 +786,14 @@ def test_bench_line_contract_and_exchange_path():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][-1])
     assert d["check"]["harvest_equals_gather"] is True and d["check"]["exchanged_counts"] > 0 and d["n_gpus"] == 1
+    # `--gpus 2` without a launcher: the parent spawns two rank processes and relays rank 0's line.  On this one-GPU box
+    # both ranks share the device and the group runs over gloo (SS_BENCH_SHARE_GPU); everything else is the N > 1 path:
+    # per-rank reads, barrier + max-over-ranks timing, exchange of the touched nodes, whole-job reads/s.
+    r = subprocess.run(base + ["--gpus", "2"], env=dict(env, SS_BENCH_SHARE_GPU="1"), capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["check"]["harvest_equals_gather"] is True
+    assert d["check"]["exchanged_counts"] > 0 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 300000 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
