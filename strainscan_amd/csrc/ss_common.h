@@ -77,7 +77,8 @@ struct ss_db {
     uint64_t *d_mkeys = nullptr;       // pages: [n_mslots] buckets of the minimizers with many k-mers (ss_mini.hip)
     uint64_t *d_dir = nullptr;         // pages: [n_dir][8] 64-byte pages of slots (inline k-mers, bucket references)
     uint32_t dirbits = 0;
-    uint32_t n_dir = 0;                // pages: number of 64-byte pages
+    uint32_t n_dir = 0;                // pages: number of home pages (range of page_of)
+    uint32_t n_dir_alloc = 0;          // pages: home pages + spare pages behind them (overflow never wraps)
     uint32_t *d_bloom = nullptr;       // buckets: one-probe Bloom filter over the minimizers (L2 resident), or null
     uint32_t bloom_bits = 0;           // log2 of its size in bits
     uint64_t n_buckets = 0;

@@ -18,20 +18,24 @@
 //                         lives in page floor(h * n_pages / 2^30), h = mix30(x) a BIJECTION of the 30 bits, or,
 //                         when that page was full at build time, in the next one(s): a lookup goes on to
 //                         the next page only if the page it read is full (slot 7 occupied), which at the
-//                         build's load (two items per page on average) is one lookup in a thousand.
-//                         slot, inline k-mer:  0 | tag20 | e5 | 6 spare || flank32
+//                         build's load (two items per page on average) is one lookup in a thousand.  No
+//                         wrap-around (spare pages follow the last home page), and the build grows the table
+//                         until every run of full pages is shorter than n_pages / 1024 -- the distance between
+//                         the home pages of two minimizers that share their tag bits -- so a lookup can never
+//                         reach another minimizer's slots with the same tag.
+//                         A slot is 8 bytes spread over four arrays of the page (byte layout: PG_SLOTS below).
+//                         inline k-mer:  tag20 | e5 | flank32
 //                              the database k-mer itself: tag20 = low 20 bits of h (with the page number they
 //                              determine h, hence x, exactly: two minimizers that agree in the low 20 bits of h
-//                              lie >= 2^20 apart, i.e. in different pages, for n_pages >= 2^11); e = 16 - o, o =
+//                              lie >= 2^20 apart, i.e. >= n_pages / 1024 pages apart); e = 16 - o, o =
 //                              offset of the minimizer inside the k-mer; flank32 = the other 16 bases (those
 //                              behind the minimizer in the low bits, then those in front of it).  A read k-mer
 //                              equals it iff tag, offset and flank agree: no second load, no key array.  Its
 //                              counter is d_counts[n_mslots + 8 * page + slot].
-//                         slot, bucket reference:  1 | tag14 | mask17 || multi | spare | start30
+//                         bucket reference:  tag14 | mask17 | multi | start30
 //                              minimizers with more than SS_INLINE_MAX database k-mers keep them in a bucket of
 //                              d_mkeys (below); the bucket's header travels in the slot.  tag14 is only a
 //                              filter: candidates are compared in full.
-//                         empty slot = 0x7FFFFFFF'FFFFFFFF (an inline slot with the impossible e = 31)
 //   d_mkeys[n_mslots] u64 buckets back to back.  A bucket = 1 header word + its k-mers sorted by
 //                         (offset of the minimizer inside the k-mer, rest):
 //                           header: bits 0..16 = which offsets occur, bit 17 = some offset occurs more
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         auto scan_more = [&](uint32_t page, uint32_t meta, uint32_t h, uint32_t ridx, bool queued) {
             uint4 tg;
             do {
-                page = page + 1u == n_pages ? 0u : page + 1u;
+                page++;                                   // the build guarantees a non-full page before the array ends
                 tg = pages[(uint64_t)page * 4u];
             } while (scan_page(tg, page, meta, h, ridx, queued));
         };
@@ -692,6 +696,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     };
     constexpr int PB = 8, NP = 1 << PB;
     unsigned nthreads = std::min<unsigned>(ss::host_cpus(), 32u);
+    if (const char *e = getenv("SS_BUILD_THREADS")) nthreads = (unsigned)std::max(1, std::min(64, atoi(e)));   // tests: the image must not depend on it
     uint32_t inline_max = 2;                        // minimizers with at most this many database k-mers keep them in page slots
     if (const char *e = getenv("SS_INLINE_MAX")) inline_max = (uint32_t)std::max(0, std::min(8, atoi(e)));
     double lambda = 2.0;                            // page items per page on average (eight slots: one page in a thousand full)
@@ -768,7 +773,6 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     const uint64_t n_mslots = std::max<uint64_t>(1, p_slots[NP]), n_items = p_items[NP], n_minis = p_minis[NP];
     if (n_mslots >= (uint64_t)START_MASK) return SS_ERANGE;
     uint64_t n_pages = std::max<uint64_t>(PG_MIN_PAGES, (uint64_t)((double)n_items / lambda) + 1);
-    if (n_mslots + n_pages * PG_SLOTS >= 0xFFFFFFF0ull) return SS_ERANGE;     // counter indices are 32 bits
     std::vector<uint64_t> mkeys(n_mslots, 0);
     std::vector<Item> items(n_items);
     std::vector<uint32_t> slot_of_row(std::max<uint64_t>(1, n_rows), SS_NO_SLOT);
@@ -820,18 +824,32 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     db->n_distinct = n_distinct_a.load();
     lap("3 buckets + items");
     // 4. place the items: home page = page_of(h), or the first page behind it that is not full (a lookup reads on while
-    //    the page it sees is full).  Serial in h order: ~20 ns per item.
-    std::vector<uint8_t> pages(n_pages * 64, 0);
-    {
-        std::vector<uint8_t> fill(n_pages, 0);
-        for (uint64_t pg = 0; pg < n_pages; pg++) {
-            memset(&pages[pg * 64], PG_EMPTY_TAG, 8);
-            memset(&pages[pg * 64 + 8], PG_EMPTY_HI, 8);
-        }
-        for (uint64_t i = 0; i < n_items; i++) {
-            const Item &it = items[i];
-            uint64_t pg = page_of(it.h, (uint32_t)n_pages);
-            while (fill[pg] == PG_SLOTS) pg = pg + 1 == n_pages ? 0 : pg + 1;
+    //    the page it sees is full; no wrap-around: a few spare pages follow the last home page).  Serial in h order:
+    //    ~20 ns per item.  Exactness of the inline slots: two minimizers whose h agree in the 20 tag bits have home pages
+    //    >= D = n_pages / 1024 apart, so neither's lookup can reach the other's slots as long as every run of
+    //    consecutive full pages is shorter than D -- checked here; the table grows until it holds (at two items per
+    //    page a run of four full pages has probability 1e-12).
+    std::vector<uint8_t> pages;
+    uint64_t n_alloc = 0;
+    for (;; n_pages += n_pages / 4) {
+        if (n_mslots + (n_pages + n_pages / 1024) * PG_SLOTS >= 0xFFFFFFF0ull) return SS_ERANGE;
+        const uint64_t D = n_pages / 1024;
+        n_alloc = n_pages + D;
+        pages.resize(n_alloc * 64);
+        std::vector<uint8_t> fill(n_alloc, 0);
+        parallel_for(nthreads, n_alloc, [&](uint64_t lo, uint64_t hi, unsigned) {
+            for (uint64_t pg = lo; pg < hi; pg++) {
+                memset(&pages[pg * 64], PG_EMPTY_TAG, 8);
+                memset(&pages[pg * 64 + 8], PG_EMPTY_HI, 8);
+                memset(&pages[pg * 64 + 16], 0, 48);
+            }
+        });
+        // partition p (the items whose h has top byte p) owns the pages [lo(p), lo(p + 1)); its thread places its items
+        // there; items that run past the end of the range (or whose home page straddles into the next range) are
+        // placed afterwards, serially, in h order -- the same image for any thread count
+        auto place = [&](const Item &it, uint64_t pg, uint64_t end) -> bool {
+            while (pg < end && fill[pg] == PG_SLOTS) pg++;
+            if (pg >= end) return false;
             const uint32_t sl = fill[pg]++;
             uint8_t *pp = &pages[pg * 64];
             pp[sl] = (uint8_t)(it.h & 0xFFu);
@@ -839,14 +857,33 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
             memcpy(pp + 16 + 4 * sl, &it.lo, 4);
             memcpy(pp + 48 + 2 * sl, &it.mid, 2);
             for (uint64_t q = it.e0; q < it.e1; q++) slot_of_row[sorted[q].row] = (uint32_t)(n_mslots + pg * PG_SLOTS + sl);
+            return true;
+        };
+        auto lo_of = [&](int pt) -> uint64_t { return pt >= NP ? n_pages : page_of((uint32_t)pt << (30 - PB), (uint32_t)n_pages); };
+        std::vector<std::vector<uint64_t>> spill(NP);
+        for_partitions([&](int pt) {
+            const uint64_t end = lo_of(pt + 1);
+            for (uint64_t i = p_items[pt]; i < p_items[pt + 1]; i++)
+                if (!place(items[i], page_of(items[i].h, (uint32_t)n_pages), end)) spill[pt].push_back(i);
+        });
+        bool ok = true;
+        for (int pt = 0; pt < NP && ok; pt++)
+            for (uint64_t i : spill[pt])
+                if (!place(items[i], std::max<uint64_t>(page_of(items[i].h, (uint32_t)n_pages), lo_of(pt + 1)), n_alloc)) { ok = false; break; }
+        uint64_t run = 0, longest = 0;
+        for (uint64_t pg = 0; pg < n_alloc && ok; pg++) {
+            run = fill[pg] == PG_SLOTS ? run + 1 : 0;
+            longest = std::max(longest, run);
         }
+        if (ok && longest < D && fill[n_alloc - 1] < PG_SLOTS) break;
     }
     sorted.clear();
     sorted.shrink_to_fit();
     db->n_mslots = n_mslots;
     db->n_inline = (db->n_distinct + n_items - p_slots[NP]) / 2;   // items = inline k-mers + references; bucket slots = references + their k-mers
-    db->n_slots = n_mslots + n_pages * PG_SLOTS;
+    db->n_slots = n_mslots + n_alloc * PG_SLOTS;
     db->n_dir = (uint32_t)n_pages;
+    db->n_dir_alloc = (uint32_t)n_alloc;
     db->dirbits = 0;
     db->n_buckets = n_minis;
     db->capacity = db->n_slots;
@@ -980,10 +1017,10 @@ __global__ void validate_image_kernel(const uint32_t *__restrict__ slot_of_row, 
 }
 
 struct ImageHeader {
-    char magic[8];          // "SSIDX08\0"
+    char magic[8];          // "SSIDX09\0"
     int32_t k, layout;
     uint64_t n_rows, n_distinct, n_slots, n_buckets, n_mslots, n_inline;
-    uint32_t n_dir, bloom_bits;
+    uint32_t n_dir, bloom_bits, n_dir_alloc, reserved;
 };
 
 bool write_dev(FILE *f, const void *d, uint64_t bytes)
@@ -1055,15 +1092,15 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX08", 8);
+    memcpy(h.magic, "SSIDX09", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
     h.n_mslots = db->n_mslots; h.n_inline = db->n_inline;
-    h.n_dir = db->n_dir;
+    h.n_dir = db->n_dir; h.n_dir_alloc = db->n_dir_alloc;
     h.bloom_bits = db->d_bloom ? db->bloom_bits : 0;
     const uint64_t nr = std::max<uint64_t>(1, db->n_rows);
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && write_dev(f, db->d_mkeys, db->n_mslots * 8) &&
-              write_dev(f, db->d_dir, (uint64_t)db->n_dir * 64) && write_dev(f, db->d_slot_of_row, nr * 4) &&
+              write_dev(f, db->d_dir, (uint64_t)db->n_dir_alloc * 64) && write_dev(f, db->d_slot_of_row, nr * 4) &&
               write_dev(f, db->d_row_valid, nr) &&
               (!h.bloom_bits || write_dev(f, db->d_bloom, (1ull << h.bloom_bits) / 8));
     ok = (fclose(f) == 0) && ok;
@@ -1078,14 +1115,14 @@ int ss_db_import(const char *path, ss_db **out)
     if (fd < 0) return SS_EIO;
     ImageHeader h;
     struct stat st;
-    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX08", 8) != 0 ||
-        h.layout != 1 || h.k != 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_slots != h.n_mslots + (uint64_t)h.n_dir * 8 ||
+    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX09", 8) != 0 ||
+        h.layout != 1 || h.k != 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_dir_alloc != h.n_dir + h.n_dir / 1024 || h.n_slots != h.n_mslots + (uint64_t)h.n_dir_alloc * 8 ||
         h.n_slots >= 0xFFFFFFF0ull || h.n_mslots >= (uint64_t)ss::START_MASK || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         close(fd);
         return SS_EINVAL;
     }
     const uint64_t nr = std::max<uint64_t>(1, h.n_rows);
-    const uint64_t sizes[5] = {h.n_mslots * 8, (uint64_t)h.n_dir * 64, nr * 4, nr, h.bloom_bits ? (1ull << h.bloom_bits) / 8 : 0};
+    const uint64_t sizes[5] = {h.n_mslots * 8, (uint64_t)h.n_dir_alloc * 64, nr * 4, nr, h.bloom_bits ? (1ull << h.bloom_bits) / 8 : 0};
     uint64_t offs[6] = {sizeof(h), 0, 0, 0, 0, 0};
     for (int i = 0; i < 5; i++) offs[i + 1] = offs[i] + sizes[i];
     if ((uint64_t)st.st_size != offs[5]) { close(fd); return SS_EIO; }     // the file must be exactly the image
@@ -1094,7 +1131,7 @@ int ss_db_import(const char *path, ss_db **out)
     db->k = h.k; db->layout = 1;
     db->n_rows = h.n_rows; db->n_distinct = h.n_distinct; db->n_slots = h.n_slots; db->capacity = h.n_slots;
     db->n_mslots = h.n_mslots; db->n_inline = h.n_inline;
-    db->n_buckets = h.n_buckets; db->n_dir = h.n_dir;
+    db->n_buckets = h.n_buckets; db->n_dir = h.n_dir; db->n_dir_alloc = h.n_dir_alloc;
     hipGetDevice(&db->device);
     bool ok = hipMalloc((void **)&db->d_mkeys, sizes[0]) == hipSuccess && hipMalloc((void **)&db->d_dir, sizes[1]) == hipSuccess &&
               hipMalloc((void **)&db->d_counts, db->n_slots * 4) == hipSuccess &&
@@ -1110,18 +1147,18 @@ int ss_db_import(const char *path, ss_db **out)
     close(fd);
     if (ok) {
         uint32_t *d_bad = nullptr, bad = 1;
-        const uint64_t nchk = std::max<uint64_t>(h.n_rows, (uint64_t)h.n_dir * 8);
+        const uint64_t nchk = std::max<uint64_t>(h.n_rows, (uint64_t)h.n_dir_alloc * 8);
         ok = hipMalloc((void **)&d_bad, 4) == hipSuccess && hipMemset(d_bad, 0, 4) == hipSuccess;
         if (ok) {
             hipLaunchKernelGGL(validate_image_kernel, dim3((unsigned)((nchk + 255) / 256)), dim3(256), 0, 0, db->d_slot_of_row, h.n_rows,
-                               h.n_slots, (const uint8_t *)db->d_dir, (uint64_t)h.n_dir, db->d_mkeys, h.n_mslots, d_bad);
+                               h.n_slots, (const uint8_t *)db->d_dir, (uint64_t)h.n_dir_alloc, db->d_mkeys, h.n_mslots, d_bad);
             ok = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
         }
         hipFree(d_bad);
     }
     if (ok && h.bloom_bits) db->bloom_bits = h.bloom_bits;
     if (!ok) { ss_db_destroy(db); return SS_EIO; }
-    db->device_bytes = db->n_mslots * 8 + db->n_slots * 4 + (uint64_t)db->n_dir * 64 + nr * 5 + sizes[4];
+    db->device_bytes = db->n_mslots * 8 + db->n_slots * 4 + (uint64_t)db->n_dir_alloc * 64 + nr * 5 + sizes[4];
     *out = db;
     return SS_OK;
 }
