@@ -6,7 +6,7 @@ kmer.fa, kmers/<id>, tree_structure.txt, node_length.txt, hclsMap_95_recls.txt .
 clusters = 1645 nodes, ~25 M rows) and a paired FASTQ sample (three-strain mix 70/20/10), then times
 library/identify.identify_cluster's mirror on it: first call (kmer.fa text parse, index build,
 image cache written), a second process-cold call (image cache read) and the phases of each
-(database image, FASTQ ingest + scan, tree walk).  Usage: bench_cli.py [n_reads] [n_leaves]"""
+(database image, FASTQ ingest + scan, tree walk).  Usage: bench_cli.py [n_reads] [n_leaves] [sampled|contiguous]"""
 import json
 import os
 import shutil
@@ -57,16 +57,17 @@ def main():
     import torch
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
     C = int(sys.argv[2]) if len(sys.argv) > 2 else 823
+    shape = sys.argv[3] if len(sys.argv) > 3 else "sampled"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "ss_cli_%d" % os.getpid())
     os.makedirs(base)
     os.environ["SS_IMAGE_CACHE"] = os.path.join(base, "cache")
     os.environ["STRAINSCAN_QUIET"] = "1"
-    out = dict(n_reads=n_reads, leaves=C, host_threads=os.cpu_count())
+    out = dict(n_reads=n_reads, leaves=C, db_shape=shape, host_threads=os.cpu_count())
     try:
         t0 = time.perf_counter()
-        spec = bench.make_db(torch, dev, C, seed=20231013)
+        spec = bench.make_db(torch, dev, C, seed=20231013, shape=shape)
         tdir = write_db(torch, dev, spec, C, base)
         out["db_rows"] = int(spec["keys"].size)
         out["db_text_bytes"] = os.path.getsize(os.path.join(tdir, "kmer.fa"))
