@@ -314,6 +314,24 @@ def test_low_complexity_and_repeats(L):
     assert np.array_equal(db.row_valid, want_valid)
     assert np.array_equal(db.counts_rows(), want)
     assert want.max() > 50          # the repeats really pile up on few k-mers
+    db.close()
+    # the same with up to eight k-mers of a minimizer inline in the pages (several slots with one tag, also with one
+    # tag AND offset), no Bloom filter, pages packed: the page-side paths on the worst input
+    for env in ({"SS_INLINE_MAX": "8", "SS_BLOOM_BITS": "0"}, {"SS_INLINE_MAX": "8", "SS_BLOOM_BITS": "0", "SS_PAGE_LAMBDA": "7.5"},
+                {"SS_INLINE_MAX": "0"}):
+        old = {k_: os.environ.get(k_) for k_ in env}
+        os.environ.update(env)
+        try:
+            db = L.KmerDB.from_text(kfa, 31, True)
+        finally:
+            for k_, v in old.items():
+                if v is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v
+        db.scan_flat(flat)
+        assert np.array_equal(db.counts_rows(), want), env
+        db.close()
 
 
 def test_queue_overflow_paths(tmp_path):
