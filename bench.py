@@ -307,6 +307,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the untimed phase breakdown (text -> HBM, walk)")
+    ap.add_argument("--no-readset", action="store_true", help="skip the extra measurement over the product's resident read set")
     ap.add_argument("--phase-reads", type=int, default=4_000_000, help="reads of the FASTQ sample written for the phase breakdown")
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
@@ -471,6 +472,57 @@ def main(argv=None):
     torch.cuda.synchronize()
     harvest_equals_gather = bool(torch.equal(stats, stats2))
 
+    # The same steps over the sample as the PRODUCT keeps it resident (ss_reads: records in locality order, ss_reorder.hip),
+    # reported beside `value`, which stays the scan of the block in file order.  Preparing the set (device copy + order) is
+    # paid once per sample at load time; it is timed here and listed under phases.
+    readset = None
+    if not args.no_readset and not args.calib_stream:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rs_loc = _lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
+        torch.cuda.synchronize()
+        prep_ms = (time.perf_counter() - t1) * 1e3
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+        def step_rs(i=None):
+            db.reset(stream)
+            if i is not None:
+                ev2[i][0].record()
+            rs_loc.scan_into(db, stream)
+            if i is not None:
+                ev2[i][1].record()
+            nodes.harvest_dev(db, stream)
+            if exchange:
+                ssdist.exchange_touched(nodes, stream=stream)
+            nodes.reduce_touched_dev(stats2.data_ptr(), stream)
+
+        for _ in range(args.warmup):
+            step_rs()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step_rs(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+        k2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
+        readset = dict(order="locality (records sorted by the minimizer of their first k-mer: ss_reorder.hip)",
+                       prepare_ms=round(prep_ms, 2), ms_per_step=round(dt2 / args.steps * 1e3, 3),
+                       value=round(args.reads * world * args.steps / dt2 / 1e6, 3), unit="M reads/s", kernel_ms=round(k2, 3),
+                       frac_algorithmic=round(args.reads * BYTES_PER_READ / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                       node_stats_equal=bool(torch.equal(stats, stats2)),
+                       note="what the CLI scans: a sample is parsed and shipped once, ordered once, scanned several times; the gain "
+                            "grows with the coverage of the sample (these 20 M reads cover a 70/20/10 three-strain mix ~400/115/60 fold)")
+        rs_loc.close()
+
     achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
     # Counter-derived figures come from separate rocprofv3 --pmc passes of THIS command (scripts/gpu_round.sh writes
     # profiles/pmc_traffic.json, one entry per database shape and hit fraction, with the commit they were taken at):
@@ -558,7 +610,7 @@ def main(argv=None):
                                           filter_bits=info.get("filter_bits"), device_gb=round(info["device_bytes"] / 1e9, 3)),
                                table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
-                   roofline=roofline, cpu_baseline=cpu, phases=phases,
+                   roofline=roofline, cpu_baseline=cpu, phases=phases, resident_read_set=readset,
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
                               harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"]),

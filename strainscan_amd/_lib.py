@@ -83,6 +83,8 @@ SIGNATURES = {
     "ss_counts_load_rows_dev": (i32, [vp, vp, vp]),
     "ss_scan_kernel_launches": (u64, [vp]),
     "ss_reads_load": (i32, [P(cp), i32, i32, i32, P(vp)]),
+    "ss_reads_from_flat_dev": (i32, [vp, u64, i32, P(vp)]),
+    "ss_reads_read_back": (i32, [vp, vp, u64, P(u64)]),
     "ss_reads_destroy": (i32, [vp]),
     "ss_reads_info": (i32, [vp, P(u64), P(u64), P(u64), P(u64)]),
     "ss_scan_reads": (i32, [vp, vp, vp]),
@@ -308,6 +310,16 @@ class ReadSet:
         check(lib().ss_reads_load(arr, len(ps), int(shard_rank), int(shard_world), C.byref(h)), "ss_reads_load")
         self._h = h
 
+    @classmethod
+    def from_flat_dev(cls, dptr, n, order=True):
+        """A resident read set from a flat base block already on the device (copied; `order`: locality order)."""
+        require_gpu()
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        check(lib().ss_reads_from_flat_dev(dptr, int(n), int(bool(order)), C.byref(h)), "ss_reads_from_flat_dev")
+        self._h = h
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             lib().ss_reads_destroy(self._h)
@@ -318,6 +330,14 @@ class ReadSet:
             self.close()
         except Exception:
             pass
+
+    def read_back(self):
+        """The resident flat blocks as bytes (tests)."""
+        n = C.c_uint64()
+        check(lib().ss_reads_read_back(self._h, None, 0, C.byref(n)), "ss_reads_read_back")
+        buf = np.zeros(max(1, n.value), np.uint8)
+        check(lib().ss_reads_read_back(self._h, ptr(buf), buf.size, C.byref(n)), "ss_reads_read_back")
+        return buf[:n.value].tobytes()
 
     def info(self):
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

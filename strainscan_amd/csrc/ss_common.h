@@ -102,7 +102,51 @@ struct ss_db {
     uint64_t device_bytes = 0;
 };
 
+#include <chrono>
+#include <mutex>
+
+// A sample's reads resident in HBM (ss_ingest.hip loads them, ss_reorder.hip orders them for locality).
+struct ss_reads {
+    // Blocks live back to back in a few large device slabs; every block is followed by at least one '\n'
+    // and padded with '\n' to a multiple of 16 bytes, so a slab is itself one flat base block: one scan
+    // launch per slab (one in all for a typical sample) instead of one per 12 MB block, and no device
+    // allocation per block while loading.
+    struct Slab { char *d = nullptr; uint64_t cap = 0, used = 0; };
+    std::vector<Slab> slabs;
+    std::mutex mu;
+    uint64_t n_records = 0, n_bases = 0, device_bytes = 0, n_blocks = 0;
+    bool has_cut_record = false;      // a record longer than a block was cut with a 30-base overlap (k = 31 only)
+    uint64_t first_slab = 0;          // size of the first slab (estimate from the file sizes)
+
+    static uint64_t padded(uint64_t len) { return (len + 1 + 15) & ~15ull; }
+    // room for a block of `len` bytes (+ padding); nullptr when the device is out of memory
+    char *reserve(uint64_t len)
+    {
+        const uint64_t need = padded(len);
+        std::lock_guard<std::mutex> g(mu);
+        if (slabs.empty() || slabs.back().used + need > slabs.back().cap) {
+            Slab sl;
+            sl.cap = std::max<uint64_t>(need, slabs.empty() ? std::max<uint64_t>(first_slab, 64ull << 20) : 512ull << 20);
+            const auto t0 = std::chrono::steady_clock::now();
+            if (hipMalloc((void **)&sl.d, sl.cap) != hipSuccess) return nullptr;
+            if (getenv("SS_INGEST_TRACE"))
+                fprintf(stderr, "[ingest] slab of %.0f MB: %.4f s\n", sl.cap / 1e6,
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            slabs.push_back(sl);
+        }
+        Slab &sl = slabs.back();
+        char *p = sl.d + sl.used;
+        sl.used += need;
+        device_bytes += need;
+        n_blocks++;
+        return p;
+    }
+};
+
+
 namespace ss {
+// Records of every slab re-ordered by the minimizer of their first k-mer (ss_reorder.hip); `force`: ignore SS_READS_ORDER
+int reads_order_for_locality(ss_reads *R, bool force = false);
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
 using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,

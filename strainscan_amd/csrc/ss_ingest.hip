@@ -538,43 +538,6 @@ void ss_db::free_workers(Worker *w, int n)
 // identify_low_depth.py:119,124).  With 288 GB of HBM the 2-byte-per-base text is parsed and
 // shipped over PCIe once; every later scan is a 10 ms kernel over resident blocks.
 // ---------------------------------------------------------------------------------------------
-struct ss_reads {
-    // Blocks live back to back in a few large device slabs; every block is followed by at least one '\n'
-    // and padded with '\n' to a multiple of 16 bytes, so a slab is itself one flat base block: one scan
-    // launch per slab (one in all for a typical sample) instead of one per 12 MB block, and no device
-    // allocation per block while loading.
-    struct Slab { char *d = nullptr; uint64_t cap = 0, used = 0; };
-    std::vector<Slab> slabs;
-    std::mutex mu;
-    uint64_t n_records = 0, n_bases = 0, device_bytes = 0, n_blocks = 0;
-    bool has_cut_record = false;      // a record longer than a block was cut with a 30-base overlap (k = 31 only)
-    uint64_t first_slab = 0;          // size of the first slab (estimate from the file sizes)
-
-    static uint64_t padded(uint64_t len) { return (len + 1 + 15) & ~15ull; }
-    // room for a block of `len` bytes (+ padding); nullptr when the device is out of memory
-    char *reserve(uint64_t len)
-    {
-        const uint64_t need = padded(len);
-        std::lock_guard<std::mutex> g(mu);
-        if (slabs.empty() || slabs.back().used + need > slabs.back().cap) {
-            Slab sl;
-            sl.cap = std::max<uint64_t>(need, slabs.empty() ? std::max<uint64_t>(first_slab, 64ull << 20) : 512ull << 20);
-            const auto t0 = std::chrono::steady_clock::now();
-            if (hipMalloc((void **)&sl.d, sl.cap) != hipSuccess) return nullptr;
-            if (getenv("SS_INGEST_TRACE"))
-                fprintf(stderr, "[ingest] slab of %.0f MB: %.4f s\n", sl.cap / 1e6,
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-            slabs.push_back(sl);
-        }
-        Slab &sl = slabs.back();
-        char *p = sl.d + sl.used;
-        sl.used += need;
-        device_bytes += need;
-        n_blocks++;
-        return p;
-    }
-};
-
 namespace {
 // pinned buffers and streams of the parse threads, shared by every ss_reads_load of the process (pinning
 // 20 x 27 MB costs more than parsing a small sample); one load at a time
@@ -674,7 +637,46 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: files done %.4f s, device idle %.4f s\n", t_parsed, load_since());
     R->n_records = recs;
     R->n_bases = bases;
+    rc = ss::reads_order_for_locality(R);      // only with SS_READS_ORDER=locality (ss_reorder.hip)
+    if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
+    if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: ordered for locality at %.4f s\n", load_since());
     *out = R;
+    return SS_OK;
+}
+
+int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads **out)
+{
+    if (!out || (n && !flat_dev)) return SS_EINVAL;
+    ss_reads *R = new (std::nothrow) ss_reads();
+    if (!R) return SS_ENOMEM;
+    R->first_slab = n + 64;
+    if (n) {
+        char *dst = R->reserve(n);
+        if (!dst) { ss_reads_destroy(R); return SS_ENOMEM; }
+        const uint64_t plen = ss_reads::padded(n);
+        if (hipMemcpy(dst, flat_dev, n, hipMemcpyDeviceToDevice) != hipSuccess ||
+            hipMemset(dst + n, '\n', plen - n) != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
+    }
+    R->n_bases = n;
+    int rc = order ? ss::reads_order_for_locality(R, true) : SS_OK;
+    if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
+    *out = R;
+    return SS_OK;
+}
+
+int ss_reads_read_back(const ss_reads *R, char *host, uint64_t cap, uint64_t *len)
+{
+    if (!R || !len) return SS_EINVAL;
+    uint64_t total = 0;
+    for (const auto &sl : R->slabs) total += sl.used;
+    *len = total;
+    if (!host) return SS_OK;                       // size query
+    if (cap < total) return SS_ERANGE;
+    uint64_t o = 0;
+    for (const auto &sl : R->slabs) {
+        if (sl.used) SS_HIP(hipMemcpy(host + o, sl.d, sl.used, hipMemcpyDeviceToHost));
+        o += sl.used;
+    }
     return SS_OK;
 }
 

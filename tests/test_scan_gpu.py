@@ -844,3 +844,95 @@ def test_index_image_independent_of_thread_count(L, tmp_path):
             else:
                 os.environ["SS_BUILD_THREADS"] = old
     assert digests[0] == digests[1] == digests[2]
+
+
+def _first_minimizer_key(rec, k=31, m=15):
+    """Ordering key of ss_reorder.hip restated: the 30-bit minimizer (ordering key of the index: ((x & 0xFFFFFF) * C1 +
+    C0) with the low five bits cleared, leftmost on ties) of the record's first 31 bases; 2^30 when there is none."""
+    code = {65: 0, 67: 1, 84: 2, 71: 3}
+    if len(rec) < k:
+        return 1 << 30
+    cs = [code.get(c & 0xDF, -1) for c in rec[:k]]
+    if min(cs) < 0:
+        return 1 << 30
+    km = sum(c << (2 * j) for j, c in enumerate(cs))
+    best, bx = None, 0
+    for i in range(k - m + 1):
+        x = (km >> (2 * i)) & 0x3FFFFFFF
+        h = (((x & 0xFFFFFF) * (0x4F1BB << 5) + 0x7F4A7C00) & 0xFFFFFFFF) & ~31
+        if best is None or h < best:
+            best, bx = h, x
+    return bx
+
+
+def test_locality_ordered_read_set(L):
+    """ss_reorder.hip: a resident read set keeps its records sorted by the minimizer of their first k-mer.  Counting
+    must not notice: every record survives exactly once, whole, '\\n'-terminated -- ragged lengths, records shorter
+    than a k-mer, N inside the first 31 bases, lower case, runs of empty lines (the 16-byte padding of the blocks),
+    records straddling the 4096-byte units of the boundary passes, a block without a final newline."""
+    import ctypes as C
+    from oracle import oracle as orc
+    kfa, flat = _random_db_and_reads(321, 150000, 40000)
+    rs = np.random.RandomState(8)
+    recs = flat.split(b"\n")[:-1]
+    extra = [b"", b"", b"ACGT", b"N" * 40, recs[5][:10] + b"n" + recs[5][11:], recs[7].lower(), b"", recs[9] * 30, b"A" * 31, b""]
+    mixed = []
+    for i, r in enumerate(recs):
+        mixed.append(r)
+        if i % 997 == 0:
+            mixed.extend(extra)
+        if i % 13 == 0:
+            mixed.extend([b""] * int(rs.randint(1, 18)))          # padding-like runs of newlines
+    block = b"\n".join(mixed)                                      # no final newline
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in mixed if r)
+    want, want_valid = orc.jellyfish_count(kfa, [fq], k=31, upper=True)
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_flat(block)
+    assert np.array_equal(db.counts_rows(), want)
+    buf = np.frombuffer(block, np.uint8)
+    d = C.c_void_p()
+    L.check(L.lib().ss_dev_alloc(C.byref(d), buf.size), "alloc")
+    L.check(L.lib().ss_memcpy_h2d(d, L.ptr(buf), buf.size, None), "h2d")
+    L.check(L.lib().ss_device_sync(), "sync")
+    for order in (True, False):
+        rset = L.ReadSet.from_flat_dev(d, buf.size, order=order)
+        db.reset()
+        rset.scan_into(db)
+        L.check(L.lib().ss_device_sync(), "sync")
+        assert np.array_equal(db.counts_rows(), want), order
+        back = [r for r in rset.read_back().split(b"\n") if r]
+        assert sorted(back) == sorted(r for r in mixed if r)                 # every record once, whole
+        if order:
+            keys = [_first_minimizer_key(r) for r in back]
+            assert keys == sorted(keys) and len(set(keys)) > 1000            # ... and in key order
+        else:
+            assert back == [r for r in mixed if r]
+        rset.close()
+    L.lib().ss_dev_free(d)
+    # through files (the loader keeps the file order unless SS_READS_ORDER=locality): same counts
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "r.fq")
+        open(p, "wb").write(fq)
+        for env in (None, "locality"):
+            old = os.environ.get("SS_READS_ORDER")
+            if env:
+                os.environ["SS_READS_ORDER"] = env
+            try:
+                rset = L.ReadSet([p])
+            finally:
+                if env:
+                    if old is None:
+                        os.environ.pop("SS_READS_ORDER", None)
+                    else:
+                        os.environ["SS_READS_ORDER"] = old
+            assert rset.info()["n_records"] == sum(1 for r in mixed if r)
+            db.reset()
+            rset.scan_into(db)
+            L.check(L.lib().ss_device_sync(), "sync")
+            assert np.array_equal(db.counts_rows(), want), env
+            back = [r for r in rset.read_back().split(b"\n") if r]
+            keys = [_first_minimizer_key(r) for r in back]
+            assert (keys == sorted(keys)) == (env == "locality")
+            rset.close()
+    db.close()
