@@ -409,3 +409,37 @@ def test_bench_gpus_argument_handling():
     assert r.returncode != 0 and b"--gpus 4" in r.stderr
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env2, capture_output=True, timeout=120)
     assert r.returncode == 0 and json.loads(r.stdout.decode())["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("shape", ["sampled", "contiguous"])
+def test_bench_database_generator(shape):
+    """bench.make_db on the CPU at a small size: both key conventions name the same k-mers (device: A0 C1 T2 G3, first
+    base in the low bits; oracle: A0 C1 G2 T3, first base in the high bits), every row belongs to exactly one node list,
+    sampled node sets are a sparse subset of their stretch with rows scattered over the file, and reads cut from the
+    path of a leaf hit that path's rows (oracle counter)."""
+    import torch
+    import bench
+    from oracle import oracle as orc
+    dev = torch.device("cpu")
+    spec = bench.make_db(torch, dev, 9, seed=3, lo_sites=300, hi_sites=900, shape=shape, hit_frac=0.05)
+    keys, okeys = spec["keys"], spec["okeys"]
+    assert keys.size == okeys.size == int(spec["row_off"][-1]) and spec["n_nodes"] == 17
+    letters = "ACTG"
+    for i in np.random.RandomState(1).choice(keys.size, size=200, replace=False):
+        txt = "".join(letters[(int(keys[i]) >> (2 * j)) & 3] for j in range(31))
+        assert orc.encode_kmer(txt) == int(okeys[i])
+    assert sorted(spec["rows"].tolist()) == list(range(keys.size))
+    off = spec["row_off"].astype(np.int64)
+    per_node = np.diff(off)
+    if shape == "sampled":
+        stretch = np.diff(spec["seq_off"]) - 30
+        assert np.all(per_node < 0.45 * 2 * stretch) and np.all(per_node > 0)          # a sparse sample of (site, orientation)
+        assert not np.array_equal(spec["rows"], np.arange(keys.size))                # scattered over kmer.fa
+    else:
+        assert np.array_equal(per_node, 2 * spec["sites"])
+    reads = bench.make_reads(torch, dev, spec, 3000, seed=5, hit_frac=0.05)
+    counts = orc.count_flat(okeys, 31, reads.numpy(), 2)
+    hit_nodes = {j for j in range(17) if counts[spec["rows"][off[j]:off[j + 1]]].sum() > 0}
+    assert 0 in hit_nodes and 3 <= len(hit_nodes) <= 12                               # the root and the three leaves' paths
+    frac = counts.sum() / (3000 * 120)
+    assert 0.01 < frac < 0.08
