@@ -89,6 +89,8 @@ def make_db(torch, dev, n_leaves, seed, lo_sites=500, hi_sites=15000, shape="con
         stretch = sites
     else:
         dens = np.minimum(1.0, rs.uniform(0.3, 2.0, size=n_nodes) * max(hit_frac, 0.025))
+        if shape == "mixed":                       # half of the nodes below the builder's cap: all their k-mers
+            dens[rs.random_sample(n_nodes) < 0.5] = 1.0
         stretch = np.ceil(sites / dens).astype(np.int64)
     seq_len = stretch + K - 1
     seq_off = np.concatenate([[0], np.cumsum(seq_len)])
@@ -301,9 +303,10 @@ def parse_args(argv=None):
     ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU (10 M pairs)")
     ap.add_argument("--leaves", type=int, default=823)
     ap.add_argument("--hit-frac", type=float, default=0.05)
-    ap.add_argument("--db-shape", choices=("sampled", "contiguous"), default="sampled",
+    ap.add_argument("--db-shape", choices=("sampled", "contiguous", "mixed"), default="sampled",
                     help="node k-mer sets: a random 1-10 %% sample of a longer stretch, rows scattered over kmer.fa "
-                         "(what Build_tree.py:590-591 writes for a node above its cap) or every k-mer of a stretch")
+                         "(what Build_tree.py:590-591 writes for a node above its cap), every k-mer of a stretch, or half "
+                         "of the nodes each way (mixed)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the untimed phase breakdown (text -> HBM, walk)")
