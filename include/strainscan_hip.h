@@ -77,6 +77,13 @@ void ss_gz_free(char *text);
 /* The same text written to out_path (the threaded inflater writes through a shared mapping of the file): the ranks
  * of one node inflate a .gz sample ONCE into /dev/shm and each parses its share of the plain text. */
 int ss_gz_inflate_to_file(const char *path, const char *out_path, int threads, uint64_t *len);
+/* The same on the GPU (ss_ginflate.hip: the two-pass scheme with one wave per chunk of the deflate data, the
+ * text verified against CRC-32 and ISIZE of the trailer); *text is a host buffer released with ss_gz_free.  SS_ERANGE:
+ * not handled on the device (several members, a damaged file, ...): use ss_gz_inflate. */
+int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len);
+/* Members the device inflater has produced / has declined in this process (SS_GZ_GPU=1 routes the .gz inputs of
+ * ss_scan_files and ss_reads_load through it first; what it declines goes to the host inflaters as before). */
+int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,

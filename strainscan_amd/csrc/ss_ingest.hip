@@ -161,6 +161,7 @@ struct TextAlloc {                                                          // s
 };
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len,
                      const TextAlloc *ta);
+bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len);      // ss_ginflate.hip
 namespace {
 struct Deflate {
     void *(*alloc)() = nullptr;
@@ -209,6 +210,12 @@ uint64_t inflate_budget_bytes()
     return mem / 4;
 }
 
+static bool gz_on_gpu()
+{
+    const char *e = getenv("SS_GZ_GPU");
+    return e && *e && strcmp(e, "0") != 0;
+}
+
 // path -> malloc'ed text of all its gzip members, or false (not gzip, no libdeflate, damaged, over `budget`)
 // mode: 0 = parallel inflater when the file is large enough, else libdeflate; 1 = parallel only; 2 = libdeflate only
 bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len, int mode, unsigned threads)
@@ -224,6 +231,19 @@ bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len
     close(fd);
     if (in == MAP_FAILED) return false;
     bool ok = in[0] == 0x1f && in[1] == 0x8b;
+    if (ok && mode != 2 && gz_on_gpu()) {
+        // SS_GZ_GPU=1: the member is inflated on the device (ss_ginflate.hip; verified against the trailer's CRC-32
+        // and length there); anything it does not handle (several members, damage, no sync points) goes on below
+        char *d = nullptr;
+        uint64_t n = 0;
+        if (gpu_gunzip(in, in_n, &d, &n)) {
+            char *h = n <= budget ? (char *)malloc(std::max<uint64_t>(n, 1)) : nullptr;
+            const bool got = h && (n == 0 || hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess);
+            hipFree(d);
+            if (got) { munmap((void *)in, in_n); *text = h; *len = n; return true; }
+            free(h);
+        }
+    }
     if (ok && mode != 2 && !getenv("SS_NO_PGZ")) {
         // many threads on ONE member (ss_pgz.hip); verified against the trailer's CRC-32 and length
         if (!threads) threads = std::min<unsigned>(host_cpus(), 32u);
@@ -359,8 +379,13 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
     // the files inflate concurrently and share the CPUs the process may use (not the machine's hardware threads)
     const unsigned per_file = std::max(1u, std::min(32u, host_cpus() / (unsigned)gz.size()));
     std::vector<std::thread> pool;
+    int device = 0;
+    if (gz_on_gpu()) hipGetDevice(&device);
     for (int i : gz)
-        pool.emplace_back([&out, paths, i, budget, per_file] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, per_file)) out[i].p = nullptr; });
+        pool.emplace_back([&out, paths, i, budget, per_file, device] {
+            if (gz_on_gpu()) hipSetDevice(device);                // the device inflater runs on the caller's GPU
+            if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, per_file)) out[i].p = nullptr;
+        });
     for (auto &th : pool) th.join();
     return out;
 }

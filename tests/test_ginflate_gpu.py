@@ -1,0 +1,212 @@
+"""The device gzip inflater (strainscan_amd/csrc/ss_ginflate.hip) against Python's gzip module.
+
+The reference reads .gz samples through gzip.open (library/identify.py:100-108 via jellyfish's input pipe); here the
+member is inflated on the GPU when SS_GZ_GPU=1.  Contract under test: whatever ss_gz_inflate_gpu returns with SS_OK
+is byte-identical to gzip.decompress; anything it cannot do (several members, damage, too few sync points, data that
+expands beyond its symbol budget) is DECLINED with SS_ERANGE, never answered wrongly; and the scan of .gz inputs
+with SS_GZ_GPU=1 counts exactly like the plain text."""
+import ctypes as C
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SS_OK, SS_ERANGE = 0, -34
+
+
+@pytest.fixture(scope="module")
+def L():
+    from strainscan_amd import _lib
+    _lib.require_gpu()
+    return _lib
+
+
+def _fastq(n, seed, read_len=150):
+    rs = np.random.RandomState(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    q = np.frombuffer(b"FFFFFFFF:FFF,FF#", np.uint8)
+    bases = lut[rs.randint(0, 4, (n, read_len))]
+    quals = q[rs.randint(0, 16, (n, read_len))]
+    return b"".join(b"@SRR1234567.%d %d/1\n" % (i, i) + bases[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n" for i in range(n))
+
+
+def _gpu_inflate(L, path):
+    t, n = C.c_void_p(), C.c_uint64()
+    rc = L.lib().ss_gz_inflate_gpu(os.fsencode(str(path)), C.byref(t), C.byref(n))
+    if rc != SS_OK:
+        return rc, None
+    s = C.string_at(t, n.value)
+    L.lib().ss_gz_free(t)
+    return rc, s
+
+
+def _counters(L):
+    a, b = C.c_uint64(), C.c_uint64()
+    L.check(L.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b)), "ss_gz_gpu_counters")
+    return int(a.value), int(b.value)
+
+
+@pytest.fixture(scope="module")
+def fastq_text():
+    return _fastq(40000, 1)
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("chunk", [None, "16384", "65536"])
+def test_fastq_levels_and_chunk_sizes(L, tmp_path, monkeypatch, fastq_text, level, chunk):
+    """FASTQ text at gzip levels 1, 6, 9 (different block sizes and match statistics), at three chunk sizes (the
+    sync search lands on different blocks): handled, and equal to the text."""
+    if chunk:
+        monkeypatch.setenv("SS_GZ_CHUNK", chunk)
+    else:
+        monkeypatch.delenv("SS_GZ_CHUNK", raising=False)
+    p = tmp_path / "a.fq.gz"
+    p.write_bytes(gzip.compress(fastq_text, level))
+    h0, _ = _counters(L)
+    rc, got = _gpu_inflate(L, p)
+    assert rc == SS_OK
+    assert got == fastq_text
+    assert _counters(L)[0] == h0 + 1
+
+
+def test_stored_fixed_and_tiny(L, tmp_path):
+    """Random bytes (zlib emits stored blocks), a short text (one fixed-Huffman block, a single chunk), text written
+    with Z_FIXED (fixed codes throughout) and with Z_HUFFMAN_ONLY (no matches): equal when handled."""
+    rnd = np.random.RandomState(3).randint(0, 256, 3_000_000).astype(np.uint8).tobytes()
+    tiny = b"hello world\n" * 10
+    txt = _fastq(6000, 5)
+
+    def deflate(data, strategy):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
+        return c.compress(data) + c.flush()
+
+    cases = dict(random=(gzip.compress(rnd, 6), rnd), tiny=(gzip.compress(tiny, 6), tiny),
+                 fixed=(deflate(txt, zlib.Z_FIXED), txt), huffman_only=(deflate(txt, zlib.Z_HUFFMAN_ONLY), txt),
+                 rle=(deflate(txt, zlib.Z_RLE), txt), level0=(gzip.compress(txt, 0), txt))
+    handled = 0
+    for name, (gz, want) in cases.items():
+        assert gzip.decompress(gz) == want
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(gz)
+        rc, got = _gpu_inflate(L, p)
+        assert rc in (SS_OK, SS_ERANGE), name
+        if rc == SS_OK:
+            handled += 1
+            assert got == want, name
+    assert handled >= 4
+
+
+def test_header_fields(L, tmp_path, fastq_text):
+    """FNAME / FCOMMENT / FEXTRA / FHCRC in the member header are skipped (RFC 1952 2.3)."""
+    raw = gzip.compress(fastq_text[: 4 << 20], 6)
+    body = raw[10:]
+    name, comment, extra = b"reads_1.fq\0", b"made by a test\0", b"\x06\x00AB\x02\x00xy"
+    flg = 4 | 8 | 16
+    hdr = raw[:3] + bytes([flg]) + raw[4:10] + extra + name + comment
+    p = tmp_path / "h.gz"
+    p.write_bytes(hdr + body)
+    assert gzip.decompress(hdr + body) == fastq_text[: 4 << 20]
+    rc, got = _gpu_inflate(L, p)
+    assert rc == SS_OK and got == fastq_text[: 4 << 20]
+    hdr2 = raw[:3] + bytes([flg | 2]) + raw[4:10] + extra + name + comment
+    hdr2 += (zlib.crc32(hdr2) & 0xFFFF).to_bytes(2, "little")
+    p.write_bytes(hdr2 + body)
+    assert gzip.decompress(hdr2 + body) == fastq_text[: 4 << 20]
+    rc, got = _gpu_inflate(L, p)
+    assert rc == SS_OK and got == fastq_text[: 4 << 20]
+
+
+def test_declines_instead_of_answering_wrongly(L, tmp_path, fastq_text):
+    """Two members, a bgzip-style file of many small members, a truncated file, a flipped byte in the deflate data, a
+    wrong CRC-32, a wrong ISIZE, text that expands 1000:1 (beyond the symbol budget), not gzip at all: SS_ERANGE --
+    or, for a flipped byte that happens to survive, the exact text -- never different bytes."""
+    txt = fastq_text[: 6 << 20]
+    gz = gzip.compress(txt, 6)
+    half = len(txt) // 2
+    mid = len(gz) // 2
+    bgz = b"".join(gzip.compress(txt[i:i + 65000], 6) for i in range(0, len(txt), 65000))
+    cases = dict(
+        two_members=gzip.compress(txt[:half], 6) + gzip.compress(txt[half:], 6),
+        many_members=bgz,
+        truncated=gz[: len(gz) - 4000],
+        flipped=gz[:mid] + bytes([gz[mid] ^ 0x10]) + gz[mid + 1:],
+        bad_crc=gz[:-8] + bytes([gz[-8] ^ 1]) + gz[-7:],
+        bad_isize=gz[:-4] + bytes([gz[-4] ^ 1]) + gz[-3:],
+        expands=gzip.compress(b"A" * (64 << 20), 6),
+        not_gzip=txt[: 1 << 20],
+    )
+    _, d0 = _counters(L)
+    declined = 0
+    for name, data in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(data)
+        rc, got = _gpu_inflate(L, p)
+        if name == "flipped" and rc == SS_OK:
+            assert got == txt
+            continue
+        assert rc == SS_ERANGE, name
+        declined += 1
+    assert _counters(L)[1] == d0 + declined
+
+
+def _kmer_fa(seed, n_rows):
+    rs = np.random.RandomState(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rows = lut[rs.randint(0, 4, (n_rows, 31))]
+    return rows, b"".join(b">1\n" + r.tobytes() + b"\n" for r in rows)
+
+
+def test_scan_of_gz_inputs_through_the_device_inflater(L, tmp_path, monkeypatch):
+    """SS_GZ_GPU=1: ss_scan_files and ss_reads_load inflate single-member .gz inputs on the device (the counters
+    move), a two-member file falls through to the host inflaters, and the row counts equal those of the plain text."""
+    rows, kfa = _kmer_fa(11, 50000)
+    rs = np.random.RandomState(12)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    n = 60000
+    reads = lut[rs.randint(0, 4, (n, 150))]
+    for i in range(0, n, 3):                                  # every third read carries a database k-mer
+        r = rows[rs.randint(0, rows.shape[0])]
+        o = rs.randint(0, 150 - 31)
+        reads[i, o:o + 31] = r
+    fq = b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + b"F" * 150 + b"\n" for i in range(n))
+    assert len(fq) > (16 << 20)
+    half = fq.index(b"\n@r%d\n" % (n // 2)) + 1
+    plain = tmp_path / "a.fq"
+    plain.write_bytes(fq)
+    one = tmp_path / "one.fq.gz"
+    one.write_bytes(gzip.compress(fq, 6))
+    p1, p2 = tmp_path / "p_1.fq.gz", tmp_path / "p_2.fq.gz"
+    p1.write_bytes(gzip.compress(fq[:half], 1))
+    p2.write_bytes(gzip.compress(fq[half:], 9))
+    multi = tmp_path / "multi.fq.gz"
+    multi.write_bytes(gzip.compress(fq[:half], 6) + gzip.compress(fq[half:], 6))
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_files([str(plain)])
+    want = db.counts_rows().copy()
+    assert want.sum() >= n // 3
+    monkeypatch.setenv("SS_GZ_GPU", "1")
+    for paths, on_device in (([str(one)], 1), ([str(p1), str(p2)], 2), ([str(multi)], 0)):
+        h0, d0 = _counters(L)
+        db.reset()
+        nrec, _ = db.scan_files(paths)
+        h1, d1 = _counters(L)
+        assert nrec == n
+        assert np.array_equal(db.counts_rows(), want), paths
+        assert h1 - h0 == on_device and d1 - d0 == len(paths) - on_device, paths
+        rset = L.ReadSet(paths, 0, 1)
+        assert rset.info()["n_records"] == n
+        assert _counters(L)[0] - h1 == on_device
+        db.reset()
+        rset.scan_into(db)
+        assert np.array_equal(db.counts_rows(), want), paths
+        rset.close()
+    monkeypatch.setenv("SS_GZ_GPU", "0")
+    h0, d0 = _counters(L)
+    db.reset()
+    db.scan_files([str(one)])
+    assert _counters(L) == (h0, d0)
+    assert np.array_equal(db.counts_rows(), want)
