@@ -94,7 +94,6 @@ struct WaveState {
     uint8_t len_extra[32], dist_extra[32];     // a constant-memory load with a data-dependent index costs a memory round trip
     uint16_t ring[RING];
     alignas(16) uint32_t stage[STAGE / 4];
-    int dist_usable;
 };
 
 // bit reader over the LDS stage (512 dwords = two halves of 1 KB): the wave refills a half with 16-byte loads when the
@@ -200,8 +199,8 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
         s_ret = ret;
     }
     __syncthreads();
-    const int ret = s_ret;
-    if (ret < 0) return ret;
+    const int ret = __builtin_amdgcn_readfirstlane(s_ret);      // uniform: a value read from LDS is "divergent" to the compiler,
+    if (ret < 0) return ret;                                    // and one divergent branch moves the whole decoder state to VGPRs
     // table: all lanes clear, then lane-parallel fill per code
     for (int e = threadIdx.x & 63; e < (1 << PB); e += 64) h.tent[e] = 0;
     __syncthreads();
@@ -210,7 +209,7 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
         int idx0 = 0;
         uint32_t code = 0;
         for (int l = 1; l <= PB; l++) {
-            const int c = h.count[l];
+            const int c = __builtin_amdgcn_readfirstlane((int)h.count[l]);
             for (int k = threadIdx.x & 63; k < c; k += 64) {
                 const uint32_t cd = code + (uint32_t)k;
                 uint32_t r = __brev(cd) >> (32 - l);
@@ -245,7 +244,7 @@ __device__ __forceinline__ int huff_decode(const LHuff<PB, MAXSYM> &h, SBits &b)
     return -1;
 }
 
-__device__ bool read_dynamic(WaveState &S, SBits &b)
+__device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
 {
     const int hlit = (int)sb_get(S, b, 5) + 257, hdist = (int)sb_get(S, b, 5) + 1, hclen = (int)sb_get(S, b, 4) + 4;
     if (hlit > 286 || hdist > 30) return false;
@@ -256,7 +255,7 @@ __device__ bool read_dynamic(WaveState &S, SBits &b)
         const uint32_t v = sb_get(S, b, 3);
         if ((threadIdx.x & 63) == 0) S.lens[c_cl_order[i]] = (uint8_t)v;
     }
-    if (huff_build(S.clc, S.lens, 19) != 0) return false;
+    if (__builtin_amdgcn_readfirstlane(huff_build(S.clc, S.lens, 19)) != 0) return false;   // (a call's result arrives in a VGPR)
     // the code lengths themselves: sequential; every lane decodes, lane 0 stores
     int i = 0;
     __shared__ uint8_t s_all[320];
@@ -265,7 +264,7 @@ __device__ bool read_dynamic(WaveState &S, SBits &b)
         const int s = huff_decode(S.clc, b);
         if (s < 0 || sb_past_end(b)) return false;
         int rep = 1, val = s;
-        if (s == 16) { if (i == 0) return false; val = s_all[i - 1]; rep = 3 + (int)sb_get(S, b, 2); }
+        if (s == 16) { if (i == 0) return false; val = __builtin_amdgcn_readfirstlane((int)s_all[i - 1]); rep = 3 + (int)sb_get(S, b, 2); }
         else if (s == 17) { val = 0; rep = 3 + (int)sb_get(S, b, 3); }
         else if (s == 18) { val = 0; rep = 11 + (int)sb_get(S, b, 7); }
         if (i + rep > hlit + hdist) return false;
@@ -274,14 +273,15 @@ __device__ bool read_dynamic(WaveState &S, SBits &b)
         __syncthreads();
         i += rep;
     }
-    if (s_all[256] == 0) return false;
+    if (__builtin_amdgcn_readfirstlane((int)s_all[256]) == 0) return false;
     for (int k = threadIdx.x & 63; k < hlit + hdist; k += 64) S.lens[k] = s_all[k];
     __syncthreads();
-    const int rl = huff_build(S.lit, S.lens, hlit);
-    if (rl < 0 || (rl > 0 && S.lit.maxlen != 1)) return false;
-    const int rd = huff_build(S.dist, S.lens + hlit, hdist);
-    if (rd < 0 || (rd > 0 && S.dist.maxlen > 1)) return false;
-    S.dist_usable = S.dist.maxlen > 0;
+    const int rl = __builtin_amdgcn_readfirstlane(huff_build(S.lit, S.lens, hlit));
+    if (rl < 0 || (rl > 0 && __builtin_amdgcn_readfirstlane(S.lit.maxlen) != 1)) return false;
+    const int rd = __builtin_amdgcn_readfirstlane(huff_build(S.dist, S.lens + hlit, hdist));
+    const int dmax = __builtin_amdgcn_readfirstlane(S.dist.maxlen);
+    if (rd < 0 || (rd > 0 && dmax > 1)) return false;
+    dist_usable = dmax > 0;
     return !sb_past_end(b);
 }
 
@@ -295,7 +295,6 @@ __device__ void fixed_codes(WaveState &S)
     for (int i = threadIdx.x & 63; i < 30; i += 64) S.lens[i] = 5;
     __syncthreads();
     huff_build(S.dist, S.lens, 30);
-    S.dist_usable = 1;
 }
 
 // Output of a wave: symbols go to the LDS ring first; whenever 1024 new ones have gathered, the 64 lanes write them to
@@ -347,8 +346,9 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         }
         GI_RET(sb_past_end(b) ? -3 : (int)bfinal);
     }
+    bool dist_usable = true;
     if (btype == 1) fixed_codes(S);
-    else if (!read_dynamic(S, b)) GI_RET(-4);
+    else if (!read_dynamic(S, b, dist_usable)) GI_RET(-4);
     const uint64_t probe_end = probe_symbols == ~0ull ? ~0ull : n + probe_symbols;
     for (;;) {
         if (store) {
@@ -376,7 +376,7 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         const int li = s - 257;
         const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.len_base[li]) +
                              sb_get(S, b, __builtin_amdgcn_readfirstlane((int)S.len_extra[li]));
-        if (!S.dist_usable) GI_RET(-7);
+        if (!dist_usable) GI_RET(-7);
         const int ds = huff_decode(S.dist, b);
         if (ds < 0 || ds > 29) GI_RET(-7);
         const uint32_t dist = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.dist_base[ds]) +
