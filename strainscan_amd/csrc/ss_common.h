@@ -119,6 +119,17 @@ struct ss_reads {
     uint64_t first_slab = 0;          // size of the first slab (estimate from the file sizes)
 
     static uint64_t padded(uint64_t len) { return (len + 1 + 15) & ~15ull; }
+    // a flat block that is already on the device (hipMalloc'ed, padded as above) becomes a slab of its own
+    void adopt(char *d, uint64_t cap, uint64_t len)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        Slab sl;
+        sl.d = d; sl.cap = cap; sl.used = padded(len);
+        if (!slabs.empty() && slabs.back().used < slabs.back().cap) slabs.insert(slabs.end() - 1, sl);      // the open slab stays last
+        else slabs.push_back(sl);
+        device_bytes += cap;
+        n_blocks++;
+    }
     // room for a block of `len` bytes (+ padding); nullptr when the device is out of memory
     char *reserve(uint64_t len)
     {
@@ -160,6 +171,18 @@ uint64_t inflate_budget_bytes();
 hipStream_t ingest_stream(unsigned i);   // a few process-wide non-blocking streams (creating one costs ~13 ms)
 void free_later(char *p);
 std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths);
+// SS_GZ_GPU=1: .gz inputs are inflated on the device (ss_ginflate.hip) and strict four-line FASTQ is turned into the flat
+// base block there (ss_fastq_dev.hip)
+bool gz_on_gpu();
+bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len);
+int gz_fastq_to_flat_dev(const char *path, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap, uint64_t *n_records, char **text,
+                         uint64_t *text_len);
+// every gzip input of a call through gz_fastq_to_flat_dev, one host thread per file: `flat(i, d_flat, len, cap, n_records)`
+// takes over the device buffer of input i (called from that file's thread; returns an SS_* code); inputs that were
+// only inflated come back as host texts in `texts`; done[i] = 1 for the inputs that need nothing more
+int gz_inputs_on_device(const char *const *paths, int n_paths,
+                        const std::function<int(int, char *, uint64_t, uint64_t, uint64_t)> &flat, std::vector<InflatedText> &texts,
+                        std::vector<char> &done);
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled, int shard_rank = 0,
                        int shard_world = 1);
 int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled,

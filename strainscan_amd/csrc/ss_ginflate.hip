@@ -446,10 +446,36 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
     const uint64_t probe_end = probe_symbols == ~0ull ? ~0ull : n + probe_symbols;
     const uint64_t end_bits = b.n * 8;
     const uint64_t mine_below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // the window whose far matches are still loading while the next one is decoded (software pipeline: a far match reads
+    // what this wave wrote tens of KB ago -- with thousands of waves at work that is HBM or the Infinity Cache, ~2 us)
+    bool p_active = false, p_far = false;
+    uint64_t p_farmask = 0, p_near = 0;
+    uint32_t p_at = 0, p_mlen = 0, p_val = 0, p_got[FAR_MAX / 2];
+#pragma unroll
+    for (uint32_t k = 0; k < FAR_MAX / 2; k++) p_got[k] = 0;
+    int ret = 0;
+#define GI_FINISH()                                                                                                          \
+    do {                                                                                                                     \
+        if (p_active) {                                                                                                      \
+            if (p_farmask) {                                                                                                 \
+                _Pragma("unroll") for (uint32_t k = 0; k < FAR_MAX; k++)                                                      \
+                    if (p_far && k < p_mlen) S.ring[(p_at + k) & (RING - 1)] = (uint16_t)(p_got[k >> 1] >> (16 * (k & 1)));   \
+            }                                                                                                                \
+            uint64_t mt_ = p_near;                                                                                           \
+            while (mt_) {                                                                                                    \
+                const int fm_ = __ffsll((long long)mt_) - 1;                                                                 \
+                mt_ &= mt_ - 1;                                                                                              \
+                copy_match(S, o, (uint32_t)__builtin_amdgcn_readlane((int)p_at, fm_), (uint32_t)__builtin_amdgcn_readlane((int)p_mlen, fm_), \
+                           (uint32_t)__builtin_amdgcn_readlane((int)p_val, fm_));                                            \
+            }                                                                                                                \
+            p_active = false;                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#define GI_OUT(v) do { ret = (v); goto out; } while (0)
     for (;;) {
-        if (store && n - o.flushed >= 1024) out_flush(S, o, n);
-        if (n >= probe_end) GI_RET(2);                     // sync search: the header was valid and this many symbols decoded
-        if (b.bp > end_bits) GI_RET(-5);
+        if (store && n - o.flushed >= 1024) { GI_FINISH(); out_flush(S, o, n); }
+        if (n >= probe_end) GI_OUT(2);                     // sync search: the header was valid and this many symbols decoded
+        if (b.bp > end_bits) GI_OUT(-5);
         GZ_T(tw0);
         sb_stage(S, b);
         // ---- every lane: the item at bp + lane
@@ -497,7 +523,7 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         uint32_t stop = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)last);
         stop = (stop & (F_EOB | F_BAD)) ? stop : 0u;
         if (stop) { chain &= ~(1ull << last); pos = last; }
-        if (stop & F_BAD) GI_RET(-5);
+        if (stop & F_BAD) GI_OUT(-5);
         GZ_T(tw2);
         // ---- deliver
         const bool on = (chain >> lane) & 1ull, is_match = on && (info & F_MATCH);
@@ -505,41 +531,37 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         const uint32_t olen = on ? (is_match ? mlen : 1u) : 0u;
         const uint32_t incl = wave_inclusive_sum(olen);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint64_t at = n + (incl - olen);             // where this lane's item goes
-        if (known_window && __ballot(is_match && (uint64_t)val > at)) GI_RET(-8);
+        const uint32_t at = (uint32_t)n + (incl - olen);   // where this lane's item goes (a chunk's output is far below 2^31 symbols)
+        if (known_window && __ballot(is_match && val > at)) GI_OUT(-8);
 #ifdef SS_GZ_TIMING
         o.t[6] += (uint64_t)__popcll(matches); o.t[7] += total; o.t[8] += (uint64_t)__popcll(__ballot(is_match && val > RING_REACH + mlen - 1));
 #endif
         if (store) {
-            if (n + total > o.cap) GI_RET(-9);
+            if (n + total > o.cap) GI_OUT(-9);
+            GI_FINISH();                                   // the window before this one: its far symbols have arrived by now
             if (total <= WIN_MAX) {
                 if (on && !is_match) S.ring[at & (RING - 1)] = (uint16_t)val;
-                // matches from far back, few symbols: all their loads in flight together
+                // matches from far back, few symbols: all their loads in flight together, and left in flight
 #ifdef SS_GZ_NOFAR
                 const bool far = false;
 #else
                 const bool far = is_match && mlen <= FAR_MAX && val > RING_REACH + mlen - 1;      // every symbol beyond the ring's reach
 #endif
-                if (__ballot(far)) {
-                    uint16_t got[FAR_MAX];
-                    const int64_t sp0 = (int64_t)at - (int64_t)val;
+                p_farmask = __ballot(far);
+                if (p_farmask) {
+                    const int32_t sp0 = (int32_t)at - (int32_t)val;
 #pragma unroll
-                    for (uint32_t k = 0; k < FAR_MAX; k++) {
-                        got[k] = (uint16_t)(UNRES | (uint32_t)((int64_t)WSIZE + sp0 + (int64_t)k));
-                        if (far && k < mlen && sp0 + (int64_t)k >= 0) got[k] = o.out[sp0 + (int64_t)k];
+                    for (uint32_t k = 0; k < FAR_MAX; k += 2) {
+                        uint16_t g0 = (uint16_t)(UNRES | (uint32_t)((int32_t)WSIZE + sp0 + (int32_t)k));
+                        uint16_t g1 = (uint16_t)(UNRES | (uint32_t)((int32_t)WSIZE + sp0 + (int32_t)k + 1));
+                        if (far && k < mlen && sp0 + (int32_t)k >= 0) g0 = o.out[sp0 + (int32_t)k];
+                        if (far && k + 1 < mlen && sp0 + (int32_t)k + 1 >= 0) g1 = o.out[sp0 + (int32_t)k + 1];
+                        p_got[k >> 1] = (uint32_t)g0 | ((uint32_t)g1 << 16);
                     }
-#pragma unroll
-                    for (uint32_t k = 0; k < FAR_MAX; k++)
-                        if (far && k < mlen) S.ring[(at + k) & (RING - 1)] = got[k];
                 }
-                uint64_t mt = matches & ~__ballot(far);
-                while (mt) {
-                    const int fm = __ffsll((long long)mt) - 1;
-                    mt &= mt - 1;
-                    const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, fm), dist = (uint32_t)__builtin_amdgcn_readlane((int)val, fm);
-                    const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)(incl - olen), fm);
-                    copy_match(S, o, n + rel, len, dist);
-                }
+                p_far = far; p_at = at; p_mlen = mlen; p_val = val;
+                p_near = matches & ~p_farmask;
+                p_active = true;
                 n += total;
             } else {
                 // a window that delivers a lot (long matches): item by item, flushing on the way
@@ -567,11 +589,16 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
 #endif
         if (stop & F_EOB) {
             sb_seek(b, b.bp + pos + (stop & 63u));
-            if (sb_past_end(b)) GI_RET(-5);
-            GI_RET((int)bfinal);
+            GI_OUT(sb_past_end(b) ? -5 : (int)bfinal);
         }
         sb_seek(b, b.bp + pos);
     }
+out:
+    if (store) GI_FINISH();
+    o.n = n;
+    return ret;
+#undef GI_FINISH
+#undef GI_OUT
 #undef GI_RET
 }
 
@@ -775,10 +802,14 @@ static std::atomic<uint64_t> g_handled{0}, g_declined{0};
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
+    // own stream and stream-ordered scratch memory: the two mates of a paired sample are inflated by two host threads, and
+    // neither the legacy default stream nor hipFree's device-wide wait may serialise them
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
-        hipDeviceSynchronize();
+        hipStreamSynchronize(st);
         fprintf(stderr, "[ginflate] %-18s at %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
     auto no = [&](const char *why, long long a = 0) {
@@ -803,21 +834,30 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     uint16_t *d_sym = nullptr;
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
     int *d_status = nullptr;
+    uint16_t *d_map[2] = {nullptr, nullptr};
+    uint32_t *d_more = nullptr;
     auto cleanup = [&](bool keep_text) {
-        hipFree(d_in); hipFree(d_win); hipFree(d_entry); hipFree(d_meta); hipFree(d_sym); hipFree(d_crc); hipFree(d_tab); hipFree(d_status);
+        void *scratch[] = {d_in, d_win, d_entry, d_meta, d_sym, d_crc, d_tab, d_status, d_map[0], d_map[1], d_more};
+        for (void *q : scratch) if (q) hipFreeAsync(q, st);
+        hipStreamSynchronize(st);
+        hipStreamDestroy(st);
         if (!keep_text) hipFree(d_text);
     };
+    auto h2d = [&](void *dst, const void *src, uint64_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess; };
+    auto d2h = [&](void *dst, const void *src, uint64_t bytes) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    };
 #define GI(call) do { if ((call) != hipSuccess) { cleanup(false); return no(#call); } } while (0)
-    GI(hipMalloc((void **)&d_in, in_n + 8192));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
-    GI(hipMemcpy(d_in, in, in_n, hipMemcpyHostToDevice));
-    GI(hipMemset(d_in + in_n, 0, 8192));
-    GI(hipMalloc((void **)&d_entry, (uint64_t)n_chunks0 * 8));
+    GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
+    GI(h2d(d_in, in, in_n) ? hipSuccess : hipErrorUnknown);
+    GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
+    GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
     uint64_t probe = 512;
     if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
-    hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, 0, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe);
+    hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe);
     std::vector<uint64_t> entry(n_chunks0);
-    GI(hipMemcpy(entry.data(), d_entry, (uint64_t)n_chunks0 * 8, hipMemcpyDeviceToHost));
+    GI(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8) ? hipSuccess : hipErrorUnknown);
     if (trace) {
         unsigned tries = 0;
         hipMemcpyFromSymbol(&tries, HIP_SYMBOL(g_sync_tries), 4);
@@ -841,13 +881,13 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         sym_total += cp;
     }
     // meta: start, stop, off, cap, out_len, end_bit, text_off
-    GI(hipMalloc((void **)&d_meta, (uint64_t)nc * 8 * 7));
+    GI(hipMallocAsync((void **)&d_meta, (uint64_t)nc * 8 * 7, st));
     uint64_t *d_start = d_meta, *d_stop = d_meta + nc, *d_off = d_meta + 2ull * nc, *d_cap = d_meta + 3ull * nc, *d_len = d_meta + 4ull * nc,
              *d_end = d_meta + 5ull * nc, *d_toff = d_meta + 6ull * nc;
-    GI(hipMemcpy(d_start, start.data(), (uint64_t)nc * 8, hipMemcpyHostToDevice));
-    GI(hipMemcpy(d_stop, stop.data(), (uint64_t)nc * 8, hipMemcpyHostToDevice));
-    GI(hipMemcpy(d_off, off.data(), (uint64_t)nc * 8, hipMemcpyHostToDevice));
-    GI(hipMemcpy(d_cap, cap.data(), (uint64_t)nc * 8, hipMemcpyHostToDevice));
+    GI(h2d(d_start, start.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+    GI(h2d(d_stop, stop.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+    GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+    GI(h2d(d_cap, cap.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
     {
         // symbols (2 B each, `ratio` per input byte), windows and maps (5 x 32 KB per chunk) and the text must fit
         size_t mem_free = 0, mem_total = 0;
@@ -855,19 +895,19 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         const uint64_t need = sym_total * 2 + (uint64_t)nc * WSIZE * 5 + ((uint64_t)want_isize | (in_n > (1ull << 32) ? in_n * 4 : 0)) + (64 << 20);
         if (need > mem_free / 2) { cleanup(false); return no("device memory", (long long)(need >> 20)); }
     }
-    GI(hipMalloc((void **)&d_sym, sym_total * 2));
-    GI(hipMalloc((void **)&d_status, (uint64_t)nc * 4));
+    GI(hipMallocAsync((void **)&d_sym, sym_total * 2, st));
+    GI(hipMallocAsync((void **)&d_status, (uint64_t)nc * 4, st));
     lap("symbol buffers");
     if (getenv("SS_GZ_COUNTONLY")) {         // timing experiment: the decode without any output
-        hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, 0, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status);
+        hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status);
         lap("inflate (count only)");
     }
-    hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, 0, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status);
+    hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status);
     std::vector<int> status(nc);
     std::vector<uint64_t> out_len(nc), end_bit(nc), text_off(nc);
-    GI(hipMemcpy(status.data(), d_status, (uint64_t)nc * 4, hipMemcpyDeviceToHost));
-    GI(hipMemcpy(out_len.data(), d_len, (uint64_t)nc * 8, hipMemcpyDeviceToHost));
-    GI(hipMemcpy(end_bit.data(), d_end, (uint64_t)nc * 8, hipMemcpyDeviceToHost));
+    GI(d2h(status.data(), d_status, (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
+    GI(d2h(out_len.data(), d_len, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+    GI(d2h(end_bit.data(), d_end, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
     lap("inflate");
 #ifdef SS_GZ_TIMING
     {
@@ -888,45 +928,42 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     // the stream must end where the trailer begins (after padding to a byte)
     if ((end_bit[nc - 1] + 7) / 8 != in_n - 8) { cleanup(false); return no("stream end", (long long)((end_bit[nc - 1] + 7) / 8)); }
     if ((uint32_t)total != want_isize) { cleanup(false); return no("isize"); }
-    GI(hipMemcpy(d_toff, text_off.data(), (uint64_t)nc * 8, hipMemcpyHostToDevice));
-    GI(hipMalloc((void **)&d_win, (uint64_t)nc * WSIZE));
+    GI(h2d(d_toff, text_off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+    GI(hipMallocAsync((void **)&d_win, (uint64_t)nc * WSIZE, st));
     {
-        uint16_t *d_map[2] = {nullptr, nullptr};
-        uint32_t *d_more = nullptr;
-        bool ok = hipMalloc((void **)&d_map[0], (uint64_t)nc * WSIZE * 2) == hipSuccess && hipMalloc((void **)&d_map[1], (uint64_t)nc * WSIZE * 2) == hipSuccess &&
-                  hipMalloc((void **)&d_more, 4) == hipSuccess;
+        bool ok = hipMallocAsync((void **)&d_map[0], (uint64_t)nc * WSIZE * 2, st) == hipSuccess &&
+                  hipMallocAsync((void **)&d_map[1], (uint64_t)nc * WSIZE * 2, st) == hipSuccess && hipMallocAsync((void **)&d_more, 4, st) == hipSuccess;
         int cur = 0;
         if (ok) {
-            hipLaunchKernelGGL(tails_kernel, dim3(8, nc), dim3(256), 0, 0, d_sym, d_off, d_len, nc, d_map[0]);
+            hipLaunchKernelGGL(tails_kernel, dim3(8, nc), dim3(256), 0, st, d_sym, d_off, d_len, nc, d_map[0]);
             for (uint32_t span = 1; span < nc && ok; span *= 2) {
                 uint32_t more = 0;
-                ok = hipMemset(d_more, 0, 4) == hipSuccess;
-                hipLaunchKernelGGL(compose_kernel, dim3(8, nc), dim3(256), 0, 0, d_map[cur], d_map[cur ^ 1], nc, span, d_more);
+                ok = hipMemsetAsync(d_more, 0, 4, st) == hipSuccess;
+                hipLaunchKernelGGL(compose_kernel, dim3(8, nc), dim3(256), 0, st, d_map[cur], d_map[cur ^ 1], nc, span, d_more);
                 cur ^= 1;
-                ok = ok && hipMemcpy(&more, d_more, 4, hipMemcpyDeviceToHost) == hipSuccess;
+                ok = ok && d2h(&more, d_more, 4);
                 if (!more) break;
             }
-            hipLaunchKernelGGL(windows_kernel, dim3(8, nc), dim3(256), 0, 0, d_map[cur], nc, d_win);
-            ok = ok && hipDeviceSynchronize() == hipSuccess;
+            hipLaunchKernelGGL(windows_kernel, dim3(8, nc), dim3(256), 0, st, d_map[cur], nc, d_win);
+            ok = ok && hipStreamSynchronize(st) == hipSuccess;
         }
-        hipFree(d_map[0]); hipFree(d_map[1]); hipFree(d_more);
         if (!ok) { cleanup(false); return no("windows"); }
     }
     lap("windows");
     GI(hipMalloc((void **)&d_text, std::max<uint64_t>(total, 16) + 64));
-    hipLaunchKernelGGL(bytes_kernel, dim3(64, nc), dim3(256), 0, 0, d_sym, d_off, d_len, d_toff, d_win, d_text);
+    hipLaunchKernelGGL(bytes_kernel, dim3(64, nc), dim3(256), 0, st, d_sym, d_off, d_len, d_toff, d_win, d_text);
     lap("bytes");
     // CRC-32 by segments of 16 KB, combined on the host with ONE precomputed operator
     constexpr int SEG_LOG2 = 14;
     const uint64_t seg = 1ull << SEG_LOG2, nseg = (total + seg - 1) / seg;
     std::vector<uint32_t> tab(256);
     for (uint32_t i = 0; i < 256; i++) { uint32_t k = i; for (int j = 0; j < 8; j++) k = (k & 1u) ? 0xEDB88320u ^ (k >> 1) : k >> 1; tab[i] = k; }
-    GI(hipMalloc((void **)&d_tab, 1024));
-    GI(hipMemcpy(d_tab, tab.data(), 1024, hipMemcpyHostToDevice));
-    GI(hipMalloc((void **)&d_crc, std::max<uint64_t>(1, nseg) * 4));
-    if (nseg) hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, 0, d_text, total, seg, d_tab, d_crc);
+    GI(hipMallocAsync((void **)&d_tab, 1024, st));
+    GI(h2d(d_tab, tab.data(), 1024) ? hipSuccess : hipErrorUnknown);
+    GI(hipMallocAsync((void **)&d_crc, std::max<uint64_t>(1, nseg) * 4, st));
+    if (nseg) hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, d_text, total, seg, d_tab, d_crc);
     std::vector<uint32_t> crcs(std::max<uint64_t>(1, nseg));
-    if (nseg) GI(hipMemcpy(crcs.data(), d_crc, nseg * 4, hipMemcpyDeviceToHost));
+    if (nseg) GI(d2h(crcs.data(), d_crc, nseg * 4) ? hipSuccess : hipErrorUnknown);
     uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
     {
         uint32_t op[32];

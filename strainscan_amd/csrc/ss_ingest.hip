@@ -161,7 +161,6 @@ struct TextAlloc {                                                          // s
 };
 bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_t budget, char **text, uint64_t *len,
                      const TextAlloc *ta);
-bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len);      // ss_ginflate.hip
 namespace {
 struct Deflate {
     void *(*alloc)() = nullptr;
@@ -210,12 +209,6 @@ uint64_t inflate_budget_bytes()
     return mem / 4;
 }
 
-static bool gz_on_gpu()
-{
-    const char *e = getenv("SS_GZ_GPU");
-    return e && *e && strcmp(e, "0") != 0;
-}
-
 // path -> malloc'ed text of all its gzip members, or false (not gzip, no libdeflate, damaged, over `budget`)
 // mode: 0 = parallel inflater when the file is large enough, else libdeflate; 1 = parallel only; 2 = libdeflate only
 bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len, int mode, unsigned threads)
@@ -231,19 +224,6 @@ bool inflate_whole(const char *path, uint64_t budget, char **text, uint64_t *len
     close(fd);
     if (in == MAP_FAILED) return false;
     bool ok = in[0] == 0x1f && in[1] == 0x8b;
-    if (ok && mode != 2 && gz_on_gpu()) {
-        // SS_GZ_GPU=1: the member is inflated on the device (ss_ginflate.hip; verified against the trailer's CRC-32
-        // and length there); anything it does not handle (several members, damage, no sync points) goes on below
-        char *d = nullptr;
-        uint64_t n = 0;
-        if (gpu_gunzip(in, in_n, &d, &n)) {
-            char *h = n <= budget ? (char *)malloc(std::max<uint64_t>(n, 1)) : nullptr;
-            const bool got = h && (n == 0 || hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess);
-            hipFree(d);
-            if (got) { munmap((void *)in, in_n); *text = h; *len = n; return true; }
-            free(h);
-        }
-    }
     if (ok && mode != 2 && !getenv("SS_NO_PGZ")) {
         // many threads on ONE member (ss_pgz.hip); verified against the trailer's CRC-32 and length
         if (!threads) threads = std::min<unsigned>(host_cpus(), 32u);
@@ -379,15 +359,47 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
     // the files inflate concurrently and share the CPUs the process may use (not the machine's hardware threads)
     const unsigned per_file = std::max(1u, std::min(32u, host_cpus() / (unsigned)gz.size()));
     std::vector<std::thread> pool;
-    int device = 0;
-    if (gz_on_gpu()) hipGetDevice(&device);
     for (int i : gz)
-        pool.emplace_back([&out, paths, i, budget, per_file, device] {
-            if (gz_on_gpu()) hipSetDevice(device);                // the device inflater runs on the caller's GPU
-            if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, per_file)) out[i].p = nullptr;
-        });
+        pool.emplace_back([&out, paths, i, budget, per_file] { if (!inflate_whole(paths[i], budget, &out[i].p, &out[i].n, 0, per_file)) out[i].p = nullptr; });
     for (auto &th : pool) th.join();
     return out;
+}
+
+int gz_inputs_on_device(const char *const *paths, int n_paths,
+                        const std::function<int(int, char *, uint64_t, uint64_t, uint64_t)> &flat, std::vector<InflatedText> &texts,
+                        std::vector<char> &done)
+{
+    texts.assign((size_t)std::max(0, n_paths), InflatedText());
+    done.assign((size_t)std::max(0, n_paths), 0);
+    if (!gz_on_gpu()) return SS_OK;
+    std::vector<int> gz;
+    for (int i = 0; i < n_paths; i++) {
+        if (!paths[i] || !paths[i][0]) continue;
+        unsigned char magic[2] = {0, 0};
+        FILE *f = fopen(paths[i], "rb");
+        if (!f) continue;
+        if (fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) gz.push_back(i);
+        fclose(f);
+    }
+    if (gz.empty()) return SS_OK;
+    int device = 0;
+    hipGetDevice(&device);
+    std::atomic<int> err(SS_OK);
+    std::vector<std::thread> pool;
+    for (int i : gz)
+        pool.emplace_back([&, i] {
+            hipSetDevice(device);
+            char *d = nullptr;
+            uint64_t len = 0, cap = 0, nrec = 0;
+            const int r = gz_fastq_to_flat_dev(paths[i], &d, &len, &cap, &nrec, &texts[i].p, &texts[i].n);
+            if (r == 0) {
+                const int rc = flat(i, d, len, cap, nrec);
+                if (rc != SS_OK) err = rc;
+                done[i] = 1;
+            }
+        });
+    for (auto &th : pool) th.join();
+    return err;
 }
 
 // returns SS_OK and *handled = true when the file was scanned here; *handled = false => caller
@@ -602,11 +614,34 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     // goes through the sequential reader -- one thread PER FILE, so the two mates of a paired
     // .fastq.gz sample inflate concurrently (zlib is the limiter there)
     std::vector<int> seq_files;
-    std::vector<ss::InflatedText> texts = ss::inflate_gz_inputs(paths, n_paths);     // .gz inputs, inflated concurrently
+    // SS_GZ_GPU=1, one rank: .gz inputs are inflated AND reduced to their sequence lines on the device; the block becomes a
+    // slab as it is.  What that path only inflated (not strict four-line FASTQ) arrives as text, the rest goes on below.
+    std::vector<ss::InflatedText> texts;
+    std::vector<char> on_device;
+    std::vector<const char *> rest(paths, paths + n_paths);
+    if (shard_world == 1) {
+        std::atomic<uint64_t> drecs(0), dbases(0);
+        rc = ss::gz_inputs_on_device(paths, n_paths, [&](int, char *d, uint64_t len, uint64_t cap, uint64_t nrec) {
+            R->adopt(d, cap, len);
+            drecs += nrec;
+            dbases += len;
+            return (int)SS_OK;
+        }, texts, on_device);
+        recs += drecs;
+        bases += dbases;
+        for (int i = 0; i < n_paths; i++)
+            if (on_device[i] || texts[i].p) rest[i] = "";
+    }
+    if (rc == SS_OK) {
+        std::vector<ss::InflatedText> more = ss::inflate_gz_inputs(rest.data(), n_paths);     // .gz inputs, inflated concurrently
+        if (texts.empty()) texts = more;
+        else for (int i = 0; i < n_paths; i++) if (more[i].p) texts[i] = more[i];
+    }
+    if (on_device.empty()) on_device.assign((size_t)n_paths, 0);
     if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: gz inputs inflated at %.4f s\n", load_since());
     for (int i = 0; i < n_paths && rc == SS_OK; i++) {
         if (!paths[i]) { rc = SS_EINVAL; break; }
-        if (!paths[i][0]) continue;
+        if (!paths[i][0] || on_device[i]) continue;
         bool handled = false;
         if (texts[i].p)
             rc = ss::parse_text_parallel(g_read_workers, texts[i].p, texts[i].n, nullptr, shard_rank, shard_world, &recs,

@@ -447,10 +447,34 @@ int ss_scan_files_shard(ss_db *db, const char *const *paths, int n_paths, int sh
         if (!paths[i]) return SS_EINVAL;
     // .gz inputs are inflated whole (libdeflate, all files at once) and parsed like plain text when possible
     std::vector<ss::InflatedText> texts;
-    if (allow_parallel) texts = ss::inflate_gz_inputs(paths, n_paths);
+    std::vector<char> on_device((size_t)n_paths, 0);
     int rc = SS_OK;
+    if (allow_parallel) {
+        // SS_GZ_GPU=1, one rank: inflated and reduced to the sequence lines on the device (ss_ginflate.hip, ss_fastq_dev.hip),
+        // scanned from there
+        std::vector<const char *> rest(paths, paths + n_paths);
+        if (shard_world == 1) {
+            std::mutex mu;
+            rc = ss::gz_inputs_on_device(paths, n_paths, [&](int, char *d, uint64_t len, uint64_t, uint64_t nrec) {
+                std::lock_guard<std::mutex> g(mu);                    // one scan at a time on the table's stream
+                int r = ss_scan_flat_dev(db, d, ss_reads::padded(len), nullptr);
+                if (r == SS_OK && hipStreamSynchronize(nullptr) != hipSuccess) r = SS_EHIP;
+                hipFree(d);
+                recs += nrec;
+                total += len;
+                return r;
+            }, texts, on_device);
+            for (int i = 0; i < n_paths; i++)
+                if (on_device[i] || texts[i].p) rest[i] = "";
+        }
+        if (rc == SS_OK) {
+            std::vector<ss::InflatedText> more = ss::inflate_gz_inputs(rest.data(), n_paths);
+            if (texts.empty()) texts = more;
+            else for (int i = 0; i < n_paths; i++) if (more[i].p) texts[i] = more[i];
+        }
+    }
     for (int i = 0; i < n_paths && rc == SS_OK; i++) {
-        if (!paths[i][0]) continue;            // '' = no second file (StrainScan.py:182)
+        if (!paths[i][0] || on_device[i]) continue;            // '' = no second file (StrainScan.py:182)
         bool handled = false;
         if (allow_parallel) {
             if (!texts.empty() && texts[i].p) rc = ss::scan_text_parallel(db, texts[i].p, texts[i].n, &recs, &total, &handled, shard_rank, shard_world);

@@ -210,3 +210,58 @@ def test_scan_of_gz_inputs_through_the_device_inflater(L, tmp_path, monkeypatch)
     db.scan_files([str(one)])
     assert _counters(L) == (h0, d0)
     assert np.array_equal(db.counts_rows(), want)
+
+
+def _records_of(read_set):
+    """The resident flat blocks as a sorted list of records (block order and padding newlines do not matter)."""
+    return sorted(r for r in read_set.read_back().split(b"\n") if r)
+
+
+@pytest.mark.parametrize("case", ["strict", "no_final_newline", "crlf", "empty_sequence", "at_in_quality", "fasta", "two_line_sequence",
+                                  "blank_lines", "short_quality", "plus_line_missing", "tiny"])
+def test_device_fastq_extraction_equals_the_host_grammar(L, tmp_path, monkeypatch, case):
+    """ss_fastq_dev.hip takes strict four-line FASTQ only and must then deliver what ss_fastx_to_flat's grammar (the
+    reference's zcat | jellyfish --if reads the same sequence lines, identify.py:81-84) delivers; every other shape
+    (FASTA, wrapped sequences, blank lines, a quality line of another length, ...) goes to that grammar on the host.
+    Records and record count of the resident read set: SS_GZ_GPU=1 == SS_GZ_GPU=0 == ss_fastx_to_flat."""
+    rs = np.random.RandomState(99)
+    lut = np.frombuffer(b"ACGTN", np.uint8)
+    n = 60 if case == "tiny" else 30000
+    seqs = [lut[rs.randint(0, 5 if i % 50 == 0 else 4, rs.randint(40, 260))].tobytes() for i in range(n)]
+    nl = b"\r\n" if case == "crlf" else b"\n"
+    recs = []
+    for i, sq in enumerate(seqs):
+        q = bytes(33 + (i * 7 + j) % 41 for j in range(len(sq)))
+        if case == "empty_sequence" and i % 97 == 5:
+            sq, q = b"", b""
+        if case == "at_in_quality":
+            q = b"@" + q[1:] if q else q
+        if case == "fasta":
+            recs.append(b">r%d" % i + nl + sq + nl)
+            continue
+        if case == "two_line_sequence" and i % 3 == 0:
+            h = len(sq) // 2
+            recs.append(b"@r%d" % i + nl + sq[:h] + nl + sq[h:] + nl + b"+" + nl + q + nl)
+            continue
+        if case == "short_quality" and i == n // 2:
+            q = q[: len(q) // 2] + nl + q[len(q) // 2:]                 # quality over two lines (the general grammar adds them up)
+        plus = b"" if (case == "plus_line_missing" and i == n - 3) else b"+" + nl
+        recs.append(b"@r%d some text" % i + nl + sq + nl + plus + q + nl + (nl if case == "blank_lines" and i % 11 == 0 else b""))
+    text = b"".join(recs)
+    if case == "no_final_newline":
+        text = text[:-1]
+    want_flat, want_n = L.fastx_to_flat(text)
+    want = sorted(r for r in want_flat.split(b"\n") if r)
+    p = tmp_path / "s.fq.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SS_GZ_GPU", mode)
+        h0, d0 = _counters(L)
+        rset = L.ReadSet([str(p)], 0, 1)
+        got[mode] = (_records_of(rset), rset.info()["n_records"])
+        rset.close()
+        if mode == "0":
+            assert _counters(L) == (h0, d0)
+    assert got["1"][0] == got["0"][0] == want, case
+    assert got["1"][1] == got["0"][1] == want_n, case
