@@ -13,7 +13,7 @@
 //               64 lanes copy matches together.  What lies in the 32 KB in front of the chunk is unknown: the output
 //               is 16-bit symbols, a byte or "byte w of the window" (a copy of a copy keeps the index).  The last 4096
 //               symbols are mirrored in an LDS ring so that a match never waits for the wave's own global stores.
-//   C  windows  chunk after chunk, the last 32 KB of a chunk are resolved with its window and become the next window;
+//   C  windows  the last 32 KB of every chunk as a map "my window -> the next chunk's window", composed in two levels;
 //   D  bytes    all symbols -> bytes in parallel; CRC-32 of the text by segments (combined on the host).
 // Accepted only if every chunk ended exactly on the next one's entry, the stream ended at the member's trailer and
 // CRC-32 and ISIZE match; anything else (several members, a chunk that expands more than SS_GZ_RATIO times, a damaged
@@ -678,43 +678,117 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
 }
 
 // C: windows.  The 32 KB in front of chunk c + 1 are the last 32 KB of chunk c's output, in which a symbol may still
-//    point into chunk c's own window, and so on down the chain.  Instead of walking the chain chunk after chunk
-//    (thousands of dependent steps), the tails are treated as maps "window of c -> window of c + 1" (an entry is a byte
-//    or an index into the previous window) and composed by doubling: after round r every map reaches 2^r chunks back;
-//    ~log2(n_chunks) fully parallel rounds, in practice two or three until no index is left.
+//    point into chunk c's own window, and so on down the chain.  The tails are treated as maps "window of c -> window of
+//    c + 1" (an entry is a byte or an index into the previous window) and composed (below).
 __global__ __launch_bounds__(256) void tails_kernel(const uint16_t *sym, const uint64_t *sym_off, const uint64_t *out_len,
                                                     uint32_t n_chunks, uint16_t *map)
 {
     const uint32_t c = blockIdx.y;                            // map[c] : window of chunk c -> window of chunk c + 1
     const uint64_t L = out_len[c];
     const uint16_t *sy = sym + sym_off[c];
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < WSIZE; i += gridDim.x * 256) {
-        uint16_t e;
-        if (L >= WSIZE - i) e = sy[L - (WSIZE - i)];
-        else e = (uint16_t)(UNRES | (i + (uint32_t)L));       // the chunk was shorter than the window: its own window shifts in
-        map[(uint64_t)c * WSIZE + i] = e;
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 8;      // eight entries (16 bytes) per lane
+    uint16_t e[8];
+    if (L >= WSIZE - i0) {
+        __builtin_memcpy(e, sy + (L - (WSIZE - i0)), 16);          // 2-byte aligned: an unaligned 16-byte load
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t i = i0 + k;
+            e[k] = L >= WSIZE - i ? sy[L - (WSIZE - i)] : (uint16_t)(UNRES | (i + (uint32_t)L));      // the chunk was shorter than
+        }                                                                                           // the window: its own window shifts in
     }
+    __builtin_memcpy(map + (uint64_t)c * WSIZE + i0, e, 16);
 }
-__global__ __launch_bounds__(256) void compose_kernel(const uint16_t *in, uint16_t *out, uint32_t n_chunks, uint32_t span, uint32_t *more)
+// Two levels instead of log2(n_chunks) doubling rounds over all maps (every chunk of a FASTQ file hands lines like
+// "+\n" down from the chunk before, so the chains are as long as the file and no round finishes early: twelve passes
+// over 260 MB for a 130 MB file).  Chunks are grouped, GROUP consecutive ones:
+//   1  one workgroup per group composes its maps IN ORDER, the running map (window at the group's start -> window behind
+//      chunk c) in LDS: a 32 K-entry gather per chunk, the next chunk's tail prefetched meanwhile;
+//   2  one workgroup walks the groups: the window at the start of group g + 1 = the last map of group g applied to the
+//      window at the start of g (32 KB of bytes in LDS);
+//   3  every chunk's window = its composed map applied to its group's start window, all in parallel.
+__global__ __launch_bounds__(1024) void group_maps_kernel(const uint16_t *tails, uint32_t n_chunks, uint32_t group, uint16_t *maps)
 {
-    const uint32_t c = blockIdx.y;
-    bool any = false;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < WSIZE; i += gridDim.x * 256) {
-        uint16_t e = in[(uint64_t)c * WSIZE + i];
-        if ((e & UNRES) && c >= span) {
-            e = in[(uint64_t)(c - span) * WSIZE + (e & (WSIZE - 1))];
-            any = any || ((e & UNRES) && c >= 2 * span);
+    __shared__ uint16_t cur[WSIZE];                        // 64 KB
+    const uint32_t c0 = blockIdx.x * group, c1 = min(c0 + group, n_chunks);
+    const uint32_t tid = threadIdx.x;
+    uint4 nx[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) nx[k] = *reinterpret_cast<const uint4 *>(tails + (uint64_t)c0 * WSIZE + ((uint32_t)k * 1024 + tid) * 8);
+    for (uint32_t c = c0; c < c1; c++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = nx[k];
+        if (c + 1 < c1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) nx[k] = *reinterpret_cast<const uint4 *>(tails + (uint64_t)(c + 1) * WSIZE + ((uint32_t)k * 1024 + tid) * 8);
         }
-        out[(uint64_t)c * WSIZE + i] = e;
+        if (c > c0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((v[k].x | v[k].y | v[k].z | v[k].w) & 0x80008000u) {
+                    uint16_t e[8];
+                    __builtin_memcpy(e, &v[k], 16);
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (e[j] & UNRES) e[j] = cur[e[j] & (WSIZE - 1)];
+                    __builtin_memcpy(&v[k], e, 16);
+                }
+            }
+        }
+        __syncthreads();                                   // all gathers from the running map are done
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            *reinterpret_cast<uint4 *>(&cur[((uint32_t)k * 1024 + tid) * 8]) = v[k];
+            *reinterpret_cast<uint4 *>(maps + (uint64_t)c * WSIZE + ((uint32_t)k * 1024 + tid) * 8) = v[k];
+        }
+        __syncthreads();
     }
-    if (__ballot(any) && (threadIdx.x & 63) == 0) atomicOr(more, 1u);
 }
-// win[c + 1] = bytes of map[c]; win[0] = nothing (chunk 0 has no unknown window)
-__global__ __launch_bounds__(256) void windows_kernel(const uint16_t *map, uint32_t n_chunks, uint8_t *win)
+// gwin[g] = the window in front of the first chunk of group g (bytes)
+__global__ __launch_bounds__(1024) void group_windows_kernel(const uint16_t *maps, uint32_t n_chunks, uint32_t group, uint32_t n_groups, uint8_t *gwin)
+{
+    __shared__ uint8_t w[WSIZE];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < WSIZE; i += 1024) w[i] = 0;     // chunk 0 has no unknown window: never read
+    __syncthreads();
+    for (uint32_t g = 0; g < n_groups; g++) {
+        for (uint32_t i = tid; i < WSIZE; i += 1024) gwin[(uint64_t)g * WSIZE + i] = w[i];
+        if (g + 1 == n_groups) break;
+        const uint16_t *m = maps + (uint64_t)(min((g + 1) * group, n_chunks) - 1) * WSIZE;      // the group's last composed map
+        uint8_t nw[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const uint16_t e = m[(uint32_t)k * 1024 + tid];
+            nw[k] = (e & UNRES) ? w[e & (WSIZE - 1)] : (uint8_t)e;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; k++) w[(uint32_t)k * 1024 + tid] = nw[k];
+        __syncthreads();
+    }
+}
+// win[c + 1] = bytes of the composed map of chunk c over its group's start window; win[0] = nothing
+__global__ __launch_bounds__(256) void windows_kernel(const uint16_t *maps, uint32_t n_chunks, uint32_t group, const uint8_t *gwin, uint8_t *win)
 {
     const uint32_t c = blockIdx.y;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < WSIZE; i += gridDim.x * 256)
-        win[(uint64_t)c * WSIZE + i] = c == 0 ? (uint8_t)0 : (uint8_t)map[(uint64_t)(c - 1) * WSIZE + i];
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    uint2 o = make_uint2(0u, 0u);
+    if (c) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(maps + (uint64_t)(c - 1) * WSIZE + i0);
+        if ((v.x | v.y | v.z | v.w) & 0x80008000u) {
+            const uint8_t *gw = gwin + (uint64_t)((c - 1) / group) * WSIZE;
+            uint16_t e[8];
+            uint8_t by[8];
+            __builtin_memcpy(e, &v, 16);
+#pragma unroll
+            for (int j = 0; j < 8; j++) by[j] = (e[j] & UNRES) ? gw[e[j] & (WSIZE - 1)] : (uint8_t)e[j];
+            __builtin_memcpy(&o, by, 8);
+        } else {
+            o.x = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y << 8) & 0xFF000000u);
+            o.y = (v.z & 0xFFu) | ((v.z >> 8) & 0xFF00u) | ((v.w & 0xFFu) << 16) | ((v.w << 8) & 0xFF000000u);
+        }
+    }
+    *reinterpret_cast<uint2 *>(win + (uint64_t)c * WSIZE + i0) = o;
 }
 
 // D: symbols -> bytes
@@ -931,21 +1005,19 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(h2d(d_toff, text_off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
     GI(hipMallocAsync((void **)&d_win, (uint64_t)nc * WSIZE, st));
     {
+        uint32_t group = 1;
+        while ((uint64_t)group * group < nc) group++;                   // ~sqrt: as many groups as chunks in a group
+        group = std::max<uint32_t>(group, 8);
+        const uint32_t n_groups = (nc + group - 1) / group;
         bool ok = hipMallocAsync((void **)&d_map[0], (uint64_t)nc * WSIZE * 2, st) == hipSuccess &&
-                  hipMallocAsync((void **)&d_map[1], (uint64_t)nc * WSIZE * 2, st) == hipSuccess && hipMallocAsync((void **)&d_more, 4, st) == hipSuccess;
-        int cur = 0;
+                  hipMallocAsync((void **)&d_map[1], (uint64_t)nc * WSIZE * 2, st) == hipSuccess &&
+                  hipMallocAsync((void **)&d_more, (uint64_t)n_groups * WSIZE, st) == hipSuccess;
         if (ok) {
-            hipLaunchKernelGGL(tails_kernel, dim3(8, nc), dim3(256), 0, st, d_sym, d_off, d_len, nc, d_map[0]);
-            for (uint32_t span = 1; span < nc && ok; span *= 2) {
-                uint32_t more = 0;
-                ok = hipMemsetAsync(d_more, 0, 4, st) == hipSuccess;
-                hipLaunchKernelGGL(compose_kernel, dim3(8, nc), dim3(256), 0, st, d_map[cur], d_map[cur ^ 1], nc, span, d_more);
-                cur ^= 1;
-                ok = ok && d2h(&more, d_more, 4);
-                if (!more) break;
-            }
-            hipLaunchKernelGGL(windows_kernel, dim3(8, nc), dim3(256), 0, st, d_map[cur], nc, d_win);
-            ok = ok && hipStreamSynchronize(st) == hipSuccess;
+            hipLaunchKernelGGL(tails_kernel, dim3(16, nc), dim3(256), 0, st, d_sym, d_off, d_len, nc, d_map[0]);
+            hipLaunchKernelGGL(group_maps_kernel, dim3(n_groups), dim3(1024), 0, st, d_map[0], nc, group, d_map[1]);
+            hipLaunchKernelGGL(group_windows_kernel, dim3(1), dim3(1024), 0, st, d_map[1], nc, group, n_groups, (uint8_t *)d_more);
+            hipLaunchKernelGGL(windows_kernel, dim3(16, nc), dim3(256), 0, st, d_map[1], nc, group, (const uint8_t *)d_more, d_win);
+            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
         }
         if (!ok) { cleanup(false); return no("windows"); }
     }
@@ -953,8 +1025,8 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(hipMalloc((void **)&d_text, std::max<uint64_t>(total, 16) + 64));
     hipLaunchKernelGGL(bytes_kernel, dim3(64, nc), dim3(256), 0, st, d_sym, d_off, d_len, d_toff, d_win, d_text);
     lap("bytes");
-    // CRC-32 by segments of 16 KB, combined on the host with ONE precomputed operator
-    constexpr int SEG_LOG2 = 14;
+    // CRC-32 by segments of 4 KB, combined on the host with ONE precomputed operator
+    constexpr int SEG_LOG2 = 12;
     const uint64_t seg = 1ull << SEG_LOG2, nseg = (total + seg - 1) / seg;
     std::vector<uint32_t> tab(256);
     for (uint32_t i = 0; i < 256; i++) { uint32_t k = i; for (int j = 0; j < 8; j++) k = (k & 1u) ? 0xEDB88320u ^ (k >> 1) : k >> 1; tab[i] = k; }
@@ -968,9 +1040,14 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     {
         uint32_t op[32];
         crc_zero_operator(op, SEG_LOG2);
+        // the operator as four byte-indexed tables: one application = four lookups (there are 250 segments per MB)
+        std::vector<uint32_t> opt(4 * 256);
+        for (int byte = 0; byte < 4; byte++)
+            for (uint32_t v = 0; v < 256; v++) opt[(size_t)byte * 256 + v] = gf2_times(op, v << (8 * byte));
         for (uint64_t s = 0; s < nseg; s++) {
             const uint64_t l = std::min<uint64_t>(seg, total - s * seg);
-            crc = l == seg ? (gf2_times(op, crc) ^ crcs[s]) : (uint32_t)crc32_combine(crc, crcs[s], (z_off_t)l);
+            if (l == seg) crc = opt[crc & 0xFF] ^ opt[256 + ((crc >> 8) & 0xFF)] ^ opt[512 + ((crc >> 16) & 0xFF)] ^ opt[768 + (crc >> 24)] ^ crcs[s];
+            else crc = (uint32_t)crc32_combine(crc, crcs[s], (z_off_t)l);
         }
     }
     lap("crc");
