@@ -63,12 +63,15 @@ __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 // code-length code's lengths: 17 + at most 57 bits), registers only: block type, HLIT / HDIST in range, and the
 // code-length code complete (zlib insists on that).  About one position in 2000 passes; those are then parsed and
 // decoded by the whole wave (read_dynamic + inflate_block), which is the real test.
-__device__ __forceinline__ bool header_prefilter(const uint8_t *in, uint64_t p)
+__device__ __forceinline__ uint4 header_bytes(const uint8_t *in, uint64_t p)
 {
-    uint64_t lo, hi;
-    const uint8_t *q = in + (p >> 3);
-    __builtin_memcpy(&lo, q, 8);
-    __builtin_memcpy(&hi, q + 8, 8);
+    uint4 v;
+    __builtin_memcpy(&v, in + (p >> 3), 16);
+    return v;
+}
+__device__ __forceinline__ bool header_prefilter(const uint4 v, uint64_t p)
+{
+    uint64_t lo = (uint64_t)v.x | (uint64_t)v.y << 32, hi = (uint64_t)v.z | (uint64_t)v.w << 32;
     const int sh = (int)(p & 7);
     if (sh) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; }
     if ((lo & 7u) != 4u) return false;                           // BFINAL = 0, BTYPE = 2 (bits: 0, then 0 1 LSB first = value 2)
@@ -254,6 +257,23 @@ __device__ __forceinline__ int huff_decode(const LHuff<PB, MAXSYM> &h, SBits &b)
     return -1;
 }
 
+// inclusive prefix sum over the 64 lanes in six DPP additions (row shifts 1, 2, 4, 8, then the row broadcasts of gfx9)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+#ifdef SS_GZ_SCAN_SHFL
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += u; }
+    return v;
+#endif
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+}
+
 __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
 {
     const int hlit = (int)sb_get(S, b, 5) + 257, hdist = (int)sb_get(S, b, 5) + 1, hclen = (int)sb_get(S, b, 4) + 4;
@@ -266,23 +286,56 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
         if ((threadIdx.x & 63) == 0) S.lens[c_cl_order[i]] = (uint8_t)v;
     }
     if (__builtin_amdgcn_readfirstlane(huff_build(S.clc, S.lens, 19)) != 0) return false;   // (a call's result arrives in a VGPR)
-    // the code lengths themselves: sequential; every lane decodes, lane 0 stores
-    int i = 0;
+    // the code lengths themselves, as the block loop decodes its symbols: the 64 lanes decode a code-length symbol (with its
+    // extra bits: at most 14 bits) at 64 bit positions, the wave follows the chain from bp and hands every item on it
+    // its value ("repeat the previous length" resolved on the way) and its place; the lanes then store their runs.
+    // [One symbol at a time was ~300 cycles x 300 symbols for each of the ~80 candidates a chunk's sync search tries.]
     __shared__ uint8_t s_all[320];
-    while (i < hlit + hdist) {
-        sb_need(S, b, 22);
-        const int s = huff_decode(S.clc, b);
-        if (s < 0 || sb_past_end(b)) return false;
-        int rep = 1, val = s;
-        if (s == 16) { if (i == 0) return false; val = __builtin_amdgcn_readfirstlane((int)s_all[i - 1]); rep = 3 + (int)sb_get(S, b, 2); }
-        else if (s == 17) { val = 0; rep = 3 + (int)sb_get(S, b, 3); }
-        else if (s == 18) { val = 0; rep = 11 + (int)sb_get(S, b, 7); }
-        if (i + rep > hlit + hdist) return false;
-        __syncthreads();
-        for (int r = threadIdx.x & 63; r < rep; r += 64) s_all[i + r] = (uint8_t)val;
-        __syncthreads();
-        i += rep;
+    const int total = hlit + hdist, lane = threadIdx.x & 63;
+    int i = 0, prev = -1;
+    while (i < total) {
+        sb_stage(S, b);
+        const uint64_t p = b.bp + (uint64_t)lane;
+        const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+        const uint32_t d0 = S.stage[w & 511], d1 = S.stage[(w + 1) & 511];
+        const uint32_t bits = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
+        const uint32_t e = S.clc.tent[bits & 127u];
+        const uint32_t l = e >> 9, sy = e & 511u;
+        const uint32_t xb = sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u;
+        const uint32_t x = (bits >> l) & ((1u << xb) - 1u);
+        const uint32_t rep = sy < 16 ? 1u : sy == 18 ? 11u + x : 3u + x;
+        const uint32_t pk = e ? ((l + xb) | (rep << 4) | ((sy < 16 ? sy : sy == 16 ? 16u : 0u) << 12)) : 0u;      // bits | run | value (16 = copy)
+        // the chain from bp (an undecodable position steps out of the window), then by prefix sum and ballots: which of
+        // its items still belong to the lengths, where their runs go, and what "copy" copies
+        const uint32_t step = (pk & 15u) ? (pk & 15u) : 64u;
+        uint64_t chain = 0;
+        uint32_t pos = 0;
+        do {
+            chain |= 1ull << pos;
+            pos += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)pos);
+        } while (pos < 64);
+        const bool on = (chain >> lane) & 1ull;
+        const uint32_t incl = wave_inclusive_sum(on ? rep : 0u), before = incl - (on ? rep : 0u);
+        const uint32_t left = (uint32_t)(total - i);
+        const bool used = on && before < left;
+        const uint64_t usedm = __ballot(used);                                   // lane 0 is in it
+        const int lu = 63 - __clzll((long long)usedm);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)incl, lu);
+        if (__ballot(used && (pk & 15u) == 0) || end > left) return false;      // undecodable, or a run beyond the last length
+        const uint32_t vc = pk >> 12;
+        const uint64_t sources = __ballot(used && vc != 16u) & ((lane == 63 ? 0ull : (~0ull << (lane + 1))) ^ ~0ull);   // at or below this lane
+        const int src = sources ? 63 - __clzll((long long)sources) : -1;
+        const int got = __shfl((int)vc, src < 0 ? 0 : src, 64);
+        const int val = src < 0 ? prev : got;
+        if (__ballot(used && val < 0)) return false;                             // "repeat the previous length" with none before
+        if (used)
+            for (uint32_t r = 0; r < rep; r++) s_all[i + (int)before + (int)r] = (uint8_t)val;
+        prev = __builtin_amdgcn_readlane(val, lu);
+        i += (int)end;
+        sb_seek(b, b.bp + (uint32_t)lu + (uint32_t)__builtin_amdgcn_readlane((int)step, lu));
+        if (sb_past_end(b)) return false;
     }
+    __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)s_all[256]) == 0) return false;
     for (int k = threadIdx.x & 63; k < hlit + hdist; k += 64) S.lens[k] = s_all[k];
     __syncthreads();
@@ -374,23 +427,6 @@ __device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint
             S.ring[(n32 + i) & (RING - 1)] = v;
         }
     }
-}
-
-// inclusive prefix sum over the 64 lanes in six DPP additions (row shifts 1, 2, 4, 8, then the row broadcasts of gfx9)
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
-{
-#ifdef SS_GZ_SCAN_SHFL
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)v, d, 64); if ((int)(threadIdx.x & 63) >= d) v += u; }
-    return v;
-#endif
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-    return (uint32_t)x;
 }
 
 // One block from the current position.  0 = block done, 1 = final block done, 2 = probe satisfied, < 0 = error.
@@ -617,9 +653,12 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
     uint64_t found = ~0ull;
     SBits b;
     sb_init(b, in, in_n, lo);
+    uint4 ahead = header_bytes(in, lo + lane);             // the next 64 positions' bytes are loaded while these are tested
     for (uint64_t p0 = lo; p0 < hi && found == ~0ull; p0 += 64) {
         const uint64_t p = p0 + lane;
-        const bool ok = p < hi && header_prefilter(in, p);
+        const uint4 bytes = ahead;
+        ahead = header_bytes(in, p + 64);                  // (the input is padded by 8 KB)
+        const bool ok = p < hi && header_prefilter(bytes, p);
         uint64_t m = __ballot(ok);
         while (m && found == ~0ull) {
             const int l = __ffsll((long long)m) - 1;
