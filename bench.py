@@ -218,14 +218,67 @@ def write_tree_files(db_spec, C, tdir):
             f.write("%d\t1\tstrain_%d\n" % (leaf, leaf))
 
 
-def write_fastq(reads_dev, n_reads, path):
+def write_fastq(reads_dev, n_reads, path, noisy_quality_seed=None):
+    """Four-line FASTQ of the block's reads; quality 'I' throughout, or (for the .gz leg, where the quality line is
+    half of what the inflater decodes) Phred values that fall off along the read with per-base noise."""
     reads = reads_dev.view(n_reads, READ_LEN + 1)[:, :READ_LEN].cpu().numpy()
     rec = np.empty((n_reads, 2 * READ_LEN + 7), np.uint8)
     rec[:, 0:2] = np.frombuffer(b"@r", np.uint8); rec[:, 2] = 10
     rec[:, 3:3 + READ_LEN] = reads
     rec[:, 3 + READ_LEN] = 10; rec[:, 4 + READ_LEN] = ord("+"); rec[:, 5 + READ_LEN] = 10
-    rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I"); rec[:, 6 + 2 * READ_LEN] = 10
+    if noisy_quality_seed is None:
+        rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = ord("I")
+    else:
+        rs = np.random.RandomState(noisy_quality_seed)
+        q = 38 - np.abs(rs.normal(0, 4, size=(n_reads, READ_LEN))).astype(np.int64) - (np.arange(READ_LEN) // 30)
+        rec[:, 6 + READ_LEN:6 + 2 * READ_LEN] = (np.clip(q, 2, 40) + 33).astype(np.uint8)
+    rec[:, 6 + 2 * READ_LEN] = 10
     rec.tofile(path)
+
+
+def measure_gz_ingest(reads, n_pair, base):
+    """A pair of .fastq.gz files (gzip -6, n_pair reads each) -> resident read set, with the device path (inflate +
+    FASTQ extraction on the GPU, the default) and with the host inflaters (SS_GZ_GPU=0).  Outside the timed region."""
+    import subprocess
+    from strainscan_amd import _lib
+    paths = []
+    for f in range(2):
+        p = os.path.join(base, "gz_%d.fq" % (f + 1))
+        write_fastq(reads[f * n_pair * (READ_LEN + 1): (f + 1) * n_pair * (READ_LEN + 1)], n_pair, p, noisy_quality_seed=77 + f)
+        paths.append(p)
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(["gzip", "-6", "-f", p]) for p in paths]
+    if any(pr.wait() != 0 for pr in procs):
+        return None
+    gz = [p + ".gz" for p in paths]
+    out = dict(reads=2 * n_pair, files=2, gz_mb=round(sum(os.path.getsize(p) for p in gz) / 1e6, 1), gzip_level=6,
+               compress_s=round(time.perf_counter() - t0, 1), host_threads=len(os.sched_getaffinity(0)))
+    prev = os.environ.get("SS_GZ_GPU")
+    try:
+        for mode, key in (("1", "device_ms"), ("0", "host_inflaters_ms")):
+            os.environ["SS_GZ_GPU"] = mode
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rs = _lib.ReadSet(gz)
+                _lib.check(_lib.lib().ss_device_sync(), "sync")
+                dt = time.perf_counter() - t0
+                n_rec = rs.info()["n_records"]
+                rs.close()
+                if n_rec != 2 * n_pair:
+                    return None
+                best = dt if best is None else min(best, dt)
+            out[key] = round(best * 1e3, 1)
+    finally:
+        if prev is None:
+            os.environ.pop("SS_GZ_GPU", None)
+        else:
+            os.environ["SS_GZ_GPU"] = prev
+    out["m_reads_per_s_device"] = round(2 * n_pair / out["device_ms"] / 1e3, 1)
+    out["m_reads_per_s_host_inflaters"] = round(2 * n_pair / out["host_inflaters_ms"] / 1e3, 1)
+    out["note"] = ("file -> resident flat blocks, best of 3, page cache warm; device = ss_ginflate.hip + ss_fastq_dev.hip (the "
+                   "default), host = the threaded two-pass inflater on this box's CPUs + parse threads")
+    return out
 
 
 class _StatsProvider:
@@ -290,6 +343,8 @@ def measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, 
                   clusters_found=len(res),
                   e2e_reads_per_s=round(n_s / (ingest_s + dev_ms * 1e-3 + walk_s), 1),
                   e2e_note="sample_reads / (text -> HBM + device phases scaled to the sample + host walk), one GPU, page cache warm")
+        if args.gz_reads > 0:
+            ph["gz_ingest"] = measure_gz_ingest(reads, int(min(args.gz_reads, n_s) // 2), base)
     finally:
         shutil.rmtree(base, ignore_errors=True)
     return ph
@@ -312,6 +367,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-phases", action="store_true", help="skip the untimed phase breakdown (text -> HBM, walk)")
     ap.add_argument("--no-readset", action="store_true", help="skip the extra measurement over the product's resident read set")
     ap.add_argument("--phase-reads", type=int, default=4_000_000, help="reads of the FASTQ sample written for the phase breakdown")
+    ap.add_argument("--gz-reads", type=int, default=1_000_000, help="reads of the .fastq.gz pair of the phase breakdown (0 = skip)")
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
     return ap.parse_args(argv)

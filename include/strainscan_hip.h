@@ -81,8 +81,9 @@ int ss_gz_inflate_to_file(const char *path, const char *out_path, int threads, u
  * text verified against CRC-32 and ISIZE of the trailer); *text is a host buffer released with ss_gz_free.  SS_ERANGE:
  * not handled on the device (several members, a damaged file, ...): use ss_gz_inflate. */
 int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len);
-/* Members the device inflater has produced / has declined in this process (SS_GZ_GPU=1 routes the .gz inputs of
- * ss_scan_files and ss_reads_load through it first; what it declines goes to the host inflaters as before). */
+/* Members the device inflater has produced / has declined in this process.  Unless SS_GZ_GPU=0, the .gz inputs of
+ * ss_scan_files and ss_reads_load (one rank, files of 1 MB and more) go through it first and strict four-line FASTQ is
+ * reduced to its sequence lines on the device too (ss_fastq_dev.hip); what it declines goes to the host inflaters. */
 int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23

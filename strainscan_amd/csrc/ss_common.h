@@ -171,7 +171,7 @@ uint64_t inflate_budget_bytes();
 hipStream_t ingest_stream(unsigned i);   // a few process-wide non-blocking streams (creating one costs ~13 ms)
 void free_later(char *p);
 std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_paths);
-// SS_GZ_GPU=1: .gz inputs are inflated on the device (ss_ginflate.hip) and strict four-line FASTQ is turned into the flat
+// unless SS_GZ_GPU=0: .gz inputs are inflated on the device (ss_ginflate.hip) and strict four-line FASTQ is turned into the flat
 // base block there (ss_fastq_dev.hip)
 bool gz_on_gpu();
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len);

@@ -113,10 +113,12 @@ __global__ void fq_pad_kernel(char *dst, uint64_t from, uint64_t to)
 
 namespace ss {
 
+// on unless SS_GZ_GPU=0 (the host inflaters of ss_pgz.hip / libdeflate / zlib then take every .gz input, as they take what
+// the device path declines)
 bool gz_on_gpu()
 {
     const char *e = getenv("SS_GZ_GPU");
-    return e && *e && strcmp(e, "0") != 0;
+    return !e || strcmp(e, "0") != 0;
 }
 
 // FASTQ text on the device -> a new device buffer with the flat base block (padded like a block of ss_reads: at least one
@@ -207,7 +209,8 @@ int gz_fastq_to_flat_dev(const char *path, char **d_flat, uint64_t *flat_len, ui
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return 1;
     struct stat sb;
-    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 20) { close(fd); return 1; }
+    // (a small file is inflated on the host before the device path has allocated its buffers)
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < (1 << 20)) { close(fd); return 1; }
     const uint64_t in_n = (uint64_t)sb.st_size;
     const uint8_t *in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);

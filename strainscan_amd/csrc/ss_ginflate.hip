@@ -363,7 +363,7 @@ __device__ void fixed_codes(WaveState &S)
 #ifdef SS_GZ_TIMING
 // diagnostic build: cycles per section, summed over the waves (0 decode, 1 chain, 2 deliver, 3 flush, 4 header, 5 windows)
 __device__ unsigned long long g_gz_t[12];
-#define GZ_T(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t var = clock64()
+#define GZ_T(var) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const uint64_t var = clock64()
 #define GZ_ACC(i, a, b) (o.t[i] += (b) - (a))
 #else
 #define GZ_T(var)
@@ -413,10 +413,11 @@ __device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint
 {
     const int lane = threadIdx.x & 63;
     const uint32_t n32 = (uint32_t)n;                  // a chunk's output is far below 2^31 symbols
+    const bool overlaps = dist < len;                  // (uniform: the division below is rarely reached)
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         if (i < len) {
-            const uint32_t k = dist >= len ? i : i % dist;          // a match that overlaps itself repeats with period dist
+            const uint32_t k = overlaps ? i % dist : i;             // a match that overlaps itself repeats with period dist
             const int32_t sp = (int32_t)(n32 - dist + k);
             uint16_t v;
             if (sp < 0) v = (uint16_t)(UNRES | (uint32_t)((int32_t)WSIZE + sp));

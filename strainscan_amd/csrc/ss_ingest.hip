@@ -614,7 +614,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     // goes through the sequential reader -- one thread PER FILE, so the two mates of a paired
     // .fastq.gz sample inflate concurrently (zlib is the limiter there)
     std::vector<int> seq_files;
-    // SS_GZ_GPU=1, one rank: .gz inputs are inflated AND reduced to their sequence lines on the device; the block becomes a
+    // one rank (and not SS_GZ_GPU=0): .gz inputs are inflated AND reduced to their sequence lines on the device; the block becomes a
     // slab as it is.  What that path only inflated (not strict four-line FASTQ) arrives as text, the rest goes on below.
     std::vector<ss::InflatedText> texts;
     std::vector<char> on_device;

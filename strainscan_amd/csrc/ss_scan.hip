@@ -450,7 +450,7 @@ int ss_scan_files_shard(ss_db *db, const char *const *paths, int n_paths, int sh
     std::vector<char> on_device((size_t)n_paths, 0);
     int rc = SS_OK;
     if (allow_parallel) {
-        // SS_GZ_GPU=1, one rank: inflated and reduced to the sequence lines on the device (ss_ginflate.hip, ss_fastq_dev.hip),
+        // one rank (and not SS_GZ_GPU=0): inflated and reduced to the sequence lines on the device (ss_ginflate.hip, ss_fastq_dev.hip),
         // scanned from there
         std::vector<const char *> rest(paths, paths + n_paths);
         if (shard_world == 1) {

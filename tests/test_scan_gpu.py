@@ -491,11 +491,14 @@ def test_node_reduce_synthetic_counts(L):
 
 
 @pytest.mark.gpu
-def test_gz_whole_file_inflate(L, tmp_path):
-    """.gz inputs large enough for the chunked parser (>= 4 MB of text) are inflated whole (libdeflate) and
-    parsed like plain text: single-member, multi-member (two concatenated gzip streams) and a pair of files,
-    through ss_scan_files and through the resident read set, count exactly like the plain files."""
+@pytest.mark.parametrize("gz_on_device", ["0", "1"])
+def test_gz_whole_file_inflate(L, tmp_path, monkeypatch, gz_on_device):
+    """.gz inputs large enough for the chunked parser (>= 4 MB of text) are inflated whole -- on the host (the
+    threaded inflater, libdeflate: SS_GZ_GPU=0) or on the device (the default; what it declines, the two-member file
+    here, goes to the host) -- and parsed like plain text: single-member, multi-member (two concatenated gzip streams)
+    and a pair of files, through ss_scan_files and through the resident read set, count exactly like the plain files."""
     import gzip
+    monkeypatch.setenv("SS_GZ_GPU", gz_on_device)
     kfa, flat = _random_db_and_reads(77, 80000, 100000)
     recs = [r for r in flat.split(b"\n") if r]
     fq = b"".join(b"@r%d\n" % i + r + b"\n+\n" + bytes(33 + (i * 7 + j) % 40 for j in range(len(r))) + b"\n"
