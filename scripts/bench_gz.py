@@ -30,18 +30,22 @@ def main():
     out = dict(n_reads=n_reads)
     try:
         db.reset(); db.scan_files(fq); want = db.counts_rows().copy()
-        t0 = time.perf_counter(); subprocess.check_call(["gzip", "-k", "-1", fq[0]]); subprocess.check_call(["gzip", "-k", "-1", fq[1]])
+        t0 = time.perf_counter(); lvl = sys.argv[2] if len(sys.argv) > 2 else "-1"; pr = [subprocess.Popen(["gzip", "-k", lvl, p]) for p in fq]; [q.wait() for q in pr]
         out["gzip_s"] = round(time.perf_counter() - t0, 1)
         gz = [p + ".gz" for p in fq]
         out["gz_bytes"] = sum(os.path.getsize(p) for p in gz)
         out["text_bytes"] = sum(os.path.getsize(p) for p in fq)
         t0 = time.perf_counter(); subprocess.check_call("zcat %s > /dev/null" % gz[0], shell=True); out["zcat_one_file_s"] = round(time.perf_counter() - t0, 2)
-        for name in ("scan_files_gz", "scan_files_gz2"):
-            db.reset(); t0 = time.perf_counter(); db.scan_files(gz); t1 = time.perf_counter()
-            out[name] = dict(s=round(t1 - t0, 3), m_reads_per_s=round(n_reads / (t1 - t0) / 1e6, 2), same=bool(np.array_equal(db.counts_rows(), want)))
-        t0 = time.perf_counter(); rs_ = _lib.ReadSet(gz, 0, 1); t1 = time.perf_counter()
-        db.reset(); rs_.scan_into(db); torch.cuda.synchronize()
-        out["readset_gz"] = dict(load_s=round(t1 - t0, 3), m_reads_per_s=round(n_reads / (t1 - t0) / 1e6, 2), same=bool(np.array_equal(db.counts_rows(), want)))
+        for mode, tag in (("0", "host_inflaters"), ("1", "device")):          # SS_GZ_GPU: ss_pgz.hip on the CPUs / ss_ginflate.hip + ss_fastq_dev.hip
+            os.environ["SS_GZ_GPU"] = mode
+            for name in ("scan_files_gz", "scan_files_gz2"):
+                db.reset(); t0 = time.perf_counter(); db.scan_files(gz); t1 = time.perf_counter()
+                out[tag + ":" + name] = dict(s=round(t1 - t0, 3), m_reads_per_s=round(n_reads / (t1 - t0) / 1e6, 2), same=bool(np.array_equal(db.counts_rows(), want)))
+            for name in ("readset_gz", "readset_gz2"):
+                t0 = time.perf_counter(); rs_ = _lib.ReadSet(gz, 0, 1); t1 = time.perf_counter()
+                db.reset(); rs_.scan_into(db); torch.cuda.synchronize()
+                out[tag + ":" + name] = dict(load_s=round(t1 - t0, 3), m_reads_per_s=round(n_reads / (t1 - t0) / 1e6, 2), same=bool(np.array_equal(db.counts_rows(), want)))
+                rs_.close()
     finally:
         for p in fq:
             for q in (p, p + ".gz"):

@@ -443,7 +443,7 @@ __device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint
 constexpr uint32_t F_MATCH = 64u, F_EOB = 128u, F_BAD = 256u;
 constexpr uint32_t FAR_MAX = 12;            // longest match of the batched kind (one 2-byte load per symbol and lane)
 constexpr uint32_t WIN_MAX = RING - RING_REACH;      // 264: a window that delivers more goes item by item (ring aliasing)
-__device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_window, uint64_t probe_symbols = ~0ull)
+__device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_window, uint64_t probe_symbols = ~0ull, uint64_t stop_bits = ~0ull)
 {
     const int lane = threadIdx.x & 63;
     const bool store = o.out != nullptr;
@@ -513,6 +513,7 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         if (store && n - o.flushed >= 1024) { GI_FINISH(); out_flush(S, o, n); }
         if (n >= probe_end) GI_OUT(2);                     // sync search: the header was valid and this many symbols decoded
         if (b.bp > end_bits) GI_OUT(-5);
+        if (b.bp > stop_bits) GI_OUT(-21);                 // ran past the next chunk's entry: that entry was not a block's start
         GZ_T(tw0);
         sb_stage(S, b);
         // ---- every lane: the item at bp + lane
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
     const uint64_t stop_at = stop[c];
     int st = 0;
     for (;;) {
-        const int r = inflate_block(S, b, o, c == 0);
+        const int r = inflate_block(S, b, o, c == 0, ~0ull, stop_at);
         if (r < 0) { st = r; break; }
         const uint64_t pos = sb_bitpos(b);
         if (r == 1) { st = (stop_at == ~0ull) ? 1 : -20; break; }      // the final block ends the LAST chunk only
@@ -980,28 +981,34 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         hipMemcpyToSymbol(HIP_SYMBOL(g_sync_tries), &tries, 4);
     }
     lap("sync");
+    if (const char *e = getenv("SS_GZ_INJECT_ENTRY")) {      // test hook: a wrong entry (a position inside a block) in chunk <n>
+        const uint64_t c = (uint64_t)atoll(e);
+        if (c > 0 && c < n_chunks0) entry[c] = (data_off + c * chunk_bytes) * 8 + 12345 % (chunk_bytes * 8);
+    }
     // chunks with an entry; a chunk without one belongs to its predecessor
     std::vector<uint64_t> start, stop, off, cap;
     for (uint32_t c = 0; c < n_chunks0; c++)
         if (entry[c] != ~0ull) start.push_back(entry[c]);
-    const uint32_t nc = (uint32_t)start.size();
+    uint32_t nc = (uint32_t)start.size();
+    const uint32_t nc_alloc = nc;
     uint64_t sym_total = 0;
-    for (uint32_t c = 0; c < nc; c++) {
-        stop.push_back(c + 1 < nc ? start[c + 1] : ~0ull);
-        const uint64_t cbits = (c + 1 < nc ? start[c + 1] : (in_n - 8) * 8) - start[c];
-        const uint64_t cp = (cbits / 8 + 1) * ratio + 4096;
-        off.push_back(sym_total);
-        cap.push_back(cp);
-        sym_total += cp;
-    }
-    // meta: start, stop, off, cap, out_len, end_bit, text_off
-    GI(hipMallocAsync((void **)&d_meta, (uint64_t)nc * 8 * 7, st));
-    uint64_t *d_start = d_meta, *d_stop = d_meta + nc, *d_off = d_meta + 2ull * nc, *d_cap = d_meta + 3ull * nc, *d_len = d_meta + 4ull * nc,
-             *d_end = d_meta + 5ull * nc, *d_toff = d_meta + 6ull * nc;
-    GI(h2d(d_start, start.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-    GI(h2d(d_stop, stop.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-    GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-    GI(h2d(d_cap, cap.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+    auto lay_out = [&] {
+        stop.clear(); off.clear(); cap.clear();
+        sym_total = 0;
+        for (uint32_t c = 0; c < nc; c++) {
+            stop.push_back(c + 1 < nc ? start[c + 1] : ~0ull);
+            const uint64_t cbits = (c + 1 < nc ? start[c + 1] : (in_n - 8) * 8) - start[c];
+            const uint64_t cp = (cbits / 8 + 1) * ratio + 4096;
+            off.push_back(sym_total);
+            cap.push_back(cp);
+            sym_total += cp;
+        }
+    };
+    lay_out();
+    // meta: start, stop, off, cap, out_len, end_bit, text_off (laid out for the first chunk list; a shorter one fits)
+    GI(hipMallocAsync((void **)&d_meta, (uint64_t)nc_alloc * 8 * 7, st));
+    uint64_t *d_start = d_meta, *d_stop = d_meta + nc_alloc, *d_off = d_meta + 2ull * nc_alloc, *d_cap = d_meta + 3ull * nc_alloc,
+             *d_len = d_meta + 4ull * nc_alloc, *d_end = d_meta + 5ull * nc_alloc, *d_toff = d_meta + 6ull * nc_alloc;
     {
         // symbols (2 B each, `ratio` per input byte), windows and maps (5 x 32 KB per chunk) and the text must fit
         size_t mem_free = 0, mem_total = 0;
@@ -1012,33 +1019,58 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(hipMallocAsync((void **)&d_sym, sym_total * 2, st));
     GI(hipMallocAsync((void **)&d_status, (uint64_t)nc * 4, st));
     lap("symbol buffers");
-    if (getenv("SS_GZ_COUNTONLY")) {         // timing experiment: the decode without any output
-        hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status);
-        lap("inflate (count only)");
-    }
-    hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status);
-    std::vector<int> status(nc);
-    std::vector<uint64_t> out_len(nc), end_bit(nc), text_off(nc);
-    GI(d2h(status.data(), d_status, (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
-    GI(d2h(out_len.data(), d_len, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-    GI(d2h(end_bit.data(), d_end, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-    lap("inflate");
-#ifdef SS_GZ_TIMING
-    {
-        unsigned long long t[12], z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gz_t), sizeof t);
-        hipMemcpyToSymbol(HIP_SYMBOL(g_gz_t), z, sizeof z);
-        fprintf(stderr, "[ginflate] per wave (cycles): total %.0f = decode %.0f + chain %.0f + deliver %.0f (flush %.0f inside) + header %.0f; windows %.0f; waves %llu\n",
-                (double)t[10] / t[11], (double)t[0] / t[11], (double)t[1] / t[11], (double)t[2] / t[11], (double)t[3] / t[11], (double)t[4] / t[11], (double)t[5] / t[11], t[11]);
-        fprintf(stderr, "[ginflate] matches %llu (symbols %llu), beyond the ring %llu, into the unknown window %llu; windows %llu\n", t[6], t[7], t[8], t[9], t[5]);
-    }
-#endif
+    std::vector<int> status;
+    std::vector<uint64_t> out_len, end_bit, text_off;
     uint64_t total = 0;
-    for (uint32_t c = 0; c < nc; c++) {
-        if (status[c] != (c + 1 == nc ? 1 : 0)) { cleanup(false); return no("chunk status", status[c] * 1000000ll + c); }
-        text_off[c] = total;
-        total += out_len[c];
+    // An entry is a position where a valid dynamic header parses and SS_GZ_PROBE symbols decode -- a position INSIDE a
+    // block passes that about once in a million candidates (every bit string decodes under a complete code).  It shows
+    // here: the chunk in front of it runs past it.  The entry is dropped and the chunks are inflated again (the chunk
+    // list only ever shrinks; chunk 0 starts at the member's first block, so what ends exactly on the next entry is right).
+    for (int attempt = 0;; attempt++) {
+        GI(h2d(d_start, start.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        GI(h2d(d_stop, stop.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        GI(h2d(d_cap, cap.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        if (getenv("SS_GZ_COUNTONLY")) {         // timing experiment: the decode without any output
+            hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status);
+            lap("inflate (count only)");
+        }
+        hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status);
+        status.assign(nc, 0);
+        out_len.assign(nc, 0); end_bit.assign(nc, 0); text_off.assign(nc, 0);
+        GI(d2h(status.data(), d_status, (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
+        GI(d2h(out_len.data(), d_len, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        GI(d2h(end_bit.data(), d_end, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        lap("inflate");
+#ifdef SS_GZ_TIMING
+        {
+            unsigned long long t[12], z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gz_t), sizeof t);
+            hipMemcpyToSymbol(HIP_SYMBOL(g_gz_t), z, sizeof z);
+            fprintf(stderr, "[ginflate] per wave (cycles): total %.0f = decode %.0f + chain %.0f + deliver %.0f (flush %.0f inside) + header %.0f; windows %.0f; waves %llu\n",
+                    (double)t[10] / t[11], (double)t[0] / t[11], (double)t[1] / t[11], (double)t[2] / t[11], (double)t[3] / t[11], (double)t[4] / t[11], (double)t[5] / t[11], t[11]);
+            fprintf(stderr, "[ginflate] matches %llu (symbols %llu), beyond the ring %llu, into the unknown window %llu; windows %llu\n", t[6], t[7], t[8], t[9], t[5]);
+        }
+#endif
+        std::vector<char> drop(nc, 0);
+        uint32_t n_drop = 0;
+        bool bad = false;
+        for (uint32_t c = 0; c < nc && !bad; c++) {
+            if (drop[c]) continue;                                     // its own outcome means nothing
+            if (status[c] == (c + 1 == nc ? 1 : 0)) continue;
+            // ran past the next entry (-21), or met the final block before it (-20: the entry lies behind the stream's end)
+            if ((status[c] == -21 || status[c] == -20) && c + 1 < nc && attempt < 4) { drop[c + 1] = 1; n_drop++; }
+            else { bad = true; cleanup(false); return no("chunk status", status[c] * 1000000ll + c); }
+        }
+        if (!n_drop) break;
+        if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block: dropped, chunks inflated again\n", n_drop);
+        std::vector<uint64_t> kept;
+        for (uint32_t c = 0; c < nc; c++) if (!drop[c]) kept.push_back(start[c]);
+        start.swap(kept);
+        nc = (uint32_t)start.size();
+        lay_out();
     }
+    for (uint32_t c = 0; c < nc; c++) { text_off[c] = total; total += out_len[c]; }
     // the stream must end where the trailer begins (after padding to a byte)
     if ((end_bit[nc - 1] + 7) / 8 != in_n - 8) { cleanup(false); return no("stream end", (long long)((end_bit[nc - 1] + 7) / 8)); }
     if ((uint32_t)total != want_isize) { cleanup(false); return no("isize"); }

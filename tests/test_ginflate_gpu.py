@@ -265,3 +265,17 @@ def test_device_fastq_extraction_equals_the_host_grammar(L, tmp_path, monkeypatc
             assert _counters(L) == (h0, d0)
     assert got["1"][0] == got["0"][0] == want, case
     assert got["1"][1] == got["0"][1] == want_n, case
+
+
+def test_a_wrong_entry_point_is_dropped_and_the_chunks_inflated_again(L, tmp_path, monkeypatch, fastq_text):
+    """The sync search accepts a position where a valid dynamic header parses and a few hundred symbols decode; about
+    one candidate in a million that passes lies INSIDE a block (seen on a 264 MB file).  The chunk in front of such an
+    entry runs past it; the entry is dropped and the chunks are inflated again.  SS_GZ_INJECT_ENTRY plants a wrong
+    entry: same text, still verified by CRC-32 and ISIZE."""
+    p = tmp_path / "a.fq.gz"
+    p.write_bytes(gzip.compress(fastq_text, 6))
+    for chunk in ("3", "17", "40"):
+        monkeypatch.setenv("SS_GZ_INJECT_ENTRY", chunk)
+        rc, got = _gpu_inflate(L, p)
+        assert rc == SS_OK, chunk
+        assert got == fastq_text, chunk
