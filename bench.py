@@ -252,7 +252,7 @@ def measure_gz_ingest(reads, n_pair, base):
         return None
     gz = [p + ".gz" for p in paths]
     out = dict(reads=2 * n_pair, files=2, gz_mb=round(sum(os.path.getsize(p) for p in gz) / 1e6, 1), gzip_level=6,
-               compress_s=round(time.perf_counter() - t0, 1), host_threads=len(os.sched_getaffinity(0)))
+               compress_s=round(time.perf_counter() - t0, 1), host_cpus=int(_lib.lib().ss_host_cpus()))
     prev = os.environ.get("SS_GZ_GPU")
     try:
         for mode, key in (("1", "device_ms"), ("0", "host_inflaters_ms")):
