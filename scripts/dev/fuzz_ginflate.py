@@ -65,8 +65,12 @@ while time.time() < t_end:
     level = int(rs.choice([1, 2, 4, 6, 9]))
     strat = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rs.randint(0, 6))]
     mem = int(rs.choice([8, 9, 4, 1]))
-    co = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strat)
-    gz = co.compress(txt) + co.flush()
+    n_members = int(rs.choice([1, 1, 1, 2, 3, 5]))                       # lanes joined with cat
+    cuts = sorted(int(x) for x in rs.randint(0, len(txt) + 1, n_members - 1))
+    gz = b""
+    for a, b in zip([0] + cuts, cuts + [len(txt)]):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strat)
+        gz += co.compress(txt[a:b]) + co.flush()
     p = "/tmp/fuzz_gi_%d.gz" % os.getpid()
     open(p, "wb").write(gz)
     os.environ["SS_GZ_CHUNK"] = str(int(rs.choice([4096, 8192, 16384, 32768, 65536])))

@@ -1,24 +1,28 @@
-// ss_ginflate.hip -- one gzip member inflated by thousands of waves on the GPU.
+// ss_ginflate.hip -- a gzip file inflated by thousands of waves on the GPU.
 //
 // The reference pipes `zcat` into jellyfish (library/identify.py:81-84).  ss_pgz.hip restates the two-pass scheme of
-// Kerbiriou & Chikhi (pugz, 2019) on host threads; on a box whose cgroup grants 16 CPUs that is 11 M reads/s, twenty
+// Kerbiriou & Chikhi (pugz, 2019) on host threads; on a box whose cgroup grants 16 CPUs that is 11-14 M reads/s, twenty
 // times slower than plain text reaches HBM.  The same scheme on the device:
 //   A  sync     the deflate data is cut into chunks of SS_GZ_CHUNK bytes.  Every wave searches its chunk for a block
 //               entry: the 64 lanes test 64 consecutive bit positions at a time with a register-only header check
-//               (non-final dynamic block, complete code-length code, valid run lengths, complete literal/length
-//               and distance codes, end-of-block present); a candidate is confirmed by decoding that whole block
-//               (count only) and finding a plausible block header behind it.
-//   B  inflate  every wave decodes from its entry to the next chunk's entry, WAVE-UNIFORMLY: all lanes follow the same
-//               bit stream (Huffman tables in LDS, compressed bytes staged through LDS), lane 0 stores literals, the
-//               64 lanes copy matches together.  What lies in the 32 KB in front of the chunk is unknown: the output
-//               is 16-bit symbols, a byte or "byte w of the window" (a copy of a copy keeps the index).  The last 4096
-//               symbols are mirrored in an LDS ring so that a match never waits for the wave's own global stores.
+//               (non-final dynamic block, complete code-length code); a survivor's header is parsed by the whole wave
+//               (code lengths decoded lane-parallel, canonical codes built with ballots: the Kraft sums reject it
+//               before a table is written) and SS_GZ_PROBE symbols are decoded.
+//   B  inflate  every wave decodes from its entry to the next chunk's entry.  The 64 lanes decode whole items (literal,
+//               or length + distance with their extra bits) SPECULATIVELY at 64 consecutive bit positions of the
+//               LDS-staged input; the wave follows the chain of item lengths (readlane), a prefix sum places the items.
+//               What lies in the 32 KB in front of the chunk is unknown: the output is 16-bit symbols, a byte or "byte
+//               w of the window" (a copy of a copy keeps the index).  The last 2048 symbols are mirrored in an LDS
+//               ring; matches that reach further back read the wave's own output from global memory, all such
+//               matches of a window together and while the next window is decoded.
 //   C  windows  the last 32 KB of every chunk as a map "my window -> the next chunk's window", composed in two levels;
 //   D  bytes    all symbols -> bytes in parallel; CRC-32 of the text by segments (combined on the host).
-// Accepted only if every chunk ended exactly on the next one's entry, the stream ended at the member's trailer and
-// CRC-32 and ISIZE match; anything else (several members, a chunk that expands more than SS_GZ_RATIO times, a damaged
-// file) returns "not handled" and the caller inflates on the host (ss_pgz.hip, libdeflate, zlib), so a wrong text cannot
-// get through.
+// Accepted only if every chunk ended exactly on the next one's entry, the stream ended at the file's last trailer and
+// CRC-32 and ISIZE of EVERY member match (lanes joined with `cat` are found member by member: the chunk that meets a
+// final block finds trailer and header behind it).  A wrong entry (a position inside a block that passed A) shows as the
+// chunk before it running past it and is dropped.  Anything else (bgzip's thousands of small members, a chunk that
+// expands more than SS_GZ_RATIO times, a damaged file) returns "not handled" and the caller inflates on the host
+// (ss_pgz.hip, libdeflate, zlib), so a wrong text cannot get through.
 #include "ss_common.h"
 
 #include <fcntl.h>
@@ -89,7 +93,7 @@ __device__ __forceinline__ bool header_prefilter(const uint4 v, uint64_t p)
     return kraft == 128u;
 }
 
-// ---- wave-uniform decoder: tables and staging in LDS -------------------------------------------------------------
+// ---- per-wave decoder state: tables, ring and staging in LDS -------------------------------------------------------------
 template <int PB, int MAXSYM>
 struct LHuff {
     uint16_t tent[1 << PB];          // symbol | code length << 9 for every PB-bit pattern; 0 = code longer than PB bits
@@ -694,12 +698,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
     const uint64_t t_wave0 = clock64();
 #endif
     SBits b;
-    sb_init(b, in, in_n, start[c]);
+    const uint64_t s0 = start[c];
+    const bool fresh = (s0 >> 63) != 0;                     // the first chunk of a member: nothing lies in front of it
+    sb_init(b, in, in_n, s0 & ~(1ull << 63));
     OutState o{sym ? sym + sym_off[c] : nullptr, sym_cap[c], 0, 0};
     const uint64_t stop_at = stop[c];
     int st = 0;
     for (;;) {
-        const int r = inflate_block(S, b, o, c == 0, ~0ull, stop_at);
+        const int r = inflate_block(S, b, o, fresh, ~0ull, stop_at);
         if (r < 0) { st = r; break; }
         const uint64_t pos = sb_bitpos(b);
         if (r == 1) { st = (stop_at == ~0ull) ? 1 : -20; break; }      // the final block ends the LAST chunk only
@@ -847,19 +853,21 @@ __global__ __launch_bounds__(256) void bytes_kernel(const uint16_t *sym, const u
     }
 }
 
-// CRC-32 (zlib's polynomial) of segment s of the text, one lane per segment, byte-wise table in LDS
-__global__ __launch_bounds__(64) void crc_kernel(const uint8_t *text, uint64_t n, uint64_t seg, const uint32_t *table, uint32_t *crc)
+// CRC-32 (zlib's polynomial) of the text's segments [seg_at[s], seg_at[s] + seg_len[s]), one lane per segment, byte-wise
+// table in LDS (the segments of a member start at its first byte: any alignment)
+__global__ __launch_bounds__(64) void crc_kernel(const uint8_t *text, const uint64_t *seg_at, const uint32_t *seg_len, uint64_t n_seg,
+                                                 const uint32_t *table, uint32_t *crc)
 {
     __shared__ uint32_t tab[256];
     for (int i = threadIdx.x; i < 256; i += 64) tab[i] = table[i];
     __syncthreads();
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t a = s * seg;
-    if (a >= n) return;
-    const uint64_t e = min(n, a + seg);
+    if (s >= n_seg) return;
+    uint64_t i = seg_at[s];
+    const uint64_t e = i + seg_len[s];
     uint32_t k = 0xFFFFFFFFu;
-    uint64_t i = a;
-    for (; i + 4 <= e; i += 4) {                                 // seg is a multiple of 4 and the text is 4-byte aligned
+    for (; i < e && (i & 3); i++) k = tab[(k ^ text[i]) & 0xFFu] ^ (k >> 8);
+    for (; i + 4 <= e; i += 4) {
         const uint32_t w = *reinterpret_cast<const uint32_t *>(text + i);
         k = tab[(k ^ w) & 0xFFu] ^ (k >> 8);
         k = tab[(k ^ (w >> 8)) & 0xFFu] ^ (k >> 8);
@@ -934,9 +942,6 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     };
     const uint64_t data_off = gzip_header_len(in, in_n);
     if (!data_off) return no("header");
-    const uint8_t *tr = in + in_n - 8;
-    const uint32_t want_crc = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
-    const uint32_t want_isize = (uint32_t)tr[4] | (uint32_t)tr[5] << 8 | (uint32_t)tr[6] << 16 | (uint32_t)tr[7] << 24;
     uint64_t chunk_bytes = 32 << 10, ratio = 12;
     if (const char *e = getenv("SS_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));
     if (const char *e = getenv("SS_GZ_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
@@ -985,19 +990,25 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         const uint64_t c = (uint64_t)atoll(e);
         if (c > 0 && c < n_chunks0) entry[c] = (data_off + c * chunk_bytes) * 8 + 12345 % (chunk_bytes * 8);
     }
-    // chunks with an entry; a chunk without one belongs to its predecessor
-    std::vector<uint64_t> start, stop, off, cap;
+    // chunks with an entry; a chunk without one belongs to its predecessor.  `fresh`: the first chunk of a gzip member
+    // (nothing in front of it); `last`: it ends with the member's final block, the trailer follows at `trailer`
+    struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; };
+    std::vector<Chunk> ch;
     for (uint32_t c = 0; c < n_chunks0; c++)
-        if (entry[c] != ~0ull) start.push_back(entry[c]);
-    uint32_t nc = (uint32_t)start.size();
-    const uint32_t nc_alloc = nc;
+        if (entry[c] != ~0ull) ch.push_back(Chunk{entry[c], c == 0, false, 0});
+    ch.back().last = true;
+    ch.back().trailer = in_n - 8;
+    uint32_t nc = (uint32_t)ch.size();
+    const uint32_t nc_alloc = nc + 64;                       // room for the first chunks of further members
+    std::vector<uint64_t> start, stop, off, cap;
     uint64_t sym_total = 0;
     auto lay_out = [&] {
-        stop.clear(); off.clear(); cap.clear();
+        start.clear(); stop.clear(); off.clear(); cap.clear();
         sym_total = 0;
         for (uint32_t c = 0; c < nc; c++) {
-            stop.push_back(c + 1 < nc ? start[c + 1] : ~0ull);
-            const uint64_t cbits = (c + 1 < nc ? start[c + 1] : (in_n - 8) * 8) - start[c];
+            start.push_back(ch[c].start | (ch[c].fresh ? 1ull << 63 : 0ull));
+            stop.push_back(ch[c].last ? ~0ull : ch[c + 1].start);
+            const uint64_t cbits = (c + 1 < nc ? ch[c + 1].start : (in_n - 8) * 8) - ch[c].start;
             const uint64_t cp = (cbits / 8 + 1) * ratio + 4096;
             off.push_back(sym_total);
             cap.push_back(cp);
@@ -1005,7 +1016,8 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         }
     };
     lay_out();
-    // meta: start, stop, off, cap, out_len, end_bit, text_off (laid out for the first chunk list; a shorter one fits)
+    const uint64_t sym_alloc = sym_total + 64 * (4096 + 64 * ratio);
+    // meta: start, stop, off, cap, out_len, end_bit, text_off
     GI(hipMallocAsync((void **)&d_meta, (uint64_t)nc_alloc * 8 * 7, st));
     uint64_t *d_start = d_meta, *d_stop = d_meta + nc_alloc, *d_off = d_meta + 2ull * nc_alloc, *d_cap = d_meta + 3ull * nc_alloc,
              *d_len = d_meta + 4ull * nc_alloc, *d_end = d_meta + 5ull * nc_alloc, *d_toff = d_meta + 6ull * nc_alloc;
@@ -1013,19 +1025,21 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         // symbols (2 B each, `ratio` per input byte), windows and maps (5 x 32 KB per chunk) and the text must fit
         size_t mem_free = 0, mem_total = 0;
         GI(hipMemGetInfo(&mem_free, &mem_total));
-        const uint64_t need = sym_total * 2 + (uint64_t)nc * WSIZE * 5 + ((uint64_t)want_isize | (in_n > (1ull << 32) ? in_n * 4 : 0)) + (64 << 20);
+        const uint64_t need = sym_alloc * 2 + (uint64_t)nc_alloc * WSIZE * 5 + in_n * 4 + (64 << 20);
         if (need > mem_free / 2) { cleanup(false); return no("device memory", (long long)(need >> 20)); }
     }
-    GI(hipMallocAsync((void **)&d_sym, sym_total * 2, st));
-    GI(hipMallocAsync((void **)&d_status, (uint64_t)nc * 4, st));
+    GI(hipMallocAsync((void **)&d_sym, sym_alloc * 2, st));
+    GI(hipMallocAsync((void **)&d_status, (uint64_t)nc_alloc * 4, st));
     lap("symbol buffers");
     std::vector<int> status;
     std::vector<uint64_t> out_len, end_bit, text_off;
-    uint64_t total = 0;
-    // An entry is a position where a valid dynamic header parses and SS_GZ_PROBE symbols decode -- a position INSIDE a
-    // block passes that about once in a million candidates (every bit string decodes under a complete code).  It shows
-    // here: the chunk in front of it runs past it.  The entry is dropped and the chunks are inflated again (the chunk
-    // list only ever shrinks; chunk 0 starts at the member's first block, so what ends exactly on the next entry is right).
+    // Two things show only when the chunks have been inflated, and both make the chunk list change and the chunks be
+    // inflated again (it converges: entries are only dropped, members only found):
+    //  * An entry is a position where a valid dynamic header parses and SS_GZ_PROBE symbols decode -- a position INSIDE a
+    //    block passes that about once in a million candidates (every bit string decodes under a complete code).  The
+    //    chunk in front of it runs past it (-21): the entry is dropped.
+    //  * A file of several members (lanes joined with `cat a.gz b.gz`): the chunk that meets a final block before its
+    //    stop (-20) ends a member if a trailer and a gzip header follow; the next member's first block becomes a chunk.
     for (int attempt = 0;; attempt++) {
         GI(h2d(d_start, start.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
         GI(h2d(d_stop, stop.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
@@ -1052,28 +1066,62 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
             fprintf(stderr, "[ginflate] matches %llu (symbols %llu), beyond the ring %llu, into the unknown window %llu; windows %llu\n", t[6], t[7], t[8], t[9], t[5]);
         }
 #endif
+        std::vector<Chunk> nxt;
         std::vector<char> drop(nc, 0);
-        uint32_t n_drop = 0;
-        bool bad = false;
-        for (uint32_t c = 0; c < nc && !bad; c++) {
+        uint32_t n_drop = 0, n_members = 0;
+        for (uint32_t c = 0; c < nc; c++) {
             if (drop[c]) continue;                                     // its own outcome means nothing
-            if (status[c] == (c + 1 == nc ? 1 : 0)) continue;
-            // ran past the next entry (-21), or met the final block before it (-20: the entry lies behind the stream's end)
-            if ((status[c] == -21 || status[c] == -20) && c + 1 < nc && attempt < 4) { drop[c + 1] = 1; n_drop++; }
-            else { bad = true; cleanup(false); return no("chunk status", status[c] * 1000000ll + c); }
+            const uint64_t e = (end_bit[c] + 7) / 8;
+            if (status[c] == (ch[c].last ? 1 : 0) && (!ch[c].last || e == ch[c].trailer)) { nxt.push_back(ch[c]); continue; }
+            if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry
+                drop[c + 1] = 1;
+                n_drop++;
+                nxt.push_back(ch[c]);
+                continue;
+            }
+            if (status[c] == -20 || (status[c] == 1 && ch[c].last)) {  // a final block before the next entry / before the file's end
+                const uint64_t hdr = e + 8 + 18 <= in_n ? gzip_header_len(in + e + 8, in_n - (e + 8)) : 0;
+                if (!hdr) { cleanup(false); return no("chunk status", status[c] * 1000000ll + c); }
+                Chunk a = ch[c];
+                a.last = true;
+                a.trailer = e;
+                nxt.push_back(a);
+                const uint64_t d = (e + 8 + hdr) * 8;                  // the next member's first block
+                for (uint32_t k = c + 1; k < nc && ch[k].start < d; k++) { drop[k] = 1; n_drop++; }      // "entries" within trailer and header
+                nxt.push_back(Chunk{d, true, ch[c].last, ch[c].trailer});      // (it ends the file if the split chunk did)
+                n_members++;
+                continue;
+            }
+            cleanup(false);
+            return no("chunk status", status[c] * 1000000ll + c);
         }
-        if (!n_drop) break;
-        if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block: dropped, chunks inflated again\n", n_drop);
-        std::vector<uint64_t> kept;
-        for (uint32_t c = 0; c < nc; c++) if (!drop[c]) kept.push_back(start[c]);
-        start.swap(kept);
-        nc = (uint32_t)start.size();
+        if (!n_drop && !n_members) break;
+        if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block, %u further members found: chunks inflated again\n", n_drop, n_members);
+        if (attempt >= 6 || nxt.size() > nc_alloc) { cleanup(false); return no("chunk list", (long long)nxt.size()); }
+        ch.swap(nxt);
+        nc = (uint32_t)ch.size();
         lay_out();
+        if (sym_total > sym_alloc) { cleanup(false); return no("symbol budget"); }
     }
-    for (uint32_t c = 0; c < nc; c++) { text_off[c] = total; total += out_len[c]; }
-    // the stream must end where the trailer begins (after padding to a byte)
-    if ((end_bit[nc - 1] + 7) / 8 != in_n - 8) { cleanup(false); return no("stream end", (long long)((end_bit[nc - 1] + 7) / 8)); }
-    if ((uint32_t)total != want_isize) { cleanup(false); return no("isize"); }
+    // members: text ranges, trailers
+    struct Member { uint64_t at, len; uint32_t crc, isize; };
+    std::vector<Member> members;
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < nc; c++) {
+        if (ch[c].fresh) members.push_back(Member{total, 0, 0, 0});
+        if (members.empty()) { cleanup(false); return no("member start"); }
+        text_off[c] = total;
+        total += out_len[c];
+        members.back().len += out_len[c];
+        if (ch[c].last) {
+            const uint8_t *t8 = in + ch[c].trailer;
+            members.back().crc = (uint32_t)t8[0] | (uint32_t)t8[1] << 8 | (uint32_t)t8[2] << 16 | (uint32_t)t8[3] << 24;
+            members.back().isize = (uint32_t)t8[4] | (uint32_t)t8[5] << 8 | (uint32_t)t8[6] << 16 | (uint32_t)t8[7] << 24;
+            if ((uint32_t)members.back().len != members.back().isize) { cleanup(false); return no("isize", (long long)members.size()); }
+        }
+    }
+    if (!ch[nc - 1].last || (end_bit[nc - 1] + 7) / 8 != in_n - 8) { cleanup(false); return no("stream end", (long long)((end_bit[nc - 1] + 7) / 8)); }
+    if (trace && members.size() > 1) fprintf(stderr, "[ginflate] %zu members\n", members.size());
     GI(h2d(d_toff, text_off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
     GI(hipMallocAsync((void **)&d_win, (uint64_t)nc * WSIZE, st));
     {
@@ -1097,18 +1145,31 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(hipMalloc((void **)&d_text, std::max<uint64_t>(total, 16) + 64));
     hipLaunchKernelGGL(bytes_kernel, dim3(64, nc), dim3(256), 0, st, d_sym, d_off, d_len, d_toff, d_win, d_text);
     lap("bytes");
-    // CRC-32 by segments of 4 KB, combined on the host with ONE precomputed operator
+    // CRC-32 by segments of 4 KB from every member's first byte, combined on the host with ONE precomputed operator
     constexpr int SEG_LOG2 = 12;
-    const uint64_t seg = 1ull << SEG_LOG2, nseg = (total + seg - 1) / seg;
+    const uint64_t seg = 1ull << SEG_LOG2;
+    std::vector<uint64_t> seg_at;
+    std::vector<uint32_t> seg_len;
+    for (const Member &m : members)
+        for (uint64_t a0 = 0; a0 < m.len; a0 += seg) { seg_at.push_back(m.at + a0); seg_len.push_back((uint32_t)std::min<uint64_t>(seg, m.len - a0)); }
+    const uint64_t nseg = seg_at.size();
     std::vector<uint32_t> tab(256);
     for (uint32_t i = 0; i < 256; i++) { uint32_t k = i; for (int j = 0; j < 8; j++) k = (k & 1u) ? 0xEDB88320u ^ (k >> 1) : k >> 1; tab[i] = k; }
-    GI(hipMallocAsync((void **)&d_tab, 1024, st));
+    uint64_t *d_seg_at = nullptr;
+    uint32_t *d_seg_len = nullptr;
+    GI(hipMallocAsync((void **)&d_tab, 1024 + std::max<uint64_t>(1, nseg) * 12, st));      // table | segment starts | lengths
+    d_seg_at = reinterpret_cast<uint64_t *>(d_tab + 256);
+    d_seg_len = reinterpret_cast<uint32_t *>(d_seg_at + nseg);
     GI(h2d(d_tab, tab.data(), 1024) ? hipSuccess : hipErrorUnknown);
+    if (nseg) {
+        GI(h2d(d_seg_at, seg_at.data(), nseg * 8) ? hipSuccess : hipErrorUnknown);
+        GI(h2d(d_seg_len, seg_len.data(), nseg * 4) ? hipSuccess : hipErrorUnknown);
+    }
     GI(hipMallocAsync((void **)&d_crc, std::max<uint64_t>(1, nseg) * 4, st));
-    if (nseg) hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, d_text, total, seg, d_tab, d_crc);
+    if (nseg) hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, d_text, d_seg_at, d_seg_len, nseg, d_tab, d_crc);
     std::vector<uint32_t> crcs(std::max<uint64_t>(1, nseg));
     if (nseg) GI(d2h(crcs.data(), d_crc, nseg * 4) ? hipSuccess : hipErrorUnknown);
-    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+    bool crc_ok = true;
     {
         uint32_t op[32];
         crc_zero_operator(op, SEG_LOG2);
@@ -1116,18 +1177,23 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         std::vector<uint32_t> opt(4 * 256);
         for (int byte = 0; byte < 4; byte++)
             for (uint32_t v = 0; v < 256; v++) opt[(size_t)byte * 256 + v] = gf2_times(op, v << (8 * byte));
-        for (uint64_t s = 0; s < nseg; s++) {
-            const uint64_t l = std::min<uint64_t>(seg, total - s * seg);
-            if (l == seg) crc = opt[crc & 0xFF] ^ opt[256 + ((crc >> 8) & 0xFF)] ^ opt[512 + ((crc >> 16) & 0xFF)] ^ opt[768 + (crc >> 24)] ^ crcs[s];
-            else crc = (uint32_t)crc32_combine(crc, crcs[s], (z_off_t)l);
+        uint64_t si = 0;
+        for (const Member &m : members) {
+            uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+            for (uint64_t a0 = 0; a0 < m.len; a0 += seg, si++) {
+                const uint64_t l = seg_len[si];
+                if (l == seg) crc = opt[crc & 0xFF] ^ opt[256 + ((crc >> 8) & 0xFF)] ^ opt[512 + ((crc >> 16) & 0xFF)] ^ opt[768 + (crc >> 24)] ^ crcs[si];
+                else crc = (uint32_t)crc32_combine(crc, crcs[si], (z_off_t)l);
+            }
+            crc_ok = crc_ok && crc == m.crc;
         }
     }
     lap("crc");
 #undef GI
 #ifdef SS_GZ_DEBUG_SKIPCRC           // diagnostic builds only (scripts/dev): hand out the text although it is wrong
-    if (crc != want_crc) fprintf(stderr, "[ginflate] CRC MISMATCH (debug build: text returned)\n");
+    if (!crc_ok) fprintf(stderr, "[ginflate] CRC MISMATCH (debug build: text returned)\n");
 #else
-    if (crc != want_crc) { cleanup(false); return no("crc"); }
+    if (!crc_ok) { cleanup(false); return no("crc"); }
 #endif
     cleanup(true);
     g_handled++;

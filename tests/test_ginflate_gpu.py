@@ -121,17 +121,20 @@ def test_header_fields(L, tmp_path, fastq_text):
 
 
 def test_declines_instead_of_answering_wrongly(L, tmp_path, fastq_text):
-    """Two members, a bgzip-style file of many small members, a truncated file, a flipped byte in the deflate data, a
-    wrong CRC-32, a wrong ISIZE, text that expands 1000:1 (beyond the symbol budget), not gzip at all: SS_ERANGE --
-    or, for a flipped byte that happens to survive, the exact text -- never different bytes."""
+    """A bgzip-style file of many small members, a truncated file, a flipped byte in the deflate data, a wrong CRC-32 (of
+    the last and of the first of two members), a wrong ISIZE, zero padding behind the member, text that expands 1000:1
+    (beyond the symbol budget), not gzip at all: SS_ERANGE -- or, for a flipped byte that happens to survive, the exact
+    text -- never different bytes."""
     txt = fastq_text[: 6 << 20]
     gz = gzip.compress(txt, 6)
     half = len(txt) // 2
     mid = len(gz) // 2
     bgz = b"".join(gzip.compress(txt[i:i + 65000], 6) for i in range(0, len(txt), 65000))
+    m1 = gzip.compress(txt[:half], 6)
     cases = dict(
-        two_members=gzip.compress(txt[:half], 6) + gzip.compress(txt[half:], 6),
         many_members=bgz,
+        first_member_bad_crc=m1[:-8] + bytes([m1[-8] ^ 1]) + m1[-7:] + gzip.compress(txt[half:], 6),
+        zero_padding=gz + b"\0" * 512,
         truncated=gz[: len(gz) - 4000],
         flipped=gz[:mid] + bytes([gz[mid] ^ 0x10]) + gz[mid + 1:],
         bad_crc=gz[:-8] + bytes([gz[-8] ^ 1]) + gz[-7:],
@@ -161,8 +164,8 @@ def _kmer_fa(seed, n_rows):
 
 
 def test_scan_of_gz_inputs_through_the_device_inflater(L, tmp_path, monkeypatch):
-    """SS_GZ_GPU=1: ss_scan_files and ss_reads_load inflate single-member .gz inputs on the device (the counters
-    move), a two-member file falls through to the host inflaters, and the row counts equal those of the plain text."""
+    """ss_scan_files and ss_reads_load inflate .gz inputs on the device (the counters move) -- one member, a pair of
+    files, a file of two members -- and the row counts equal those of the plain text; SS_GZ_GPU=0: the host inflaters."""
     rows, kfa = _kmer_fa(11, 50000)
     rs = np.random.RandomState(12)
     lut = np.frombuffer(b"ACGT", np.uint8)
@@ -189,7 +192,7 @@ def test_scan_of_gz_inputs_through_the_device_inflater(L, tmp_path, monkeypatch)
     want = db.counts_rows().copy()
     assert want.sum() >= n // 3
     monkeypatch.setenv("SS_GZ_GPU", "1")
-    for paths, on_device in (([str(one)], 1), ([str(p1), str(p2)], 2), ([str(multi)], 0)):
+    for paths, on_device in (([str(one)], 1), ([str(p1), str(p2)], 2), ([str(multi)], 1)):
         h0, d0 = _counters(L)
         db.reset()
         nrec, _ = db.scan_files(paths)
@@ -279,3 +282,23 @@ def test_a_wrong_entry_point_is_dropped_and_the_chunks_inflated_again(L, tmp_pat
         rc, got = _gpu_inflate(L, p)
         assert rc == SS_OK, chunk
         assert got == fastq_text, chunk
+
+
+@pytest.mark.parametrize("layout", ["two", "lanes", "small_middle", "small_last", "levels"])
+def test_files_of_several_members(L, tmp_path, layout, fastq_text):
+    """Lanes joined with `cat a.gz b.gz` are one file of several gzip members.  The chunk that meets a member's final
+    block finds trailer and next header behind it; the next member's first block becomes a chunk of its own (nothing in
+    front of it), every member is checked against ITS CRC-32 and ISIZE.  Equal to gzip.decompress."""
+    t = fastq_text
+    n = len(t)
+    cuts = dict(two=[n // 2], lanes=[n // 4, n // 2, 3 * n // 4], small_middle=[n // 3, n // 3 + 5000], small_last=[n - 3000],
+                levels=[n // 5, 2 * n // 5, 3 * n // 5, 4 * n // 5])[layout]
+    parts = [t[a:b] for a, b in zip([0] + cuts, cuts + [n])]
+    levels = [6, 1, 9, 4, 6] if layout == "levels" else [6] * len(parts)
+    gz = b"".join(gzip.compress(part, lv) for part, lv in zip(parts, levels))
+    assert gzip.decompress(gz) == t
+    p = tmp_path / "m.fq.gz"
+    p.write_bytes(gz)
+    rc, got = _gpu_inflate(L, p)
+    assert rc == SS_OK, layout
+    assert got == t, layout

@@ -494,8 +494,7 @@ def test_node_reduce_synthetic_counts(L):
 @pytest.mark.parametrize("gz_on_device", ["0", "1"])
 def test_gz_whole_file_inflate(L, tmp_path, monkeypatch, gz_on_device):
     """.gz inputs large enough for the chunked parser (>= 4 MB of text) are inflated whole -- on the host (the
-    threaded inflater, libdeflate: SS_GZ_GPU=0) or on the device (the default; what it declines, the two-member file
-    here, goes to the host) -- and parsed like plain text: single-member, multi-member (two concatenated gzip streams)
+    threaded inflater, libdeflate: SS_GZ_GPU=0) or on the device (the default) -- and parsed like plain text: single-member, multi-member (two concatenated gzip streams)
     and a pair of files, through ss_scan_files and through the resident read set, count exactly like the plain files."""
     import gzip
     monkeypatch.setenv("SS_GZ_GPU", gz_on_device)
@@ -917,7 +916,10 @@ def test_locality_ordered_read_set(L):
     with tempfile.TemporaryDirectory() as td:
         p = os.path.join(td, "r.fq")
         open(p, "wb").write(fq)
-        for env in (None, "locality"):
+        import gzip
+        pgz = os.path.join(td, "r.fq.gz")           # (1 MB and more: inflated and reduced to sequence lines on the device,
+        open(pgz, "wb").write(gzip.compress(fq, 6))  #  the block adopted as a slab; smaller: the host inflaters)
+        for p, env in ((p, None), (p, "locality"), (pgz, None), (pgz, "locality")):
             old = os.environ.get("SS_READS_ORDER")
             if env:
                 os.environ["SS_READS_ORDER"] = env
