@@ -79,7 +79,7 @@ void ss_gz_free(char *text);
 int ss_gz_inflate_to_file(const char *path, const char *out_path, int threads, uint64_t *len);
 /* The same on the GPU (ss_ginflate.hip: the two-pass scheme with one wave per chunk of the deflate data, the
  * text verified against CRC-32 and ISIZE of the trailer); *text is a host buffer released with ss_gz_free.  SS_ERANGE:
- * not handled on the device (bgzip's many small members, a damaged file, ...): use ss_gz_inflate. */
+ * not handled on the device (a damaged file, data that expands beyond the symbol budget, ...): use ss_gz_inflate. */
 int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len);
 /* Members the device inflater has produced / has declined in this process.  Unless SS_GZ_GPU=0, the .gz inputs of
  * ss_scan_files and ss_reads_load (one rank, files of 1 MB and more) go through it first and strict four-line FASTQ is

@@ -20,8 +20,8 @@
 // Accepted only if every chunk ended exactly on the next one's entry, the stream ended at the file's last trailer and
 // CRC-32 and ISIZE of EVERY member match (lanes joined with `cat` are found member by member: the chunk that meets a
 // final block finds trailer and header behind it).  A wrong entry (a position inside a block that passed A) shows as the
-// chunk before it running past it and is dropped.  Anything else (bgzip's thousands of small members, a chunk that
-// expands more than SS_GZ_RATIO times, a damaged file) returns "not handled" and the caller inflates on the host
+// chunk before it running past it and is dropped.  A bgzip file (BGZF: every member names its size) needs no search: its
+// members are the chunks.  Anything else (a chunk that expands more than SS_GZ_RATIO times, a damaged file) returns "not handled" and the caller inflates on the host
 // (ss_pgz.hip, libdeflate, zlib), so a wrong text cannot get through.
 #include "ss_common.h"
 
@@ -914,6 +914,31 @@ uint64_t gzip_header_len(const uint8_t *p, uint64_t n)
     return pos + 8 < n ? pos : 0;
 }
 
+// bgzip (BGZF): every member carries its size in an extra field ("BC", 2 bytes: BSIZE = size - 1), so the members -- at most
+// 64 KB of text each, nothing in front of any -- are found without decoding.  -> (first data byte, trailer byte) of every
+// member, or nothing when the file is not BGZF throughout
+struct Bgzf { uint64_t data, trailer; };
+std::vector<Bgzf> bgzf_members(const uint8_t *p, uint64_t n)
+{
+    std::vector<Bgzf> out;
+    uint64_t pos = 0;
+    while (pos < n) {
+        if (pos + 18 > n || p[pos] != 0x1f || p[pos + 1] != 0x8b || p[pos + 2] != 8 || p[pos + 3] != 4) return {};
+        const uint64_t xlen = (uint64_t)p[pos + 10] | (uint64_t)p[pos + 11] << 8;
+        if (xlen < 6 || pos + 12 + xlen > n) return {};
+        uint64_t bsize = 0;
+        for (uint64_t q = pos + 12; q + 4 <= pos + 12 + xlen;) {
+            const uint64_t slen = (uint64_t)p[q + 2] | (uint64_t)p[q + 3] << 8;
+            if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= pos + 12 + xlen) bsize = ((uint64_t)p[q + 4] | (uint64_t)p[q + 5] << 8) + 1;
+            q += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 2 + 8 || pos + bsize > n) return {};
+        out.push_back(Bgzf{pos + 12 + xlen, pos + bsize - 8});
+        pos += bsize;
+    }
+    return out;
+}
+
 }  // namespace
 
 namespace ss {
@@ -973,12 +998,16 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
     GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
+    const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
+    if (bgzf.size() > 60000) { cleanup(false); return no("bgzf members", (long long)bgzf.size()); }      // (a grid dimension)
     uint64_t probe = 512;
     if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
-    hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe);
     std::vector<uint64_t> entry(n_chunks0);
-    GI(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8) ? hipSuccess : hipErrorUnknown);
-    if (trace) {
+    if (bgzf.empty()) {
+        hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe);
+        GI(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8) ? hipSuccess : hipErrorUnknown);
+    }
+    if (trace && bgzf.empty()) {
         unsigned tries = 0;
         hipMemcpyFromSymbol(&tries, HIP_SYMBOL(g_sync_tries), 4);
         fprintf(stderr, "[ginflate] %u chunks, %u candidate blocks decoded\n", n_chunks0, tries);
@@ -994,10 +1023,15 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     // (nothing in front of it); `last`: it ends with the member's final block, the trailer follows at `trailer`
     struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; };
     std::vector<Chunk> ch;
-    for (uint32_t c = 0; c < n_chunks0; c++)
-        if (entry[c] != ~0ull) ch.push_back(Chunk{entry[c], c == 0, false, 0});
-    ch.back().last = true;
-    ch.back().trailer = in_n - 8;
+    if (bgzf.empty()) {
+        for (uint32_t c = 0; c < n_chunks0; c++)
+            if (entry[c] != ~0ull) ch.push_back(Chunk{entry[c], c == 0, false, 0});
+        ch.back().last = true;
+        ch.back().trailer = in_n - 8;
+    } else {
+        for (const Bgzf &m : bgzf) ch.push_back(Chunk{m.data * 8, true, true, m.trailer});
+        if (trace) fprintf(stderr, "[ginflate] bgzip: %zu members\n", bgzf.size());
+    }
     uint32_t nc = (uint32_t)ch.size();
     const uint32_t nc_alloc = nc + 64;                       // room for the first chunks of further members
     std::vector<uint64_t> start, stop, off, cap;
