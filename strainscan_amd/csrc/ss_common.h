@@ -175,12 +175,12 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
 // base block there (ss_fastq_dev.hip)
 bool gz_on_gpu();
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len);
-int gz_fastq_to_flat_dev(const char *path, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap, uint64_t *n_records, char **text,
-                         uint64_t *text_len);
+int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap,
+                         uint64_t *n_records, char **text, uint64_t *text_len);
 // every gzip input of a call through gz_fastq_to_flat_dev, one host thread per file: `flat(i, d_flat, len, cap, n_records)`
 // takes over the device buffer of input i (called from that file's thread; returns an SS_* code); inputs that were
 // only inflated come back as host texts in `texts`; done[i] = 1 for the inputs that need nothing more
-int gz_inputs_on_device(const char *const *paths, int n_paths,
+int gz_inputs_on_device(const char *const *paths, int n_paths, int shard_rank, int shard_world,
                         const std::function<int(int, char *, uint64_t, uint64_t, uint64_t)> &flat, std::vector<InflatedText> &texts,
                         std::vector<char> &done);
 int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_t *n_bases, bool *handled, int shard_rank = 0,

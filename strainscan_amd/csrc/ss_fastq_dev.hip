@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256) void fq_lines_kernel(const char *__restrict__ 
     if (blockIdx.x == 0 && tid == 0) ls[0] = 0;
 }
 
-// record r = lines 4r .. 4r + 3.  bad |= 1 when it is not the strict form; len1[r] = sequence line + its '\n'
+// record r = lines 4r .. 4r + 3.  bad |= 1 when it is not the strict form; len1[r] = sequence line + its '\n' -- or 0 when
+// the record belongs to another rank of a sharded run (blocks of SHARD_RECORDS records go round the ranks)
+constexpr int SHARD_LOG2 = 12;
 __global__ void fq_records_kernel(const char *__restrict__ t, uint64_t n, const uint64_t *__restrict__ ls, uint64_t n_nl,
-                                  uint64_t n_rec, uint64_t *__restrict__ len1, uint32_t *__restrict__ bad)
+                                  uint64_t n_rec, uint32_t shard_rank, uint32_t shard_world, uint64_t *__restrict__ len1,
+                                  uint32_t *__restrict__ bad)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
@@ -81,7 +84,7 @@ __global__ void fq_records_kernel(const char *__restrict__ t, uint64_t n, const 
     const uint64_t seq = s2 - 1 - s1;
     const bool ok = t[s0] == '@' && t[s2] == '+' && (seq == 0 || t[s1] != '+') && e3 - s3 == seq;
     if (!ok) atomicOr(bad, 1u);
-    len1[r] = seq + 1;
+    len1[r] = (r >> SHARD_LOG2) % shard_world == shard_rank ? seq + 1 : 0;
 }
 
 // sequence line of record r (with its '\n') -> dst + off[r]; 16 lanes per record, 16 (unaligned) bytes per lane and round
@@ -123,7 +126,8 @@ bool gz_on_gpu()
 
 // FASTQ text on the device -> a new device buffer with the flat base block (padded like a block of ss_reads: at least one
 // '\n' behind it, a multiple of 16 bytes).  0 = done, 1 = not strict four-line FASTQ (nothing returned), < 0 = SS_E*.
-int fastq_text_to_flat_dev(const char *d_text, uint64_t n, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap, uint64_t *n_records)
+int fastq_text_to_flat_dev(const char *d_text, uint64_t n, int shard_rank, int shard_world, char **d_flat, uint64_t *flat_len,
+                           uint64_t *flat_cap, uint64_t *n_records)
 {
     if (n == 0) return 1;
     hipStream_t st = nullptr;
@@ -166,7 +170,8 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, char **d_flat, uint64
     FQ(hipMallocAsync((void **)&d_bad, 4, st));
     FQ(hipMemsetAsync(d_bad, 0, 4, st));
     FQ(hipMemsetAsync(d_len1 + n_rec, 0, 8, st));
-    hipLaunchKernelGGL(fq_records_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, d_text, n, d_ls, n_nl, n_rec, d_len1, d_bad);
+    hipLaunchKernelGGL(fq_records_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st, d_text, n, d_ls, n_nl, n_rec, (uint32_t)shard_rank,
+                       (uint32_t)shard_world, d_len1, d_bad);
     size_t tmp2 = 0;
     FQ(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, d_len1, d_off, (int)(n_rec + 1), st));
     if (tmp2 > tmp_have) {
@@ -192,16 +197,22 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, char **d_flat, uint64
     *d_flat = flat;
     *flat_len = total;
     *flat_cap = cap;
-    *n_records = n_rec;
+    // this rank's records: the blocks b = rank, rank + world, ... of SHARD_RECORDS records (the last one may be short)
+    uint64_t own = 0;
+    const uint64_t blk = 1ull << SHARD_LOG2, n_blk = (n_rec + blk - 1) / blk;
+    for (uint64_t b = (uint64_t)shard_rank; b < n_blk; b += (uint64_t)shard_world) own += std::min<uint64_t>(blk, n_rec - b * blk);
+    *n_records = own;
     return done(0);
 }
 
-// One .gz file: inflated on the device (ss_ginflate.hip), the sequence lines extracted there.
+// One .gz file: inflated on the device (ss_ginflate.hip), the sequence lines extracted there.  In a sharded run every
+// rank inflates the whole file on its own GPU (a gzip stream has no entry points to share out; 30-40 ms per 130 MB) and
+// keeps the records of its blocks.
 //   0  *d_flat (hipMalloc, *flat_cap bytes, padded with '\n') holds the *flat_len bytes of the flat block
 //   1  not handled here (not one gzip member, damaged, no room, ...): nothing returned
 //   2  inflated, but not strict four-line FASTQ: the text is returned on the host (*text, malloc) for the general grammar
-int gz_fastq_to_flat_dev(const char *path, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap, uint64_t *n_records, char **text,
-                         uint64_t *text_len)
+int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap,
+                         uint64_t *n_records, char **text, uint64_t *text_len)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -221,7 +232,7 @@ int gz_fastq_to_flat_dev(const char *path, char **d_flat, uint64_t *flat_len, ui
     munmap((void *)in, in_n);
     if (!ok) return 1;
     if (trace) fprintf(stderr, "[ingest] %s: %.1f MB of text on the device at %.4f s\n", path, n / 1e6, since());
-    int rc = fastq_text_to_flat_dev(d_text, n, d_flat, flat_len, flat_cap, n_records);
+    int rc = fastq_text_to_flat_dev(d_text, n, shard_rank, shard_world, d_flat, flat_len, flat_cap, n_records);
     if (trace) fprintf(stderr, "[ingest] %s: sequence lines extracted (rc %d) at %.4f s\n", path, rc, since());
     if (rc == 0) { hipFree(d_text); return 0; }
     // the general grammar runs on the host

@@ -365,7 +365,7 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
     return out;
 }
 
-int gz_inputs_on_device(const char *const *paths, int n_paths,
+int gz_inputs_on_device(const char *const *paths, int n_paths, int shard_rank, int shard_world,
                         const std::function<int(int, char *, uint64_t, uint64_t, uint64_t)> &flat, std::vector<InflatedText> &texts,
                         std::vector<char> &done)
 {
@@ -391,7 +391,7 @@ int gz_inputs_on_device(const char *const *paths, int n_paths,
             hipSetDevice(device);
             char *d = nullptr;
             uint64_t len = 0, cap = 0, nrec = 0;
-            const int r = gz_fastq_to_flat_dev(paths[i], &d, &len, &cap, &nrec, &texts[i].p, &texts[i].n);
+            const int r = gz_fastq_to_flat_dev(paths[i], shard_rank, shard_world, &d, &len, &cap, &nrec, &texts[i].p, &texts[i].n);
             if (r == 0) {
                 const int rc = flat(i, d, len, cap, nrec);
                 if (rc != SS_OK) err = rc;
@@ -614,14 +614,14 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     // goes through the sequential reader -- one thread PER FILE, so the two mates of a paired
     // .fastq.gz sample inflate concurrently (zlib is the limiter there)
     std::vector<int> seq_files;
-    // one rank (and not SS_GZ_GPU=0): .gz inputs are inflated AND reduced to their sequence lines on the device; the block becomes a
+    // (not SS_GZ_GPU=0) .gz inputs are inflated AND reduced to their sequence lines on the device; the block becomes a
     // slab as it is.  What that path only inflated (not strict four-line FASTQ) arrives as text, the rest goes on below.
     std::vector<ss::InflatedText> texts;
     std::vector<char> on_device;
     std::vector<const char *> rest(paths, paths + n_paths);
-    if (shard_world == 1) {
+    {
         std::atomic<uint64_t> drecs(0), dbases(0);
-        rc = ss::gz_inputs_on_device(paths, n_paths, [&](int, char *d, uint64_t len, uint64_t cap, uint64_t nrec) {
+        rc = ss::gz_inputs_on_device(paths, n_paths, shard_rank, shard_world, [&](int, char *d, uint64_t len, uint64_t cap, uint64_t nrec) {
             R->adopt(d, cap, len);
             drecs += nrec;
             dbases += len;

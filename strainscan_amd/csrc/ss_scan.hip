@@ -450,12 +450,12 @@ int ss_scan_files_shard(ss_db *db, const char *const *paths, int n_paths, int sh
     std::vector<char> on_device((size_t)n_paths, 0);
     int rc = SS_OK;
     if (allow_parallel) {
-        // one rank (and not SS_GZ_GPU=0): inflated and reduced to the sequence lines on the device (ss_ginflate.hip, ss_fastq_dev.hip),
+        // (not SS_GZ_GPU=0) inflated and reduced to the sequence lines on the device (ss_ginflate.hip, ss_fastq_dev.hip),
         // scanned from there
         std::vector<const char *> rest(paths, paths + n_paths);
-        if (shard_world == 1) {
+        {
             std::mutex mu;
-            rc = ss::gz_inputs_on_device(paths, n_paths, [&](int, char *d, uint64_t len, uint64_t, uint64_t nrec) {
+            rc = ss::gz_inputs_on_device(paths, n_paths, shard_rank, shard_world, [&](int, char *d, uint64_t len, uint64_t, uint64_t nrec) {
                 std::lock_guard<std::mutex> g(mu);                    // one scan at a time on the table's stream
                 int r = ss_scan_flat_dev(db, d, ss_reads::padded(len), nullptr);
                 if (r == SS_OK && hipStreamSynchronize(nullptr) != hipSuccess) r = SS_EHIP;

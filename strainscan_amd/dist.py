@@ -152,7 +152,8 @@ def scan_files_sharded(kdb, paths, allreduce=True):
 
 
 def share_inflated(paths, shm_dir="/dev/shm"):
-    """.gz inputs under torch.distributed on ONE node: rank 0 inflates each of them once into a plain file on tmpfs
+    """.gz inputs that the device inflater does not take (SS_GZ_GPU=0, files below 1 MB or above 4 GB) under
+    torch.distributed on ONE node: rank 0 inflates each of them once into a plain file on tmpfs
     (ss_gz_inflate_to_file: the threaded inflater writes through a shared mapping), the names are broadcast, every
     rank then parses only its share of the plain text -- instead of every rank inflating the whole file before it
     can pick its share (a gzip member has no entry points).  -> (paths to read, cleanup): call cleanup() when the
@@ -177,6 +178,11 @@ def share_inflated(paths, shm_dir="/dev/shm"):
                 with open(p, "rb") as f:
                     if f.read(2) != b"\x1f\x8b":
                         continue
+                # every rank inflates such a file on its own GPU and keeps its blocks of records (ss_ginflate.hip,
+                # ss_fastq_dev.hip): nothing to share.  (Should the device path decline it after all, the ranks fall
+                # back to inflating it on the host each.)
+                if os.environ.get("SS_GZ_GPU", "1") != "0" and (1 << 20) <= os.path.getsize(p) <= (4 << 30):
+                    continue
                 fs = os.statvfs(shm_dir)
                 if fs.f_bavail * fs.f_frsize < 8 * os.path.getsize(p):
                     continue

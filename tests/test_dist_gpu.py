@@ -144,3 +144,82 @@ def test_sharded_identify_equals_golden(world, golden_dir, l1_dbs, l1_reads, tmp
                 for (_, b), (_, wb) in zip(got["ranks"]["result"], want_r["result"]):
                     assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
     assert any_rows            # B_mix's Poisson branch asked for single rows: the full row vector was all-reduced there
+
+
+GZ_WORKER = r'''
+import ctypes as C, json, os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+import torch
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from strainscan_amd import dist as sdist, _lib
+job = json.load(open(%(jobs)r))
+kdb = _lib.KmerDB.from_text(open(job["kfa"], "rb").read(), 31, True)
+nrec, nb = sdist.scan_files_sharded(kdb, job["paths"], allreduce=True)
+counts = kdb.counts_rows()
+rset = _lib.ReadSet(job["paths"], rank, world)
+own = rset.info()["n_records"]
+rset.close()
+a, b = C.c_uint64(), C.c_uint64()
+_lib.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b))
+np.save(os.path.join(%(out)r, "counts%%d.npy" %% rank), counts)
+json.dump(dict(nrec=int(nrec), own=int(own), handled=int(a.value), declined=int(b.value)), open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_scan_of_gz_pair_on_the_device(world, tmp_path):
+    """A pair of .fastq.gz files under torch.distributed: every rank inflates both files on the GPU and keeps its blocks
+    of 4096 records (ss_fastq_dev.hip), nothing goes through /dev/shm; the summed row counts equal the single-process
+    scan of the plain text, the ranks' record counts add up, and the device inflater (not the host's) did the work."""
+    import gzip
+    import socket
+    from strainscan_amd import _lib as L
+    rs = np.random.RandomState(5)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rows = lut[rs.randint(0, 4, (30000, 31))]
+    kfa = b"".join(b">1\n" + r.tobytes() + b"\n" for r in rows)
+    n = 50000
+    reads = lut[rs.randint(0, 4, (n, 150))]
+    for i in range(0, n, 2):
+        o = rs.randint(0, 119)
+        reads[i, o:o + 31] = rows[rs.randint(0, rows.shape[0])]
+    fq = [b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + bytes(35 + (i + j) % 30 for j in range(150)) + b"\n" for i in range(n)]
+    half = n // 2 + 777
+    kp = tmp_path / "k.fa"
+    kp.write_bytes(kfa)
+    plain = tmp_path / "all.fq"
+    plain.write_bytes(b"".join(fq))
+    p1, p2 = tmp_path / "s_1.fq.gz", tmp_path / "s_2.fq.gz"
+    p1.write_bytes(gzip.compress(b"".join(fq[:half]), 6))
+    p2.write_bytes(gzip.compress(b"".join(fq[half:]), 6))
+    assert min(p1.stat().st_size, p2.stat().st_size) > (1 << 20)
+    db = L.KmerDB.from_text(kfa, 31, True)
+    db.scan_files([str(plain)])
+    want = db.counts_rows().copy()
+    db.close()
+    assert want.sum() >= n // 2
+    jp = tmp_path / "job.json"
+    jp.write_text(json.dumps(dict(kfa=str(kp), paths=[str(p1), str(p2)])))
+    code = GZ_WORKER % dict(repo=REPO, jobs=str(jp), out=str(tmp_path))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("SS_GZ_GPU", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
+    errs = [p.communicate(timeout=600)[1].decode()[-2000:] for p in procs]
+    assert all(p.returncode == 0 for p in procs), errs
+    infos = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("counts%d.npy" % r)), want), r          # the global counts, on every rank
+        assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0                      # two files, scanned and loaded
+    assert sum(i["nrec"] for i in infos) == n and sum(i["own"] for i in infos) == n
+    assert all(i["nrec"] > 0 for i in infos)
