@@ -6,7 +6,7 @@ kmer.fa, kmers/<id>, tree_structure.txt, node_length.txt, hclsMap_95_recls.txt .
 clusters = 1645 nodes, ~25 M rows) and a paired FASTQ sample (three-strain mix 70/20/10), then times
 library/identify.identify_cluster's mirror on it: first call (kmer.fa text parse, index build,
 image cache written), a second process-cold call (image cache read) and the phases of each
-(database image, FASTQ ingest + scan, tree walk).  Usage: bench_cli.py [n_reads] [n_leaves] [sampled|contiguous]"""
+(database image, FASTQ ingest + scan, tree walk).  Usage: bench_cli.py [n_reads] [n_leaves] [sampled|contiguous] [gz[-LEVEL]]"""
 import json
 import os
 import shutil
@@ -77,6 +77,22 @@ def main():
         write_fastq(r[: half * 151], half, fq[0])
         write_fastq(r[half * 151:], n_reads - half, fq[1])
         out["fastq_bytes"] = sum(os.path.getsize(p) for p in fq)
+        if len(sys.argv) > 4 and sys.argv[4].startswith("gz"):         # gz[-LEVEL]: the sample as a .fastq.gz pair (gzip -1 by default)
+            import subprocess
+            lvl = "-" + (sys.argv[4].split("-")[1] if "-" in sys.argv[4] else "1")
+            # (a constant quality line deflates to nothing: Phred values that fall off along the read, with noise)
+            rs = np.random.RandomState(5)
+            for p in fq:
+                a = np.fromfile(p, np.uint8).reshape(-1, 307)
+                q = np.clip(38 - np.abs(rs.normal(0, 4, size=(a.shape[0], 150))).astype(np.int64) - (np.arange(150) // 30), 2, 40) + 33
+                a[:, 156:306] = q.astype(np.uint8)
+                a.tofile(p)
+                del a, q
+            t1 = time.perf_counter()
+            pr = [subprocess.Popen(["gzip", lvl, p]) for p in fq]
+            assert all(q.wait() == 0 for q in pr)
+            fq = [p + ".gz" for p in fq]
+            out["gzip"] = dict(level=lvl, seconds=round(time.perf_counter() - t1, 1), gz_bytes=sum(os.path.getsize(p) for p in fq))
         del r, spec
         torch.cuda.empty_cache()
         out["setup_s"] = round(time.perf_counter() - t0, 1)
