@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -688,10 +689,10 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
 // B: every listed chunk from its entry to the next entry (or the end of the stream)
 __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t in_n, const uint64_t *start, const uint64_t *stop,
                                                      uint32_t n_chunks, uint16_t *sym, const uint64_t *sym_off, const uint64_t *sym_cap,
-                                                     uint64_t *out_len, uint64_t *end_bit, int *status)
+                                                     uint64_t *out_len, uint64_t *end_bit, int *status, const uint32_t *only)
 {
     __shared__ WaveState S;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = only ? only[blockIdx.x] : blockIdx.x;      // (a second pass inflates the changed chunks only)
     if (c >= n_chunks) return;
     const int lane = threadIdx.x & 63;
 #ifdef SS_GZ_TIMING
@@ -980,9 +981,9 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
     int *d_status = nullptr;
     uint16_t *d_map[2] = {nullptr, nullptr};
-    uint32_t *d_more = nullptr;
+    uint32_t *d_more = nullptr, *d_todo = nullptr;
     auto cleanup = [&](bool keep_text) {
-        void *scratch[] = {d_in, d_win, d_entry, d_meta, d_sym, d_crc, d_tab, d_status, d_map[0], d_map[1], d_more};
+        void *scratch[] = {d_in, d_win, d_entry, d_meta, d_sym, d_crc, d_tab, d_status, d_map[0], d_map[1], d_more, d_todo};
         for (void *q : scratch) if (q) hipFreeAsync(q, st);
         hipStreamSynchronize(st);
         hipStreamDestroy(st);
@@ -994,7 +995,31 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     };
 #define GI(call) do { if ((call) != hipSuccess) { cleanup(false); return no(#call); } } while (0)
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
-    GI(h2d(d_in, in, in_n) ? hipSuccess : hipErrorUnknown);
+    if (in_n < (64ull << 20)) {
+        GI(h2d(d_in, in, in_n) ? hipSuccess : hipErrorUnknown);
+    } else {
+        // the file image is pageable (a mapping of the page cache): the runtime stages it through its own pinned buffers
+        // on the CALLING thread, ~8 GB/s -- four threads, four slices, four streams
+        GI(hipStreamSynchronize(st));                        // the allocation is stream-ordered
+        int device = 0;
+        hipGetDevice(&device);
+        constexpr unsigned T = 4;
+        std::atomic<int> failed(0);
+        std::vector<std::thread> pool;
+        const uint64_t slice = ((in_n / T) + 4095) & ~4095ull;
+        for (unsigned t = 0; t < T; t++)
+            pool.emplace_back([&, t] {
+                const uint64_t a = std::min<uint64_t>(in_n, t * slice), e = std::min<uint64_t>(in_n, a + slice);
+                hipStream_t s2 = nullptr;
+                if (e <= a) return;
+                if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
+                    hipMemcpyAsync(d_in + a, in + a, e - a, hipMemcpyHostToDevice, s2) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess)
+                    failed = 1;
+                if (s2) hipStreamDestroy(s2);
+            });
+        for (auto &th : pool) th.join();
+        if (failed) { cleanup(false); return no("input copy"); }
+    }
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
     GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
@@ -1074,18 +1099,29 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     //    chunk in front of it runs past it (-21): the entry is dropped.
     //  * A file of several members (lanes joined with `cat a.gz b.gz`): the chunk that meets a final block before its
     //    stop (-20) ends a member if a trailer and a gzip header follow; the next member's first block becomes a chunk.
+    std::vector<uint32_t> todo;                                // empty = all chunks
+    status.assign(nc, 0);
+    out_len.assign(nc, 0); end_bit.assign(nc, 0);
     for (int attempt = 0;; attempt++) {
         GI(h2d(d_start, start.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
         GI(h2d(d_stop, stop.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
         GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
         GI(h2d(d_cap, cap.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+        if (!todo.empty()) {                                   // what the other chunks produced stays as it is
+            GI(h2d(d_status, status.data(), (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
+            GI(h2d(d_len, out_len.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+            GI(h2d(d_end, end_bit.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+            if (!d_todo) GI(hipMallocAsync((void **)&d_todo, (uint64_t)nc_alloc * 4, st));
+            GI(h2d(d_todo, todo.data(), todo.size() * 4) ? hipSuccess : hipErrorUnknown);
+        }
+        const uint32_t n_run = todo.empty() ? nc : (uint32_t)todo.size();
         if (getenv("SS_GZ_COUNTONLY")) {         // timing experiment: the decode without any output
-            hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status);
+            hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status,
+                               todo.empty() ? (const uint32_t *)nullptr : d_todo);
             lap("inflate (count only)");
         }
-        hipLaunchKernelGGL(inflate_kernel, dim3(nc), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status);
-        status.assign(nc, 0);
-        out_len.assign(nc, 0); end_bit.assign(nc, 0); text_off.assign(nc, 0);
+        hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status,
+                           todo.empty() ? (const uint32_t *)nullptr : d_todo);
         GI(d2h(status.data(), d_status, (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
         GI(d2h(out_len.data(), d_len, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
         GI(d2h(end_bit.data(), d_end, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
@@ -1100,17 +1136,32 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
             fprintf(stderr, "[ginflate] matches %llu (symbols %llu), beyond the ring %llu, into the unknown window %llu; windows %llu\n", t[6], t[7], t[8], t[9], t[5]);
         }
 #endif
+        // the new chunk list, with what the unchanged chunks produced; `again`: positions in it that must be inflated (again)
         std::vector<Chunk> nxt;
+        std::vector<uint64_t> n_off, n_cap, n_len, n_end;
+        std::vector<int> n_status;
+        std::vector<uint32_t> again;
         std::vector<char> drop(nc, 0);
         uint32_t n_drop = 0, n_members = 0;
+        bool relayout = false;                                 // new chunks need room of their own: lay everything out anew
+        auto keep = [&](uint32_t c, const Chunk &a) {
+            nxt.push_back(a); n_off.push_back(off[c]); n_cap.push_back(cap[c]); n_len.push_back(out_len[c]); n_end.push_back(end_bit[c]);
+            n_status.push_back(status[c]);
+        };
         for (uint32_t c = 0; c < nc; c++) {
             if (drop[c]) continue;                                     // its own outcome means nothing
             const uint64_t e = (end_bit[c] + 7) / 8;
-            if (status[c] == (ch[c].last ? 1 : 0) && (!ch[c].last || e == ch[c].trailer)) { nxt.push_back(ch[c]); continue; }
-            if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry
+            if (status[c] == (ch[c].last ? 1 : 0) && (!ch[c].last || e == ch[c].trailer)) { keep(c, ch[c]); continue; }
+            if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry: the two chunks become one
                 drop[c + 1] = 1;
                 n_drop++;
-                nxt.push_back(ch[c]);
+                Chunk a = ch[c];
+                a.last = ch[c + 1].last;
+                a.trailer = ch[c + 1].trailer;
+                keep(c, a);
+                if (off[c + 1] == off[c] + cap[c]) n_cap.back() += cap[c + 1];      // their symbol regions are neighbours
+                else relayout = true;
+                again.push_back((uint32_t)nxt.size() - 1);
                 continue;
             }
             if (status[c] == -20 || (status[c] == 1 && ch[c].last)) {  // a final block before the next entry / before the file's end
@@ -1119,24 +1170,40 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
                 Chunk a = ch[c];
                 a.last = true;
                 a.trailer = e;
-                nxt.push_back(a);
+                keep(c, a);
                 const uint64_t d = (e + 8 + hdr) * 8;                  // the next member's first block
                 for (uint32_t k = c + 1; k < nc && ch[k].start < d; k++) { drop[k] = 1; n_drop++; }      // "entries" within trailer and header
                 nxt.push_back(Chunk{d, true, ch[c].last, ch[c].trailer});      // (it ends the file if the split chunk did)
                 n_members++;
+                relayout = true;
                 continue;
             }
             cleanup(false);
             return no("chunk status", status[c] * 1000000ll + c);
         }
         if (!n_drop && !n_members) break;
-        if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block, %u further members found: chunks inflated again\n", n_drop, n_members);
+        if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block, %u further members found: %s inflated again\n", n_drop, n_members,
+                           relayout ? "all chunks" : "their chunks");
         if (attempt >= 6 || nxt.size() > nc_alloc) { cleanup(false); return no("chunk list", (long long)nxt.size()); }
         ch.swap(nxt);
         nc = (uint32_t)ch.size();
-        lay_out();
-        if (sym_total > sym_alloc) { cleanup(false); return no("symbol budget"); }
+        if (relayout) {
+            lay_out();
+            if (sym_total > sym_alloc) { cleanup(false); return no("symbol budget"); }
+            todo.clear();
+            status.assign(nc, 0);
+            out_len.assign(nc, 0); end_bit.assign(nc, 0);
+        } else {
+            off.swap(n_off); cap.swap(n_cap); out_len.swap(n_len); end_bit.swap(n_end); status.swap(n_status);
+            start.clear(); stop.clear();
+            for (uint32_t c = 0; c < nc; c++) {
+                start.push_back(ch[c].start | (ch[c].fresh ? 1ull << 63 : 0ull));
+                stop.push_back(ch[c].last ? ~0ull : ch[c + 1].start);
+            }
+            todo.swap(again);
+        }
     }
+    text_off.assign(nc, 0);
     // members: text ranges, trailers
     struct Member { uint64_t at, len; uint32_t crc, isize; };
     std::vector<Member> members;
