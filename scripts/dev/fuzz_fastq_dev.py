@@ -1,0 +1,59 @@
+"""Differential fuzz of the device FASTQ extraction (ss_fastq_dev.hip, behind a .gz input) against the host grammar
+(ss_fastx_to_flat): FASTQ-like texts with random defects.  Records of the resident read set must be equal either way."""
+import gzip, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from strainscan_amd import _lib as L
+L.require_gpu()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+lut = np.frombuffer(b"ACGTNacgtn", np.uint8)
+t_end = time.time() + budget
+n_files = n_strict = 0
+while time.time() < t_end:
+    rs = np.random.RandomState(seed)
+    nl = b"\r\n" if rs.rand() < 0.15 else b"\n"
+    defect_rate = float(rs.choice([0.0, 0.0, 1e-4, 1e-3, 1e-2]))
+    fasta = rs.rand() < 0.1
+    recs = []
+    n = int(rs.randint(9000, 16000))
+    for i in range(n):
+        ln = int(rs.randint(0, 3)) if rs.rand() < 0.01 else int(rs.randint(35, 400))
+        sq = lut[rs.randint(0, 10 if rs.rand() < 0.1 else 4, ln)].tobytes()
+        q = bytes(rs.randint(33, 74, ln).astype(np.uint8))
+        if fasta:
+            recs.append(b">s%d" % i + nl + sq + nl)
+            continue
+        d = rs.rand() < defect_rate
+        kind = int(rs.randint(0, 8)) if d else -1
+        if kind == 0: q = q[:-1]                                   # short quality
+        if kind == 1: recs.append(nl)                              # blank line in front
+        if kind == 2 and ln > 10: sq = sq[:ln // 2] + nl + sq[ln // 2:]      # wrapped sequence
+        if kind == 3: q = q + b"!"                                  # long quality
+        plus = b"+" + (b"s%d" % i if rs.rand() < 0.2 else b"")
+        if kind == 4: plus = b""                                    # no plus line (and no newline for it)
+        if kind == 5 and ln > 0: q = b"@" + q[1:]                   # quality starts with '@'
+        if kind == 6 and ln > 0: sq = b"+" + sq[1:]                 # sequence starts with '+'
+        head = b"@s%d comment %d" % (i, i) if kind != 7 else b"s%d" % i           # no '@'
+        recs.append(head + nl + sq + nl + (plus + nl if kind != 4 else b"") + q + nl)
+    text = b"".join(recs)
+    if rs.rand() < 0.3: text = text[:-len(nl)]
+    want_flat, want_n = L.fastx_to_flat(text)
+    want = sorted(r for r in want_flat.split(b"\n") if r)
+    p = "/tmp/fuzz_fq_%d.fq.gz" % os.getpid()
+    open(p, "wb").write(gzip.compress(text, 1))
+    a0 = L.lib()
+    got = {}
+    for mode in ("1", "0"):
+        os.environ["SS_GZ_GPU"] = mode
+        rset = L.ReadSet([p], 0, 1)
+        got[mode] = (sorted(r for r in rset.read_back().split(b"\n") if r), rset.info()["n_records"])
+        rset.close()
+    if not (got["1"][0] == got["0"][0] == want and got["1"][1] == got["0"][1] == want_n):
+        print("MISMATCH seed", seed, "records", len(got["1"][0]), len(got["0"][0]), len(want), "n", got["1"][1], got["0"][1], want_n, flush=True)
+        sys.exit(1)
+    n_files += 1
+    n_strict += defect_rate == 0.0 and not fasta
+    seed += 1
+os.remove(p)
+print("fuzz: %d files (%d without defects), device == host grammar == ss_fastx_to_flat" % (n_files, n_strict))
