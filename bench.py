@@ -592,6 +592,14 @@ def main(argv=None):
     if os.path.exists(pmc_path) and args.reads == 20_000_000 and args.leaves == 823:
         with open(pmc_path) as f:
             pmc = json.load(f).get(pmc_key, {})
+    # ... and they describe THIS kernel only while it still runs as it did when they were collected: if the live kernel time
+    # has moved by more than 5 % from the one recorded with them, they are not reported (traffic = null)
+    pmc_ms = pmc.get("kernel_ms_at_collection")
+    pmc_stale = bool(pmc) and pmc_ms is not None and abs(kern_ms - pmc_ms) > 0.05 * pmc_ms
+    if pmc_stale:
+        log("[bench] profiles/pmc_traffic.json[%s] was collected at %.3f ms per launch, the kernel now takes %.3f ms: counters not reported"
+            % (pmc_key, pmc_ms, kern_ms))
+        pmc = dict(stale=True, kernel_ms_at_collection=pmc_ms, source=pmc.get("source"), commit=pmc.get("commit"))
     traffic = pmc.get("traffic_gb_per_launch")
     compulsory_gb = (reads.numel() + 8.0 * hits) / 1e9          # every base once + 4 B read + 4 B write per hit
     roofline = dict(bound="hbm", kernel="scan_mini_kernel" if layout == "mini" else "scan_kernel",
@@ -610,7 +618,7 @@ def main(argv=None):
                         read_requests_per_launch=pmc.get("rdreq_per_launch"),
                         achieved_gsectors_s=(round(pmc["rdreq_per_launch"] / (kern_ms * 1e-3) / 1e9, 1) if pmc.get("rdreq_per_launch") else None)),
                     traffic_source=(dict(file="profiles/pmc_traffic.json", key=pmc_key, summary=pmc.get("source"),
-                                         commit=pmc.get("commit")) if pmc else None))
+                                         commit=pmc.get("commit"), kernel_ms_at_collection=pmc_ms, stale=pmc_stale) if pmc else None))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
