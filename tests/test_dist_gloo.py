@@ -77,15 +77,22 @@ def _share_worker(rank, world, port, gz_path, plain_path, out_dir):
     assert not os.path.exists(use[0])                              # rank 0 removed it after everyone had read it
     os.environ["SS_GZ_SHARE"] = "0"
     assert sdist.share_inflated([gz_path])[0] == [gz_path]
+    os.environ["SS_GZ_SHARE"] = "1"
+    os.environ["SS_GZ_GPU"] = "1"                                  # the device path takes a file of this size: nothing to share
+    use2, cleanup2 = sdist.share_inflated([gz_path, plain_path])
+    assert use2 == [gz_path, plain_path]
+    cleanup2()
     dist.destroy_process_group()
 
 
 @pytest.mark.skipif(not os.path.isdir("/dev/shm"), reason="no tmpfs")
-def test_two_ranks_share_one_inflate(tmp_path):
-    """dist.share_inflated: rank 0 inflates a .gz once into /dev/shm, both ranks get the same plain file with the right
-    bytes, plain inputs pass through, cleanup removes the file."""
+def test_two_ranks_share_one_inflate(tmp_path, monkeypatch):
+    """dist.share_inflated, for .gz inputs the device inflater does not take (here: SS_GZ_GPU=0): rank 0 inflates a .gz once
+    into /dev/shm, both ranks get the same plain file with the right bytes, plain inputs pass through, cleanup removes
+    the file.  With the device path on (the default) a file of 1 MB and more is left to the ranks' GPUs."""
     import gzip
     import zlib
+    monkeypatch.setenv("SS_GZ_GPU", "0")
     rs = np.random.RandomState(4)
     lut = np.frombuffer(b"ACGT", np.uint8)
     text = b"".join(b"@r%d\n" % i + lut[rs.randint(0, 4, size=150)].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(20000))
