@@ -689,7 +689,7 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
 // B: every listed chunk from its entry to the next entry (or the end of the stream)
 __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t in_n, const uint64_t *start, const uint64_t *stop,
                                                      uint32_t n_chunks, uint16_t *sym, const uint64_t *sym_off, const uint64_t *sym_cap,
-                                                     uint64_t *out_len, uint64_t *end_bit, int *status, const uint32_t *only)
+                                                     uint64_t *out_len, uint64_t *end_bit, int *status, const uint32_t *only, uint32_t max_over)
 {
     __shared__ WaveState S;
     const uint32_t c = only ? only[blockIdx.x] : blockIdx.x;      // (a second pass inflates the changed chunks only)
@@ -703,19 +703,27 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
     const bool fresh = (s0 >> 63) != 0;                     // the first chunk of a member: nothing lies in front of it
     sb_init(b, in, in_n, s0 & ~(1ull << 63));
     OutState o{sym ? sym + sym_off[c] : nullptr, sym_cap[c], 0, 0};
-    const uint64_t stop_at = stop[c];
+    // A block that ends BEHIND the next chunk's entry: that entry was no block's start (a position inside a block passes the
+    // sync search about once in a million candidates).  The chunk simply goes on to the entry after it -- its symbol
+    // region (12x its input) has room for two or three chunks of FASTQ -- and says how many entries it ran over; within
+    // a block it gives up beyond the second entry ahead (what itself started at a wrong entry decodes garbage).
+    const uint64_t stop0 = stop[c];
+    uint64_t stop_at = stop0;
+    const uint64_t hard = stop[min(c + max_over, n_chunks - 1)];
+    uint32_t skipped = 0;
     int st = 0;
     for (;;) {
-        const int r = inflate_block(S, b, o, fresh, ~0ull, stop_at);
-        if (r < 0) { st = r; break; }
+        const int r = inflate_block(S, b, o, fresh, ~0ull, hard);
+        if (r < 0) { st = (r == -9 && sb_bitpos(b) > stop0) ? -21 : r; break; }      // (no room for more than its own: the host merges the two)
         const uint64_t pos = sb_bitpos(b);
-        if (r == 1) { st = (stop_at == ~0ull) ? 1 : -20; break; }      // the final block ends the LAST chunk only
+        while (pos > stop_at && skipped < max_over && c + skipped + 1 < n_chunks) stop_at = stop[c + ++skipped];
+        if (r == 1) { st = (stop_at == ~0ull) ? 1 : -20; break; }      // the final block ends the LAST chunk of a member only
         if (pos == stop_at) { st = 0; break; }
         if (pos > stop_at) { st = -21; break; }
     }
     if (st >= 0 && o.out) out_flush(S, o, o.n);
     const uint64_t n = o.n;
-    if (lane == 0) { out_len[c] = n; end_bit[c] = sb_bitpos(b); status[c] = st; }
+    if (lane == 0) { out_len[c] = n; end_bit[c] = sb_bitpos(b); status[c] = st >= 0 ? st + 16 * (int)skipped : st; }
 #ifdef SS_GZ_TIMING
     if (lane == 0) {
         for (int i = 0; i < 10; i++) atomicAdd(&g_gz_t[i], (unsigned long long)o.t[i]);
@@ -1100,6 +1108,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     //  * A file of several members (lanes joined with `cat a.gz b.gz`): the chunk that meets a final block before its
     //    stop (-20) ends a member if a trailer and a gzip header follow; the next member's first block becomes a chunk.
     std::vector<uint32_t> todo;                                // empty = all chunks
+    const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : 2u;      // (test hook: wrong entries are then handled by the host only)
     status.assign(nc, 0);
     out_len.assign(nc, 0); end_bit.assign(nc, 0);
     for (int attempt = 0;; attempt++) {
@@ -1117,11 +1126,11 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         const uint32_t n_run = todo.empty() ? nc : (uint32_t)todo.size();
         if (getenv("SS_GZ_COUNTONLY")) {         // timing experiment: the decode without any output
             hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status,
-                               todo.empty() ? (const uint32_t *)nullptr : d_todo);
+                               todo.empty() ? (const uint32_t *)nullptr : d_todo, max_over);
             lap("inflate (count only)");
         }
         hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status,
-                           todo.empty() ? (const uint32_t *)nullptr : d_todo);
+                           todo.empty() ? (const uint32_t *)nullptr : d_todo, max_over);
         GI(d2h(status.data(), d_status, (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
         GI(d2h(out_len.data(), d_len, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
         GI(d2h(end_bit.data(), d_end, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
@@ -1142,7 +1151,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         std::vector<int> n_status;
         std::vector<uint32_t> again;
         std::vector<char> drop(nc, 0);
-        uint32_t n_drop = 0, n_members = 0;
+        uint32_t n_drop = 0, n_members = 0, n_over = 0;
         bool relayout = false;                                 // new chunks need room of their own: lay everything out anew
         auto keep = [&](uint32_t c, const Chunk &a) {
             nxt.push_back(a); n_off.push_back(off[c]); n_cap.push_back(cap[c]); n_len.push_back(out_len[c]); n_end.push_back(end_bit[c]);
@@ -1151,7 +1160,25 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         for (uint32_t c = 0; c < nc; c++) {
             if (drop[c]) continue;                                     // its own outcome means nothing
             const uint64_t e = (end_bit[c] + 7) / 8;
-            if (status[c] == (ch[c].last ? 1 : 0) && (!ch[c].last || e == ch[c].trailer)) { keep(c, ch[c]); continue; }
+            if (status[c] >= 0) {
+                // done; `over` entries behind it were positions inside its blocks: their chunks go, nothing is inflated again
+                const uint32_t over = (uint32_t)status[c] >> 4;
+                const int st = status[c] & 15;
+                if (c + over < nc) {
+                    const Chunk &eff = ch[c + over];
+                    if (st == (eff.last ? 1 : 0) && (!eff.last || e == eff.trailer)) {
+                        Chunk a = ch[c];
+                        a.last = eff.last;
+                        a.trailer = eff.trailer;
+                        keep(c, a);
+                        n_status.back() = st;
+                        for (uint32_t k = 1; k <= over; k++) drop[c + k] = 1;
+                        n_over += over;
+                        continue;
+                    }
+                }
+                status[c] = st == 1 ? 1 : -21;                        // (falls through: a member's end, or not explainable)
+            }
             if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry: the two chunks become one
                 drop[c + 1] = 1;
                 n_drop++;
@@ -1181,7 +1208,17 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
             cleanup(false);
             return no("chunk status", status[c] * 1000000ll + c);
         }
-        if (!n_drop && !n_members) break;
+        if (trace && n_over) fprintf(stderr, "[ginflate] %u entries were inside a block: run over\n", n_over);
+        if (!n_drop && !n_members) {
+            if (n_over) {                                              // the shorter chunk list, everything else as it is
+                ch.swap(nxt);
+                nc = (uint32_t)ch.size();
+                off.swap(n_off); cap.swap(n_cap); out_len.swap(n_len); end_bit.swap(n_end); status.swap(n_status);
+                GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+                GI(h2d(d_len, out_len.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
+            }
+            break;
+        }
         if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block, %u further members found: %s inflated again\n", n_drop, n_members,
                            relayout ? "all chunks" : "their chunks");
         if (attempt >= 6 || nxt.size() > nc_alloc) { cleanup(false); return no("chunk list", (long long)nxt.size()); }

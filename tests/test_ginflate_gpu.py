@@ -273,15 +273,19 @@ def test_device_fastq_extraction_equals_the_host_grammar(L, tmp_path, monkeypatc
 def test_a_wrong_entry_point_is_dropped_and_the_chunks_inflated_again(L, tmp_path, monkeypatch, fastq_text):
     """The sync search accepts a position where a valid dynamic header parses and a few hundred symbols decode; about
     one candidate in a million that passes lies INSIDE a block (seen on a 264 MB file).  The chunk in front of such an
-    entry runs past it; the entry is dropped and the chunks are inflated again.  SS_GZ_INJECT_ENTRY plants a wrong
-    entry: same text, still verified by CRC-32 and ISIZE."""
+    entry ends its block behind it: it goes on to the entry after that and the wrong one's chunk is dropped (or, when the
+    symbol region has no room, the two chunks are merged and inflated again).  SS_GZ_INJECT_ENTRY plants a wrong entry:
+    same text, still verified by CRC-32 and ISIZE."""
     p = tmp_path / "a.fq.gz"
     p.write_bytes(gzip.compress(fastq_text, 6))
-    for chunk in ("3", "17", "40"):
-        monkeypatch.setenv("SS_GZ_INJECT_ENTRY", chunk)
-        rc, got = _gpu_inflate(L, p)
-        assert rc == SS_OK, chunk
-        assert got == fastq_text, chunk
+    for host_only in (False, True):          # the chunk runs over the wrong entry itself / the host merges the two chunks
+        if host_only:
+            monkeypatch.setenv("SS_GZ_NO_RUNOVER", "1")
+        for chunk in ("3", "17", "40"):
+            monkeypatch.setenv("SS_GZ_INJECT_ENTRY", chunk)
+            rc, got = _gpu_inflate(L, p)
+            assert rc == SS_OK, (chunk, host_only)
+            assert got == fastq_text, (chunk, host_only)
 
 
 @pytest.mark.parametrize("layout", ["two", "lanes", "small_middle", "small_last", "levels"])
