@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <vector>
 
 namespace {
 
@@ -223,7 +224,9 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     // (a small file is inflated on the host before the device path has allocated its buffers)
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < (1 << 20)) { close(fd); return 1; }
     const uint64_t in_n = (uint64_t)sb.st_size;
-    const uint8_t *in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);      // (faulting the pages in one by one during the copy: 8 GB/s)
+    // (a plain mapping, copied by one thread: a populated mapping, a read into memory and four copy threads were all
+    //  slower -- 0.157 / 0.233 / 0.144 s against 0.129 s for a pair of 290 MB files, scripts/dev/t_gz_input_ab.py)
+    const uint8_t *in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (in == MAP_FAILED) return 1;
     char *d_text = nullptr;

@@ -1003,31 +1003,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     };
 #define GI(call) do { if ((call) != hipSuccess) { cleanup(false); return no(#call); } } while (0)
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
-    if (in_n < (64ull << 20)) {
-        GI(h2d(d_in, in, in_n) ? hipSuccess : hipErrorUnknown);
-    } else {
-        // the file image is pageable (a mapping of the page cache): the runtime stages it through its own pinned buffers
-        // on the CALLING thread, ~8 GB/s -- four threads, four slices, four streams
-        GI(hipStreamSynchronize(st));                        // the allocation is stream-ordered
-        int device = 0;
-        hipGetDevice(&device);
-        constexpr unsigned T = 4;
-        std::atomic<int> failed(0);
-        std::vector<std::thread> pool;
-        const uint64_t slice = ((in_n / T) + 4095) & ~4095ull;
-        for (unsigned t = 0; t < T; t++)
-            pool.emplace_back([&, t] {
-                const uint64_t a = std::min<uint64_t>(in_n, t * slice), e = std::min<uint64_t>(in_n, a + slice);
-                hipStream_t s2 = nullptr;
-                if (e <= a) return;
-                if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
-                    hipMemcpyAsync(d_in + a, in + a, e - a, hipMemcpyHostToDevice, s2) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess)
-                    failed = 1;
-                if (s2) hipStreamDestroy(s2);
-            });
-        for (auto &th : pool) th.join();
-        if (failed) { cleanup(false); return no("input copy"); }
-    }
+    GI(h2d(d_in, in, in_n) ? hipSuccess : hipErrorUnknown);
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
     GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
