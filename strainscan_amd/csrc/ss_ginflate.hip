@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -801,11 +802,13 @@ __global__ __launch_bounds__(1024) void group_maps_kernel(const uint16_t *tails,
     }
 }
 // gwin[g] = the window in front of the first chunk of group g (bytes)
-__global__ __launch_bounds__(1024) void group_windows_kernel(const uint16_t *maps, uint32_t n_chunks, uint32_t group, uint32_t n_groups, uint8_t *gwin)
+__global__ __launch_bounds__(1024) void group_windows_kernel(const uint16_t *maps, uint32_t n_chunks, uint32_t group, uint32_t n_groups,
+                                                             const uint8_t *w0, uint8_t *gwin)
 {
     __shared__ uint8_t w[WSIZE];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < WSIZE; i += 1024) w[i] = 0;     // chunk 0 has no unknown window: never read
+    for (uint32_t i = tid; i < WSIZE; i += 1024) w[i] = w0 ? w0[i] : (uint8_t)0;     // the 32 KB in front of the first chunk: the end of
+                                                                                  // the text so far (a file's first chunk: nothing, never read)
     __syncthreads();
     for (uint32_t g = 0; g < n_groups; g++) {
         for (uint32_t i = tid; i < WSIZE; i += 1024) gwin[(uint64_t)g * WSIZE + i] = w[i];
@@ -823,12 +826,12 @@ __global__ __launch_bounds__(1024) void group_windows_kernel(const uint16_t *map
         __syncthreads();
     }
 }
-// win[c + 1] = bytes of the composed map of chunk c over its group's start window; win[0] = nothing
+// win[c + 1] = bytes of the composed map of chunk c over its group's start window; win[0] = the window in front of the segment
 __global__ __launch_bounds__(256) void windows_kernel(const uint16_t *maps, uint32_t n_chunks, uint32_t group, const uint8_t *gwin, uint8_t *win)
 {
     const uint32_t c = blockIdx.y;
     const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-    uint2 o = make_uint2(0u, 0u);
+    uint2 o = *reinterpret_cast<const uint2 *>(gwin + i0);      // the first chunk: what lies in front of the segment (group 0's start)
     if (c) {
         const uint4 v = *reinterpret_cast<const uint4 *>(maps + (uint64_t)(c - 1) * WSIZE + i0);
         if ((v.x | v.y | v.z | v.w) & 0x80008000u) {
@@ -860,6 +863,13 @@ __global__ __launch_bounds__(256) void bytes_kernel(const uint16_t *sym, const u
         const uint16_t s = sy[i];
         dst[i] = (s & UNRES) ? w[s & (WSIZE - 1)] : (uint8_t)s;
     }
+}
+
+// the last 32 KB of the text so far = the window in front of the next segment's first chunk
+__global__ __launch_bounds__(256) void lastwin_kernel(const uint8_t *text, uint64_t total, uint8_t *prev)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < WSIZE) prev[i] = total >= WSIZE - i ? text[total - (WSIZE - i)] : (uint8_t)0;
 }
 
 // CRC-32 (zlib's polynomial) of the text's segments [seg_at[s], seg_at[s] + seg_len[s]), one lane per segment, byte-wise
@@ -948,19 +958,72 @@ std::vector<Bgzf> bgzf_members(const uint8_t *p, uint64_t n)
     return out;
 }
 
+// Scratch of one call, kept for the next one: the per-segment symbol streams, window maps and chunk arrays.  (Allocating
+// and freeing tens of GB per file is what this replaces: on this platform a large hipMalloc that follows a large hipFree
+// can take 1.6 s -- scripts/dev/t_bigalloc.py -- and a 1 GB .gz needed 28 GB of symbols in one piece.)  At most two are
+// kept (the two mates of a pair are inflated concurrently), ~4.5 GB each, until the process ends.
+struct Arena {
+    uint64_t cap_chunks = 0, sym_elems = 0;
+    uint16_t *sym = nullptr, *map[2] = {nullptr, nullptr};
+    uint64_t *meta = nullptr;
+    int *status = nullptr;
+    uint8_t *win = nullptr, *gwin = nullptr, *prev = nullptr;
+    uint32_t *todo = nullptr;
+};
+std::mutex g_arena_mu;
+std::vector<Arena *> g_arena_free;
+void arena_destroy(Arena *a)
+{
+    if (!a) return;
+    void *q[] = {a->sym, a->map[0], a->map[1], a->meta, a->status, a->win, a->gwin, a->prev, a->todo};
+    for (void *x : q) if (x) hipFree(x);
+    delete a;
+}
+Arena *arena_get(uint64_t cap_chunks, uint64_t sym_elems)
+{
+    Arena *a = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_arena_mu);
+        if (!g_arena_free.empty()) { a = g_arena_free.back(); g_arena_free.pop_back(); }
+    }
+    if (a && a->cap_chunks >= cap_chunks && a->sym_elems >= sym_elems) return a;
+    arena_destroy(a);
+    a = new (std::nothrow) Arena();
+    if (!a) return nullptr;
+    a->cap_chunks = cap_chunks;
+    a->sym_elems = sym_elems;
+    const uint64_t n_groups = cap_chunks / 8 + 2;
+    const bool ok = hipMalloc((void **)&a->sym, sym_elems * 2) == hipSuccess && hipMalloc((void **)&a->map[0], cap_chunks * WSIZE * 2) == hipSuccess &&
+                    hipMalloc((void **)&a->map[1], cap_chunks * WSIZE * 2) == hipSuccess && hipMalloc((void **)&a->meta, cap_chunks * 8 * 7) == hipSuccess &&
+                    hipMalloc((void **)&a->status, cap_chunks * 4) == hipSuccess && hipMalloc((void **)&a->win, cap_chunks * WSIZE) == hipSuccess &&
+                    hipMalloc((void **)&a->gwin, n_groups * WSIZE) == hipSuccess && hipMalloc((void **)&a->prev, WSIZE) == hipSuccess &&
+                    hipMalloc((void **)&a->todo, cap_chunks * 4) == hipSuccess;
+    if (!ok) { arena_destroy(a); return nullptr; }
+    return a;
+}
+void arena_put(Arena *a)
+{
+    if (!a) return;
+    {
+        std::lock_guard<std::mutex> g(g_arena_mu);
+        if (g_arena_free.size() < 2) { g_arena_free.push_back(a); return; }
+    }
+    arena_destroy(a);
+}
+
 }  // namespace
 
 namespace ss {
 
-// The file image `in` (host) inflated on the device.  true: *text_dev (hipMalloc) holds *len bytes, verified against the
-// trailer.  false: not handled here (the caller inflates on the host).
+// The file image `in` (host) inflated on the device.  true: *text_dev (hipMalloc) holds *len bytes, every member verified
+// against its trailer.  false: not handled here (the caller inflates on the host).
 static std::atomic<uint64_t> g_handled{0}, g_declined{0};
 
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
-    // own stream and stream-ordered scratch memory: the two mates of a paired sample are inflated by two host threads, and
-    // neither the legacy default stream nor hipFree's device-wide wait may serialise them
+    // own stream: the two mates of a paired sample are inflated by two host threads, and the legacy default stream would
+    // serialise them
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -969,52 +1032,55 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         hipStreamSynchronize(st);
         fprintf(stderr, "[ginflate] %-18s at %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    auto no = [&](const char *why, long long a = 0) {
-        if (trace) fprintf(stderr, "[ginflate] not handled: %s (%lld)\n", why, a);
-        g_declined++;
-        return false;
-    };
-    const uint64_t data_off = gzip_header_len(in, in_n);
-    if (!data_off) return no("header");
-    uint64_t chunk_bytes = 32 << 10, ratio = 12;
-    if (const char *e = getenv("SS_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));
-    if (const char *e = getenv("SS_GZ_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
-    const uint64_t data_n = in_n - 8 - data_off;
-    chunk_bytes = std::max<uint64_t>(chunk_bytes, data_n / 32768 + 1);                  // grid dimensions
-    const uint32_t n_chunks0 = (uint32_t)std::max<uint64_t>(1, (data_n + chunk_bytes - 1) / chunk_bytes);
-
-    uint8_t *d_in = nullptr, *d_win = nullptr, *d_text = nullptr;
-    uint64_t *d_entry = nullptr, *d_meta = nullptr;
-    uint16_t *d_sym = nullptr;
+    uint8_t *d_in = nullptr, *d_text = nullptr;
+    uint64_t *d_entry = nullptr;
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
-    int *d_status = nullptr;
-    uint16_t *d_map[2] = {nullptr, nullptr};
-    uint32_t *d_more = nullptr, *d_todo = nullptr;
+    Arena *A = nullptr;
     auto cleanup = [&](bool keep_text) {
-        void *scratch[] = {d_in, d_win, d_entry, d_meta, d_sym, d_crc, d_tab, d_status, d_map[0], d_map[1], d_more, d_todo};
+        void *scratch[] = {d_in, d_entry, d_crc, d_tab};
         for (void *q : scratch) if (q) hipFreeAsync(q, st);
         hipStreamSynchronize(st);
         hipStreamDestroy(st);
-        if (!keep_text) hipFree(d_text);
+        arena_put(A);
+        A = nullptr;
+        if (!keep_text && d_text) hipFree(d_text);
+    };
+    auto no = [&](const char *why, long long a = 0) {
+        if (trace) fprintf(stderr, "[ginflate] not handled: %s (%lld)\n", why, a);
+        g_declined++;
+        cleanup(false);
+        return false;
     };
     auto h2d = [&](void *dst, const void *src, uint64_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess; };
     auto d2h = [&](void *dst, const void *src, uint64_t bytes) {
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     };
-#define GI(call) do { if ((call) != hipSuccess) { cleanup(false); return no(#call); } } while (0)
+#define GI(call) do { if ((call) != hipSuccess) return no(#call); } while (0)
+#define GB(call) do { if (!(call)) return no(#call); } while (0)
+    const uint64_t data_off = gzip_header_len(in, in_n);
+    if (!data_off) return no("header");
+    uint64_t chunk_bytes = 32 << 10, ratio = 12, seg_bytes = 128ull << 20;
+    if (const char *e = getenv("SS_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));
+    if (const char *e = getenv("SS_GZ_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
+    if (const char *e = getenv("SS_GZ_SEG_KB")) seg_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) << 10;      // (tests: many segments)
+    const uint64_t data_n = in_n - 8 - data_off;
+    seg_bytes = std::max(seg_bytes, 8 * chunk_bytes);
+    const uint64_t n_chunks0_ = std::max<uint64_t>(1, (data_n + chunk_bytes - 1) / chunk_bytes);
+    if (n_chunks0_ > 0x7FFFFFF0ull) return no("size");
+    const uint32_t n_chunks0 = (uint32_t)n_chunks0_;
+
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
-    GI(h2d(d_in, in, in_n) ? hipSuccess : hipErrorUnknown);
+    GB(h2d(d_in, in, in_n));
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
     GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
     const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
-    if (bgzf.size() > 60000) { cleanup(false); return no("bgzf members", (long long)bgzf.size()); }      // (a grid dimension)
     uint64_t probe = 512;
     if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
     std::vector<uint64_t> entry(n_chunks0);
     if (bgzf.empty()) {
         hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe);
-        GI(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8) ? hipSuccess : hipErrorUnknown);
+        GB(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8));
     }
     if (trace && bgzf.empty()) {
         unsigned tries = 0;
@@ -1028,237 +1094,299 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         const uint64_t c = (uint64_t)atoll(e);
         if (c > 0 && c < n_chunks0) entry[c] = (data_off + c * chunk_bytes) * 8 + 12345 % (chunk_bytes * 8);
     }
-    // chunks with an entry; a chunk without one belongs to its predecessor.  `fresh`: the first chunk of a gzip member
-    // (nothing in front of it); `last`: it ends with the member's final block, the trailer follows at `trailer`
+    // The file's chunks: one per entry (a chunk of the search without one belongs to its predecessor).  `fresh`: the first
+    // chunk of a gzip member (nothing in front of it); `last`: it ends with the member's final block, the trailer follows
+    // at `trailer`.
     struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; };
-    std::vector<Chunk> ch;
+    std::vector<Chunk> G;
     if (bgzf.empty()) {
         for (uint32_t c = 0; c < n_chunks0; c++)
-            if (entry[c] != ~0ull) ch.push_back(Chunk{entry[c], c == 0, false, 0});
-        ch.back().last = true;
-        ch.back().trailer = in_n - 8;
+            if (entry[c] != ~0ull) G.push_back(Chunk{entry[c], c == 0, false, 0});
+        G.back().last = true;
+        G.back().trailer = in_n - 8;
     } else {
-        for (const Bgzf &m : bgzf) ch.push_back(Chunk{m.data * 8, true, true, m.trailer});
+        for (const Bgzf &m : bgzf) G.push_back(Chunk{m.data * 8, true, true, m.trailer});
         if (trace) fprintf(stderr, "[ginflate] bgzip: %zu members\n", bgzf.size());
     }
-    uint32_t nc = (uint32_t)ch.size();
-    const uint32_t nc_alloc = nc + 64;                       // room for the first chunks of further members
-    std::vector<uint64_t> start, stop, off, cap;
-    uint64_t sym_total = 0;
-    auto lay_out = [&] {
-        start.clear(); stop.clear(); off.clear(); cap.clear();
-        sym_total = 0;
-        for (uint32_t c = 0; c < nc; c++) {
-            start.push_back(ch[c].start | (ch[c].fresh ? 1ull << 63 : 0ull));
-            stop.push_back(ch[c].last ? ~0ull : ch[c + 1].start);
-            const uint64_t cbits = (c + 1 < nc ? ch[c + 1].start : (in_n - 8) * 8) - ch[c].start;
-            const uint64_t cp = (cbits / 8 + 1) * ratio + 4096;
-            off.push_back(sym_total);
-            cap.push_back(cp);
-            sym_total += cp;
-        }
+    entry.clear();
+    entry.shrink_to_fit();
+
+    // The chunks are inflated SEGMENT by segment (seg_bytes of deflate data, 128 MB): the scratch stays a few GB whatever
+    // the file's size, and the text of one segment is complete -- bytes -- before the next one starts, so the 32 KB in
+    // front of a segment's first chunk are simply the end of the text so far.
+    constexpr size_t SEG_CHUNKS = 16384;
+    auto segment_end = [&](size_t gi) {
+        size_t gj = gi + 1;
+        while (gj < G.size() && (G[gj].start - G[gi].start) / 8 < seg_bytes && gj - gi < SEG_CHUNKS) gj++;
+        return gj;
     };
-    lay_out();
-    const uint64_t sym_alloc = sym_total + 64 * (4096 + 64 * ratio);
-    // meta: start, stop, off, cap, out_len, end_bit, text_off
-    GI(hipMallocAsync((void **)&d_meta, (uint64_t)nc_alloc * 8 * 7, st));
-    uint64_t *d_start = d_meta, *d_stop = d_meta + nc_alloc, *d_off = d_meta + 2ull * nc_alloc, *d_cap = d_meta + 3ull * nc_alloc,
-             *d_len = d_meta + 4ull * nc_alloc, *d_end = d_meta + 5ull * nc_alloc, *d_toff = d_meta + 6ull * nc_alloc;
+    uint64_t need_sym = 0, need_chunks = 0;                   // the largest segment decides the scratch
+    for (size_t gi = 0; gi < G.size();) {
+        const size_t gj = segment_end(gi);
+        const uint64_t bytes = ((gj < G.size() ? G[gj].start : (in_n - 8) * 8) - G[gi].start) / 8;
+        need_sym = std::max<uint64_t>(need_sym, (bytes + (gj - gi)) * ratio + (gj - gi) * 4096);
+        need_chunks = std::max<uint64_t>(need_chunks, gj - gi);
+        gi = gj;
+    }
+    const uint64_t cap_chunks = need_chunks + 80;
+    const uint64_t sym_elems = need_sym + need_sym / 4 + 64 * (4096 + 64 * ratio);      // (+ what run-over and further members add)
+    if (sym_elems * 2 > (24ull << 30)) return no("segment", (long long)(sym_elems >> 20));      // (GBs without a single block start)
+    uint64_t text_cap;
     {
-        // symbols (2 B each, `ratio` per input byte), windows and maps (5 x 32 KB per chunk) and the text must fit
+        const uint8_t *t8 = in + in_n - 8;
+        uint64_t guess = (uint64_t)t8[4] | (uint64_t)t8[5] << 8 | (uint64_t)t8[6] << 16 | (uint64_t)t8[7] << 24;      // ISIZE of the last member
+        while (guess < in_n) guess += 1ull << 32;
+        text_cap = (guess <= 16 * in_n ? guess : 3 * in_n) + 64;
         size_t mem_free = 0, mem_total = 0;
         GI(hipMemGetInfo(&mem_free, &mem_total));
-        const uint64_t need = sym_alloc * 2 + (uint64_t)nc_alloc * WSIZE * 5 + in_n * 4 + (64 << 20);
-        if (need > mem_free / 2) { cleanup(false); return no("device memory", (long long)(need >> 20)); }
+        const uint64_t need = 2 * text_cap + sym_elems * 2 + cap_chunks * WSIZE * 5 + (256ull << 20);
+        if (need > mem_free / 2) return no("device memory", (long long)(need >> 20));
     }
-    GI(hipMallocAsync((void **)&d_sym, sym_alloc * 2, st));
-    GI(hipMallocAsync((void **)&d_status, (uint64_t)nc_alloc * 4, st));
-    lap("symbol buffers");
-    std::vector<int> status;
-    std::vector<uint64_t> out_len, end_bit, text_off;
-    // Two things show only when the chunks have been inflated, and both make the chunk list change and the chunks be
-    // inflated again (it converges: entries are only dropped, members only found):
-    //  * An entry is a position where a valid dynamic header parses and SS_GZ_PROBE symbols decode -- a position INSIDE a
-    //    block passes that about once in a million candidates (every bit string decodes under a complete code).  The
-    //    chunk in front of it runs past it (-21): the entry is dropped.
-    //  * A file of several members (lanes joined with `cat a.gz b.gz`): the chunk that meets a final block before its
-    //    stop (-20) ends a member if a trailer and a gzip header follow; the next member's first block becomes a chunk.
-    std::vector<uint32_t> todo;                                // empty = all chunks
+    A = arena_get(cap_chunks, sym_elems);
+    if (!A) return no("scratch");
+    GI(hipMalloc((void **)&d_text, text_cap));
+    lap("buffers");
+    uint64_t *d_start = A->meta, *d_stop = A->meta + cap_chunks, *d_off = A->meta + 2ull * cap_chunks, *d_cap = A->meta + 3ull * cap_chunks,
+             *d_len = A->meta + 4ull * cap_chunks, *d_end = A->meta + 5ull * cap_chunks, *d_toff = A->meta + 6ull * cap_chunks;
     const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : 2u;      // (test hook: wrong entries are then handled by the host only)
-    status.assign(nc, 0);
-    out_len.assign(nc, 0); end_bit.assign(nc, 0);
-    for (int attempt = 0;; attempt++) {
-        GI(h2d(d_start, start.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-        GI(h2d(d_stop, stop.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-        GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-        GI(h2d(d_cap, cap.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-        if (!todo.empty()) {                                   // what the other chunks produced stays as it is
-            GI(h2d(d_status, status.data(), (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
-            GI(h2d(d_len, out_len.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-            GI(h2d(d_end, end_bit.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-            if (!d_todo) GI(hipMallocAsync((void **)&d_todo, (uint64_t)nc_alloc * 4, st));
-            GI(h2d(d_todo, todo.data(), todo.size() * 4) ? hipSuccess : hipErrorUnknown);
-        }
-        const uint32_t n_run = todo.empty() ? nc : (uint32_t)todo.size();
-        if (getenv("SS_GZ_COUNTONLY")) {         // timing experiment: the decode without any output
-            hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, (uint16_t *)nullptr, d_off, d_cap, d_len, d_end, d_status,
-                               todo.empty() ? (const uint32_t *)nullptr : d_todo, max_over);
-            lap("inflate (count only)");
-        }
-        hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, nc, d_sym, d_off, d_cap, d_len, d_end, d_status,
-                           todo.empty() ? (const uint32_t *)nullptr : d_todo, max_over);
-        GI(d2h(status.data(), d_status, (uint64_t)nc * 4) ? hipSuccess : hipErrorUnknown);
-        GI(d2h(out_len.data(), d_len, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-        GI(d2h(end_bit.data(), d_end, (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-        lap("inflate");
-#ifdef SS_GZ_TIMING
-        {
-            unsigned long long t[12], z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gz_t), sizeof t);
-            hipMemcpyToSymbol(HIP_SYMBOL(g_gz_t), z, sizeof z);
-            fprintf(stderr, "[ginflate] per wave (cycles): total %.0f = decode %.0f + chain %.0f + deliver %.0f (flush %.0f inside) + header %.0f; windows %.0f; waves %llu\n",
-                    (double)t[10] / t[11], (double)t[0] / t[11], (double)t[1] / t[11], (double)t[2] / t[11], (double)t[3] / t[11], (double)t[4] / t[11], (double)t[5] / t[11], t[11]);
-            fprintf(stderr, "[ginflate] matches %llu (symbols %llu), beyond the ring %llu, into the unknown window %llu; windows %llu\n", t[6], t[7], t[8], t[9], t[5]);
-        }
-#endif
-        // the new chunk list, with what the unchanged chunks produced; `again`: positions in it that must be inflated (again)
-        std::vector<Chunk> nxt;
-        std::vector<uint64_t> n_off, n_cap, n_len, n_end;
-        std::vector<int> n_status;
-        std::vector<uint32_t> again;
-        std::vector<char> drop(nc, 0);
-        uint32_t n_drop = 0, n_members = 0, n_over = 0;
-        bool relayout = false;                                 // new chunks need room of their own: lay everything out anew
-        auto keep = [&](uint32_t c, const Chunk &a) {
-            nxt.push_back(a); n_off.push_back(off[c]); n_cap.push_back(cap[c]); n_len.push_back(out_len[c]); n_end.push_back(end_bit[c]);
-            n_status.push_back(status[c]);
+    struct Member { uint64_t at, len; uint32_t crc, isize; bool open; };
+    std::vector<Member> members;
+    uint64_t total = 0, last_end_bit = 0;
+    bool have_prev = false, ended = false;
+    uint32_t n_segments = 0;
+
+    for (size_t gi = 0; gi < G.size();) {
+        // ---- the segment's chunks [gi, gj) and up to two look-ahead entries behind them (what a chunk may run over)
+        const size_t gj = segment_end(gi);
+        std::vector<Chunk> ch(G.begin() + (long)gi, G.begin() + (long)gj), ph(G.begin() + (long)gj, G.begin() + (long)std::min(G.size(), gj + 2));
+        uint32_t nc = (uint32_t)ch.size();
+        std::vector<uint64_t> start, stop, off, cap;
+        uint64_t sym_total = 0;
+        auto bit_behind = [&](uint32_t c) -> uint64_t {      // where chunk c's input ends at the latest
+            if (c + 1 < nc) return ch[c + 1].start;
+            if (!ph.empty()) return ph[0].start;
+            return (in_n - 8) * 8;
         };
-        for (uint32_t c = 0; c < nc; c++) {
-            if (drop[c]) continue;                                     // its own outcome means nothing
-            const uint64_t e = (end_bit[c] + 7) / 8;
-            if (status[c] >= 0) {
-                // done; `over` entries behind it were positions inside its blocks: their chunks go, nothing is inflated again
-                const uint32_t over = (uint32_t)status[c] >> 4;
-                const int st = status[c] & 15;
-                if (c + over < nc) {
-                    const Chunk &eff = ch[c + over];
-                    if (st == (eff.last ? 1 : 0) && (!eff.last || e == eff.trailer)) {
-                        Chunk a = ch[c];
-                        a.last = eff.last;
-                        a.trailer = eff.trailer;
-                        keep(c, a);
-                        n_status.back() = st;
-                        for (uint32_t k = 1; k <= over; k++) drop[c + k] = 1;
-                        n_over += over;
-                        continue;
-                    }
-                }
-                status[c] = st == 1 ? 1 : -21;                        // (falls through: a member's end, or not explainable)
-            }
-            if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry: the two chunks become one
-                drop[c + 1] = 1;
-                n_drop++;
-                Chunk a = ch[c];
-                a.last = ch[c + 1].last;
-                a.trailer = ch[c + 1].trailer;
-                keep(c, a);
-                if (off[c + 1] == off[c] + cap[c]) n_cap.back() += cap[c + 1];      // their symbol regions are neighbours
-                else relayout = true;
-                again.push_back((uint32_t)nxt.size() - 1);
-                continue;
-            }
-            if (status[c] == -20 || (status[c] == 1 && ch[c].last)) {  // a final block before the next entry / before the file's end
-                const uint64_t hdr = e + 8 + 18 <= in_n ? gzip_header_len(in + e + 8, in_n - (e + 8)) : 0;
-                if (!hdr) { cleanup(false); return no("chunk status", status[c] * 1000000ll + c); }
-                Chunk a = ch[c];
-                a.last = true;
-                a.trailer = e;
-                keep(c, a);
-                const uint64_t d = (e + 8 + hdr) * 8;                  // the next member's first block
-                for (uint32_t k = c + 1; k < nc && ch[k].start < d; k++) { drop[k] = 1; n_drop++; }      // "entries" within trailer and header
-                nxt.push_back(Chunk{d, true, ch[c].last, ch[c].trailer});      // (it ends the file if the split chunk did)
-                n_members++;
-                relayout = true;
-                continue;
-            }
-            cleanup(false);
-            return no("chunk status", status[c] * 1000000ll + c);
-        }
-        if (trace && n_over) fprintf(stderr, "[ginflate] %u entries were inside a block: run over\n", n_over);
-        if (!n_drop && !n_members) {
-            if (n_over) {                                              // the shorter chunk list, everything else as it is
-                ch.swap(nxt);
-                nc = (uint32_t)ch.size();
-                off.swap(n_off); cap.swap(n_cap); out_len.swap(n_len); end_bit.swap(n_end); status.swap(n_status);
-                GI(h2d(d_off, off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-                GI(h2d(d_len, out_len.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-            }
-            break;
-        }
-        if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block, %u further members found: %s inflated again\n", n_drop, n_members,
-                           relayout ? "all chunks" : "their chunks");
-        if (attempt >= 6 || nxt.size() > nc_alloc) { cleanup(false); return no("chunk list", (long long)nxt.size()); }
-        ch.swap(nxt);
-        nc = (uint32_t)ch.size();
-        if (relayout) {
-            lay_out();
-            if (sym_total > sym_alloc) { cleanup(false); return no("symbol budget"); }
-            todo.clear();
-            status.assign(nc, 0);
-            out_len.assign(nc, 0); end_bit.assign(nc, 0);
-        } else {
-            off.swap(n_off); cap.swap(n_cap); out_len.swap(n_len); end_bit.swap(n_end); status.swap(n_status);
-            start.clear(); stop.clear();
+        auto lay_out = [&] {
+            start.clear(); stop.clear(); off.clear(); cap.clear();
+            sym_total = 0;
             for (uint32_t c = 0; c < nc; c++) {
                 start.push_back(ch[c].start | (ch[c].fresh ? 1ull << 63 : 0ull));
-                stop.push_back(ch[c].last ? ~0ull : ch[c + 1].start);
+                stop.push_back(ch[c].last ? ~0ull : bit_behind(c));
+                const uint64_t cbits = bit_behind(c) - ch[c].start;
+                const uint64_t cp = (cbits / 8 + 1) * ratio + 4096;
+                off.push_back(sym_total);
+                cap.push_back(cp);
+                sym_total += cp;
             }
-            todo.swap(again);
+            for (size_t k = 0; k < ph.size(); k++) {              // look-ahead: only their stops are read
+                start.push_back(ph[k].start);
+                stop.push_back(ph[k].last ? ~0ull : (k + 1 < ph.size() ? ph[k + 1].start : (gj + k + 1 < G.size() ? G[gj + k + 1].start : ~0ull)));
+                off.push_back(0);
+                cap.push_back(0);
+            }
+        };
+        lay_out();
+        if (sym_total > A->sym_elems) return no("segment", (long long)gi);
+        std::vector<int> status(nc, 0);
+        std::vector<uint64_t> out_len(nc, 0), end_bit(nc, 0);
+        std::vector<uint32_t> todo;                                // empty = all chunks
+        uint32_t consumed_ph = 0;
+        // Two things show only when the chunks have been inflated:
+        //  * An entry is a position where a valid dynamic header parses and SS_GZ_PROBE symbols decode -- a position INSIDE a
+        //    block passes that about once in a million candidates (every bit string decodes under a complete code).  The
+        //    chunk in front of it ends a block BEHIND it and goes on to the entry after it (inflate_kernel); the wrong
+        //    entry's chunk is dropped.  (No room left in its symbol region, or more than two in a row: -21, the two
+        //    chunks are merged here and inflated again.)
+        //  * A file of several members (lanes joined with `cat a.gz b.gz`): the chunk that meets a final block before its
+        //    stop (-20) ends a member if a trailer and a gzip header follow; the next member's first block becomes a chunk
+        //    and the segment is inflated again.
+        for (int attempt = 0;; attempt++) {
+            const uint32_t n_all = nc + (uint32_t)ph.size();
+            GB(h2d(d_start, start.data(), (uint64_t)n_all * 8));
+            GB(h2d(d_stop, stop.data(), (uint64_t)n_all * 8));
+            GB(h2d(d_off, off.data(), (uint64_t)n_all * 8));
+            GB(h2d(d_cap, cap.data(), (uint64_t)n_all * 8));
+            if (!todo.empty()) {                                   // what the other chunks produced stays as it is
+                GB(h2d(A->status, status.data(), (uint64_t)nc * 4));
+                GB(h2d(d_len, out_len.data(), (uint64_t)nc * 8));
+                GB(h2d(d_end, end_bit.data(), (uint64_t)nc * 8));
+                GB(h2d(A->todo, todo.data(), todo.size() * 4));
+            }
+            const uint32_t n_run = todo.empty() ? nc : (uint32_t)todo.size();
+            hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, n_all, A->sym, d_off, d_cap, d_len, d_end, A->status,
+                               todo.empty() ? (const uint32_t *)nullptr : A->todo, max_over);
+            GB(d2h(status.data(), A->status, (uint64_t)nc * 4));
+            GB(d2h(out_len.data(), d_len, (uint64_t)nc * 8));
+            GB(d2h(end_bit.data(), d_end, (uint64_t)nc * 8));
+#ifdef SS_GZ_TIMING
+            {
+                unsigned long long t[12], z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gz_t), sizeof t);
+                hipMemcpyToSymbol(HIP_SYMBOL(g_gz_t), z, sizeof z);
+                fprintf(stderr, "[ginflate] per wave (cycles): total %.0f = decode %.0f + chain %.0f + deliver %.0f (flush %.0f inside) + header %.0f; windows %.0f; waves %llu\n",
+                        (double)t[10] / t[11], (double)t[0] / t[11], (double)t[1] / t[11], (double)t[2] / t[11], (double)t[3] / t[11], (double)t[4] / t[11], (double)t[5] / t[11], t[11]);
+                fprintf(stderr, "[ginflate] matches %llu (symbols %llu), beyond the ring %llu, into the unknown window %llu; windows %llu\n", t[6], t[7], t[8], t[9], t[5]);
+            }
+#endif
+            // the new chunk list, with what the unchanged chunks produced; `again`: positions in it that must be inflated (again)
+            std::vector<Chunk> nxt;
+            std::vector<uint64_t> n_off, n_cap, n_len, n_end;
+            std::vector<int> n_status;
+            std::vector<uint32_t> again;
+            std::vector<char> drop(nc, 0);
+            uint32_t n_drop = 0, n_members = 0, n_over = 0, over_ph = 0;
+            bool relayout = false;                                 // new chunks need room of their own: lay everything out anew
+            auto keep = [&](uint32_t c, const Chunk &a) {
+                nxt.push_back(a); n_off.push_back(off[c]); n_cap.push_back(cap[c]); n_len.push_back(out_len[c]); n_end.push_back(end_bit[c]);
+                n_status.push_back(status[c]);
+            };
+            for (uint32_t c = 0; c < nc; c++) {
+                if (drop[c]) continue;                                     // its own outcome means nothing
+                const uint64_t e = (end_bit[c] + 7) / 8;
+                if (status[c] >= 0) {
+                    // done; `over` entries behind it were positions inside its blocks: their chunks go, nothing is inflated again
+                    const uint32_t over = (uint32_t)status[c] >> 4;
+                    const int stc = status[c] & 15;
+                    if (c + over < n_all) {
+                        const Chunk &eff = c + over < nc ? ch[c + over] : ph[c + over - nc];
+                        if (stc == (eff.last ? 1 : 0) && (!eff.last || e == eff.trailer)) {
+                            Chunk a = ch[c];
+                            a.last = eff.last;
+                            a.trailer = eff.trailer;
+                            keep(c, a);
+                            n_status.back() = stc;
+                            for (uint32_t k = 1; k <= over; k++) {
+                                if (c + k < nc) drop[c + k] = 1;
+                                else over_ph = std::max(over_ph, c + k - nc + 1);
+                            }
+                            n_over += over;
+                            continue;
+                        }
+                    }
+                    status[c] = stc == 1 ? 1 : -21;                        // (falls through: a member's end, or not explainable)
+                }
+                if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry: the two chunks become one
+                    drop[c + 1] = 1;
+                    n_drop++;
+                    Chunk a = ch[c];
+                    a.last = ch[c + 1].last;
+                    a.trailer = ch[c + 1].trailer;
+                    keep(c, a);
+                    if (off[c + 1] == off[c] + cap[c]) n_cap.back() += cap[c + 1];      // their symbol regions are neighbours
+                    else relayout = true;
+                    again.push_back((uint32_t)nxt.size() - 1);
+                    continue;
+                }
+                if (status[c] == -20 || (status[c] == 1 && ch[c].last)) {  // a final block before the next entry / before the file's end
+                    const uint64_t hdr = e + 8 + 18 <= in_n ? gzip_header_len(in + e + 8, in_n - (e + 8)) : 0;
+                    if (!hdr) return no("chunk status", status[c] * 1000000ll + c);
+                    Chunk a = ch[c];
+                    a.last = true;
+                    a.trailer = e;
+                    keep(c, a);
+                    const uint64_t d = (e + 8 + hdr) * 8;                  // the next member's first block
+                    for (uint32_t k = c + 1; k < nc && ch[k].start < d; k++) { drop[k] = 1; n_drop++; }      // "entries" within trailer and header
+                    if (c + 1 >= nc || drop[nc - 1])                       // (the look-ahead entries too)
+                        for (size_t k = 0; k < ph.size() && ph[k].start < d; k++) over_ph = std::max<uint32_t>(over_ph, (uint32_t)k + 1);
+                    nxt.push_back(Chunk{d, true, ch[c].last, ch[c].trailer});      // (it ends the file if the split chunk did)
+                    n_members++;
+                    relayout = true;
+                    continue;
+                }
+                return no("chunk status", status[c] * 1000000ll + c);
+            }
+            if (over_ph) {                                             // look-ahead entries that were run over are no chunks any more
+                over_ph = (uint32_t)std::min<size_t>(over_ph, ph.size());
+                consumed_ph += over_ph;
+                ph.erase(ph.begin(), ph.begin() + over_ph);
+                // (the arrays' look-ahead part is only read by chunks that run over again: rebuilt below when something is inflated again)
+            }
+            if (trace && n_over) fprintf(stderr, "[ginflate] %u entries were inside a block: run over\n", n_over);
+            if (!n_drop && !n_members) {
+                if (n_over) {                                          // the shorter chunk list, everything else as it is
+                    ch.swap(nxt);
+                    nc = (uint32_t)ch.size();
+                    off.swap(n_off); cap.swap(n_cap); out_len.swap(n_len); end_bit.swap(n_end); status.swap(n_status);
+                }
+                break;
+            }
+            if (trace) fprintf(stderr, "[ginflate] %u entries were inside a block, %u further members found: %s inflated again\n", n_drop, n_members,
+                               relayout ? "the segment" : "their chunks");
+            if (attempt >= 6 || nxt.size() + ph.size() > cap_chunks - 4) return no("chunk list", (long long)nxt.size());
+            ch.swap(nxt);
+            nc = (uint32_t)ch.size();
+            if (relayout) {
+                lay_out();
+                if (sym_total > A->sym_elems) return no("symbol budget");
+                todo.clear();
+                status.assign(nc, 0);
+                out_len.assign(nc, 0); end_bit.assign(nc, 0);
+            } else {
+                off.swap(n_off); cap.swap(n_cap); out_len.swap(n_len); end_bit.swap(n_end); status.swap(n_status);
+                const std::vector<uint64_t> o2 = off, c2 = cap;
+                lay_out();                                             // (starts, stops, look-ahead) ...
+                off = o2; cap = c2;                                    // ... the symbol regions stay where they are
+                off.resize(nc + ph.size(), 0); cap.resize(nc + ph.size(), 0);
+                todo.swap(again);
+            }
         }
-    }
-    text_off.assign(nc, 0);
-    // members: text ranges, trailers
-    struct Member { uint64_t at, len; uint32_t crc, isize; };
-    std::vector<Member> members;
-    uint64_t total = 0;
-    for (uint32_t c = 0; c < nc; c++) {
-        if (ch[c].fresh) members.push_back(Member{total, 0, 0, 0});
-        if (members.empty()) { cleanup(false); return no("member start"); }
-        text_off[c] = total;
-        total += out_len[c];
-        members.back().len += out_len[c];
-        if (ch[c].last) {
-            const uint8_t *t8 = in + ch[c].trailer;
-            members.back().crc = (uint32_t)t8[0] | (uint32_t)t8[1] << 8 | (uint32_t)t8[2] << 16 | (uint32_t)t8[3] << 24;
-            members.back().isize = (uint32_t)t8[4] | (uint32_t)t8[5] << 8 | (uint32_t)t8[6] << 16 | (uint32_t)t8[7] << 24;
-            if ((uint32_t)members.back().len != members.back().isize) { cleanup(false); return no("isize", (long long)members.size()); }
+        // ---- the segment's text
+        std::vector<uint64_t> text_off(nc, 0);
+        for (uint32_t c = 0; c < nc; c++) {
+            if (ch[c].fresh) members.push_back(Member{total, 0, 0, 0, true});
+            if (members.empty() || !members.back().open) return no("member start");
+            text_off[c] = total;
+            total += out_len[c];
+            members.back().len += out_len[c];
+            if (ch[c].last) {
+                const uint8_t *t8 = in + ch[c].trailer;
+                Member &m = members.back();
+                m.crc = (uint32_t)t8[0] | (uint32_t)t8[1] << 8 | (uint32_t)t8[2] << 16 | (uint32_t)t8[3] << 24;
+                m.isize = (uint32_t)t8[4] | (uint32_t)t8[5] << 8 | (uint32_t)t8[6] << 16 | (uint32_t)t8[7] << 24;
+                m.open = false;
+                if ((uint32_t)m.len != m.isize) return no("isize", (long long)members.size());
+                ended = ch[c].trailer == in_n - 8;
+            }
         }
-    }
-    if (!ch[nc - 1].last || (end_bit[nc - 1] + 7) / 8 != in_n - 8) { cleanup(false); return no("stream end", (long long)((end_bit[nc - 1] + 7) / 8)); }
-    if (trace && members.size() > 1) fprintf(stderr, "[ginflate] %zu members\n", members.size());
-    GI(h2d(d_toff, text_off.data(), (uint64_t)nc * 8) ? hipSuccess : hipErrorUnknown);
-    GI(hipMallocAsync((void **)&d_win, (uint64_t)nc * WSIZE, st));
-    {
-        uint32_t group = 1;
-        while ((uint64_t)group * group < nc) group++;                   // ~sqrt: as many groups as chunks in a group
-        group = std::max<uint32_t>(group, 8);
-        const uint32_t n_groups = (nc + group - 1) / group;
-        bool ok = hipMallocAsync((void **)&d_map[0], (uint64_t)nc * WSIZE * 2, st) == hipSuccess &&
-                  hipMallocAsync((void **)&d_map[1], (uint64_t)nc * WSIZE * 2, st) == hipSuccess &&
-                  hipMallocAsync((void **)&d_more, (uint64_t)n_groups * WSIZE, st) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(tails_kernel, dim3(16, nc), dim3(256), 0, st, d_sym, d_off, d_len, nc, d_map[0]);
-            hipLaunchKernelGGL(group_maps_kernel, dim3(n_groups), dim3(1024), 0, st, d_map[0], nc, group, d_map[1]);
-            hipLaunchKernelGGL(group_windows_kernel, dim3(1), dim3(1024), 0, st, d_map[1], nc, group, n_groups, (uint8_t *)d_more);
-            hipLaunchKernelGGL(windows_kernel, dim3(16, nc), dim3(256), 0, st, d_map[1], nc, group, (const uint8_t *)d_more, d_win);
-            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        last_end_bit = end_bit[nc - 1];
+        if (total + 64 > text_cap) {                                   // (several members: the last ISIZE said little)
+            const uint64_t ncap = std::max(total + 64, text_cap + text_cap / 2);
+            uint8_t *nt = nullptr;
+            GI(hipMalloc((void **)&nt, ncap));
+            const uint64_t have = total - (total - text_off[0]);
+            const bool ok = hipMemcpyAsync(nt, d_text, have, hipMemcpyDeviceToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            hipFree(d_text);
+            d_text = nt;
+            text_cap = ncap;
+            if (!ok) return no("text copy");
         }
-        if (!ok) { cleanup(false); return no("windows"); }
+        GB(h2d(d_off, off.data(), (uint64_t)nc * 8));
+        GB(h2d(d_len, out_len.data(), (uint64_t)nc * 8));
+        GB(h2d(d_toff, text_off.data(), (uint64_t)nc * 8));
+        {
+            uint32_t group = 1;
+            while ((uint64_t)group * group < nc) group++;               // ~sqrt: as many groups as chunks in a group
+            group = std::max<uint32_t>(group, 8);
+            const uint32_t n_groups = (nc + group - 1) / group;
+            hipLaunchKernelGGL(tails_kernel, dim3(16, nc), dim3(256), 0, st, A->sym, d_off, d_len, nc, A->map[0]);
+            hipLaunchKernelGGL(group_maps_kernel, dim3(n_groups), dim3(1024), 0, st, A->map[0], nc, group, A->map[1]);
+            hipLaunchKernelGGL(group_windows_kernel, dim3(1), dim3(1024), 0, st, A->map[1], nc, group, n_groups,
+                               have_prev ? (const uint8_t *)A->prev : (const uint8_t *)nullptr, A->gwin);
+            hipLaunchKernelGGL(windows_kernel, dim3(16, nc), dim3(256), 0, st, A->map[1], nc, group, (const uint8_t *)A->gwin, A->win);
+            hipLaunchKernelGGL(bytes_kernel, dim3(64, nc), dim3(256), 0, st, A->sym, d_off, d_len, d_toff, A->win, d_text);
+            hipLaunchKernelGGL(lastwin_kernel, dim3(WSIZE / 256), dim3(256), 0, st, d_text, total, A->prev);
+            GI(hipGetLastError());
+            GI(hipStreamSynchronize(st));                          // (the host arrays of this segment go out of scope)
+        }
+        have_prev = true;
+        n_segments++;
+        gi = gj + consumed_ph;
     }
-    lap("windows");
-    GI(hipMalloc((void **)&d_text, std::max<uint64_t>(total, 16) + 64));
-    hipLaunchKernelGGL(bytes_kernel, dim3(64, nc), dim3(256), 0, st, d_sym, d_off, d_len, d_toff, d_win, d_text);
-    lap("bytes");
+    lap("inflate + windows + bytes");
+    if (trace) fprintf(stderr, "[ginflate] %u segments, %zu members\n", n_segments, members.size());
+    // the stream must end where the last trailer begins (after padding to a byte)
+    if (!ended || members.empty() || members.back().open || (last_end_bit + 7) / 8 != in_n - 8) return no("stream end", (long long)((last_end_bit + 7) / 8));
     // CRC-32 by segments of 4 KB from every member's first byte, combined on the host with ONE precomputed operator
     constexpr int SEG_LOG2 = 12;
     const uint64_t seg = 1ull << SEG_LOG2;
@@ -1274,15 +1402,15 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(hipMallocAsync((void **)&d_tab, 1024 + std::max<uint64_t>(1, nseg) * 12, st));      // table | segment starts | lengths
     d_seg_at = reinterpret_cast<uint64_t *>(d_tab + 256);
     d_seg_len = reinterpret_cast<uint32_t *>(d_seg_at + nseg);
-    GI(h2d(d_tab, tab.data(), 1024) ? hipSuccess : hipErrorUnknown);
+    GB(h2d(d_tab, tab.data(), 1024));
     if (nseg) {
-        GI(h2d(d_seg_at, seg_at.data(), nseg * 8) ? hipSuccess : hipErrorUnknown);
-        GI(h2d(d_seg_len, seg_len.data(), nseg * 4) ? hipSuccess : hipErrorUnknown);
+        GB(h2d(d_seg_at, seg_at.data(), nseg * 8));
+        GB(h2d(d_seg_len, seg_len.data(), nseg * 4));
     }
     GI(hipMallocAsync((void **)&d_crc, std::max<uint64_t>(1, nseg) * 4, st));
     if (nseg) hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, d_text, d_seg_at, d_seg_len, nseg, d_tab, d_crc);
     std::vector<uint32_t> crcs(std::max<uint64_t>(1, nseg));
-    if (nseg) GI(d2h(crcs.data(), d_crc, nseg * 4) ? hipSuccess : hipErrorUnknown);
+    if (nseg) GB(d2h(crcs.data(), d_crc, nseg * 4));
     bool crc_ok = true;
     {
         uint32_t op[32];
@@ -1304,10 +1432,11 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     }
     lap("crc");
 #undef GI
+#undef GB
 #ifdef SS_GZ_DEBUG_SKIPCRC           // diagnostic builds only (scripts/dev): hand out the text although it is wrong
     if (!crc_ok) fprintf(stderr, "[ginflate] CRC MISMATCH (debug build: text returned)\n");
 #else
-    if (!crc_ok) { cleanup(false); return no("crc"); }
+    if (!crc_ok) return no("crc");
 #endif
     cleanup(true);
     g_handled++;

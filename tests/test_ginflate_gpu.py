@@ -335,3 +335,25 @@ def test_bgzip_file(L, tmp_path, fastq_text):
     p.write_bytes(gz[:mid] + bytes([gz[mid] ^ 0x21]) + gz[mid + 1:])
     rc, got = _gpu_inflate(L, p)
     assert rc == SS_ERANGE or got == fastq_text
+
+
+@pytest.mark.parametrize("seg_kb", ["256", "1024", "3000"])
+def test_segments(L, tmp_path, monkeypatch, fastq_text, seg_kb):
+    """The chunks are inflated segment by segment (128 MB of deflate data each; here SS_GZ_SEG_KB forces tens of them):
+    the window in front of a segment's first chunk is the end of the text so far; wrong entries at segment edges, members
+    across segments and the scratch kept between calls must not show.  One member, four members, bgzip."""
+    monkeypatch.setenv("SS_GZ_SEG_KB", seg_kb)
+    n = len(fastq_text)
+    one = gzip.compress(fastq_text, 6)
+    four = b"".join(gzip.compress(fastq_text[a:b], lv) for a, b, lv in ((0, n // 3, 6), (n // 3, n // 3 + 70000, 1), (n // 3 + 70000, n - 10, 9), (n - 10, n, 6)))
+    for name, gz in (("one", one), ("four", four), ("bgzf", _bgzf(fastq_text))):
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(gz)
+        for inject in (None, "5", "33"):
+            if inject:
+                monkeypatch.setenv("SS_GZ_INJECT_ENTRY", inject)
+            else:
+                monkeypatch.delenv("SS_GZ_INJECT_ENTRY", raising=False)
+            rc, got = _gpu_inflate(L, p)
+            assert rc == SS_OK, (name, inject)
+            assert got == fastq_text, (name, inject)
