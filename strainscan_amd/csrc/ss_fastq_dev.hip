@@ -231,17 +231,18 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     if (in == MAP_FAILED) return 1;
     char *d_text = nullptr;
     uint64_t n = 0;
-    const bool ok = in[0] == 0x1f && in[1] == 0x8b && gpu_gunzip(in, in_n, &d_text, &n);
+    void *lease = nullptr;
+    const bool ok = in[0] == 0x1f && in[1] == 0x8b && gpu_gunzip(in, in_n, &d_text, &n, &lease);
     munmap((void *)in, in_n);
     if (!ok) return 1;
     if (trace) fprintf(stderr, "[ingest] %s: %.1f MB of text on the device at %.4f s\n", path, n / 1e6, since());
     int rc = fastq_text_to_flat_dev(d_text, n, shard_rank, shard_world, d_flat, flat_len, flat_cap, n_records);
     if (trace) fprintf(stderr, "[ingest] %s: sequence lines extracted (rc %d) at %.4f s\n", path, rc, since());
-    if (rc == 0) { hipFree(d_text); return 0; }
+    if (rc == 0) { gpu_gunzip_done(lease); return 0; }
     // the general grammar runs on the host
     char *h = n <= inflate_budget_bytes() ? (char *)malloc(std::max<uint64_t>(n, 1)) : nullptr;
     const bool got = h && (n == 0 || hipMemcpy(h, d_text, n, hipMemcpyDeviceToHost) == hipSuccess);
-    hipFree(d_text);
+    gpu_gunzip_done(lease);
     if (!got) { free(h); return 1; }
     *text = h;
     *text_len = n;

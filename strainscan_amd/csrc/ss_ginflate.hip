@@ -969,13 +969,15 @@ struct Arena {
     int *status = nullptr;
     uint8_t *win = nullptr, *gwin = nullptr, *prev = nullptr;
     uint32_t *todo = nullptr;
+    uint8_t *text = nullptr;              // the text of the call that holds the arena (lent to the caller until gpu_gunzip_done)
+    uint64_t text_cap = 0;
 };
 std::mutex g_arena_mu;
 std::vector<Arena *> g_arena_free;
 void arena_destroy(Arena *a)
 {
     if (!a) return;
-    void *q[] = {a->sym, a->map[0], a->map[1], a->meta, a->status, a->win, a->gwin, a->prev, a->todo};
+    void *q[] = {a->sym, a->map[0], a->map[1], a->meta, a->status, a->win, a->gwin, a->prev, a->todo, a->text};
     for (void *x : q) if (x) hipFree(x);
     delete a;
 }
@@ -987,8 +989,12 @@ Arena *arena_get(uint64_t cap_chunks, uint64_t sym_elems)
         if (!g_arena_free.empty()) { a = g_arena_free.back(); g_arena_free.pop_back(); }
     }
     if (a && a->cap_chunks >= cap_chunks && a->sym_elems >= sym_elems) return a;
+    uint8_t *text = nullptr;
+    uint64_t text_cap = 0;
+    if (a) { text = a->text; text_cap = a->text_cap; a->text = nullptr; }      // (the text buffer moves to the new arena)
     arena_destroy(a);
     a = new (std::nothrow) Arena();
+    if (a) { a->text = text; a->text_cap = text_cap; } else if (text) hipFree(text);
     if (!a) return nullptr;
     a->cap_chunks = cap_chunks;
     a->sym_elems = sym_elems;
@@ -1004,6 +1010,7 @@ Arena *arena_get(uint64_t cap_chunks, uint64_t sym_elems)
 void arena_put(Arena *a)
 {
     if (!a) return;
+    if (a->text_cap > (6ull << 30)) { hipFree(a->text); a->text = nullptr; a->text_cap = 0; }      // (not kept: the text of a very large file)
     {
         std::lock_guard<std::mutex> g(g_arena_mu);
         if (g_arena_free.size() < 2) { g_arena_free.push_back(a); return; }
@@ -1015,11 +1022,14 @@ void arena_put(Arena *a)
 
 namespace ss {
 
-// The file image `in` (host) inflated on the device.  true: *text_dev (hipMalloc) holds *len bytes, every member verified
-// against its trailer.  false: not handled here (the caller inflates on the host).
+// The file image `in` (host) inflated on the device.  true: *text_dev holds *len bytes, every member verified against its
+// trailer; the buffer belongs to the scratch arena of the call and is lent until gpu_gunzip_done(*lease).  false: not
+// handled here (the caller inflates on the host).
 static std::atomic<uint64_t> g_handled{0}, g_declined{0};
 
-bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len)
+void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
+
+bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     // own stream: the two mates of a paired sample are inflated by two host threads, and the legacy default stream would
@@ -1041,9 +1051,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         for (void *q : scratch) if (q) hipFreeAsync(q, st);
         hipStreamSynchronize(st);
         hipStreamDestroy(st);
-        arena_put(A);
-        A = nullptr;
-        if (!keep_text && d_text) hipFree(d_text);
+        if (!keep_text) { arena_put(A); A = nullptr; }            // (else the caller holds it, with the text, until gpu_gunzip_done)
     };
     auto no = [&](const char *why, long long a = 0) {
         if (trace) fprintf(stderr, "[ginflate] not handled: %s (%lld)\n", why, a);
@@ -1144,7 +1152,16 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     }
     A = arena_get(cap_chunks, sym_elems);
     if (!A) return no("scratch");
-    GI(hipMalloc((void **)&d_text, text_cap));
+    if (A->text_cap < text_cap) {
+        if (A->text) hipFree(A->text);
+        A->text = nullptr;
+        A->text_cap = 0;
+        GI(hipMalloc((void **)&A->text, text_cap));
+        A->text_cap = text_cap;
+    } else {
+        text_cap = A->text_cap;
+    }
+    d_text = A->text;
     lap("buffers");
     uint64_t *d_start = A->meta, *d_stop = A->meta + cap_chunks, *d_off = A->meta + 2ull * cap_chunks, *d_cap = A->meta + 3ull * cap_chunks,
              *d_len = A->meta + 4ull * cap_chunks, *d_end = A->meta + 5ull * cap_chunks, *d_toff = A->meta + 6ull * cap_chunks;
@@ -1359,6 +1376,8 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
             hipFree(d_text);
             d_text = nt;
             text_cap = ncap;
+            A->text = nt;
+            A->text_cap = ncap;
             if (!ok) return no("text copy");
         }
         GB(h2d(d_off, off.data(), (uint64_t)nc * 8));
@@ -1442,6 +1461,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     g_handled++;
     *text_dev = (char *)d_text;
     *len = total;
+    *lease = A;
     return true;
 }
 
@@ -1474,11 +1494,12 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
     if (got != buf.size()) return SS_EIO;
     char *d = nullptr;
     uint64_t n = 0;
-    if (!ss::gpu_gunzip(buf.data(), buf.size(), &d, &n)) return SS_ERANGE;
+    void *lease = nullptr;
+    if (!ss::gpu_gunzip(buf.data(), buf.size(), &d, &n, &lease)) return SS_ERANGE;
     char *h = (char *)malloc(std::max<uint64_t>(n, 1));
-    if (!h) { hipFree(d); return SS_ENOMEM; }
+    if (!h) { ss::gpu_gunzip_done(lease); return SS_ENOMEM; }
     const hipError_t e = n ? hipMemcpy(h, d, n, hipMemcpyDeviceToHost) : hipSuccess;
-    hipFree(d);
+    ss::gpu_gunzip_done(lease);
     if (e != hipSuccess) { free(h); return SS_EHIP; }
     *text = h;
     *len = n;
