@@ -85,6 +85,9 @@ int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len);
  * ss_scan_files and ss_reads_load (one rank, files of 1 MB and more) go through it first and strict four-line FASTQ is
  * reduced to its sequence lines on the device too (ss_fastq_dev.hip); what it declines goes to the host inflaters. */
 int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
+/* The device inflater keeps its scratch (symbol streams, window maps, the text buffer: ~6-12 GB, at most two sets) for
+ * the next call -- large allocations are slow to come by on this platform; this hands it back. */
+int ss_gz_gpu_release(void);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "ss_gz_inflate": (i32, [cp, i32, i32, P(vp), P(u64)]),
     "ss_gz_inflate_gpu": (i32, [cp, P(vp), P(u64)]),
     "ss_gz_gpu_counters": (i32, [P(u64), P(u64)]),
+    "ss_gz_gpu_release": (i32, []),
     "ss_gz_free": (None, [vp]),
     "ss_gz_inflate_to_file": (i32, [cp, cp, i32, P(u64)]),
     "ss_host_cpus": (i32, []),

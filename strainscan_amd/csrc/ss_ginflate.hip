@@ -1467,6 +1467,18 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
 
 }  // namespace ss
 
+// the scratch arenas kept between calls (up to two, ~6 GB each, plus a text buffer) go back to the device
+extern "C" int ss_gz_gpu_release(void)
+{
+    std::vector<Arena *> all;
+    {
+        std::lock_guard<std::mutex> g(g_arena_mu);
+        all.swap(g_arena_free);
+    }
+    for (Arena *a : all) arena_destroy(a);
+    return SS_OK;
+}
+
 // members the device inflater has produced / has left to the host inflaters, in this process
 extern "C" int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined)
 {

@@ -100,6 +100,19 @@ def test_stored_fixed_and_tiny(L, tmp_path):
     assert handled >= 4
 
 
+def test_scratch_is_kept_and_can_be_released(L, tmp_path, fastq_text):
+    """The scratch arena of a call is reused by the next one; ss_gz_gpu_release hands it back; the call after that builds
+    a new one.  Same text every time."""
+    p = tmp_path / "a.fq.gz"
+    p.write_bytes(gzip.compress(fastq_text, 6))
+    for step in range(4):
+        rc, got = _gpu_inflate(L, p)
+        assert rc == SS_OK and got == fastq_text, step
+        if step == 1:
+            assert L.lib().ss_gz_gpu_release() == 0
+    assert L.lib().ss_gz_gpu_release() == 0
+
+
 def test_header_fields(L, tmp_path, fastq_text):
     """FNAME / FCOMMENT / FEXTRA / FHCRC in the member header are skipped (RFC 1952 2.3)."""
     raw = gzip.compress(fastq_text[: 4 << 20], 6)
