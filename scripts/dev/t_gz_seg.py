@@ -22,7 +22,7 @@ pr = [subprocess.Popen(["gzip", "-f", "-1", p]) for p in paths]
 [q.wait() for q in pr]
 paths = [p + ".gz" for p in paths]
 print("gz MB", [round(os.path.getsize(p) / 1e6) for p in paths], flush=True)
-for seg_mb in (128, 64, 256, 512, 128):
+for seg_mb in (128, 128):
     os.environ["SS_GZ_SEG_KB"] = str(seg_mb * 1024)
     ts = []
     for rep in range(3):

@@ -227,12 +227,12 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     // (a plain mapping, copied by one thread: a populated mapping, a read into memory and four copy threads were all
     //  slower -- 0.157 / 0.233 / 0.144 s against 0.129 s for a pair of 290 MB files, scripts/dev/t_gz_input_ab.py)
     const uint8_t *in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (in == MAP_FAILED) return 1;
+    if (in == MAP_FAILED) { close(fd); return 1; }
     char *d_text = nullptr;
     uint64_t n = 0;
     void *lease = nullptr;
-    const bool ok = in[0] == 0x1f && in[1] == 0x8b && gpu_gunzip(in, in_n, &d_text, &n, &lease);
+    const bool ok = in[0] == 0x1f && in[1] == 0x8b && gpu_gunzip(in, in_n, &d_text, &n, &lease, fd);
+    close(fd);
     munmap((void *)in, in_n);
     if (!ok) return 1;
     if (trace) fprintf(stderr, "[ingest] %s: %.1f MB of text on the device at %.4f s\n", path, n / 1e6, since());
