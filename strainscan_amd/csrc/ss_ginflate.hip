@@ -17,6 +17,9 @@
 //               matches of a window together and while the next window is decoded.
 //   C  windows  the last 32 KB of every chunk as a map "my window -> the next chunk's window", composed in two levels;
 //   D  bytes    all symbols -> bytes in parallel; CRC-32 of the text by segments (combined on the host).
+// B-D run SEGMENT by segment (128 MB of deflate data): a segment's text is complete before the next one starts, so the
+// window in front of a segment is the end of the text so far, and the scratch (a reusable arena, ~6 GB) does not grow
+// with the file.
 // Accepted only if every chunk ended exactly on the next one's entry, the stream ended at the file's last trailer and
 // CRC-32 and ISIZE of EVERY member match (lanes joined with `cat` are found member by member: the chunk that meets a
 // final block finds trailer and header behind it).  A wrong entry (a position inside a block that passed A) shows as the
