@@ -137,6 +137,25 @@ def test_identify_cluster_from_files_cold_and_cached(tmp_path, monkeypatch):
     assert dict(second) == dict(first)
     assert np.array_equal(ssdb.tree_image(tdir, True).counts, counts_first)
     ssdb.clear_cache()
+    # the same sample as a .fastq.gz pair: inflated and reduced to its sequence lines on the device (the default), and with
+    # the host inflaters: same result, same counts
+    import ctypes as C
+    import subprocess
+    from strainscan_amd import _lib
+    for p in fq:
+        subprocess.check_call(["gzip", "-1", "-k", p])
+    gz = [p + ".gz" for p in fq]
+    for mode, on_device in (("1", 2), ("0", 0)):
+        monkeypatch.setenv("SS_GZ_GPU", mode)
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b))
+        h0 = a.value
+        third = identify.identify_cluster((gz[0], gz[1]), tdir, [0.1, 0.4, 1])
+        assert dict(third) == dict(first), mode
+        assert np.array_equal(ssdb.tree_image(tdir, True).counts, counts_first), mode
+        _lib.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b))
+        assert a.value - h0 == on_device, mode
+        ssdb.clear_cache()
 
 
 def _rank_paths_restated(parent_of, leaves, frac):
