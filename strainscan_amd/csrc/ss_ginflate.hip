@@ -654,7 +654,7 @@ __device__ unsigned g_sync_tries;      // candidates that passed the header chec
 // ---- kernels ------------------------------------------------------------------------------------------------------
 // A: entry point of every chunk (chunk 0: the start of the deflate data)
 __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in_n, uint64_t data_off, uint64_t chunk_bytes,
-                                                  uint32_t n_chunks, uint64_t *entry /* bit position or ~0 */, uint64_t probe)
+                                                  uint32_t n_chunks, uint64_t *entry /* bit position or ~0 */, uint64_t probe, int count_tries)
 {
     __shared__ WaveState S;
     const uint32_t c = blockIdx.x;
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
             // passes this with negligible probability, and if one ever does, the chunk will not end on the next entry and
             // the file goes to the host inflater
             const int r = inflate_block(S, b, o, false, probe);
-            if (lane == 0) atomicAdd(&g_sync_tries, 1u);
+            if (count_tries && lane == 0) atomicAdd(&g_sync_tries, 1u);
             if (r == 2 || (r == 0 && o.n > 0)) found = cand;
         }
     }
@@ -1163,7 +1163,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
     std::vector<uint64_t> entry(n_chunks0);
     if (bgzf.empty()) {
-        hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe);
+        hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe, trace ? 1 : 0);
         GB(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8));
     }
     if (trace && bgzf.empty()) {
