@@ -131,6 +131,7 @@ def test_identify_cluster_from_files_cold_and_cached(tmp_path, monkeypatch):
     per = sorted((float(v["cls_per"]) for v in first.values()), reverse=True)
     assert abs(per[0] - 0.7) < 0.02 and abs(per[1] - 0.2) < 0.02 and abs(per[2] - 0.1) < 0.02
     assert all(v["strain"] == "strain_%d" % k and float(v["cls_cov"]) > 0.9 for k, v in first.items())
+    ssdb.wait_cache_writes()
     assert {f[:5] for f in os.listdir(tmp_path / "cache")} == {"tree_", "index"}
     ssdb.clear_cache()
     second = identify.identify_cluster((fq[0], fq[1]), tdir, [0.1, 0.4, 1])
