@@ -6,7 +6,7 @@ Tree_database/ (written by the reference's library/Build_tree.py:494-526,648-698
     node_length.txt         `id \\t len`
     reconstructed_nodes.txt one id per line
     overlapping_info/<leaf>, <leaf>_supple
-Kmer_Sets_L2/Kmer_Sets/C<id>/ is handled by strainscan_amd/l2db.py.
+Kmer_Sets_L2/Kmer_Sets/C<id>/ is handled by strainscan_amd/Vote_Strain_L2_Lasso_new_sp.py (cluster image cache there).
 
 A TreeImage owns the device k-mer table of kmer.fa and the node row lists; scans accumulate in
 it.  Images are cached per (directory, key mode) for the life of the process so that the cutoff
@@ -129,13 +129,21 @@ def fasta_index(path, k, upper_keys):
     kdb = _lib.KmerDB.from_fasta(path, int(k), upper_keys=upper_keys)
     if img:
         try:
-            os.makedirs(cdir, exist_ok=True)
-            tmp = img + ".%d.tmp" % os.getpid()
-            kdb.export(tmp)
-            os.replace(tmp, img)
+            _export_image(kdb, cdir, img)
         except (RuntimeError, OSError):
             pass
     return kdb
+
+
+def _export_image(kdb, cdir, img):
+    os.makedirs(cdir, exist_ok=True)
+    tmp = _cache_tmp(img)
+    try:
+        kdb.export(tmp)
+        os.replace(tmp, img)
+    except BaseException:
+        _unlink_quiet(tmp)
+        raise
 
 
 def _cache_dir():
@@ -170,26 +178,49 @@ def _write_tree_cache(path, t):
               np.asarray(t.uoffs, np.int64), np.zeros(0, np.uint32) if same else np.asarray(t.urows, np.uint32),
               np.asarray(t.flags, np.uint8), np.asarray(t.keys, np.uint64)]
     hdr = np.array([t.keys.size, len(t.ids), t.rows.size, 0 if same else t.urows.size, int(same), 0], np.uint64)
-    tmp = path + ".%d.tmp" % os.getpid()
-    with open(tmp, "wb") as f:
-        f.write(_TREE_MAGIC)
-        f.write(hdr.tobytes())
-        pos = 8 + hdr.nbytes
-        for a in arrays:
-            f.write(b"\0" * (_pad64(pos) - pos))
-            pos = _pad64(pos)
-            f.write(memoryview(np.ascontiguousarray(a)).cast("B"))
-            pos += a.nbytes
-    os.replace(tmp, path)
+    tmp = _cache_tmp(path)
+    try:
+        with open(tmp, "wb") as f:
+            f.write(_TREE_MAGIC)
+            f.write(hdr.tobytes())
+            pos = 8 + hdr.nbytes
+            for a in arrays:
+                f.write(b"\0" * (_pad64(pos) - pos))
+                pos = _pad64(pos)
+                f.write(memoryview(np.ascontiguousarray(a)).cast("B"))
+                pos += a.nbytes
+        os.replace(tmp, path)
+    except BaseException:
+        _unlink_quiet(tmp)
+        raise
 
 
-_CACHE_WRITERS = []
+def _cache_tmp(path):
+    """A temp file of its own in the cache directory for every writer (thread or process): `path.<pid>.tmp` was shared
+    by two writer threads of one process, the second truncating what the first was still writing.  The finished
+    file reaches `path` through os.replace, so a reader sees the old image, none, or a complete new one."""
+    import tempfile
+    fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path), prefix=os.path.basename(path) + ".", suffix=".tmp")
+    os.close(fd)
+    return tmp
+
+
+def _unlink_quiet(p):
+    try:
+        os.unlink(p)
+    except OSError:
+        pass
+
+
+_CACHE_WRITERS = {}                  # cache path -> thread writing it
+_CACHE_WRITERS_LOCK = threading.Lock()
 
 
 def _write_tree_cache_later(cdir, path, t):
-    """The tree cache is written on a worker thread (0.2 s for an E. coli tree) while the first scan runs; the
-    interpreter waits for it at exit, wait_cache_writes() before that."""
-    import threading
+    """The tree cache is written on a worker thread (0.2 s for an E. coli tree) while the first scan runs.  At most
+    one writer per path: load_tree() of the same database joins it before it looks for the file (`-b 1` on a new
+    database loads the tree twice, identify_low_depth.py:119 then identify.py:402); the interpreter waits for the
+    writers at exit, wait_cache_writes() before that."""
 
     def work():
         try:
@@ -198,14 +229,34 @@ def _write_tree_cache_later(cdir, path, t):
         except OSError:
             pass
 
+    with _CACHE_WRITERS_LOCK:
+        old = _CACHE_WRITERS.get(path)
+    if old is not None:
+        old.join()
     th = threading.Thread(target=work)
+    with _CACHE_WRITERS_LOCK:
+        _CACHE_WRITERS[path] = th
     th.start()
-    _CACHE_WRITERS.append(th)
+
+
+def _join_cache_writer(path):
+    with _CACHE_WRITERS_LOCK:
+        th = _CACHE_WRITERS.get(path)
+    if th is not None:
+        th.join()
+        with _CACHE_WRITERS_LOCK:
+            if _CACHE_WRITERS.get(path) is th:
+                del _CACHE_WRITERS[path]
 
 
 def wait_cache_writes():
-    while _CACHE_WRITERS:
-        _CACHE_WRITERS.pop().join()
+    while True:
+        with _CACHE_WRITERS_LOCK:
+            paths = list(_CACHE_WRITERS)
+        if not paths:
+            return
+        for p in paths:
+            _join_cache_writer(p)
 
 
 def _read_tree_cache(path):
@@ -284,6 +335,8 @@ def load_tree(db_dir, k=L1_K, with_keys=None):
                                              os.stat(kdir).st_mtime_ns)).encode()).hexdigest()[:20]
     cdir = _cache_dir()
     path = os.path.join(cdir, "tree_%s.bin" % tag) if cdir else None
+    if path:
+        _join_cache_writer(path)          # an earlier load_tree of this database may still be writing it
     if path and os.path.exists(path):
         try:
             t = _read_tree_cache(path)
@@ -367,10 +420,7 @@ class TreeImage:
         kdb = _lib.KmerDB(keys, flags, L1_K, upper_keys)
         if path:
             try:
-                os.makedirs(cdir, exist_ok=True)
-                tmp = path + ".%d.tmp" % os.getpid()
-                kdb.export(tmp)
-                os.replace(tmp, path)
+                _export_image(kdb, cdir, path)
             except (RuntimeError, OSError):
                 pass
         return kdb

@@ -8,7 +8,6 @@ passes become bit-plane popcounts and masked radix selects on the MI355X
 (strainscan_amd/csrc/ss_l2.hip) and scikit-learn's ElasticNetCV / ElasticNet become a Gram
 coordinate descent on exact per-pattern statistics (ss_enet.hip); see SURVEY.md Appendix B/C.
 """
-import pickle
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -220,17 +219,22 @@ def _write_l2_cache(path, img, om):
     arrays = [img.planes(), np.asarray(om.indptr, np.int64), np.asarray(om.indices, np.int32), np.asarray(om.data, np.int8)]
     hdr = np.array([img.K, img.S, img.W, om.shape[1], om.nnz, 0], np.uint64)
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    tmp = path + ".%d.tmp" % os.getpid()
-    with open(tmp, "wb") as f:
-        f.write(_L2_MAGIC)
-        f.write(hdr.tobytes())
-        pos = 8 + hdr.nbytes
-        for a in arrays:
-            f.write(b"\0" * (_pad64(pos) - pos))
-            pos = _pad64(pos)
-            f.write(a.tobytes())
-            pos += a.nbytes
-    os.replace(tmp, path)
+    from .db import _cache_tmp, _unlink_quiet
+    tmp = _cache_tmp(path)               # a file of its own per writer: clusters run on several host threads
+    try:
+        with open(tmp, "wb") as f:
+            f.write(_L2_MAGIC)
+            f.write(hdr.tobytes())
+            pos = 8 + hdr.nbytes
+            for a in arrays:
+                f.write(b"\0" * (_pad64(pos) - pos))
+                pos = _pad64(pos)
+                f.write(a.tobytes())
+                pos += a.nbytes
+        os.replace(tmp, path)
+    except BaseException:
+        _unlink_quiet(tmp)
+        raise
 
 
 def _read_l2_cache(path):
@@ -264,8 +268,8 @@ def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_co
                    emode):
     """:177-478.  input_csv = <C>/all_strains_re.npz, ids = <C>/id2strain_re.pkl,
     omatrix = <C>/overlap_matrix.npz, input_y = counts ordered by k-mer id with 1s zeroed."""
-    with open(ids, "rb") as f:
-        sid = pickle.load(f)
+    from .tree import load_plain_pkl
+    sid = load_plain_pkl(ids)
     cache = _l2_cache_path(input_csv, omatrix)
     img = om = None
     if cache:

@@ -150,6 +150,21 @@ class _PickledNode(_PickledObject):
     pass
 
 
+def load_plain_pkl(path):
+    """id2strain_re.pkl (a list of strain names, Recls_withR_new.py:114-115) and all_kid.pkl (k-mer -> id dict,
+    Build_kmer_sets..._sp.py:409-410) hold only builtin containers, strings and numbers: such a pickle names no
+    global at all, so the Unpickler admits none -- a database file cannot make the identification call anything."""
+    import pickle
+
+    class _NoGlobals(pickle.Unpickler):
+        def find_class(self, module, name):
+            raise pickle.UnpicklingError("%s: %s.%s is not data (only lists, dicts, strings and numbers are read)"
+                                         % (path, module, name))
+
+    with open(path, "rb") as f:
+        return _NoGlobals(f).load()
+
+
 def load_tree_pkl(path):
     """tree.pkl of a single-cluster database: `pkl.dump(tree, ...)` of a treelib.Tree (Build_tree.py:329),
     read back by identify.py:19-21.  treelib is a dependency of the reference that this package does not

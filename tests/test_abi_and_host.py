@@ -355,8 +355,10 @@ def test_tree_image_cache_roundtrip(l1_dbs, tmp_path, monkeypatch):
     monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
     tdb = os.path.join(l1_dbs["A"]["db_dir"], "Tree_database")
     k1, f1, ids1, l1 = sdb.load_tree_text(tdb)
-    assert len(os.listdir(tmp_path / "cache")) == 1
-    k2, f2, ids2, l2 = sdb.load_tree_text(tdb)           # second call: from the cache
+    k2, f2, ids2, l2 = sdb.load_tree_text(tdb)           # second call: joins the first call's writer, reads the cache
+    assert not sdb._CACHE_WRITERS
+    assert [f[:5] for f in os.listdir(tmp_path / "cache")] == ["tree_"]      # one image, no temp file left
+    assert isinstance(k2, np.memmap) or isinstance(getattr(k2, "base", None), (np.memmap, np.ndarray))
     assert np.array_equal(k1, k2) and np.array_equal(f1, f2) and ids1 == ids2
     assert all(np.array_equal(a, b) for a, b in zip(l1, l2))
     info = l1_dbs["A"]
@@ -366,6 +368,65 @@ def test_tree_image_cache_roundtrip(l1_dbs, tmp_path, monkeypatch):
     monkeypatch.setenv("SS_IMAGE_CACHE", "off")
     k3, _, _, _ = sdb.load_tree_text(tdb)
     assert np.array_equal(k1, k3)
+
+
+def test_tree_cache_writers_do_not_collide(l1_dbs, tmp_path, monkeypatch):
+    """`-b 1` on a new database loads the tree twice in a row (identify_low_depth.py:119 then identify.py:402).  The
+    cache is written on a worker thread: the second load must wait for the first one's writer instead of parsing
+    again and starting a second writer on the same file; every writer has a temp file of its own; what ends up in
+    the cache maps back to exactly the arrays of a fresh parse."""
+    import threading
+    from strainscan_amd import db as sdb
+    cache = tmp_path / "cache"
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(cache))
+    tdb = os.path.join(l1_dbs["A"]["db_dir"], "Tree_database")
+    gate = threading.Event()
+    real_write = sdb._write_tree_cache
+    n_writes = []
+
+    def slow_write(path, t):
+        n_writes.append(path)
+        gate.wait(10)                     # the writer is still busy when the second load_tree starts
+        real_write(path, t)
+
+    monkeypatch.setattr(sdb, "_write_tree_cache", slow_write)
+    t1 = sdb.load_tree(tdb)
+    assert len(sdb._CACHE_WRITERS) == 1
+    threading.Timer(0.3, gate.set).start()
+    t2 = sdb.load_tree(tdb)               # joins the writer, then maps the finished file
+    assert len(n_writes) == 1 and not sdb._CACHE_WRITERS
+    files = os.listdir(cache)
+    assert len(files) == 1 and files[0].startswith("tree_") and files[0].endswith(".bin")
+    fresh = sdb._read_tree_cache(str(cache / files[0]))
+    monkeypatch.setenv("SS_IMAGE_CACHE", "off")
+    t3 = sdb.load_tree(tdb)
+    for t in (t1, t2, fresh):
+        assert list(t.ids) == list(t3.ids)
+        for name in ("keys", "flags", "rows", "offs", "urows", "uoffs"):
+            assert np.array_equal(getattr(t, name), getattr(t3, name)), name
+    # two writers of the same image at once (two processes in real life): both finish, one complete file
+    monkeypatch.setattr(sdb, "_write_tree_cache", real_write)
+    ths = [threading.Thread(target=real_write, args=(str(cache / files[0]), t3)) for _ in range(4)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    assert os.listdir(cache) == files
+    again = sdb._read_tree_cache(str(cache / files[0]))
+    assert np.array_equal(again.keys, t3.keys) and np.array_equal(again.rows, t3.rows)
+
+
+def test_plain_pickles_admit_no_globals(tmp_path):
+    """id2strain_re.pkl is a list of names (Recls_withR_new.py:114-115): read without admitting any global."""
+    import pickle
+    from strainscan_amd.tree import load_plain_pkl
+    p = tmp_path / "ok.pkl"
+    with open(p, "wb") as f:
+        pickle.dump(["GCF_1", "GCF_2", {"a": 1, "b": [2.5, None]}], f, pickle.HIGHEST_PROTOCOL)
+    assert load_plain_pkl(str(p)) == ["GCF_1", "GCF_2", {"a": 1, "b": [2.5, None]}]
+    q = tmp_path / "bad.pkl"
+    with open(q, "wb") as f:
+        pickle.dump([os.getcwd, "x"], f)
+    with pytest.raises(pickle.UnpicklingError):
+        load_plain_pkl(str(q))
 
 
 def test_revcomp_host_vs_golden(golden_dir):

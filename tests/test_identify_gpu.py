@@ -238,4 +238,17 @@ def test_config4_low_depth_cli(shape, tmp_path, monkeypatch):
     rs = np.random.RandomState(9)
     true_leaves = {bench.heap_to_id(int(h), C) for h in rs.choice(np.arange(spec["n_nodes"] // 2, spec["n_nodes"]), size=2, replace=False)}
     assert {a for a, _ in got[:2]} == true_leaves
+    # `-b 1` on a COLD cache loaded the tree twice (identify_ranks, then identify_cluster: identify_low_depth.py:119,
+    # identify.py:402): exactly one tree image and one index image, no temp file, and the mapped image holds the
+    # arrays of a fresh parse
+    ssdb.wait_cache_writes()
+    files = sorted(os.listdir(tmp_path / "cache"))
+    # (two index images: identify_ranks keys the table by the raw text, identify_cluster by its upper case)
+    assert [f[:5] for f in files] == ["index", "index", "tree_"] and all(f.endswith(".bin") for f in files), files
+    cached = ssdb._read_tree_cache(str(tmp_path / "cache" / files[2]))
+    monkeypatch.setenv("SS_IMAGE_CACHE", "off")
+    fresh = ssdb.load_tree(tdir)
+    assert list(cached.ids) == list(fresh.ids)
+    for name in ("keys", "flags", "rows", "offs", "urows", "uoffs"):
+        assert np.array_equal(getattr(cached, name), getattr(fresh, name)), name
     ssdb.clear_cache()
