@@ -355,7 +355,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU (10 M pairs)")
+    ap.add_argument("--reads", type=int, default=0,
+                    help="reads per GPU; default: 20 M (configs[1]: 10 M pairs on one GPU) at --gpus 1, 25 M at --gpus N > 1 "
+                         "(configs[2]: 200 M reads sharded over 8 GPUs = 25 M per GPU)")
     ap.add_argument("--leaves", type=int, default=823)
     ap.add_argument("--hit-frac", type=float, default=0.05)
     ap.add_argument("--db-shape", choices=("sampled", "contiguous", "mixed"), default="sampled",
@@ -399,6 +401,8 @@ def spawn_ranks(args, argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.reads <= 0:
+        args.reads = 20_000_000 if args.gpus == 1 else 25_000_000
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
@@ -414,7 +418,8 @@ def main(argv=None):
     if os.environ.get("SS_BENCH_WORKER_STUB"):     # tests/test_abi_and_host.py: argument handling up to here, no GPU
         if rank == 0:
             os.write(real_stdout, (json.dumps(dict(stub=True, n_gpus=world, rank=rank, local_rank=local,
-                                                   master=os.environ.get("MASTER_ADDR"), argv=list(argv))) + "\n").encode())
+                                                   master=os.environ.get("MASTER_ADDR"), argv=list(argv),
+                                                   reads_per_gpu=args.reads)) + "\n").encode())
         return
 
     import torch
@@ -448,7 +453,24 @@ def main(argv=None):
     t0 = time.time()
     db_spec = make_db(torch, dev, args.leaves, seed=20231013, shape=args.db_shape, hit_frac=args.hit_frac)
     n_rows = db_spec["keys"].size
-    db = _lib.KmerDB(db_spec["keys"], np.ones(n_rows, np.uint8), K, True)
+    index_how = "built"
+    if world > 1:
+        # as the product does (strainscan_amd/db.py rank0_first): rank 0 builds the index on the host's CPUs and exports
+        # the image, the others wait and import it -- not N host-side builds competing for the same cores
+        img_path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                                "ss_bench_index_%s.bin" % os.environ.get("MASTER_PORT", "0"))
+        if rank == 0:
+            db = _lib.KmerDB(db_spec["keys"], np.ones(n_rows, np.uint8), K, True)
+            db.export(img_path)
+        dist.barrier()
+        if rank != 0:
+            db = _lib.KmerDB.from_image(img_path)
+            index_how = "imported from rank 0's image"
+        dist.barrier()
+        if rank == 0:
+            os.unlink(img_path)
+    else:
+        db = _lib.KmerDB(db_spec["keys"], np.ones(n_rows, np.uint8), K, True)
     info = db.info()
     rows = db_spec["rows"]
     nodes = _lib.NodeSet.__new__(_lib.NodeSet)
@@ -456,7 +478,7 @@ def main(argv=None):
     h = C.c_void_p()
     _lib.check(_lib.lib().ss_nodes_create(_lib.ptr(rows), _lib.ptr(db_spec["row_off"]), db_spec["n_nodes"],
                                           C.byref(h)), "ss_nodes_create")
-    nodes._h, nodes.n_nodes = h, db_spec["n_nodes"]
+    nodes._h, nodes.n_nodes, nodes.n_rows_total = h, db_spec["n_nodes"], int(db_spec["row_off"][-1])
     layout = os.environ.get("SS_LAYOUT", "mini")
     log("[bench] db: %d rows, %d distinct, %d slots (%s layout), %.2f GB on device (%.1f s)" % (
         n_rows, info["n_distinct"], info["capacity"], layout, info["device_bytes"] / 1e9, time.time() - t0))
@@ -475,10 +497,9 @@ def main(argv=None):
     nodes.bind(db)
     stats = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(5)) for _ in range(args.steps)]
     exchange = world > 1 or self_group
-    packed = dict(n=0)
+    packed = dict(n=0, cap=0, pending=[])
 
     def step(i=None):
         db.reset(stream)
@@ -491,13 +512,33 @@ def main(argv=None):
         if i is not None:
             ev[i][2].record()
         if exchange:
-            packed["n"] = ssdist.exchange_touched(nodes, stream=stream)
-        nodes.reduce_touched_dev(stats.data_ptr(), stream)
+            # no host round trip inside: the packed buffer's size was decided by the previous exchange of this node set
+            packed["pending"].append(ssdist.exchange_touched(nodes, stream=stream))
         if i is not None:
             ev[i][3].record()
+        nodes.reduce_touched_dev(stats.data_ptr(), stream)
+        if i is not None:
+            ev[i][4].record()
 
+    def settle_exchanges():
+        """After a synchronisation: did every exchange carry all its counts?  (The first one of a node set sizes the buffer;
+        NodeSet.harvest repeats such a scan's harvest + exchange, here the steps are simply run again.)"""
+        ok = True
+        for pe in packed["pending"]:
+            ok = pe.complete() and ok
+            packed["n"], packed["cap"] = pe.total(), pe.cap
+        packed["pending"] = []
+        return ok
+
+    if exchange:
+        step()
+        torch.cuda.synchronize()
+        settle_exchanges()                       # learns the buffer size for this sample
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    if exchange and not settle_exchanges():
+        raise SystemExit("bench.py: the exchange buffer did not settle during warm-up")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -515,9 +556,13 @@ def main(argv=None):
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     reads_per_s = args.reads * world * args.steps / dt
+    if exchange and not settle_exchanges():
+        raise SystemExit("bench.py: an exchange inside the timed region did not carry all counts")
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     harvest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    tail_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))     # [exchange +] node reductions
+    exch_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))     # N > 1: flags + pack + all-reduce + unpack
+    reduce_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in ev]))   # node reductions
+    tail_ms = exch_ms + reduce_ms
     st_np = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
     # the counters of the last step are still in the table (a step resets them at its start): whole-table checksum,
     # and the harvest path against the row-gather path it replaces (ss_counts_rows_dev + ss_nodes_reduce_dev)
@@ -552,7 +597,7 @@ def main(argv=None):
                 ev2[i][1].record()
             nodes.harvest_dev(db, stream)
             if exchange:
-                ssdist.exchange_touched(nodes, stream=stream)
+                packed["pending"].append(ssdist.exchange_touched(nodes, stream=stream))
             nodes.reduce_touched_dev(stats2.data_ptr(), stream)
 
         for _ in range(args.warmup):
@@ -660,16 +705,24 @@ def main(argv=None):
 
     phases = None
     if rank == 0 and world == 1 and not args.no_phases and not args.calib_stream:
-        phases = measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, harvest_ms, tail_ms, stream)
+        phases = measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, harvest_ms, reduce_ms, stream)
     elif rank == 0:
-        phases = dict(kernel_ms=round(kern_ms, 3), gather_ms=round(harvest_ms, 3),
-                      allreduce_and_node_reduce_ms=round(tail_ms, 3), exchanged_counts=packed["n"])
+        phases = dict(kernel_ms=round(kern_ms, 3), gather_ms=round(harvest_ms, 3), allreduce_ms=round(exch_ms, 3),
+                      node_reduce_ms=round(reduce_ms, 3), exchanged_counts=packed["n"], exchange_buffer_counts=packed["cap"],
+                      exchange_bytes_per_rank=4 * (packed["cap"] + int(db_spec["n_nodes"])),
+                      allreduce_note="flags MAX-all-reduce + pack + SUM-all-reduce of the touched nodes' counts + unpack, "
+                                     "no host synchronisation inside (dist.exchange_touched)",
+                      index=index_how)
     if rank == 0:
         out = dict(metric="M reads/sec vs 1433-strain E. coli DB", value=round(reads_per_s / 1e6, 3),
                    unit="M reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms_per_step, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="u64", data="synthetic",
-                   config=dict(workload="E. coli 1433-strain/823-cluster DB, 10M synthetic 150 bp PE reads (20M reads) per GPU",
+                   config=dict(workload=("E. coli 1433-strain/823-cluster DB, 10M synthetic 150 bp PE reads (20M reads), 1xMI355X "
+                                         "[BASELINE configs[1]]" if world == 1 and args.reads == 20_000_000 else
+                                         "E. coli 1433-strain DB, %dM reads sharded %dxMI355X (%dM per GPU), RCCL all-reduce of per-node "
+                                         "hit counts [BASELINE configs[2]: 200M reads over 8 GPUs = 25M per GPU]"
+                                         % (args.reads * world // 1_000_000, world, args.reads // 1_000_000)),
                                db_rows=int(n_rows), tree_nodes=int(db_spec["n_nodes"]), reads_per_gpu=args.reads,
                                read_len=READ_LEN, k=K, hit_frac=args.hit_frac, db_shape=args.db_shape,
                                table_slots=int(info["capacity"]), minimizer_buckets=int(info.get("n_buckets", 0)),
@@ -682,7 +735,7 @@ def main(argv=None):
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
                               harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"]),
                    step_breakdown_ms=dict(scan_kernel=round(kern_ms, 3), harvest=round(harvest_ms, 3),
-                                          exchange_and_node_reduce=round(tail_ms, 3)))
+                                          exchange=round(exch_ms, 3) if exchange else None, node_reduce=round(reduce_ms, 3)))
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or self_group:
         dist.destroy_process_group()

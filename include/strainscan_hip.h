@@ -239,7 +239,11 @@ int ss_nodes_reduce(const ss_nodes *ns, const ss_db *db, ss_node_stat *stats /* 
  *                               in a node-major buffer and flags their nodes
  *   ss_nodes_reduce_touched_dev statistics of all nodes (untouched ones: length, zeros), buffer and flags cleared
  * Several GPUs, between the two (dist.py): touched flags MAX-all-reduced (get/set), the touched nodes' segments packed
- * (ss_nodes_pack_dev; packed_dev = NULL only returns the size; needs a host sync for that size), summed, unpacked. */
+ * (ss_nodes_pack_dev; packed_dev = NULL only returns the size; needs a host sync for that size), summed, unpacked.
+ * The product path uses the CAPPED forms, which never wait for the host: the first `cap` packed counts go into the
+ * buffer, the full packed size is left in *total_dev for the caller to read when it reads the statistics (total > cap:
+ * harvest again and exchange with a larger cap; dist.exchange_touched keeps cap at about twice the last total).
+ * ss_nodes_clear_dev zeroes the buffer and the flags (after a failed exchange, before the next harvest). */
 int ss_nodes_bind(ss_nodes *ns, const ss_db *db);
 int ss_nodes_harvest_dev(ss_nodes *ns, const ss_db *db, void *stream);
 int ss_nodes_reduce_touched_dev(ss_nodes *ns, ss_node_stat *stats_dev, void *stream);
@@ -247,6 +251,9 @@ int ss_nodes_touched_get_dev(const ss_nodes *ns, uint32_t *flags_dev, void *stre
 int ss_nodes_touched_set_dev(ss_nodes *ns, const uint32_t *flags_dev, void *stream);
 int ss_nodes_pack_dev(ss_nodes *ns, uint32_t *packed_dev, uint64_t cap, uint64_t *n_packed, void *stream);
 int ss_nodes_unpack_dev(ss_nodes *ns, const uint32_t *packed_dev, void *stream);
+int ss_nodes_pack_capped_dev(ss_nodes *ns, uint32_t *packed_dev, uint64_t cap, uint64_t *total_dev, void *stream);
+int ss_nodes_unpack_capped_dev(ss_nodes *ns, const uint32_t *packed_dev, uint64_t cap, void *stream);
+int ss_nodes_clear_dev(ss_nodes *ns, void *stream);
 /* one ad-hoc row list (adjust_profile's `remain` set, identify.py:181-189) */
 int ss_rows_reduce(const ss_db *db, const uint32_t *rows, uint64_t n, ss_node_stat *stat);
 

@@ -107,6 +107,9 @@ SIGNATURES = {
     "ss_nodes_touched_set_dev": (i32, [vp, vp, vp]),
     "ss_nodes_pack_dev": (i32, [vp, vp, u64, P(u64), vp]),
     "ss_nodes_unpack_dev": (i32, [vp, vp, vp]),
+    "ss_nodes_pack_capped_dev": (i32, [vp, vp, u64, vp, vp]),
+    "ss_nodes_unpack_capped_dev": (i32, [vp, vp, u64, vp]),
+    "ss_nodes_clear_dev": (i32, [vp, vp]),
     "ss_rows_reduce": (i32, [vp, vp, u64, P(NodeStat)]),
     "ss_l2_create": (i32, [vp, vp, u64, u32, P(vp)]),
     "ss_l2_create_planes": (i32, [vp, u64, u32, P(vp)]),
@@ -368,6 +371,7 @@ class NodeSet:
         check(lib().ss_nodes_create(ptr(rows), ptr(offs), len(row_lists), C.byref(h)), "ss_nodes_create")
         self._h = h
         self.n_nodes = len(row_lists)
+        self.n_rows_total = int(offs[-1])
 
     @classmethod
     def from_sorted(cls, rows, offsets):
@@ -381,6 +385,7 @@ class NodeSet:
         check(lib().ss_nodes_create(ptr(rows), ptr(offs), offs.size - 1, C.byref(h)), "ss_nodes_create")
         self._h = h
         self.n_nodes = offs.size - 1
+        self.n_rows_total = int(offs[-1]) if offs.size else 0
         return self
 
     def close(self):
@@ -413,24 +418,36 @@ class NodeSet:
 
     def harvest(self, db, between=None):
         """Statistics of all nodes from the counters of `db` (bound): harvest, [between(self): the multi-GPU
-        exchange], reduce over the touched nodes."""
+        exchange], reduce over the touched nodes.  `between` may return an object with .complete() (read after the
+        statistics have arrived: dist.exchange_touched's capped packing never waits for the host; when the packed counts
+        did not fit its buffer, the harvest is simply run again -- the counters are still in the table -- and the
+        exchange repeats with the larger buffer it has sized meanwhile; all ranks see the same total and repeat together)."""
         if getattr(self, "_bound", None) is not db:
             self.bind(db)
         dst = C.c_void_p()
         nbytes = max(1, self.n_nodes) * NODE_STAT_DTYPE.itemsize
         check(lib().ss_dev_alloc(C.byref(dst), nbytes), "ss_dev_alloc")
+        dirty = False
         try:
-            self.harvest_dev(db)
-            if between is not None:
-                between(self)
-            self.reduce_touched_dev(dst)
-            st = np.zeros(self.n_nodes, NODE_STAT_DTYPE)
-            if self.n_nodes:
-                check(lib().ss_memcpy_d2h(ptr(st), dst, self.n_nodes * NODE_STAT_DTYPE.itemsize, None), "ss_memcpy_d2h")
-            check(lib().ss_device_sync(), "ss_device_sync")
+            for _ in range(3):
+                dirty = True
+                self.harvest_dev(db)
+                pending = between(self) if between is not None else None
+                self.reduce_touched_dev(dst)          # clears the count buffer and the flags
+                dirty = False
+                st = np.zeros(self.n_nodes, NODE_STAT_DTYPE)
+                if self.n_nodes:
+                    check(lib().ss_memcpy_d2h(ptr(st), dst, self.n_nodes * NODE_STAT_DTYPE.itemsize, None), "ss_memcpy_d2h")
+                check(lib().ss_device_sync(), "ss_device_sync")
+                if pending is None or not hasattr(pending, "complete") or pending.complete():
+                    return st
+            raise RuntimeError("exchange of the touched nodes did not fit its buffer after three rounds")
         finally:
+            if dirty:
+                # harvest or the exchange raised: the dense buffer still holds counts that the next harvest would add to
+                lib().ss_nodes_clear_dev(self._h, None)
+                lib().ss_device_sync()
             lib().ss_dev_free(dst)
-        return st
 
     def reduce_dev(self, counts_rows_dptr, row_valid_dptr, stats_dptr, stream=None):
         check(lib().ss_nodes_reduce_dev(self._h, counts_rows_dptr, row_valid_dptr, stats_dptr, stream),

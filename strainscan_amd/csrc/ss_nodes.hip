@@ -346,11 +346,13 @@ __global__ __launch_bounds__(1024) void pack_offsets_kernel(const uint32_t *__re
 template <bool PACK>
 __global__ __launch_bounds__(256) void pack_copy_kernel(const uint32_t *__restrict__ touched, const uint64_t *__restrict__ offsets,
                                                         const uint64_t *__restrict__ packoff, uint32_t *__restrict__ val,
-                                                        uint32_t *__restrict__ packed)
+                                                        uint32_t *__restrict__ packed, uint64_t cap)
 {
     const uint32_t node = blockIdx.x;
     if (!touched[node]) return;
-    const uint64_t lo = offsets[node], n = offsets[node + 1] - lo, po = packoff[node];
+    const uint64_t lo = offsets[node], po = packoff[node];
+    if (po >= cap) return;
+    const uint64_t n = min(offsets[node + 1] - lo, cap - po);     // capped form: what does not fit stays where it is
     for (uint64_t i = threadIdx.x; i < n; i += 256) {
         if (PACK) packed[po + i] = val[lo + i];
         else val[lo + i] = packed[po + i];
@@ -406,7 +408,7 @@ int ss_nodes_bind(ss_nodes *ns, const ss_db *db)
     ns->d_packoff = nullptr;
     ns->bound = nullptr;
     const uint64_t n = ns->n_rows_total, n1 = std::max<uint64_t>(1, n), nn = std::max<uint32_t>(1, ns->n_nodes);
-    if (n >= 0xFFFFFFF0ull) return SS_ERANGE;
+    if (n > 0x7FFFFFFFull) return SS_ERANGE;            // hipcub's radix sort takes an int count
     uint32_t *k_in = nullptr, *p_in = nullptr;
     void *tmp = nullptr;
     auto cleanup = [&] { hipFree(k_in); hipFree(p_in); hipFree(tmp); };
@@ -492,8 +494,40 @@ int ss_nodes_pack_dev(ss_nodes *ns, uint32_t *packed_dev, uint64_t cap, uint64_t
     if (!packed_dev) return SS_OK;              // size query
     if (total > cap) return SS_ERANGE;
     hipLaunchKernelGGL((pack_copy_kernel<true>), dim3(ns->n_nodes), dim3(256), 0, st, ns->d_touched, ns->d_offsets, ns->d_packoff,
-                       ns->d_val, packed_dev);
+                       ns->d_val, packed_dev, ~0ull);
     SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_nodes_pack_capped_dev(ss_nodes *ns, uint32_t *packed_dev, uint64_t cap, uint64_t *total_dev, void *stream)
+{
+    if (!ns || !ns->bound || !packed_dev || !total_dev) return SS_EINVAL;
+    hipStream_t st = ss::as_stream(stream);
+    if (!ns->n_nodes) { SS_HIP(hipMemsetAsync(total_dev, 0, 8, st)); return SS_OK; }
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, st, ns->d_touched, ns->d_offsets, ns->n_nodes, ns->d_packoff);
+    SS_HIP(hipMemcpyAsync(total_dev, ns->d_packoff + ns->n_nodes, 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL((pack_copy_kernel<true>), dim3(ns->n_nodes), dim3(256), 0, st, ns->d_touched, ns->d_offsets, ns->d_packoff,
+                       ns->d_val, packed_dev, cap);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_nodes_unpack_capped_dev(ss_nodes *ns, const uint32_t *packed_dev, uint64_t cap, void *stream)
+{
+    if (!ns || !ns->bound || !packed_dev) return SS_EINVAL;
+    if (!ns->n_nodes) return SS_OK;
+    hipLaunchKernelGGL((pack_copy_kernel<false>), dim3(ns->n_nodes), dim3(256), 0, ss::as_stream(stream), ns->d_touched, ns->d_offsets,
+                       ns->d_packoff, ns->d_val, const_cast<uint32_t *>(packed_dev), cap);
+    SS_HIP(hipGetLastError());
+    return SS_OK;
+}
+
+int ss_nodes_clear_dev(ss_nodes *ns, void *stream)
+{
+    if (!ns || !ns->bound) return SS_EINVAL;
+    hipStream_t st = ss::as_stream(stream);
+    SS_HIP(hipMemsetAsync(ns->d_val, 0, std::max<uint64_t>(1, ns->n_rows_total) * 4, st));
+    SS_HIP(hipMemsetAsync(ns->d_touched, 0, (uint64_t)std::max<uint32_t>(1, ns->n_nodes) * 4, st));
     return SS_OK;
 }
 
@@ -502,7 +536,7 @@ int ss_nodes_unpack_dev(ss_nodes *ns, const uint32_t *packed_dev, void *stream)
     if (!ns || !ns->bound || !packed_dev) return SS_EINVAL;
     if (!ns->n_nodes) return SS_OK;
     hipLaunchKernelGGL((pack_copy_kernel<false>), dim3(ns->n_nodes), dim3(256), 0, ss::as_stream(stream), ns->d_touched, ns->d_offsets,
-                       ns->d_packoff, ns->d_val, const_cast<uint32_t *>(packed_dev));
+                       ns->d_packoff, ns->d_val, const_cast<uint32_t *>(packed_dev), ~0ull);
     SS_HIP(hipGetLastError());
     return SS_OK;
 }

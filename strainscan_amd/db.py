@@ -109,10 +109,39 @@ def scan_into(kdb, paths, allreduce=True):
         kdb.scan_files([p for p in paths if p])
 
 
+INDEX_EVENTS = {"built": 0, "imported": 0}       # device indexes built from keys / imported from an image, this process
+
+
+def rank0_first(fn):
+    """Several ranks and an image cache: rank 0 runs fn() first -- it parses / builds and EXPORTS whatever image is
+    missing -- the others wait at a barrier and then run the same fn(), which now finds the image and imports it:
+    one host-side index build per node instead of one per rank (an E. coli tree: ~1 s of all the box's CPUs each).
+    The barrier is unconditional (every rank takes it once per call), so the ranks cannot disagree about it; a rank
+    that finds no image after all (cache not writable) simply builds its own."""
+    from . import dist
+    if not dist.is_distributed() or not _cache_dir():
+        return fn()
+    import torch.distributed as td
+    rank, _ = dist.rank_world()
+    if rank == 0:
+        try:
+            out = fn()
+            wait_cache_writes()
+        finally:
+            td.barrier()
+        return out
+    td.barrier()
+    return fn()
+
+
 def fasta_index(path, k, upper_keys):
     """Device index of a k-mer FASTA (a cluster's all_kmer.fasta): imported from the image cache when there is
     one for this file (path, size, mtime, k, key convention), else parsed, built and exported.  Only the
     minimizer layout (k = 31) has an image; other k are built every time."""
+    return rank0_first(lambda: _fasta_index(path, k, upper_keys))
+
+
+def _fasta_index(path, k, upper_keys):
     import hashlib
     cdir = _cache_dir()
     img = None
@@ -123,10 +152,13 @@ def fasta_index(path, k, upper_keys):
         img = os.path.join(cdir, "index_%s.bin" % tag)
         if os.path.exists(img):
             try:
-                return _lib.KmerDB.from_image(img)
+                kdb = _lib.KmerDB.from_image(img)
+                INDEX_EVENTS["imported"] += 1
+                return kdb
             except RuntimeError:
                 pass
     kdb = _lib.KmerDB.from_fasta(path, int(k), upper_keys=upper_keys)
+    INDEX_EVENTS["built"] += 1
     if img:
         try:
             _export_image(kdb, cdir, img)
@@ -388,7 +420,8 @@ class TreeImage:
     def __init__(self, db_dir, upper_keys=True):
         self.db_dir = db_dir
         self.upper_keys = upper_keys
-        t, self.kdb = load_tree(db_dir, L1_K, with_keys=lambda keys, flags: self._index(db_dir, keys, flags, upper_keys))
+        t, self.kdb = rank0_first(lambda: load_tree(db_dir, L1_K, with_keys=lambda keys, flags:
+                                                    self._index(db_dir, keys, flags, upper_keys)))
         self.node_ids = list(t.ids)
         self.node_rows = dict(zip(t.ids, t.lists))   # id -> rows in FILE order (adjust_profile indexes it)
         self.node_index = {i: j for j, i in enumerate(self.node_ids)}
@@ -413,11 +446,13 @@ class TreeImage:
                 try:
                     kdb = _lib.KmerDB.from_image(path)
                     if kdb.n_rows == keys.size:
+                        INDEX_EVENTS["imported"] += 1
                         return kdb
                     kdb.close()
                 except RuntimeError:
                     pass
         kdb = _lib.KmerDB(keys, flags, L1_K, upper_keys)
+        INDEX_EVENTS["built"] += 1
         if path:
             try:
                 _export_image(kdb, cdir, path)

@@ -83,8 +83,26 @@ class _NodeExchange:
     def unpack(self, t, stream):
         _lib.check(_lib.lib().ss_nodes_unpack_dev(self.nodes._h, t.data_ptr(), stream), "ss_nodes_unpack_dev")
 
+    # capped forms: no host round trip; the packed size stays on the device until the statistics are read
+    def pack_capped(self, t, cap, total_t, stream):
+        _lib.check(_lib.lib().ss_nodes_pack_capped_dev(self.nodes._h, t.data_ptr(), cap, total_t.data_ptr(), stream),
+                   "ss_nodes_pack_capped_dev")
+
+    def unpack_capped(self, t, cap, stream):
+        _lib.check(_lib.lib().ss_nodes_unpack_capped_dev(self.nodes._h, t.data_ptr(), cap, stream), "ss_nodes_unpack_capped_dev")
+
+    @property
+    def n_positions(self):
+        return int(self.nodes.n_rows_total)
+
+    @property
+    def state(self):
+        """Where the buffer size learnt from earlier scans lives (the node set itself)."""
+        return self.nodes.__dict__
+
 
 _PACK_BUF = {}
+PACK_MIN = 1 << 18        # elements: 1 MB -- below this a smaller all-reduce is no faster
 
 
 def exchange_device():
@@ -92,13 +110,43 @@ def exchange_device():
     return "cuda"
 
 
+class PackedExchange:
+    """What exchange_touched returns: the buffer size it used and, on the device, the size the packed counts needed.
+    complete() reads that number (call it once the stream has been synchronised -- the caller does that anyway to
+    read the node statistics) and sizes the next exchange of this node set: about twice the last total."""
+
+    def __init__(self, cap, total_t, state, n_positions):
+        self.cap, self._total_t, self._state, self._n_positions = cap, total_t, state, n_positions
+        self._total = None
+
+    def total(self):
+        if self._total is None:
+            self._total = int(self._total_t.item()) if self._total_t is not None else 0
+            want = min(max(PACK_MIN, 2 * self._total), max(1, self._n_positions))
+            if self._total > self.cap or 4 * want <= self.cap:      # grow at once, shrink only when far too large
+                self._state["_pack_cap"] = want
+        return self._total
+
+    def complete(self):
+        return self.total() <= self.cap
+
+    def __int__(self):
+        return self.total()
+
+
 def exchange_touched(nodes, group=None, device="cuda", stream=None, ex=None):
     """The collective of a sharded tree scan, between ss_nodes_harvest_dev and ss_nodes_reduce_touched_dev: every rank
     has harvested ITS reads' counts into the node-major buffer.  (1) MAX-all-reduce of the touched flags (4 bytes per
     node) -> every rank knows the union of the nodes with hits; (2) the segments of those nodes, packed in node order
     (same layout on every rank), are SUM-all-reduced and unpacked.  Bytes per rank per scan: 4 * n_nodes + 4 * (rows
-    of the touched nodes) -- ~2.5 MB for a three-strain sample against an E. coli tree of 25 M rows, where the full
-    row vector is 100 MB.  Integer sums: bit-identical to a single-GPU scan.  Returns the packed length."""
+    of the touched nodes, times the slack of the buffer: <= 2) -- a few MB for a three-strain sample against an E. coli
+    tree of 25 M rows, where the full row vector is 100 MB.  Integer sums: bit-identical to a single-GPU scan.
+
+    Nothing here waits for the host: the buffer has a size decided BEFORE the scan (twice what the previous exchange
+    of this node set needed, 1 MB at least, never more than all list positions), the device packs what fits and leaves
+    the real total in a device word.  -> PackedExchange; its complete() tells the caller -- when it reads the node
+    statistics -- whether everything travelled (every rank computes the same total from the same flags, so all ranks
+    agree); if not, the caller harvests again and calls this again, now with the larger buffer (NodeSet.harvest)."""
     import torch
     import torch.distributed as dist
     ex = ex or _NodeExchange(nodes)
@@ -108,18 +156,20 @@ def exchange_touched(nodes, group=None, device="cuda", stream=None, ex=None):
     ex.flags_get(flags, stream)
     dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
     ex.flags_set(flags, stream)
-    n = ex.pack(None, stream)
-    if n == 0:
-        return 0
+    n_pos = ex.n_positions
+    if n_pos == 0:
+        return PackedExchange(0, None, ex.state, 0)
+    cap = min(int(ex.state.get("_pack_cap", PACK_MIN)), n_pos)
     buf = _PACK_BUF.get(device)
-    if buf is None or buf.numel() < n:
-        buf = torch.empty(max(n, 1 << 20), dtype=torch.int32, device=device)
+    if buf is None or buf.numel() < cap:
+        buf = torch.zeros(max(cap, 1 << 20), dtype=torch.int32, device=device)
         _PACK_BUF.clear()
         _PACK_BUF[device] = buf
-    ex.pack(buf, stream)
-    allreduce_counts(buf[:n], group)
-    ex.unpack(buf, stream)
-    return n
+    total_t = torch.zeros(1, dtype=torch.int64, device=device)
+    ex.pack_capped(buf, cap, total_t, stream)
+    allreduce_counts(buf[:cap], group)
+    ex.unpack_capped(buf, cap, stream)
+    return PackedExchange(cap, total_t, ex.state, n_pos)
 
 
 def allreduce_table(kdb):

@@ -111,7 +111,8 @@ class _NumpyNodes:
     """What ss_nodes_* gives dist.exchange_touched, on numpy arrays: a dense node-major buffer, touched flags, packing of
     the touched nodes' segments in node order.  The semantics of ss_nodes.hip (pack_offsets_kernel / pack_copy_kernel)."""
 
-    def __init__(self, offsets, val):
+    def __init__(self, offsets, val, state=None):
+        self._state = {} if state is None else state       # what the product keeps on the NodeSet: the learnt buffer size
         self.offsets = np.asarray(offsets, np.int64)
         self.n_nodes = self.offsets.size - 1
         self.val = val
@@ -145,6 +146,30 @@ class _NumpyNodes:
             self.val[a:b] = t[o:o + b - a].numpy().view(np.uint32)
             o += b - a
 
+    # capped forms (ss_nodes_pack_capped_dev / ss_nodes_unpack_capped_dev): the first `cap` packed counts travel
+    def pack_capped(self, t, cap, total_t, stream):
+        o = 0
+        for a, b in self._segments():
+            m = max(0, min(b - a, cap - o))
+            t[o:o + m] = torch.from_numpy(self.val[a:a + m].view(np.int32))
+            o += b - a
+        total_t[0] = o
+
+    def unpack_capped(self, t, cap, stream):
+        o = 0
+        for a, b in self._segments():
+            m = max(0, min(b - a, cap - o))
+            self.val[a:a + m] = t[o:o + m].numpy().view(np.uint32)
+            o += b - a
+
+    @property
+    def n_positions(self):
+        return int(self.offsets[-1])
+
+    @property
+    def state(self):
+        return self._state
+
 
 def _exchange_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
@@ -168,7 +193,16 @@ def _exchange_worker(rank, world, port, out_dir):
         val[0] += np.uint32(0x90000000)                      # unsigned wrap across ranks
     np.save(os.path.join(out_dir, "val%d.npy" % rank), val)
     ex = _NumpyNodes(offsets, val.copy())
-    n = sdist.exchange_touched(None, device="cpu", ex=ex)
+    sdist.PACK_MIN = 64                                      # the first buffer is too small on purpose
+    pend = sdist.exchange_touched(None, device="cpu", ex=ex)
+    rounds = 1
+    assert pend.cap == 64 and not pend.complete()            # ... every rank sees that from the same total ...
+    while not pend.complete():                               # ... and repeats as NodeSet.harvest does: harvest again, exchange
+        ex = _NumpyNodes(offsets, val.copy(), ex.state)
+        pend = sdist.exchange_touched(None, device="cpu", ex=ex)
+        rounds += 1
+    assert rounds == 2 and pend.cap >= pend.total()
+    n = pend.total()
     np.save(os.path.join(out_dir, "sum%d.npy" % rank), ex.val)
     np.save(os.path.join(out_dir, "flags%d.npy" % rank), ex.touched)
     with open(os.path.join(out_dir, "n%d.txt" % rank), "w") as f:

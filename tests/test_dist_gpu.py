@@ -60,6 +60,7 @@ for job in jobs:
             e2 = type(e).__name__
         rec["ranks"] = dict(error=e2, result=None if r is None else [[int(a), float(b)] for a, b in r])
     out.append(rec)
+out.append(dict(index_events=dict(ssdb.INDEX_EVENTS)))
 json.dump(out, open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w"))
 dist.barrier()
 dist.destroy_process_group()
@@ -77,7 +78,7 @@ def _spawn(world, jobs, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), SS_IMAGE_CACHE=str(tmp_path / ("cache%d" % r)))
+                   MASTER_PORT=str(port), SS_IMAGE_CACHE=str(tmp_path / "cache"))      # one cache for the node
         env.pop("STRAINSCAN_QUIET", None)
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
     errs = [p.communicate(timeout=900)[1].decode()[-3000:] for p in procs]
@@ -115,6 +116,11 @@ def test_sharded_identify_equals_golden(world, golden_dir, l1_dbs, l1_reads, tmp
     jobs.append(dict(module="identify", seed=sc.POISSON_SEED, fq=[str(p1), str(p2)], tdb=tdbA, cutoff=[0.1, 0.4, 1]))
     wants.append(("A_mix3", run0))
     outs = _spawn(world, jobs, tmp_path)
+    # one image cache for all ranks (db.rank0_first): rank 0 parsed and built every index and exported it, the others
+    # waited at the barrier and imported -- no rank but 0 built anything, and no temp file is left
+    ev = [o.pop()["index_events"] for o in outs]
+    assert ev[0]["built"] >= 1 and all(e["built"] == 0 and e["imported"] >= 1 for e in ev[1:]), ev
+    assert all(f.endswith(".bin") for f in os.listdir(tmp_path / "cache"))
     any_rows = False
     for ji, (sname, run) in enumerate(wants):
         recs_ = [o[ji] for o in outs]

@@ -820,6 +820,20 @@ def test_bench_line_contract_and_exchange_path():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["check"]["harvest_equals_gather"] is True
     assert d["check"]["exchanged_counts"] > 0 and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 300000 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
+    # what a first 8-GPU run needs: the all-reduce phase reported on its own, the exchange buffer sized without a host
+    # round trip (and large enough: the counts all travelled), rank 0's index image imported by the other ranks
+    ph = d["phases"]
+    assert ph["allreduce_ms"] > 0 and ph["node_reduce_ms"] > 0 and ph["exchanged_counts"] == d["check"]["exchanged_counts"]
+    assert ph["exchange_buffer_counts"] >= ph["exchanged_counts"] and ph["exchange_bytes_per_rank"] >= 4 * ph["exchanged_counts"]
+    assert d["step_breakdown_ms"]["exchange"] == ph["allreduce_ms"]
+    assert "configs[2]" in d["config"]["workload"] and "sharded 2xMI355X" in d["config"]["workload"]
+    # default batch: 20 M reads at one GPU (configs[1]), 25 M per GPU at N > 1 (configs[2] = 200 M over 8)
+    import bench
+    for gpus, want in ((1, 20_000_000), (8, 25_000_000)):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(gpus)],
+                           env=dict(env, SS_BENCH_WORKER_STUB="1", RANK="0", WORLD_SIZE=str(gpus), LOCAL_RANK="0"), capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert json.loads(r.stdout.decode().strip().splitlines()[-1])["reads_per_gpu"] == want
 
 
 def test_index_image_independent_of_thread_count(L, tmp_path):
