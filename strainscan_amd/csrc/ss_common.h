@@ -158,6 +158,7 @@ struct ss_reads {
 namespace ss {
 // Records of every slab re-ordered by the minimizer of their first k-mer (ss_reorder.hip); `force`: ignore SS_READS_ORDER
 int reads_order_for_locality(ss_reads *R, bool force = false);
+int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used, uint64_t *out_cap);
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
 using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,

@@ -697,7 +697,7 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
     if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: files done %.4f s, device idle %.4f s\n", t_parsed, load_since());
     R->n_records = recs;
     R->n_bases = bases;
-    rc = ss::reads_order_for_locality(R);      // only with SS_READS_ORDER=locality (ss_reorder.hip)
+    rc = ss::reads_order_for_locality(R);      // unless SS_READS_ORDER=file (ss_reorder.hip)
     if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
     if (getenv("SS_INGEST_TRACE")) fprintf(stderr, "[ingest] ss_reads_load: ordered for locality at %.4f s\n", load_since());
     *out = R;
@@ -710,16 +710,25 @@ int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads
     ss_reads *R = new (std::nothrow) ss_reads();
     if (!R) return SS_ENOMEM;
     R->first_slab = n + 64;
-    if (n) {
+    R->n_bases = n;
+    if (n && order && n >= 64) {
+        // binned straight out of the caller's block (ss_reorder.hip): no intermediate copy
+        char *d = nullptr;
+        uint64_t used = 0, cap = 0;
+        const int rc = ss::order_flat_dev(static_cast<const char *>(flat_dev), n, &d, &used, &cap);
+        if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
+        ss_reads::Slab sl;
+        sl.d = d; sl.cap = cap; sl.used = used;
+        R->slabs.push_back(sl);
+        R->device_bytes = cap;
+        R->n_blocks = 1;
+    } else if (n) {
         char *dst = R->reserve(n);
         if (!dst) { ss_reads_destroy(R); return SS_ENOMEM; }
         const uint64_t plen = ss_reads::padded(n);
         if (hipMemcpy(dst, flat_dev, n, hipMemcpyDeviceToDevice) != hipSuccess ||
             hipMemset(dst + n, '\n', plen - n) != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
     }
-    R->n_bases = n;
-    int rc = order ? ss::reads_order_for_locality(R, true) : SS_OK;
-    if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
     *out = R;
     return SS_OK;
 }

@@ -4,23 +4,35 @@
 // from memory (ss_mini.hip): ~13 lookups per read, 54 G/s, all the memory system gives.  But a sample
 // covers its genomes many times: the reads that start within the same 17 bases of a genome have the same minimizer in
 // their first k-mer and share nearly all of their other minimizers too.  In file order such reads are millions of
-// records apart -- every lookup misses the 4 MB L2; when they are neighbours, the first read of a group pays the
-// sector and the others find it in L2.  Counting does not care about the order of the records (integer sums), and the
-// reads are parsed and shipped once per sample but scanned several times (tree scan, one scan per identified
-// cluster, two more with -b: identify.py:409, Vote_Strain_L2_Lasso_new_sp.py:354-372, identify_low_depth.py:119,124;
-// or one sample against the databases of many species).
-// So a resident read set can be rewritten with its records sorted by the minimizer (the 30-bit m-mer, same ordering key
-// as the index) of their first 31 bases: find the record starts and ends (two streaming passes, 16 bytes per lane),
-// key every record, radix-sort (key, record) pairs, prefix-sum the lengths, copy.  9.7 ms per 20 M reads on MI355X
-// (copy 4.6, the rest 0.6-1.1 each); the scan of 20 M reads of a 70/20/10 three-strain sample then takes 3.8 instead of
-// 5.7 ms (sampled table) / 2.8 instead of 3.4 ms (contiguous).  The gain grows with the coverage (these reads cover
-// their genomes 400/115/60 fold; at one-fold coverage it is nil), and it is won per scan while the ordering is paid
-// once: it pays from about five scans of the same resident sample on -- one sample against many databases -- and does
-// not for the CLI's one tree scan plus a few small cluster scans.  Hence OPT-IN: SS_READS_ORDER=locality for
-// ss_reads_load, the `order` argument of ss_reads_from_flat_dev; bench.py reports both orders.
+// records apart -- every lookup misses the 4 MB L2; when they are processed at about the same time, the first read of a
+// group pays the sector and the others find it in L2.  Counting does not care about the order of the records (integer
+// sums), and the reads are parsed and shipped once per sample but scanned several times (tree scan, one scan per
+// identified cluster, two more with -b: identify.py:409, Vote_Strain_L2_Lasso_new_sp.py:354-372,
+// identify_low_depth.py:119,124).
+//
+// "About the same time" is all that is needed: the chip has ~8 K scan waves = ~50 K reads in flight, so a total order
+// buys nothing over BINS of a few thousand reads.  Round 2 sorted (hipcub radix sort of 20 M (key, record) pairs, five
+// passes over per-record arrays, a gather copy at 1.3 TB/s: 9.7 ms per 20 M reads); now the records are binned in two
+// streaming passes over the slab, with no per-record array at all:
+//   bin  = top SS_ORDER_BITS (12) bits of h = mix30(minimizer of the record's first 31 bases) -- the hash that addresses the
+//          index pages (ss_mini.hip), so a bin's FIRST lookups also walk the page table in ascending order;
+//          records without a first k-mer (shorter, or a non-ACGT base in it) go to one extra bin at the end
+//   pass 1  count_kernel: find the record starts of a 4 KB tile (16 bytes per lane, SWAR newline masks), the end of each
+//           record (suffix minimum over the tile + a 512-byte halo), its bin; atomicAdd of the record's slot size to the
+//           bin's byte count.  A slot = record + '\n', padded with '\n' to 8 bytes (152 bytes for a 150-base read: nothing
+//           added) so that every piece of the copy is an aligned store
+//   scan    exclusive prefix over the 4097 bin sizes (one workgroup)
+//   pass 2  the same discovery again (cheaper than storing and re-reading 16 bytes per record), a returning atomicAdd
+//           on the bin's cursor claims the slot, and the WAVE copies its records together: the records' 16-byte pieces are
+//           numbered across the wave (prefix sum of the piece counts), every lane finds the record of its piece by
+//           binary search in LDS, loads 16 unaligned bytes, pads behind the record's end with '\n' and stores them
+//           aligned -- ~70 pieces for the ~7 records of a wave's 1 KB, two rounds of full-width loads and stores.
+// Order inside a bin is whatever the atomics decide (not reproducible run to run; the multiset of records is, and so
+// is every count).  ON by default for resident read sets (SS_READS_ORDER=file keeps the file order): it costs ~2-3 ms per
+// 20 M reads against ~80 ms of parsing and PCIe for the same reads, and every scan of the set is then 0-35 % faster
+// depending on the coverage of the sample (profiles/r03_locality_sweep.json).
 #include "ss_common.h"
-
-#include <hipcub/hipcub.hpp>
+#include "ss_scan_dev.h"
 
 #include <algorithm>
 #include <chrono>
@@ -28,8 +40,10 @@
 
 namespace {
 
-constexpr int RB = 4096;                    // bytes of a slab handled by one workgroup of the boundary passes
-constexpr uint32_t KEY_NONE = 0x40000000u;  // records shorter than a k-mer or with a non-ACGT base in their first 31
+constexpr int RB = 4096;                    // bytes of a slab owned by one workgroup (256 lanes x 16 bytes)
+constexpr int HALO = 512;                   // bytes behind the tile searched (in parallel) for the end of its last record
+constexpr int MAX_BITS = 16;
+constexpr uint32_t NO_NL = 0xFFFFu;         // "no newline" as a tile-relative position
 
 // newline mask of 16 bytes (bit i = byte i is '\n'), SWAR zero-byte test on w ^ 0x0A0A0A0A
 __device__ __forceinline__ uint32_t nl_mask16(const uint4 v)
@@ -45,114 +59,228 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint4 v)
     return m;
 }
 
-// pass 1: record starts per workgroup; pass 2 (WRITE): their positions and the positions of the record ends.
-// A workgroup = 256 threads x 16 bytes; a record starts at a base that follows a '\n' (or the slab's first byte) and
-// ends at the first '\n' behind it.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void bounds_kernel(const char *__restrict__ b, uint64_t n, uint32_t *__restrict__ counts,
-                                                     const uint64_t *__restrict__ base, uint64_t *__restrict__ starts,
-                                                     uint64_t *__restrict__ ends)
+// 16 bytes at b + i; bytes at or beyond n read as '\n'
+__device__ __forceinline__ uint4 load16_nl(const char *__restrict__ b, uint64_t i, uint64_t n)
 {
-    __shared__ uint32_t s_wave[4][2];
+    if (i + 16 <= n) { uint4 v; __builtin_memcpy(&v, b + i, 16); return v; }
+    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    for (int k = 0; k < 16 && i + k < n; k++) {
+        const uint32_t ch = (uint8_t)b[i + k];
+        w[k >> 2] = (w[k >> 2] & ~(0xFFu << (8 * (k & 3)))) | (ch << (8 * (k & 3)));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// bin of a record: top `bits` bits of mix30(minimizer of its first 31 bases) (ordering key of the index, leftmost on
+// ties); 1 << bits when the record has no first k-mer.  `b + s .. + 32` is inside the buffer (callers check).
+__device__ __forceinline__ uint32_t record_bin(const char *__restrict__ b, uint64_t s, uint64_t len, int bits)
+{
+    if (len < 31) return 1u << bits;
+    uint4 q[2];
+    __builtin_memcpy(q, b + s, 32);
+    const uint32_t w[8] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w};
+    uint64_t km = 0;
+    uint32_t bad = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const uint32_t c = (w[d] >> 1) & 0x03030303u;
+        const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, c);          // code -> 'A' 'C' 'T' 'G'
+        uint32_t diff = (w[d] & 0xDFDFDFDFu) ^ letter;
+        if (d == 7) diff &= 0x00FFFFFFu;                                            // byte 31 is not part of the k-mer
+        bad |= diff;
+        km |= (uint64_t)__builtin_amdgcn_udot4(c, 0x40100401u, 0u, false) << (8 * d);
+    }
+    if (bad) return 1u << bits;
+    km &= 0x3FFFFFFFFFFFFFFFull;
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 31 - ss::MINI_M + 1; i++) {
+        const uint32_t x = (uint32_t)(km >> (2 * i));
+        best = min(best, (ss::mmkey(x) & ss::KEY_MASK) | (uint32_t)i);              // (key, position): leftmost on ties
+    }
+    const uint32_t x = (uint32_t)(km >> (2 * (best & 31u))) & ss::M30;
+    return ss::mix30(x) >> (30 - bits);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// One kernel, two uses.  WRITE = false: bins[bin] += slot bytes of every record that STARTS in this tile.
+// WRITE = true: bins[] holds the bins' cursors (exclusive prefix of the counts): claim and copy.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bin_kernel(const char *__restrict__ b, uint64_t n, int bits,
+                                                  unsigned long long *__restrict__ bins, char *__restrict__ dst)
+{
+    __shared__ uint32_t s_first[5];                     // first newline (tile-relative) of waves 0..3 and of the halo
+    __shared__ uint64_t s_src[4][64], s_dst[4][64];
+    __shared__ uint32_t s_len[4][64], s_pend[4][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint64_t i0 = (uint64_t)blockIdx.x * RB + (uint64_t)t * 16;
-    uint32_t nl = 0xFFFFu, prev = 1u;                           // beyond the slab: newlines
-    if (i0 < n) {                                               // n is a multiple of 16 (padded blocks)
-        nl = nl_mask16(*reinterpret_cast<const uint4 *>(b + i0));
+    const uint64_t tile0 = (uint64_t)blockIdx.x * RB, i0 = tile0 + (uint64_t)t * 16;
+    uint32_t nl = 0xFFFFu, prev = 1u;                   // beyond the buffer: newlines
+    if (i0 < n) {
+        nl = nl_mask16(load16_nl(b, i0, n));
         prev = i0 == 0 ? 1u : (uint32_t)(b[i0 - 1] == '\n');
     }
-    const uint32_t before = ((nl << 1) | prev) & 0xFFFFu;       // bit i = byte i - 1 is a newline
-    const uint32_t st = ~nl & before & 0xFFFFu, en = nl & ~before & 0xFFFFu;
-    uint32_t cs = (uint32_t)__popc(st), ce = (uint32_t)__popc(en);
-    // inclusive wave scan of (cs, ce) packed in one word (<= 16 per thread, 1024 per wave)
-    uint32_t pk = cs | (ce << 16);
+    // first newline at or behind every lane's chunk: suffix minimum over the wave, then over the later waves and the halo
+    uint32_t mine = nl ? (uint32_t)t * 16u + (uint32_t)__builtin_ctz(nl) : NO_NL, suf = mine;
+#pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)pk, off, 64);
-        if (lane >= off) pk += o;
+        const uint32_t o = (uint32_t)__shfl_down((int)suf, off, 64);
+        if (lane + off < 64) suf = min(suf, o);
     }
-    if (lane == 63) { s_wave[wave][0] = pk & 0xFFFFu; s_wave[wave][1] = pk >> 16; }
-    __syncthreads();
-    if (!WRITE) {
-        if (t == 0) counts[blockIdx.x] = s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0];
-        return;
-    }
-    uint64_t s_off = base[blockIdx.x], e_off = s_off;
-    // a record's end may lie in a later workgroup than its start: the ends before this workgroup = the starts before it
-    // minus the record that is still open at its first byte
-    const uint64_t lo = (uint64_t)blockIdx.x * RB;
-    if (lo > 0 && lo < n && b[lo - 1] != '\n') e_off -= 1;
-    for (int w = 0; w < wave; w++) { s_off += s_wave[w][0]; e_off += s_wave[w][1]; }
-    s_off += (pk & 0xFFFFu) - cs;
-    e_off += (pk >> 16) - ce;
-    for (uint32_t m = st; m; m &= m - 1) starts[s_off++] = i0 + (uint32_t)__ffs(m) - 1u;
-    for (uint32_t m = en; m; m &= m - 1) ends[e_off++] = i0 + (uint32_t)__ffs(m) - 1u;
-}
-
-// key of a record = the minimizer (30-bit m-mer, ordering key of ss_mini.hip, leftmost on ties) of its first 31 bases
-__global__ void keys_kernel(const char *__restrict__ b, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends,
-                            uint32_t n_rec, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx, uint64_t *__restrict__ len1)
-{
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rec) return;
-    const uint64_t s = starts[r], len = ends[r] - s;
-    idx[r] = r;
-    len1[r] = len + 1;
-    uint32_t key = KEY_NONE;
-    if (len >= 31) {
-        uint64_t km = 0;
-        bool ok = true;
-        unsigned char by[32];
-        __builtin_memcpy(by, b + s, 32);                    // the slab is padded: 32 bytes from a record start are inside it
-        for (int j = 0; j < 31; j++) {
-            const int c = ss::base_code(by[j]);
-            ok = ok && c >= 0;
-            km |= (uint64_t)(c & 3) << (2 * j);
-        }
-        if (ok) {
-            uint32_t best = 0xFFFFFFFFu, bx = 0;
-            for (int i = 0; i < 17; i++) {
-                const uint32_t x = (uint32_t)(km >> (2 * i)) & 0x3FFFFFFFu;
-                const uint32_t h = ((x & 0xFFFFFFu) * (0x4F1BBu << 5) + 0x7F4A7C00u) & ~31u;
-                if (h < best) { best = h; bx = x; }
+    if (lane == 0) s_first[wave] = suf;
+    if (wave == 0) {                                    // halo: HALO bytes behind the tile, 32 lanes x 16 bytes
+        uint32_t h = NO_NL;
+        const uint64_t j0 = tile0 + RB + (uint64_t)lane * 16;
+        if (lane < HALO / 16) {
+            if (j0 < n) {
+                const uint32_t m = nl_mask16(load16_nl(b, j0, n));         // (the buffer's end reads as a newline)
+                if (m) h = RB + (uint32_t)lane * 16u + (uint32_t)__builtin_ctz(m);
+            } else {
+                h = RB + (uint32_t)lane * 16u;
             }
-            key = bx;
         }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) h = min(h, (uint32_t)__shfl_xor((int)h, off, 64));
+        if (lane == 0) s_first[4] = h;
     }
-    keys[r] = key;
-}
+    __syncthreads();
+    uint32_t later = (uint32_t)__shfl_down((int)suf, 1, 64);               // first newline behind this lane's chunk
+    if (lane == 63) later = NO_NL;
+    for (int w = wave + 1; w < 5; w++) later = min(later, s_first[w]);
 
-__global__ void gather_len_kernel(const uint64_t *__restrict__ len1, const uint32_t *__restrict__ order, uint32_t n_rec,
-                                  uint64_t *__restrict__ out)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n_rec) out[j] = len1[order[j]];
-}
-
-// record order[j] -> dst + off[j], followed by its '\n'; 16 lanes per record, 16 (unaligned) bytes per lane and round
-__global__ __launch_bounds__(256) void copy_records_kernel(const char *__restrict__ src, const uint64_t *__restrict__ starts,
-                                                           const uint64_t *__restrict__ len1, const uint32_t *__restrict__ order,
-                                                           const uint64_t *__restrict__ off, uint32_t n_rec, char *__restrict__ dst)
-{
-    const uint32_t j = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (j >= n_rec) return;
-    const uint32_t r = order[j];
-    const uint64_t s = starts[r], l1 = len1[r], o = off[j], len = l1 - 1;
-    for (uint64_t c = (uint64_t)(threadIdx.x & 15) * 16; c < l1; c += 256) {
-        if (c + 16 <= len) {
-            uint4 v;
-            __builtin_memcpy(&v, src + s + c, 16);
-            __builtin_memcpy(dst + o + c, &v, 16);
-        } else {
-            for (uint64_t i = c; i < l1 && i < c + 16; i++) dst[o + i] = i == len ? '\n' : src[s + i];
+    const uint32_t before = ((nl << 1) | prev) & 0xFFFFu;                  // bit i = byte i - 1 is a newline
+    uint32_t st = ~nl & before & 0xFFFFu;                                  // record starts in this chunk
+    while (__any(st != 0)) {
+        // ---- every lane takes its next record start (usually there is one round: a 16-byte chunk starts <= 1 read)
+        const bool has = st != 0;
+        uint64_t s = 0, len = 0;
+        uint32_t slot = 0, bin = 0;
+        if (has) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(st);
+            st &= st - 1;
+            s = i0 + bit;
+            const uint32_t up = nl & ~((2u << bit) - 1u);
+            uint64_t e;
+            if (up) e = i0 + (uint32_t)__builtin_ctz(up);
+            else if (later != NO_NL) e = tile0 + later;
+            else {                                                         // a record longer than the halo: walk on
+                e = tile0 + RB + HALO;
+                while (e < n) {
+                    const uint32_t m = nl_mask16(load16_nl(b, e, n));
+                    if (m) { e += (uint32_t)__builtin_ctz(m); break; }
+                    e += 16;
+                }
+                e = min(e, n);
+            }
+            len = e - s;
+            slot = (uint32_t)((len + 1 + 7) & ~7ull);                      // (a record of 4 GB does not exist: blocks are cut far below)
+            bin = (s + 32 <= n) ? record_bin(b, s, len, bits) : (1u << bits);
         }
+        if (!WRITE) {
+            if (has) atomicAdd(&bins[bin], (unsigned long long)slot);
+            continue;
+        }
+        // ---- claim the slots, then copy the wave's records together, 16 bytes per lane and round
+        uint64_t d0 = 0;
+        if (has) d0 = atomicAdd(&bins[bin], (unsigned long long)slot);
+        const uint64_t mask = __ballot(has);
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull)), n_rec = __popcll(mask);
+        const uint32_t pieces = has ? (slot + 15u) >> 4 : 0u;
+        const uint32_t pend = wave_incl_sum(pieces, lane);
+        const uint32_t total = (uint32_t)__shfl((int)pend, 63, 64);
+        if (has) {
+            s_src[wave][rank] = s; s_dst[wave][rank] = d0; s_len[wave][rank] = (uint32_t)min(len, (uint64_t)0xFFFFFFFFu);
+            s_pend[wave][rank] = pend;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0): the LDS stores above are visible to the wave
+        for (uint32_t p = (uint32_t)lane; p < total; p += 64) {
+            int lo = 0, hi = n_rec - 1;                                    // first record whose inclusive piece count exceeds p
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pend[wave][mid] <= p) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t rlen = s_len[wave][lo], rslot = (rlen + 1u + 7u) & ~7u;
+            const uint32_t first = s_pend[wave][lo] - ((rslot + 15u) >> 4);
+            const uint32_t c = (p - first) * 16u;
+            const uint64_t src = s_src[wave][lo] + c, out = s_dst[wave][lo] + c;
+            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+            const int keep = (int)min(16u, rlen > c ? rlen - c : 0u);      // record bytes in this piece
+            if (keep > 0) {
+                if (src + 16 <= n) {
+                    uint4 v;
+                    __builtin_memcpy(&v, b + src, 16);
+                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                } else {
+                    for (int i = 0; i < keep; i++) {
+                        const uint32_t ch = (uint8_t)b[src + i];
+                        w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | (ch << (8 * (i & 3)));
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int k = keep - 4 * d;
+                    if (k <= 0) w[d] = 0x0A0A0A0Au;
+                    else if (k < 4) { const uint32_t m = (1u << (8 * k)) - 1u; w[d] = (w[d] & m) | (0x0A0A0A0Au & ~m); }
+                }
+            }
+            char *o8 = static_cast<char *>(__builtin_assume_aligned(dst + out, 8));        // slots are multiples of 8 bytes
+            if (c + 16 <= rslot) __builtin_memcpy(o8, w, 16);
+            else __builtin_memcpy(o8, w, 8);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-int order_slab(ss_reads::Slab &sl)
+// exclusive prefix of the bin sizes (in place); total -> *total; one workgroup
+__global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned long long *__restrict__ bins, uint32_t n_bins, unsigned long long *total)
 {
-    const uint64_t n = sl.used;
-    if (n < 64) return SS_OK;
-    const unsigned nb = (unsigned)((n + RB - 1) / RB);
+    __shared__ unsigned long long s_part[1024];
+    const int t = threadIdx.x;
+    const uint32_t per = (n_bins + 1023u) / 1024u, a = min(n_bins, (uint32_t)t * per), e = min(n_bins, a + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = a; i < e; i++) sum += bins[i];
+    s_part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; i++) { const unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = s_part[t];
+    for (uint32_t i = a; i < e; i++) { const unsigned long long v = bins[i]; bins[i] = run; run += v; }
+}
+
+int order_bits()
+{
+    static const int bits = [] {
+        const char *e = getenv("SS_ORDER_BITS");
+        const int v = e ? atoi(e) : 12;
+        return std::min(MAX_BITS, std::max(1, v));
+    }();
+    return bits;
+}
+
+}  // namespace
+
+namespace ss {
+
+// src[0, n) (a flat base block on the device) -> a new buffer with the records
+// binned; *out_d (hipMalloc'ed), *out_used (multiple of 16, '\n' padded), *out_cap.
+int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used, uint64_t *out_cap)
+{
+    *out_d = nullptr; *out_used = 0; *out_cap = 0;
+    const int bits = order_bits();
+    const uint32_t n_bins = (1u << bits) + 1u;
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -160,87 +288,51 @@ int order_slab(ss_reads::Slab &sl)
         hipDeviceSynchronize();
         fprintf(stderr, "[reorder] %-22s at %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    uint32_t *d_cnt = nullptr, *d_keys = nullptr, *d_keys2 = nullptr, *d_idx = nullptr, *d_ord = nullptr;
-    uint64_t *d_base = nullptr, *d_starts = nullptr, *d_ends = nullptr, *d_len1 = nullptr, *d_lsort = nullptr, *d_off = nullptr;
-    void *d_tmp = nullptr;
-    char *d_new = nullptr, *d_small = nullptr, *d_big = nullptr;       // two allocations hold all the scratch (a hipMalloc costs ~0.2 ms)
-    auto cleanup = [&] { hipFree(d_small); hipFree(d_big); };
-#define SS_R(call) do { if ((call) != hipSuccess) { ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); cleanup(); hipFree(d_new); return SS_EHIP; } } while (0)
-    size_t tb0 = 0;
-    SS_R(hipcub::DeviceScan::ExclusiveSum(nullptr, tb0, d_cnt, d_base, (int)nb));
-    const uint64_t small_bytes = (((uint64_t)nb * 4 + 255) & ~255ull) + (((uint64_t)nb + 1) * 8 + 255 & ~255ull) + std::max<size_t>(tb0, 256);
-    SS_R(hipMalloc((void **)&d_small, small_bytes));
-    d_cnt = (uint32_t *)d_small;
-    d_base = (uint64_t *)(d_small + (((uint64_t)nb * 4 + 255) & ~255ull));
-    d_tmp = (char *)d_base + (((uint64_t)nb + 1) * 8 + 255 & ~255ull);
-    hipLaunchKernelGGL((bounds_kernel<false>), dim3(nb), dim3(256), 0, 0, sl.d, n, d_cnt, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr);
-    SS_R(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb0, d_cnt, d_base, (int)nb));
-    uint64_t last_base = 0;
-    uint32_t last_cnt = 0;
-    SS_R(hipMemcpy(&last_base, d_base + (nb - 1), 8, hipMemcpyDeviceToHost));
-    SS_R(hipMemcpy(&last_cnt, d_cnt + (nb - 1), 4, hipMemcpyDeviceToHost));
-    lap("count starts");
-    const uint64_t n_rec64 = last_base + last_cnt;
-    if (n_rec64 < 2 || n_rec64 >= 0x7FFFFFF0ull) { cleanup(); return SS_OK; }      // nothing to order / too many for 32-bit record numbers
-    const uint32_t n_rec = (uint32_t)n_rec64;
-    size_t tb1 = 0, tb2 = 0;
-    SS_R(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_idx, d_ord, (int)n_rec, 0, 31));
-    SS_R(hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_lsort, d_off, (int)n_rec));
-    const uint64_t a8 = ((uint64_t)n_rec * 8 + 255) & ~255ull, a4 = ((uint64_t)n_rec * 4 + 255) & ~255ull;
-    const size_t tbig = std::max<size_t>(std::max(tb1, tb2), 256);
-    SS_R(hipMalloc((void **)&d_big, 5 * a8 + 4 * a4 + tbig));
-    d_starts = (uint64_t *)d_big; d_ends = (uint64_t *)(d_big + a8); d_len1 = (uint64_t *)(d_big + 2 * a8);
-    d_lsort = (uint64_t *)(d_big + 3 * a8); d_off = (uint64_t *)(d_big + 4 * a8);
-    d_keys = (uint32_t *)(d_big + 5 * a8); d_keys2 = (uint32_t *)(d_big + 5 * a8 + a4); d_idx = (uint32_t *)(d_big + 5 * a8 + 2 * a4);
-    d_ord = (uint32_t *)(d_big + 5 * a8 + 3 * a4);
-    void *d_tmp2 = d_big + 5 * a8 + 4 * a4;
-    lap("allocations");
-    hipLaunchKernelGGL((bounds_kernel<true>), dim3(nb), dim3(256), 0, 0, sl.d, n, d_cnt, d_base, d_starts, d_ends);
-    lap("starts + ends");
-    const unsigned rb = (n_rec + 255) / 256;
-    hipLaunchKernelGGL(keys_kernel, dim3(rb), dim3(256), 0, 0, sl.d, d_starts, d_ends, n_rec, d_keys, d_idx, d_len1);
-    lap("keys");
-    SS_R(hipcub::DeviceRadixSort::SortPairs(d_tmp2, tb1, d_keys, d_keys2, d_idx, d_ord, (int)n_rec, 0, 31));
-    lap("sort");
-    hipLaunchKernelGGL(gather_len_kernel, dim3(rb), dim3(256), 0, 0, d_len1, d_ord, n_rec, d_lsort);
-    SS_R(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tb2, d_lsort, d_off, (int)n_rec));
-    uint64_t off_last = 0, len_last = 0;
-    SS_R(hipMemcpy(&off_last, d_off + (n_rec - 1), 8, hipMemcpyDeviceToHost));
-    SS_R(hipMemcpy(&len_last, d_lsort + (n_rec - 1), 8, hipMemcpyDeviceToHost));
-    const uint64_t total = off_last + len_last, cap = (total + 15) & ~15ull;
-    if (total > n) { cleanup(); return SS_EINVAL; }                                 // cannot happen: every record + one '\n' was in the slab
-    lap("offsets");
-    SS_R(hipMalloc((void **)&d_new, std::max<uint64_t>(cap, 16)));
+    unsigned long long *d_bins = nullptr;
+    char *d_new = nullptr;
+#define SS_R(call) do { if ((call) != hipSuccess) { ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); hipFree(d_bins); hipFree(d_new); return SS_EHIP; } } while (0)
+    SS_R(hipMalloc((void **)&d_bins, ((uint64_t)n_bins + 1) * 8));
+    SS_R(hipMemsetAsync(d_bins, 0, ((uint64_t)n_bins + 1) * 8, 0));
+    const unsigned nb = (unsigned)((n + RB - 1) / RB);
+    hipLaunchKernelGGL((bin_kernel<false>), dim3(nb), dim3(256), 0, 0, src, n, bits, d_bins, (char *)nullptr);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, 0, d_bins, n_bins, d_bins + n_bins);
+    unsigned long long total = 0;
+    SS_R(hipMemcpy(&total, d_bins + n_bins, 8, hipMemcpyDeviceToHost));
+    lap("count + scan");
+    const uint64_t cap = std::max<uint64_t>((total + 15) & ~15ull, 16);
+    SS_R(hipMalloc((void **)&d_new, cap));
     lap("new slab");
-    hipLaunchKernelGGL(copy_records_kernel, dim3((n_rec + 15) / 16), dim3(256), 0, 0, sl.d, d_starts, d_len1, d_ord, d_off, n_rec, d_new);
-    SS_R(hipMemset(d_new + total, '\n', cap - total));
+    hipLaunchKernelGGL((bin_kernel<true>), dim3(nb), dim3(256), 0, 0, src, n, bits, d_bins, d_new);
+    if (cap > total) SS_R(hipMemsetAsync(d_new + total, '\n', cap - total, 0));
+    SS_R(hipGetLastError());
     SS_R(hipDeviceSynchronize());
     lap("copy");
 #undef SS_R
-    cleanup();
-    hipFree(sl.d);
-    lap("frees");
-    sl.d = d_new;
-    sl.cap = std::max<uint64_t>(cap, 16);
-    sl.used = cap;
+    hipFree(d_bins);
+    *out_d = d_new; *out_used = cap; *out_cap = cap;
     return SS_OK;
 }
 
-}  // namespace
-
-namespace ss {
+bool reads_order_wanted()
+{
+    const char *e = getenv("SS_READS_ORDER");
+    return !(e && (!strcmp(e, "file") || !strcmp(e, "0") || !strcmp(e, "off")));
+}
 
 int reads_order_for_locality(ss_reads *R, bool force)
 {
     if (!R) return SS_EINVAL;
-    if (!force) {
-        const char *e = getenv("SS_READS_ORDER");
-        if (!e || strcmp(e, "locality")) return SS_OK;          // default: file order (see the header comment)
-    }
+    if (!force && !reads_order_wanted()) return SS_OK;
     uint64_t bytes = 0;
     for (auto &sl : R->slabs) {
-        const int rc = order_slab(sl);
-        if (rc) return rc;
+        if (sl.used >= 64) {
+            char *d = nullptr;
+            uint64_t used = 0, cap = 0;
+            const int rc = order_flat_dev(sl.d, sl.used, &d, &used, &cap);
+            if (rc) return rc;
+            hipFree(sl.d);
+            sl.d = d; sl.used = used; sl.cap = cap;
+        }
         bytes += sl.cap;
     }
     R->device_bytes = bytes;

@@ -2,6 +2,48 @@
 #pragma once
 #include "ss_common.h"
 
+namespace ss {
+
+// ---- minimizers of the k = 31 index (ss_mini.hip) and of the locality order of resident reads (ss_reorder.hip) ----
+constexpr int MINI_M = 15;                       // minimizer length (30 bits)
+constexpr uint32_t M30 = 0x3FFFFFFFu;
+
+// Ordering key of a 30-bit m-mer: the m-mer with the smallest key, leftmost on ties, is the
+// minimizer of a k-mer.  key = lo24(x) * C1 + C0 with C1 = an odd 19-bit constant << 5 and C0 a
+// multiple of 32: ONE v_mad_u32_u24 per m-mer on the device (full rate; the 24-bit multiplier
+// ignores the operand's upper bits, so the device never masks the window).  The key orders the
+// m-mers by their first 12 bases (a bijection of those 24 bits onto the 27 key bits); m-mers that
+// agree there tie and resolve leftmost like any other tie.  The low five bits are zero by
+// construction: the kernel adds the m-mer's index there (for free, inside C0), so ONE v_min_u32
+// per step compares (key, position).  The constant keeps poly-A from being everybody's minimizer.
+// It need not be injective: a bucket is named by the m-mer itself and holds full k-mers.
+constexpr uint32_t MMK_C1 = 0x4F1BBu << 5, MMK_C0 = 0x7F4A7C00u;
+__host__ __device__ __forceinline__ uint32_t mmkey(uint32_t x)
+{
+    return (x & 0xFFFFFFu) * MMK_C1 + MMK_C0;
+}
+constexpr uint32_t KEY_MASK = ~31u;
+
+// Once per RUN: h = mix30(minimizer), a bijection of the 30 bits (odd multipliers modulo 2^30, xor-shifts).
+// Page = high half of (h << 2) x n_pages (any table size, no power-of-two rounding); tags = low bits of h.
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t mix30(uint32_t x)
+{
+    uint32_t h = (x * 0x9E3779B1u) & M30;
+    h ^= h >> 15;
+    h = (h * 0x2C1B3C6Du) & M30;
+    h ^= h >> 14;
+    return h;
+}
+}  // namespace ss
+
 namespace ss { namespace dev {
 
 constexpr int SCAN_THREADS = 256;

@@ -862,15 +862,16 @@ def test_index_image_independent_of_thread_count(L, tmp_path):
     assert digests[0] == digests[1] == digests[2]
 
 
-def _first_minimizer_key(rec, k=31, m=15):
-    """Ordering key of ss_reorder.hip restated: the 30-bit minimizer (ordering key of the index: ((x & 0xFFFFFF) * C1 +
-    C0) with the low five bits cleared, leftmost on ties) of the record's first 31 bases; 2^30 when there is none."""
+def _locality_bin(rec, bits=12, k=31, m=15):
+    """Bin of ss_reorder.hip restated: the top `bits` bits of mix30 (the index's page hash, ss_scan_dev.h) of the 30-bit
+    minimizer (ordering key of the index: ((x & 0xFFFFFF) * C1 + C0) with the low five bits cleared, leftmost on ties)
+    of the record's first 31 bases; 1 << bits when there is none."""
     code = {65: 0, 67: 1, 84: 2, 71: 3}
     if len(rec) < k:
-        return 1 << 30
+        return 1 << bits
     cs = [code.get(c & 0xDF, -1) for c in rec[:k]]
     if min(cs) < 0:
-        return 1 << 30
+        return 1 << bits
     km = sum(c << (2 * j) for j, c in enumerate(cs))
     best, bx = None, 0
     for i in range(k - m + 1):
@@ -878,14 +879,21 @@ def _first_minimizer_key(rec, k=31, m=15):
         h = (((x & 0xFFFFFF) * (0x4F1BB << 5) + 0x7F4A7C00) & 0xFFFFFFFF) & ~31
         if best is None or h < best:
             best, bx = h, x
-    return bx
+    M30 = 0x3FFFFFFF
+    h = (bx * 0x9E3779B1) & M30
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & M30
+    h ^= h >> 14
+    return h >> (30 - bits)
 
 
 def test_locality_ordered_read_set(L):
-    """ss_reorder.hip: a resident read set keeps its records sorted by the minimizer of their first k-mer.  Counting
-    must not notice: every record survives exactly once, whole, '\\n'-terminated -- ragged lengths, records shorter
-    than a k-mer, N inside the first 31 bases, lower case, runs of empty lines (the 16-byte padding of the blocks),
-    records straddling the 4096-byte units of the boundary passes, a block without a final newline."""
+    """ss_reorder.hip: a resident read set keeps its records binned by the minimizer of their first k-mer (4096 bins in
+    ascending order + one for the records without a first k-mer).  Counting must not notice: every record survives
+    exactly once, whole, '\\n'-terminated -- ragged lengths, records shorter than a k-mer, N inside the first 31 bases,
+    lower case, runs of empty lines (the 16-byte padding of the blocks), records straddling the 4096-byte tiles and
+    their 512-byte halo (a 4500-base record), a block without a final newline, a block whose length is not a
+    multiple of 16."""
     import ctypes as C
     from oracle import oracle as orc
     kfa, flat = _random_db_and_reads(321, 150000, 40000)
@@ -919,13 +927,15 @@ def test_locality_ordered_read_set(L):
         back = [r for r in rset.read_back().split(b"\n") if r]
         assert sorted(back) == sorted(r for r in mixed if r)                 # every record once, whole
         if order:
-            keys = [_first_minimizer_key(r) for r in back]
-            assert keys == sorted(keys) and len(set(keys)) > 1000            # ... and in key order
+            bins = [_locality_bin(r) for r in back]
+            assert bins == sorted(bins) and len(set(bins)) > 1000 and bins[-1] == 4096      # ... and in bin order
+            slots = rset.read_back()
+            assert len(slots) % 16 == 0 and slots.endswith(b"\n")
         else:
             assert back == [r for r in mixed if r]
         rset.close()
     L.lib().ss_dev_free(d)
-    # through files (the loader keeps the file order unless SS_READS_ORDER=locality): same counts
+    # through files (the loader bins the records unless SS_READS_ORDER=file): same counts
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         p = os.path.join(td, "r.fq")
@@ -933,7 +943,7 @@ def test_locality_ordered_read_set(L):
         import gzip
         pgz = os.path.join(td, "r.fq.gz")           # (1 MB and more: inflated and reduced to sequence lines on the device,
         open(pgz, "wb").write(gzip.compress(fq, 6))  #  the block adopted as a slab; smaller: the host inflaters)
-        for p, env in ((p, None), (p, "locality"), (pgz, None), (pgz, "locality")):
+        for p, env in ((p, None), (p, "file"), (pgz, None), (pgz, "file")):
             old = os.environ.get("SS_READS_ORDER")
             if env:
                 os.environ["SS_READS_ORDER"] = env
@@ -951,7 +961,9 @@ def test_locality_ordered_read_set(L):
             L.check(L.lib().ss_device_sync(), "sync")
             assert np.array_equal(db.counts_rows(), want), env
             back = [r for r in rset.read_back().split(b"\n") if r]
-            keys = [_first_minimizer_key(r) for r in back]
-            assert (keys == sorted(keys)) == (env == "locality")
+            bins = [_locality_bin(r) for r in back]
+            assert (bins == sorted(bins)) == (env is None)
+            if env == "file":
+                assert back == [r for r in mixed if r]
             rset.close()
     db.close()
