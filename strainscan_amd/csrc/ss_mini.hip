@@ -294,7 +294,7 @@ template <bool ALIGNED, bool BLOOM, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(SS_NUM_SGPR))) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
     const uint4 *__restrict__ pages, uint32_t n_pages, uint32_t *__restrict__ counts, uint32_t cbase,
-    const uint32_t *__restrict__ bloom, uint32_t bloom_shift)
+    const uint32_t *__restrict__ bloom, uint32_t bloom_shift, uint32_t xcd_swizzle)
 {
     constexpr int K = 31;                            // 17 m-mers of length 15 per k-mer
     static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
@@ -304,16 +304,27 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 
     // the 16 bases of this lane are fetched one tile AHEAD: the HBM
     // round trip of the stream overlaps the previous tile's phases
+    // Workgroup b runs on XCD b % 8 (observed; a speed matter only): with the swizzle, XCD x works through the x-th
+    // eighth of the TILES in order (its workgroups stride through that eighth), so neighbouring tiles -- reads that a
+    // resident set keeps binned by their first minimizer (ss_reorder.hip) and that share their page sectors -- meet in
+    // ONE 4 MB L2 instead of eight.  (The grid is a multiple of 8 then; every XCD gets the same number of tiles.)
+    uint64_t tile = blockIdx.x, tile_end = n_tiles, stride = gridDim.x;
+    if (xcd_swizzle) {
+        const uint64_t per = (n_tiles + 7) >> 3, x = blockIdx.x & 7u;
+        stride = gridDim.x >> 3;
+        tile = x * per + (blockIdx.x >> 3);
+        tile_end = min(n_tiles, (x + 1) * per);
+    }
     uint32_t wn[4];
-    if (blockIdx.x < n_tiles) {
-        const uint64_t b0 = (uint64_t)blockIdx.x * MTILE;
+    if (tile < tile_end) {
+        const uint64_t b0 = tile * MTILE;
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
     }
 #ifdef SS_TIMING
     unsigned long long t_prev = __builtin_readcyclecounter();
     uint32_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (; tile < tile_end; tile += stride) {
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
         {
             uint32_t code, inv;
@@ -324,8 +335,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #ifdef SS_LDS_PAD
         if (n == 1) S.pad[t] = 1;
 #endif
-            const uint64_t nt = tile + gridDim.x;
-            if (nt < n_tiles) {
+            const uint64_t nt = tile + stride;
+            if (nt < tile_end) {
                 const uint64_t nb = nt * (uint64_t)MTILE;
                 load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
             }
@@ -922,8 +933,9 @@ static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const u
 {
     const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
     const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
+    static const uint32_t swz = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
 #define SS_LAUNCH(A, B) hipLaunchKernelGGL((scan_mini_kernel<A, B, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
-                                           db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift)
+                                           db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz)
     if (db->d_bloom) { if (aligned) SS_LAUNCH(true, true); else SS_LAUNCH(false, true); }
     else             { if (aligned) SS_LAUNCH(true, false); else SS_LAUNCH(false, false); }
 #undef SS_LAUNCH
@@ -956,6 +968,7 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     // per SIMD resident (20 M reads = 3.04 M tiles; blocks = x * 1024): x = 8 (one round of resident blocks)
     // 4.03 ms, 32: 3.76, 128: 3.59, 512: 3.55, 2048 (1.5 tiles per block): 3.50, 4096 (one tile each): 3.51
     blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
+    blocks = (blocks + 7u) & ~7u;                           // a multiple of 8: the same number of workgroups on every XCD
     const uint8_t *b = (const uint8_t *)bases_dev;
     switch (lb) {
     case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;

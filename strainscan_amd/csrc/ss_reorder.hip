@@ -40,23 +40,31 @@
 
 namespace {
 
-constexpr int RB = 4096;                    // bytes of a slab owned by one workgroup (256 lanes x 16 bytes)
+#ifndef SS_ORDER_CH
+#define SS_ORDER_CH 64
+#endif
+constexpr int CH = SS_ORDER_CH;             // bytes of a slab owned by one lane (64 or 128): that many / 16 loads in flight
+constexpr int RB = 256 * CH;                // ... and by one workgroup (16 KB: what bounds these passes is the chain of dependent
+                                            // round trips of a workgroup -- load, neighbours, key bytes, atomic -- not its instructions)
 constexpr int HALO = 512;                   // bytes behind the tile searched (in parallel) for the end of its last record
-constexpr int MAX_BITS = 16;
-constexpr uint32_t NO_NL = 0xFFFFu;         // "no newline" as a tile-relative position
+constexpr int MAX_BITS = 23;                // (SS_ORDER_BITS; a table entry has 24 bits for the bin; the default stays at or below 22)
+constexpr uint32_t NO_NL = 0xFFFFFFFFu;     // "no newline" as a tile-relative position
+constexpr int TCAP = 2 * CH;                // record starts per tile that the record table holds (reads of ~125 bases and more)
 
-// newline mask of 16 bytes (bit i = byte i is '\n'), SWAR zero-byte test on w ^ 0x0A0A0A0A
+// newline mask of 16 bytes (bit i = byte i is '\n'): exact SWAR zero-byte test on w ^ 0x0A0A0A0A leaves 0x80 in the bytes
+// that were '\n'; byte dot products with weights 1, 2, 4, 8 (x 16 for the odd dwords) gather the flags, 128 x the mask
 __device__ __forceinline__ uint32_t nl_mask16(const uint4 v)
 {
-    uint32_t m = 0;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t z[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const uint32_t x = w[d] ^ 0x0A0A0A0Au;
-        const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;      // 0x80 where the byte was '\n'
-        m |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu) << (4 * d);
+        z[d] = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
     }
-    return m;
+    const uint32_t lo = __builtin_amdgcn_udot4(z[1], 0x80402010u, __builtin_amdgcn_udot4(z[0], 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(z[3], 0x80402010u, __builtin_amdgcn_udot4(z[2], 0x08040201u, 0u, false), false);
+    return (lo >> 7) | ((hi >> 7) << 8);
 }
 
 // 16 bytes at b + i; bytes at or beyond n read as '\n'
@@ -112,33 +120,60 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, int lane)
     return v;
 }
 
-// One kernel, two uses.  WRITE = false: bins[bin] += slot bytes of every record that STARTS in this tile.
-// WRITE = true: bins[] holds the bins' cursors (exclusive prefix of the counts): claim and copy.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void bin_kernel(const char *__restrict__ b, uint64_t n, int bits,
-                                                  unsigned long long *__restrict__ bins, char *__restrict__ dst)
+// ---- what a workgroup knows about its 4 KB tile -------------------------------------------------------------------
+// Per-tile record table, written by the first pass and read by the second (so the second neither looks for newlines
+// nor keys anything): entry = start in the tile (14 bits) | length (26 bits) | bin (24 bits); a tile with more than
+// TCAP record starts (reads shorter than ~125 bases), or a record of 64 MB, says T_OVERFLOW and is discovered again.
+constexpr uint32_t T_OVERFLOW = 0xFFFFFFFFu;
+constexpr int START_BITS = CH == 64 ? 14 : 15, LEN_BITS = 40 - START_BITS;
+constexpr uint32_t LEN_LIMIT = 1u << LEN_BITS;
+static_assert(RB == 1 << START_BITS, "a table entry holds the start within the tile in START_BITS bits");
+
+struct TileLds {
+    uint32_t first[5];                      // first newline (tile-relative) of waves 0..3 and of the halo
+    uint32_t wcnt[4];                       // records taken by each wave in the current round
+    uint32_t more;                          // some lane has another record start left
+    uint64_t src[256], dst[256];            // the round's records: where they start, where they go
+    uint32_t len[256], bin[256], pend[256]; // length, bin, inclusive count of 16-byte pieces
+};
+
+#if SS_ORDER_CH == 128
+typedef unsigned __int128 mask_t;           // one bit per byte of the lane's chunk
+__device__ __forceinline__ uint32_t mask_ctz(mask_t m) { const uint64_t lo = (uint64_t)m; return lo ? (uint32_t)__builtin_ctzll(lo) : 64u + (uint32_t)__builtin_ctzll((uint64_t)(m >> 64)); }
+#else
+typedef uint64_t mask_t;
+__device__ __forceinline__ uint32_t mask_ctz(mask_t m) { return (uint32_t)__builtin_ctzll(m); }
+#endif
+struct TileState { mask_t nl, st; uint32_t later; uint64_t tile0, i0; };
+
+// loads the lane's 64 bytes, finds the record starts in them and the first newline behind them (tile + halo)
+__device__ __forceinline__ void tile_setup(const char *__restrict__ b, uint64_t n, TileLds &L, TileState &S)
 {
-    __shared__ uint32_t s_first[5];                     // first newline (tile-relative) of waves 0..3 and of the halo
-    __shared__ uint64_t s_src[4][64], s_dst[4][64];
-    __shared__ uint32_t s_len[4][64], s_pend[4][64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * RB, i0 = tile0 + (uint64_t)t * 16;
-    uint32_t nl = 0xFFFFu, prev = 1u;                   // beyond the buffer: newlines
-    if (i0 < n) {
-        nl = nl_mask16(load16_nl(b, i0, n));
-        prev = i0 == 0 ? 1u : (uint32_t)(b[i0 - 1] == '\n');
+    S.tile0 = (uint64_t)blockIdx.x * RB;
+    S.i0 = S.tile0 + (uint64_t)t * CH;
+    mask_t nl = ~(mask_t)0;                             // beyond the buffer: newlines
+    uint32_t prev = 1u;
+    if (S.i0 < n) {
+        uint4 v[CH / 16];
+#pragma unroll
+        for (int k = 0; k < CH / 16; k++) v[k] = load16_nl(b, S.i0 + 16u * k, n);
+        prev = S.i0 == 0 ? 1u : (uint32_t)(b[S.i0 - 1] == '\n');
+        nl = 0;
+#pragma unroll
+        for (int k = 0; k < CH / 16; k++) nl |= (mask_t)nl_mask16(v[k]) << (16 * k);
     }
     // first newline at or behind every lane's chunk: suffix minimum over the wave, then over the later waves and the halo
-    uint32_t mine = nl ? (uint32_t)t * 16u + (uint32_t)__builtin_ctz(nl) : NO_NL, suf = mine;
+    uint32_t suf = nl ? (uint32_t)t * CH + mask_ctz(nl) : NO_NL;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_down((int)suf, off, 64);
         if (lane + off < 64) suf = min(suf, o);
     }
-    if (lane == 0) s_first[wave] = suf;
+    if (lane == 0) L.first[wave] = suf;
     if (wave == 0) {                                    // halo: HALO bytes behind the tile, 32 lanes x 16 bytes
         uint32_t h = NO_NL;
-        const uint64_t j0 = tile0 + RB + (uint64_t)lane * 16;
+        const uint64_t j0 = S.tile0 + RB + (uint64_t)lane * 16;
         if (lane < HALO / 16) {
             if (j0 < n) {
                 const uint32_t m = nl_mask16(load16_nl(b, j0, n));         // (the buffer's end reads as a newline)
@@ -149,82 +184,127 @@ __global__ __launch_bounds__(256) void bin_kernel(const char *__restrict__ b, ui
         }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) h = min(h, (uint32_t)__shfl_xor((int)h, off, 64));
-        if (lane == 0) s_first[4] = h;
+        if (lane == 0) L.first[4] = h;
     }
     __syncthreads();
     uint32_t later = (uint32_t)__shfl_down((int)suf, 1, 64);               // first newline behind this lane's chunk
     if (lane == 63) later = NO_NL;
-    for (int w = wave + 1; w < 5; w++) later = min(later, s_first[w]);
+    for (int w = wave + 1; w < 5; w++) later = min(later, L.first[w]);
+    const mask_t before = (nl << 1) | prev;                                // bit i = byte i - 1 is a newline
+    S.nl = nl; S.later = later;
+    S.st = ~nl & before;                                                   // record starts in this chunk
+}
 
-    const uint32_t before = ((nl << 1) | prev) & 0xFFFFu;                  // bit i = byte i - 1 is a newline
-    uint32_t st = ~nl & before & 0xFFFFu;                                  // record starts in this chunk
-    while (__any(st != 0)) {
-        // ---- every lane takes its next record start (usually there is one round: a 16-byte chunk starts <= 1 read)
-        const bool has = st != 0;
-        uint64_t s = 0, len = 0;
-        uint32_t slot = 0, bin = 0;
-        if (has) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(st);
-            st &= st - 1;
-            s = i0 + bit;
-            const uint32_t up = nl & ~((2u << bit) - 1u);
-            uint64_t e;
-            if (up) e = i0 + (uint32_t)__builtin_ctz(up);
-            else if (later != NO_NL) e = tile0 + later;
-            else {                                                         // a record longer than the halo: walk on
-                e = tile0 + RB + HALO;
-                while (e < n) {
-                    const uint32_t m = nl_mask16(load16_nl(b, e, n));
-                    if (m) { e += (uint32_t)__builtin_ctz(m); break; }
-                    e += 16;
-                }
-                e = min(e, n);
+// One round: every lane hands in its next record start (a 64-byte chunk starts at most one read, so there is usually one
+// round); the records are numbered across the workgroup and land in L.src / L.len.  Returns their number; L.more tells
+// whether another round is needed.
+__device__ __forceinline__ uint32_t tile_round(const char *__restrict__ b, uint64_t n, TileLds &L, TileState &S)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool has = S.st != 0;
+    uint64_t s = 0, len = 0;
+    if (has) {
+        const uint32_t bit = mask_ctz(S.st);
+        S.st &= S.st - 1;
+        s = S.i0 + bit;
+        const mask_t up = bit + 1 < (uint32_t)CH ? S.nl & ~((((mask_t)1) << (bit + 1)) - 1) : (mask_t)0;
+        uint64_t e;
+        if (up) e = S.i0 + mask_ctz(up);
+        else if (S.later != NO_NL) e = S.tile0 + S.later;
+        else {                                                             // a record longer than the halo: walk on
+            e = S.tile0 + RB + HALO;
+            while (e < n) {
+                const uint32_t m = nl_mask16(load16_nl(b, e, n));
+                if (m) { e += (uint32_t)__builtin_ctz(m); break; }
+                e += 16;
             }
-            len = e - s;
-            slot = (uint32_t)((len + 1 + 7) & ~7ull);                      // (a record of 4 GB does not exist: blocks are cut far below)
+            e = min(e, n);
+        }
+        len = e - s;
+    }
+    const uint64_t mask = __ballot(has);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) L.wcnt[wave] = (uint32_t)__popcll(mask);
+    if (t == 0) L.more = 0;
+    __syncthreads();
+    uint32_t base = 0, cnt = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t c = L.wcnt[w]; if (w < wave) base += c; cnt += c; }
+    if (has) { L.src[base + rank] = s; L.len[base + rank] = (uint32_t)min(len, (uint64_t)0xFFFFFFFFu); }
+    if (S.st != 0) L.more = 1;
+    __syncthreads();
+    return cnt;
+}
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t len) { return (len + 1u + 7u) & ~7u; }     // record + '\n', padded to 8 bytes
+
+// ---- pass 1: bytes per bin, and the tile's record table -----------------------------------------------------------------
+__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void count_kernel(const char *__restrict__ b, uint64_t n, int bits, unsigned long long *__restrict__ hist,
+                                                    uint32_t *__restrict__ tab_cnt, unsigned long long *__restrict__ tab,
+                                                    unsigned long long *__restrict__ n_overflow)
+{
+    __shared__ TileLds L;
+    TileState S;
+    tile_setup(b, n, L, S);
+    const int t = threadIdx.x;
+    bool first = true;
+    while (true) {
+        const uint32_t cnt = tile_round(b, n, L, S);
+        const bool more = L.more != 0;
+        uint32_t bin = 0, len = 0;
+        bool big = false;
+        if ((uint32_t)t < cnt) {
+            const uint64_t s = L.src[t];
+            len = L.len[t];
             bin = (s + 32 <= n) ? record_bin(b, s, len, bits) : (1u << bits);
+            atomicAdd(&hist[bin], (unsigned long long)slot_of(len));
+            big = len >= LEN_LIMIT;
         }
-        if (!WRITE) {
-            if (has) atomicAdd(&bins[bin], (unsigned long long)slot);
-            continue;
-        }
-        // ---- claim the slots, then copy the wave's records together, 16 bytes per lane and round
-        uint64_t d0 = 0;
-        if (has) d0 = atomicAdd(&bins[bin], (unsigned long long)slot);
-        const uint64_t mask = __ballot(has);
-        const int rank = __popcll(mask & ((1ull << lane) - 1ull)), n_rec = __popcll(mask);
-        const uint32_t pieces = has ? (slot + 15u) >> 4 : 0u;
-        const uint32_t pend = wave_incl_sum(pieces, lane);
-        const uint32_t total = (uint32_t)__shfl((int)pend, 63, 64);
-        if (has) {
-            s_src[wave][rank] = s; s_dst[wave][rank] = d0; s_len[wave][rank] = (uint32_t)min(len, (uint64_t)0xFFFFFFFFu);
-            s_pend[wave][rank] = pend;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                // lgkmcnt(0): the LDS stores above are visible to the wave
-        for (uint32_t p = (uint32_t)lane; p < total; p += 64) {
-            int lo = 0, hi = n_rec - 1;                                    // first record whose inclusive piece count exceeds p
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_pend[wave][mid] <= p) lo = mid + 1; else hi = mid;
+        if (first) {
+            const bool fits = !more && cnt <= (uint32_t)TCAP && !__syncthreads_or(big);
+            if (fits && (uint32_t)t < cnt)
+                tab[(uint64_t)blockIdx.x * TCAP + t] = (unsigned long long)(L.src[t] - S.tile0) | ((unsigned long long)len << START_BITS) |
+                                                        ((unsigned long long)bin << (START_BITS + LEN_BITS));
+            if (t == 0) {
+                tab_cnt[blockIdx.x] = fits ? cnt : T_OVERFLOW;
+                if (!fits) atomicAdd(n_overflow, 1ull);
             }
-            const uint32_t rlen = s_len[wave][lo], rslot = (rlen + 1u + 7u) & ~7u;
-            const uint32_t first = s_pend[wave][lo] - ((rslot + 15u) >> 4);
-            const uint32_t c = (p - first) * 16u;
-            const uint64_t src = s_src[wave][lo] + c, out = s_dst[wave][lo] + c;
-            uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-            const int keep = (int)min(16u, rlen > c ? rlen - c : 0u);      // record bytes in this piece
-            if (keep > 0) {
-                if (src + 16 <= n) {
-                    uint4 v;
-                    __builtin_memcpy(&v, b + src, 16);
-                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-                } else {
-                    for (int i = 0; i < keep; i++) {
-                        const uint32_t ch = (uint8_t)b[src + i];
-                        w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | (ch << (8 * (i & 3)));
-                    }
-                }
+        }
+        first = false;
+        if (!more) break;
+        __syncthreads();
+    }
+}
+
+// ---- pass 2: claim the slots, copy -----------------------------------------------------------------------------------------
+// The workgroup copies its records together: their 16-byte pieces are numbered across the workgroup (prefix sum of the
+// piece counts), every lane finds the record of its piece by binary search in LDS, loads 16 unaligned bytes, pads behind
+// the record's end with '\n' and stores them aligned (slots are multiples of 8 bytes).
+__device__ __forceinline__ void copy_round(const char *__restrict__ b, uint64_t n, char *__restrict__ dst, TileLds &L, uint32_t cnt)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t pieces = (uint32_t)t < cnt ? (slot_of(L.len[t]) + 15u) >> 4 : 0u;
+    uint32_t pend = wave_incl_sum(pieces, lane);
+    if (lane == 63) L.wcnt[wave] = pend;
+    __syncthreads();
+    uint32_t total = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t c = L.wcnt[w]; if (w < wave) pend += c; total += c; }
+    if ((uint32_t)t < cnt) L.pend[t] = pend;
+    __syncthreads();
+    for (uint32_t p = (uint32_t)t; p < total; p += 256) {
+        int lo = 0, hi = (int)cnt - 1;                                     // first record whose inclusive piece count exceeds p
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (L.pend[mid] <= p) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t rlen = L.len[lo], rslot = slot_of(rlen);
+        const uint32_t c = (p - (L.pend[lo] - ((rslot + 15u) >> 4))) * 16u;
+        const uint64_t src = L.src[lo] + c, out = L.dst[lo] + c;
+        uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+        const int keep = (int)min(16u, rlen > c ? rlen - c : 0u);          // record bytes in this piece
+        if (keep > 0) {
+            const uint4 v = load16_nl(b, src, n);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            if (keep < 16) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const int k = keep - 4 * d;
@@ -232,22 +312,83 @@ __global__ __launch_bounds__(256) void bin_kernel(const char *__restrict__ b, ui
                     else if (k < 4) { const uint32_t m = (1u << (8 * k)) - 1u; w[d] = (w[d] & m) | (0x0A0A0A0Au & ~m); }
                 }
             }
-            char *o8 = static_cast<char *>(__builtin_assume_aligned(dst + out, 8));        // slots are multiples of 8 bytes
-            if (c + 16 <= rslot) __builtin_memcpy(o8, w, 16);
-            else __builtin_memcpy(o8, w, 8);
         }
-        __builtin_amdgcn_wave_barrier();
+        char *o8 = static_cast<char *>(__builtin_assume_aligned(dst + out, 8));
+        if (c + 16 <= rslot) __builtin_memcpy(o8, w, 16);
+        else __builtin_memcpy(o8, w, 8);
     }
 }
 
-// exclusive prefix of the bin sizes (in place); total -> *total; one workgroup
-__global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned long long *__restrict__ bins, uint32_t n_bins, unsigned long long *total)
+// the usual tile: everything is in the table
+__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void place_kernel(
+    const char *__restrict__ b, uint64_t n, unsigned long long *__restrict__ cursor, const uint32_t *__restrict__ tab_cnt,
+    const unsigned long long *__restrict__ tab, char *__restrict__ dst)
+{
+    __shared__ TileLds L;
+    const int t = threadIdx.x;
+    static_assert(TCAP <= 256, "one table entry per thread");
+    const unsigned long long e = t < TCAP ? tab[(uint64_t)blockIdx.x * TCAP + t] : 0ull;     // (in flight together with the count)
+    const uint32_t known = tab_cnt[blockIdx.x];
+    if (known == T_OVERFLOW || known == 0) return;
+    if ((uint32_t)t < known) {
+        const uint32_t len = (uint32_t)(e >> START_BITS) & (LEN_LIMIT - 1u);
+        L.src[t] = (uint64_t)blockIdx.x * RB + (uint32_t)(e & (uint32_t)(RB - 1));
+        L.len[t] = len;
+        L.dst[t] = atomicAdd(&cursor[(uint32_t)(e >> (START_BITS + LEN_BITS))], (unsigned long long)slot_of(len));
+    }
+    __syncthreads();
+    copy_round(b, n, dst, L, known);
+}
+
+// a tile whose records did not fit the table (short reads, several record starts in one lane's chunk): found and keyed again
+__global__ __launch_bounds__(256) void place_again_kernel(const char *__restrict__ b, uint64_t n, int bits, unsigned long long *__restrict__ cursor,
+                                                          const uint32_t *__restrict__ tab_cnt, char *__restrict__ dst)
+{
+    __shared__ TileLds L;
+    const int t = threadIdx.x;
+    if (tab_cnt[blockIdx.x] != T_OVERFLOW) return;
+    TileState S;
+    tile_setup(b, n, L, S);
+    while (true) {
+        const uint32_t cnt = tile_round(b, n, L, S);
+        const bool more = L.more != 0;
+        if ((uint32_t)t < cnt) {
+            const uint64_t s = L.src[t];
+            const uint32_t len = L.len[t];
+            const uint32_t bin = (s + 32 <= n) ? record_bin(b, s, len, bits) : (1u << bits);
+            L.dst[t] = atomicAdd(&cursor[bin], (unsigned long long)slot_of(len));
+        }
+        __syncthreads();
+        copy_round(b, n, dst, L, cnt);
+        if (!more) break;
+        __syncthreads();
+    }
+}
+
+// ---- exclusive prefix over the bin sizes (up to 4 M of them): block sums, their prefix, local prefixes ----------------------
+constexpr int SCAN_PER = 4096;              // entries per workgroup of 1024 threads
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(const unsigned long long *__restrict__ v, uint32_t n, unsigned long long *__restrict__ sums)
+{
+    __shared__ unsigned long long s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t i0 = blockIdx.x * SCAN_PER + (uint32_t)t * 4u;
+    unsigned long long x = 0;
+    for (uint32_t i = i0; i < min(n, i0 + 4u); i++) x += v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += (unsigned long long)__shfl_xor((long long)x, off, 64);
+    if (lane == 0) s_w[wave] = x;
+    __syncthreads();
+    if (t == 0) { unsigned long long r = 0; for (int w = 0; w < 16; w++) r += s_w[w]; sums[blockIdx.x] = r; }
+}
+
+__global__ __launch_bounds__(1024) void scan_top_kernel(unsigned long long *__restrict__ sums, uint32_t nb, unsigned long long *__restrict__ total)
 {
     __shared__ unsigned long long s_part[1024];
     const int t = threadIdx.x;
-    const uint32_t per = (n_bins + 1023u) / 1024u, a = min(n_bins, (uint32_t)t * per), e = min(n_bins, a + per);
+    const uint32_t per = (nb + 1023u) / 1024u, a = min(nb, (uint32_t)t * per), e = min(nb, a + per);
     unsigned long long sum = 0;
-    for (uint32_t i = a; i < e; i++) sum += bins[i];
+    for (uint32_t i = a; i < e; i++) sum += sums[i];
     s_part[t] = sum;
     __syncthreads();
     if (t == 0) {
@@ -257,16 +398,39 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned long long *__re
     }
     __syncthreads();
     unsigned long long run = s_part[t];
-    for (uint32_t i = a; i < e; i++) { const unsigned long long v = bins[i]; bins[i] = run; run += v; }
+    for (uint32_t i = a; i < e; i++) { const unsigned long long v = sums[i]; sums[i] = run; run += v; }
 }
 
-int order_bits()
+__global__ __launch_bounds__(1024) void scan_apply_kernel(unsigned long long *__restrict__ v, uint32_t n, const unsigned long long *__restrict__ sums)
 {
-    static const int bits = [] {
-        const char *e = getenv("SS_ORDER_BITS");
-        const int v = e ? atoi(e) : 12;
-        return std::min(MAX_BITS, std::max(1, v));
-    }();
+    __shared__ unsigned long long s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t i0 = blockIdx.x * SCAN_PER + (uint32_t)t * 4u;
+    unsigned long long x[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = i0 + k < n ? v[i0 + k] : 0ull; mine += x[k]; }
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = (unsigned long long)__shfl_up((long long)incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned long long run = sums[blockIdx.x] + incl - mine;
+    for (int w = 0; w < wave; w++) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k < n) v[i0 + k] = run; run += x[k]; }
+}
+
+// bin width: about four records per bin for the block at hand (reads that share their first minimizer then sit in the
+// same scan tile or the next), 12 bits at least, 22 at most (4 M counters = 32 MB); SS_ORDER_BITS overrides
+int order_bits(uint64_t n_bytes)
+{
+    static const int forced = [] { const char *e = getenv("SS_ORDER_BITS"); return e ? std::min(MAX_BITS, std::max(1, atoi(e))) : 0; }();
+    if (forced) return forced;
+    int bits = 12;
+    while (bits < 22 && (n_bytes / 152) >> (bits + 2)) bits++;
     return bits;
 }
 
@@ -279,7 +443,7 @@ namespace ss {
 int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used, uint64_t *out_cap)
 {
     *out_d = nullptr; *out_used = 0; *out_cap = 0;
-    const int bits = order_bits();
+    const int bits = order_bits(n);
     const uint32_t n_bins = (1u << bits) + 1u;
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -288,27 +452,37 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
         hipDeviceSynchronize();
         fprintf(stderr, "[reorder] %-22s at %.4f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    unsigned long long *d_bins = nullptr;
-    char *d_new = nullptr;
-#define SS_R(call) do { if ((call) != hipSuccess) { ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); hipFree(d_bins); hipFree(d_new); return SS_EHIP; } } while (0)
-    SS_R(hipMalloc((void **)&d_bins, ((uint64_t)n_bins + 1) * 8));
-    SS_R(hipMemsetAsync(d_bins, 0, ((uint64_t)n_bins + 1) * 8, 0));
-    const unsigned nb = (unsigned)((n + RB - 1) / RB);
-    hipLaunchKernelGGL((bin_kernel<false>), dim3(nb), dim3(256), 0, 0, src, n, bits, d_bins, (char *)nullptr);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, 0, d_bins, n_bins, d_bins + n_bins);
-    unsigned long long total = 0;
-    SS_R(hipMemcpy(&total, d_bins + n_bins, 8, hipMemcpyDeviceToHost));
-    lap("count + scan");
+    const unsigned nb = (unsigned)((n + RB - 1) / RB), nsb = (n_bins + SCAN_PER - 1) / SCAN_PER;
+    // one allocation for the scratch: bin sizes / cursors (+ total), block sums of the prefix, per-tile record counts and table
+    const uint64_t o_sums = ((uint64_t)n_bins + 2) * 8, o_cnt = o_sums + (((uint64_t)nsb + 1) * 8), o_tab = (o_cnt + (uint64_t)nb * 4 + 255) & ~255ull;
+    const uint64_t scratch = o_tab + (uint64_t)nb * TCAP * 8;
+    char *d_scr = nullptr, *d_new = nullptr;
+#define SS_R(call) do { if ((call) != hipSuccess) { ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); hipFree(d_scr); hipFree(d_new); return SS_EHIP; } } while (0)
+    SS_R(hipMalloc((void **)&d_scr, scratch));
+    unsigned long long *d_hist = (unsigned long long *)d_scr, *d_sums = (unsigned long long *)(d_scr + o_sums);
+    uint32_t *d_cnt = (uint32_t *)(d_scr + o_cnt);
+    unsigned long long *d_tab = (unsigned long long *)(d_scr + o_tab);
+    SS_R(hipMemsetAsync(d_hist, 0, o_sums, 0));
+    static const unsigned pad1 = getenv("SS_ORDER_PAD1") ? atoi(getenv("SS_ORDER_PAD1")) : 0, pad2 = getenv("SS_ORDER_PAD2") ? atoi(getenv("SS_ORDER_PAD2")) : 0;
+    hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(256), pad1, 0, src, n, bits, d_hist, d_cnt, d_tab, d_hist + n_bins + 1);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, 0, d_sums, nsb, d_hist + n_bins);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
+    unsigned long long tail[2] = {0, 0};                 // bytes of the new slab, tiles that did not fit the table
+    SS_R(hipMemcpy(tail, d_hist + n_bins, 16, hipMemcpyDeviceToHost));
+    const unsigned long long total = tail[0];
+    lap("count + prefix");
     const uint64_t cap = std::max<uint64_t>((total + 15) & ~15ull, 16);
     SS_R(hipMalloc((void **)&d_new, cap));
     lap("new slab");
-    hipLaunchKernelGGL((bin_kernel<true>), dim3(nb), dim3(256), 0, 0, src, n, bits, d_bins, d_new);
+    hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), pad2, 0, src, n, d_hist, d_cnt, d_tab, d_new);
+    if (tail[1]) hipLaunchKernelGGL(place_again_kernel, dim3(nb), dim3(256), 0, 0, src, n, bits, d_hist, d_cnt, d_new);
     if (cap > total) SS_R(hipMemsetAsync(d_new + total, '\n', cap - total, 0));
     SS_R(hipGetLastError());
     SS_R(hipDeviceSynchronize());
-    lap("copy");
+    lap("place");
 #undef SS_R
-    hipFree(d_bins);
+    hipFree(d_scr);
     *out_d = d_new; *out_used = cap; *out_cap = cap;
     return SS_OK;
 }

@@ -927,8 +927,14 @@ def test_locality_ordered_read_set(L):
         back = [r for r in rset.read_back().split(b"\n") if r]
         assert sorted(back) == sorted(r for r in mixed if r)                 # every record once, whole
         if order:
-            bins = [_locality_bin(r) for r in back]
-            assert bins == sorted(bins) and len(set(bins)) > 1000 and bins[-1] == 4096      # ... and in bin order
+            bits = 12                                   # ss_reorder.hip order_bits(): about four records per bin, 12..22 bits
+            while bits < 22 and (buf.size // 152) >> (bits + 2):
+                bits += 1
+            assert bits > 12
+            for bb in (12, bits):                       # in bin order under the width used (hence under any smaller one)
+                bins = [_locality_bin(r, bb) for r in back]
+                assert bins == sorted(bins) and len(set(bins)) > 1000 and bins[-1] == 1 << bb, bb
+            assert [_locality_bin(r, bits + 3) for r in back] != sorted(_locality_bin(r, bits + 3) for r in back)
             slots = rset.read_back()
             assert len(slots) % 16 == 0 and slots.endswith(b"\n")
         else:
