@@ -34,6 +34,8 @@ extern "C" {
 #define SS_ENODEV (-19)   /* no usable GPU */
 #define SS_EKEY (-2)      /* the reference would raise KeyError here */
 #define SS_ERANGE (-34)   /* value out of the supported range (k > 31, p > 16, ...) */
+#define SS_EAGAIN (-11)   /* strict .gz policy (ss_gz_set_policy(1)): the device path declined an input; agree with the other
+                             ranks, then load again under policy 2 */
 
 #define SS_ROW_VALID 1u   /* row flag: ACGT-only k-mer of length k */
 #define SS_ROW_LOWER 2u   /* row flag: text contains lower-case letters */
@@ -88,6 +90,13 @@ int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
 /* The device inflater keeps its scratch (symbol streams, window maps, the text buffer: ~6-12 GB, at most two sets) for
  * the next call -- large allocations are slow to come by on this platform; this hands it back. */
 int ss_gz_gpu_release(void);
+/* Who inflates the .gz inputs of the next ss_reads_load / ss_scan_files* calls of this process: 0 (default) the device, and
+ * the host inflaters for whatever it declines; 1 the device or NOBODY -- a declined input makes the call return SS_EAGAIN
+ * with nothing loaded; 2 the host inflaters.  The two paths give a rank different shares of the reads (blocks of 4096
+ * records / parse chunks), and the device path can decline for reasons of its own (free memory, a HIP error), so the
+ * ranks of a sharded run must all take the same path for a file: they load under policy 1, all-reduce the outcome and,
+ * if any of them was declined, all load again under policy 2 (strainscan_amd/dist.py load_agreed). */
+int ss_gz_set_policy(int mode);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,

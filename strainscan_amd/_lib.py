@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SS_LIB") or os.path.join(_HERE, "lib", "libstrainscan_hip.so")
 
 SS_OK, SS_EINVAL, SS_ENOMEM, SS_EIO, SS_EHIP, SS_ENODEV, SS_EKEY, SS_ERANGE = 0, -22, -12, -5, -1000, -19, -2, -34
+SS_EAGAIN = -11
 ROW_VALID, ROW_LOWER = 1, 2
 
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "ss_gz_inflate_gpu": (i32, [cp, P(vp), P(u64)]),
     "ss_gz_gpu_counters": (i32, [P(u64), P(u64)]),
     "ss_gz_gpu_release": (i32, []),
+    "ss_gz_set_policy": (i32, [i32]),
     "ss_gz_free": (None, [vp]),
     "ss_gz_inflate_to_file": (i32, [cp, cp, i32, P(u64)]),
     "ss_host_cpus": (i32, []),
@@ -176,6 +178,22 @@ def check(rc, where):
 
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class gz_policy:
+    """with gz_policy(1): ...  -- who inflates .gz inputs inside the block (ss_gz_set_policy: 1 = the device or SS_EAGAIN,
+    2 = the host inflaters); back to 0 (device, then host for what it declines) afterwards."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        check(lib().ss_gz_set_policy(self.mode), "ss_gz_set_policy")
+        return self
+
+    def __exit__(self, *exc):
+        lib().ss_gz_set_policy(0)
+        return False
 
 
 def device_count():

@@ -175,6 +175,7 @@ std::vector<InflatedText> inflate_gz_inputs(const char *const *paths, int n_path
 // unless SS_GZ_GPU=0: .gz inputs are inflated on the device (ss_ginflate.hip) and strict four-line FASTQ is turned into the flat
 // base block there (ss_fastq_dev.hip)
 bool gz_on_gpu();
+int gz_policy();                         // ss_gz_set_policy: 0 device then host, 1 device or SS_EAGAIN, 2 host
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd);      // the text is lent until ...
 void gpu_gunzip_done(void *lease);
 int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap,

@@ -12,6 +12,8 @@
 //   4  exclusive sum -> copy, 16 lanes per record
 #include "ss_common.h"
 
+#include <atomic>
+
 #include <hipcub/hipcub.hpp>
 
 #include <fcntl.h>
@@ -119,8 +121,12 @@ namespace ss {
 
 // on unless SS_GZ_GPU=0 (the host inflaters of ss_pgz.hip / libdeflate / zlib then take every .gz input, as they take what
 // the device path declines)
+static std::atomic<int> g_gz_policy{0};      // ss_gz_set_policy: 0 device then host, 1 device or SS_EAGAIN, 2 host
+int gz_policy() { return g_gz_policy.load(); }
+
 bool gz_on_gpu()
 {
+    if (g_gz_policy.load() == 2) return false;
     const char *e = getenv("SS_GZ_GPU");
     return !e || strcmp(e, "0") != 0;
 }
@@ -218,6 +224,7 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    if (const char *inj = getenv("SS_GZ_INJECT_DECLINE")) if (atoi(inj)) return 1;       // test hook: this process declines
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return 1;
     struct stat sb;
@@ -239,6 +246,9 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     int rc = fastq_text_to_flat_dev(d_text, n, shard_rank, shard_world, d_flat, flat_len, flat_cap, n_records);
     if (trace) fprintf(stderr, "[ingest] %s: sequence lines extracted (rc %d) at %.4f s\n", path, rc, since());
     if (rc == 0) { gpu_gunzip_done(lease); return 0; }
+    // a failure of this process's own (rc < 0) under the strict policy is a decline, not a reason to parse the text here:
+    // the other ranks would keep their blocks of records while this one keeps parse chunks
+    if (rc < 0 && gz_policy() == 1) { gpu_gunzip_done(lease); return 1; }
     // the general grammar runs on the host
     char *h = n <= inflate_budget_bytes() ? (char *)malloc(std::max<uint64_t>(n, 1)) : nullptr;
     const bool got = h && (n == 0 || hipMemcpy(h, d_text, n, hipMemcpyDeviceToHost) == hipSuccess);
@@ -250,3 +260,10 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
 }
 
 }  // namespace ss
+
+extern "C" int ss_gz_set_policy(int mode)
+{
+    if (mode < 0 || mode > 2) return SS_EINVAL;
+    ss::g_gz_policy.store(mode);
+    return SS_OK;
+}

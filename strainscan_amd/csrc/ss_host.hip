@@ -161,6 +161,7 @@ const char *ss_strerror(int code)
     case SS_ENODEV: return "no usable GPU";
     case SS_EKEY: return "k-mer without an owning row (KeyError in the reference)";
     case SS_ERANGE: return "value out of supported range";
+    case SS_EAGAIN: return "the device path declined a .gz input under the strict policy (ss_gz_set_policy)";
     default: return "unknown error";
     }
 }

@@ -396,6 +396,8 @@ int gz_inputs_on_device(const char *const *paths, int n_paths, int shard_rank, i
                 const int rc = flat(i, d, len, cap, nrec);
                 if (rc != SS_OK) err = rc;
                 done[i] = 1;
+            } else if (r == 1 && gz_policy() == 1) {
+                err = SS_EAGAIN;          // strict policy: a declined input is the caller's to settle with the other ranks
             }
         });
     for (auto &th : pool) th.join();

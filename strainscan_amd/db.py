@@ -82,11 +82,8 @@ def resident_reads(paths):
             for old in _READS.values():
                 old.close()
             _READS.clear()
-            use, cleanup = dist.share_inflated([p for p in paths if p])    # .gz under torch.distributed: one inflate per node
-            try:
-                rs = _lib.ReadSet(use, rank, world)
-            finally:
-                cleanup()
+            # (.gz under torch.distributed: all ranks take the same inflate path for a file, dist.load_agreed)
+            rs = dist.load_agreed([p for p in paths if p], lambda use: _lib.ReadSet(use, rank, world), discard=lambda r: r.close())
             _READS[key] = rs
     return rs
 

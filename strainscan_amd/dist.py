@@ -185,25 +185,87 @@ def allreduce_table(kdb):
 
 
 def scan_files_sharded(kdb, paths, allreduce=True):
-    """Scan this rank's share of the reads into `kdb` (ss_scan_files_shard: a rank parses, copies and scans only the
-    chunks c % world == rank of every file; .gz inputs are inflated once per node, share_inflated); with `allreduce`
-    the row counts are then summed over the ranks and loaded back (layer-2 scans need every row; the tree scan
-    exchanges the touched nodes instead, exchange_touched).  Returns this rank's (n_records, n_bases)."""
+    """Scan this rank's share of the reads into `kdb` (ss_scan_files_shard: a rank parses, copies and scans only its share
+    of every file; .gz inputs: load_agreed); with `allreduce` the row counts are then summed over the ranks and loaded
+    back (layer-2 scans need every row; the tree scan exchanges the touched nodes instead, exchange_touched).
+    Returns this rank's (n_records, n_bases)."""
     rank, world = rank_world()
-    kdb.reset()
-    use, cleanup = share_inflated([p for p in paths if p])
-    try:
-        nrec, nb = kdb.scan_files(use, rank, world)
-    finally:
-        cleanup()
+
+    def scan(use):
+        kdb.reset()                       # (a second attempt starts from zero: the first may have counted some files)
+        return kdb.scan_files(use, rank, world)
+
+    nrec, nb = load_agreed([p for p in paths if p], scan)
     if world > 1 and allreduce:
         allreduce_table(kdb)
     return nrec, nb
 
 
+def _is_gz(p):
+    try:
+        with open(p, "rb") as f:
+            return f.read(2) == b"\x1f\x8b"
+    except OSError:
+        return False
+
+
+def load_agreed(paths, load, discard=None):
+    """load(paths) under torch.distributed when some inputs are .gz.  The device path (ss_ginflate.hip + ss_fastq_dev.hip)
+    gives a rank its blocks of 4096 records, the host inflaters give it parse chunks of the text, and the device path may
+    decline a file for reasons of one rank's own (free memory, a HIP error): if the ranks took different paths for a file,
+    reads would be counted twice or not at all, silently.  So: every rank loads under the STRICT policy (the device or
+    SS_EAGAIN, nothing loaded), the outcomes are MIN-all-reduced, and unless every rank succeeded all of them load again
+    with the host inflaters -- rank 0 inflating each .gz once into /dev/shm for all (share_inflated).  An exception on one
+    rank is raised on all of them (no rank is left waiting at a collective).  `discard(obj)` releases what a successful
+    first attempt of THIS rank produced when another rank was declined."""
+    paths = list(paths)
+    if not is_distributed() or not any(_is_gz(p) for p in paths if p):
+        return load(paths)
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+
+    def agree(status):
+        t = torch.tensor([status], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
+    err = None
+    if os.environ.get("SS_GZ_GPU", "1") != "0":
+        obj, status = None, 1
+        try:
+            with _lib.gz_policy(1):
+                obj = load(paths)
+        except _lib.SSError as e:
+            status, err = (0, None) if e.code == _lib.SS_EAGAIN else (-1, e)
+        except BaseException as e:          # noqa: B902 -- re-raised below, after the other ranks have been told
+            status, err = -1, e
+        agreed = agree(status)
+        if agreed == 1:
+            return obj
+        if obj is not None and discard is not None:
+            discard(obj)
+        if agreed < 0:
+            raise err if err is not None else RuntimeError("another rank failed while loading the reads")
+    use, cleanup = share_inflated(paths)
+    obj, status = None, 1
+    try:
+        with _lib.gz_policy(2):
+            obj = load(use)
+    except BaseException as e:              # noqa: B902
+        status, err = -1, e
+    try:
+        agreed = agree(status)
+    finally:
+        cleanup()
+    if agreed < 0:
+        raise err if err is not None else RuntimeError("another rank failed while loading the reads")
+    return obj
+
+
 def share_inflated(paths, shm_dir="/dev/shm"):
-    """.gz inputs that the device inflater does not take (SS_GZ_GPU=0, files below 1 MB or above 4 GB) under
-    torch.distributed on ONE node: rank 0 inflates each of them once into a plain file on tmpfs
+    """.gz inputs that go through the HOST inflaters under torch.distributed on ONE node (SS_GZ_GPU=0, or the device path
+    declined one of them on some rank: load_agreed): rank 0 inflates each of them once into a plain file on tmpfs
     (ss_gz_inflate_to_file: the threaded inflater writes through a shared mapping), the names are broadcast, every
     rank then parses only its share of the plain text -- instead of every rank inflating the whole file before it
     can pick its share (a gzip member has no entry points).  -> (paths to read, cleanup): call cleanup() when the
@@ -223,15 +285,7 @@ def share_inflated(paths, shm_dir="/dev/shm"):
         import tempfile
         try:
             for i, p in enumerate(paths):
-                if not p:
-                    continue
-                with open(p, "rb") as f:
-                    if f.read(2) != b"\x1f\x8b":
-                        continue
-                # every rank inflates such a file on its own GPU and keeps its blocks of records (ss_ginflate.hip,
-                # ss_fastq_dev.hip): nothing to share.  (Should the device path decline it after all, the ranks fall
-                # back to inflating it on the host each.)
-                if os.environ.get("SS_GZ_GPU", "1") != "0" and (1 << 20) <= os.path.getsize(p) <= (4 << 30):
+                if not p or not _is_gz(p):
                     continue
                 fs = os.statvfs(shm_dir)
                 if fs.f_bavail * fs.f_frsize < 8 * os.path.getsize(p):

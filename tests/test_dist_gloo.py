@@ -78,18 +78,49 @@ def _share_worker(rank, world, port, gz_path, plain_path, out_dir):
     os.environ["SS_GZ_SHARE"] = "0"
     assert sdist.share_inflated([gz_path])[0] == [gz_path]
     os.environ["SS_GZ_SHARE"] = "1"
-    os.environ["SS_GZ_GPU"] = "1"                                  # the device path takes a file of this size: nothing to share
-    use2, cleanup2 = sdist.share_inflated([gz_path, plain_path])
-    assert use2 == [gz_path, plain_path]
-    cleanup2()
+    # load_agreed: every rank loads under the strict policy; if ANY rank was declined (or SS_GZ_GPU=0), all of them load
+    # again from the shared plain text -- no rank keeps what it loaded alone
+    from strainscan_amd import _lib
+    calls = []
+
+    def load(paths):
+        calls.append(list(paths))
+        if len(calls) == 1 and rank == 1:                          # the first attempt: rank 1's device path declines
+            raise _lib.SSError(_lib.SS_EAGAIN, "test")
+        return ("loaded", len(calls))
+
+    dropped = []
+    os.environ["SS_GZ_GPU"] = "1"
+    got = sdist.load_agreed([gz_path, plain_path], load, discard=dropped.append)
+    assert got == ("loaded", 2) and calls[0] == [gz_path, plain_path] and calls[1][0] != gz_path and calls[1][1] == plain_path
+    assert dropped == ([] if rank == 1 else [("loaded", 1)])       # rank 0 gave up what it had loaded alone
+    assert not os.path.exists(calls[1][0])
+    calls.clear()
+    assert sdist.load_agreed([gz_path], lambda ps: ("ok", list(ps))) == ("ok", [gz_path])        # nobody declined: one attempt
+    os.environ["SS_GZ_GPU"] = "0"                                  # host inflaters asked for: shared text at once
+    got = sdist.load_agreed([gz_path], lambda ps: list(ps))
+    assert got != [gz_path] and got[0].startswith("/dev/shm/")
+    assert sdist.load_agreed([plain_path], lambda ps: list(ps)) == [plain_path]                   # no .gz: no collective
+    os.environ["SS_GZ_GPU"] = "1"
+    with pytest.raises(ValueError):                                # a failure on one rank is raised on both
+        def bad(ps):
+            if rank == 0:
+                raise ValueError("rank 0 only")
+            return 1
+        try:
+            sdist.load_agreed([gz_path], bad)
+        except RuntimeError as e:
+            assert rank == 1 and "another rank" in str(e)
+            raise ValueError("told")
     dist.destroy_process_group()
 
 
 @pytest.mark.skipif(not os.path.isdir("/dev/shm"), reason="no tmpfs")
 def test_two_ranks_share_one_inflate(tmp_path, monkeypatch):
-    """dist.share_inflated, for .gz inputs the device inflater does not take (here: SS_GZ_GPU=0): rank 0 inflates a .gz once
-    into /dev/shm, both ranks get the same plain file with the right bytes, plain inputs pass through, cleanup removes
-    the file.  With the device path on (the default) a file of 1 MB and more is left to the ranks' GPUs."""
+    """dist.share_inflated, for .gz inputs that go through the host inflaters: rank 0 inflates a .gz once into /dev/shm, both
+    ranks get the same plain file with the right bytes, plain inputs pass through, cleanup removes the file.
+    dist.load_agreed: the ranks agree on ONE inflate path per load (strict device attempt, MIN-all-reduce, host path for
+    all when any rank was declined); an exception on one rank reaches all."""
     import gzip
     import zlib
     monkeypatch.setenv("SS_GZ_GPU", "0")

@@ -166,7 +166,7 @@ job = json.load(open(%(jobs)r))
 kdb = _lib.KmerDB.from_text(open(job["kfa"], "rb").read(), 31, True)
 nrec, nb = sdist.scan_files_sharded(kdb, job["paths"], allreduce=True)
 counts = kdb.counts_rows()
-rset = _lib.ReadSet(job["paths"], rank, world)
+rset = sdist.load_agreed(job["paths"], lambda use: _lib.ReadSet(use, rank, world), discard=lambda r: r.close())
 own = rset.info()["n_records"]
 rset.close()
 a, b = C.c_uint64(), C.c_uint64()
@@ -178,11 +178,13 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_scan_of_gz_pair_on_the_device(world, tmp_path):
+@pytest.mark.parametrize("world,decline", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_scan_of_gz_pair_on_the_device(world, decline, tmp_path):
     """A pair of .fastq.gz files under torch.distributed: every rank inflates both files on the GPU and keeps its blocks
     of 4096 records (ss_fastq_dev.hip), nothing goes through /dev/shm; the summed row counts equal the single-process
-    scan of the plain text, the ranks' record counts add up, and the device inflater (not the host's) did the work."""
+    scan of the plain text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
+    `decline`: the device path of rank 1 alone declines (test hook) -- dist.load_agreed must move ALL ranks to the host
+    inflaters (one inflate into /dev/shm, parse chunks shared out), or reads would be counted twice or not at all."""
     import gzip
     import socket
     from strainscan_amd import _lib as L
@@ -220,12 +222,17 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, tmp_path):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.pop("SS_GZ_GPU", None)
+        if decline and r == 1:
+            env["SS_GZ_INJECT_DECLINE"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
     errs = [p.communicate(timeout=600)[1].decode()[-2000:] for p in procs]
     assert all(p.returncode == 0 for p in procs), errs
     infos = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("counts%d.npy" % r)), want), r          # the global counts, on every rank
-        assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0                      # two files, scanned and loaded
+        if not decline:
+            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0                  # two files, scanned and loaded
+        else:       # the ranks that were not declined did inflate on the device, and gave that up
+            assert infos[r]["handled"] == (0 if r == 1 else 4)
     assert sum(i["nrec"] for i in infos) == n and sum(i["own"] for i in infos) == n
     assert all(i["nrec"] > 0 for i in infos)
