@@ -123,41 +123,62 @@ struct SelState {
     uint32_t done;
 };
 
+// Lane = four consecutive rows: their bits are one nibble of the plane's word (eight lanes share a word), their values one
+// 16-byte load of y -- coalesced, where walking the set bits of a word per lane gathered y four bytes at a time from 64
+// different lines per instruction (the address path of the L1, not HBM, was what bound it: 2.2 GB of algorithmic bytes
+// per pass in 1.03 ms).  y (4 K bytes, 20 MB at K = 5 M) is read once per column and stays in the 256 MB MALL.  k-mer
+// counts crowd into a few values, i.e. a few bins: the histogram is kept in HCOPY copies (copy = lane mod HCOPY) so that
+// the lanes of one LDS instruction rarely share a word.
+constexpr int HCOPY = 8;
+
+__device__ __forceinline__ uint4 load_y4(const uint32_t *__restrict__ y, uint64_t k, uint64_t K)
+{
+    if (k + 4 <= K) return *reinterpret_cast<const uint4 *>(y + k);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (k < K) v.x = y[k];
+    if (k + 1 < K) v.y = y[k + 1];
+    if (k + 2 < K) v.z = y[k + 2];
+    return v;
+}
+
 __global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
                                                       const uint32_t *__restrict__ y,
                                                       const uint32_t *__restrict__ cols, int shift, int first,
                                                       const SelState *__restrict__ st, uint32_t *hist /*[ncols][2][256]*/)
 {
-    __shared__ uint32_t h[2][256];
+    __shared__ uint32_t h[2][HCOPY][256];
     const uint32_t c = blockIdx.y;
     const uint32_t *xs = x + (uint64_t)cols[c] * W;
-    h[0][threadIdx.x] = 0;
-    h[1][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 2 * HCOPY * 256; i += NT) (&h[0][0][0])[i] = 0;
     __syncthreads();
     const uint32_t p0 = st[c].prefix[0], p1 = st[c].prefix[1];
-    for (uint64_t w = (uint64_t)blockIdx.x * NT + threadIdx.x; w < W; w += (uint64_t)gridDim.x * NT) {
-        uint32_t bits = xs[w];
-        while (bits) {
-            const int b = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const uint64_t k = (w << 5) + b;
-            if (k >= K) break;
-            const uint32_t v = y[k];
-            if (v == 0) continue;
+    const int cp = threadIdx.x % HCOPY;
+    const uint64_t K4 = (K + 3) >> 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < K4; i += (uint64_t)gridDim.x * NT) {
+        const uint32_t nib = (xs[i >> 3] >> ((uint32_t)(i & 7) * 4u)) & 15u;
+        if (!nib) continue;
+        const uint4 y4 = load_y4(y, i << 2, K);
+        const uint32_t vv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t v = vv[r];
+            if (!((nib >> r) & 1u) || v == 0) continue;
             const uint32_t d = (v >> shift) & 255u;
             if (first) {                          // no prefix yet (the bytes above `shift` are zero in every value)
-                atomicAdd(&h[0][d], 1u);
+                atomicAdd(&h[0][cp][d], 1u);
             } else {
                 const uint32_t hi = v >> (shift + 8);
-                if (hi == p0) atomicAdd(&h[0][d], 1u);
-                if (hi == p1) atomicAdd(&h[1][d], 1u);
+                if (hi == p0) atomicAdd(&h[0][cp][d], 1u);
+                if (hi == p1) atomicAdd(&h[1][cp][d], 1u);
             }
         }
     }
     __syncthreads();
     uint32_t *g = hist + (uint64_t)c * 512;
-    if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
-    if (!first && h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
+    uint32_t t0 = 0, t1 = 0;
+    for (int k = 0; k < HCOPY; k++) { t0 += h[0][k][threadIdx.x]; t1 += h[1][k][threadIdx.x]; }
+    if (t0) atomicAdd(&g[threadIdx.x], t0);
+    if (!first && t1) atomicAdd(&g[256 + threadIdx.x], t1);
 }
 
 // numpy.percentile(..., interpolation='nearest'): index = around(q/100 * (n-1)), half to even
@@ -197,7 +218,7 @@ __global__ void sel_pick_kernel(int first, double q_lo, double q_hi, SelState *s
     for (int b = 0; b < 512; b++) g[b] = 0;
 }
 
-// sums over rows with X bit set and lo <= y <= hi (y != 0): count and sum of y
+// sums over rows with X bit set and lo <= y <= hi (y != 0): count and sum of y (lane = four rows, as above)
 __global__ __launch_bounds__(NT) void sel_sum_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
                                                      const uint32_t *__restrict__ y,
                                                      const uint32_t *__restrict__ cols,
@@ -208,15 +229,16 @@ __global__ __launch_bounds__(NT) void sel_sum_kernel(const uint32_t *__restrict_
     const uint32_t lo = st[c].prefix[0], hi = st[c].prefix[1];
     unsigned long long cnt = 0, sum = 0;
     if (st[c].n) {
-        for (uint64_t w = (uint64_t)blockIdx.x * NT + threadIdx.x; w < W; w += (uint64_t)gridDim.x * NT) {
-            uint32_t bits = xs[w];
-            while (bits) {
-                const int b = __ffs(bits) - 1;
-                bits &= bits - 1;
-                const uint64_t k = (w << 5) + b;
-                if (k >= K) break;
-                const uint32_t v = y[k];
-                if (v == 0 || v < lo || v > hi) continue;
+        const uint64_t K4 = (K + 3) >> 2;
+        for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < K4; i += (uint64_t)gridDim.x * NT) {
+            const uint32_t nib = (xs[i >> 3] >> ((uint32_t)(i & 7) * 4u)) & 15u;
+            if (!nib) continue;
+            const uint4 y4 = load_y4(y, i << 2, K);
+            const uint32_t vv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t v = vv[r];
+                if (!((nib >> r) & 1u) || v == 0 || v < lo || v > hi) continue;
                 cnt++;
                 sum += v;
             }
@@ -277,6 +299,52 @@ __global__ __launch_bounds__(NT) void pattern_stats_kernel(const uint32_t *__res
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < M * 3; i += NT)
             if (s_acc[i]) atomicAdd(&g[i], s_acc[i]);
+    }
+}
+
+// The same statistics for p <= 6 in ONE pass over the rows (the kernel above reads the planes, y and the fold words once
+// per fold group: 21 times): lane = row -- fold word and y arrive coalesced, the pattern's p bits come from the two words
+// of each plane that the wave's 64 rows share -- and every group the row belongs to (the kept rows, the test halves it is
+// in: ~11 of 21) takes its three additions in LDS.  With at most 64 patterns all lanes would hammer a handful of LDS words
+// (one wave instruction then takes as many passes as lanes share its word), so the tables are kept in COPIES copies
+// (copy = lane mod COPIES) that are added up when the workgroup is done.  [groups][patterns][3] u64 per copy: 32 KB at p = 6.
+template <int COPIES>
+__global__ __launch_bounds__(NT) void pattern_stats_once_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
+                                                                const uint32_t *__restrict__ cols, int p,
+                                                                const uint32_t *__restrict__ y, const uint32_t *__restrict__ fold,
+                                                                int n_folds, unsigned long long *stats)
+{
+    extern __shared__ unsigned long long s_tab[];       // [COPIES][G][M][3]
+    const uint32_t M = 1u << p, G = (uint32_t)n_folds + 1u, per_copy = G * M * 3u;
+    for (uint32_t i = threadIdx.x; i < per_copy * COPIES; i += NT) s_tab[i] = 0;
+    __syncthreads();
+    unsigned long long *mine = s_tab + (threadIdx.x % COPIES) * per_copy;
+    const uint32_t fold_mask = n_folds >= 32 ? 0xFFFFFFFFu : ((1u << n_folds) - 1u);
+    const uint64_t n_batches = (K + 63) / 64;            // a wave takes 64 rows at a time
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint64_t bt = (uint64_t)blockIdx.x * (NT / 64) + wave; bt < n_batches; bt += (uint64_t)gridDim.x * (NT / 64)) {
+        const uint64_t k = bt * 64 + lane;
+        uint32_t groups = 0, v = 0, m = 0;
+        if (k < K) {
+            const uint32_t fb = fold[k];
+            if (fb >> 31) groups = (fb & fold_mask) | (1u << n_folds);       // kept: its test halves + "all kept rows"
+            v = y[k];
+        }
+        const uint64_t w = bt * 2 + (lane >> 5);                             // the word of every plane with this row's bit
+        for (int j = 0; j < p; j++) m |= ((w < W ? x[(uint64_t)cols[j] * W + w] : 0u) >> (lane & 31) & 1u) << j;
+        const unsigned long long vv = (unsigned long long)v * v;
+        for (uint32_t f = 0; f < G; f++) {
+            if (!((groups >> f) & 1u)) continue;
+            unsigned long long *e = mine + ((uint64_t)f * M + m) * 3u;
+            atomicAdd(&e[0], 1ull);
+            if (v) { atomicAdd(&e[1], (unsigned long long)v); atomicAdd(&e[2], vv); }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < per_copy; i += NT) {
+        unsigned long long t = 0;
+        for (int c = 0; c < COPIES; c++) t += s_tab[(uint32_t)c * per_copy + i];
+        if (t) atomicAdd(&stats[i], t);
     }
 }
 
@@ -435,13 +503,19 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
         hipMemset(d_hist, 0, (uint64_t)ncols * 2048);
         hipMemset(d_st, 0, ncols * sizeof(SelState));
         hipMemset(d_out, 0, (uint64_t)ncols * 16);
-        const dim3 grid(grid_for(h->W, ncols), ncols);
+        const dim3 grid(grid_for((h->K + 3) / 4, ncols), ncols);      // one lane per four rows
         // the radix passes start at the highest byte that is non-zero in any value (k-mer counts are small numbers:
         // usually ONE pass instead of four, each of which reads the bit planes and gathers y for every set bit)
         uint32_t *d_max = reinterpret_cast<uint32_t *>(d_out), ymax = 0;       // d_out is zero and unused until sel_sum_kernel
         hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)std::min<uint64_t>((h->K + 1023) / 1024, 512)), dim3(256), 0, 0, y_dev, h->K, d_max);
-        hipMemcpy(&ymax, d_max, 4, hipMemcpyDeviceToHost);
-        hipMemset(d_max, 0, 4);
+        hipError_t e0 = hipGetLastError();
+        if (e0 == hipSuccess) e0 = hipMemcpy(&ymax, d_max, 4, hipMemcpyDeviceToHost);
+        if (e0 == hipSuccess) e0 = hipMemset(d_max, 0, 4);
+        if (e0 != hipSuccess) {             // without the maximum the passes cannot be shortened safely: report, do not guess
+            ss::set_last_error("ss_l2_quantile_sums (max of y)", __FILE__, __LINE__, e0);
+            hipFree(d_cols); hipFree(d_hist); hipFree(d_st); hipFree(d_out);
+            return SS_EHIP;
+        }
         const int top = ymax >> 24 ? 24 : ymax >> 16 ? 16 : ymax >> 8 ? 8 : 0;
         for (int shift = top; shift >= 0; shift -= 8) {
             hipLaunchKernelGGL(sel_hist_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, shift, (int)(shift == top), d_st, d_hist);
@@ -482,10 +556,21 @@ int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint3
     for (int i = 0; i < p; i++) c16[i] = cols[i];
     hipMemcpy(d_cols, c16, 64, hipMemcpyHostToDevice);
     hipMemset(d_stats, 0, n * 8);
-    const int use_lds = (M * 24 <= 48 * 1024) ? 1 : 0;   // p <= 11
-    const size_t lds = use_lds ? (size_t)M * 24 : 0;
-    hipLaunchKernelGGL(pattern_stats_kernel, dim3(grid_for(h->W, (unsigned)n_folds + 1), (unsigned)n_folds + 1), dim3(NT),
-                       lds, 0, h->d_x, h->W, h->K, d_cols, p, y_dev, fold_dev, n_folds, d_stats, use_lds);
+    static const bool per_group = getenv("SS_L2_STATS_PER_GROUP") != nullptr;       // A/B and tests: the general kernel
+    const size_t once_bytes = (size_t)(n_folds + 1) * M * 24;                        // one copy of the tables of the one-pass kernel
+    if (p <= 6 && once_bytes <= 32 * 1024 && !per_group) {
+        const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(512, (h->K + 64 * (NT / 64) - 1) / (64 * (NT / 64))));
+        const int copies = once_bytes * 8 <= 64 * 1024 ? 8 : once_bytes * 4 <= 64 * 1024 ? 4 : 2;
+#define SS_ONCE(C) hipLaunchKernelGGL((pattern_stats_once_kernel<C>), dim3(blocks), dim3(NT), once_bytes * C, 0, h->d_x, h->W, h->K, d_cols, \
+                                      p, y_dev, fold_dev, n_folds, d_stats)
+        if (copies == 8) SS_ONCE(8); else if (copies == 4) SS_ONCE(4); else SS_ONCE(2);
+#undef SS_ONCE
+    } else {
+        const int use_lds = (M * 24 <= 48 * 1024) ? 1 : 0;   // p <= 11
+        const size_t lds = use_lds ? (size_t)M * 24 : 0;
+        hipLaunchKernelGGL(pattern_stats_kernel, dim3(grid_for(h->W, (unsigned)n_folds + 1), (unsigned)n_folds + 1), dim3(NT),
+                           lds, 0, h->d_x, h->W, h->K, d_cols, p, y_dev, fold_dev, n_folds, d_stats, use_lds);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(stats, d_stats, n * 8, hipMemcpyDeviceToHost);
     hipFree(d_cols); hipFree(d_stats);

@@ -235,4 +235,4 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, tmp_path):
         else:       # the ranks that were not declined did inflate on the device, and gave that up
             assert infos[r]["handled"] == (0 if r == 1 else 4)
     assert sum(i["nrec"] for i in infos) == n and sum(i["own"] for i in infos) == n
-    assert all(i["nrec"] > 0 for i in infos)
+    assert decline or all(i["nrec"] > 0 for i in infos)      # (parse chunks are 24 MB: these small files are one chunk each)

@@ -324,6 +324,46 @@ def test_detect_core_at_config3_size(case):
         assert "S003" in res and "S057" in res          # both near-duplicates are reported
 
 
+@pytest.mark.parametrize("p,n_folds", [(1, 20), (3, 20), (5, 20), (6, 20), (6, 31), (7, 20), (11, 5), (12, 3)])
+def test_pattern_stats_both_kernels(p, n_folds):
+    """ss_l2_pattern_stats against numpy: {count, sum y, sum y^2} per p-bit row pattern for every fold's test half and for
+    all kept rows -- the one-pass kernel (p <= 6 with the tables of all groups in LDS: lane = row, copies against LDS
+    conflicts) and the per-group kernel (larger p; tables in LDS up to p = 11, in global memory beyond).  K is not a
+    multiple of 64, some rows are not kept, y has zeros and large values (sums beyond 2^32)."""
+    import scipy.sparse as sp
+    from strainscan_amd import l2
+    rs = np.random.RandomState(100 + p)
+    K, S = 200_003, 14
+    X = (rs.random_sample((K, S)) < 0.45)
+    img = l2.ClusterImage(sp.csr_matrix(X.astype(np.int8)))
+    cols = rs.choice(S, size=p, replace=False).astype(np.uint32)
+    y = rs.poisson(9, K).astype(np.uint64)
+    y[rs.random_sample(K) < 0.1] = 0
+    y[rs.randint(0, K, 50)] = 3_000_000                              # y^2 = 9e12 each
+    fold = rs.randint(0, 1 << min(n_folds, 31), size=K, dtype=np.int64).astype(np.uint32) & np.uint32((1 << n_folds) - 1 if n_folds < 32 else 0xFFFFFFFF)
+    if n_folds == 31:
+        fold &= np.uint32(0x7FFFFFFF)
+    kept = rs.random_sample(K) < 0.8
+    fold = np.where(kept, fold | np.uint32(1 << 31), fold & np.uint32(0x7FFFFFFF)).astype(np.uint32)
+    got = img.pattern_stats(cols, img.u32(y), l2.DevBuf.from_array(fold), n_folds)
+    pat = np.zeros(K, np.int64)
+    for j, c in enumerate(cols):
+        pat |= X[:, c].astype(np.int64) << j
+    M = 1 << p
+    for f in range(n_folds + 1):
+        sel = kept & (((fold >> np.uint32(f)) & 1).astype(bool) if f < n_folds else True)
+        want = np.zeros((M, 3), np.uint64)
+        want[:, 0] = np.bincount(pat[sel], minlength=M).astype(np.uint64)
+        want[:, 1] = np.bincount(pat[sel], weights=None, minlength=M) * 0
+        ys = y[sel]
+        for col, vals in ((1, ys), (2, ys * ys)):
+            acc = np.zeros(M, np.uint64)
+            np.add.at(acc, pat[sel], vals)
+            want[:, col] = acc
+        assert np.array_equal(got[f], want), (p, f)
+    img.close()
+
+
 def test_csr_pack_and_quantiles_edge_inputs():
     """ss_l2_create: canonical CSR takes the atomic-free pack kernel, rows with unsorted or repeated column indices fall
     back to the atomicOr kernel -- same bit planes; out-of-range indices are refused.  ss_l2_quantile_sums starts its
