@@ -72,6 +72,51 @@ __global__ __launch_bounds__(256) void pack_csr_sorted_kernel(const int64_t *__r
     if (p < e) *redo = 1;
 }
 
+// CSR -> bit planes with COALESCED reads of the index array.  The kernel above gives every lane a row and lets it walk its
+// own list four bytes at a time: neighbouring lanes are a whole row (~100 entries) apart, every step touches 64 different
+// sectors and each sector is fetched again for each of its 16 entries -- 19.9 GB fetched for a 2 GB CSR (K = 5 M, S = 300,
+// 5.6 ms).  Here a wave owns 64 consecutive rows = one CONTIGUOUS span of the index array (their lists lie back to back):
+// the lanes read the span 64 entries at a time, find each entry's row by binary search over the wave's 65 row offsets (LDS),
+// and OR the row's bit into the column's 64-bit word in LDS; the S words are then stored to the planes.  Any column order,
+// duplicates welcome (OR); a column index outside [0, S) raises *bad.  S <= PACK_SMAX (the LDS words), else the kernels above.
+constexpr uint32_t PACK_SMAX = 4096;
+
+__global__ __launch_bounds__(64) void pack_csr_span_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                           uint64_t K, uint32_t S, uint64_t W, uint32_t *x, int *bad)
+{
+    extern __shared__ unsigned long long s_words[];      // [S] column words of these 64 rows, then 65 row offsets
+    const int lane = threadIdx.x;
+    const uint64_t k0 = (uint64_t)blockIdx.x * 64;
+    long long *s_off = reinterpret_cast<long long *>(s_words + S);
+    for (uint32_t c = lane; c < S; c += 64) s_words[c] = 0;
+    const uint64_t kr = min(K, k0 + lane);
+    s_off[lane] = indptr[kr];
+    if (lane == 0) s_off[64] = indptr[min(K, k0 + 64)];
+    __syncthreads();
+    const long long lo = s_off[0], hi = s_off[64];
+    int flag = 0;
+    for (long long e = lo + lane; e < hi; e += 64) {
+        const int32_t c = indices[e];
+        int a = 0, b = 63;                               // the last row whose offset is <= e
+        while (a < b) {
+            const int mid = (a + b + 1) >> 1;
+            if (s_off[mid] <= e) a = mid; else b = mid - 1;
+        }
+        if (c < 0 || (uint32_t)c >= S) flag = 1;
+        else atomicOr(&s_words[c], 1ull << a);
+    }
+    if (flag) *bad = 1;
+    __syncthreads();
+    const uint64_t w0 = k0 >> 5;
+    for (uint32_t c = lane; c < S; c += 64) {
+        const unsigned long long m = s_words[c];
+        if (!m) continue;                                // the planes were zeroed
+        uint32_t *dst = x + (uint64_t)c * W + w0;
+        dst[0] = (uint32_t)m;
+        if (w0 + 1 < W) dst[1] = (uint32_t)(m >> 32);
+    }
+}
+
 // out1[s] = popc(X_s & A), out2[s] = popc(X_s & A & B); A or B may be null (= all ones)
 __global__ __launch_bounds__(NT) void popc2_kernel(const uint32_t *__restrict__ x, uint64_t W,
                                                    const uint32_t *__restrict__ A, const uint32_t *__restrict__ B,
@@ -123,13 +168,14 @@ struct SelState {
     uint32_t done;
 };
 
-// Lane = four consecutive rows: their bits are one nibble of the plane's word (eight lanes share a word), their values one
-// 16-byte load of y -- coalesced, where walking the set bits of a word per lane gathered y four bytes at a time from 64
-// different lines per instruction (the address path of the L1, not HBM, was what bound it: 2.2 GB of algorithmic bytes
-// per pass in 1.03 ms).  y (4 K bytes, 20 MB at K = 5 M) is read once per column and stays in the 256 MB MALL.  k-mer
-// counts crowd into a few values, i.e. a few bins: the histogram is kept in HCOPY copies (copy = lane mod HCOPY) so that
-// the lanes of one LDS instruction rarely share a word.
-constexpr int HCOPY = 8;
+// Lane = four consecutive rows -- their values are one 16-byte load of y, their bits one nibble of a plane's word (eight
+// lanes share a word) -- and a workgroup takes CT columns at a time for its rows, so y is read once per CT columns instead
+// of once per column.  (Walking the set bits of a word per lane gathered y four bytes at a time from 64 different lines per
+// instruction: 1.03 ms per pass over K = 5 M x S = 300, bound by the L1's address path; one column per workgroup with
+// coalesced y: 0.97 ms, now bound by re-reading y 300 times out of the MALL.)  k-mer counts crowd into a few values, i.e. a
+// few bins: every column's histogram is kept in HCOPY copies (copy = lane mod HCOPY) so that the lanes of one LDS
+// instruction rarely share a word.
+constexpr int CT = 8, HCOPY = 4;
 
 __device__ __forceinline__ uint4 load_y4(const uint32_t *__restrict__ y, uint64_t k, uint64_t K)
 {
@@ -141,44 +187,61 @@ __device__ __forceinline__ uint4 load_y4(const uint32_t *__restrict__ y, uint64_
     return v;
 }
 
+// blockIdx.y = tile of CT listed columns; hist[ncols][2][256]
+template <bool FIRST>
 __global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
-                                                      const uint32_t *__restrict__ y,
-                                                      const uint32_t *__restrict__ cols, int shift, int first,
-                                                      const SelState *__restrict__ st, uint32_t *hist /*[ncols][2][256]*/)
+                                                      const uint32_t *__restrict__ y, const uint32_t *__restrict__ cols, uint32_t ncols,
+                                                      int shift, const SelState *__restrict__ st, uint32_t *hist)
 {
-    __shared__ uint32_t h[2][HCOPY][256];
-    const uint32_t c = blockIdx.y;
-    const uint32_t *xs = x + (uint64_t)cols[c] * W;
-    for (int i = threadIdx.x; i < 2 * HCOPY * 256; i += NT) (&h[0][0][0])[i] = 0;
+    constexpr int NH = FIRST ? 1 : 2;
+    __shared__ uint32_t h[NH][CT][HCOPY][256];
+    __shared__ uint32_t s_p[2][CT];
+    __shared__ const uint32_t *s_x[CT];
+    const uint32_t c0 = blockIdx.y * CT, nc = min((uint32_t)CT, ncols - c0);
+    for (int i = threadIdx.x; i < NH * CT * HCOPY * 256; i += NT) (&h[0][0][0][0])[i] = 0;
+    if (threadIdx.x < nc) {
+        s_x[threadIdx.x] = x + (uint64_t)cols[c0 + threadIdx.x] * W;
+        s_p[0][threadIdx.x] = st[c0 + threadIdx.x].prefix[0];
+        s_p[1][threadIdx.x] = st[c0 + threadIdx.x].prefix[1];
+    }
     __syncthreads();
-    const uint32_t p0 = st[c].prefix[0], p1 = st[c].prefix[1];
     const int cp = threadIdx.x % HCOPY;
     const uint64_t K4 = (K + 3) >> 2;
     for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < K4; i += (uint64_t)gridDim.x * NT) {
-        const uint32_t nib = (xs[i >> 3] >> ((uint32_t)(i & 7) * 4u)) & 15u;
-        if (!nib) continue;
         const uint4 y4 = load_y4(y, i << 2, K);
         const uint32_t vv[4] = {y4.x, y4.y, y4.z, y4.w};
+        if (!(vv[0] | vv[1] | vv[2] | vv[3])) continue;
+        uint32_t d[4], hi[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t v = vv[r];
-            if (!((nib >> r) & 1u) || v == 0) continue;
-            const uint32_t d = (v >> shift) & 255u;
-            if (first) {                          // no prefix yet (the bytes above `shift` are zero in every value)
-                atomicAdd(&h[0][cp][d], 1u);
-            } else {
-                const uint32_t hi = v >> (shift + 8);
-                if (hi == p0) atomicAdd(&h[0][cp][d], 1u);
-                if (hi == p1) atomicAdd(&h[1][cp][d], 1u);
+        for (int r = 0; r < 4; r++) { d[r] = (vv[r] >> shift) & 255u; hi[r] = FIRST ? 0u : vv[r] >> (shift + 8); }
+        const uint32_t sh = (uint32_t)(i & 7) * 4u;
+        uint32_t xw[CT];                          // the CT planes' words first: their round trips overlap
+#pragma unroll
+        for (int c = 0; c < CT; c++) xw[c] = (uint32_t)c < nc ? s_x[c][i >> 3] : 0u;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const uint32_t nib = (xw[c] >> sh) & 15u;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (!((nib >> r) & 1u) || vv[r] == 0) continue;
+                if (FIRST) {                      // no prefix yet (the bytes above `shift` are zero in every value)
+                    atomicAdd(&h[0][c][cp][d[r]], 1u);
+                } else {
+                    if (hi[r] == s_p[0][c]) atomicAdd(&h[0][c][cp][d[r]], 1u);
+                    if (hi[r] == s_p[1][c]) atomicAdd(&h[NH - 1][c][cp][d[r]], 1u);
+                }
             }
         }
     }
     __syncthreads();
-    uint32_t *g = hist + (uint64_t)c * 512;
-    uint32_t t0 = 0, t1 = 0;
-    for (int k = 0; k < HCOPY; k++) { t0 += h[0][k][threadIdx.x]; t1 += h[1][k][threadIdx.x]; }
-    if (t0) atomicAdd(&g[threadIdx.x], t0);
-    if (!first && t1) atomicAdd(&g[256 + threadIdx.x], t1);
+    for (uint32_t c = 0; c < nc; c++) {
+        uint32_t *g = hist + (uint64_t)(c0 + c) * 512;
+        for (int t = 0; t < NH; t++) {
+            uint32_t tot = 0;
+            for (int k = 0; k < HCOPY; k++) tot += h[t][c][k][threadIdx.x];
+            if (tot) atomicAdd(&g[256 * t + threadIdx.x], tot);
+        }
+    }
 }
 
 // numpy.percentile(..., interpolation='nearest'): index = around(q/100 * (n-1)), half to even
@@ -218,39 +281,57 @@ __global__ void sel_pick_kernel(int first, double q_lo, double q_hi, SelState *s
     for (int b = 0; b < 512; b++) g[b] = 0;
 }
 
-// sums over rows with X bit set and lo <= y <= hi (y != 0): count and sum of y (lane = four rows, as above)
+// sums over rows with X bit set and lo <= y <= hi (y != 0): count and sum of y (lane = four rows, CT columns per
+// workgroup, as above; the sums live in registers)
 __global__ __launch_bounds__(NT) void sel_sum_kernel(const uint32_t *__restrict__ x, uint64_t W, uint64_t K,
-                                                     const uint32_t *__restrict__ y,
-                                                     const uint32_t *__restrict__ cols,
+                                                     const uint32_t *__restrict__ y, const uint32_t *__restrict__ cols, uint32_t ncols,
                                                      const SelState *__restrict__ st, unsigned long long *out /*[ncols][2]*/)
 {
-    const uint32_t c = blockIdx.y;
-    const uint32_t *xs = x + (uint64_t)cols[c] * W;
-    const uint32_t lo = st[c].prefix[0], hi = st[c].prefix[1];
-    unsigned long long cnt = 0, sum = 0;
-    if (st[c].n) {
-        const uint64_t K4 = (K + 3) >> 2;
-        for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < K4; i += (uint64_t)gridDim.x * NT) {
-            const uint32_t nib = (xs[i >> 3] >> ((uint32_t)(i & 7) * 4u)) & 15u;
-            if (!nib) continue;
-            const uint4 y4 = load_y4(y, i << 2, K);
-            const uint32_t vv[4] = {y4.x, y4.y, y4.z, y4.w};
+    __shared__ uint32_t s_lo[CT], s_hi[CT], s_on[CT];
+    __shared__ const uint32_t *s_x[CT];
+    const uint32_t c0 = blockIdx.y * CT, nc = min((uint32_t)CT, ncols - c0);
+    if (threadIdx.x < CT) {
+        const bool in = threadIdx.x < nc;
+        s_x[threadIdx.x] = x + (uint64_t)(in ? cols[c0 + threadIdx.x] : 0u) * W;
+        s_lo[threadIdx.x] = in ? st[c0 + threadIdx.x].prefix[0] : 1u;
+        s_hi[threadIdx.x] = in ? st[c0 + threadIdx.x].prefix[1] : 0u;          // lo > hi: nothing passes
+        s_on[threadIdx.x] = in && st[c0 + threadIdx.x].n ? 1u : 0u;
+    }
+    __syncthreads();
+    uint32_t cnt[CT];
+    unsigned long long sum[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) { cnt[c] = 0; sum[c] = 0; }
+    const uint64_t K4 = (K + 3) >> 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < K4; i += (uint64_t)gridDim.x * NT) {
+        const uint4 y4 = load_y4(y, i << 2, K);
+        const uint32_t vv[4] = {y4.x, y4.y, y4.z, y4.w};
+        if (!(vv[0] | vv[1] | vv[2] | vv[3])) continue;
+        const uint32_t sh = (uint32_t)(i & 7) * 4u;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (!s_on[c]) continue;
+            const uint32_t nib = (s_x[c][i >> 3] >> sh) & 15u, lo = s_lo[c], hi = s_hi[c];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint32_t v = vv[r];
-                if (!((nib >> r) & 1u) || v == 0 || v < lo || v > hi) continue;
-                cnt++;
-                sum += v;
+                const bool in = ((nib >> r) & 1u) && v != 0 && v >= lo && v <= hi;
+                cnt[c] += in ? 1u : 0u;
+                sum[c] += in ? v : 0u;
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        cnt += __shfl_down(cnt, off, 64);
-        sum += __shfl_down(sum, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicAdd(&out[(uint64_t)c * 2], cnt);
-        atomicAdd(&out[(uint64_t)c * 2 + 1], sum);
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        unsigned long long a = cnt[c], b = sum[c];
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off, 64);
+            b += __shfl_down(b, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && a && (uint32_t)c < nc) {
+            atomicAdd(&out[(uint64_t)(c0 + c) * 2], a);
+            atomicAdd(&out[(uint64_t)(c0 + c) * 2 + 1], b);
+        }
     }
 }
 
@@ -383,9 +464,16 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
                (nnz && hipMemcpy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
         rc = SS_EHIP;
     } else if (K) {
-        static const bool force_atomic = getenv("SS_L2_PACK_ATOMIC") != nullptr;          // tests: the general kernel
+        const bool force_atomic = getenv("SS_L2_PACK_ATOMIC") != nullptr;                 // tests: the general kernel
         int redo = 1;
-        if (!force_atomic) {
+        const bool no_span = getenv("SS_L2_PACK_WALK") != nullptr;                    // A/B and tests: the row-walk kernel
+        if (!force_atomic && !no_span && S <= PACK_SMAX) {
+            hipLaunchKernelGGL(pack_csr_span_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), (size_t)S * 8 + 65 * 8, 0, d_ptr, d_idx, K, S,
+                               h->W, h->d_x, d_bad);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            else if (bad) rc = SS_EINVAL;
+            redo = 0;
+        } else if (!force_atomic) {
             hipLaunchKernelGGL(pack_csr_sorted_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
                                h->W, h->d_x, d_bad);
             if (hipMemcpy(&redo, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
@@ -503,7 +591,8 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
         hipMemset(d_hist, 0, (uint64_t)ncols * 2048);
         hipMemset(d_st, 0, ncols * sizeof(SelState));
         hipMemset(d_out, 0, (uint64_t)ncols * 16);
-        const dim3 grid(grid_for((h->K + 3) / 4, ncols), ncols);      // one lane per four rows
+        const unsigned ctiles = (ncols + CT - 1) / CT;
+        const dim3 grid(grid_for((h->K + 3) / 4, ctiles), ctiles);      // one lane per four rows, CT columns per workgroup
         // the radix passes start at the highest byte that is non-zero in any value (k-mer counts are small numbers:
         // usually ONE pass instead of four, each of which reads the bit planes and gathers y for every set bit)
         uint32_t *d_max = reinterpret_cast<uint32_t *>(d_out), ymax = 0;       // d_out is zero and unused until sel_sum_kernel
@@ -518,10 +607,11 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
         }
         const int top = ymax >> 24 ? 24 : ymax >> 16 ? 16 : ymax >> 8 ? 8 : 0;
         for (int shift = top; shift >= 0; shift -= 8) {
-            hipLaunchKernelGGL(sel_hist_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, shift, (int)(shift == top), d_st, d_hist);
+            if (shift == top) hipLaunchKernelGGL((sel_hist_kernel<true>), grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, ncols, shift, d_st, d_hist);
+            else hipLaunchKernelGGL((sel_hist_kernel<false>), grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, ncols, shift, d_st, d_hist);
             hipLaunchKernelGGL(sel_pick_kernel, dim3((ncols + 63) / 64), dim3(64), 0, 0, (int)(shift == top), q_lo, q_hi, d_st, d_hist, ncols);
         }
-        hipLaunchKernelGGL(sel_sum_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, d_st, d_out);
+        hipLaunchKernelGGL(sel_sum_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, ncols, d_st, d_out);
         std::vector<SelState> st(ncols);
         std::vector<unsigned long long> o((size_t)ncols * 2);
         hipError_t e = hipMemcpy(st.data(), d_st, ncols * sizeof(SelState), hipMemcpyDeviceToHost);
@@ -544,7 +634,7 @@ int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint3
                         const uint32_t *fold_dev, int n_folds, uint64_t *stats /* [(n_folds+1)][2^p][3] host */)
 {
     if (!h || !cols || !y_dev || !fold_dev || !stats) return SS_EINVAL;
-    if (p < 1 || p > 16 || n_folds < 0 || n_folds > 30) return SS_ERANGE;
+    if (p < 1 || p > 16 || n_folds < 0 || n_folds > 30) return SS_ERANGE;      // bit 31 of a fold word = "row kept"; 30 folds at most
     for (int i = 0; i < p; i++) if (cols[i] >= h->S) return SS_EINVAL;
     const uint64_t M = 1ull << p;
     const uint64_t n = (uint64_t)(n_folds + 1) * M * 3;

@@ -324,7 +324,7 @@ def test_detect_core_at_config3_size(case):
         assert "S003" in res and "S057" in res          # both near-duplicates are reported
 
 
-@pytest.mark.parametrize("p,n_folds", [(1, 20), (3, 20), (5, 20), (6, 20), (6, 31), (7, 20), (11, 5), (12, 3)])
+@pytest.mark.parametrize("p,n_folds", [(1, 20), (3, 20), (5, 20), (6, 20), (4, 30), (7, 20), (11, 5), (12, 3)])
 def test_pattern_stats_both_kernels(p, n_folds):
     """ss_l2_pattern_stats against numpy: {count, sum y, sum y^2} per p-bit row pattern for every fold's test half and for
     all kept rows -- the one-pass kernel (p <= 6 with the tables of all groups in LDS: lane = row, copies against LDS
@@ -365,8 +365,9 @@ def test_pattern_stats_both_kernels(p, n_folds):
 
 
 def test_csr_pack_and_quantiles_edge_inputs():
-    """ss_l2_create: canonical CSR takes the atomic-free pack kernel, rows with unsorted or repeated column indices fall
-    back to the atomicOr kernel -- same bit planes; out-of-range indices are refused.  ss_l2_quantile_sums starts its
+    """ss_l2_create: the span kernel (a wave reads its 64 rows' entries coalesced, ORs bits into LDS words; any order of
+    the column indices), the row-walk kernel (canonical CSR; S beyond the LDS words) and the atomicOr kernel (what the
+    row walk falls back to for unsorted or repeated indices) -- same bit planes; out-of-range indices are refused.  ss_l2_quantile_sums starts its
     radix passes at the highest non-zero byte of y: counts below 256, below 65536 and up to 2^31 against
     numpy.percentile(..., 'nearest') semantics (oracle.percentile_nearest)."""
     import ctypes as C
@@ -387,15 +388,27 @@ def test_csr_pack_and_quantiles_edge_inputs():
         indices.extend(r)
         indptr.append(len(indices))
     ip, ix = np.array(indptr, np.int64), np.array(indices, np.int32)
-    h = C.c_void_p()
-    _lib.check(_lib.lib().ss_l2_create(_lib.ptr(ip), _lib.ptr(ix), K, S, C.byref(h)), "ss_l2_create")
-    got = np.zeros_like(want)
-    _lib.check(_lib.lib().ss_l2_export_planes(h, _lib.ptr(got)), "export")
-    _lib.lib().ss_l2_destroy(h)
-    assert np.array_equal(got, want)
     ix_bad = ix.copy()
     ix_bad[3] = S
-    assert _lib.lib().ss_l2_create(_lib.ptr(ip), _lib.ptr(ix_bad), K, S, C.byref(h)) == _lib.SS_EINVAL
+    Xc = X.tocsr()
+    Xc.sort_indices()
+    cip, cix = Xc.indptr.astype(np.int64), Xc.indices.astype(np.int32)
+    for env in (None, "SS_L2_PACK_WALK", "SS_L2_PACK_ATOMIC"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            for a, b in ((ip, ix), (cip, cix)):              # scrambled + repeated entries, canonical
+                h = C.c_void_p()
+                _lib.check(_lib.lib().ss_l2_create(_lib.ptr(a), _lib.ptr(b), K, S, C.byref(h)), "ss_l2_create")
+                got = np.zeros_like(want)
+                _lib.check(_lib.lib().ss_l2_export_planes(h, _lib.ptr(got)), "export")
+                _lib.lib().ss_l2_destroy(h)
+                assert np.array_equal(got, want), env
+            h = C.c_void_p()
+            assert _lib.lib().ss_l2_create(_lib.ptr(ip), _lib.ptr(ix_bad), K, S, C.byref(h)) == _lib.SS_EINVAL, env
+        finally:
+            if env:
+                os.environ.pop(env)
     Xd = X.toarray().astype(bool)
     for top in (200, 60_000, 2**31 - 1, 1):
         y = rs.randint(0, top + 1, size=K).astype(np.int64)
