@@ -43,6 +43,11 @@ __host__ __device__ __forceinline__ uint32_t slot_of(uint64_t key, uint32_t log2
 {
     return (uint32_t)(mix64(key) >> (64 - log2cap));
 }
+// flat layout's Bloom filter (ss_scan.hip): bit index from the LOW half of the same mix (the table slot takes the top bits)
+__host__ __device__ __forceinline__ uint32_t bloom_bit_of(uint64_t mixed, uint32_t bloom_bits)
+{
+    return (uint32_t)(mixed & 0xFFFFFFFFull) >> (32 - bloom_bits);
+}
 
 // ascii -> 2-bit code ((c >> 1) & 3: A0 C1 T2 G3) or -1
 __host__ __device__ __forceinline__ int base_code(unsigned char c)

@@ -35,10 +35,16 @@ constexpr uint64_t STAGE_BYTES = 32ull << 20;  // pinned staging chunk for host-
 // shifts, issues the 16 first-probe loads back to back (16 independent HBM gathers in flight
 // per lane), then resolves them; only the rare collision chains loop.
 // ---------------------------------------------------------------------------------------------
-template <bool ALIGNED>
+// BLOOM: a one-probe Bloom filter over the table's k-mers that fits one XCD's L2 (<= 2^25 bits; built for tables of up to
+// ~4 M k-mers, i.e. cluster tables -- the flat layout serves `-k` other than 31 for them): bit = the TOP bits of the same
+// mix64 whose next bits address the table, so a lookup costs one more shift.  ~95 % of a sample's k-mers are not in the
+// table and stop at the filter (L2) instead of pulling a random sector of the table (MALL / HBM): 12.5 -> 3.x ms for
+// 4 M reads against a 2 M-row table (scripts/bench_k.py).
+template <bool ALIGNED, bool BLOOM>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles,
-    const uint64_t *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t log2cap, int k)
+    const uint64_t *__restrict__ keys, uint32_t *__restrict__ counts, uint32_t log2cap, int k,
+    const uint32_t *__restrict__ bloom, uint32_t bloom_bits)
 {
     __shared__ uint32_t s_code[2][SCAN_THREADS + 2];
     __shared__ uint16_t s_inv[2][SCAN_THREADS + 2];
@@ -74,12 +80,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(
         uint64_t key[PPT], got[PPT];
         uint32_t slot[PPT];
         uint32_t live = 0;
+        if (BLOOM) {
+            uint32_t bw[PPT], bb[PPT];
 #pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            uint64_t km = (j == 0) ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)));
-            key[j] = km & kmask;
-            slot[j] = ss::slot_of(key[j], log2cap);
-            if (((inv >> j) & wmask) == 0) live |= 1u << j;
+            for (int j = 0; j < PPT; j++) {
+                uint64_t km = (j == 0) ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)));
+                key[j] = km & kmask;
+                const uint64_t m = ss::mix64(key[j]);
+                slot[j] = (uint32_t)(m >> (64 - log2cap));
+                bb[j] = ss::bloom_bit_of(m, bloom_bits);
+                if (((inv >> j) & wmask) == 0) live |= 1u << j;
+            }
+#pragma unroll
+            for (int j = 0; j < PPT; j++) bw[j] = ((live >> j) & 1u) ? bloom[bb[j] >> 5] : 0u;
+#pragma unroll
+            for (int j = 0; j < PPT; j++) if (!((bw[j] >> (bb[j] & 31u)) & 1u)) live &= ~(1u << j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                uint64_t km = (j == 0) ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)));
+                key[j] = km & kmask;
+                slot[j] = ss::slot_of(key[j], log2cap);
+                if (((inv >> j) & wmask) == 0) live |= 1u << j;
+            }
         }
 #pragma unroll
         for (int j = 0; j < PPT; j++)
@@ -122,6 +145,16 @@ __global__ void build_insert_kernel(const uint64_t *__restrict__ in_keys, const 
     // dict overwrite at identify.py:94: the LAST row with this text owns the count.  With raw
     // (non-upper) keys a lower-case row can never equal jellyfish's upper-case dump.
     if (upper_keys == 1 || !(f & SS_ROW_LOWER)) atomicMax(&last_row[s], (uint32_t)(i + 1));
+}
+
+__global__ void build_bloom_kernel(const uint64_t *__restrict__ keys, uint64_t capacity, uint32_t bloom_bits, uint32_t *bloom)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= capacity) return;
+    const uint64_t key = keys[s];
+    if (key == ss::EMPTY_KEY) return;
+    const uint32_t b = ss::bloom_bit_of(ss::mix64(key), bloom_bits);
+    atomicOr(&bloom[b >> 5], 1u << (b & 31u));
 }
 
 __global__ void build_finalize_kernel(const uint32_t *__restrict__ slot_of_row, const uint32_t *__restrict__ last_row,
@@ -268,6 +301,23 @@ int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int
     unsigned long long ctr[2] = {0, 0};
     SS_TRY(hipMemcpy(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost));
     db->n_distinct = ctr[0];
+    {
+        // Bloom filter over the k-mers when it fits an XCD's L2 with >= 8 bits per k-mer (cluster tables); SS_FLAT_BLOOM_BITS=0
+        // disables, = n forces 2^n bits
+        int bits = 12;
+        while (bits < 25 && (1ull << bits) < 16 * db->n_distinct) bits++;
+        if ((1ull << bits) < 8 * db->n_distinct) bits = 0;
+        if (const char *e = getenv("SS_FLAT_BLOOM_BITS")) bits = atoi(e);
+        if (bits >= 10 && bits <= 30 && db->n_distinct) {
+            SS_TRY(hipMalloc((void **)&db->d_bloom, (1ull << bits) / 8));
+            SS_TRY(hipMemset(db->d_bloom, 0, (1ull << bits) / 8));
+            hipLaunchKernelGGL(build_bloom_kernel, dim3((unsigned)((db->capacity + 255) / 256)), dim3(256), 0, 0, db->d_keys, db->capacity,
+                               (uint32_t)bits, db->d_bloom);
+            SS_TRY(hipDeviceSynchronize());
+            db->bloom_bits = (uint32_t)bits;
+            db->device_bytes += (1ull << bits) / 8;
+        }
+    }
     hipFree(d_in); hipFree(d_flags); hipFree(d_last); hipFree(d_ctr);
     d_in = nullptr; d_flags = nullptr; d_last = nullptr; d_ctr = nullptr;
 #undef SS_TRY
@@ -349,12 +399,11 @@ int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream)
         return rc;
     }
     const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
-    if (aligned)
-        hipLaunchKernelGGL(scan_kernel<true>, dim3(blocks), dim3(SCAN_THREADS), 0, ss::as_stream(stream),
-                           (const uint8_t *)bases_dev, n, n_tiles, db->d_keys, db->d_counts, db->log2cap, db->k);
-    else
-        hipLaunchKernelGGL(scan_kernel<false>, dim3(blocks), dim3(SCAN_THREADS), 0, ss::as_stream(stream),
-                           (const uint8_t *)bases_dev, n, n_tiles, db->d_keys, db->d_counts, db->log2cap, db->k);
+#define SS_FLAT(A, B) hipLaunchKernelGGL((scan_kernel<A, B>), dim3(blocks), dim3(SCAN_THREADS), 0, ss::as_stream(stream), (const uint8_t *)bases_dev, n, \
+                                         n_tiles, db->d_keys, db->d_counts, db->log2cap, db->k, db->d_bloom, db->bloom_bits)
+    if (db->d_bloom) { if (aligned) SS_FLAT(true, true); else SS_FLAT(false, true); }
+    else             { if (aligned) SS_FLAT(true, false); else SS_FLAT(false, false); }
+#undef SS_FLAT
     SS_HIP(hipGetLastError());
     db->launches++;
     return SS_OK;
