@@ -332,17 +332,32 @@ def measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, 
             t0 = time.perf_counter()
             res = cst.Walk(_StatsProvider(st_np, args.leaves), tdir, [0.1, 0.4, 1], identify._PARAMS, out=lambda *a: None).run()
             walk_s = time.perf_counter() - t0
-        scale = n_s / float(args.reads)
-        dev_ms = (kern_ms + harvest_ms + reduce_ms) * scale
+        # end to end as ONE timed run over the sample: FASTQ text -> resident read set (parse threads || PCIe, binned) -> reset ->
+        # scan -> harvest -> node reductions -> statistics on the host -> tree walk on THOSE statistics
+        e2e = []
+        stats_s = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs = _lib.ReadSet([fq])
+            db.reset(stream)
+            rs.scan_into(db, stream)
+            nodes.harvest_dev(db, stream)
+            nodes.reduce_touched_dev(stats_s.data_ptr(), stream)
+            st_s = stats_s.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
+            res_s = cst.Walk(_StatsProvider(st_s, args.leaves), tdir, [0.1, 0.4, 1], identify._PARAMS, out=lambda *a: None).run()
+            e2e.append(time.perf_counter() - t0)
+            rs.close()
         ph = dict(sample_reads=n_s, fastq_text_gb=round(text_bytes / 1e9, 3),
                   parse_and_h2d_ms=round(ingest_s * 1e3, 2), h2d_ms=round(h2d_s * 1e3, 2),
-                  parse_note="the product's ingest parses on host threads while earlier chunks cross PCIe: parse_and_h2d_ms is "
-                             "their union; h2d_ms = the same flat bytes as one pinned copy",
+                  parse_note="the product's ingest parses on host threads while earlier chunks cross PCIe, then bins the records "
+                             "(ss_reorder.hip): parse_and_h2d_ms is all of that; h2d_ms = the same flat bytes as one pinned copy",
                   kernel_ms=round(kern_ms, 3), gather_ms=round(harvest_ms, 3), node_reduce_ms=round(reduce_ms, 3),
                   allreduce_ms=None, l1_host_ms=round(walk_s * 1e3, 2), scan_of_sample_ms=round(scan_sample_s * 1e3, 3),
-                  clusters_found=len(res),
-                  e2e_reads_per_s=round(n_s / (ingest_s + dev_ms * 1e-3 + walk_s), 1),
-                  e2e_note="sample_reads / (text -> HBM + device phases scaled to the sample + host walk), one GPU, page cache warm")
+                  clusters_found=len(res), clusters_found_in_sample=len(res_s),
+                  e2e_ms=round(min(e2e) * 1e3, 2), e2e_reads_per_s=round(n_s / min(e2e), 1),
+                  e2e_note="ONE timed run over the sample (best of 2): FASTQ text in the page cache -> resident read set -> scan -> "
+                           "harvest -> node reductions -> host tree walk; one GPU")
         if args.gz_reads > 0:
             ph["gz_ingest"] = measure_gz_ingest(reads, int(min(args.gz_reads, n_s) // 2), base)
     finally:
