@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Locality order of a resident read set (ss_reorder.hip): what it costs and what it buys, over the coverage of the sample.
 
-    bench_locality.py [sampled|contiguous] [--bits 12] [--out profiles/r03_locality_sweep.json]
+    bench_locality.py [sampled|contiguous] [--bits 0] [--out profiles/r03_locality_sweep.json]
 (the library reads SS_ORDER_BITS once per process: sweep the bin width with one run per value)
 
 Cases (E. coli-shaped table of bench.py, 70/20/10 three-strain mix, ~5.3 Mb genomes):
@@ -46,11 +46,14 @@ def with_background(torch, dev, reads, n_mix, n_total, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("shape", nargs="?", default="sampled")
-    ap.add_argument("--bits", type=int, default=12)
+    ap.add_argument("--bits", type=int, default=0, help="bin width; 0 = the library's choice (about four records per bin, 12..22 bits)")
     ap.add_argument("--out", default="")
     ap.add_argument("--cases", default="400x,40x,5x,meta")
     args = ap.parse_args()
-    os.environ["SS_ORDER_BITS"] = str(args.bits)
+    if args.bits > 0:
+        os.environ["SS_ORDER_BITS"] = str(args.bits)
+    else:
+        os.environ.pop("SS_ORDER_BITS", None)
     import torch
     from strainscan_amd import _lib
     dev = torch.device("cuda", 0)
@@ -100,7 +103,7 @@ def main():
         res["cases"][name] = c
         del reads
         torch.cuda.empty_cache()
-    res["bits"] = args.bits
+    res["bits"] = args.bits or "adaptive (12..22: about four records per bin)"
     line = json.dumps(res)
     print(line)
     if args.out:

@@ -165,6 +165,8 @@ namespace ss {
 int reads_order_for_locality(ss_reads *R, bool force = false);
 int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used, uint64_t *out_cap);
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
+// the same index built on the device (ss_build_dev.hip); anything but SS_OK / SS_EKEY: nothing was built, use the host build
+int build_mini_dev(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
 using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
                         uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink, bool copy = true);

@@ -42,6 +42,45 @@ __host__ __device__ __forceinline__ uint32_t mix30(uint32_t x)
     h ^= h >> 14;
     return h;
 }
+
+// ---- the page index of ss_mini.hip (built by ss_mini.hip on the host, by ss_build_dev.hip on the device) ----
+constexpr uint32_t HDR_MULTI = 1u << 17;
+__host__ __device__ __forceinline__ uint32_t page_of(uint32_t h, uint32_t n_pages) { return mulhi32(h << 2, n_pages); }
+constexpr uint32_t PG_SLOTS = 8;                          // slots per 64-byte page
+constexpr uint32_t PG_MIN_PAGES = 4096;                   // >= 2^11: (page, low 20 bits of h) determines h
+// A page, structure of arrays, so that ONE 16-byte load decides almost every lookup:
+//   bytes  0.. 7  tag8[8]   h & 0xFF of the slot's minimizer                         (0xFF when empty)
+//   bytes  8..15  hi8[8]    inline k-mer: e = 16 - offset (5 bits); bucket reference: 0x80 | mask bit 16 << 6 | h[13:8]
+//                           (0x7F when empty: an inline slot with the impossible e = 31)
+//   bytes 16..47  lo32[8]   inline: flank32; reference: multi << 31 | bucket start
+//   bytes 48..63  mid16[8]  inline: h[19:8] << 4; reference: mask bits 0..15
+// Only slots whose tag8 (and e range / reference filter bits) match have their lo32 / mid16 read, from the sector the
+// first load has just brought into the L1.
+constexpr uint8_t PG_EMPTY_TAG = 0xFF, PG_EMPTY_HI = 0x7F;
+constexpr uint32_t START_MASK = 0x3FFFFFFFu;
+// the 16 bases of a k-mer that are not its minimizer: rotate the 62-bit key right by 2 * offset (the minimizer
+// comes to stand in bits 0..29), the upper 32 bits = bases behind the minimizer, then the bases in front of it
+__host__ __device__ __forceinline__ uint32_t flank_of_key(uint64_t key, uint32_t off)
+{
+    const uint64_t M62 = (1ull << 62) - 1;
+    const uint64_t r = off ? (((key >> (2 * off)) | (key << (62 - 2 * off))) & M62) : key;
+    return (uint32_t)(r >> 30);
+}
+
+// minimizer (the m-mer itself) of a k-mer and its LEFTMOST offset inside the k-mer
+__host__ __device__ inline uint32_t mini_of_key(uint64_t key, int k, uint32_t *offset)
+{
+    const int w = k - MINI_M + 1;
+    uint32_t best = 0, bo = 0, bx = 0;
+    for (int i = 0; i < w; i++) {
+        const uint32_t x = (uint32_t)(key >> (2 * i)) & M30;
+        const uint32_t h = mmkey(x) & KEY_MASK;
+        if (i == 0 || h < best) { best = h; bo = (uint32_t)i; bx = x; }
+    }
+    *offset = bo;
+    return bx;
+}
+
 }  // namespace ss
 
 namespace ss { namespace dev {

@@ -862,6 +862,68 @@ def test_index_image_independent_of_thread_count(L, tmp_path):
     assert digests[0] == digests[1] == digests[2]
 
 
+@pytest.mark.parametrize("inline_max", ["2", "0", "8"])
+def test_device_index_build_equals_host_build(L, tmp_path, inline_max):
+    """ss_build_dev.hip (the default) and the host build of ss_mini.hip (SS_BUILD=host) must export the SAME image, byte
+    for byte: a sampled database (nearly every k-mer alone under its minimizer: inline page slots), a contiguous one
+    (nine k-mers per minimizer: buckets, offset masks, the Bloom filter), a FASTA with duplicate rows, lower-case rows,
+    rows with N and short rows in the three key modes of the reference's modules (owner rows, row_valid, SS_EKEY), a
+    tiny table, and a crowded one (SS_PAGE_LAMBDA=7: long runs of full pages -> items leave their partition's pages,
+    the table has to grow); SS_INLINE_MAX 0 / 2 / 8 move k-mers between page slots and buckets."""
+    import hashlib
+    import ctypes as C
+    keys_s, _, _ = _sampled_db_and_reads(43, 1_200_000, 0.08, 10)
+    kfa_c, _ = _random_db_and_reads(44, 150_000, 10)
+    rs = np.random.RandomState(45)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    rows = [lut[rs.randint(0, 4, 31)].tobytes() for _ in range(3000)]
+    rows += rows[:500] + [r.lower() for r in rows[100:300]] + [rows[7][:10] + b"N" + rows[7][11:], b"ACGT", rows[9][:15] + rows[9][15:].lower()]
+    perm = rs.permutation(len(rows))
+    kfa_m = b"".join(b">1\n" + rows[i] + b"\n" for i in perm)
+    old = {k: os.environ.get(k) for k in ("SS_BUILD", "SS_INLINE_MAX", "SS_PAGE_LAMBDA")}
+    os.environ["SS_INLINE_MAX"] = inline_max
+
+    def image(make):
+        out = []
+        for how in ("host", "device"):
+            if how == "host":
+                os.environ["SS_BUILD"] = "host"
+            else:
+                os.environ.pop("SS_BUILD", None)
+            try:
+                db = make()
+            except (KeyError, RuntimeError) as e:
+                out.append(type(e).__name__)
+                continue
+            p = str(tmp_path / ("img_%s.bin" % how))
+            db.export(p)
+            out.append(hashlib.sha256(open(p, "rb").read()).hexdigest())
+            info = db.info()
+            out[-1] += "|%d|%d" % (info["n_distinct"], info["capacity"])
+            db.close()
+        return out
+
+    try:
+        cases = [("sampled", lambda: L.KmerDB(keys_s, np.ones(keys_s.size, np.uint8), 31, True)),
+                 ("contiguous", lambda: L.KmerDB.from_text(kfa_c, 31, True)),
+                 ("tiny", lambda: L.KmerDB.from_text(kfa_c[:35 * 3], 31, True))]
+        for mode in (0, 1, 2):
+            cases.append(("mixed rows, key mode %d" % mode, lambda mode=mode: L.KmerDB.from_text(kfa_m, 31, mode)))
+        for name, make in cases:
+            a, b = image(make)
+            assert a == b, (name, inline_max, a, b)
+        if inline_max == "2":
+            os.environ["SS_PAGE_LAMBDA"] = "7"
+            a, b = image(lambda: L.KmerDB(keys_s, np.ones(keys_s.size, np.uint8), 31, True))
+            assert a == b, ("crowded pages", a, b)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _locality_bin(rec, bits=12, k=31, m=15):
     """Bin of ss_reorder.hip restated: the top `bits` bits of mix30 (the index's page hash, ss_scan_dev.h) of the 30-bit
     minimizer (ordering key of the index: ((x & 0xFFFFFF) * C1 + C0) with the low five bits cleared, leftmost on ties)
