@@ -97,6 +97,20 @@ int ss_gz_gpu_release(void);
  * ranks of a sharded run must all take the same path for a file: they load under policy 1, all-reduce the outcome and,
  * if any of them was declined, all load again under policy 2 (strainscan_amd/dist.py load_agreed). */
 int ss_gz_set_policy(int mode);
+/* Several ranks SHARE the inflation of a gzip member (ss_ginflate.hip, range mode; the reference pipes one `zcat` per file,
+ * identify.py:81-84).  The deflate data is cut into slices, slice s belongs to rank s mod world: a rank finds the block
+ * starts of its slices, inflates them to symbols (the expensive part, all ranks at once) and receives what lies in front
+ * of each slice -- 32 KB of text, the count of newlines so far, the bytes of the record that straddles the cut, CRC-32 and
+ * length so far -- from the owner of the slice before, through `chain`: direction 0 = fill msg with what the owner of
+ * slice - 1 sent, 1 = send msg to the owner of slice + 1 (blocking; return 0, anything else breaks the chain off).  The
+ * rank keeps ALL records that begin in its slices (no further sharding of these files).  Active while world > 1 and chain
+ * != NULL, and only under policy 1: a rank that cannot take part (several members, bgzip, no room, text that is not
+ * four-line FASTQ, ...) still serves the chain, passes the bad news on and returns SS_EAGAIN; the ranks then settle for the
+ * whole-file path (range off) or the host inflaters.  slice_bytes = 0: file size / (2 world), 4 MB .. 128 MB. */
+typedef int (*ss_gz_chain_fn)(void *msg, uint64_t bytes, int slice, int direction, void *user);
+int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_chain_fn chain, void *user);
+/* files this process has inflated its share of in range mode, and the slices that came to */
+int ss_gz_range_counters(uint64_t *files, uint64_t *pieces);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,

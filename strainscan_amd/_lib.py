@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("SS_LIB") or os.path.join(_HERE, "lib", "libstrainscan
 
 SS_OK, SS_EINVAL, SS_ENOMEM, SS_EIO, SS_EHIP, SS_ENODEV, SS_EKEY, SS_ERANGE = 0, -22, -12, -5, -1000, -19, -2, -34
 SS_EAGAIN = -11
+GZ_CHAIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p)      # ss_gz_chain_fn (strainscan_hip.h)
+NO_CHAIN = C.cast(None, GZ_CHAIN_FN)
 ROW_VALID, ROW_LOWER = 1, 2
 
 
@@ -61,6 +63,8 @@ SIGNATURES = {
     "ss_gz_gpu_counters": (i32, [P(u64), P(u64)]),
     "ss_gz_gpu_release": (i32, []),
     "ss_gz_set_policy": (i32, [i32]),
+    "ss_gz_set_range": (i32, [i32, i32, u64, GZ_CHAIN_FN, vp]),
+    "ss_gz_range_counters": (i32, [P(u64), P(u64)]),
     "ss_gz_free": (None, [vp]),
     "ss_gz_inflate_to_file": (i32, [cp, cp, i32, P(u64)]),
     "ss_host_cpus": (i32, []),

@@ -185,6 +185,13 @@ bool gz_on_gpu();
 int gz_policy();                         // ss_gz_set_policy: 0 device then host, 1 device or SS_EAGAIN, 2 host
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd);      // the text is lent until ...
 void gpu_gunzip_done(void *lease);
+// range mode (ss_gz_set_range): this rank's slices of a member.  text[at, at + len) is a slice's text, its first `keep` bytes
+// end with the last record that is complete in it, `carry` holds the bytes of the record that began in the slice before
+struct GzPiece { uint64_t at, len, keep; std::vector<uint8_t> carry; };
+bool gz_range_active();
+bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **lease, int fd, std::vector<GzPiece> *pieces,
+                      bool decline = false);      // decline: test hook -- plan the slices, serve the chain, hand nothing back
+int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat);
 int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap,
                          uint64_t *n_records, char **text, uint64_t *text_len);
 // every gzip input of a call through gz_fastq_to_flat_dev, one host thread per file: `flat(i, d_flat, len, cap, n_records)`

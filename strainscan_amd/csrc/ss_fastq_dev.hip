@@ -259,6 +259,60 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     return 2;
 }
 
+// The same when several ranks share the file's inflation (range mode, ss_gz_set_range): this rank gets the text of ITS slices
+// (gpu_gunzip_range), every piece = the bytes of the record that straddles the cut in front of it + its own complete records;
+// the sequence lines of each piece become a flat block handed to `flat`.  0 = done (every record that begins in this rank's
+// slices has been handed over), 1 = declined (nothing usable was handed over: the caller reports SS_EAGAIN and all ranks
+// settle for another path).
+int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat)
+{
+    static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    std::vector<GzPiece> pieces;
+    char *d_text = nullptr;
+    void *lease = nullptr;
+    bool ok = false;
+    {
+        const int fd = open(path, O_RDONLY);
+        struct stat sb;
+        const uint8_t *in = nullptr;
+        uint64_t in_n = 0;
+        const bool inj = getenv("SS_GZ_INJECT_DECLINE") && atoi(getenv("SS_GZ_INJECT_DECLINE"));      // test hook: this rank declines
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 32) {
+            in_n = (uint64_t)sb.st_size;
+            in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (in == MAP_FAILED) in = nullptr;
+        }
+        // (a rank that declines still serves the chain -- gpu_gunzip_range sees to that once it knows the slices, which it
+        //  derives from the file's size; a file that cannot be opened is the same failure on every rank)
+        if (in && in[0] == 0x1f && in[1] == 0x8b) ok = gpu_gunzip_range(in, in_n, &d_text, &lease, fd, &pieces, inj);
+        if (in) munmap((void *)in, in_n);
+        if (fd >= 0) close(fd);
+    }
+    if (!ok) return 1;
+    if (trace) fprintf(stderr, "[ingest] %s: %zu pieces of this rank on the device at %.4f s\n", path, pieces.size(), since());
+    int rc = 0;
+    for (const GzPiece &pc : pieces) {
+        const uint64_t n = pc.carry.size() + pc.keep;
+        if (!n) continue;
+        char *buf = nullptr;
+        if (hipMalloc((void **)&buf, n + 16) != hipSuccess) { rc = 1; break; }
+        bool good = (pc.carry.empty() || hipMemcpy(buf, pc.carry.data(), pc.carry.size(), hipMemcpyHostToDevice) == hipSuccess) &&
+                    (!pc.keep || hipMemcpy(buf + pc.carry.size(), d_text + pc.at, pc.keep, hipMemcpyDeviceToDevice) == hipSuccess);
+        char *d_flat = nullptr;
+        uint64_t flen = 0, fcap = 0, nrec = 0;
+        const int r = good ? fastq_text_to_flat_dev(buf, n, 0, 1, &d_flat, &flen, &fcap, &nrec) : SS_EHIP;
+        hipFree(buf);
+        if (r != 0) { rc = 1; break; }                         // not four-line FASTQ (or a failure of this rank's own): declined
+        const int fr = flat(d_flat, flen, fcap, nrec);
+        if (fr != SS_OK) { rc = fr; break; }
+    }
+    gpu_gunzip_done(lease);
+    if (trace) fprintf(stderr, "[ingest] %s: sequence lines of the pieces extracted (rc %d) at %.4f s\n", path, rc, since());
+    return rc;
+}
+
 }  // namespace ss
 
 extern "C" int ss_gz_set_policy(int mode)

@@ -653,12 +653,20 @@ __device__ unsigned g_sync_tries;      // candidates that passed the header chec
 
 // ---- kernels ------------------------------------------------------------------------------------------------------
 // A: entry point of every chunk (chunk 0: the start of the deflate data)
+// slice_chunks != 0 (several ranks share a file, gpu_gunzip's range mode): a rank looks for entries only in the slices it
+// owns (slice s belongs to rank s mod world) and in the first `look` chunks behind each of them (where its last chunk stops)
 __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in_n, uint64_t data_off, uint64_t chunk_bytes,
-                                                  uint32_t n_chunks, uint64_t *entry /* bit position or ~0 */, uint64_t probe, int count_tries)
+                                                  uint32_t n_chunks, uint64_t *entry /* bit position or ~0 */, uint64_t probe, int count_tries,
+                                                  uint32_t slice_chunks, uint32_t rank, uint32_t world, uint32_t look)
 {
     __shared__ WaveState S;
     const uint32_t c = blockIdx.x;
     const int lane = threadIdx.x & 63;
+    if (slice_chunks) {
+        const uint32_t sl = c / slice_chunks, within = c % slice_chunks;
+        const bool mine = sl % world == rank || (sl > 0 && (sl - 1) % world == rank && within < look);
+        if (!mine) { if (lane == 0) entry[c] = ~0ull; return; }
+    }
     if (c == 0) { if (lane == 0) entry[0] = data_off * 8; return; }
     const uint64_t lo = (data_off + (uint64_t)c * chunk_bytes) * 8, hi = min(in_n * 8, lo + chunk_bytes * 8);
     uint64_t found = ~0ull;
@@ -908,6 +916,15 @@ uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
     for (int i = 0; vec; vec >>= 1, i++) if (vec & 1u) sum ^= mat[i];
     return sum;
 }
+// newlines of text[0, n)
+__global__ __launch_bounds__(256) void count_nl_kernel(const uint8_t *text, uint64_t n, unsigned long long *out)
+{
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += text[i] == '\n' ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 void gf2_square(uint32_t *sq, const uint32_t *mat) { for (int i = 0; i < 32; i++) sq[i] = gf2_times(mat, mat[i]); }
 void crc_zero_operator(uint32_t *op /*[32]*/, int log2_bytes)
 {
@@ -1095,11 +1112,98 @@ namespace ss {
 // The file image `in` (host) inflated on the device.  true: *text_dev holds *len bytes, every member verified against its
 // trailer; the buffer belongs to the scratch arena of the call and is lent until gpu_gunzip_done(*lease).  false: not
 // handled here (the caller inflates on the host).
-static std::atomic<uint64_t> g_handled{0}, g_declined{0};
+static std::atomic<uint64_t> g_handled{0}, g_declined{0}, g_range_files{0}, g_range_pieces{0};
 
 void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
 
+// ---- several ranks share ONE gzip member (ss_gz_set_range) -------------------------------------------------------------------
+// The deflate data is cut into slices of `slice_chunks` search chunks; slice s belongs to rank s mod world.  A rank looks
+// for block starts in its slices only, inflates their chunks to symbols -- the expensive part, all ranks at once -- and
+// then needs what lies in front of each slice: the last 32 KB of the text before it.  That comes from the owner of the
+// slice before, down a CHAIN of small messages (the caller's callback: point-to-point send / receive between ranks):
+//     window     the 32 KB in front of the next slice
+//     end_bit    where this slice's last chunk ended: the next slice's first chunk must start exactly there
+//     nl         newlines so far: the next rank knows which of the four FASTQ lines its text starts in
+//     carry      the bytes behind the last complete record (its rest is in the next slice)
+//     crc, len   CRC-32 and length of the text so far (the owner of the last slice checks them against the trailer)
+//     status     < 0: somebody declined -- passed on to the end of the chain, everybody declines
+// A rank that fails at any point still takes part in the chain for all its slices (receives, passes the bad news on), so
+// nobody waits for a message that never comes.  One member only (several members, bgzip: declined here, the whole-file
+// path takes them).
+constexpr uint32_t CARRY_MAX = 65536;
+struct ChainMsg {
+    int32_t status;
+    uint32_t crc;
+    uint64_t len, nl, end_bit;
+    uint32_t carry_len, pad;
+    uint8_t window[WSIZE];
+    uint8_t carry[CARRY_MAX];
+};
+struct RangeRun {
+    uint32_t rank = 0, world = 1, slice_chunks = 0, n_slices = 0;
+    ss_gz_chain_fn fn = nullptr;
+    void *user = nullptr;
+    std::vector<uint32_t> mine;           // my slices, ascending
+    size_t duty = 0;                      // mine[duty]: the first slice whose part in the chain is not finished
+    bool received = false;                // ... and whether its message has come in
+    bool broken = false;                  // the callback failed: no more chain traffic
+    bool inject_decline = false;          // test hook
+    ChainMsg msg;                         // the last message received / the one being sent
+    std::vector<GzPiece> *pieces = nullptr;
+    bool recv_for(uint32_t s)
+    {
+        if (s == 0 || broken) return !broken;
+        if (fn(&msg, sizeof(ChainMsg), (int)s, 0, user) != 0) { broken = true; return false; }
+        received = true;
+        return true;
+    }
+    bool send_from(uint32_t s)
+    {
+        if (s + 1 >= n_slices || broken) return !broken;
+        if (fn(&msg, sizeof(ChainMsg), (int)s, 1, user) != 0) { broken = true; return false; }
+        return true;
+    }
+    // whatever is left of this rank's part in the chain, as a bystander: receive, pass on that it went wrong
+    void abort_chain()
+    {
+        for (; duty < mine.size() && !broken; duty++) {
+            const uint32_t s = mine[duty];
+            if (s > 0 && !received) recv_for(s);
+            msg.status = -1;
+            msg.carry_len = 0;
+            send_from(s);
+            received = false;
+        }
+    }
+};
+static std::mutex g_range_mu;            // one file at a time goes down the chain
+static struct { int rank = 0, world = 1; uint64_t slice_bytes = 0; ss_gz_chain_fn fn = nullptr; void *user = nullptr; } g_range;
+
+bool gz_range_active() { return g_range.world > 1 && g_range.fn != nullptr; }
+
+static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd, RangeRun *rr);
+
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd)
+{
+    return gpu_gunzip_impl(in, in_n, text_dev, len, lease, fd, nullptr);
+}
+
+// This rank's slices of the file: *text_dev holds their texts back to back, `pieces` says where each lies, what came down
+// the chain in front of it (the bytes of a record that began in the slice before) and where its last complete record
+// ends.  false: declined (the chain has been served all the same).
+bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **lease, int fd, std::vector<GzPiece> *pieces, bool decline)
+{
+    std::lock_guard<std::mutex> one(g_range_mu);
+    if (!gz_range_active()) return false;
+    RangeRun rr;
+    rr.rank = (uint32_t)g_range.rank; rr.world = (uint32_t)g_range.world; rr.fn = g_range.fn; rr.user = g_range.user;
+    rr.pieces = pieces;
+    rr.inject_decline = decline;
+    uint64_t n = 0;
+    return gpu_gunzip_impl(in, in_n, text_dev, &n, lease, fd, &rr);
+}
+
+static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd, RangeRun *rr)
 {
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     // own stream: the two mates of a paired sample are inflated by two host threads, and the legacy default stream would
@@ -1125,6 +1229,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     };
     auto no = [&](const char *why, long long a = 0) {
         if (trace) fprintf(stderr, "[ginflate] not handled: %s (%lld)\n", why, a);
+        if (rr) rr->abort_chain();                            // (the other ranks' chain goes on through this one)
         g_declined++;
         cleanup(false);
         return false;
@@ -1146,6 +1251,19 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     const uint64_t n_chunks0_ = std::max<uint64_t>(1, (data_n + chunk_bytes - 1) / chunk_bytes);
     if (n_chunks0_ > 0x7FFFFFF0ull) return no("size");
     const uint32_t n_chunks0 = (uint32_t)n_chunks0_;
+    constexpr uint32_t LOOK = 64;                             // search chunks behind a slice in which its last chunk's stop is looked for
+    if (rr) {
+        // the slices, before anything can fail: every rank derives the same ones from the file's size
+        uint64_t slice_bytes = g_range.slice_bytes ? g_range.slice_bytes : std::min<uint64_t>(128ull << 20, std::max<uint64_t>(4ull << 20, data_n / (2ull * rr->world)));
+        if (const char *e = getenv("SS_GZ_SLICE_KB")) slice_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) << 10;      // (tests: many slices)
+        rr->slice_chunks = (uint32_t)std::max<uint64_t>(2 * LOOK, slice_bytes / chunk_bytes);
+        rr->n_slices = (n_chunks0 + rr->slice_chunks - 1) / rr->slice_chunks;
+        for (uint32_t sl = rr->rank; sl < rr->n_slices; sl += rr->world) rr->mine.push_back(sl);
+        if (rr->n_slices < 2) return no("one slice");         // nothing to share out: the whole-file path
+        if (rr->inject_decline) return no("declined on request (test hook)");
+        if (trace) fprintf(stderr, "[ginflate] range mode: rank %u of %u, %u slices of %u chunks, %zu mine\n", rr->rank, rr->world, rr->n_slices,
+                           rr->slice_chunks, rr->mine.size());
+    }
 
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
     static const bool no_pread = getenv("SS_GZ_NO_PREAD") != nullptr;
@@ -1159,11 +1277,13 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
     const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
+    if (rr && !bgzf.empty()) return no("bgzip in range mode");
     uint64_t probe = 512;
     if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
     std::vector<uint64_t> entry(n_chunks0);
     if (bgzf.empty()) {
-        hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe, trace ? 1 : 0);
+        hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe, trace ? 1 : 0,
+                           rr ? rr->slice_chunks : 0u, rr ? rr->rank : 0u, rr ? rr->world : 1u, LOOK);
         GB(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8));
     }
     if (trace && bgzf.empty()) {
@@ -1183,7 +1303,27 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     // at `trailer`.
     struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; };
     std::vector<Chunk> G;
-    if (bgzf.empty()) {
+    struct Seg { size_t gi, gj, n_ph; uint32_t slice; };
+    std::vector<Seg> segs;                                   // range mode: one segment per slice of this rank, its look-ahead entries behind it
+    if (rr) {
+        for (uint32_t sl : rr->mine) {
+            const uint32_t c_lo = sl * rr->slice_chunks, c_hi = std::min<uint32_t>(n_chunks0, c_lo + rr->slice_chunks);
+            Seg sg{G.size(), 0, 0, sl};
+            for (uint32_t c = c_lo; c < c_hi; c++)
+                if (entry[c] != ~0ull) G.push_back(Chunk{entry[c], c == 0, false, 0});
+            sg.gj = G.size();
+            if (sg.gj == sg.gi) return no("slice without a block start", sl);
+            if (sl + 1 < rr->n_slices) {
+                for (uint32_t c = c_hi; c < std::min<uint32_t>(n_chunks0, c_hi + LOOK) && sg.n_ph < 2; c++)
+                    if (entry[c] != ~0ull) { G.push_back(Chunk{entry[c], false, false, 0}); sg.n_ph++; }
+                if (!sg.n_ph) return no("no block start behind the slice", sl);
+            } else {
+                G[sg.gj - 1].last = true;
+                G[sg.gj - 1].trailer = in_n - 8;
+            }
+            segs.push_back(sg);
+        }
+    } else if (bgzf.empty()) {
         for (uint32_t c = 0; c < n_chunks0; c++)
             if (entry[c] != ~0ull) G.push_back(Chunk{entry[c], c == 0, false, 0});
         G.back().last = true;
@@ -1205,12 +1345,13 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         return gj;
     };
     uint64_t need_sym = 0, need_chunks = 0;                   // the largest segment decides the scratch
-    for (size_t gi = 0; gi < G.size();) {
-        const size_t gj = segment_end(gi);
-        const uint64_t bytes = ((gj < G.size() ? G[gj].start : (in_n - 8) * 8) - G[gi].start) / 8;
+    for (size_t gi = 0, si = 0; gi < G.size(); si++) {
+        const size_t gj = rr ? segs[si].gj : segment_end(gi);
+        const bool more = rr ? segs[si].n_ph > 0 : gj < G.size();
+        const uint64_t bytes = ((more ? G[gj].start : (in_n - 8) * 8) - G[gi].start) / 8;
         need_sym = std::max<uint64_t>(need_sym, (bytes + (gj - gi)) * ratio + (gj - gi) * 4096);
         need_chunks = std::max<uint64_t>(need_chunks, gj - gi);
-        gi = gj;
+        gi = rr ? (si + 1 < segs.size() ? segs[si + 1].gi : G.size()) : gj;
     }
     const uint64_t cap_chunks = need_chunks + 80;
     const uint64_t sym_elems = need_sym + need_sym / 4 + 64 * (4096 + 64 * ratio);      // (+ what run-over and further members add)
@@ -1221,6 +1362,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         uint64_t guess = (uint64_t)t8[4] | (uint64_t)t8[5] << 8 | (uint64_t)t8[6] << 16 | (uint64_t)t8[7] << 24;      // ISIZE of the last member
         while (guess < in_n) guess += 1ull << 32;
         text_cap = (guess <= 16 * in_n ? guess : 3 * in_n) + 64;
+        if (rr) text_cap = text_cap / rr->n_slices * rr->mine.size() * 13 / 10 + (1ull << 20);      // this rank's share (it grows when short)
         size_t mem_free = 0, mem_total = 0;
         GI(hipMemGetInfo(&mem_free, &mem_total));
         const uint64_t need = 2 * text_cap + sym_elems * 2 + cap_chunks * WSIZE * 5 + (256ull << 20);
@@ -1248,10 +1390,41 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
     bool have_prev = false, ended = false;
     uint32_t n_segments = 0;
 
+    // CRC-32 of text[at, at + n) (range mode: one piece at a time; the members of the whole-file path are done together below)
+    auto piece_crc = [&](uint64_t at, uint64_t n, uint32_t *out) -> bool {
+        constexpr int LG = 12;
+        const uint64_t sg = 1ull << LG, ns = (n + sg - 1) / sg;
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        if (!ns) { *out = crc; return true; }
+        std::vector<uint64_t> at_v(ns);
+        std::vector<uint32_t> ln_v(ns), tabv(256), got(ns);
+        for (uint64_t i = 0; i < ns; i++) { at_v[i] = at + i * sg; ln_v[i] = (uint32_t)std::min<uint64_t>(sg, n - i * sg); }
+        for (uint32_t i = 0; i < 256; i++) { uint32_t kx = i; for (int j = 0; j < 8; j++) kx = (kx & 1u) ? 0xEDB88320u ^ (kx >> 1) : kx >> 1; tabv[i] = kx; }
+        uint32_t *pt = nullptr, *pc = nullptr;
+        if (hipMallocAsync((void **)&pt, 1024 + ns * 12, st) != hipSuccess) return false;
+        if (hipMallocAsync((void **)&pc, ns * 4, st) != hipSuccess) { hipFreeAsync(pt, st); return false; }
+        uint64_t *p_at = reinterpret_cast<uint64_t *>(pt + 256);
+        uint32_t *p_ln = reinterpret_cast<uint32_t *>(p_at + ns);
+        bool ok = h2d(pt, tabv.data(), 1024) && h2d(p_at, at_v.data(), ns * 8) && h2d(p_ln, ln_v.data(), ns * 4);
+        if (ok) {
+            hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st, d_text, p_at, p_ln, ns, pt, pc);
+            ok = d2h(got.data(), pc, ns * 4);
+        }
+        hipFreeAsync(pt, st);
+        hipFreeAsync(pc, st);
+        if (!ok) return false;
+        uint32_t op[32];
+        crc_zero_operator(op, LG);
+        for (uint64_t i = 0; i < ns; i++) crc = ln_v[i] == sg ? gf2_times(op, crc) ^ got[i] : (uint32_t)crc32_combine(crc, got[i], (z_off_t)ln_v[i]);
+        *out = crc;
+        return true;
+    };
+    size_t seg_i = 0;
     for (size_t gi = 0; gi < G.size();) {
         // ---- the segment's chunks [gi, gj) and up to two look-ahead entries behind them (what a chunk may run over)
-        const size_t gj = segment_end(gi);
-        std::vector<Chunk> ch(G.begin() + (long)gi, G.begin() + (long)gj), ph(G.begin() + (long)gj, G.begin() + (long)std::min(G.size(), gj + 2));
+        const size_t gj = rr ? segs[seg_i].gj : segment_end(gi);
+        const size_t ph_end = rr ? gj + segs[seg_i].n_ph : std::min(G.size(), gj + 2);
+        std::vector<Chunk> ch(G.begin() + (long)gi, G.begin() + (long)gj), ph(G.begin() + (long)gj, G.begin() + (long)ph_end);
         uint32_t nc = (uint32_t)ch.size();
         std::vector<uint64_t> start, stop, off, cap;
         uint64_t sym_total = 0;
@@ -1274,7 +1447,10 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
             }
             for (size_t k = 0; k < ph.size(); k++) {              // look-ahead: only their stops are read
                 start.push_back(ph[k].start);
-                stop.push_back(ph[k].last ? ~0ull : (k + 1 < ph.size() ? ph[k + 1].start : (gj + k + 1 < G.size() ? G[gj + k + 1].start : ~0ull)));
+                // (range mode: what follows the look-ahead entries in G is another slice: a chunk that runs over both of them is
+                //  stopped a few search chunks further on and declined)
+                stop.push_back(ph[k].last ? ~0ull : (k + 1 < ph.size() ? ph[k + 1].start
+                                                     : rr ? ph[k].start + 4 * chunk_bytes * 8 : (gj + k + 1 < G.size() ? G[gj + k + 1].start : ~0ull)));
                 off.push_back(0);
                 cap.push_back(0);
             }
@@ -1424,10 +1600,34 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
                 todo.swap(again);
             }
         }
+        // ---- range mode: what lies in front of this slice comes down the chain now (the symbols are ready: the ranks did that
+        //      part at the same time); the slice must begin exactly where the one before ended
+        const uint32_t my_slice = rr ? segs[seg_i].slice : 0;
+        uint64_t nl_before = 0, len_before = 0;
+        uint32_t crc_before = (uint32_t)crc32(0L, Z_NULL, 0);
+        std::vector<uint8_t> carry_in;
+        if (rr) {
+            if (consumed_ph || ch.size() == 0) return no("range: entries dropped at the slice edge", my_slice);
+            if (my_slice > 0) {
+                if (!rr->recv_for(my_slice)) return no("chain receive", my_slice);
+                if (rr->msg.status < 0) return no("chain: a rank before this one declined", my_slice);
+                if (rr->msg.end_bit != ch[0].start || rr->msg.carry_len > CARRY_MAX) return no("range: the slice before ends elsewhere", my_slice);
+                GB(h2d(A->prev, rr->msg.window, WSIZE));
+                have_prev = true;
+                nl_before = rr->msg.nl; len_before = rr->msg.len; crc_before = rr->msg.crc;
+                carry_in.assign(rr->msg.carry, rr->msg.carry + rr->msg.carry_len);
+            } else {
+                have_prev = false;
+            }
+            for (uint32_t c = 0; c < nc; c++)
+                if ((ch[c].fresh && !(my_slice == 0 && c == 0)) || (ch[c].last && !(my_slice + 1 == rr->n_slices && c + 1 == nc)))
+                    return no("range: several members", my_slice);
+            members.push_back(Member{total, 0, 0, 0, true});              // this slice's text, for the piece's CRC
+        }
         // ---- the segment's text
         std::vector<uint64_t> text_off(nc, 0);
         for (uint32_t c = 0; c < nc; c++) {
-            if (ch[c].fresh) members.push_back(Member{total, 0, 0, 0, true});
+            if (ch[c].fresh && !rr) members.push_back(Member{total, 0, 0, 0, true});
             if (members.empty() || !members.back().open) return no("member start");
             text_off[c] = total;
             total += out_len[c];
@@ -1438,7 +1638,7 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
                 m.crc = (uint32_t)t8[0] | (uint32_t)t8[1] << 8 | (uint32_t)t8[2] << 16 | (uint32_t)t8[3] << 24;
                 m.isize = (uint32_t)t8[4] | (uint32_t)t8[5] << 8 | (uint32_t)t8[6] << 16 | (uint32_t)t8[7] << 24;
                 m.open = false;
-                if ((uint32_t)m.len != m.isize) return no("isize", (long long)members.size());
+                if ((uint32_t)(m.len + len_before) != m.isize) return no("isize", (long long)members.size());      // (range mode: + the slices before)
                 ended = ch[c].trailer == in_n - 8;
             }
         }
@@ -1476,10 +1676,72 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
         }
         have_prev = true;
         n_segments++;
-        gi = gj + consumed_ph;
+        if (rr) {
+            // ---- this slice's piece: CRC, newlines, the bytes behind its last complete record; then the chain goes on
+            const uint64_t p_at = text_off[0], p_len = total - text_off[0];
+            uint32_t p_crc = 0;
+            if (!piece_crc(p_at, p_len, &p_crc)) return no("piece crc", my_slice);
+            const uint32_t crc_now = (uint32_t)crc32_combine(crc_before, p_crc, (z_off_t)p_len);
+            unsigned long long p_nl = 0;
+            GI(hipMemsetAsync(d_entry, 0, 8, st));                   // (the entries are on the host by now: a free device word)
+            hipLaunchKernelGGL(count_nl_kernel, dim3(1024), dim3(256), 0, st, d_text + p_at, p_len, reinterpret_cast<unsigned long long *>(d_entry));
+            GB(d2h(&p_nl, d_entry, 8));
+            const bool final_slice = my_slice + 1 == rr->n_slices;
+            uint64_t keep = p_len;                                   // bytes of the piece up to the end of its last complete record
+            if (!final_slice) {
+                // records end at newlines whose number in the file is a multiple of four: the last such newline of this piece is
+                // among its last four; the tail of the piece is looked at on the host
+                const uint64_t drop = (nl_before + p_nl) % 4;        // newlines behind the last complete record
+                if (p_nl < drop + 1) return no("range: a slice without a complete record", my_slice);
+                const uint64_t tail = std::min<uint64_t>(p_len, (uint64_t)CARRY_MAX + 1);
+                std::vector<uint8_t> tb(tail);
+                GB(d2h(tb.data(), d_text + p_at + (p_len - tail), tail));
+                uint64_t seen = 0, q = tail;
+                while (q > 0) {                                      // q - 1: the newline that ends the last complete record
+                    if (tb[q - 1] == '\n') { if (seen == drop) break; seen++; }
+                    q--;
+                }
+                if (q == 0) return no("range: a record longer than the chain carries", my_slice);
+                keep = p_len - tail + q;
+                rr->msg.status = 0;
+                rr->msg.crc = crc_now;
+                rr->msg.len = len_before + p_len;
+                rr->msg.nl = nl_before + p_nl;
+                rr->msg.end_bit = end_bit[nc - 1];
+                rr->msg.carry_len = (uint32_t)(p_len - keep);
+                memcpy(rr->msg.carry, tb.data() + q, p_len - keep);
+                GB(d2h(rr->msg.window, A->prev, WSIZE));
+                if (!rr->send_from(my_slice)) return no("chain send", my_slice);
+            } else {
+                // the last slice: the whole member's CRC-32 and length against its trailer
+                const Member &m = members.back();
+                if (crc_now != m.crc) return no("crc (range mode)");
+            }
+            rr->pieces->push_back(GzPiece{p_at, p_len, keep, carry_in});
+            rr->duty++;
+            rr->received = false;
+            seg_i++;
+            gi = seg_i < segs.size() ? segs[seg_i].gi : G.size();
+        } else {
+            gi = gj + consumed_ph;
+        }
     }
     lap("inflate + windows + bytes");
     if (trace) fprintf(stderr, "[ginflate] %u segments, %zu members\n", n_segments, members.size());
+    if (rr) {
+        // (every piece was checked as it was made; the owner of the last slice has compared CRC-32 and length with the trailer
+        //  and seen the stream end where the trailer begins)
+        if (!rr->mine.empty() && rr->mine.back() + 1 == rr->n_slices && (!ended || (last_end_bit + 7) / 8 != in_n - 8))
+            return no("stream end (range mode)", (long long)((last_end_bit + 7) / 8));
+        cleanup(true);
+        g_handled++;
+        g_range_files++;
+        g_range_pieces += rr->pieces->size();
+        *text_dev = (char *)d_text;
+        *len = total;
+        *lease = A;
+        return true;
+    }
     // the stream must end where the last trailer begins (after padding to a byte)
     if (!ended || members.empty() || members.back().open || (last_end_bit + 7) / 8 != in_n - 8) return no("stream end", (long long)((last_end_bit + 7) / 8));
     // CRC-32 by segments of 4 KB from every member's first byte, combined on the host with ONE precomputed operator
@@ -1597,5 +1859,20 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
     if (e != hipSuccess) { free(h); return SS_EHIP; }
     *text = h;
     *len = n;
+    return SS_OK;
+}
+
+extern "C" int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_chain_fn chain, void *user)
+{
+    if (world < 1 || rank < 0 || rank >= world) return SS_EINVAL;
+    std::lock_guard<std::mutex> one(ss::g_range_mu);
+    ss::g_range.rank = rank; ss::g_range.world = world; ss::g_range.slice_bytes = slice_bytes; ss::g_range.fn = chain; ss::g_range.user = user;
+    return SS_OK;
+}
+
+extern "C" int ss_gz_range_counters(uint64_t *files, uint64_t *pieces)
+{
+    if (files) *files = ss::g_range_files.load();
+    if (pieces) *pieces = ss::g_range_pieces.load();
     return SS_OK;
 }

@@ -382,6 +382,18 @@ int gz_inputs_on_device(const char *const *paths, int n_paths, int shard_rank, i
         fclose(f);
     }
     if (gz.empty()) return SS_OK;
+    if (gz_range_active() && gz_policy() == 1) {
+        // the ranks share every file's inflation (ss_gz_set_range): one file after the other, in the order of the paths (the
+        // chain of messages between the ranks is per file); a rank keeps all records that begin in its slices
+        int rc = SS_OK;
+        for (int i : gz) {
+            const int r = gz_fastq_pieces_dev(paths[i], [&](char *d, uint64_t len, uint64_t cap, uint64_t nrec) { return flat(i, d, len, cap, nrec); });
+            if (r == 0) done[i] = 1;
+            else if (r == 1) rc = SS_EAGAIN;          // (the chain of the remaining files is still served: every rank goes through all of them)
+            else if (rc == SS_OK) rc = r;
+        }
+        return rc;
+    }
     int device = 0;
     hipGetDevice(&device);
     std::atomic<int> err(SS_OK);

@@ -201,6 +201,32 @@ def scan_files_sharded(kdb, paths, allreduce=True):
     return nrec, nb
 
 
+def _gz_chain(rank, world):
+    """The callback of ss_gz_set_range: direction 1 = send the message to the owner of the next slice, 0 = receive the one
+    for `slice` from the owner of the slice before (slice s belongs to rank s mod world).  Called on the loader's worker
+    thread while this thread waits inside the library.  NCCL moves device tensors, gloo host tensors."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    on_dev = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
+
+    def chain(msg, nbytes, slice_, direction, _user):
+        try:
+            host = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(msg)))
+            if direction == 1:
+                dist.send(host.to(dev) if on_dev else host, (slice_ + 1) % world)
+            else:
+                box = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                dist.recv(box, (slice_ - 1) % world)
+                host.copy_(box.cpu() if on_dev else box)
+            return 0
+        except BaseException:               # noqa: B902 -- the library breaks the chain off and declines
+            return 1
+
+    return _lib.GZ_CHAIN_FN(chain)
+
+
 def _is_gz(p):
     try:
         with open(p, "rb") as f:
@@ -231,6 +257,31 @@ def load_agreed(paths, load, discard=None):
         return int(t.item())
 
     err = None
+    rank, world = rank_world()
+    if os.environ.get("SS_GZ_GPU", "1") != "0" and os.environ.get("SS_GZ_RANGE", "1") != "0":
+        # first: the ranks SHARE every file's inflation (ss_gz_set_range: slices of the deflate data round-robin, a chain of
+        # small point-to-point messages hands each slice what lies in front of it); strict as well -- a rank that cannot take
+        # part serves the chain, reports SS_EAGAIN, and everybody moves on to the next way
+        obj, status = None, 1
+        chain = _gz_chain(rank, world)
+        try:
+            _lib.check(_lib.lib().ss_gz_set_range(rank, world, 0, chain, None), "ss_gz_set_range")
+            with _lib.gz_policy(1):
+                obj = load(paths)
+        except _lib.SSError as e:
+            status, err = (0, None) if e.code == _lib.SS_EAGAIN else (-1, e)
+        except BaseException as e:          # noqa: B902 -- re-raised below, after the other ranks have been told
+            status, err = -1, e
+        finally:
+            _lib.lib().ss_gz_set_range(0, 1, 0, _lib.NO_CHAIN, None)
+        agreed = agree(status)
+        if agreed == 1:
+            return obj
+        if obj is not None and discard is not None:
+            discard(obj)
+        if agreed < 0:
+            raise err if err is not None else RuntimeError("another rank failed while loading the reads")
+        err = None
     if os.environ.get("SS_GZ_GPU", "1") != "0":
         obj, status = None, 1
         try:

@@ -78,23 +78,39 @@ def _share_worker(rank, world, port, gz_path, plain_path, out_dir):
     os.environ["SS_GZ_SHARE"] = "0"
     assert sdist.share_inflated([gz_path])[0] == [gz_path]
     os.environ["SS_GZ_SHARE"] = "1"
-    # load_agreed: every rank loads under the strict policy; if ANY rank was declined (or SS_GZ_GPU=0), all of them load
-    # again from the shared plain text -- no rank keeps what it loaded alone
+    # load_agreed: every rank loads under the strict policy -- first with the file's inflation shared between the ranks
+    # (range mode), then every rank inflating the whole file on its GPU --; if ANY rank was declined, all of them go on to
+    # the next way, at last (or with SS_GZ_GPU=0) to the shared plain text: no rank keeps what it loaded alone
     from strainscan_amd import _lib
     calls = []
 
     def load(paths):
         calls.append(list(paths))
-        if len(calls) == 1 and rank == 1:                          # the first attempt: rank 1's device path declines
+        if len(calls) <= decline_first and rank == 1:              # rank 1's device path declines
             raise _lib.SSError(_lib.SS_EAGAIN, "test")
         return ("loaded", len(calls))
 
     dropped = []
     os.environ["SS_GZ_GPU"] = "1"
+    decline_first = 1                                              # the shared inflation fails on rank 1: whole-file device path for all
     got = sdist.load_agreed([gz_path, plain_path], load, discard=dropped.append)
-    assert got == ("loaded", 2) and calls[0] == [gz_path, plain_path] and calls[1][0] != gz_path and calls[1][1] == plain_path
+    assert got == ("loaded", 2) and calls == [[gz_path, plain_path]] * 2
     assert dropped == ([] if rank == 1 else [("loaded", 1)])       # rank 0 gave up what it had loaded alone
-    assert not os.path.exists(calls[1][0])
+    calls.clear()
+    dropped.clear()
+    decline_first = 2                                              # ... that one too: the host inflaters, one shared inflate
+    got = sdist.load_agreed([gz_path, plain_path], load, discard=dropped.append)
+    assert got == ("loaded", 3) and calls[0] == calls[1] == [gz_path, plain_path] and calls[2][0] != gz_path and calls[2][1] == plain_path
+    assert dropped == ([] if rank == 1 else [("loaded", 1), ("loaded", 2)])
+    dist.barrier()                                                 # (rank 0 removes the shared text behind load_agreed's own barrier)
+    assert not os.path.exists(calls[2][0])
+    calls.clear()
+    os.environ["SS_GZ_RANGE"] = "0"                                # without the shared inflation: two ways left
+    decline_first = 1
+    got = sdist.load_agreed([gz_path, plain_path], load, discard=dropped.append)
+    assert got == ("loaded", 2) and calls[1][0] != gz_path
+    os.environ.pop("SS_GZ_RANGE")
+    decline_first = 0
     calls.clear()
     assert sdist.load_agreed([gz_path], lambda ps: ("ok", list(ps))) == ("ok", [gz_path])        # nobody declined: one attempt
     os.environ["SS_GZ_GPU"] = "0"                                  # host inflaters asked for: shared text at once

@@ -169,22 +169,29 @@ counts = kdb.counts_rows()
 rset = sdist.load_agreed(job["paths"], lambda use: _lib.ReadSet(use, rank, world), discard=lambda r: r.close())
 own = rset.info()["n_records"]
 rset.close()
-a, b = C.c_uint64(), C.c_uint64()
+a, b, rf, rp = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
 _lib.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b))
+_lib.lib().ss_gz_range_counters(C.byref(rf), C.byref(rp))
 np.save(os.path.join(%(out)r, "counts%%d.npy" %% rank), counts)
-json.dump(dict(nrec=int(nrec), own=int(own), handled=int(a.value), declined=int(b.value)), open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w"))
+json.dump(dict(nrec=int(nrec), own=int(own), handled=int(a.value), declined=int(b.value), range_files=int(rf.value), range_pieces=int(rp.value)),
+          open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w"))
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,decline", [(2, False), (3, False), (2, True), (3, True)])
-def test_sharded_scan_of_gz_pair_on_the_device(world, decline, tmp_path):
-    """A pair of .fastq.gz files under torch.distributed: every rank inflates both files on the GPU and keeps its blocks
-    of 4096 records (ss_fastq_dev.hip), nothing goes through /dev/shm; the summed row counts equal the single-process
-    scan of the plain text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
-    `decline`: the device path of rank 1 alone declines (test hook) -- dist.load_agreed must move ALL ranks to the host
-    inflaters (one inflate into /dev/shm, parse chunks shared out), or reads would be counted twice or not at all."""
+@pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"),
+                                                  (2, True, "range"), (3, True, "range")])
+def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
+    """A pair of .fastq.gz files under torch.distributed; the summed row counts equal the single-process scan of the plain
+    text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
+    `range`: the ranks SHARE every file's inflation (ss_gz_set_range: slices of the deflate data -- SS_GZ_SLICE_KB makes
+    them small here -- a chain of messages for the windows, newline counts and straddling records, CRC-32 down the chain).
+    `whole` (SS_GZ_RANGE=0): every rank inflates both files on its GPU and keeps its blocks of 4096 records.
+    `members`: one file is two members joined with cat -- the shared inflation declines it (all ranks), the whole-file
+    path takes it.  `decline`: the device path of rank 1 alone declines (test hook: it still serves the chain) --
+    dist.load_agreed must move ALL ranks on, in the end to the host inflaters (one inflate into /dev/shm, parse chunks
+    shared out), or reads would be counted twice or not at all."""
     import gzip
     import socket
     from strainscan_amd import _lib as L
@@ -205,7 +212,11 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, tmp_path):
     plain.write_bytes(b"".join(fq))
     p1, p2 = tmp_path / "s_1.fq.gz", tmp_path / "s_2.fq.gz"
     p1.write_bytes(gzip.compress(b"".join(fq[:half]), 6))
-    p2.write_bytes(gzip.compress(b"".join(fq[half:]), 6))
+    if mode == "members":
+        q = half + (n - half) // 3
+        p2.write_bytes(gzip.compress(b"".join(fq[half:q]), 6) + gzip.compress(b"".join(fq[q:]), 1))
+    else:
+        p2.write_bytes(gzip.compress(b"".join(fq[half:]), 6))
     assert min(p1.stat().st_size, p2.stat().st_size) > (1 << 20)
     db = L.KmerDB.from_text(kfa, 31, True)
     db.scan_files([str(plain)])
@@ -222,17 +233,30 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, tmp_path):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.pop("SS_GZ_GPU", None)
+        env["SS_GZ_SLICE_KB"] = "256"
+        env["SS_GZ_CHUNK"] = "4096"          # (search chunks of 4 KB: slices of 128 of them, three or so per file)
+        if mode == "whole":
+            env["SS_GZ_RANGE"] = "0"
         if decline and r == 1:
             env["SS_GZ_INJECT_DECLINE"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
-    errs = [p.communicate(timeout=600)[1].decode()[-2000:] for p in procs]
+    errs = [p.communicate(timeout=600)[1].decode()[-6000:] for p in procs]
     assert all(p.returncode == 0 for p in procs), errs
+    if os.environ.get("SS_INGEST_TRACE"):
+        print("\n".join("rank %d:\n%s" % (r, e) for r, e in enumerate(errs)))
     infos = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("counts%d.npy" % r)), want), r          # the global counts, on every rank
-        if not decline:
-            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0                  # two files, scanned and loaded
-        else:       # the ranks that were not declined did inflate on the device, and gave that up
-            assert infos[r]["handled"] == (0 if r == 1 else 4)
+        if not decline and mode == "range":      # two files, scanned and loaded, both times shared between the ranks
+            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4 and infos[r]["range_pieces"] >= 4
+        elif not decline and mode == "whole":
+            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 0
+        elif not decline:                        # members: the first file shared, the second (two members) declined there and taken whole
+            assert infos[r]["range_files"] == 2 and infos[r]["handled"] == 6 and infos[r]["declined"] == 2
+        else:       # the ranks that were not declined did inflate on the device (a rank whose slices all lie in front of
+            #             rank 1's even finished its share of the shared inflation), and gave that up
+            assert infos[r]["handled"] == 0 if r == 1 else infos[r]["handled"] >= 4
     assert sum(i["nrec"] for i in infos) == n and sum(i["own"] for i in infos) == n
     assert decline or all(i["nrec"] > 0 for i in infos)      # (parse chunks are 24 MB: these small files are one chunk each)
+    if mode == "range" and not decline:                      # every rank inflated about its share, not everything
+        assert max(i["own"] for i in infos) < 0.75 * n
