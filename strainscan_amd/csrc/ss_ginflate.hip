@@ -1258,6 +1258,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         if (const char *e = getenv("SS_GZ_SLICE_KB")) slice_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) << 10;      // (tests: many slices)
         rr->slice_chunks = (uint32_t)std::max<uint64_t>(2 * LOOK, slice_bytes / chunk_bytes);
         rr->n_slices = (n_chunks0 + rr->slice_chunks - 1) / rr->slice_chunks;
+        rr->slice_chunks = (n_chunks0 + rr->n_slices - 1) / rr->n_slices;      // equal slices (no sliver at the end)
+        rr->n_slices = (n_chunks0 + rr->slice_chunks - 1) / rr->slice_chunks;
         for (uint32_t sl = rr->rank; sl < rr->n_slices; sl += rr->world) rr->mine.push_back(sl);
         if (rr->n_slices < 2) return no("one slice");         // nothing to share out: the whole-file path
         if (rr->inject_decline) return no("declined on request (test hook)");

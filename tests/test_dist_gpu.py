@@ -181,7 +181,7 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"),
-                                                  (2, True, "range"), (3, True, "range")])
+                                                  (2, True, "range"), (3, True, "range"), (2, False, "entry100"), (2, False, "entry128"), (3, False, "entry129")])
 def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     """A pair of .fastq.gz files under torch.distributed; the summed row counts equal the single-process scan of the plain
     text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
@@ -191,7 +191,9 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     `members`: one file is two members joined with cat -- the shared inflation declines it (all ranks), the whole-file
     path takes it.  `decline`: the device path of rank 1 alone declines (test hook: it still serves the chain) --
     dist.load_agreed must move ALL ranks on, in the end to the host inflaters (one inflate into /dev/shm, parse chunks
-    shared out), or reads would be counted twice or not at all."""
+    shared out), or reads would be counted twice or not at all.  `entryN`: a wrong entry point (a position inside a
+    block, test hook) in search chunk N -- inside a slice the chunk in front of it runs over it as in the whole-file path;
+    at a slice's edge (128 = the first chunk of slice 1) the slices no longer meet and the shared inflation is declined."""
     import gzip
     import socket
     from strainscan_amd import _lib as L
@@ -237,6 +239,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
         env["SS_GZ_CHUNK"] = "4096"          # (search chunks of 4 KB: slices of 128 of them, three or so per file)
         if mode == "whole":
             env["SS_GZ_RANGE"] = "0"
+        if mode.startswith("entry"):
+            env["SS_GZ_INJECT_ENTRY"] = mode[5:]
         if decline and r == 1:
             env["SS_GZ_INJECT_DECLINE"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
@@ -251,12 +255,14 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4 and infos[r]["range_pieces"] >= 4
         elif not decline and mode == "whole":
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 0
-        elif not decline:                        # members: the first file shared, the second (two members) declined there and taken whole
+        elif mode == "members":                  # the first file shared, the second (two members) declined there and taken whole
             assert infos[r]["range_files"] == 2 and infos[r]["handled"] == 6 and infos[r]["declined"] == 2
-        else:       # the ranks that were not declined did inflate on the device (a rank whose slices all lie in front of
+        elif decline:   # the ranks that were not declined did inflate on the device (a rank whose slices all lie in front of
             #             rank 1's even finished its share of the shared inflation), and gave that up
             assert infos[r]["handled"] == 0 if r == 1 else infos[r]["handled"] >= 4
     assert sum(i["nrec"] for i in infos) == n and sum(i["own"] for i in infos) == n
     assert decline or all(i["nrec"] > 0 for i in infos)      # (parse chunks are 24 MB: these small files are one chunk each)
+    if mode == "entry100":                                   # run over inside a slice: still shared
+        assert all(i["range_files"] == 4 for i in infos)
     if mode == "range" and not decline:                      # every rank inflated about its share, not everything
         assert max(i["own"] for i in infos) < 0.75 * n
