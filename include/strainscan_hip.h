@@ -127,6 +127,12 @@ int ss_revcomp_dev(const char *in_dev, char *out_dev, uint64_t seq_len, uint64_t
  * SS_ROW_VALID and its 2-bit key; other rows get flags 0.
  * ------------------------------------------------------------------------------------------ */
 int ss_kmerfa_count_rows(const char *path, uint64_t *n_rows);
+/* <Tree_database>/kmers/<id> (one line of 0-based row numbers of kmer.fa each, Build_tree.py:686-698; read by match_node,
+ * identify.py:116-118) for all listed ids, on the host's threads.  rows == NULL: counts[i] = row numbers of file i; else they are
+ * written to rows + offsets[i] (counts from the first call are checked).  A token that is not a decimal number below n_rows:
+ * SS_EINVAL, *bad = index of the first such file.  Host only. */
+int ss_node_lists_parse(const char *kmers_dir, const long long *ids, uint32_t n_ids, uint64_t n_rows, uint64_t *counts,
+                        const uint64_t *offsets, uint32_t *rows, uint32_t *bad);
 int ss_kmerfa_encode(const char *path, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags, int threads);
 /* same on an in-memory text */
 int ss_kmerfa_encode_mem(const char *text, uint64_t len, int k, uint64_t n_rows, uint64_t *keys, uint8_t *flags);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "ss_host_cpus": (i32, []),
     "ss_revcomp_dev": (i32, [vp, vp, u64, u64, vp]),
     "ss_kmerfa_count_rows": (i32, [cp, P(u64)]),
+    "ss_node_lists_parse": (i32, [cp, vp, C.c_uint32, u64, vp, vp, vp, P(C.c_uint32)]),
     "ss_kmerfa_encode": (i32, [cp, i32, u64, vp, vp, i32]),
     "ss_kmerfa_encode_mem": (i32, [cp, u64, i32, u64, vp, vp]),
     "ss_encode_kmer": (i32, [cp, i32, P(u64)]),

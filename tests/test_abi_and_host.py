@@ -414,6 +414,36 @@ def test_tree_cache_writers_do_not_collide(l1_dbs, tmp_path, monkeypatch):
     assert np.array_equal(again.keys, t3.keys) and np.array_equal(again.rows, t3.rows)
 
 
+def test_node_lists_native_parser_equals_numpy(tmp_path, monkeypatch):
+    """kmers/<id> through ss_node_lists_parse (host threads) and through the numpy loop: same rows, offsets and de-duplicated
+    forms -- ascending lists, a list with repeats and disorder, an empty file, tabs and trailing blanks, a second line that
+    must be ignored (identify.py:116-118 reads one line); a row outside kmer.fa, a negative number or a word are left to
+    the numpy loop, which raises."""
+    from strainscan_amd import db as sdb
+    kd = tmp_path / "kmers"
+    kd.mkdir()
+    rs = np.random.RandomState(3)
+    lists = {1: np.sort(rs.choice(5000, 700, replace=False)), 2: rs.randint(0, 5000, 300), 3: np.zeros(0, np.int64), 7: np.arange(10, 20),
+             12: np.array([4999, 0, 4999])}
+    for i, r in lists.items():
+        sep = "\t" if i == 7 else " "
+        (kd / str(i)).write_text(sep.join(map(str, r.tolist())) + (" " if r.size else "") + ("\n999999 x\n" if i == 2 else ""))
+    ids = sorted(lists)
+    a = sdb._node_lists_native(str(kd), ids, 5000)
+    assert a is not None
+    monkeypatch.setattr(sdb, "_node_lists_native", lambda *args: None)
+    b = sdb._node_lists(str(tmp_path), ids, 5000)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y) and x.dtype == y.dtype
+    assert a[0][a[1][1]:a[1][2]].tolist() == lists[2].tolist()
+    monkeypatch.undo()
+    for bad in ("5000", "-3", "12 abc"):
+        (kd / "7").write_text("1 2 " + bad + " ")
+        assert sdb._node_lists_native(str(kd), ids, 5000) is None
+        with pytest.raises(ValueError):
+            sdb._node_lists(str(tmp_path), ids, 5000)
+
+
 def test_plain_pickles_admit_no_globals(tmp_path):
     """id2strain_re.pkl is a list of names (Recls_withR_new.py:114-115): read without admitting any global."""
     import pickle
