@@ -1270,9 +1270,22 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
     static const bool no_pread = getenv("SS_GZ_NO_PREAD") != nullptr;
     bool uploaded = false;
-    if (fd >= 0 && in_n >= (256ull << 20) && !no_pread) {    // (`fd`: the same file; smaller ones are there before the buffers are)
+    if (fd >= 0 && in_n >= (256ull << 20) && !no_pread && !rr) {    // (`fd`: the same file; smaller ones are there before the buffers are)
         GI(hipStreamSynchronize(st));                         // the allocation is stream-ordered
         uploaded = upload_file(fd, in_n, d_in);
+    }
+    if (!uploaded && rr) {
+        // range mode: only this rank's slices travel (+ the search chunks behind each in which its last chunk stops, + the
+        // header and the trailer); the rest of the image is never read
+        const uint64_t margin = 64 << 10;
+        auto part = [&](uint64_t lo, uint64_t hi) { hi = std::min(hi, in_n); return lo >= hi || h2d(d_in + lo, in + lo, hi - lo); };
+        GB(part(0, data_off + margin));
+        GB(part(in_n > margin ? in_n - margin : 0, in_n));
+        for (uint32_t sl : rr->mine) {
+            const uint64_t lo = data_off + (uint64_t)sl * rr->slice_chunks * chunk_bytes, hi = lo + ((uint64_t)rr->slice_chunks + LOOK + 8) * chunk_bytes;
+            GB(part(lo > margin ? lo - margin : 0, hi + margin));
+        }
+        uploaded = true;
     }
     if (!uploaded) GB(h2d(d_in, in, in_n));
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
