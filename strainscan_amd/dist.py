@@ -213,6 +213,8 @@ def _gz_chain(rank, world):
 
     def chain(msg, nbytes, slice_, direction, _user):
         try:
+            if on_dev:
+                torch.cuda.set_device(dev)          # (the current device is a property of the thread: this is the loader's)
             host = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(msg)))
             if direction == 1:
                 dist.send(host.to(dev) if on_dev else host, (slice_ + 1) % world)
@@ -225,6 +227,36 @@ def _gz_chain(rank, world):
             return 1
 
     return _lib.GZ_CHAIN_FN(chain)
+
+
+_P2P_OK = {}
+
+
+def _p2p_works():
+    """Point-to-point traffic between neighbouring ranks, tried ONCE per process group before the first shared inflation
+    (a ring: every rank sends a word to the next and receives one from the one before; the outcomes are MIN-all-reduced):
+    range mode's chain hangs where send / recv do not work, so it is only used where they have been seen to."""
+    import torch
+    import torch.distributed as dist
+    key = (dist.get_backend(), dist.get_world_size(), dist.get_rank())
+    if key not in _P2P_OK:
+        rank, world = dist.get_rank(), dist.get_world_size()
+        on_dev = dist.get_backend() == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
+        ok = 1
+        try:
+            out = torch.full((1,), rank, dtype=torch.int32, device=dev)
+            box = torch.empty(1, dtype=torch.int32, device=dev)
+            reqs = [dist.isend(out, (rank + 1) % world), dist.irecv(box, (rank - 1) % world)]
+            for r in reqs:
+                r.wait()
+            ok = int(int(box.item()) == (rank - 1) % world)
+        except BaseException:               # noqa: B902
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        _P2P_OK[key] = bool(int(t.item()))
+    return _P2P_OK[key]
 
 
 def _is_gz(p):
@@ -258,7 +290,7 @@ def load_agreed(paths, load, discard=None):
 
     err = None
     rank, world = rank_world()
-    if os.environ.get("SS_GZ_GPU", "1") != "0" and os.environ.get("SS_GZ_RANGE", "1") != "0":
+    if os.environ.get("SS_GZ_GPU", "1") != "0" and os.environ.get("SS_GZ_RANGE", "1") != "0" and _p2p_works():
         # first: the ranks SHARE every file's inflation (ss_gz_set_range: slices of the deflate data round-robin, a chain of
         # small point-to-point messages hands each slice what lies in front of it); strict as well -- a rank that cannot take
         # part serves the chain, reports SS_EAGAIN, and everybody moves on to the next way
