@@ -69,7 +69,13 @@ def _trace(*a):
 
 def _identify(fq_path, db_dir, cutoff, params, upper_keys):
     start = time.time()
-    img = tree_image(db_dir, upper_keys)
+    from .db import prefetch_reads
+    pre = prefetch_reads(_paths(fq_path))         # the reads load while the database image does
+    try:
+        img = tree_image(db_dir, upper_keys)
+    finally:
+        if pre is not None:
+            pre.join()
     if not img.is_external:
         img.scan(_paths(fq_path))
     walk = cst.Walk(cst.ImageProvider(img), db_dir, cutoff, params, out=_trace)

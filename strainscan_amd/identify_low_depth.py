@@ -44,7 +44,13 @@ def rank_paths(tree, frac):
 def identify_ranks(fq_path, db_dir):
     start = time.time()
     tree, _ = read_tree_structure(db_dir)
-    img = tree_image(db_dir, _UPPER_KEYS)
+    from .db import prefetch_reads
+    pre = prefetch_reads(_id._paths(fq_path))     # the reads load while the database image does
+    try:
+        img = tree_image(db_dir, _UPPER_KEYS)
+    finally:
+        if pre is not None:
+            pre.join()
     if not img.is_external:
         img.scan(_id._paths(fq_path))
     st = img.node_stats()
