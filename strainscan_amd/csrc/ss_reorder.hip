@@ -319,25 +319,93 @@ __device__ __forceinline__ void copy_round(const char *__restrict__ b, uint64_t 
     }
 }
 
-// the usual tile: everything is in the table
+// one piece: the record's bytes from `v`, '\n' behind its end, stored aligned (slots are multiples of 8 bytes)
+__device__ __forceinline__ void store_piece(char *__restrict__ dst, uint64_t out, uint4 v, uint32_t rlen, uint32_t rslot, uint32_t c)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const int keep = (int)min(16u, rlen > c ? rlen - c : 0u);              // record bytes in this piece
+    if (keep < 16) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int k = keep - 4 * d;
+            if (k <= 0) w[d] = 0x0A0A0A0Au;
+            else if (k < 4) { const uint32_t m = (1u << (8 * k)) - 1u; w[d] = (w[d] & m) | (0x0A0A0A0Au & ~m); }
+        }
+    }
+    char *o8 = static_cast<char *>(__builtin_assume_aligned(dst + out, 8));
+    if (c + 16 <= rslot) __builtin_memcpy(o8, w, 16);
+    else __builtin_memcpy(o8, w, 8);
+}
+
+// the usual tile: everything is in the table.  The chain of dependent round trips is what bounds this pass, so it is kept
+// short: table entries and count together; the returning atomics that claim the slots are ISSUED, and while they are on
+// their way every lane finds its pieces (up to PRE of them: ~1100 pieces per tile of 150-base reads over 256 lanes) and
+// loads their bytes -- neither needs the destination; only the stores wait for it.
+constexpr int PRE = 6;
 __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void place_kernel(
     const char *__restrict__ b, uint64_t n, unsigned long long *__restrict__ cursor, const uint32_t *__restrict__ tab_cnt,
     const unsigned long long *__restrict__ tab, char *__restrict__ dst)
 {
     __shared__ TileLds L;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     static_assert(TCAP <= 256, "one table entry per thread");
     const unsigned long long e = t < TCAP ? tab[(uint64_t)blockIdx.x * TCAP + t] : 0ull;     // (in flight together with the count)
     const uint32_t known = tab_cnt[blockIdx.x];
     if (known == T_OVERFLOW || known == 0) return;
+    uint64_t d0 = 0;
+    uint32_t pieces = 0;
     if ((uint32_t)t < known) {
         const uint32_t len = (uint32_t)(e >> START_BITS) & (LEN_LIMIT - 1u);
         L.src[t] = (uint64_t)blockIdx.x * RB + (uint32_t)(e & (uint32_t)(RB - 1));
         L.len[t] = len;
-        L.dst[t] = atomicAdd(&cursor[(uint32_t)(e >> (START_BITS + LEN_BITS))], (unsigned long long)slot_of(len));
+        d0 = atomicAdd(&cursor[(uint32_t)(e >> (START_BITS + LEN_BITS))], (unsigned long long)slot_of(len));      // (answer needed at the stores)
+        pieces = (slot_of(len) + 15u) >> 4;
     }
+    uint32_t pend = wave_incl_sum(pieces, lane);
+    if (lane == 63) L.wcnt[wave] = pend;
     __syncthreads();
-    copy_round(b, n, dst, L, known);
+    uint32_t total = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t c = L.wcnt[w]; if (w < wave) pend += c; total += c; }
+    if ((uint32_t)t < known) L.pend[t] = pend;
+    __syncthreads();
+    uint4 v[PRE];
+    uint32_t rec[PRE], off[PRE];
+#pragma unroll
+    for (int r = 0; r < PRE; r++) {
+        const uint32_t p = (uint32_t)t + 256u * r;
+        rec[r] = 0; off[r] = 0;
+        v[r] = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+        if (p < total) {
+            int lo = 0, hi = (int)known - 1;                               // first record whose inclusive piece count exceeds p
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (L.pend[mid] <= p) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t rlen = L.len[lo], c = (p - (L.pend[lo] - ((slot_of(rlen) + 15u) >> 4))) * 16u;
+            rec[r] = (uint32_t)lo; off[r] = c;
+            if (rlen > c) v[r] = load16_nl(b, L.src[lo] + c, n);
+        }
+    }
+    if ((uint32_t)t < known) L.dst[t] = d0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PRE; r++) {
+        const uint32_t p = (uint32_t)t + 256u * r;
+        if (p < total) {
+            const uint32_t rlen = L.len[rec[r]];
+            store_piece(dst, L.dst[rec[r]] + off[r], v[r], rlen, slot_of(rlen), off[r]);
+        }
+    }
+    for (uint32_t p = (uint32_t)t + 256u * PRE; p < total; p += 256) {    // long records: the rest, piece by piece
+        int lo = 0, hi = (int)known - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (L.pend[mid] <= p) lo = mid + 1; else hi = mid;
+        }
+        const uint32_t rlen = L.len[lo], rslot = slot_of(rlen), c = (p - (L.pend[lo] - ((rslot + 15u) >> 4))) * 16u;
+        const uint4 x = rlen > c ? load16_nl(b, L.src[lo] + c, n) : make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+        store_piece(dst, L.dst[lo] + c, x, rlen, rslot, c);
+    }
 }
 
 // a tile whose records did not fit the table (short reads, several record starts in one lane's chunk): found and keyed again
@@ -499,7 +567,10 @@ int reads_order_for_locality(ss_reads *R, bool force)
     if (!force && !reads_order_wanted()) return SS_OK;
     uint64_t bytes = 0;
     for (auto &sl : R->slabs) {
-        if (sl.used >= 64) {
+        size_t mem_free = 0, mem_total = 0;
+        // (the binned copy lives beside the slab until it replaces it: a slab that leaves no room for that stays in file order)
+        const bool room = hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free > sl.used + sl.used / 8 + (1ull << 30);
+        if (sl.used >= 64 && (room || force)) {
             char *d = nullptr;
             uint64_t used = 0, cap = 0;
             const int rc = order_flat_dev(sl.d, sl.used, &d, &used, &cap);
