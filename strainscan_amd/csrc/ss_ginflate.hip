@@ -916,11 +916,25 @@ uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
     for (int i = 0; vec; vec >>= 1, i++) if (vec & 1u) sum ^= mat[i];
     return sum;
 }
-// newlines of text[0, n)
+// newlines of text[0, n): 16 bytes per lane and step (SWAR zero-byte test on w ^ 0x0A0A0A0A), the ragged ends byte by byte
 __global__ __launch_bounds__(256) void count_nl_kernel(const uint8_t *text, uint64_t n, unsigned long long *out)
 {
     unsigned long long c = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) c += text[i] == '\n' ? 1u : 0u;
+    const uint64_t head = std::min<uint64_t>(n, (16 - ((uintptr_t)text & 15)) & 15), body = (n - head) / 16;
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(text + head);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < body; i += (uint64_t)gridDim.x * 256) {
+        const uint4 v = t4[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t x = w[d] ^ 0x0A0A0A0Au;
+            c += (unsigned)__popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u);
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t i = threadIdx.x; i < head; i += 256) c += text[i] == '\n' ? 1u : 0u;
+        for (uint64_t i = head + body * 16 + threadIdx.x; i < n; i += 256) c += text[i] == '\n' ? 1u : 0u;
+    }
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
@@ -1695,6 +1709,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             // ---- this slice's piece: CRC, newlines, the bytes behind its last complete record; then the chain goes on
             const uint64_t p_at = text_off[0], p_len = total - text_off[0];
             uint32_t p_crc = 0;
+            if (p_len < WSIZE && my_slice + 1 < rr->n_slices) return no("range: a slice with less text than a window", my_slice);      // (the window it hands on would reach into another piece)
             if (!piece_crc(p_at, p_len, &p_crc)) return no("piece crc", my_slice);
             const uint32_t crc_now = (uint32_t)crc32_combine(crc_before, p_crc, (z_off_t)p_len);
             unsigned long long p_nl = 0;

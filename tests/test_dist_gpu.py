@@ -252,7 +252,7 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("counts%d.npy" % r)), want), r          # the global counts, on every rank
         if not decline and mode == "range":      # two files, scanned and loaded, both times shared between the ranks
-            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4 and infos[r]["range_pieces"] >= 4
+            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4 and infos[r]["range_pieces"] >= 4, (infos, errs)
         elif not decline and mode == "whole":
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 0
         elif mode == "members":                  # the first file shared, the second (two members) declined there and taken whole
