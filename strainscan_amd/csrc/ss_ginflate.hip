@@ -1142,8 +1142,9 @@ void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
 //     crc, len   CRC-32 and length of the text so far (the owner of the last slice checks them against the trailer)
 //     status     < 0: somebody declined -- passed on to the end of the chain, everybody declines
 // A rank that fails at any point still takes part in the chain for all its slices (receives, passes the bad news on), so
-// nobody waits for a message that never comes.  One member only (several members, bgzip: declined here, the whole-file
-// path takes them).
+// nobody waits for a message that never comes.  Several members (lanes joined with cat) are followed inside the slices as in
+// the whole-file path -- a member that ends in a slice is checked against its trailer by the slice's owner, crc / len
+// always describe the member that is open at the cut; bgzip is declined here (the whole-file path takes it).
 constexpr uint32_t CARRY_MAX = 65536;
 struct ChainMsg {
     int32_t status;
@@ -1413,7 +1414,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     uint64_t *d_start = A->meta, *d_stop = A->meta + cap_chunks, *d_off = A->meta + 2ull * cap_chunks, *d_cap = A->meta + 3ull * cap_chunks,
              *d_len = A->meta + 4ull * cap_chunks, *d_end = A->meta + 5ull * cap_chunks, *d_toff = A->meta + 6ull * cap_chunks;
     const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : 2u;      // (test hook: wrong entries are then handled by the host only)
-    struct Member { uint64_t at, len; uint32_t crc, isize; bool open; };
+    struct Member { uint64_t at, len; uint32_t crc, isize; bool open; uint32_t crc0; uint64_t len0; };      // crc0, len0: range mode -- the member's part in the slices before
     std::vector<Member> members;
     uint64_t total = 0, last_end_bit = 0;
     bool have_prev = false, ended = false;
@@ -1648,15 +1649,16 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             } else {
                 have_prev = false;
             }
-            for (uint32_t c = 0; c < nc; c++)
-                if ((ch[c].fresh && !(my_slice == 0 && c == 0)) || (ch[c].last && !(my_slice + 1 == rr->n_slices && c + 1 == nc)))
-                    return no("range: several members", my_slice);
-            members.push_back(Member{total, 0, 0, 0, true});              // this slice's text, for the piece's CRC
+            // the member that is open at the cut goes on in this slice (several members -- lanes joined with cat -- are followed
+            // as in the whole-file path: a member that ends inside the slice is checked against its trailer here, the next one
+            // starts with nothing in front of it; CRC-32 and length of the open member travel down the chain)
+            if (!ch[0].fresh) members.push_back(Member{total, 0, 0, 0, true, crc_before, len_before});
         }
+        const size_t m_first = members.empty() ? 0 : members.size() - ((rr && !ch[0].fresh) ? 1 : 0);      // members of this segment: [m_first, ...)
         // ---- the segment's text
         std::vector<uint64_t> text_off(nc, 0);
         for (uint32_t c = 0; c < nc; c++) {
-            if (ch[c].fresh && !rr) members.push_back(Member{total, 0, 0, 0, true});
+            if (ch[c].fresh) members.push_back(Member{total, 0, 0, 0, true, (uint32_t)crc32(0L, Z_NULL, 0), 0});
             if (members.empty() || !members.back().open) return no("member start");
             text_off[c] = total;
             total += out_len[c];
@@ -1667,7 +1669,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                 m.crc = (uint32_t)t8[0] | (uint32_t)t8[1] << 8 | (uint32_t)t8[2] << 16 | (uint32_t)t8[3] << 24;
                 m.isize = (uint32_t)t8[4] | (uint32_t)t8[5] << 8 | (uint32_t)t8[6] << 16 | (uint32_t)t8[7] << 24;
                 m.open = false;
-                if ((uint32_t)(m.len + len_before) != m.isize) return no("isize", (long long)members.size());      // (range mode: + the slices before)
+                if ((uint32_t)(m.len + m.len0) != m.isize) return no("isize", (long long)members.size());      // (range mode: + its part in the slices before)
                 ended = ch[c].trailer == in_n - 8;
             }
         }
@@ -1708,10 +1710,19 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         if (rr) {
             // ---- this slice's piece: CRC, newlines, the bytes behind its last complete record; then the chain goes on
             const uint64_t p_at = text_off[0], p_len = total - text_off[0];
-            uint32_t p_crc = 0;
             if (p_len < WSIZE && my_slice + 1 < rr->n_slices) return no("range: a slice with less text than a window", my_slice);      // (the window it hands on would reach into another piece)
-            if (!piece_crc(p_at, p_len, &p_crc)) return no("piece crc", my_slice);
-            const uint32_t crc_now = (uint32_t)crc32_combine(crc_before, p_crc, (z_off_t)p_len);
+            // CRC-32 of every member's part in this slice: a member that ended here against its trailer, the open one goes on
+            uint32_t crc_now = (uint32_t)crc32(0L, Z_NULL, 0);
+            uint64_t len_now = 0;
+            for (size_t mi = m_first; mi < members.size(); mi++) {
+                const Member &m = members[mi];
+                uint32_t p_crc = 0;
+                if (!piece_crc(m.at, m.len, &p_crc)) return no("piece crc", my_slice);
+                const uint32_t c = m.len ? (uint32_t)crc32_combine(m.crc0, p_crc, (z_off_t)m.len) : m.crc0;
+                if (!m.open) { if (c != m.crc) return no("crc (range mode)", (long long)mi); }
+                else if (mi + 1 == members.size()) { crc_now = c; len_now = m.len0 + m.len; }
+                else return no("member left open", (long long)mi);
+            }
             unsigned long long p_nl = 0;
             GI(hipMemsetAsync(d_entry, 0, 8, st));                   // (the entries are on the host by now: a free device word)
             hipLaunchKernelGGL(count_nl_kernel, dim3(1024), dim3(256), 0, st, d_text + p_at, p_len, reinterpret_cast<unsigned long long *>(d_entry));
@@ -1735,17 +1746,15 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                 keep = p_len - tail + q;
                 rr->msg.status = 0;
                 rr->msg.crc = crc_now;
-                rr->msg.len = len_before + p_len;
+                rr->msg.len = len_now;
                 rr->msg.nl = nl_before + p_nl;
                 rr->msg.end_bit = end_bit[nc - 1];
                 rr->msg.carry_len = (uint32_t)(p_len - keep);
                 memcpy(rr->msg.carry, tb.data() + q, p_len - keep);
                 GB(d2h(rr->msg.window, A->prev, WSIZE));
                 if (!rr->send_from(my_slice)) return no("chain send", my_slice);
-            } else {
-                // the last slice: the whole member's CRC-32 and length against its trailer
-                const Member &m = members.back();
-                if (crc_now != m.crc) return no("crc (range mode)");
+            } else if (members.empty() || members.back().open) {
+                return no("the last member is not closed (range mode)");     // (every closed member was checked against its trailer above)
             }
             rr->pieces->push_back(GzPiece{p_at, p_len, keep, carry_in});
             rr->duty++;

@@ -180,7 +180,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"),
+@pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"), (2, False, "members"),
                                                   (2, True, "range"), (3, True, "range"), (2, False, "entry100"), (2, False, "entry128"), (3, False, "entry129")])
 def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     """A pair of .fastq.gz files under torch.distributed; the summed row counts equal the single-process scan of the plain
@@ -188,8 +188,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     `range`: the ranks SHARE every file's inflation (ss_gz_set_range: slices of the deflate data -- SS_GZ_SLICE_KB makes
     them small here -- a chain of messages for the windows, newline counts and straddling records, CRC-32 down the chain).
     `whole` (SS_GZ_RANGE=0): every rank inflates both files on its GPU and keeps its blocks of 4096 records.
-    `members`: one file is two members joined with cat -- the shared inflation declines it (all ranks), the whole-file
-    path takes it.  `decline`: the device path of rank 1 alone declines (test hook: it still serves the chain) --
+    `members`: one file is two members joined with cat -- the member that ends inside a slice is checked against its
+    trailer there, the next starts with nothing in front of it, CRC-32 and length of the open member travel down the chain.  `decline`: the device path of rank 1 alone declines (test hook: it still serves the chain) --
     dist.load_agreed must move ALL ranks on, in the end to the host inflaters (one inflate into /dev/shm, parse chunks
     shared out), or reads would be counted twice or not at all.  `entryN`: a wrong entry point (a position inside a
     block, test hook) in search chunk N -- inside a slice the chunk in front of it runs over it as in the whole-file path;
@@ -255,8 +255,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4 and infos[r]["range_pieces"] >= 4, (infos, errs)
         elif not decline and mode == "whole":
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 0
-        elif mode == "members":                  # the first file shared, the second (two members) declined there and taken whole
-            assert infos[r]["range_files"] == 2 and infos[r]["handled"] == 6 and infos[r]["declined"] == 2
+        elif mode == "members":                  # the second file is two members: followed inside the slices like one
+            assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4, (infos, errs)
         elif decline:   # the ranks that were not declined did inflate on the device (a rank whose slices all lie in front of
             #             rank 1's even finished its share of the shared inflation), and gave that up
             assert infos[r]["handled"] == 0 if r == 1 else infos[r]["handled"] >= 4
