@@ -751,7 +751,7 @@ def main(argv=None):
                                index=dict(pages=info.get("n_dir"), bucket_slots=info.get("n_mslots"), inline_kmers=info.get("n_inline"),
                                           filter_bits=info.get("filter_bits"), device_gb=round(info["device_bytes"] / 1e9, 3)),
                                table_layout=layout,
-                               parallelism="reads sharded x%d, table replicated, all-reduce of row counts" % world),
+                               parallelism="reads sharded x%d, table replicated, all-reduce of the touched nodes' hit counts" % world),
                    roofline=roofline, cpu_baseline=cpu, phases=phases, resident_read_set=readset,
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),

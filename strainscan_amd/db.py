@@ -163,13 +163,12 @@ def fasta_index(path, k, upper_keys):
 
 
 def _fasta_index(path, k, upper_keys):
-    import hashlib
     cdir = _cache_dir()
     img = None
     if cdir and int(k) == 31:
         st = os.stat(path)
-        tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, st.st_mtime_ns, int(k),
-                                                 int(upper_keys))).encode()).hexdigest()[:20]
+        tag = cache_tag("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, st.st_mtime_ns, int(k),
+                                                 int(upper_keys)))
         img = os.path.join(cdir, "index_%s.bin" % tag)
         if os.path.exists(img):
             try:
@@ -197,6 +196,14 @@ def _export_image(kdb, cdir, img):
     except BaseException:
         _unlink_quiet(tmp)
         raise
+
+
+def cache_tag(text):
+    """Name of a cache entry from the string that identifies it (path | size | mtime | ...): 64 bits of two CRC-32s.  (Not
+    hashlib: importing it costs a fresh CLI process 0.05-0.1 s -- OpenSSL -- for what is a file name.)"""
+    import zlib
+    b = text.encode()
+    return "%08x%08x" % (zlib.crc32(b) & 0xFFFFFFFF, zlib.crc32(b[::-1], 0x5EED) & 0xFFFFFFFF)
 
 
 def _cache_dir():
@@ -414,12 +421,11 @@ def load_tree(db_dir, k=L1_K, with_keys=None):
     `with_keys(keys, flags)`: called on this thread as soon as kmer.fa is encoded -- the caller builds the device index
     there (native code, the interpreter lock is free) WHILE a worker thread parses the 1645 node files (numpy, 0.7 s
     for an E. coli tree); its result comes back as the second element of the returned pair."""
-    import hashlib
     fa = os.path.join(db_dir, "kmer.fa")
     st = os.stat(fa)
     kdir = os.path.join(db_dir, "kmers")
-    tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, st.st_mtime_ns, k,
-                                             os.stat(kdir).st_mtime_ns)).encode()).hexdigest()[:20]
+    tag = cache_tag("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, st.st_mtime_ns, k,
+                                             os.stat(kdir).st_mtime_ns))
     cdir = _cache_dir()
     path = os.path.join(cdir, "tree_%s.bin" % tag) if cdir else None
     if path:
@@ -489,13 +495,12 @@ class TreeImage:
     @staticmethod
     def _index(db_dir, keys, flags, upper_keys):
         """Device index of kmer.fa: imported from the image cache when present, else built and exported."""
-        import hashlib
         cdir = _cache_dir()
         path = None
         if cdir:
             st = os.stat(os.path.join(db_dir, "kmer.fa"))
-            tag = hashlib.sha1(("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, st.st_mtime_ns, L1_K,
-                                                     int(upper_keys))).encode()).hexdigest()[:20]
+            tag = cache_tag("%s|%d|%d|%d|%d" % (os.path.realpath(db_dir), st.st_size, st.st_mtime_ns, L1_K,
+                                                     int(upper_keys)))
             path = os.path.join(cdir, "index_%s.bin" % tag)
             if os.path.exists(path):
                 try:

@@ -201,15 +201,14 @@ def _pad64(n):
 
 def _l2_cache_path(input_csv, omatrix):
     """Cluster image cache (SS_IMAGE_CACHE, like the tree image): keyed by path, size and mtime of both files."""
-    import hashlib
     import os
-    from .db import _cache_dir
+    from .db import _cache_dir, cache_tag
     cdir = _cache_dir()
     if not cdir:
         return None
     st1, st2 = os.stat(input_csv), os.stat(omatrix)
-    tag = hashlib.sha1(("%s|%d|%d|%s|%d|%d" % (os.path.realpath(input_csv), st1.st_size, st1.st_mtime_ns,
-                                                os.path.realpath(omatrix), st2.st_size, st2.st_mtime_ns)).encode()).hexdigest()[:20]
+    tag = cache_tag("%s|%d|%d|%s|%d|%d" % (os.path.realpath(input_csv), st1.st_size, st1.st_mtime_ns,
+                                                os.path.realpath(omatrix), st2.st_size, st2.st_mtime_ns))
     return os.path.join(cdir, "l2_%s.bin" % tag)
 
 
