@@ -210,6 +210,9 @@ uint64_t ss_scan_kernel_launches(const ss_db *db);   /* scan kernels enqueued so
  * ------------------------------------------------------------------------------------------ */
 typedef struct ss_reads ss_reads;
 int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int shard_world, ss_reads **out);
+/* The one-time costs of the first ss_reads_load of a process (pinned parse buffers, streams: ~0.1 s), paid ahead of time --
+ * a command-line process calls it on a worker thread while the interpreter starts up. */
+int ss_ingest_warm_up(void);
 /* A resident read set from a flat base block that is already on the device (copied; order != 0: its records are put
  * in locality order, see below). */
 int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads **out);

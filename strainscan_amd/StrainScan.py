@@ -9,6 +9,18 @@ import os
 import re
 import sys
 
+if __name__ == "__main__" or os.path.basename(sys.argv[0] or "") in ("strainscan", "StrainScan.py"):
+    # the command itself: the library is loaded and the HIP runtime started on a worker thread (0.15-0.2 s) while this
+    # thread imports numpy and the modules below and reads the arguments
+    import threading
+
+    def _early():
+        from . import _lib
+        # (plain-text reads in a single process: the parse threads' pinned buffers too; .gz inputs never use them)
+        _lib.warm_up(ingest=int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not any(a.endswith(".gz") for a in sys.argv[1:]))
+
+    threading.Thread(target=_early, name="ss-gpu-warm-up", daemon=True).start()
+
 from . import identify, identify_low_mem, identify_low_depth, Vote_Strain_L2_Lasso_new_sp
 
 usage = "StrainScan - A kmer-based strain-level identification tool (MI355X-native identification path)."
@@ -58,7 +70,20 @@ def identify_with_ladder(in_fq, tdb, ldep, mdb):
     return cls_dict, l2
 
 
+def _clock(what):
+    """SS_CLI_TRACE=1: seconds since the interpreter started, at the CLI's milestones."""
+    if os.environ.get("SS_CLI_TRACE"):
+        import time
+        try:
+            import psutil
+            t0 = psutil.Process().create_time()
+        except Exception:                   # noqa: B902
+            t0 = time.time()
+        sys.stderr.write("[cli] %-28s %.3f s after process start\n" % (what, time.time() - t0))
+
+
 def main(argv=None):
+    _clock("main() entered")
     pwd = os.getcwd()
     ap = argparse.ArgumentParser(prog="StrainScan.py", description=usage)
     ap.add_argument("-i", "--input_fastq", dest="input_fq", type=str, required=True,
@@ -117,7 +142,9 @@ def main(argv=None):
         prob = identify_low_depth.identify_ranks(in_fq, tdb)
         generate_prob_report(prob, out_dir, tdb)
     mdb = 1 if os.path.exists(db_dir + "/Memory_DB") else 0
+    _clock("arguments read")
     cls_dict, l2 = identify_with_ladder(in_fq, tdb, ldep, mdb)
+    _clock("clusters identified")
     print(cls_dict)
     if len(cls_dict) == 0:
         print("Warning: No clusters can be detected!")
@@ -126,5 +153,27 @@ def main(argv=None):
                                                      pmode, emode)
 
 
+def cli():
+    """Entry of the `strainscan` command (pyproject.toml, bin/strainscan, python -m): main(), then the process ENDS -- pending
+    cache images are written, the streams flushed, and nothing is torn down piece by piece (unpinning the parse buffers,
+    freeing GBs of device memory and joining the thread pools cost a fresh process 0.1 s of its 0.65 s; the driver reclaims
+    everything at once)."""
+    try:
+        rc = main()
+    except SystemExit as e:
+        rc = e.code
+    _clock("reports written")
+    try:
+        from . import db
+        db.wait_cache_writes()
+    except Exception:                       # noqa: B902
+        pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # several ranks: the ordinary way out (process group, RCCL)
+        sys.exit(rc)
+    os._exit(rc if isinstance(rc, int) else (0 if rc is None else 1))
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    cli()
