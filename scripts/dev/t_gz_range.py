@@ -22,7 +22,7 @@ sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
-dist.init_process_group("gloo", rank=rank, world_size=world)
+dist.init_process_group("gloo", init_method="file://" + os.path.join(%(out)r, "store_" + os.environ.get("SS_GZ_RANGE", "1")), rank=rank, world_size=world)
 from strainscan_amd import dist as sdist, _lib
 import ctypes as C
 job = json.load(open(%(job)r))

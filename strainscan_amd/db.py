@@ -198,6 +198,27 @@ def _export_image(kdb, cdir, img):
         raise
 
 
+def _export_image_later(kdb, cdir, img):
+    """The 0.9 GB image of an E. coli tree takes 0.25 s to read back and write: on a worker thread (like the tree cache),
+    while the reads are scanned -- it only reads the index arrays, scans only add to the counters.  The handle must outlive
+    the writer: wait_cache_writes() runs before an image is dropped (tree_image, clear_cache, TreeImage.__del__)."""
+
+    def work():
+        try:
+            _export_image(kdb, cdir, img)
+        except (RuntimeError, OSError):
+            pass
+
+    with _CACHE_WRITERS_LOCK:
+        old = _CACHE_WRITERS.get(img)
+    if old is not None:
+        old.join()
+    th = threading.Thread(target=work, name="ss-export-image")
+    with _CACHE_WRITERS_LOCK:
+        _CACHE_WRITERS[img] = th
+    th.start()
+
+
 def cache_tag(text):
     """Name of a cache entry from the string that identifies it (path | size | mtime | ...): 64 bits of two CRC-32s.  (Not
     hashlib: importing it costs a fresh CLI process 0.05-0.1 s -- OpenSSL -- for what is a file name.)"""
@@ -492,6 +513,12 @@ class TreeImage:
         self._stats = None
         self._rows_global = True      # False: several ranks, the table holds THIS rank's counts only
 
+    def __del__(self):
+        try:
+            wait_cache_writes()      # the index may still be on its way to the image cache
+        except Exception:            # noqa: B902 -- interpreter shutdown
+            pass
+
     @staticmethod
     def _index(db_dir, keys, flags, upper_keys):
         """Device index of kmer.fa: imported from the image cache when present, else built and exported."""
@@ -514,10 +541,7 @@ class TreeImage:
         kdb = _lib.KmerDB(keys, flags, L1_K, upper_keys)
         INDEX_EVENTS["built"] += 1
         if path:
-            try:
-                _export_image(kdb, cdir, path)
-            except (RuntimeError, OSError):
-                pass
+            _export_image_later(kdb, cdir, path)
         return kdb
 
     # -- scanning ---------------------------------------------------------------------------
@@ -596,6 +620,8 @@ def tree_image(db_dir, upper_keys=True):
     img = _CACHE.get(key)
     if img is None:
         img = TreeImage(db_dir, upper_keys)
+        if _CACHE:
+            wait_cache_writes()      # (an image that is still being exported must not be dropped)
         _CACHE.clear()               # one database image at a time on the device
         _CACHE[key] = img
     return img

@@ -17,7 +17,7 @@ def _worker(rank, world, port, kfa_path, fq_path, out_dir):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "store_%d" % port), rank=rank, world_size=world)
     from strainscan_amd import _lib
     from strainscan_amd import dist as sdist
     from oracle import oracle as orc
@@ -63,7 +63,7 @@ def _share_worker(rank, world, port, gz_path, plain_path, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LOCAL_WORLD_SIZE"] = str(world)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "store_%d" % port), rank=rank, world_size=world)
     from strainscan_amd import dist as sdist
     use, cleanup = sdist.share_inflated([gz_path, plain_path, ""])
     assert use[1] == plain_path and use[2] == ""
@@ -222,7 +222,7 @@ def _exchange_worker(rank, world, port, out_dir):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "store_%d" % port), rank=rank, world_size=world)
     from strainscan_amd import dist as sdist
     rs = np.random.RandomState(7)                            # the same tree on every rank ...
     lens = rs.randint(0, 400, size=40)

@@ -26,7 +26,7 @@ import torch
 import torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
-dist.init_process_group("gloo", rank=rank, world_size=world)
+dist.init_process_group("gloo", init_method="file://" + os.environ["SS_TEST_STORE"], rank=rank, world_size=world)   # (no fixed port: nothing to collide with)
 from strainscan_amd import identify, identify_low_mem, identify_low_depth, db as ssdb, dist as sdist, _lib
 assert sdist.is_distributed() and sdist.rank_world() == (rank, world)
 jobs = json.load(open(%(jobs)r))
@@ -78,7 +78,8 @@ def _spawn(world, jobs, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), SS_IMAGE_CACHE=str(tmp_path / "cache"))      # one cache for the node
+                   MASTER_PORT=str(port), SS_IMAGE_CACHE=str(tmp_path / "cache"),      # one cache for the node
+                   SS_TEST_STORE=str(tmp_path / ("store_%d" % port)))
         env.pop("STRAINSCAN_QUIET", None)
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
     errs = [p.communicate(timeout=900)[1].decode()[-3000:] for p in procs]
@@ -160,7 +161,7 @@ import torch
 import torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
-dist.init_process_group("gloo", rank=rank, world_size=world)
+dist.init_process_group("gloo", init_method="file://" + os.environ["SS_TEST_STORE"], rank=rank, world_size=world)   # (no fixed port: nothing to collide with)
 from strainscan_amd import dist as sdist, _lib
 job = json.load(open(%(jobs)r))
 kdb = _lib.KmerDB.from_text(open(job["kfa"], "rb").read(), 31, True)
@@ -233,7 +234,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
         port = so.getsockname()[1]
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SS_TEST_STORE=str(tmp_path / ("store_%d" % port)))
         env.pop("SS_GZ_GPU", None)
         env["SS_GZ_SLICE_KB"] = "256"
         env["SS_GZ_CHUNK"] = "4096"          # (search chunks of 4 KB: slices of 128 of them, three or so per file)
