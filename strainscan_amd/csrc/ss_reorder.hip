@@ -235,7 +235,10 @@ __device__ __forceinline__ uint32_t tile_round(const char *__restrict__ b, uint6
     return cnt;
 }
 
-__device__ __forceinline__ uint32_t slot_of(uint32_t len) { return (len + 1u + 7u) & ~7u; }     // record + '\n', padded to 8 bytes
+#ifndef SS_SLOT_ALIGN
+#define SS_SLOT_ALIGN 8u
+#endif
+__device__ __forceinline__ uint32_t slot_of(uint32_t len) { return (len + 1u + (SS_SLOT_ALIGN - 1u)) & ~(SS_SLOT_ALIGN - 1u); }     // record + '\n', padded to 8 bytes
 
 // ---- pass 1: bytes per bin, and the tile's record table -----------------------------------------------------------------
 __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void count_kernel(const char *__restrict__ b, uint64_t n, int bits, unsigned long long *__restrict__ hist,
