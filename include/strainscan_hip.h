@@ -103,8 +103,9 @@ int ss_gz_set_policy(int mode);
  * of each slice -- 32 KB of text, the count of newlines so far, the bytes of the record that straddles the cut, CRC-32 and
  * length so far -- from the owner of the slice before, through `chain`: direction 0 = fill msg with what the owner of
  * slice - 1 sent, 1 = send msg to the owner of slice + 1 (blocking; return 0, anything else breaks the chain off).  The
- * rank keeps ALL records that begin in its slices (no further sharding of these files).  Active while world > 1 and chain
- * != NULL, and only under policy 1: a rank that cannot take part (bgzip, a wrong entry at a slice's edge, no room, text that
+ * rank keeps ALL records that begin in its slices (no further sharding of these files).  One member, several members
+ * joined with cat, or bgzip (a slice = the members that begin in its byte range).  Active while world > 1 and chain
+ * != NULL, and only under policy 1: a rank that cannot take part (a wrong entry at a slice's edge, no room, text that
  * is not four-line FASTQ, ...) still serves the chain, passes the bad news on and returns SS_EAGAIN; the ranks then settle for the
  * whole-file path (range off) or the host inflaters.  slice_bytes = 0: file size / (2 world), 4 MB .. 128 MB. */
 typedef int (*ss_gz_chain_fn)(void *msg, uint64_t bytes, int slice, int direction, void *user);

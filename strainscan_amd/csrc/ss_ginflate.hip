@@ -1144,7 +1144,8 @@ void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
 // A rank that fails at any point still takes part in the chain for all its slices (receives, passes the bad news on), so
 // nobody waits for a message that never comes.  Several members (lanes joined with cat) are followed inside the slices as in
 // the whole-file path -- a member that ends in a slice is checked against its trailer by the slice's owner, crc / len
-// always describe the member that is open at the cut; bgzip is declined here (the whole-file path takes it).
+// always describe the member that is open at the cut.  bgzip: a slice's chunks are the members that begin in its byte range
+// (no search, no window needed); the chain carries the newline count and the straddling record all the same.
 constexpr uint32_t CARRY_MAX = 65536;
 struct ChainMsg {
     int32_t status;
@@ -1307,7 +1308,6 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
     const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
-    if (rr && !bgzf.empty()) return no("bgzip in range mode");
     uint64_t probe = 512;
     if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
     std::vector<uint64_t> entry(n_chunks0);
@@ -1333,12 +1333,29 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // at `trailer`.
     struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; };
     std::vector<Chunk> G;
-    struct Seg { size_t gi, gj, n_ph; uint32_t slice; };
+    struct Seg { size_t gi, gj, n_ph; uint32_t slice; uint64_t hdr_bit; };
     std::vector<Seg> segs;                                   // range mode: one segment per slice of this rank, its look-ahead entries behind it
-    if (rr) {
+    const bool is_bgzf = !bgzf.empty();
+    if (rr && is_bgzf) {
+        // bgzip in range mode: a slice's chunks are the members whose deflate data begins in its byte range -- complete in
+        // themselves (no search, no look-ahead, nothing unknown in front of any); the chain still carries the newline count,
+        // the record that straddles the cut and the position the slice must begin at (hdr_bit: where its first member's header starts)
+        size_t mi = 0;
+        for (uint32_t sl : rr->mine) {
+            const uint64_t lo = sl == 0 ? 0 : data_off + (uint64_t)sl * rr->slice_chunks * chunk_bytes;
+            const uint64_t hi = sl + 1 == rr->n_slices ? ~0ull : data_off + (uint64_t)(sl + 1) * rr->slice_chunks * chunk_bytes;
+            while (mi < bgzf.size() && bgzf[mi].data < lo) mi++;
+            Seg sg{G.size(), 0, 0, sl, mi ? (bgzf[mi - 1].trailer + 8) * 8 : 0};
+            for (; mi < bgzf.size() && bgzf[mi].data < hi; mi++) G.push_back(Chunk{bgzf[mi].data * 8, true, true, bgzf[mi].trailer});
+            sg.gj = G.size();
+            if (sg.gj == sg.gi) return no("slice without a member", sl);
+            segs.push_back(sg);
+        }
+        if (trace) fprintf(stderr, "[ginflate] bgzip: %zu members, %zu in this rank's slices\n", bgzf.size(), G.size());
+    } else if (rr) {
         for (uint32_t sl : rr->mine) {
             const uint32_t c_lo = sl * rr->slice_chunks, c_hi = std::min<uint32_t>(n_chunks0, c_lo + rr->slice_chunks);
-            Seg sg{G.size(), 0, 0, sl};
+            Seg sg{G.size(), 0, 0, sl, 0};
             for (uint32_t c = c_lo; c < c_hi; c++)
                 if (entry[c] != ~0ull) G.push_back(Chunk{entry[c], c == 0, false, 0});
             sg.gj = G.size();
@@ -1378,7 +1395,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     for (size_t gi = 0, si = 0; gi < G.size(); si++) {
         const size_t gj = rr ? segs[si].gj : segment_end(gi);
         const bool more = rr ? segs[si].n_ph > 0 : gj < G.size();
-        const uint64_t bytes = ((more ? G[gj].start : (in_n - 8) * 8) - G[gi].start) / 8;
+        const uint64_t bytes = ((more ? G[gj].start : G[gj - 1].last ? G[gj - 1].trailer * 8 : (in_n - 8) * 8) - G[gi].start) / 8;
         need_sym = std::max<uint64_t>(need_sym, (bytes + (gj - gi)) * ratio + (gj - gi) * 4096);
         need_chunks = std::max<uint64_t>(need_chunks, gj - gi);
         gi = rr ? (si + 1 < segs.size() ? segs[si + 1].gi : G.size()) : gj;
@@ -1420,15 +1437,19 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     bool have_prev = false, ended = false;
     uint32_t n_segments = 0;
 
-    // CRC-32 of text[at, at + n) (range mode: one piece at a time; the members of the whole-file path are done together below)
-    auto piece_crc = [&](uint64_t at, uint64_t n, uint32_t *out) -> bool {
+    // CRC-32 of text[at, at + n) for a list of (at, n) (range mode: every member's part in one slice, ONE launch for all of them --
+    // a bgzip slice holds thousands of members; the members of the whole-file path are done together below)
+    auto pieces_crc = [&](const std::vector<std::pair<uint64_t, uint64_t>> &items, std::vector<uint32_t> &out) -> bool {
         constexpr int LG = 12;
-        const uint64_t sg = 1ull << LG, ns = (n + sg - 1) / sg;
-        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-        if (!ns) { *out = crc; return true; }
-        std::vector<uint64_t> at_v(ns);
-        std::vector<uint32_t> ln_v(ns), tabv(256), got(ns);
-        for (uint64_t i = 0; i < ns; i++) { at_v[i] = at + i * sg; ln_v[i] = (uint32_t)std::min<uint64_t>(sg, n - i * sg); }
+        const uint64_t sg = 1ull << LG;
+        std::vector<uint64_t> at_v;
+        std::vector<uint32_t> ln_v, tabv(256);
+        for (const auto &it : items)
+            for (uint64_t a0 = 0; a0 < it.second; a0 += sg) { at_v.push_back(it.first + a0); ln_v.push_back((uint32_t)std::min<uint64_t>(sg, it.second - a0)); }
+        const uint64_t ns = at_v.size();
+        out.assign(items.size(), (uint32_t)crc32(0L, Z_NULL, 0));
+        if (!ns) return true;
+        std::vector<uint32_t> got(ns);
         for (uint32_t i = 0; i < 256; i++) { uint32_t kx = i; for (int j = 0; j < 8; j++) kx = (kx & 1u) ? 0xEDB88320u ^ (kx >> 1) : kx >> 1; tabv[i] = kx; }
         uint32_t *pt = nullptr, *pc = nullptr;
         if (hipMallocAsync((void **)&pt, 1024 + ns * 12, st) != hipSuccess) return false;
@@ -1445,8 +1466,13 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         if (!ok) return false;
         uint32_t op[32];
         crc_zero_operator(op, LG);
-        for (uint64_t i = 0; i < ns; i++) crc = ln_v[i] == sg ? gf2_times(op, crc) ^ got[i] : (uint32_t)crc32_combine(crc, got[i], (z_off_t)ln_v[i]);
-        *out = crc;
+        uint64_t si = 0;
+        for (size_t k = 0; k < items.size(); k++) {
+            uint32_t crc = out[k];
+            for (uint64_t a0 = 0; a0 < items[k].second; a0 += sg, si++)
+                crc = ln_v[si] == sg ? gf2_times(op, crc) ^ got[si] : (uint32_t)crc32_combine(crc, got[si], (z_off_t)ln_v[si]);
+            out[k] = crc;
+        }
         return true;
     };
     size_t seg_i = 0;
@@ -1459,6 +1485,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         std::vector<uint64_t> start, stop, off, cap;
         uint64_t sym_total = 0;
         auto bit_behind = [&](uint32_t c) -> uint64_t {      // where chunk c's input ends at the latest
+            if (ch[c].last) return ch[c].trailer * 8;
             if (c + 1 < nc) return ch[c + 1].start;
             if (!ph.empty()) return ph[0].start;
             return (in_n - 8) * 8;
@@ -1641,7 +1668,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             if (my_slice > 0) {
                 if (!rr->recv_for(my_slice)) return no("chain receive", my_slice);
                 if (rr->msg.status < 0) return no("chain: a rank before this one declined", my_slice);
-                if (rr->msg.end_bit != ch[0].start || rr->msg.carry_len > CARRY_MAX) return no("range: the slice before ends elsewhere", my_slice);
+                if (rr->msg.end_bit != (is_bgzf ? segs[seg_i].hdr_bit : ch[0].start) || rr->msg.carry_len > CARRY_MAX)
+                    return no("range: the slice before ends elsewhere", my_slice);
                 GB(h2d(A->prev, rr->msg.window, WSIZE));
                 have_prev = true;
                 nl_before = rr->msg.nl; len_before = rr->msg.len; crc_before = rr->msg.crc;
@@ -1714,11 +1742,13 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             // CRC-32 of every member's part in this slice: a member that ended here against its trailer, the open one goes on
             uint32_t crc_now = (uint32_t)crc32(0L, Z_NULL, 0);
             uint64_t len_now = 0;
+            std::vector<std::pair<uint64_t, uint64_t>> m_items;
+            for (size_t mi = m_first; mi < members.size(); mi++) m_items.emplace_back(members[mi].at, members[mi].len);
+            std::vector<uint32_t> m_crc;
+            if (!pieces_crc(m_items, m_crc)) return no("piece crc", my_slice);
             for (size_t mi = m_first; mi < members.size(); mi++) {
                 const Member &m = members[mi];
-                uint32_t p_crc = 0;
-                if (!piece_crc(m.at, m.len, &p_crc)) return no("piece crc", my_slice);
-                const uint32_t c = m.len ? (uint32_t)crc32_combine(m.crc0, p_crc, (z_off_t)m.len) : m.crc0;
+                const uint32_t c = m.len ? (uint32_t)crc32_combine(m.crc0, m_crc[mi - m_first], (z_off_t)m.len) : m.crc0;
                 if (!m.open) { if (c != m.crc) return no("crc (range mode)", (long long)mi); }
                 else if (mi + 1 == members.size()) { crc_now = c; len_now = m.len0 + m.len; }
                 else return no("member left open", (long long)mi);
@@ -1748,7 +1778,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                 rr->msg.crc = crc_now;
                 rr->msg.len = len_now;
                 rr->msg.nl = nl_before + p_nl;
-                rr->msg.end_bit = end_bit[nc - 1];
+                rr->msg.end_bit = is_bgzf ? (ch[nc - 1].trailer + 8) * 8 : end_bit[nc - 1];      // (bgzip: the next member's header)
                 rr->msg.carry_len = (uint32_t)(p_len - keep);
                 memcpy(rr->msg.carry, tb.data() + q, p_len - keep);
                 GB(d2h(rr->msg.window, A->prev, WSIZE));

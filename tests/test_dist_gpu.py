@@ -182,7 +182,8 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"), (2, False, "members"),
-                                                  (2, True, "range"), (3, True, "range"), (2, False, "entry100"), (2, False, "entry128"), (3, False, "entry129")])
+                                                  (2, True, "range"), (3, True, "range"), (2, False, "entry100"), (2, False, "entry128"), (3, False, "entry129"),
+                                                  (2, False, "bgzip"), (3, False, "bgzip")])
 def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     """A pair of .fastq.gz files under torch.distributed; the summed row counts equal the single-process scan of the plain
     text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
@@ -190,7 +191,9 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     them small here -- a chain of messages for the windows, newline counts and straddling records, CRC-32 down the chain).
     `whole` (SS_GZ_RANGE=0): every rank inflates both files on its GPU and keeps its blocks of 4096 records.
     `members`: one file is two members joined with cat -- the member that ends inside a slice is checked against its
-    trailer there, the next starts with nothing in front of it, CRC-32 and length of the open member travel down the chain.  `decline`: the device path of rank 1 alone declines (test hook: it still serves the chain) --
+    trailer there, the next starts with nothing in front of it, CRC-32 and length of the open member travel down the chain.
+    `bgzip`: both files are BGZF -- a slice's chunks are the members that begin in its byte range, the chain carries the newline
+    count and the straddling record.  `decline`: the device path of rank 1 alone declines (test hook: it still serves the chain) --
     dist.load_agreed must move ALL ranks on, in the end to the host inflaters (one inflate into /dev/shm, parse chunks
     shared out), or reads would be counted twice or not at all.  `entryN`: a wrong entry point (a position inside a
     block, test hook) in search chunk N -- inside a slice the chunk in front of it runs over it as in the whole-file path;
@@ -215,7 +218,11 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     plain.write_bytes(b"".join(fq))
     p1, p2 = tmp_path / "s_1.fq.gz", tmp_path / "s_2.fq.gz"
     p1.write_bytes(gzip.compress(b"".join(fq[:half]), 6))
-    if mode == "members":
+    if mode == "bgzip":
+        from tests.test_ginflate_gpu import _bgzf
+        p1.write_bytes(_bgzf(b"".join(fq[:half])))
+        p2.write_bytes(_bgzf(b"".join(fq[half:]), block=33333, level=4))
+    elif mode == "members":
         q = half + (n - half) // 3
         p2.write_bytes(gzip.compress(b"".join(fq[half:q]), 6) + gzip.compress(b"".join(fq[q:]), 1))
     else:
@@ -253,7 +260,7 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     infos = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("counts%d.npy" % r)), want), r          # the global counts, on every rank
-        if not decline and mode == "range":      # two files, scanned and loaded, both times shared between the ranks
+        if not decline and mode in ("range", "bgzip"):      # two files, scanned and loaded, both times shared between the ranks
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 4 and infos[r]["range_pieces"] >= 4, (infos, errs)
         elif not decline and mode == "whole":
             assert infos[r]["handled"] == 4 and infos[r]["declined"] == 0 and infos[r]["range_files"] == 0
@@ -266,5 +273,5 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     assert decline or all(i["nrec"] > 0 for i in infos)      # (parse chunks are 24 MB: these small files are one chunk each)
     if mode == "entry100":                                   # run over inside a slice: still shared
         assert all(i["range_files"] == 4 for i in infos)
-    if mode == "range" and not decline:                      # every rank inflated about its share, not everything
+    if mode in ("range", "bgzip") and not decline:           # every rank inflated about its share, not everything
         assert max(i["own"] for i in infos) < 0.75 * n
