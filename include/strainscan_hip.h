@@ -90,6 +90,10 @@ int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
 /* The device inflater keeps its scratch (symbol streams, window maps, the text buffer: ~6-12 GB, at most two sets) for
  * the next call -- large allocations are slow to come by on this platform; this hands it back. */
 int ss_gz_gpu_release(void);
+/* The pinned upload buffers of n_files (<= 2) concurrent .gz inputs, made ahead of time (~40 ms a set; a command-line process
+ * calls this on its warm-up thread): a file of 32 MB or more then travels through them (8 ms instead of 12-30 per 66 MB);
+ * without them only files of 256 MB or more make their own. */
+int ss_gz_warm_up(int n_files);
 /* Who inflates the .gz inputs of the next ss_reads_load / ss_scan_files* calls of this process: 0 (default) the device, and
  * the host inflaters for whatever it declines; 1 the device or NOBODY -- a declined input makes the call return SS_EAGAIN
  * with nothing loaded; 2 the host inflaters.  The two paths give a rank different shares of the reads (blocks of 4096

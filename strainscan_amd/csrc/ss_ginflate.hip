@@ -439,9 +439,7 @@ __device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint
     }
 }
 
-// One block from the current position.  0 = block done, 1 = final block done, 2 = probe satisfied, < 0 = error.
-//
-// The symbols of a compressed block: the 64 lanes decode SPECULATIVELY at the 64 bit positions bp .. bp + 63 -- each a
+// The symbols of a compressed block (block_body below): the 64 lanes decode SPECULATIVELY at the 64 bit positions bp .. bp + 63 -- each a
 // whole item (literal, end of block, or length + extra + distance + extra: at most 48 bits, every lane has 64) --, then
 // the wave follows the chain of item lengths from bp (one readlane per item on the scalar unit) and the lanes ON the
 // chain deliver at the offsets a prefix sum over their output lengths gives them: the literals in one store; the
@@ -452,11 +450,16 @@ __device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint
 constexpr uint32_t F_MATCH = 64u, F_EOB = 128u, F_BAD = 256u;
 constexpr uint32_t FAR_MAX = 12;            // longest match of the batched kind (one 2-byte load per symbol and lane)
 constexpr uint32_t WIN_MAX = RING - RING_REACH;      // 264: a window that delivers more goes item by item (ring aliasing)
-__device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_window, uint64_t probe_symbols = ~0ull, uint64_t stop_bits = ~0ull)
+// the block's first bits: BFINAL, BTYPE and the code tables (a stored block is copied here and now).
+// 0 = tables in LDS, block_body follows; 10 + BFINAL = a stored block, done; < 0 = error
+struct BlockCtx { uint32_t bfinal; bool dist_usable; };
+__device__ int block_begin(WaveState &S, SBits &b, OutState &o, BlockCtx &cx)
 {
     const int lane = threadIdx.x & 63;
     const bool store = o.out != nullptr;
     const uint32_t bfinal = sb_get(S, b, 1), btype = sb_get(S, b, 2);
+    cx.bfinal = bfinal;
+    cx.dist_usable = true;
     if (btype == 3) return -1;
     uint64_t n = o.n;
 #define GI_RET(v) do { o.n = n; return (v); } while (0)
@@ -480,14 +483,29 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
             n += len;
         }
         sb_seek(b, b.bp + 8ull * len);
-        GI_RET((int)bfinal);
+        GI_RET(10 + (int)bfinal);
     }
-    bool dist_usable = true;
     GZ_T(th0);
     if (btype == 1) fixed_codes(S);
-    else if (!read_dynamic(S, b, dist_usable)) GI_RET(-4);
+    else if (!read_dynamic(S, b, cx.dist_usable)) GI_RET(-4);
     GZ_T(th1);
     GZ_ACC(4, th0, th1);
+    return 0;
+#undef GI_RET
+}
+
+// The items of a compressed block from the current position (the block's first item, or -- a chunk that was entered inside a
+// block, or one that goes on behind an entry it ran over -- any item's first bit) to its end-of-block code.
+// 0 = block done, 1 = final block done, 2 = probe satisfied, 3 = stopped exactly AT mid_target (an item's first bit inside
+// this block: the next chunk's entry), 4 = mid_target lies behind the position and was not an item's first bit, < 0 = error.
+__device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window, const BlockCtx cx, uint64_t probe_symbols, uint64_t stop_bits,
+                          uint64_t mid_target)
+{
+    const int lane = threadIdx.x & 63;
+    const bool store = o.out != nullptr;
+    const uint32_t bfinal = cx.bfinal;
+    const bool dist_usable = cx.dist_usable;
+    uint64_t n = o.n;
     const int lit_maxlen = __builtin_amdgcn_readfirstlane(S.lit.maxlen), dist_maxlen = __builtin_amdgcn_readfirstlane(S.dist.maxlen);
     const uint64_t probe_end = probe_symbols == ~0ull ? ~0ull : n + probe_symbols;
     const uint64_t end_bits = b.n * 8;
@@ -523,6 +541,7 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         if (n >= probe_end) GI_OUT(2);                     // sync search: the header was valid and this many symbols decoded
         if (b.bp > end_bits) GI_OUT(-5);
         if (b.bp > stop_bits) GI_OUT(-21);                 // ran past the next chunk's entry: that entry was not a block's start
+        if (b.bp >= mid_target) GI_OUT(b.bp == mid_target ? 3 : 4);
         GZ_T(tw0);
         sb_stage(S, b);
         // ---- every lane: the item at bp + lane
@@ -570,6 +589,11 @@ __device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_win
         uint32_t stop = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)last);
         stop = (stop & (F_EOB | F_BAD)) ? stop : 0u;
         if (stop) { chain &= ~(1ull << last); pos = last; }
+        if (mid_target - b.bp < 64ull && ((chain >> (uint32_t)(mid_target - b.bp)) & 1ull)) {      // the next chunk begins at an item of this window
+            pos = (uint32_t)(mid_target - b.bp);
+            chain &= (1ull << pos) - 1ull;
+            stop = 0;
+        }
         if (stop & F_BAD) GI_OUT(-5);
         GZ_T(tw2);
         // ---- deliver
@@ -646,7 +670,15 @@ out:
     return ret;
 #undef GI_FINISH
 #undef GI_OUT
-#undef GI_RET
+}
+
+// One block from the current position.  0 = block done, 1 = final block done, 2 = probe satisfied, < 0 = error.
+__device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_window, uint64_t probe_symbols = ~0ull, uint64_t stop_bits = ~0ull)
+{
+    BlockCtx cx;
+    const int r = block_begin(S, b, o, cx);
+    if (r != 0) return r >= 10 ? r - 10 : r;
+    return block_body(S, b, o, known_window, cx, probe_symbols, stop_bits, ~0ull);
 }
 
 __device__ unsigned g_sync_tries;      // candidates that passed the header check and were decoded (trace)
@@ -698,8 +730,89 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
     if (lane == 0) entry[c] = found;
 }
 
-// B: every listed chunk from its entry to the next entry (or the end of the stream)
-__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t in_n, const uint64_t *start, const uint64_t *stop,
+// A2: entries INSIDE blocks.  A block is the unit the search can find (a sync point exists only at a block's start), and a
+// wave that decodes 30-60 KB of deflate data alone is what the inflate kernel waits for.  But Huffman-coded data
+// synchronises itself: decode from ANY bit with the block's tables and after a few dozen items the decoder is on the true
+// item boundaries.  One wave per wanted position `from` inside the block whose header is at `hdr`: parse the header, then
+// window by window (64 bits) every lane decodes the item at its bit as the inflate kernel does; all 64 offsets are
+// hypotheses at first, a window maps the live ones to the offsets at which their chains enter the next window (chains
+// followed by pointer doubling: six bpermutes), dead ends (undecodable, end of block) drop out.  When ONE offset is left it is the
+// true chain -- the true one never dies before the block ends -- and becomes the entry: a chunk that begins there with
+// `hdr`'s tables.  Verified when the chunks are inflated: the chunk in front must arrive exactly there, inside that block.
+constexpr int SUB_WINDOWS = 48;
+__device__ __forceinline__ uint32_t lane_item_bits(const WaveState &S, uint64_t bits, int lit_maxlen, int dist_maxlen, bool dist_usable)
+{
+    const uint32_t e = S.lit.tent[(uint32_t)bits & ((1u << SS_GZ_LITBITS) - 1)];
+    int l = (int)(e >> 9), sym = (int)(e & 511u);
+    if (e == 0) sym = lane_long(S.lit, (uint32_t)bits & 0x7FFFu, lit_maxlen, l);
+    if (sym < 0 || sym > 285 || sym == 256) return 0;           // undecodable, or the end of the block: the hypothesis ends
+    if (sym < 256) return (uint32_t)l;
+    int xb, xd;
+    uint32_t base;
+    len_code(sym - 257, base, xb);
+    l += xb;
+    const uint32_t v = (uint32_t)(bits >> l) & 0x7FFFu;
+    const uint32_t de = S.dist.tent[v & 255u];
+    int dl = (int)(de >> 9), ds = (int)(de & 511u);
+    if (de == 0) ds = lane_long(S.dist, v, dist_maxlen, dl);
+    if (!dist_usable || ds < 0 || ds > 29) return 0;
+    dist_code(ds, base, xd);
+    return (uint32_t)(l + dl + xd);
+}
+__global__ __launch_bounds__(64) void subsync_kernel(const uint8_t *in, uint64_t in_n, const uint64_t *hdr, const uint32_t *first /* [n_blocks + 1] */,
+                                                     const uint64_t *from, const uint64_t *limit, uint32_t n_blocks, uint64_t *entry)
+{
+    __shared__ WaveState S;
+    __shared__ uint32_t flag[64];
+    const uint32_t blk = blockIdx.x;                          // one wave per block: its header is parsed once for all its positions
+    if (blk >= n_blocks) return;
+    const int lane = threadIdx.x & 63;
+    SBits b;
+    sb_init(b, in, in_n, hdr[blk]);
+    OutState o{nullptr, 0, 0, 0};
+    BlockCtx cx;
+    const bool usable = block_begin(S, b, o, cx) == 0;
+    const uint64_t body = b.bp;
+    const int lit_maxlen = __builtin_amdgcn_readfirstlane(S.lit.maxlen), dist_maxlen = __builtin_amdgcn_readfirstlane(S.dist.maxlen);
+    for (uint32_t i = first[blk]; i < first[blk + 1]; i++) {
+        uint64_t found = ~0ull;
+        const uint64_t p0 = from[i], lim = limit[i];
+        if (usable && p0 >= body) {
+            uint64_t live = ~0ull;
+            for (int w = 0; w < SUB_WINDOWS; w++) {
+                const uint64_t base = p0 + 64ull * (uint64_t)w;
+                if (base + 192 > lim) break;
+                sb_seek(b, base);
+                sb_stage(S, b);
+                const uint64_t p = base + (uint64_t)lane;
+                const uint32_t wd = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+                const uint32_t d0 = S.stage[wd & 511], d1 = S.stage[(wd + 1) & 511], d2 = S.stage[(wd + 2) & 511];
+                uint64_t bits = (((uint64_t)d1 << 32) | d0) >> sh;
+                if (sh) bits |= (uint64_t)d2 << (64 - sh);
+                const uint32_t step = lane_item_bits(S, bits, lit_maxlen, dist_maxlen, cx.dist_usable);
+                uint32_t e = step ? (uint32_t)lane + step : 255u;              // < 64: the chain goes on at that lane; 255: dead
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((e & 63u) << 2), (int)e);
+                    if (e < 64u) e = t;
+                }
+                __builtin_amdgcn_wave_barrier();
+                flag[lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (((live >> lane) & 1ull) && e != 255u) flag[e - 64u] = 1u; // (an item has at most 48 bits: e - 64 < 48)
+                __builtin_amdgcn_wave_barrier();
+                live = __ballot(flag[lane] != 0u);
+                if (!live) break;
+                if (__popcll(live) == 1) { found = base + 64ull + (uint64_t)(__ffsll((long long)live) - 1); break; }
+            }
+        }
+        if (lane == 0) entry[i] = found;
+    }
+}
+
+// B: every listed chunk from its entry to the next entry (or the end of the stream).  An entry is a block's start
+// (hdr[c] = ~0) or an item's first bit inside the block whose header is at hdr[c] (subsync_kernel).
+__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t in_n, const uint64_t *start, const uint64_t *stop, const uint64_t *hdr,
                                                      uint32_t n_chunks, uint16_t *sym, const uint64_t *sym_off, const uint64_t *sym_cap,
                                                      uint64_t *out_len, uint64_t *end_bit, int *status, const uint32_t *only, uint32_t max_over)
 {
@@ -713,24 +826,60 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
     SBits b;
     const uint64_t s0 = start[c];
     const bool fresh = (s0 >> 63) != 0;                     // the first chunk of a member: nothing lies in front of it
-    sb_init(b, in, in_n, s0 & ~(1ull << 63));
+    const uint64_t first_bit = s0 & ~(1ull << 63);
+    sb_init(b, in, in_n, first_bit);
     OutState o{sym ? sym + sym_off[c] : nullptr, sym_cap[c], 0, 0};
     // A block that ends BEHIND the next chunk's entry: that entry was no block's start (a position inside a block passes the
     // sync search about once in a million candidates).  The chunk simply goes on to the entry after it -- its symbol
     // region (12x its input) has room for two or three chunks of FASTQ -- and says how many entries it ran over; within
     // a block it gives up beyond the second entry ahead (what itself started at a wrong entry decodes garbage).
+    // An entry INSIDE a block (hdr != ~0) is met when this chunk, in the block with that header, arrives at an item's first
+    // bit exactly there; if it passes it, or is in another block, the entry was wrong and is run over like the others.
     const uint64_t stop0 = stop[c];
     uint64_t stop_at = stop0;
     const uint64_t hard = stop[min(c + max_over, n_chunks - 1)];
     uint32_t skipped = 0;
     int st = 0;
+    uint64_t block_at = hdr[c];                             // the header of the block the position is in
+    bool resume = block_at != ~0ull;
     for (;;) {
-        const int r = inflate_block(S, b, o, fresh, ~0ull, hard);
+        BlockCtx cx;
+        int r;
+        if (resume) {                                        // a chunk that begins inside a block: its tables first
+            sb_seek(b, block_at);
+            OutState none{nullptr, 0, 0, 0};
+            r = block_begin(S, b, none, cx);
+            if (r != 0 || first_bit < sb_bitpos(b)) { st = -22; break; }
+            sb_seek(b, first_bit);
+            resume = false;
+        } else {
+            block_at = sb_bitpos(b);
+            r = block_begin(S, b, o, cx);
+        }
+        if (r == 0) {
+            for (;;) {
+                const uint32_t k = c + 1 + skipped;
+                const uint64_t mid = (k < n_chunks && skipped <= max_over && hdr[k] == block_at) ? (start[k] & ~(1ull << 63)) : ~0ull;
+                r = block_body(S, b, o, fresh, cx, ~0ull, hard, mid);
+                if (r == 4 && skipped < max_over) { stop_at = stop[c + ++skipped]; continue; }      // not an item's first bit: a wrong entry, run over
+                break;
+            }
+            if (r == 4) { st = -21; break; }
+            if (r == 3) { st = 0; stop_at = sb_bitpos(b); break; }              // exactly at the next (not skipped) entry
+        } else if (r >= 10) {
+            r -= 10;
+        }
         if (r < 0) { st = (r == -9 && sb_bitpos(b) > stop0) ? -21 : r; break; }      // (no room for more than its own: the host merges the two)
         const uint64_t pos = sb_bitpos(b);
-        while (pos > stop_at && skipped < max_over && c + skipped + 1 < n_chunks) stop_at = stop[c + ++skipped];
+        // (an entry inside a block cannot lie at a block's end -- it claims a header in front of it --: wrong, run over as well)
+        while (skipped < max_over && c + skipped + 1 < n_chunks && (pos > stop_at || (pos == stop_at && hdr[c + 1 + skipped] != ~0ull)))
+            stop_at = stop[c + ++skipped];
         if (r == 1) { st = (stop_at == ~0ull) ? 1 : -20; break; }      // the final block ends the LAST chunk of a member only
-        if (pos == stop_at) { st = 0; break; }
+        if (pos == stop_at) {
+            const uint32_t k = c + 1 + skipped;
+            st = (k < n_chunks && hdr[k] != ~0ull) ? -21 : 0;
+            break;
+        }
         if (pos > stop_at) { st = -21; break; }
     }
     if (st >= 0 && o.out) out_flush(S, o, o.n);
@@ -1034,7 +1183,7 @@ Arena *arena_get(uint64_t cap_chunks, uint64_t sym_elems)
     a->sym_elems = sym_elems;
     const uint64_t n_groups = cap_chunks / 8 + 2;
     const bool ok = hipMalloc((void **)&a->sym, sym_elems * 2) == hipSuccess && hipMalloc((void **)&a->map[0], cap_chunks * WSIZE * 2) == hipSuccess &&
-                    hipMalloc((void **)&a->map[1], cap_chunks * WSIZE * 2) == hipSuccess && hipMalloc((void **)&a->meta, cap_chunks * 8 * 7) == hipSuccess &&
+                    hipMalloc((void **)&a->map[1], cap_chunks * WSIZE * 2) == hipSuccess && hipMalloc((void **)&a->meta, cap_chunks * 8 * 8) == hipSuccess &&
                     hipMalloc((void **)&a->status, cap_chunks * 4) == hipSuccess && hipMalloc((void **)&a->win, cap_chunks * WSIZE) == hipSuccess &&
                     hipMalloc((void **)&a->gwin, n_groups * WSIZE) == hipSuccess && hipMalloc((void **)&a->prev, WSIZE) == hipSuccess &&
                     hipMalloc((void **)&a->todo, cap_chunks * 4) == hipSuccess;
@@ -1077,6 +1226,11 @@ PinSet *pin_get()
         if (hipHostMalloc((void **)&p->b[i], PIN_BYTES, hipHostMallocDefault) != hipSuccess) { pin_destroy(p); return nullptr; }
     return p;
 }
+bool pin_waiting()
+{
+    std::lock_guard<std::mutex> g(g_arena_mu);
+    return !g_pin_free.empty();
+}
 void pin_put(PinSet *p)
 {
     if (!p) return;
@@ -1094,14 +1248,16 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in)
     hipGetDevice(&device);
     std::atomic<uint64_t> next(0);
     std::atomic<int> failed(0);
-    const uint64_t n_blocks = (n + PIN_BYTES - 1) / PIN_BYTES;
+    // (a file of a few tens of MB: smaller blocks, so that all four threads have some)
+    const uint64_t blk = std::min<uint64_t>(PIN_BYTES, std::max<uint64_t>(4ull << 20, ((n / 8) + (1ull << 20) - 1) & ~((1ull << 20) - 1)));
+    const uint64_t n_blocks = (n + blk - 1) / blk;
     std::vector<std::thread> pool;
     for (int t = 0; t < PIN_N; t++)
         pool.emplace_back([&, t] {
             hipStream_t s2 = nullptr;
             if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
             for (uint64_t b; !failed && (b = next.fetch_add(1)) < n_blocks;) {
-                const uint64_t a = b * PIN_BYTES, len = std::min<uint64_t>(PIN_BYTES, n - a);
+                const uint64_t a = b * blk, len = std::min<uint64_t>(blk, n - a);
                 uint64_t got = 0;
                 while (got < len) {
                     const ssize_t r = pread(fd, pins->b[t] + got, len - got, (off_t)(a + got));
@@ -1258,7 +1414,10 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
 #define GB(call) do { if (!(call)) return no(#call); } while (0)
     const uint64_t data_off = gzip_header_len(in, in_n);
     if (!data_off) return no("header");
-    uint64_t chunk_bytes = 32 << 10, ratio = 12, seg_bytes = 128ull << 20;
+    // SS_GZ_SPLIT_KB: blocks are entered every so many KB of deflate data (subsync_kernel; 0 = at their starts only)
+    uint64_t split_bytes = 12 << 10;
+    if (const char *e = getenv("SS_GZ_SPLIT_KB")) split_bytes = (uint64_t)std::max<long long>(0, atoll(e)) << 10;
+    uint64_t chunk_bytes = split_bytes ? 16 << 10 : 32 << 10, ratio = 12, seg_bytes = 128ull << 20;      // (split: every block's start should be found)
     if (const char *e = getenv("SS_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));
     if (const char *e = getenv("SS_GZ_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
     if (const char *e = getenv("SS_GZ_SEG_KB")) seg_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) << 10;      // (tests: many segments)
@@ -1286,7 +1445,11 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
     static const bool no_pread = getenv("SS_GZ_NO_PREAD") != nullptr;
     bool uploaded = false;
-    if (fd >= 0 && in_n >= (256ull << 20) && !no_pread && !rr) {    // (`fd`: the same file; smaller ones are there before the buffers are)
+    // (pinned buffers cost ~40 ms to make: a file of less than 256 MB takes that way only when a set is there already --
+    //  ss_gz_warm_up, or an earlier call -- and then arrives in 8 ms instead of 12-30)
+    static const uint64_t pread_env = getenv("SS_GZ_PREAD_MB") ? (uint64_t)atoll(getenv("SS_GZ_PREAD_MB")) << 20 : 0;
+    const uint64_t pread_from = pread_env ? pread_env : pin_waiting() ? 32ull << 20 : 256ull << 20;
+    if (fd >= 0 && in_n >= pread_from && !no_pread && !rr) {    // (`fd`: the same file; smaller ones are there before the buffers are)
         GI(hipStreamSynchronize(st));                         // the allocation is stream-ordered
         uploaded = upload_file(fd, in_n, d_in);
     }
@@ -1331,7 +1494,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // The file's chunks: one per entry (a chunk of the search without one belongs to its predecessor).  `fresh`: the first
     // chunk of a gzip member (nothing in front of it); `last`: it ends with the member's final block, the trailer follows
     // at `trailer`.
-    struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; };
+    // `hdr`: ~0, or -- an entry INSIDE a block (subsync_kernel) -- where that block's header is.
+    struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; uint64_t hdr = ~0ull; };
     std::vector<Chunk> G;
     struct Seg { size_t gi, gj, n_ph; uint32_t slice; uint64_t hdr_bit; };
     std::vector<Seg> segs;                                   // range mode: one segment per slice of this rank, its look-ahead entries behind it
@@ -1381,6 +1545,66 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     }
     entry.clear();
     entry.shrink_to_fit();
+    uint32_t n_sub = 0;
+    if (split_bytes && !is_bgzf && !G.empty()) {
+        // ---- entries inside the blocks: a block [its start, the next entry) of more than 2 x split_bytes is entered at
+        //      equidistant places as well (at most eight pieces; range mode: the look-ahead entries stay whole)
+        std::vector<uint64_t> b_hdr, s_from, s_lim;
+        std::vector<uint32_t> b_first, s_of;                   // positions of a block: [b_first[b], b_first[b + 1]); s_of: which chunk of G
+        auto want = [&](size_t i, uint64_t endb) {
+            const uint64_t len = endb - G[i].start, pieces = std::min<uint64_t>(8, len / (split_bytes * 8));
+            if (pieces < 2) return;
+            b_hdr.push_back(G[i].start);
+            b_first.push_back((uint32_t)s_of.size());
+            for (uint64_t j = 1; j < pieces; j++) { s_from.push_back(G[i].start + len * j / pieces); s_lim.push_back(endb); s_of.push_back((uint32_t)i); }
+        };
+        if (rr) {
+            for (const Seg &sg : segs)
+                for (size_t i = sg.gi; i < sg.gj; i++) {
+                    if (i + 1 < sg.gj + sg.n_ph) want(i, G[i + 1].start);
+                    else if (G[i].last) want(i, G[i].trailer * 8);
+                }
+        } else {
+            for (size_t i = 0; i < G.size(); i++) want(i, i + 1 < G.size() ? G[i + 1].start : (in_n - 8) * 8);
+        }
+        const size_t ns = s_of.size(), nb = b_hdr.size();
+        b_first.push_back((uint32_t)ns);
+        if (ns) {
+            uint64_t *d_sub = nullptr;                         // block headers | from | limit | entries | first (u32)
+            GI(hipMallocAsync((void **)&d_sub, nb * 8 + ns * 8 * 3 + (nb + 1) * 4, st));
+            uint64_t *d_bh = d_sub, *d_from = d_sub + nb, *d_lim = d_from + ns, *d_ent = d_lim + ns;
+            uint32_t *d_first = reinterpret_cast<uint32_t *>(d_ent + ns);
+            std::vector<uint64_t> got(ns);
+            const bool ok = h2d(d_bh, b_hdr.data(), nb * 8) && h2d(d_from, s_from.data(), ns * 8) && h2d(d_lim, s_lim.data(), ns * 8) &&
+                            h2d(d_first, b_first.data(), (nb + 1) * 4);
+            if (ok) hipLaunchKernelGGL(subsync_kernel, dim3((unsigned)nb), dim3(64), 0, st, d_in, in_n - 8, d_bh, d_first, d_from, d_lim, (uint32_t)nb, d_ent);
+            const bool ok2 = ok && d2h(got.data(), d_ent, ns * 8);
+            hipFreeAsync(d_sub, st);
+            if (!ok2) return no("sub-entries");
+            std::vector<Chunk> G2;
+            std::vector<size_t> at(G.size() + 1);
+            size_t k = 0;
+            for (size_t i = 0; i < G.size(); i++) {
+                at[i] = G2.size();
+                G2.push_back(G[i]);
+                uint64_t prev = G[i].start;
+                for (; k < ns && s_of[k] == i; k++) {
+                    if (got[k] == ~0ull || got[k] <= prev || got[k] + 256 >= s_lim[k]) continue;      // (none found, or two searches met in one place)
+                    Chunk sub{got[k], false, G[i].last, G[i].trailer, G[i].start};
+                    G2.back().last = false;                    // the member's final block ends the LAST piece
+                    G2.back().trailer = 0;
+                    G2.push_back(sub);
+                    prev = got[k];
+                    n_sub++;
+                }
+            }
+            at[G.size()] = G2.size();
+            for (Seg &sg : segs) { const size_t ph = sg.n_ph; sg.gi = at[sg.gi]; sg.gj = at[sg.gj]; sg.n_ph = ph; }
+            G.swap(G2);
+        }
+        if (trace) fprintf(stderr, "[ginflate] %zu entries inside blocks wanted, %u found: %zu chunks\n", ns, n_sub, G.size());
+        lap("sub-entries");
+    }
 
     // The chunks are inflated SEGMENT by segment (seg_bytes of deflate data, 128 MB): the scratch stays a few GB whatever
     // the file's size, and the text of one segment is complete -- bytes -- before the next one starts, so the 32 KB in
@@ -1429,8 +1653,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     d_text = A->text;
     lap("buffers");
     uint64_t *d_start = A->meta, *d_stop = A->meta + cap_chunks, *d_off = A->meta + 2ull * cap_chunks, *d_cap = A->meta + 3ull * cap_chunks,
-             *d_len = A->meta + 4ull * cap_chunks, *d_end = A->meta + 5ull * cap_chunks, *d_toff = A->meta + 6ull * cap_chunks;
-    const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : 2u;      // (test hook: wrong entries are then handled by the host only)
+             *d_len = A->meta + 4ull * cap_chunks, *d_end = A->meta + 5ull * cap_chunks, *d_toff = A->meta + 6ull * cap_chunks, *d_hdr = A->meta + 7ull * cap_chunks;
+    const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : n_sub ? 4u : 2u;      // (test hook: wrong entries are then handled by the host only)
     struct Member { uint64_t at, len; uint32_t crc, isize; bool open; uint32_t crc0; uint64_t len0; };      // crc0, len0: range mode -- the member's part in the slices before
     std::vector<Member> members;
     uint64_t total = 0, last_end_bit = 0;
@@ -1482,7 +1706,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         const size_t ph_end = rr ? gj + segs[seg_i].n_ph : std::min(G.size(), gj + 2);
         std::vector<Chunk> ch(G.begin() + (long)gi, G.begin() + (long)gj), ph(G.begin() + (long)gj, G.begin() + (long)ph_end);
         uint32_t nc = (uint32_t)ch.size();
-        std::vector<uint64_t> start, stop, off, cap;
+        std::vector<uint64_t> start, stop, off, cap, hdrs;
         uint64_t sym_total = 0;
         auto bit_behind = [&](uint32_t c) -> uint64_t {      // where chunk c's input ends at the latest
             if (ch[c].last) return ch[c].trailer * 8;
@@ -1491,9 +1715,10 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             return (in_n - 8) * 8;
         };
         auto lay_out = [&] {
-            start.clear(); stop.clear(); off.clear(); cap.clear();
+            start.clear(); stop.clear(); off.clear(); cap.clear(); hdrs.clear();
             sym_total = 0;
             for (uint32_t c = 0; c < nc; c++) {
+                hdrs.push_back(ch[c].hdr);
                 start.push_back(ch[c].start | (ch[c].fresh ? 1ull << 63 : 0ull));
                 stop.push_back(ch[c].last ? ~0ull : bit_behind(c));
                 const uint64_t cbits = bit_behind(c) - ch[c].start;
@@ -1504,6 +1729,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             }
             for (size_t k = 0; k < ph.size(); k++) {              // look-ahead: only their stops are read
                 start.push_back(ph[k].start);
+                hdrs.push_back(ph[k].hdr);
                 // (range mode: what follows the look-ahead entries in G is another slice: a chunk that runs over both of them is
                 //  stopped a few search chunks further on and declined)
                 stop.push_back(ph[k].last ? ~0ull : (k + 1 < ph.size() ? ph[k + 1].start
@@ -1533,6 +1759,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             GB(h2d(d_stop, stop.data(), (uint64_t)n_all * 8));
             GB(h2d(d_off, off.data(), (uint64_t)n_all * 8));
             GB(h2d(d_cap, cap.data(), (uint64_t)n_all * 8));
+            GB(h2d(d_hdr, hdrs.data(), (uint64_t)n_all * 8));
             if (!todo.empty()) {                                   // what the other chunks produced stays as it is
                 GB(h2d(A->status, status.data(), (uint64_t)nc * 4));
                 GB(h2d(d_len, out_len.data(), (uint64_t)nc * 8));
@@ -1540,7 +1767,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                 GB(h2d(A->todo, todo.data(), todo.size() * 4));
             }
             const uint32_t n_run = todo.empty() ? nc : (uint32_t)todo.size();
-            hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, n_all, A->sym, d_off, d_cap, d_len, d_end, A->status,
+            hipLaunchKernelGGL(inflate_kernel, dim3(n_run), dim3(64), 0, st, d_in, in_n - 8, d_start, d_stop, d_hdr, n_all, A->sym, d_off, d_cap, d_len, d_end, A->status,
                                todo.empty() ? (const uint32_t *)nullptr : A->todo, max_over);
             GB(d2h(status.data(), A->status, (uint64_t)nc * 4));
             GB(d2h(out_len.data(), d_len, (uint64_t)nc * 8));
@@ -1593,31 +1820,66 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                     status[c] = stc == 1 ? 1 : -21;                        // (falls through: a member's end, or not explainable)
                 }
                 if (status[c] == -21 && c + 1 < nc) {                      // ran past the next entry: the two chunks become one
-                    drop[c + 1] = 1;
-                    n_drop++;
+                    // (... and with them the entries inside blocks that follow: found with the tables of a block they are not in --
+                    //  a chunk of the search that held two block starts --, what they decoded means nothing)
+                    uint32_t k = c + 1;
+                    while (k + 1 < nc && ch[k + 1].hdr != ~0ull) k++;
                     Chunk a = ch[c];
-                    a.last = ch[c + 1].last;
-                    a.trailer = ch[c + 1].trailer;
+                    a.last = ch[k].last;
+                    a.trailer = ch[k].trailer;
                     keep(c, a);
-                    if (off[c + 1] == off[c] + cap[c]) n_cap.back() += cap[c + 1];      // their symbol regions are neighbours
-                    else relayout = true;
+                    for (uint32_t d = c + 1; d <= k; d++) {
+                        drop[d] = 1;
+                        n_drop++;
+                        if (off[d] == off[c] + n_cap.back()) n_cap.back() += cap[d];      // their symbol regions are neighbours
+                        else relayout = true;
+                    }
                     again.push_back((uint32_t)nxt.size() - 1);
                     continue;
                 }
-                if (status[c] == -20 || (status[c] == 1 && ch[c].last)) {  // a final block before the next entry / before the file's end
+                if (status[c] == -20 || status[c] == 1) {      // a final block before the next entry / before the file's end (its own, or run over to it)
                     const uint64_t hdr = e + 8 + 18 <= in_n ? gzip_header_len(in + e + 8, in_n - (e + 8)) : 0;
+                    if (!hdr && ch[c].hdr != ~0ull && !nxt.empty()) {         // (an entry inside a block that decoded garbage: see below)
+                        Chunk &pv = nxt.back();
+                        pv.last = ch[c].last;
+                        pv.trailer = ch[c].trailer;
+                        if (n_off.size() == nxt.size() && off[c] == n_off.back() + n_cap.back()) n_cap.back() += cap[c];
+                        else relayout = true;
+                        if (again.empty() || again.back() != (uint32_t)nxt.size() - 1) again.push_back((uint32_t)nxt.size() - 1);
+                        n_drop++;
+                        continue;
+                    }
                     if (!hdr) return no("chunk status", status[c] * 1000000ll + c);
                     Chunk a = ch[c];
                     a.last = true;
                     a.trailer = e;
                     keep(c, a);
                     const uint64_t d = (e + 8 + hdr) * 8;                  // the next member's first block
-                    for (uint32_t k = c + 1; k < nc && ch[k].start < d; k++) { drop[k] = 1; n_drop++; }      // "entries" within trailer and header
+                    bool was_last = ch[c].last;                            // (the new chunk ends the file if what it replaces did)
+                    uint64_t was_trailer = ch[c].trailer;
+                    // "entries" within the block, trailer and header -- and entries that claim to lie inside a block of the member that ends here
+                    for (uint32_t k = c + 1; k < nc && (ch[k].start < d || (ch[k].hdr != ~0ull && ch[k].hdr < d)); k++) {
+                        drop[k] = 1;
+                        n_drop++;
+                        if (ch[k].last) { was_last = true; was_trailer = ch[k].trailer; }
+                    }
                     if (c + 1 >= nc || drop[nc - 1])                       // (the look-ahead entries too)
                         for (size_t k = 0; k < ph.size() && ph[k].start < d; k++) over_ph = std::max<uint32_t>(over_ph, (uint32_t)k + 1);
-                    nxt.push_back(Chunk{d, true, ch[c].last, ch[c].trailer});      // (it ends the file if the split chunk did)
+                    nxt.push_back(Chunk{d, true, was_last, was_trailer});
                     n_members++;
                     relayout = true;
+                    continue;
+                }
+                if (ch[c].hdr != ~0ull && !nxt.empty()) {
+                    // an entry inside a block whose chunk cannot be explained (the chunk in front did not arrive there: what it decoded
+                    // means nothing): no entry -- the chunk in front takes its bytes and is inflated again
+                    Chunk &pv = nxt.back();
+                    pv.last = ch[c].last;
+                    pv.trailer = ch[c].trailer;
+                    if (n_off.size() == nxt.size() && off[c] == n_off.back() + n_cap.back()) n_cap.back() += cap[c];
+                    else relayout = true;
+                    if (again.empty() || again.back() != (uint32_t)nxt.size() - 1) again.push_back((uint32_t)nxt.size() - 1);
+                    n_drop++;
                     continue;
                 }
                 return no("chunk status", status[c] * 1000000ll + c);
@@ -1929,6 +2191,20 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
     *text = h;
     *len = n;
     return SS_OK;
+}
+
+// the pinned upload buffers of `n_files` concurrent .gz inputs (at most two sets are kept), made ahead of time
+extern "C" int ss_gz_warm_up(int n_files)
+{
+    std::vector<PinSet *> got;
+    for (int i = 0; i < std::min(n_files, 2); i++) {
+        PinSet *p = pin_get();
+        if (!p) break;
+        got.push_back(p);
+    }
+    const bool ok = (int)got.size() == std::min(n_files, 2);
+    for (PinSet *p : got) pin_put(p);
+    return ok ? SS_OK : SS_ENOMEM;
 }
 
 extern "C" int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_chain_fn chain, void *user)
