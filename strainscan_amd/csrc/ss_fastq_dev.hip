@@ -300,6 +300,9 @@ int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64
         if (hipMalloc((void **)&buf, n + 16) != hipSuccess) { rc = 1; break; }
         bool good = (pc.carry.empty() || hipMemcpy(buf, pc.carry.data(), pc.carry.size(), hipMemcpyHostToDevice) == hipSuccess) &&
                     (!pc.keep || hipMemcpy(buf + pc.carry.size(), d_text + pc.at, pc.keep, hipMemcpyDeviceToDevice) == hipSuccess);
+        // (a device-to-device hipMemcpy is only ENQUEUED on the null stream when it returns, and the extraction below runs on
+        //  a non-blocking stream of its own: seen as a piece that was "not FASTQ" once in twenty runs on a busy device)
+        good = good && hipStreamSynchronize(nullptr) == hipSuccess;
         char *d_flat = nullptr;
         uint64_t flen = 0, fcap = 0, nrec = 0;
         const int r = good ? fastq_text_to_flat_dev(buf, n, 0, 1, &d_flat, &flen, &fcap, &nrec) : SS_EHIP;

@@ -774,8 +774,9 @@ int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads
         char *dst = R->reserve(n);
         if (!dst) { ss_reads_destroy(R); return SS_ENOMEM; }
         const uint64_t plen = ss_reads::padded(n);
+        // (both only enqueued on the null stream when they return: the scans may run on any stream)
         if (hipMemcpy(dst, flat_dev, n, hipMemcpyDeviceToDevice) != hipSuccess ||
-            hipMemset(dst + n, '\n', plen - n) != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
+            hipMemset(dst + n, '\n', plen - n) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { ss_reads_destroy(R); return SS_EHIP; }
     }
     *out = R;
     return SS_OK;
