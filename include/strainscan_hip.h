@@ -346,6 +346,16 @@ int ss_enet_path_gram(const double *Q, const double *q, const double *yy, const 
                       int max_iter, double tol, int positive, const uint64_t *test_stats, double *mse,
                       double *coefs, int *iters, double *gaps);
 
+/* The same coordinate descent in its RESIDUAL form -- scikit-learn's _cd_fast.enet_coordinate_descent, what
+ * ElasticNet(alpha, precompute=False).fit runs at identify_strains...:451-455 -- for callers that hold the design matrix
+ * itself: R = y - X w lives on the device beside X, one pass over the rows per coordinate (32 B per row), block sums added
+ * in a fixed order.  X: host, column-major [p][N] doubles (Fortran order, as scikit-learn holds it), p <= 64; y: host [N];
+ * w [p]: in = the start, out = the coefficients; l1 = alpha * l1_ratio * N, l2 = alpha * (1 - l1_ratio) * N as
+ * ElasticNet.fit passes them; gap / n_iter as the Cython routine returns them (may be NULL).  [The product's refit uses
+ * ss_enet_path_gram with F = 1: for binary columns the Gram statistics are exact and p x p.] */
+int ss_enet_cd(const double *X, const double *y, uint64_t N, int p, double l1, double l2, int max_iter, double tol,
+               int positive, double *w, double *gap, int *n_iter);
+
 #ifdef __cplusplus
 }
 #endif

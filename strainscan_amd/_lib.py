@@ -131,6 +131,7 @@ SIGNATURES = {
     "ss_l2_pattern_stats": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "ss_enet_path_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, i32, C.c_double, i32, C.c_double, i32, vp, vp,
                                 vp, vp, vp]),
+    "ss_enet_cd": (i32, [vp, vp, u64, i32, C.c_double, C.c_double, i32, C.c_double, i32, vp, vp, vp]),
 }
 
 

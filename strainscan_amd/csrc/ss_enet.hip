@@ -16,6 +16,8 @@
 // Test-fold MSE: mean((X_te w - y_te)^2) = sum_m [c_m pred_m^2 - 2 pred_m s_m + t_m] / n_te.
 #include "ss_common.h"
 
+#include <algorithm>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -131,6 +133,154 @@ __global__ __launch_bounds__(64) void enet_path_kernel(const FoldIn *__restrict_
     }
 }
 
+// ---- the residual form: R = y - X w on the device beside X ---------------------------------------------------------
+// _cd_fast.enet_coordinate_descent (ElasticNet(precompute=False).fit, identify_strains...:451-455) keeps the residual
+// vector and touches a whole column per coordinate: per coordinate ONE pass over the rows -- R loses the update of the
+// coordinate before (applied late: it would be a pass of its own), gains w_j X_j, and X_j'R is summed on the way -- in
+// a fixed grid whose block sums are added in a fixed order (the same bits on every run), then one block finishes the
+// coordinate (soft threshold, the sweep's max |w| and max |dw|).  32 bytes per row and coordinate: HBM-bound.
+constexpr int CD_BLOCKS = 1024, CD_THREADS = 256, CD_MAXP = 64;
+
+struct CdState {
+    double w[CD_MAXP];
+    double norm[CD_MAXP];
+    double pend_w;          // R still holds + pend_w * X[pend_j]
+    int pend_j;
+    double w_max, d_w_max;
+    double red[CD_MAXP + 3];     // finished sums: X_j'R, R'R, R'y, y'y
+};
+
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < CD_THREADS / 64; i++) t += sh[i];
+    return t;                                                   // (thread 0 holds the block's sum)
+}
+
+// R = y - sum_j w_j X_j; partial sums of X_j'X_j (j < p) and y'y (slot p)
+__global__ __launch_bounds__(CD_THREADS) void cd_prep_kernel(const double *__restrict__ X, const double *__restrict__ y, uint64_t N, int p,
+                                                               const CdState *__restrict__ st, double *__restrict__ R, double *__restrict__ part)
+{
+    __shared__ double sh[CD_THREADS / 64];
+    __shared__ double sw[CD_MAXP];
+    if (threadIdx.x < p) sw[threadIdx.x] = st->w[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * CD_THREADS;
+    double yy = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * CD_THREADS + threadIdx.x; i < N; i += stride) {
+        const double yi = y[i];
+        double r = yi;
+        for (int j = 0; j < p; j++) { const double wj = sw[j]; if (wj != 0.0) r -= wj * X[(uint64_t)j * N + i]; }
+        R[i] = r;
+        yy += yi * yi;
+    }
+    const double t = block_sum(yy, sh);
+    if (threadIdx.x == 0) part[(uint64_t)p * gridDim.x + blockIdx.x] = t;
+    for (int j = 0; j < p; j++) {
+        double s = 0.0;
+        const double *Xj = X + (uint64_t)j * N;
+        for (uint64_t i = (uint64_t)blockIdx.x * CD_THREADS + threadIdx.x; i < N; i += stride) s += Xj[i] * Xj[i];
+        const double tj = block_sum(s, sh);
+        if (threadIdx.x == 0) part[(uint64_t)j * gridDim.x + blockIdx.x] = tj;
+    }
+}
+// sums of `n` partial rows -> st->red[0 .. n); what == 1: they are the column norms and y'y
+__global__ __launch_bounds__(CD_THREADS) void cd_sum_kernel(const double *__restrict__ part, int n, int blocks, CdState *st, int what)
+{
+    __shared__ double sh[CD_THREADS / 64];
+    for (int k = 0; k < n; k++) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += CD_THREADS) s += part[(uint64_t)k * blocks + b];
+        const double t = block_sum(s, sh);
+        if (threadIdx.x == 0) { st->red[k] = t; if (what == 1 && k < n - 1) st->norm[k] = t; }
+    }
+}
+// coordinate j: R <- R - pend_w X_pend + w_j X_j, partial sums of X_j'R
+__global__ __launch_bounds__(CD_THREADS) void cd_step_kernel(const double *__restrict__ X, uint64_t N, int j, const CdState *__restrict__ st,
+                                                               double *__restrict__ R, double *__restrict__ part)
+{
+    __shared__ double sh[CD_THREADS / 64];
+    const double wj = st->w[j], pw = st->pend_w;
+    const int pj = st->pend_j;
+    const double *Xj = X + (uint64_t)j * N, *Xp = X + (uint64_t)(pj < 0 ? 0 : pj) * N;
+    const uint64_t stride = (uint64_t)gridDim.x * CD_THREADS;
+    double s = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * CD_THREADS + threadIdx.x; i < N; i += stride) {
+        const double xj = Xj[i];
+        double r = R[i];
+        if (pj >= 0 && pw != 0.0) r -= pw * Xp[i];
+        if (wj != 0.0) r += wj * xj;
+        R[i] = r;
+        s += xj * r;
+    }
+    const double t = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(CD_THREADS) void cd_update_kernel(const double *__restrict__ part, int blocks, int j, double l1, double l2, int positive, CdState *st)
+{
+    __shared__ double sh[CD_THREADS / 64];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += CD_THREADS) s += part[b];
+    const double tmp = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        const double w_old = st->w[j];
+        double w_new;
+        if (positive && tmp < 0) w_new = 0.0;
+        else {
+            const double sg = (double)((tmp > 0) - (tmp < 0));
+            w_new = sg * fmax(fabs(tmp) - l1, 0.0) / (st->norm[j] + l2);
+        }
+        st->w[j] = w_new;
+        st->pend_j = j;
+        st->pend_w = w_new;
+        const double d = fabs(w_new - w_old);
+        if (d > st->d_w_max) st->d_w_max = d;
+        if (fabs(w_new) > st->w_max) st->w_max = fabs(w_new);
+    }
+}
+// the pending update applied; partial sums of X_j'R (j < p), R'R (p), R'y (p + 1)
+__global__ __launch_bounds__(CD_THREADS) void cd_gap_kernel(const double *__restrict__ X, const double *__restrict__ y, uint64_t N, int p,
+                                                              const CdState *__restrict__ st, double *__restrict__ R, double *__restrict__ part)
+{
+    __shared__ double sh[CD_THREADS / 64];
+    const double pw = st->pend_w;
+    const int pj = st->pend_j;
+    const double *Xp = X + (uint64_t)(pj < 0 ? 0 : pj) * N;
+    const uint64_t stride = (uint64_t)gridDim.x * CD_THREADS;
+    double rr = 0.0, ry = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * CD_THREADS + threadIdx.x; i < N; i += stride) {
+        double r = R[i];
+        if (pj >= 0 && pw != 0.0) r -= pw * Xp[i];
+        R[i] = r;
+        rr += r * r;
+        ry += r * y[i];
+    }
+    double t = block_sum(rr, sh);
+    if (threadIdx.x == 0) part[(uint64_t)p * gridDim.x + blockIdx.x] = t;
+    t = block_sum(ry, sh);
+    if (threadIdx.x == 0) part[(uint64_t)(p + 1) * gridDim.x + blockIdx.x] = t;
+    __threadfence();
+    __syncthreads();
+    for (int j = 0; j < p; j++) {
+        double s = 0.0;
+        const double *Xj = X + (uint64_t)j * N;
+        for (uint64_t i = (uint64_t)blockIdx.x * CD_THREADS + threadIdx.x; i < N; i += stride) s += Xj[i] * R[i];
+        const double tj = block_sum(s, sh);
+        if (threadIdx.x == 0) part[(uint64_t)j * gridDim.x + blockIdx.x] = tj;
+    }
+}
+__global__ void cd_clear_pending_kernel(CdState *st, int sweep_only)
+{
+    if (!sweep_only) { st->pend_j = -1; st->pend_w = 0.0; }
+    st->w_max = 0.0;
+    st->d_w_max = 0.0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -183,6 +333,91 @@ int ss_enet_path_gram(const double *Q, const double *q, const double *yy, const 
         if (e != hipSuccess) { ss::set_last_error("ss_enet_path_gram", __FILE__, __LINE__, e); rc = SS_EHIP; }
     }
     hipFree(d_in); hipFree(d_alphas); hipFree(d_mse); hipFree(d_coefs); hipFree(d_gaps); hipFree(d_iters); hipFree(d_ts);
+    return rc;
+}
+
+// The residual form (_cd_fast.enet_coordinate_descent; ElasticNet(precompute=False).fit at identify_strains...:451-455).
+// X: HOST, column-major [p][N] doubles (Fortran order, as scikit-learn holds it); y: host [N]; w [p]: in = the start, out =
+// the coefficients; l1 = alpha * l1_ratio * N and l2 = alpha * (1 - l1_ratio) * N, as ElasticNet.fit passes them.
+int ss_enet_cd(const double *X, const double *y, uint64_t N, int p, double l1, double l2, int max_iter, double tol, int positive,
+               double *w, double *gap_out, int *n_iter_out)
+{
+    if (!X || !y || !w || N == 0 || max_iter < 1) return SS_EINVAL;
+    if (p < 1 || p > CD_MAXP) return SS_ERANGE;
+    double *d_X = nullptr, *d_y = nullptr, *d_R = nullptr, *d_part = nullptr;
+    CdState *d_st = nullptr;
+    CdState h;
+    memset(&h, 0, sizeof h);
+    for (int j = 0; j < p; j++) h.w[j] = w[j];
+    h.pend_j = -1;
+    const int blocks = (int)std::min<uint64_t>(CD_BLOCKS, (N + CD_THREADS - 1) / CD_THREADS);
+    int rc = SS_OK;
+    hipError_t e = hipSuccess;
+#define CD(call) do { if (e == hipSuccess) e = (call); } while (0)
+    if (hipMalloc((void **)&d_X, (uint64_t)p * N * 8) != hipSuccess || hipMalloc((void **)&d_y, N * 8) != hipSuccess ||
+        hipMalloc((void **)&d_R, N * 8) != hipSuccess || hipMalloc((void **)&d_part, (uint64_t)(p + 2) * blocks * 8) != hipSuccess ||
+        hipMalloc((void **)&d_st, sizeof(CdState)) != hipSuccess)
+        rc = SS_ENOMEM;
+    double gap = 0.0;
+    int n_iter = 0;
+    if (!rc) {
+        CD(hipMemcpy(d_X, X, (uint64_t)p * N * 8, hipMemcpyHostToDevice));
+        CD(hipMemcpy(d_y, y, N * 8, hipMemcpyHostToDevice));
+        CD(hipMemcpy(d_st, &h, sizeof h, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cd_prep_kernel, dim3(blocks), dim3(CD_THREADS), 0, 0, d_X, d_y, N, p, d_st, d_R, d_part);
+        hipLaunchKernelGGL(cd_sum_kernel, dim3(1), dim3(CD_THREADS), 0, 0, d_part, p + 1, blocks, d_st, 1);
+        CD(hipMemcpy(&h, d_st, sizeof h, hipMemcpyDeviceToHost));
+        const double yy = h.red[p];
+        const double d_w_tol = tol;
+        tol *= yy;
+        gap = tol + 1.0;
+        for (n_iter = 0; n_iter < max_iter && e == hipSuccess; n_iter++) {
+            hipLaunchKernelGGL(cd_clear_pending_kernel, dim3(1), dim3(1), 0, 0, d_st, 1);
+            for (int j = 0; j < p; j++) {
+                if (h.norm[j] == 0.0) continue;
+                hipLaunchKernelGGL(cd_step_kernel, dim3(blocks), dim3(CD_THREADS), 0, 0, d_X, N, j, d_st, d_R, d_part);
+                hipLaunchKernelGGL(cd_update_kernel, dim3(1), dim3(CD_THREADS), 0, 0, d_part, blocks, j, l1, l2, positive, d_st);
+            }
+            CdState s2;
+            CD(hipMemcpy(&s2, d_st, sizeof s2, hipMemcpyDeviceToHost));
+            if (e != hipSuccess) break;
+            if (s2.w_max == 0.0 || s2.d_w_max / s2.w_max < d_w_tol || n_iter == max_iter - 1) {
+                hipLaunchKernelGGL(cd_gap_kernel, dim3(blocks), dim3(CD_THREADS), 0, 0, d_X, d_y, N, p, d_st, d_R, d_part);
+                hipLaunchKernelGGL(cd_sum_kernel, dim3(1), dim3(CD_THREADS), 0, 0, d_part, p + 2, blocks, d_st, 0);
+                hipLaunchKernelGGL(cd_clear_pending_kernel, dim3(1), dim3(1), 0, 0, d_st, 0);
+                CD(hipMemcpy(&s2, d_st, sizeof s2, hipMemcpyDeviceToHost));
+                if (e != hipSuccess) break;
+                double dual = 0.0, w_norm2 = 0.0, l1_norm = 0.0;
+                for (int j = 0; j < p; j++) {
+                    const double xta = s2.red[j] - l2 * s2.w[j];
+                    const double v = positive ? xta : fabs(xta);
+                    if (j == 0 || v > dual) dual = v;
+                    w_norm2 += s2.w[j] * s2.w[j];
+                    l1_norm += fabs(s2.w[j]);
+                }
+                const double R_norm2 = s2.red[p], Ry = s2.red[p + 1];
+                double cst = 1.0;
+                if (dual > l1) {
+                    cst = l1 / dual;
+                    gap = 0.5 * (R_norm2 + R_norm2 * cst * cst);
+                } else {
+                    gap = R_norm2;
+                }
+                gap += l1 * l1_norm - cst * Ry + 0.5 * l2 * (1.0 + cst * cst) * w_norm2;
+                if (gap < tol) { h = s2; n_iter++; break; }
+            }
+            h = s2;
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { ss::set_last_error("ss_enet_cd", __FILE__, __LINE__, e); rc = SS_EHIP; }
+    }
+#undef CD
+    hipFree(d_X); hipFree(d_y); hipFree(d_R); hipFree(d_part); hipFree(d_st);
+    if (!rc) {
+        for (int j = 0; j < p; j++) w[j] = h.w[j];
+        if (gap_out) *gap_out = gap;
+        if (n_iter_out) *n_iter_out = n_iter;
+    }
     return rc;
 }
 

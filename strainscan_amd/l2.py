@@ -171,6 +171,21 @@ def enet_path_gram(Q, q, yy, n_train, alphas, n_test=None, test_stats=None, l1_r
     return dict(mse=mse, coefs=coefs, iters=iters, gaps=gaps)
 
 
+def enet_cd(X, y, l1, l2, w0=None, max_iter=5000, tol=1e-4, positive=True):
+    """The residual form on the device (ss_enet_cd; scikit-learn's _cd_fast.enet_coordinate_descent, what
+    ElasticNet(precompute=False).fit runs at identify_strains...:451-455) for a caller that holds X itself:
+    -> (w [p], gap, n_iter).  l1 = alpha * l1_ratio * n, l2 = alpha * (1 - l1_ratio) * n."""
+    import ctypes as C
+    Xf = np.asfortranarray(X, np.float64)
+    y = np.ascontiguousarray(y, np.float64)
+    n, p = Xf.shape
+    w = np.zeros(p) if w0 is None else np.array(w0, np.float64)
+    gap, it = C.c_double(), C.c_int()
+    _lib.check(_lib.lib().ss_enet_cd(Xf.ctypes.data_as(C.c_void_p), _lib.ptr(y), n, p, float(l1), float(l2), int(max_iter), float(tol),
+                                     int(positive), _lib.ptr(w), C.byref(gap), C.byref(it)), "ss_enet_cd")
+    return w, gap.value, it.value
+
+
 def gram_from_stats(stats, p):
     """{count, sum y, sum y^2} per p-bit pattern -> (Q [p,p], q [p], yy, n) as exact integers
     converted once to float64 (what X'X, X'y, y'y, len(y) are for a 0/1 matrix)."""

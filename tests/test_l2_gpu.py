@@ -426,3 +426,55 @@ def test_csr_pack_and_quantiles_edge_inputs():
                 inside = nz[(nz >= lo) & (nz <= hi)]
                 assert int(q["cnt_in"][s_]) == inside.size and int(q["sum_in"][s_]) == int(inside.sum())
     img.close()
+
+
+def test_enet_cd_residual_form(golden_dir):
+    """ss_enet_cd -- the residual form of the refit (scikit-learn's _cd_fast.enet_coordinate_descent, what
+    ElasticNet(precompute=False).fit runs at identify_strains...:451-455) with X and R on the device -- against
+    (a) the coefficients scikit-learn 0.24.2 produced for the golden cases, (b) the oracle's restatement of the Cython loop:
+    same number of sweeps, coefficients to rounding (the sums are added in another order), at N = 3 M rows too; also without
+    the positivity constraint, from a warm start, and with a column of zeros."""
+    from oracle import oracle as orc
+    from strainscan_amd import l2
+    from tests import scenarios as sc
+    g = json.load(open(os.path.join(golden_dir, "l2_detect.json")))
+    arrs = np.load(os.path.join(golden_dir, "l2_enet_arrays.npz"))
+    done = 0
+    for name in sc.L2_CASES:
+        if name + "_coef" not in arrs.files:
+            continue
+        case = sc.l2_case(name)
+        X, y = case["X"].toarray(), case["y"]
+        O = case["O"].toarray()
+        ln = O[:, [c - 1 for c in case["all_cls"]]].sum(axis=1)
+        ln[ln > 1] = 0
+        cols = orc.prescan(X, y, y * ln, case["ids"], case["msn"] * case["ksize"], case["l2"], case["pmode"], case["emode"])[0]
+        if len(cols) < 2:
+            continue
+        keep = (y >= case["npp25"]) & (y <= case["npp75"]) & (y <= case["npp_out"])
+        Xs, ys = X[keep][:, cols].astype(np.float64), y[keep].astype(np.float64)
+        a, n = g[name]["alpha"], len(ys)
+        w, gap, it = l2.enet_cd(Xs, ys, a * 0.5 * n, a * 0.5 * n)
+        assert np.allclose(w, arrs[name + "_coef"], rtol=0, atol=ABUND_TOL), name
+        assert it == g[name]["n_iter"], name
+        wo, go, ito = orc.enet_cd(np.zeros(len(cols)), a * 0.5 * n, a * 0.5 * n, Xs, ys)
+        assert it == ito and np.allclose(w, wo, rtol=1e-10, atol=1e-12), name
+        done += 1
+    assert done >= 2
+    rs = np.random.RandomState(11)
+    for n, p, positive in ((3_000_000, 6, True), (200_001, 16, False), (70_000, 3, True), (257, 2, True)):
+        X = (rs.rand(n, p) < rs.uniform(0.2, 0.7, p)).astype(np.float64)
+        if p == 3:
+            X[:, 1] = 0.0                                   # a strain without a k-mer among the kept rows
+        truth = rs.uniform(0, 30, p) * (rs.rand(p) < 0.7)
+        y = np.floor(X @ truth + rs.poisson(2.0, n)).astype(np.float64)
+        alpha = 0.05 * np.abs(X.T @ y).max() / n
+        l1, l2_ = alpha * 0.5 * n, alpha * 0.5 * n
+        w0 = rs.uniform(0, 5, p) if p == 16 else np.zeros(p)
+        w, gap, it = l2.enet_cd(X, y, l1, l2_, w0=w0, positive=positive)
+        wo, go, ito = orc.enet_cd(w0.copy(), l1, l2_, X, y, positive=positive)
+        assert it == ito, (n, p, it, ito)
+        assert np.allclose(w, wo, rtol=1e-9, atol=1e-11), (n, p, w, wo)
+        assert abs(gap - go) <= 1e-6 * max(1.0, abs(go))
+        if p == 3:
+            assert w[1] == 0.0
