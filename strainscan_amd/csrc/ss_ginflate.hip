@@ -51,7 +51,12 @@ constexpr uint16_t UNRES = 0x8000;          // symbol = UNRES | index into the 3
 #define SS_GZ_LITBITS 9
 #endif
 constexpr int RING = SS_GZ_RING;            // most recent symbols of a wave, in LDS
-constexpr int STAGE = 2048;                 // compressed bytes staged in LDS at a time (two halves of 1 KB)
+#ifndef SS_GZ_STAGE
+#define SS_GZ_STAGE 1024
+#endif
+constexpr int STAGE = SS_GZ_STAGE;          // compressed bytes staged in LDS at a time (two halves); LDS decides the waves per SIMD
+constexpr uint32_t STAGE_DW = STAGE / 4, HALF_DW = STAGE_DW / 2, STAGE_MASK = STAGE_DW - 1;
+static_assert(STAGE == 1024 || STAGE == 2048, "a half is filled by one 8- or 16-byte load per lane");
 
 // length code li = symbol - 257 and distance code ds -> base value and extra bits (RFC 1951 3.2.5), computed: a table
 // lookup with a data-dependent index is a memory (or LDS) round trip in the middle of a dependent chain
@@ -106,15 +111,20 @@ struct LHuff {
     int maxlen;                                                     // first code value and where its symbols start in sorted[]
 };
 struct WaveState {
-    LHuff<SS_GZ_LITBITS, 288> lit;
+    union {                              // the code-length code is dead when the literal/length code is built from what it decoded
+        LHuff<SS_GZ_LITBITS, 288> lit;
+        LHuff<7, 19> clc;
+    };
     LHuff<8, 32> dist;
-    LHuff<7, 19> clc;
     uint8_t lens[320];
     uint16_t ring[RING];
     alignas(16) uint32_t stage[STAGE / 4];
+#ifdef SS_GZ_PAD_LDS
+    uint8_t pad[SS_GZ_PAD_LDS];        // (experiment: fewer waves per SIMD)
+#endif
 };
 
-// Bit positions over the LDS stage (512 dwords = two halves of 1 KB; the wave refills a half with 16-byte loads when the
+// Bit positions over the LDS stage (STAGE_DW dwords = two halves; the wave refills a half with one load per lane when the
 // position has left it).  `bp` is the absolute bit position of the next unread bit; the block loop below lets the 64
 // lanes decode at bp + lane, the headers are read through a small scalar cache (buf / cnt) of the bits at bp.
 // Everything here is called wave-uniformly; LDS operations of one wave execute in order, so no barrier is needed
@@ -123,33 +133,38 @@ struct SBits {
     const uint32_t *in;      // global, dword aligned, padded with zeros behind the data
     uint64_t n;              // bytes of data
     uint64_t bp;             // next bit
-    uint64_t staged_to;      // dword index up to which the stage holds data: it covers [staged_to - 512, staged_to)
+    uint64_t staged_to;      // dword index up to which the stage holds data: it covers [staged_to - STAGE_DW, staged_to)
     uint64_t buf;            // scalar cache: cnt bits from bp on
     int cnt;
 };
 __device__ __forceinline__ void sb_fill_half(WaveState &S, const SBits &b, uint64_t w0)
 {
-    // dwords [w0, w0 + 256) -> stage; w0 is a multiple of 256
+    // dwords [w0, w0 + HALF_DW) -> stage; w0 is a multiple of HALF_DW
     const int lane = threadIdx.x & 63;
-    const uint4 v = *reinterpret_cast<const uint4 *>(b.in + w0 + (uint64_t)lane * 4);
-    *reinterpret_cast<uint4 *>(&S.stage[(w0 & 511) + lane * 4]) = v;
+    if constexpr (HALF_DW == 256) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(b.in + w0 + (uint64_t)lane * 4);
+        *reinterpret_cast<uint4 *>(&S.stage[(w0 & STAGE_MASK) + lane * 4]) = v;
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(b.in + w0 + (uint64_t)lane * 2);
+        *reinterpret_cast<uint2 *>(&S.stage[(w0 & STAGE_MASK) + lane * 2]) = v;
+    }
     __builtin_amdgcn_wave_barrier();
 }
-// the dwords [bp >> 5, (bp >> 5) + 256) are in the stage afterwards (a start, a jump or a step back reloads both halves;
-// the sync search tries positions a few bits apart and finds its 2 KB still there)
+// the dwords [bp >> 5, (bp >> 5) + HALF_DW) are in the stage afterwards (a start, a jump or a step back reloads both halves;
+// the sync search tries positions a few bits apart and finds its data still there)
 __device__ __forceinline__ void sb_stage(WaveState &S, SBits &b)
 {
     const uint64_t w = b.bp >> 5;
-    if (w >= b.staged_to || w + 512 < b.staged_to) {
-        const uint64_t h0 = w & ~255ull;
+    if (w >= b.staged_to || w + STAGE_DW < b.staged_to) {
+        const uint64_t h0 = w & ~(uint64_t)(HALF_DW - 1);
         __builtin_amdgcn_wave_barrier();
         sb_fill_half(S, b, h0);
-        sb_fill_half(S, b, h0 + 256);
-        b.staged_to = h0 + 512;
+        sb_fill_half(S, b, h0 + HALF_DW);
+        b.staged_to = h0 + STAGE_DW;
     } else {
-        while (w + 256 >= b.staged_to) {     // the half behind the position is refilled with the data behind the other one
+        while (w + HALF_DW >= b.staged_to) {     // the half behind the position is refilled with the data behind the other one
             sb_fill_half(S, b, b.staged_to);
-            b.staged_to += 256;
+            b.staged_to += HALF_DW;
         }
     }
 }
@@ -165,8 +180,8 @@ __device__ __forceinline__ void sb_load(WaveState &S, SBits &b)
 {
     sb_stage(S, b);
     const uint32_t w = (uint32_t)(b.bp >> 5);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.stage[w & 511]);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.stage[(w + 1) & 511]);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.stage[w & STAGE_MASK]);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.stage[(w + 1) & STAGE_MASK]);
     const int sh = (int)(b.bp & 31);
     b.buf = (((uint64_t)hi << 32) | lo) >> sh;
     b.cnt = 64 - sh;
@@ -306,7 +321,7 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
         sb_stage(S, b);
         const uint64_t p = b.bp + (uint64_t)lane;
         const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-        const uint32_t d0 = S.stage[w & 511], d1 = S.stage[(w + 1) & 511];
+        const uint32_t d0 = S.stage[w & STAGE_MASK], d1 = S.stage[(w + 1) & STAGE_MASK];
         const uint32_t bits = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
         const uint32_t e = S.clc.tent[bits & 127u];
         const uint32_t l = e >> 9, sy = e & 511u;
@@ -549,7 +564,7 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
         {
             const uint64_t p = b.bp + (uint64_t)lane;
             const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-            const uint32_t d0 = S.stage[w & 511], d1 = S.stage[(w + 1) & 511], d2 = S.stage[(w + 2) & 511];
+            const uint32_t d0 = S.stage[w & STAGE_MASK], d1 = S.stage[(w + 1) & STAGE_MASK], d2 = S.stage[(w + 2) & STAGE_MASK];
             uint64_t bits = (((uint64_t)d1 << 32) | d0) >> sh;
             if (sh) bits |= (uint64_t)d2 << (64 - sh);
             const uint32_t e = S.lit.tent[(uint32_t)bits & ((1u << SS_GZ_LITBITS) - 1)];
@@ -786,7 +801,7 @@ __global__ __launch_bounds__(64) void subsync_kernel(const uint8_t *in, uint64_t
                 sb_stage(S, b);
                 const uint64_t p = base + (uint64_t)lane;
                 const uint32_t wd = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
-                const uint32_t d0 = S.stage[wd & 511], d1 = S.stage[(wd + 1) & 511], d2 = S.stage[(wd + 2) & 511];
+                const uint32_t d0 = S.stage[wd & STAGE_MASK], d1 = S.stage[(wd + 1) & STAGE_MASK], d2 = S.stage[(wd + 2) & STAGE_MASK];
                 uint64_t bits = (((uint64_t)d1 << 32) | d0) >> sh;
                 if (sh) bits |= (uint64_t)d2 << (64 - sh);
                 const uint32_t step = lane_item_bits(S, bits, lit_maxlen, dist_maxlen, cx.dist_usable);
