@@ -83,6 +83,13 @@ __device__ __forceinline__ uint4 header_bytes(const uint8_t *in, uint64_t p)
     __builtin_memcpy(&v, in + (p >> 3), 16);
     return v;
 }
+// the first 13 bits only (block type, HLIT, HDIST): one position in nine passes
+__device__ __forceinline__ bool header_quick(const uint4 v, uint64_t p)
+{
+    const uint64_t lo = (uint64_t)v.x | (uint64_t)v.y << 32;
+    const uint32_t h = (uint32_t)(lo >> (p & 7));                 // (13 bits behind a shift of at most 7)
+    return (h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u;
+}
 __device__ __forceinline__ bool header_prefilter(const uint4 v, uint64_t p)
 {
     uint64_t lo = (uint64_t)v.x | (uint64_t)v.y << 32, hi = (uint64_t)v.z | (uint64_t)v.w << 32;
@@ -116,7 +123,7 @@ struct WaveState {
         LHuff<7, 19> clc;
     };
     LHuff<8, 32> dist;
-    uint8_t lens[320];
+    alignas(16) uint8_t lens[320];       // (code lengths while a header is read; 64 words of scratch while a block's items are decoded)
     uint16_t ring[RING];
     alignas(16) uint32_t stage[STAGE / 4];
 #ifdef SS_GZ_PAD_LDS
@@ -298,6 +305,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
     return (uint32_t)x;
 }
 
+// inclusive prefix MAXIMUM over the 64 lanes (unsigned, 0 = nothing yet), the same six DPP steps
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v)
+{
+    int x = (int)v;
+#define SS_MAXU(a, b) (int)max((uint32_t)(a), (uint32_t)(b))
+    x = SS_MAXU(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));      // row_shr:1
+    x = SS_MAXU(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));      // row_shr:2
+    x = SS_MAXU(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));      // row_shr:4
+    x = SS_MAXU(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));      // row_shr:8
+    x = SS_MAXU(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+    x = SS_MAXU(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
+#undef SS_MAXU
+    return (uint32_t)x;
+}
+
 __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
 {
     const int hlit = (int)sb_get(S, b, 5) + 257, hdist = (int)sb_get(S, b, 5) + 1, hclen = (int)sb_get(S, b, 4) + 4;
@@ -317,6 +339,7 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
     __shared__ uint8_t s_all[320];
     const int total = hlit + hdist, lane = threadIdx.x & 63;
     int i = 0, prev = -1;
+    uint32_t kraft_lit = 0;
     while (i < total) {
         sb_stage(S, b);
         const uint64_t p = b.bp + (uint64_t)lane;
@@ -352,6 +375,16 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
         const int got = __shfl((int)vc, src < 0 ? 0 : src, 64);
         const int val = src < 0 ? prev : got;
         if (__ballot(used && val < 0)) return false;                             // "repeat the previous length" with none before
+        // Kraft sums as the lengths arrive: a position that is no header -- the sync search tries ~40 per chunk -- decodes to
+        // random lengths, and those over-subscribe a code within the first window or two (a symbol adds 1 700 / 32 768 on average):
+        // out here, not after all ~300 lengths and the counting of huff_build
+        {
+            const uint32_t idx0 = (uint32_t)i + before;                          // (the literal/length code's lengths come first)
+            const uint32_t n_lit = !used || idx0 >= (uint32_t)hlit ? 0u : min(rep, (uint32_t)hlit - idx0);
+            const uint32_t unit = val > 0 ? (1u << (15 - val)) : 0u;
+            kraft_lit += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(n_lit * unit), 63);
+            if (kraft_lit > 32768u) return false;
+        }
         if (used)
             for (uint32_t r = 0; r < rep; r++) s_all[i + (int)before + (int)r] = (uint8_t)val;
         prev = __builtin_amdgcn_readlane(val, lu);
@@ -527,19 +560,15 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
     const uint64_t mine_below = lane ? (~0ull >> (64 - lane)) : 0ull;
     // the window whose far matches are still loading while the next one is decoded (software pipeline: a far match reads
     // what this wave wrote tens of KB ago -- with thousands of waves at work that is HBM or the Infinity Cache, ~2 us)
-    bool p_active = false, p_far = false;
+    bool p_active = false, p_fv = false;
     uint64_t p_farmask = 0, p_near = 0;
-    uint32_t p_at = 0, p_mlen = 0, p_val = 0, p_got[FAR_MAX / 2];
-#pragma unroll
-    for (uint32_t k = 0; k < FAR_MAX / 2; k++) p_got[k] = 0;
+    uint32_t p_at = 0, p_mlen = 0, p_val = 0, p_fdst = 0;
+    uint16_t p_fg = 0;
     int ret = 0;
 #define GI_FINISH()                                                                                                          \
     do {                                                                                                                     \
         if (p_active) {                                                                                                      \
-            if (p_farmask) {                                                                                                 \
-                _Pragma("unroll") for (uint32_t k = 0; k < FAR_MAX; k++)                                                      \
-                    if (p_far && k < p_mlen) S.ring[(p_at + k) & (RING - 1)] = (uint16_t)(p_got[k >> 1] >> (16 * (k & 1)));   \
-            }                                                                                                                \
+            if (p_farmask && p_fv) S.ring[p_fdst & (RING - 1)] = p_fg;                                                       \
             uint64_t mt_ = p_near;                                                                                           \
             while (mt_) {                                                                                                    \
                 const int fm_ = __ffsll((long long)mt_) - 1;                                                                 \
@@ -633,19 +662,35 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
 #else
                 const bool far = is_match && mlen <= FAR_MAX && val > RING_REACH + mlen - 1;      // every symbol beyond the ring's reach
 #endif
-                p_farmask = __ballot(far);
+                // ONE LANE PER SYMBOL of those matches (a window has ~4 of them, ~30 symbols): a prefix sum over their lengths
+                // gives every match its run of slots, the match's lane number is dropped at the run's first slot (LDS) and
+                // spread over the run by a prefix maximum; slot t then fetches its match's position and distance (two
+                // bpermutes) and loads ITS symbol -- one load instruction per window instead of twelve
+                const uint32_t fl = far ? mlen : 0u;
+                const uint32_t fincl = wave_inclusive_sum(fl);
+                const bool far2 = far && fincl <= 64u;     // (what does not fit the 64 slots goes the near way)
+                p_farmask = __ballot(far2);
                 if (p_farmask) {
-                    const int32_t sp0 = (int32_t)at - (int32_t)val;
-#pragma unroll
-                    for (uint32_t k = 0; k < FAR_MAX; k += 2) {
-                        uint16_t g0 = (uint16_t)(UNRES | (uint32_t)((int32_t)WSIZE + sp0 + (int32_t)k));
-                        uint16_t g1 = (uint16_t)(UNRES | (uint32_t)((int32_t)WSIZE + sp0 + (int32_t)k + 1));
-                        if (far && k < mlen && sp0 + (int32_t)k >= 0) g0 = o.out[sp0 + (int32_t)k];
-                        if (far && k + 1 < mlen && sp0 + (int32_t)k + 1 >= 0) g1 = o.out[sp0 + (int32_t)k + 1];
-                        p_got[k >> 1] = (uint32_t)g0 | ((uint32_t)g1 << 16);
-                    }
+                    uint32_t *own = reinterpret_cast<uint32_t *>(S.lens);
+                    __builtin_amdgcn_wave_barrier();
+                    own[lane] = 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (far2) own[fincl - fl] = (uint32_t)lane + 1u;
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t ow = wave_inclusive_max(own[lane]);
+                    const uint32_t slots = (uint32_t)__builtin_amdgcn_readlane((int)fincl, 63 - __clzll((long long)p_farmask));
+                    const int from = (int)((ow ? ow - 1u : 0u) << 2);
+                    const uint32_t o_at = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)at);
+                    const uint32_t o_vf = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(val | ((fincl - fl) << 16)));      // distance <= 32768 | first slot
+                    const uint32_t k = (uint32_t)lane - (o_vf >> 16);
+                    const int32_t sp = (int32_t)o_at - (int32_t)(o_vf & 0xFFFFu) + (int32_t)k;
+                    p_fv = (uint32_t)lane < slots;
+                    uint16_t g = (uint16_t)(UNRES | (uint32_t)((int32_t)WSIZE + sp));
+                    if (p_fv && sp >= 0) g = o.out[sp];
+                    p_fg = g;
+                    p_fdst = o_at + k;
                 }
-                p_far = far; p_at = at; p_mlen = mlen; p_val = val;
+                p_at = at; p_mlen = mlen; p_val = val;
                 p_near = matches & ~p_farmask;
                 p_active = true;
                 n += total;
@@ -719,27 +764,49 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
     uint64_t found = ~0ull;
     SBits b;
     sb_init(b, in, in_n, lo);
+    // Two sieves.  The first 13 bits (type, HLIT, HDIST) are tested for every position; the one in nine that passes is QUEUED, and
+    // the second sieve -- the code-length code's Kraft sum, a loop of up to 19 steps that a wave runs as long as its
+    // slowest lane -- only sees full waves of queued positions (a ninth of the loop's executions).  The queue is in
+    // position order, so the first confirmed entry is still the first in the chunk.
+    __shared__ uint32_t queue[128];
+    uint32_t qn = 0;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint4 ahead = header_bytes(in, lo + lane);             // the next 64 positions' bytes are loaded while these are tested
     for (uint64_t p0 = lo; p0 < hi && found == ~0ull; p0 += 64) {
         const uint64_t p = p0 + lane;
         const uint4 bytes = ahead;
         ahead = header_bytes(in, p + 64);                  // (the input is padded by 8 KB)
-        const bool ok = p < hi && header_prefilter(bytes, p);
-        uint64_t m = __ballot(ok);
-        while (m && found == ~0ull) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint64_t cand = p0 + (uint64_t)l;
-            // confirm with the whole wave: the header parses, the block decodes to its end, and what follows looks like
-            // the start of a block
-            sb_seek(b, cand);
-            OutState o{nullptr, 0, 0, 0};
-            // a complete, valid header (zlib's rules) and SS_GZ_PROBE symbols that decode: a position inside a block
-            // passes this with negligible probability, and if one ever does, the chunk will not end on the next entry and
-            // the file goes to the host inflater
-            const int r = inflate_block(S, b, o, false, probe);
-            if (count_tries && lane == 0) atomicAdd(&g_sync_tries, 1u);
-            if (r == 2 || (r == 0 && o.n > 0)) found = cand;
+        const bool ok1 = p < hi && header_quick(bytes, p);
+        const uint64_t m1 = __ballot(ok1);
+        if (ok1) queue[qn + (uint32_t)__popcll(m1 & below)] = (uint32_t)(p - lo);
+        qn += (uint32_t)__popcll(m1);
+        const bool last = p0 + 64 >= hi;
+        while ((qn >= 64u || (last && qn > 0u)) && found == ~0ull) {
+            const uint32_t take = min(qn, 64u);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t q = (uint32_t)lane < take ? queue[lane] : 0u;
+            const uint64_t pos = lo + (uint64_t)q;
+            const bool ok = (uint32_t)lane < take && header_prefilter(header_bytes(in, pos), pos);
+            uint64_t m = __ballot(ok);
+            while (m && found == ~0ull) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint64_t cand = lo + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)q, l);
+                // confirm with the whole wave: a complete, valid header (zlib's rules) and SS_GZ_PROBE symbols that decode: a
+                // position inside a block passes this with negligible probability, and if one ever does, the chunk in front
+                // runs over it (inflate_kernel)
+                sb_seek(b, cand);
+                OutState o{nullptr, 0, 0, 0};
+                const int r = inflate_block(S, b, o, false, probe);
+                if (count_tries && lane == 0) atomicAdd(&g_sync_tries, 1u);
+                if (r == 2 || (r == 0 && o.n > 0)) found = cand;
+            }
+            const uint32_t rest = qn - take;               // what is queued behind the 64 taken moves to the front
+            const uint32_t mv = (uint32_t)lane < rest ? queue[64 + lane] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if ((uint32_t)lane < rest) queue[lane] = mv;
+            __builtin_amdgcn_wave_barrier();
+            qn = rest;
         }
     }
     if (lane == 0) entry[c] = found;
@@ -1408,10 +1475,15 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
     Arena *A = nullptr;
     auto cleanup = [&](bool keep_text) {
+        auto now = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+        const double c0 = now();
         void *scratch[] = {d_in, d_entry, d_crc, d_tab};
         for (void *q : scratch) if (q) hipFreeAsync(q, st);
+        const double c1 = now();
         hipStreamSynchronize(st);
+        const double c2 = now();
         hipStreamDestroy(st);
+        if (trace) fprintf(stderr, "[ginflate] cleanup: free %.4f, sync %.4f, stream destroy %.4f s\n", c1 - c0, c2 - c1, now() - c2);
         if (!keep_text) { arena_put(A); A = nullptr; }            // (else the caller holds it, with the text, until gpu_gunzip_done)
     };
     auto no = [&](const char *why, long long a = 0) {
