@@ -254,6 +254,7 @@ def measure_gz_ingest(reads, n_pair, base):
     out = dict(reads=2 * n_pair, files=2, gz_mb=round(sum(os.path.getsize(p) for p in gz) / 1e6, 1), gzip_level=6,
                compress_s=round(time.perf_counter() - t0, 1), host_cpus=int(_lib.lib().ss_host_cpus()))
     prev = os.environ.get("SS_GZ_GPU")
+    _lib.warm_up(gz=2)       # (as the CLI does on its warm-up thread when it is given .gz files: the pinned upload buffers)
     try:
         for mode, key in (("1", "device_ms"), ("0", "host_inflaters_ms")):
             os.environ["SS_GZ_GPU"] = mode
@@ -277,7 +278,8 @@ def measure_gz_ingest(reads, n_pair, base):
     out["m_reads_per_s_device"] = round(2 * n_pair / out["device_ms"] / 1e3, 1)
     out["m_reads_per_s_host_inflaters"] = round(2 * n_pair / out["host_inflaters_ms"] / 1e3, 1)
     out["note"] = ("file -> resident flat blocks, best of 3, page cache warm; device = ss_ginflate.hip + ss_fastq_dev.hip (the "
-                   "default), host = the threaded two-pass inflater on this box's CPUs + parse threads")
+                   "default; pinned upload buffers made beforehand as the CLI's warm-up thread does), host = the threaded two-pass "
+                   "inflater on this box's CPUs + parse threads")
     return out
 
 
@@ -597,14 +599,17 @@ def main(argv=None):
     readset = None
     if not args.no_readset and not args.calib_stream:
         prep = []
-        for _ in range(3):                          # first call: first touch of 3 GB of fresh device memory
+        rs_loc = None
+        for _ in range(5):                          # first call: first touch of 3 GB of fresh device memory
+            if rs_loc is not None:
+                rs_loc.close()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             rs_loc = _lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
             torch.cuda.synchronize()
             prep.append((time.perf_counter() - t1) * 1e3)
-            if len(prep) < 3:
-                rs_loc.close()
+        # (median of five: the call allocates the new 3 GB slab, and on some boxes of the pool a hipMalloc of that size takes
+        #  tens of ms now and then -- scripts/dev/t_bigalloc.py; the kernels' share is 3.6 ms, profiles/r03_reorder_kernel_stats.csv)
         prep_ms = float(np.median(prep))
         ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -639,7 +644,7 @@ def main(argv=None):
             dt2 = float(tt.item())
         k2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
         readset = dict(order="locality (records binned by the minimizer of their first k-mer, ~4 records per bin: ss_reorder.hip)",
-                       prepare_ms=round(prep_ms, 2), prepare_ms_first_call=round(prep[0], 2), ms_per_step=round(dt2 / args.steps * 1e3, 3),
+                       prepare_ms=round(prep_ms, 2), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
                        value=round(args.reads * world * args.steps / dt2 / 1e6, 3), unit="M reads/s", kernel_ms=round(k2, 3),
                        frac_algorithmic=round(args.reads * BYTES_PER_READ / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                        node_stats_equal=bool(torch.equal(stats, stats2)),
