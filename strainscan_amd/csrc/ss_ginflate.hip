@@ -623,13 +623,15 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
         GZ_T(tw1);
         // ---- the chain of items from bp: a stopping item (end of block, undecodable) steps out of the window
         const uint32_t step = (info & (F_EOB | F_BAD)) ? 64u : (info & 63u);
+        // (three scalar instructions, a readlane and the branch per item: the bit is set in place, the last item is looked up
+        //  afterwards -- the scalar unit is shared by the CU's four SIMDs and this kernel keeps it as busy as the vector units)
         uint64_t chain = 0;
-        uint32_t pos = 0, last;
+        uint32_t pos = 0;
         do {
-            last = pos;
-            chain |= 1ull << pos;
+            asm volatile("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(pos));
             pos += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)pos);
         } while (pos < 64);
+        const uint32_t last = 63u - (uint32_t)__clzll((long long)chain);
         uint32_t stop = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)last);
         stop = (stop & (F_EOB | F_BAD)) ? stop : 0u;
         if (stop) { chain &= ~(1ull << last); pos = last; }
