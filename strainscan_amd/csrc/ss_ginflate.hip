@@ -210,7 +210,7 @@ __device__ __forceinline__ bool sb_past_end(const SBits &b) { return b.bp > b.n 
 // The 64 lanes hold the lengths of symbols lane, lane + 64, ...; a ballot per code length counts the codes and ranks a
 // lane's symbol among those of its length, so the Kraft sum rejects a wrong header (the sync search sees ~80 per chunk)
 // before any table is written.
-template <int PB, int MAXSYM>
+template <int PB, int MAXSYM, int MAXLEN = 15>
 __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
 {
     constexpr int NS = (MAXSYM + 63) / 64;
@@ -222,7 +222,7 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
     uint32_t cnt[16];
     cnt[0] = 0;
 #pragma unroll
-    for (int l = 1; l <= 15; l++) {
+    for (int l = 1; l <= MAXLEN; l++) {
         uint32_t c = 0;
 #pragma unroll
         for (int s = 0; s < NS; s++) c += (uint32_t)__popcll(__ballot(ls[s] == l));
@@ -231,7 +231,7 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
     int left = 1, maxlen = 0;
     bool over = false;
 #pragma unroll
-    for (int l = 1; l <= 15; l++) {
+    for (int l = 1; l <= MAXLEN; l++) {
         left = 2 * left - (int)cnt[l];
         over = over || left < 0;
         if (cnt[l]) maxlen = l;
@@ -241,7 +241,7 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
     __syncthreads();
     uint32_t code = 0, off = 0;
 #pragma unroll
-    for (int l = 1; l <= 15; l++) {
+    for (int l = 1; l <= MAXLEN; l++) {
         const uint32_t c = cnt[l];
         if (lane == 0) { h.count[l] = (uint16_t)c; h.first[l] = (uint16_t)code; h.index[l] = (uint16_t)off; }
         if (c) {
@@ -327,11 +327,18 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
     __syncthreads();
     if ((threadIdx.x & 63) < 19) S.lens[threadIdx.x & 63] = 0;
     __syncthreads();
-    for (int i = 0; i < hclen; i++) {
-        const uint32_t v = sb_get(S, b, 3);
-        if ((threadIdx.x & 63) == 0) S.lens[c_cl_order[i]] = (uint8_t)v;
+    {
+        // the HCLEN 3-bit lengths (at most 57 bits) in one go: lane i takes the i-th
+        sb_stage(S, b);
+        const int li = threadIdx.x & 63;
+        const uint64_t p = b.bp + 3ull * (uint64_t)li;
+        const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+        const uint32_t d0 = S.stage[w & STAGE_MASK], d1 = S.stage[(w + 1) & STAGE_MASK];
+        const uint32_t v = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) & 7u;
+        if (li < hclen) S.lens[c_cl_order[li]] = (uint8_t)v;
+        sb_seek(b, b.bp + 3ull * (uint64_t)hclen);
     }
-    if (__builtin_amdgcn_readfirstlane(huff_build(S.clc, S.lens, 19)) != 0) return false;   // (a call's result arrives in a VGPR)
+    if (__builtin_amdgcn_readfirstlane(huff_build<7, 19, 7>(S.clc, S.lens, 19)) != 0) return false;   // (a call's result arrives in a VGPR)
     // the code lengths themselves, as the block loop decodes its symbols: the 64 lanes decode a code-length symbol (with its
     // extra bits: at most 14 bits) at 64 bit positions, the wave follows the chain from bp and hands every item on it
     // its value ("repeat the previous length" resolved on the way) and its place; the lanes then store their runs.
