@@ -114,8 +114,13 @@ __device__ __forceinline__ bool header_prefilter(const uint4 v, uint64_t p)
 template <int PB, int MAXSYM>
 struct LHuff {
     uint16_t tent[1 << PB];          // symbol | code length << 9 for every PB-bit pattern; 0 = code longer than PB bits
-    uint16_t count[16], first[16], index[16], sorted[MAXSYM];      // canonical code: per length the number of codes, the
-    int maxlen;                                                     // first code value and where its symbols start in sorted[]
+    // canonical code, for the codes longer than PB bits: ub[l] = the end of the length-l codes among the 15-bit left-justified
+    // code values (they are sorted by length: a code's length is the number of ub[] it has reached), delta[l] = where the
+    // length-l symbols start in sorted[] minus the first length-l code
+    uint16_t ub[16];
+    int16_t delta[16];
+    uint16_t sorted[MAXSYM];
+    int maxlen;
 };
 struct WaveState {
     union {                              // the code-length code is dead when the literal/length code is built from what it decoded
@@ -124,7 +129,7 @@ struct WaveState {
     };
     LHuff<8, 32> dist;
     alignas(16) uint8_t lens[320];       // (code lengths while a header is read; 64 words of scratch while a block's items are decoded)
-    uint16_t ring[RING];
+    alignas(16) uint16_t ring[RING];
     alignas(16) uint32_t stage[STAGE / 4];
 #ifdef SS_GZ_PAD_LDS
     uint8_t pad[SS_GZ_PAD_LDS];        // (experiment: fewer waves per SIMD)
@@ -243,7 +248,7 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
 #pragma unroll
     for (int l = 1; l <= MAXLEN; l++) {
         const uint32_t c = cnt[l];
-        if (lane == 0) { h.count[l] = (uint16_t)c; h.first[l] = (uint16_t)code; h.index[l] = (uint16_t)off; }
+        if (lane == 0) { h.ub[l] = (uint16_t)((code + c) << (15 - l)); h.delta[l] = (int16_t)((int)off - (int)code); }
         if (c) {
             uint32_t running = 0;
 #pragma unroll
@@ -268,26 +273,6 @@ __device__ int huff_build(LHuff<PB, MAXSYM> &h, const uint8_t *lens, int n)
     __syncthreads();
     return left > 0 ? 1 : 0;
 }
-template <int PB, int MAXSYM>
-__device__ __forceinline__ int huff_decode(const LHuff<PB, MAXSYM> &h, SBits &b)     // needs >= 15 bits buffered
-{
-    const uint32_t v = sb_peek(b, 15);
-    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.tent[v & ((1u << PB) - 1)]);
-    if (e) { sb_drop(b, (int)(e >> 9)); return (int)(e & 511u); }
-    // codes longer than the table's PB bits (rare)
-    uint32_t code = __brev(v & ((1u << PB) - 1)) >> (32 - PB);
-#pragma nounroll
-    for (int len = PB + 1; len <= 15; len++) {
-        code = (code << 1) | ((v >> (len - 1)) & 1u);
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.count[len]), f = (uint32_t)__builtin_amdgcn_readfirstlane((int)h.first[len]);
-        if (code - f < c) {
-            sb_drop(b, len);
-            return __builtin_amdgcn_readfirstlane((int)h.sorted[(uint32_t)__builtin_amdgcn_readfirstlane((int)h.index[len]) + (code - f)]);
-        }
-    }
-    return -1;
-}
-
 // inclusive prefix sum over the 64 lanes in six DPP additions (row shifts 1, 2, 4, 8, then the row broadcasts of gfx9)
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
 {
@@ -457,19 +442,20 @@ __device__ __forceinline__ void out_flush(WaveState &S, OutState &o, uint64_t up
     GZ_ACC(3, tf0, tf1);
 }
 
-// a code longer than the table's PB bits (or none at all), per lane: canonical decode from length PB + 1 on
+// a code longer than the table's PB bits (or none at all), per lane, without a loop: the 15 bits as a left-justified code
+// value; canonical codes are sorted by length, so the length is PB + 1 + the number of ends ub[PB + 1 .. 14] the value has reached
 template <int PB, int MAXSYM>
 __device__ __forceinline__ int lane_long(const LHuff<PB, MAXSYM> &h, uint32_t v, int maxlen, int &len)
 {
-    uint32_t code = __brev(v & ((1u << PB) - 1)) >> (32 - PB);       // the first PB bits of the stream as a number
-#pragma nounroll
-    for (int l = PB + 1; l <= maxlen; l++) {
-        code = (code << 1) | ((v >> (l - 1)) & 1u);
-        const uint32_t c = h.count[l], f = h.first[l];
-        if (code - f < c) { len = l; return h.sorted[(uint32_t)h.index[l] + (code - f)]; }
-    }
-    len = 0;
-    return -1;
+    (void)maxlen;
+    const uint32_t c15 = __brev(v & 0x7FFFu) >> 17;                  // the first bit of the stream is the code's most significant
+    uint32_t l = PB + 1;
+#pragma unroll
+    for (int k = PB + 1; k <= 14; k++) l += c15 >= (uint32_t)h.ub[k] ? 1u : 0u;
+    const bool ok = c15 < (uint32_t)h.ub[l];                           // (beyond the last code: an incomplete code's unused values)
+    len = ok ? (int)l : 0;
+    const int at = (int)h.delta[l] + (int)(c15 >> (15u - l));
+    return ok ? (int)h.sorted[ok ? at : 0] : -1;
 }
 
 // `len` symbols from `dist` back to position n of the wave's output (the 64 lanes together)
@@ -777,7 +763,7 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
     // the second sieve -- the code-length code's Kraft sum, a loop of up to 19 steps that a wave runs as long as its
     // slowest lane -- only sees full waves of queued positions (a ninth of the loop's executions).  The queue is in
     // position order, so the first confirmed entry is still the first in the chunk.
-    __shared__ uint32_t queue[128];
+    uint32_t *queue = reinterpret_cast<uint32_t *>(S.ring);      // (128 words; the ring holds output, and the search produces none)
     uint32_t qn = 0;
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint4 ahead = header_bytes(in, lo + lane);             // the next 64 positions' bytes are loaded while these are tested
