@@ -370,3 +370,24 @@ def test_segments(L, tmp_path, monkeypatch, fastq_text, seg_kb):
             rc, got = _gpu_inflate(L, p)
             assert rc == SS_OK, (name, inject)
             assert got == fastq_text, (name, inject)
+
+
+def test_warm_up_then_pinned_upload(L, tmp_path, monkeypatch):
+    """ss_gz_warm_up makes the pinned upload buffers ahead of time (the CLI's warm-up thread); a file of 32 MB or more then
+    travels through them (four pread threads, blocks of n / 8) instead of being copied out of the mapping: the same records
+    (SS_READS_ORDER=file: as they stand in the file)."""
+    monkeypatch.setenv("SS_READS_ORDER", "file")
+    assert L.lib().ss_gz_warm_up(2) == SS_OK
+    assert L.lib().ss_gz_warm_up(0) == SS_OK
+    t = _fastq(330000, 9)                      # ~100 MB of text, ~40 MB of .gz
+    p = tmp_path / "w.fq.gz"
+    p.write_bytes(gzip.compress(t, 1))
+    assert p.stat().st_size >= (32 << 20)
+    h0, _ = _counters(L)
+    rs = L.ReadSet([str(p)])
+    got = rs.read_back()
+    rs.close()
+    assert _counters(L)[0] == h0 + 1
+    want, n_rec = L.fastx_to_flat(t)
+    assert n_rec == 330000
+    assert [r for r in got.split(b"\n") if r] == [r for r in want.split(b"\n") if r]
