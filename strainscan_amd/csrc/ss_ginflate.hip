@@ -8,13 +8,16 @@
 //               (non-final dynamic block, complete code-length code); a survivor's header is parsed by the whole wave
 //               (code lengths decoded lane-parallel, canonical codes built with ballots: the Kraft sums reject it
 //               before a table is written) and SS_GZ_PROBE symbols are decoded.
+//   A2 subsync  a block is entered every SS_GZ_SPLIT_KB (12 KB) of deflate data as well: Huffman-coded data synchronises
+//               itself, so a wave that decodes from any bit inside a block with the block's tables -- all 64 bit offsets of
+//               a window as hypotheses -- is left with ONE offset after a few windows: an item's first bit, an entry.
 //   B  inflate  every wave decodes from its entry to the next chunk's entry.  The 64 lanes decode whole items (literal,
 //               or length + distance with their extra bits) SPECULATIVELY at 64 consecutive bit positions of the
 //               LDS-staged input; the wave follows the chain of item lengths (readlane), a prefix sum places the items.
 //               What lies in the 32 KB in front of the chunk is unknown: the output is 16-bit symbols, a byte or "byte
 //               w of the window" (a copy of a copy keeps the index).  The last 2048 symbols are mirrored in an LDS
 //               ring; matches that reach further back read the wave's own output from global memory, all such
-//               matches of a window together and while the next window is decoded.
+//               matches of a window together (one lane per symbol) and while the next window is decoded.
 //   C  windows  the last 32 KB of every chunk as a map "my window -> the next chunk's window", composed in two levels;
 //   D  bytes    all symbols -> bytes in parallel; CRC-32 of the text by segments (combined on the host).
 // B-D run SEGMENT by segment (128 MB of deflate data): a segment's text is complete before the next one starts, so the
