@@ -32,6 +32,8 @@
 // 20 M reads against ~80 ms of parsing and PCIe for the same reads, and every scan of the set is then 0-35 % faster
 // depending on the coverage of the sample (profiles/r03_locality_sweep.json).
 #include "ss_common.h"
+
+#include <mutex>
 #include "ss_scan_dev.h"
 
 #include <algorithm>
@@ -509,6 +511,10 @@ int order_bits(uint64_t n_bytes)
 
 namespace ss {
 
+static std::mutex g_scr_mu;
+static char *g_scr = nullptr;            // the scratch of the last call (bin cursors, per-tile record tables), kept for the next
+static uint64_t g_scr_cap = 0;
+
 // src[0, n) (a flat base block on the device) -> a new buffer with the records
 // binned; *out_d (hipMalloc'ed), *out_used (multiple of 16, '\n' padded), *out_cap.
 int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used, uint64_t *out_cap)
@@ -529,7 +535,13 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     const uint64_t scratch = o_tab + (uint64_t)nb * TCAP * 8;
     char *d_scr = nullptr, *d_new = nullptr;
 #define SS_R(call) do { if ((call) != hipSuccess) { ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); hipFree(d_scr); hipFree(d_new); return SS_EHIP; } } while (0)
-    SS_R(hipMalloc((void **)&d_scr, scratch));
+    // (the scratch of the call before is kept -- 0.19 GB for 20 M reads --: two driver calls fewer per sample)
+    uint64_t scr_cap = 0;
+    {
+        std::lock_guard<std::mutex> g(g_scr_mu);
+        if (g_scr && g_scr_cap >= scratch) { d_scr = g_scr; scr_cap = g_scr_cap; g_scr = nullptr; g_scr_cap = 0; }
+    }
+    if (!d_scr) { SS_R(hipMalloc((void **)&d_scr, scratch)); scr_cap = scratch; }
     unsigned long long *d_hist = (unsigned long long *)d_scr, *d_sums = (unsigned long long *)(d_scr + o_sums);
     uint32_t *d_cnt = (uint32_t *)(d_scr + o_cnt);
     unsigned long long *d_tab = (unsigned long long *)(d_scr + o_tab);
@@ -553,7 +565,11 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     SS_R(hipDeviceSynchronize());
     lap("place");
 #undef SS_R
-    hipFree(d_scr);
+    {
+        std::lock_guard<std::mutex> g(g_scr_mu);
+        if (!g_scr || g_scr_cap < scr_cap) { std::swap(g_scr, d_scr); std::swap(g_scr_cap, scr_cap); }
+    }
+    if (d_scr) hipFree(d_scr);
     *out_d = d_new; *out_used = cap; *out_cap = cap;
     return SS_OK;
 }
