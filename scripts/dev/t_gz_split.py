@@ -23,7 +23,10 @@ for f in range(2):
     open(pz, "wb").write(gzip.compress(a.tobytes(), 6))
     subprocess.check_call(["gzip", "-f", "-6", p])
     sets["gnu"].append(p + ".gz"); sets["zlib"].append(pz)
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 for name, paths in sets.items():
+    if only and name != only:
+        continue
     for sp in splits:
         os.environ["SS_GZ_SPLIT_KB"] = str(sp)
         ts = []
