@@ -87,8 +87,9 @@ int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len);
  * ss_scan_files and ss_reads_load (one rank, files of 1 MB and more) go through it first and strict four-line FASTQ is
  * reduced to its sequence lines on the device too (ss_fastq_dev.hip); what it declines goes to the host inflaters. */
 int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
-/* The device inflater keeps its scratch (symbol streams, window maps, the text buffer: ~6-12 GB, at most two sets) for
- * the next call -- large allocations are slow to come by on this platform; this hands it back. */
+/* The device inflater keeps its scratch (symbol streams, window maps, the text buffer: ~6-12 GB, at most two sets; its
+ * pinned upload buffers) for the next call, the binning of resident reads its 0.2 GB -- large allocations are slow to come
+ * by on this platform; this hands all of it back. */
 int ss_gz_gpu_release(void);
 /* The pinned upload buffers of n_files (<= 2) concurrent .gz inputs, made ahead of time (~40 ms a set; a command-line process
  * calls this on its warm-up thread): a file of 32 MB or more then travels through them (8 ms instead of 12-30 per 66 MB);

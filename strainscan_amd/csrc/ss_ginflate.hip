@@ -2236,6 +2236,7 @@ extern "C" int ss_gz_gpu_release(void)
         pins.swap(g_pin_free);
     }
     for (PinSet *p : pins) pin_destroy(p);
+    ss::reorder_release();
     return SS_OK;
 }
 

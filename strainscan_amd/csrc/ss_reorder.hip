@@ -574,6 +574,17 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     return SS_OK;
 }
 
+void reorder_release()
+{
+    char *d = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_scr_mu);
+        std::swap(d, g_scr);
+        g_scr_cap = 0;
+    }
+    if (d) hipFree(d);
+}
+
 bool reads_order_wanted()
 {
     const char *e = getenv("SS_READS_ORDER");
