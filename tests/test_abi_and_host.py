@@ -534,3 +534,18 @@ def test_bench_database_generator(shape):
     assert 0 in hit_nodes and 3 <= len(hit_nodes) <= 12                               # the root and the three leaves' paths
     frac = counts.sum() / (3000 * 120)
     assert 0.01 < frac < 0.08
+
+
+def test_documents_name_only_what_the_header_declares():
+    """Every `ss_*` entry point that INTEGRATION.md, DESIGN.md or README.md name is declared in include/strainscan_hip.h
+    (file stems like `ss_mini.hip` and prefixes like `ss_nodes_*` aside)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "strainscan_hip.h")).read()
+    known = set(re.findall(r"\b(ss_[a-z0-9_]+)\b", hdr))
+    stems = {os.path.splitext(f)[0] for f in os.listdir(os.path.join(root, "strainscan_amd", "csrc"))}
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md"):
+        text = open(os.path.join(root, doc)).read()
+        names = set(re.findall(r"`(ss_[a-z0-9_]+)", text))
+        unknown = sorted(n for n in names if n not in known and n not in stems and not n.endswith("_"))
+        assert not unknown, (doc, unknown)
