@@ -86,13 +86,6 @@ __device__ __forceinline__ uint4 header_bytes(const uint8_t *in, uint64_t p)
     __builtin_memcpy(&v, in + (p >> 3), 16);
     return v;
 }
-// the first 13 bits only (block type, HLIT, HDIST): one position in nine passes
-__device__ __forceinline__ bool header_quick(const uint4 v, uint64_t p)
-{
-    const uint64_t lo = (uint64_t)v.x | (uint64_t)v.y << 32;
-    const uint32_t h = (uint32_t)(lo >> (p & 7));                 // (13 bits behind a shift of at most 7)
-    return (h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u;
-}
 __device__ __forceinline__ bool header_prefilter(const uint4 v, uint64_t p)
 {
     uint64_t lo = (uint64_t)v.x | (uint64_t)v.y << 32, hi = (uint64_t)v.z | (uint64_t)v.w << 32;
@@ -762,27 +755,46 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
     uint64_t found = ~0ull;
     SBits b;
     sb_init(b, in, in_n, lo);
-    // Two sieves.  The first 13 bits (type, HLIT, HDIST) are tested for every position; the one in nine that passes is QUEUED, and
-    // the second sieve -- the code-length code's Kraft sum, a loop of up to 19 steps that a wave runs as long as its
-    // slowest lane -- only sees full waves of queued positions (a ninth of the loop's executions).  The queue is in
-    // position order, so the first confirmed entry is still the first in the chunk.
-    uint32_t *queue = reinterpret_cast<uint32_t *>(S.ring);      // (128 words; the ring holds output, and the search produces none)
-    uint32_t qn = 0;
-    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    uint4 ahead = header_bytes(in, lo + lane);             // the next 64 positions' bytes are loaded while these are tested
-    for (uint64_t p0 = lo; p0 < hi && found == ~0ull; p0 += 64) {
-        const uint64_t p = p0 + lane;
-        const uint4 bytes = ahead;
-        ahead = header_bytes(in, p + 64);                  // (the input is padded by 8 KB)
-        const bool ok1 = p < hi && header_quick(bytes, p);
-        const uint64_t m1 = __ballot(ok1);
-        if (ok1) queue[qn + (uint32_t)__popcll(m1 & below)] = (uint32_t)(p - lo);
-        qn += (uint32_t)__popcll(m1);
-        const bool last = p0 + 64 >= hi;
+    // Two sieves.  The first 13 bits (type, HLIT, HDIST) are tested for every position -- a lane takes the eight positions of one
+    // byte from a single 4-byte load --; the one in nine that passes is QUEUED, and the second sieve -- the code-length code's
+    // Kraft sum, a loop of up to 19 steps that a wave runs as long as its slowest lane -- only sees full waves of queued
+    // positions (a ninth of the loop's executions).  The queue is in position order, so the first confirmed entry is still
+    // the first in the chunk.  (lo and hi are whole bytes.)
+    uint32_t *queue = reinterpret_cast<uint32_t *>(S.ring);      // (1024 words, a ring; the LDS ring holds output, and the search produces none)
+    constexpr uint32_t QMASK = RING * 2 / 4 - 1;
+    static_assert(RING * 2 / 4 >= 1024, "the queue takes up to 63 + 512 positions");
+    uint32_t qh = 0, qn = 0;
+    auto word_at = [&](uint64_t p) { uint32_t w; __builtin_memcpy(&w, in + (p >> 3) + (uint64_t)lane, 4); return w; };
+    uint32_t ahead = word_at(lo);                           // the next 512 positions' bytes are loaded while these are tested
+    for (uint64_t p0 = lo; p0 < hi && found == ~0ull; p0 += 512) {
+        const uint32_t w = ahead;
+        ahead = word_at(p0 + 512);                          // (the input is padded by 8 KB)
+        const uint64_t pl = p0 + 8ull * (uint64_t)lane;
+        uint32_t m8 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t h = w >> j;
+            const bool t = (h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u;
+            m8 |= (t ? 1u : 0u) << j;
+        }
+        if (pl >= hi) m8 = 0;
+        const uint32_t cnt = (uint32_t)__popc(m8);
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        uint32_t at = qh + qn + incl - cnt;
+        while (__ballot(m8 != 0u)) {
+            if (m8) {
+                const int j = __ffs((int)m8) - 1;
+                m8 &= m8 - 1u;
+                queue[at & QMASK] = (uint32_t)(pl - lo) + (uint32_t)j;
+                at++;
+            }
+        }
+        qn += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const bool last = p0 + 512 >= hi;
         while ((qn >= 64u || (last && qn > 0u)) && found == ~0ull) {
             const uint32_t take = min(qn, 64u);
             __builtin_amdgcn_wave_barrier();
-            const uint32_t q = (uint32_t)lane < take ? queue[lane] : 0u;
+            const uint32_t q = (uint32_t)lane < take ? queue[(qh + (uint32_t)lane) & QMASK] : 0u;
             const uint64_t pos = lo + (uint64_t)q;
             const bool ok = (uint32_t)lane < take && header_prefilter(header_bytes(in, pos), pos);
             uint64_t m = __ballot(ok);
@@ -799,12 +811,9 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
                 if (count_tries && lane == 0) atomicAdd(&g_sync_tries, 1u);
                 if (r == 2 || (r == 0 && o.n > 0)) found = cand;
             }
-            const uint32_t rest = qn - take;               // what is queued behind the 64 taken moves to the front
-            const uint32_t mv = (uint32_t)lane < rest ? queue[64 + lane] : 0u;
             __builtin_amdgcn_wave_barrier();
-            if ((uint32_t)lane < rest) queue[lane] = mv;
-            __builtin_amdgcn_wave_barrier();
-            qn = rest;
+            qh = (qh + take) & QMASK;
+            qn -= take;
         }
     }
     if (lane == 0) entry[c] = found;
