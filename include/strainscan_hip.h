@@ -175,6 +175,12 @@ uint64_t ss_db_device_bytes(const ss_db *db);
  * out[0] layout (0 flat table, 1 minimizer pages), [1] counters, [2] minimizers, [3] 64-byte pages,
  * [4] log2 of the filter size in bits (0 = none), [5] distinct k-mers, [6] bucket-array slots, [7] k-mers inline in pages. */
 int ss_db_index_info(const ss_db *db, uint64_t out[8]);
+/* A hint, not a semantic switch (counts are the same either way): most k-mers of the reads ARE in this table -- a layer-2
+ * cluster table, all_kmer.fasta of a cluster the sample was found to contain (Vote_Strain_L2_Lasso_new_sp.py:354-372; the
+ * reference runs the same jellyfish command for it as for the tree).  Scans of such a table skip the minimizer filter and,
+ * for a resident read set in locality order, add the hits of neighbouring reads up in LDS before they go to the counters
+ * (ss_mini.hip: a global atomic costs the same whatever it carries, 27 G line requests/s on MI355X). */
+int ss_db_expect_hits(ss_db *db, int expect);
 
 /* --------------------------------------------------------------------------------------------
  * The scan  (the `jellyfish count` + `dump -c` pair of identify.py:82-87,
@@ -209,8 +215,9 @@ uint64_t ss_scan_kernel_launches(const ss_db *db);   /* scan kernels enqueued so
  * multi-strain cluster and twice more with -b (identify.py:409; Vote_Strain_L2_Lasso_new_sp.py:
  * 354-372; identify_low_depth.py:119,124).  Counting does not depend on the order of the records, so the resident
  * records CAN be kept in locality order -- sorted by the minimizer of their first k-mer, reads that start within the same
- * 17 bases of a genome become neighbours and share their page lookups in L2: scans 20-35 % faster at high coverage, 10 ms
- * per 20 M reads once (ss_reorder.hip; opt-in: SS_READS_ORDER=locality).  ss_reads_load parses the files ONCE (worker threads
+ * 17 bases of a genome become neighbours and share their page lookups: scans 20-35 % faster at high coverage, 3.5 ms
+ * per 20 M reads once (ss_reorder.hip; the default since round 3, SS_READS_ORDER=file keeps the file order: it pays from
+ * the second scan of a sample on, a sample that is scanned once loses ~1.4 ms per 20 M reads).  ss_reads_load parses the files ONCE (worker threads
  * for plain files) and keeps the flat base blocks in HBM; ss_scan_reads scans them against any
  * database image.  shard_rank / shard_world: keep every shard_world-th block (multi-GPU).
  * ------------------------------------------------------------------------------------------ */

@@ -23,6 +23,8 @@ for j in range(k):
     rc |= (cj ^ 2) << (2 * (k - 1 - j))
 keys = torch.stack([key, rc], 1).reshape(-1).cpu().numpy().view(np.uint64)
 db = _lib.KmerDB(keys, np.ones(keys.size, np.uint8), 31, True)
+if os.environ.get("SS_EXPECT_HITS", "1") != "0":
+    db.expect_hits()
 asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)
 st = torch.randint(0, G, (n_reads,), generator=g, device=dev)
 reads = torch.empty((n_reads, 151), dtype=torch.uint8, device=dev)
@@ -57,5 +59,22 @@ for bits in sys.argv[3:] or ["0"]:
     t_bin = ms(lambda: rs.scan_into(db, stream))
     out["binned_ms"] = round(t_bin, 3)
     out["counts_equal"] = bool(np.array_equal(db.counts_rows(), want))
+    if hasattr(_lib.lib(), "ss_debug_timing"):
+        import ctypes
+        tm = (ctypes.c_ulonglong * 32)()
+        _lib.lib().ss_debug_timing(tm, 1)
+        db.reset(stream); rs.scan_into(db, stream)
+        _lib.lib().ss_debug_timing(tm, 1)
+        tiles = flat.numel() / 992
+        names = {0: "0 load/encode", 1: "1a keys", 6: "1b minimizers", 2: "1b run walk", 7: "setup", 3: "2 pages", 10: "3 start", 8: "comb flush",
+                 9: "comb claim", 4: "3 candidates", 5: "end barrier"}
+        out["cycles_per_tile"] = {names[i]: round(tm[i] / tiles) for i in names}
+    if hasattr(_lib.lib(), "ss_debug_comb_stats"):
+        import ctypes
+        st8 = (ctypes.c_ulonglong * 8)()
+        _lib.lib().ss_debug_comb_stats(st8, 1)
+        db.reset(stream); rs.scan_into(db, stream)
+        _lib.lib().ss_debug_comb_stats(st8, 1)
+        out["comb_stats"] = dict(zip(("tiles", "flushes", "entries", "counters", "found_runs", "runs_without_entry", "full_flushes"), list(st8)[:7]))
     rs.close()
 print(out)

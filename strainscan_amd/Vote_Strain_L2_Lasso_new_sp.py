@@ -124,6 +124,7 @@ def cluster_counts(input_fq, fq2, cls_db_dir, ksize):
     (Build_kmer_sets_unique_region_lasso_test_allinone_sp.py:397-399,409-410)."""
     from .db import fasta_index, scan_into
     db = fasta_index(os.path.join(cls_db_dir, "all_kmer.fasta"), int(ksize), 2)
+    db.expect_hits()                         # every k-mer of the cluster's strains, and the sample holds the cluster
     try:
         scan_into(db, [input_fq, fq2])       # resident reads: no second parse, no second PCIe trip
         _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")

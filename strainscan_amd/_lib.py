@@ -83,6 +83,7 @@ SIGNATURES = {
     "ss_db_row_valid_dev": (vp, [vp]),
     "ss_db_device_bytes": (u64, [vp]),
     "ss_db_index_info": (i32, [vp, vp]),
+    "ss_db_expect_hits": (i32, [vp, i32]),
     "ss_scan_reset": (i32, [vp, vp]),
     "ss_scan_flat_dev": (i32, [vp, vp, u64, vp]),
     "ss_scan_flat_host": (i32, [vp, cp, u64]),
@@ -324,6 +325,11 @@ class KmerDB:
     @property
     def row_valid_dev(self):
         return lib().ss_db_row_valid_dev(self._h)
+
+    def expect_hits(self, expect=True):
+        """Hint: most read k-mers are in this table (a layer-2 cluster table)."""
+        check(lib().ss_db_expect_hits(self._h, 1 if expect else 0), "ss_db_expect_hits")
+        return self
 
     def reset(self, stream=None):
         check(lib().ss_scan_reset(self._h, stream), "ss_scan_reset")

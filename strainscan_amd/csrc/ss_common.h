@@ -88,6 +88,7 @@ struct ss_db {
     uint32_t bloom_bits = 0;           // log2 of its size in bits
     uint64_t n_buckets = 0;
     uint32_t *d_counts = nullptr;      // [n_slots] occurrences per slot (accumulated by scans)
+    int expect_hits = 0;               // ss_db_expect_hits: most read k-mers are in the table (a layer-2 cluster table)
     uint32_t *d_slot_of_row = nullptr; // [n_rows]   slot owning row i, SS_NO_SLOT if none
     uint8_t *d_row_valid = nullptr;    // [n_rows]   1 iff row i is a key of match_results
     // pinned staging for host-resident base blocks
@@ -116,7 +117,7 @@ struct ss_reads {
     // and padded with '\n' to a multiple of 16 bytes, so a slab is itself one flat base block: one scan
     // launch per slab (one in all for a typical sample) instead of one per 12 MB block, and no device
     // allocation per block while loading.
-    struct Slab { char *d = nullptr; uint64_t cap = 0, used = 0; };
+    struct Slab { char *d = nullptr; uint64_t cap = 0, used = 0; bool binned = false; };   // binned: ss_reorder.hip has ordered its records
     std::vector<Slab> slabs;
     std::mutex mu;
     uint64_t n_records = 0, n_bases = 0, device_bytes = 0, n_blocks = 0;
@@ -206,5 +207,7 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
 int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled,
                        int shard_rank = 0, int shard_world = 1);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
-                     uint64_t n_tiles);
+                     uint64_t n_tiles, bool binned = false);
+// ss_scan_flat_dev for a block whose records ss_reorder.hip has binned by locus (the scan may add hits up in LDS first)
+int scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned);
 }  // namespace ss

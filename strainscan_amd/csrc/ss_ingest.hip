@@ -766,7 +766,7 @@ int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads
         const int rc = ss::order_flat_dev(static_cast<const char *>(flat_dev), n, &d, &used, &cap);
         if (rc != SS_OK) { ss_reads_destroy(R); return rc; }
         ss_reads::Slab sl;
-        sl.d = d; sl.cap = cap; sl.used = used;
+        sl.d = d; sl.cap = cap; sl.used = used; sl.binned = true;
         R->slabs.push_back(sl);
         R->device_bytes = cap;
         R->n_blocks = 1;
@@ -824,7 +824,7 @@ int ss_scan_reads(ss_db *db, const ss_reads *R, void *stream)
     if (R->has_cut_record && k != 31) return SS_ERANGE;   // cut records carry a 30-base overlap
     for (const auto &sl : R->slabs) {
         if (!sl.used) continue;
-        int rc = ss_scan_flat_dev(db, sl.d, sl.used, stream);
+        int rc = ss::scan_flat_dev(db, sl.d, sl.used, stream, sl.binned);
         if (rc) return rc;
     }
     return SS_OK;

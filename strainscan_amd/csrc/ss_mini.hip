@@ -133,13 +133,37 @@ struct QShared {
     uint16_t inv[MT + 2];
     uint32_t q1[Q1CAP + 64];           // run:   len << 12 | tile position of its first k-mer (+64 dump slots)
     alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
-    uint64_t q1b[Q1CAP];               // run that passed the Bloom filter: h << 32 | minimizer offset in the first k-mer << 17 | q1 entry
     uint64_t q2[Q1CAP];                // found bucket: bucket start << 32 | multi << 31 | aligned offset mask << 12 | run index (q1b with a
                                        // Bloom filter, q1 without)
     uint32_t cnt[4];                   // [1] = found runs
 #ifdef SS_LDS_PAD
     uint32_t pad[SS_LDS_PAD / 4];      // occupancy experiments only
 #endif
+};
+// (a __shared__ variable of its own: instantiations without a Bloom filter do not pay its 1.25 KB)
+struct QBloom {
+    uint64_t q1b[Q1CAP];               // run that passed the Bloom filter: h << 32 | minimizer offset in the first k-mer << 17 | q1 entry
+};
+
+// ---------------------------------------------------------------------------------------------
+// Counting where most read k-mers HIT (layer-2 cluster tables hold every k-mer of their strains; Vote_Strain_L2_Lasso_new_sp.py
+// :354-372 scans all reads against one per identified cluster).  What a global atomicAdd costs on this chip
+// (scripts/micro/atomics.hip, profiles/r04_atomics_micro_*.txt): 27 G (wave instruction, 64-byte line) pairs per second,
+// whatever the footprint (2 MB or 40 MB), the scope, the number of lanes on the line (1..16) -- and the kernel's other work does
+// not overlap it.  A read's 120 hits fall into ~13 buckets = ~19 lines, a tile of 6.5 reads pays ~100 line requests: 11 of the
+// 17 ms of such a scan.  In a BINNED read set (ss_reorder.hip) the neighbours of a read come from the same locus and hit the same
+// buckets, so the hits are first added up in LDS: a small open-address table keyed by the bucket, one byte per bucket slot
+// (a run adds at most one to a slot, and the table is flushed before 255 runs have gone into it), flushed with one global
+// atomic per non-zero counter every few tiles.  A workgroup works through CONSECUTIVE tiles for that.
+// ---------------------------------------------------------------------------------------------
+constexpr int COMB_NE = 64;            // entries (= lanes of the wave: the flush looks at one entry per lane)
+constexpr int COMB_CH = 4;             // consecutive tiles per workgroup
+constexpr uint32_t COMB_NONE = 0xFFu;
+struct QComb {
+    uint32_t key[COMB_NE];             // bucket start + 1, 0 = free
+    uint32_t acc[COMB_NE][5];          // byte o = occurrences of the bucket's slot o (1..19; slot 0 is the header)
+    uint8_t ent[Q1CAP];                // per found run of the tile: its entry, COMB_NONE = count in global memory
+    uint8_t list[COMB_NE];             // flush: the occupied entries
 };
 
 // the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
@@ -174,21 +198,32 @@ __device__ __forceinline__ uint32_t cand_slot(uint32_t bstart, uint32_t amask, u
 }
 __device__ __forceinline__ uint32_t aligned_mask(uint32_t hdr, uint32_t o0) { return ((hdr & 0x1FFFFu) << (16u - o0)) & 0x1FFFFu; }
 
+// one occurrence of the database k-mer in slot `cpos` of the bucket at `bstart`: into the LDS entry `ent` of the bucket when it
+// has one (QComb), else straight to the counter
+template <bool COMB>
+__device__ __forceinline__ void count_slot(uint32_t cpos, uint32_t bstart, uint32_t ent, uint32_t *__restrict__ acc5,
+                                           uint32_t *__restrict__ counts)
+{
+    const uint32_t off = cpos - bstart;
+    if (COMB && ent != COMB_NONE && off < 20u) atomicAdd(&acc5[ent * 5u + (off >> 2)], 1u << ((off & 3u) * 8u));
+    else atomicAdd(&counts[cpos], 1u);
+}
 // compare the candidate (already loaded) with k-mer `pos`; count; fall back to a bucket scan when
 // several database k-mers share a minimizer offset (repeated / colliding minimizer)
+template <bool COMB>
 __device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t multi, uint32_t cpos,
                                             uint64_t cand, const uint64_t *__restrict__ mkeys,
-                                            uint32_t *__restrict__ counts)
+                                            uint32_t *__restrict__ counts, uint32_t ent = COMB_NONE, uint32_t *__restrict__ acc5 = nullptr)
 {
     uint32_t klo, khi;
     kmer_at(S, pos, klo, khi);
     if ((uint32_t)cand == klo && (uint32_t)(cand >> 32) == khi) {
-        atomicAdd(&counts[cpos], 1u);
+        count_slot<COMB>(cpos, bstart, ent, acc5, counts);
     } else if (multi) {
         const uint64_t km = ((uint64_t)khi << 32) | klo;
         const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
         for (uint32_t q = 0; q < cnt; q++)
-            if (mkeys[bstart + 1 + q] == km) { atomicAdd(&counts[bstart + 1 + q], 1u); break; }
+            if (mkeys[bstart + 1 + q] == km) { count_slot<COMB>(bstart + 1 + q, bstart, ent, acc5, counts); break; }
     }
 }
 
@@ -232,10 +267,18 @@ __device__ __forceinline__ uint32_t shift_in_ne(uint32_t m, uint32_t a, uint32_t
     return m;
 }
 
+#ifdef SS_COMB_STATS
+// debug build: what the combining scan did -- [0] tiles, [1] flushes, [2] entries flushed, [3] counters flushed, [4] found runs,
+// [5] runs without an entry, [6] flushes because the table was full
+__device__ unsigned long long ss_comb_stats[8];
+#define SS_CS(i, v) do { if (t == 0) atomicAdd(&ss_comb_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define SS_CS(i, v)
+#endif
 #ifdef SS_TIMING
 // debug build: cycles a wave spends between the phase markers, accumulated in registers and flushed once per block
 __device__ unsigned long long ss_timing[32];
-#define SS_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[(i) & 7] += (uint32_t)(now_ - t_prev); t_prev = now_; } while (0)
+#define SS_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[(i) & 15] += (uint32_t)(now_ - t_prev); t_prev = now_; } while (0)
 #else
 #define SS_T(i) asm volatile("; SSMARK " #i)
 #endif
@@ -253,7 +296,7 @@ __device__ unsigned long long ss_timing[32];
 #ifndef SS_NUM_SGPR
 #define SS_NUM_SGPR 80
 #endif
-template <bool ALIGNED, bool BLOOM, int WAVES_PER_SIMD>
+template <bool ALIGNED, bool BLOOM, bool COMB, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(SS_NUM_SGPR))) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
     const uint4 *__restrict__ pages, uint32_t n_pages, uint32_t *__restrict__ counts, uint32_t cbase,
@@ -262,8 +305,11 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
     constexpr int K = 31;                            // 17 m-mers of length 15 per k-mer
     static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
+    __shared__ QBloom SB;                            // (dropped from the instantiations that never touch it)
+    __shared__ QComb C;
     const int t = threadIdx.x;
     const uint32_t vc1 = ss::MMK_C1;
+    constexpr uint64_t CH = COMB ? COMB_CH : 1;      // consecutive tiles per workgroup
 
     // the 16 bases of this lane are fetched one tile AHEAD: the HBM
     // round trip of the stream overlaps the previous tile's phases
@@ -271,23 +317,72 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
     // eighth of the TILES in order (its workgroups stride through that eighth), so neighbouring tiles -- reads that a
     // resident set keeps binned by their first minimizer (ss_reorder.hip) and that share their page sectors -- meet in
     // ONE 4 MB L2 instead of eight.  (The grid is a multiple of 8 then; every XCD gets the same number of tiles.)
-    uint64_t tile = blockIdx.x, tile_end = n_tiles, stride = gridDim.x;
+    // A workgroup takes CH consecutive tiles, then the next CH `stride` chunks further on (CH = 1: a plain grid stride)
+    uint64_t tile = (uint64_t)blockIdx.x * CH, tile_end = n_tiles, stride = gridDim.x, tile0 = 0;
     if (xcd_swizzle) {
-        const uint64_t per = (n_tiles + 7) >> 3, x = blockIdx.x & 7u;
+        const uint64_t per = (((n_tiles + 7) >> 3) + CH - 1) / CH * CH, x = blockIdx.x & 7u;
         stride = gridDim.x >> 3;
-        tile = x * per + (blockIdx.x >> 3);
+        tile0 = x * per;
+        tile = tile0 + (uint64_t)(blockIdx.x >> 3) * CH;
         tile_end = min(n_tiles, (x + 1) * per);
     }
+    auto next_tile = [&](uint64_t tl) -> uint64_t {
+        if (CH == 1) return tl + stride;
+        return ((tl + 1 - tile0) % CH) ? tl + 1 : tl + 1 + (stride - 1) * CH;
+    };
+#ifdef SS_TIMING
+    unsigned long long t_prev = __builtin_readcyclecounter();
+    uint32_t t_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    uint32_t comb_runs = 0;                          // found runs added to the LDS counters since their last flush
+    if (COMB) {
+        C.key[t] = 0u;
+#pragma unroll
+        for (int w = 0; w < 5; w++) C.acc[t][w] = 0u;
+    }
+    // the non-zero LDS counters go to global memory (16 lanes per occupied entry: slots 1..16, then a lane per entry for the
+    // slots 17..19), the table is emptied
+    auto comb_flush = [&]() {
+        const uint32_t key = C.key[t];
+        const uint64_t occ = __ballot(key != 0u);
+        const uint32_t nocc = (uint32_t)__popcll(occ);
+        SS_CS(1, 1); SS_CS(2, nocc);
+        if (key) C.list[__builtin_amdgcn_mbcnt_hi((uint32_t)(occ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)occ, 0u))] = (uint8_t)t;
+        __syncthreads();
+        for (uint32_t g0 = 0; g0 < nocc * 16u; g0 += MT) {
+            const uint32_t g = g0 + (uint32_t)t;
+            if ((g >> 4) < nocc) {
+                const uint32_t e = C.list[g >> 4], off = 1u + (g & 15u);
+                const uint32_t c = (C.acc[e][off >> 2] >> ((off & 3u) * 8u)) & 0xFFu;
+#ifdef SS_COMB_STATS
+                { const unsigned long long nz = __popcll(__ballot(c != 0u)); SS_CS(3, nz); }
+#endif
+                if (c) atomicAdd(&counts[C.key[e] - 1u + off], c);
+            }
+        }
+        if (key) {
+            const uint32_t w = C.acc[t][4] >> 8;
+            if (w) {
+#pragma unroll
+                for (uint32_t o = 0; o < 3; o++)
+                    if ((w >> (8u * o)) & 0xFFu) atomicAdd(&counts[key - 1u + 17u + o], (w >> (8u * o)) & 0xFFu);
+            }
+        }
+        __syncthreads();
+        if (key) {
+            C.key[t] = 0u;
+#pragma unroll
+            for (int w = 0; w < 5; w++) C.acc[t][w] = 0u;
+        }
+        __syncthreads();
+        comb_runs = 0;
+    };
     uint32_t wn[4];
     if (tile < tile_end) {
         const uint64_t b0 = tile * MTILE;
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
     }
-#ifdef SS_TIMING
-    unsigned long long t_prev = __builtin_readcyclecounter();
-    uint32_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    for (; tile < tile_end; tile += stride) {
+    for (; tile < tile_end; tile = next_tile(tile)) {
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
         {
             uint32_t code, inv;
@@ -298,7 +393,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #ifdef SS_LDS_PAD
         if (n == 1) S.pad[t] = 1;
 #endif
-            const uint64_t nt = tile + stride;
+            const uint64_t nt = next_tile(tile);
             if (nt < tile_end) {
                 const uint64_t nb = nt * (uint64_t)MTILE;
                 load16<ALIGNED>(bases, nb + (uint64_t)t * 16, n, wn);
@@ -440,7 +535,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 const uint32_t rpos = meta & 0xFFFu, len = (meta >> 12) & 31u;
                 for (uint32_t q = 0; q < len; q++) {
                     const uint32_t cpos = cand_slot(bstart, amask, q);
-                    if (cpos) settle_item(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts);
+                    if (cpos) settle_item<false>(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts);
                 }
             }
         };
@@ -517,7 +612,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
                 for (int u = 0; u < RPL; u++) {
                     const uint64_t pass = __ballot(ok[u]);
-                    if (ok[u]) S.q1b[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(pass >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pass, 0u))] =
+                    if (ok[u]) SB.q1b[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(pass >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pass, 0u))] =
                         ((uint64_t)hs[u] << 32) | meta[u];
                     ns += (uint32_t)__popcll(pass);
                 }
@@ -538,7 +633,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 const uint32_t i = i0 + u * MT + t;
                 ok[u] = i < ns;
                 if (BLOOM) {
-                    const uint64_t sv = S.q1b[ok[u] ? i : 0u];
+                    const uint64_t sv = SB.q1b[ok[u] ? i : 0u];
                     meta[u] = (uint32_t)sv;
                     hs[u] = (uint32_t)(sv >> 32);
                 } else {
@@ -565,25 +660,53 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #endif
             constexpr int U3 = SS_U3;
             const uint32_t n2 = min(S.cnt[1], (uint32_t)Q1CAP);
+            bool comb_full = false;
+            if (COMB) {
+                // every found run claims the LDS entry of its bucket (the runs of a locus' reads share theirs); a byte
+                // counter takes at most one from a run, so the table is flushed before 255 runs have gone into it
+                SS_T(10);
+                if (comb_runs + n2 > 255u) { comb_flush(); SS_T(8); }
+                comb_runs += n2;
+                for (uint32_t r = (uint32_t)t; r < n2; r += MT) {
+                    const uint32_t key = (uint32_t)(S.q2[r] >> 32) + 1u;
+                    uint32_t i = (key * 0x9E3779B1u) >> 26, e = COMB_NONE;
+                    static_assert(COMB_NE == 64, "hash: top six bits");
+                    for (int pr = 0; pr < 8; pr++) {
+                        const uint32_t old = atomicCAS(&C.key[i], 0u, key);
+                        if (old == 0u || old == key) { e = i; break; }
+                        i = (i + 1u) & (COMB_NE - 1u);
+                    }
+                    C.ent[r] = (uint8_t)e;
+                    comb_full = comb_full || e == COMB_NONE;
+                }
+#ifdef SS_COMB_STATS
+                { const unsigned long long nf = __popcll(__ballot(comb_full)); SS_CS(0, 1); SS_CS(4, n2); SS_CS(5, nf); SS_CS(6, nf ? 1 : 0); }
+#endif
+                comb_full = __ballot(comb_full) != 0ull;      // runs without an entry count in global memory; the table is emptied after the tile
+                __syncthreads();
+                SS_T(9);
+            }
             for (uint32_t g0 = 0; g0 < n2 * 16u; g0 += U3 * MT) {
-                uint32_t pos[U3], bst[U3], mul[U3], cps[U3];
+                uint32_t pos[U3], bst[U3], mul[U3], cps[U3], ent[U3];
                 uint64_t cnd[U3];
 #pragma unroll
                 for (int u = 0; u < U3; u++) {
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
                     const bool v = (g >> 4) < n2;
                     const uint64_t r = S.q2[v ? (g >> 4) : 0u];
-                    const uint32_t run = BLOOM ? (uint32_t)S.q1b[(uint32_t)r & 0xFFFu] : S.q1[(uint32_t)r & 0xFFFu];
+                    const uint32_t run = BLOOM ? (uint32_t)SB.q1b[(uint32_t)r & 0xFFFu] : S.q1[(uint32_t)r & 0xFFFu];
                     pos[u] = (run & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32);
                     mul[u] = (uint32_t)r >> 31;
                     cps[u] = (v && q < ((run >> 12) & 31u)) ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q) : 0u;
                     cnd[u] = mkeys[cps[u]];
+                    ent[u] = COMB ? (uint32_t)C.ent[v ? (g >> 4) : 0u] : COMB_NONE;
                 }
 #pragma unroll
                 for (int u = 0; u < U3; u++)
-                    if (cps[u]) settle_item(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts);
+                    if (cps[u]) settle_item<COMB>(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, ent[u], &C.acc[0][0]);
             }
+            if (COMB && comb_full) { __syncthreads(); SS_T(4); comb_flush(); SS_T(8); }
         }
         // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
         if (ovf) {
@@ -600,9 +723,10 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         __syncthreads();   // queues and codes are rewritten by the next tile
         SS_T(5);
     }
+    if (COMB && comb_runs) comb_flush();
 #ifdef SS_TIMING
     if (t == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&ss_timing[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 16; i++) atomicAdd(&ss_timing[i], (unsigned long long)t_acc[i]);
 #endif
 }
 
@@ -901,19 +1025,30 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
 }
 
 template <int LB>
-static void launch_lb(bool aligned, unsigned blocks, hipStream_t stream, const uint8_t *bases, uint64_t n,
+static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stream, const uint8_t *bases, uint64_t n,
                       uint64_t n_tiles, ss_db *db)
 {
     const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
     const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
     static const uint32_t swz = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
-#define SS_LAUNCH(A, B) hipLaunchKernelGGL((scan_mini_kernel<A, B, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
-                                           db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz)
-    if (db->d_bloom) { if (aligned) SS_LAUNCH(true, true); else SS_LAUNCH(false, true); }
-    else             { if (aligned) SS_LAUNCH(true, false); else SS_LAUNCH(false, false); }
+#define SS_LAUNCH(A, B, C_) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
+                                               db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz)
+    // a table that expects hits (ss_db_expect_hits) skips its Bloom filter: nearly every minimizer of the reads is in it
+    if (comb)             { if (aligned) SS_LAUNCH(true, false, true); else SS_LAUNCH(false, false, true); }
+    else if (db->d_bloom && !db->expect_hits) { if (aligned) SS_LAUNCH(true, true, false); else SS_LAUNCH(false, true, false); }
+    else                  { if (aligned) SS_LAUNCH(true, false, false); else SS_LAUNCH(false, false, false); }
 #undef SS_LAUNCH
 }
 
+#ifdef SS_COMB_STATS
+extern "C" int ss_debug_comb_stats(unsigned long long *out8, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ss_comb_stats), 64);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ss_comb_stats), z, 64); }
+    return 0;
+}
+#endif
 #ifdef SS_TIMING
 extern "C" int ss_debug_timing(unsigned long long *out32, int reset)
 {
@@ -925,13 +1060,13 @@ extern "C" int ss_debug_timing(unsigned long long *out32, int reset)
 #endif
 
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
-                     uint64_t n_tiles)
+                     uint64_t n_tiles, bool binned)
 {
     const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
     static int lb = -1, bpc = 0;
     if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
         const char *e = getenv("SS_MINI_LB");
-        lb = e ? atoi(e) : 8;
+        lb = e ? atoi(e) : 0;
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
@@ -940,14 +1075,19 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     // the waves sharing a SIMD stop marching through their ALU and memory phases in step.  Measured with 8 waves
     // per SIMD resident (20 M reads = 3.04 M tiles; blocks = x * 1024): x = 8 (one round of resident blocks)
     // 4.03 ms, 32: 3.76, 128: 3.59, 512: 3.55, 2048 (1.5 tiles per block): 3.50, 4096 (one tile each): 3.51
-    blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
+    // hits added up in LDS before they go to the counters (QComb): tables that expect hits, reads binned by locus
+    // (SS_COMBINE=0 never, =1 for every scan of such a table)
+    static const int comb_env = [] { const char *e = getenv("SS_COMBINE"); return e ? atoi(e) : -1; }();
+    const bool comb = db->expect_hits && (comb_env < 0 ? binned : comb_env != 0);
+    const uint64_t units = comb ? (n_tiles + COMB_CH - 1) / COMB_CH : n_tiles;
+    blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
     blocks = (blocks + 7u) & ~7u;                           // a multiple of 8: the same number of workgroups on every XCD
     const uint8_t *b = (const uint8_t *)bases_dev;
-    switch (lb) {
-    case 3: launch_lb<3>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    case 6: launch_lb<6>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    case 4: launch_lb<4>(aligned, blocks, stream, b, n, n_tiles, db); break;
-    default: launch_lb<8>(aligned, blocks, stream, b, n, n_tiles, db); break;
+    // (the combining variant needs 71 VGPRs: at 8 waves per SIMD it would spill four of them to scratch)
+    switch (lb ? lb : comb ? 6 : 8) {
+    case 4: launch_lb<4>(aligned, comb, blocks, stream, b, n, n_tiles, db); break;
+    case 6: launch_lb<6>(aligned, comb, blocks, stream, b, n, n_tiles, db); break;
+    default: launch_lb<8>(aligned, comb, blocks, stream, b, n, n_tiles, db); break;
     }
     SS_HIP(hipGetLastError());
     return SS_OK;

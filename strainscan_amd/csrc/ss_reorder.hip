@@ -606,7 +606,7 @@ int reads_order_for_locality(ss_reads *R, bool force)
             const int rc = order_flat_dev(sl.d, sl.used, &d, &used, &cap);
             if (rc) return rc;
             hipFree(sl.d);
-            sl.d = d; sl.used = used; sl.cap = cap;
+            sl.d = d; sl.used = used; sl.cap = cap; sl.binned = true;
         }
         bytes += sl.cap;
     }

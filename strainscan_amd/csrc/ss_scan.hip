@@ -386,7 +386,18 @@ int ss_scan_reset(ss_db *db, void *stream)
     return SS_OK;
 }
 
-int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream)
+int ss_db_expect_hits(ss_db *db, int expect)
+{
+    if (!db) return SS_EINVAL;
+    db->expect_hits = expect != 0;
+    return SS_OK;
+}
+
+int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream) { return ss::scan_flat_dev(db, bases_dev, n, stream, false); }
+
+}  // extern "C"
+
+int ss::scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned)
 {
     if (!db || (n && !bases_dev)) return SS_EINVAL;
     if (n < (uint64_t)db->k) return SS_OK;
@@ -394,7 +405,7 @@ int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream)
     const uint64_t max_blocks = (uint64_t)cu_count() * 8;
     const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, max_blocks);
     if (db->layout == 1) {
-        int rc = ss::launch_scan_mini(db, bases_dev, n, ss::as_stream(stream), blocks, n_tiles);
+        int rc = ss::launch_scan_mini(db, bases_dev, n, ss::as_stream(stream), blocks, n_tiles, binned);
         if (rc == SS_OK) db->launches++;
         return rc;
     }
@@ -408,6 +419,8 @@ int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream)
     db->launches++;
     return SS_OK;
 }
+
+extern "C" {
 
 int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n)
 {

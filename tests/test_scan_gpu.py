@@ -1035,3 +1035,93 @@ def test_locality_ordered_read_set(L):
                 assert back == [r for r in mixed if r]
             rset.close()
     db.close()
+
+
+def _dense_case(seed=5, G=40000, n_reads=12000):
+    """A cluster-table-like case: EVERY k-mer of a genome, both orientations, reads at high coverage with errors."""
+    rs = np.random.RandomState(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    ga = lut[rs.randint(0, 4, size=G + 30)]
+    g = ga.tobytes()
+    kfa = b"".join(b">1\n" + g[i:i + 31] + b"\n>1\n" + synth.revcomp(g[i:i + 31]) + b"\n" for i in range(G))
+    recs = []
+    for s in rs.randint(0, G - 150, size=n_reads):
+        r = ga[s:s + rs.randint(31, 151)].copy()
+        m = rs.random_sample(r.size) < 0.01
+        r[m] = lut[rs.randint(0, 4, size=int(m.sum()))]
+        b = r.tobytes()
+        recs.append(synth.revcomp(b) if rs.random_sample() < 0.5 else b)
+    return kfa, b"\n".join(recs) + b"\n"
+
+
+def _scan_binned(L, db, flat):
+    import torch
+    d = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    rs = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=True)
+    rs.scan_into(db)
+    L.check(L.lib().ss_device_sync(), "sync")
+    rs.close()
+
+
+@pytest.mark.parametrize("expect", [True, False])
+def test_hits_combined_in_lds(L, expect):
+    """ss_db_expect_hits + a binned read set: the hits of a tile are added up in LDS first (ss_mini.hip QComb) and flushed
+    every few tiles.  Against the oracle: a dense table at high coverage (byte counters flushed before 255 runs), at low
+    coverage with gaps in the offset masks (more buckets per tile than table entries: the overflow goes straight to the
+    counters), repeats (buckets with several k-mers per offset, slots beyond the 19 an entry holds); accumulation over two
+    scans; the harvest path."""
+    from oracle import oracle as orc
+    for name, (kfa, flat) in (("dense", _dense_case()), ("deep", _dense_case(6, 3000, 20000)), ("gaps", _random_db_and_reads(21, 80000, 20000)),
+                              ("repeats", _adversarial_case(78))):
+        fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+        want, want_valid = orc.jellyfish_count(kfa, [fq], k=31, upper=True)
+        db = L.KmerDB.from_text(kfa, 31, True)
+        if expect:
+            db.expect_hits()
+        _scan_binned(L, db, flat)
+        assert np.array_equal(db.counts_rows(), want), name
+        _scan_binned(L, db, flat)
+        assert np.array_equal(db.counts_rows(), 2 * want), name
+        db.scan_flat(flat)                                             # file order: never combined
+        assert np.array_equal(db.counts_rows(), 3 * want), name
+        n = want.size
+        lists = [np.arange(0, n, 2), np.arange(1, n, 3), np.arange(n)[::-1][: n // 2]]
+        ns = L.NodeSet(lists)
+        db.reset()
+        _scan_binned(L, db, flat)
+        st = ns.harvest(db)
+        valid = db.row_valid
+        for j, rows in enumerate(lists):
+            o = orc.match_node(want, valid, rows)
+            assert (int(st[j]["length"]), int(st[j]["n_pos"]), int(st[j]["n_kept"]), int(st[j]["sum_kept"])) == \
+                (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"]), (name, j)
+        ns.close()
+        db.close()
+    assert want.max() > 50
+
+
+def test_hits_combined_tiny_queues_and_file_order():
+    """The combining scan with the tiny-queue build (found runs overflow q2 and settle inline) and forced on reads in file
+    order (SS_COMBINE=1: every tile fills the table)."""
+    import subprocess
+    import sys
+    from strainscan_amd import _lib
+    tiny = os.path.join(os.path.dirname(_lib.LIB_PATH), "libstrainscan_hip_tinyq.so")
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from strainscan_amd import _lib\n"
+        "from oracle import oracle as orc\n"
+        "from tests.test_scan_gpu import _adversarial_case, _dense_case, _scan_binned\n"
+        "for kfa, flat in (_adversarial_case(), _dense_case(9, 20000, 20000)):\n"
+        "    fq = b''.join(b'@r\\n' + r + b'\\n+\\n' + b'I' * len(r) + b'\\n' for r in flat.split(b'\\n') if r)\n"
+        "    want, _ = orc.jellyfish_count(kfa, [fq], k=31, upper=True)\n"
+        "    db = _lib.KmerDB.from_text(kfa, 31, True).expect_hits()\n"
+        "    _scan_binned(_lib, db, flat)\n"
+        "    assert np.array_equal(db.counts_rows(), want)\n"
+        "    db.scan_flat(flat)\n"
+        "    assert np.array_equal(db.counts_rows(), 2 * want)\n"
+        "print('comb ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for env in (dict(SS_LIB=tiny), dict(SS_COMBINE="1"), dict(SS_LIB=tiny, SS_COMBINE="1")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "comb ok" in out.stdout, (env, out.stderr[-2000:])
