@@ -367,6 +367,164 @@ def measure_phases(torch, dev, args, db, nodes, db_spec, reads, st_np, kern_ms, 
     return ph
 
 
+def measure_config3(torch, dev, args, stream):
+    """BASELINE configs[3] (one large cluster; the reference re-runs jellyfish over ALL reads for every identified cluster,
+    Vote_Strain_L2_Lasso_new_sp.py:354-372, then solves it, identify_strains_L2_Enet_Pscan_new_sp.py:177-478), OUTSIDE the
+    timed region of `value`:
+      cluster_scan  a 10 M-row cluster table = every k-mer of a 5 Mb genome, both orientations, and 20 M resident reads of that
+                    genome (600-fold, 0.5 % substitutions): scan kernel in file order and binned (ss_reorder.hip), with the
+                    hits of a tile added up in LDS (ss_db_expect_hits, the product's setting) and without
+      l2_solve      K = 5 M k-mers x S = 300 strains, three strains present: detect_core from the device image, phases;
+                    abundances against the oracle on a sub-sample of the rows"""
+    from strainscan_amd import _lib
+    from oracle import oracle as orc
+    out = {}
+    # ---- cluster scan -------------------------------------------------------------------------------------------------
+    G, n_reads = args.cluster_genome, args.reads
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    genome = torch.randint(0, 4, (G + 200,), generator=g, device=dev, dtype=torch.uint8)
+    key, rc, okey, orc_ = _kmer_keys(torch, genome, torch.arange(0, G, device=dev), dev)
+    keys = torch.stack([key, rc], 1).reshape(-1).cpu().numpy().view(np.uint64)
+    okeys = torch.stack([okey, orc_], 1).reshape(-1).cpu().numpy().view(np.uint64)
+    del key, rc, okey, orc_
+    asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)
+    reads = torch.empty((n_reads, READ_LEN + 1), dtype=torch.uint8, device=dev)
+    ar = torch.arange(READ_LEN, device=dev)
+    st = torch.randint(0, G, (n_reads,), generator=g, device=dev)
+    for lo in range(0, n_reads, 1 << 20):
+        s_ = st[lo:lo + (1 << 20)]
+        c = genome[s_[:, None] + ar[None, :]]
+        err = torch.rand(c.shape, generator=g, device=dev) < 0.005
+        c = torch.where(err, torch.randint(0, 4, c.shape, generator=g, device=dev, dtype=torch.uint8), c)
+        rev = torch.rand((s_.numel(),), generator=g, device=dev) < 0.5
+        c = torch.where(rev[:, None], c.flip(1) ^ 2, c)
+        reads[lo:lo + (1 << 20), :READ_LEN] = asc[c.long()]
+    reads[:, READ_LEN] = 10
+    flat = reads.view(-1)
+
+    def kernel_ms(fn, db, reps=3):
+        ts = []
+        for _ in range(reps + 1):
+            db.reset(stream)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts[1:]))
+
+    def fracs(ms, hits):
+        return dict(frac=round(n_reads * BYTES_PER_READ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    frac_with_hit_bytes=round((n_reads * BYTES_PER_READ + 8.0 * hits) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+
+    db = _lib.KmerDB(keys, np.ones(keys.size, np.uint8), K, True).expect_hits()
+    t_file = kernel_ms(lambda: db.scan_flat_dev(flat.data_ptr(), flat.numel(), stream), db)
+    want = db.counts_rows()
+    hits = int(want.astype(np.int64).sum())
+    rs = _lib.ReadSet.from_flat_dev(flat.data_ptr(), flat.numel(), order=True)
+    t_bin = kernel_ms(lambda: rs.scan_into(db, stream), db)
+    equal = bool(np.array_equal(db.counts_rows(), want))
+    db.expect_hits(False)
+    t_bin_plain = kernel_ms(lambda: rs.scan_into(db, stream), db)
+    equal = equal and bool(np.array_equal(db.counts_rows(), want))
+    db.expect_hits(True)
+    # the oracle on a sub-sample (checker only)
+    n_s = min(n_reads, 200_000)
+    threads = max(1, min(orc.lib().orc_omp_threads(), int(_lib.lib().ss_host_cpus())))
+    got = orc.count_flat(okeys, K, flat[: n_s * (READ_LEN + 1)].cpu().numpy(), threads)
+    db.reset(stream)
+    sub = _lib.ReadSet.from_flat_dev(flat.data_ptr(), n_s * (READ_LEN + 1), order=True)
+    sub.scan_into(db, stream)
+    torch.cuda.synchronize()
+    parity = bool(np.array_equal(db.counts_rows(), got))
+    sub.close()
+    out["cluster_scan"] = dict(
+        workload="cluster table of %d rows (every 31-mer of a %.0f Mb genome, both orientations), %d reads of that genome, %d-fold"
+                 % (keys.size, G / 1e6, n_reads, n_reads * READ_LEN // G),
+        hits=hits, hits_per_read=round(hits / n_reads, 1),
+        file_order=dict(kernel_ms=round(t_file, 3), **fracs(t_file, hits)),
+        binned=dict(kernel_ms=round(t_bin, 3), **fracs(t_bin, hits), m_reads_per_s=round(n_reads / t_bin / 1e3, 1)),
+        binned_without_lds_combining=dict(kernel_ms=round(t_bin_plain, 3), **fracs(t_bin_plain, hits)),
+        counters_added_per_s_binned=round(hits / (t_bin * 1e-3) / 1e9, 1), counters_unit="G hits/s",
+        counts_equal_across_orders=equal, parity_on_sample=parity, parity_sample="first %d reads vs oracle orc_count_flat" % n_s,
+        bound="VALU issue (profiles/r04_cluster_scan_pmc_summary.txt: 5.4 G wave instructions per launch); a global atomicAdd "
+              "costs one of 27 G line requests/s whatever it carries (profiles/r04_atomics_micro_40MB.txt)")
+    rs.close()
+    db.close()
+    del reads, flat, genome, st
+    torch.cuda.empty_cache()
+
+    # ---- layer-2 solve ------------------------------------------------------------------------------------------------
+    import contextlib
+    import io
+    import scipy.sparse as sp
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    from strainscan_amd import l2 as L2
+    Kc, S, NSEG = args.l2_rows, args.l2_strains, 64
+    rs_ = np.random.RandomState(5)
+    pres = rs_.random_sample((S, NSEG)) < 0.35
+    seg = rs_.randint(0, NSEG, size=Kc)
+    depths = {3 % S: 30.0, 57 % S: 11.0, 120 % S: 5.0}
+    lam = np.zeros(Kc)
+    for s_i, d in depths.items():
+        lam += pres[s_i, seg] * d
+    y = rs_.poisson(lam).astype(np.int64)
+    y[y == 1] = 0
+    ids = ["S%03d" % i for i in range(S)]
+    W = ((Kc + 31) // 32 + 3) & ~3
+    seg_d = torch.from_numpy(seg).to(dev)
+    pres_d = torch.from_numpy(pres).to(dev)
+    wts = (1 << torch.arange(32, device=dev, dtype=torch.int64))
+    planes = np.zeros(S * W, np.uint32)
+    pad = W * 32 - Kc
+    for s_i in range(S):
+        b = pres_d[s_i][seg_d]
+        b = torch.cat([b, torch.zeros(pad, dtype=torch.bool, device=dev)]).view(W, 32).to(torch.int64)
+        planes[s_i * W:(s_i + 1) * W] = (b * wts).sum(1).cpu().numpy().astype(np.uint32)
+    om = sp.csr_matrix(np.ones((Kc, 1), np.int8))
+    npp = float(np.median(y[y != 0]) * 1000)
+    walls, trace = [], {}
+    for _ in range(3):
+        img = L2.ClusterImage.from_planes(planes, Kc, S)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = m.detect_core(None, om, ids, y.copy(), K, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=trace, img=img)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        img.close()
+    t0 = time.perf_counter()
+    L2.shuffle_split_test_bits(trace["n_rows"], 20, 0.5, 0)
+    split_ms = (time.perf_counter() - t0) * 1e3
+    # sub-sample of the rows through the product and through the oracle
+    Ks = min(Kc, args.l2_check_rows)
+    Xs = sp.csr_matrix(pres[:, seg[:Ks]].T.astype(np.int8))
+    ys = y[:Ks]
+    tr2 = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        r2 = m.detect_core(Xs, sp.csr_matrix(np.ones((Ks, 1), np.int8)), ids, ys.copy(), K, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=tr2)
+    cols, names, scov, sval, fsrc, depth = orc.prescan_packed(Xs, ys, ys, ids, 40 * K, 0, 0, 0)
+    keep = (ys >= 0) & (ys <= npp)
+    Xd = Xs[:, cols].toarray()[keep]
+    al, mse = orc.enet_cv(Xd, ys[keep])
+    a_, _, _ = orc.lasso_mpm(al, mse)
+    coef = orc.enet_fit(Xd, ys[keep], a_)
+    rel = coef / coef.sum()
+    got = np.array([float(r2[0].get(n, 0.0)) for n in names])
+    tm = trace.get("timing_ms", {})
+    out["l2_solve"] = dict(
+        workload="K = %d k-mers x S = %d strains (bit planes resident), strains at 30 / 11 / 5 fold" % (Kc, S),
+        wall_ms=round(min(walls), 2), wall_ms_all=[round(w, 2) for w in walls],
+        phases_ms={k_: round(v, 2) for k_, v in tm.items()},
+        shuffle_split_generator_ms=round(split_ms, 2),
+        selected=list(res[0].keys()), rel=[round(float(v), 6) for v in res[0].values()],
+        abundance_max_abs_diff=float(np.abs(got - rel).max()),
+        prescan_equal=bool(names == list(r2[2].keys()) and {k_: int(v) for k_, v in r2[3].items()} == {k_: int(v) for k_, v in sval.items()}),
+        check="the first %d rows through detect_core and through oracle.prescan_packed + enet_cv + lasso_mpm + enet_fit" % Ks)
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -387,6 +545,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-readset", action="store_true", help="skip the extra measurement over the product's resident read set")
     ap.add_argument("--phase-reads", type=int, default=4_000_000, help="reads of the FASTQ sample written for the phase breakdown")
     ap.add_argument("--gz-reads", type=int, default=1_000_000, help="reads of the .fastq.gz pair of the phase breakdown (0 = skip)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the cluster_scan / l2_solve blocks (BASELINE configs[3])")
+    ap.add_argument("--cluster-genome", type=int, default=5_000_000, help="bases of the cluster_scan block's genome (rows = 2x)")
+    ap.add_argument("--l2-rows", type=int, default=5_000_000)
+    ap.add_argument("--l2-strains", type=int, default=300)
+    ap.add_argument("--l2-check-rows", type=int, default=400_000)
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
     return ap.parse_args(argv)
@@ -742,6 +905,11 @@ def main(argv=None):
                       allreduce_note="flags MAX-all-reduce + pack + SUM-all-reduce of the touched nodes' counts + unpack, "
                                      "no host synchronisation inside (dist.exchange_touched)",
                       index=index_how)
+    config3 = None
+    if rank == 0 and world == 1 and not args.no_config3 and not args.calib_stream:
+        del reads
+        torch.cuda.empty_cache()
+        config3 = measure_config3(torch, dev, args, stream)
     if rank == 0:
         out = dict(metric="M reads/sec vs 1433-strain E. coli DB", value=round(reads_per_s / 1e6, 3),
                    unit="M reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -760,6 +928,7 @@ def main(argv=None):
                                table_layout=layout,
                                parallelism="reads sharded x%d, table replicated, all-reduce of the touched nodes' hit counts" % world),
                    roofline=roofline, cpu_baseline=cpu, phases=phases, resident_read_set=readset,
+                   cluster_scan=(config3 or {}).get("cluster_scan"), l2_solve=(config3 or {}).get("l2_solve"),
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
                               harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"]),

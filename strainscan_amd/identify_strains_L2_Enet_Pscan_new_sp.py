@@ -118,15 +118,28 @@ def enet_cv_fit(img, cols, py, keep_rows, trace=None, split=None):
     """ElasticNetCV -> lasso_mpm -> ElasticNet (:433-456) on the selected columns / kept rows.
     -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests.  `split`: a future
     of shuffle_split_test_bits(n, ...) started earlier (the splits depend on the number of kept rows only)."""
+    import time
+    lap = [time.perf_counter()]
+    tm = trace.setdefault("timing_ms", {}) if trace is not None else {}
+
+    def mark(name):
+        now = time.perf_counter()
+        tm[name] = tm.get(name, 0.0) + (now - lap[0]) * 1e3
+        lap[0] = now
+
     p = len(cols)
     kept = np.nonzero(keep_rows)[0]
     n = int(kept.size)
+    y_dev = img.u32(np.where(keep_rows, py, 0))
+    mark("fit_vectors_host")
     bits, n_test = split.result() if split is not None else L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
+    mark("wait_for_shuffle_split")
     assert bits.size == n
     fold = np.zeros(img.K, np.uint32)
     fold[kept] = bits | np.uint32(1 << 31)
-    y_dev = img.u32(np.where(keep_rows, py, 0))
+    mark("fit_vectors_host")
     stats = img.pattern_stats(cols, y_dev, L2.DevBuf.from_array(fold), CV_NITER)
+    mark("pattern_stats")
     total = stats[CV_NITER]
     Qt, qt, yyt, nt = L2.gram_from_stats(total, p)
     assert int(nt) == n
@@ -141,10 +154,12 @@ def enet_cv_fit(img, cols, py, keep_rows, trace=None, split=None):
         nte[f] = float(stats[f][:, 0].astype(np.int64).sum())
     cv = L2.enet_path_gram(Q, q, yy, ntr, alphas, n_test=nte, test_stats=stats[:CV_NITER], l1_ratio=0.5,
                            max_iter=MAX_NITER, tol=1e-4, positive=True)
+    mark("enet_cv_path")
     alpha, _, _ = lasso_mpm(alphas, cv["mse"])
     fit = L2.enet_path_gram(Qt[None], qt[None], [yyt], [nt], [alpha], l1_ratio=0.5, max_iter=MAX_NITER, tol=1e-4,
                             positive=True)
     coef = fit["coefs"][0, 0].copy()
+    mark("refit")
     if trace is not None:
         trace.update(alphas_=alphas, mse_path_=cv["mse"], alpha=float(alpha), coef_=coef, n_rows=n, p=p,
                      n_iter=int(fit["iters"][0, 0]))
@@ -155,6 +170,10 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
                 trace=None, img=None):
     """detect_strains on in-memory matrices (X: K x S CSR, om: K x n_clusters CSR); `img`: the device image
     of X when the caller already has one (X is then not looked at)."""
+    import time
+    t_begin = time.perf_counter()
+    if trace is not None:
+        trace["timing_ms"] = {}
     new_als = [int(a - 1) for a in all_cls]
     ln = np.asarray(om.tocsr()[:, new_als].sum(axis=1)).ravel().astype(np.int64)   # :191-197
     ln[ln > 1] = 0
@@ -170,11 +189,16 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, n_keep, CV_NITER, TEST_SIZE, 0) \
         if n_keep >= 200000 else None
     own_img = img is None
+    t_pro = time.perf_counter()
     if own_img:
         img = L2.ClusterImage(X)
+    t_img = time.perf_counter()
     try:
         out_columns, out_strains, strain_cov, strain_val, final_src, depth = pre_scan(
             img, py, py_u, sid, cutoff, l2, pmode, emode)
+        if trace is not None:
+            trace["timing_ms"].update(prologue_host=(t_pro - t_begin) * 1e3, image=(t_img - t_pro) * 1e3,
+                                      pre_scan=(time.perf_counter() - t_img) * 1e3)
         if len(out_columns) == 1:                                              # :379-382
             return dict(zip(out_strains, [1])), dict(zip(out_strains, [depth])), strain_cov, strain_val, final_src
         print("Pre-scan finished, now we will start ElasticNet fitting...")

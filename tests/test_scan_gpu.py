@@ -788,7 +788,7 @@ def test_bench_line_contract_and_exchange_path():
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(repo, "bench.py"), "--reads", "300000", "--leaves", "23", "--steps", "2", "--warmup", "1",
-            "--phase-reads", "100000"]
+            "--phase-reads", "100000", "--cluster-genome", "200000", "--l2-rows", "300000", "--l2-strains", "40", "--l2-check-rows", "100000"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for shape in ("sampled", "contiguous"):
         r = subprocess.run(base + ["--db-shape", shape], env=env, capture_output=True, timeout=600)
@@ -797,8 +797,16 @@ def test_bench_line_contract_and_exchange_path():
         assert len(lines) == 1
         d = json.loads(lines[0])
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                    "dtype", "data", "config", "roofline", "cpu_baseline", "phases", "e2e_reads_per_s"):
+                    "dtype", "data", "config", "roofline", "cpu_baseline", "phases", "e2e_reads_per_s", "cluster_scan", "l2_solve"):
             assert key in d, key
+        # BASELINE configs[3] beside the headline: the cluster scan (both read orders, counts equal, oracle on a sub-sample)
+        # and the layer-2 solve (phases, abundances against the oracle on a sub-sample of the rows)
+        cs, l2s = d["cluster_scan"], d["l2_solve"]
+        assert cs["counts_equal_across_orders"] is True and cs["parity_on_sample"] is True and cs["hits"] > 0
+        for k_ in ("file_order", "binned", "binned_without_lds_combining"):
+            assert cs[k_]["kernel_ms"] > 0 and 0 < cs[k_]["frac"] < cs[k_]["frac_with_hit_bytes"]
+        assert l2s["prescan_equal"] is True and l2s["abundance_max_abs_diff"] < 1e-5 and l2s["wall_ms"] > 0
+        assert len(l2s["selected"]) >= 2 and "pattern_stats" in l2s["phases_ms"] and "pre_scan" in l2s["phases_ms"]
         assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["db_shape"] == shape and d["vs_baseline"] is None
         rf = d["roofline"]
         assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0
