@@ -281,7 +281,7 @@ def _big_cluster(K, S, depths, seed, near_dup=None, density=0.35, G=64):
     return X, O, ["S%03d" % i for i in range(S)], y
 
 
-@pytest.mark.parametrize("case", ["three_strains", "near_duplicates"])
+@pytest.mark.parametrize("case", ["three_strains", "near_duplicates", "full_5M_x_300"])
 def test_detect_core_at_config3_size(case):
     """BASELINE configs[3] scale: one cluster of K = 2 M k-mers x S = 200 strains (140 M non-zeros).  detect_core against
     the oracle on the same inputs: every pre-scan integer bit-exact (oracle.prescan_packed = prescan on packed columns,
@@ -290,8 +290,8 @@ def test_detect_core_at_config3_size(case):
     collinear, which is where the refit's Gram form could drift from sklearn's residual form)."""
     from oracle import oracle as orc
     from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
-    K, S = 2_000_000, 200
-    if case == "three_strains":
+    K, S = (5_000_000, 300) if case == "full_5M_x_300" else (2_000_000, 200)   # full: 513 M non-zeros, the bench's l2_solve block
+    if case != "near_duplicates":
         X, O, ids, y = _big_cluster(K, S, {3: 30.0, 57: 11.0, 120: 5.0}, seed=5)
     else:
         X, O, ids, y = _big_cluster(K, S, {3: 24.0, 57: 9.0, 120: 5.0}, seed=6, near_dup=(3, 57, 4))

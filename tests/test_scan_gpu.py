@@ -733,7 +733,8 @@ def test_full_size_config1(L, shape):
     25.4 M rows, node sets sampled as Build_tree.py:590-591 writes them, or contiguous) and 20 M reads.  The first
     2.5 M reads against the oracle, bit for bit; then shard additivity over the rest (counts of the whole batch = counts
     of the sample + counts of the remainder: integer sums, the property the multi-GPU split relies on); node statistics of
-    all 1645 nodes: harvest path = row-gather path = the oracle's match_node on the nodes with hits."""
+    all 1645 nodes: harvest path = row-gather path = the oracle's match_node on the nodes with hits.  The same through the
+    binned resident read set, the product's default."""
     import ctypes as C
     import torch
     import bench
@@ -767,6 +768,23 @@ def test_full_size_config1(L, shape):
     ns._h, ns.n_nodes = h, spec["n_nodes"]
     a, b = ns.reduce(db), ns.harvest(db)
     assert a.tobytes() == b.tobytes()
+    # what the PRODUCT scans: the same reads as a resident set binned by locus (ss_reorder.hip, the loader's default) --
+    # (a) the first 2.5 M reads, binned on their own, against the oracle's counts; (b) all 20 M: counts and the statistics
+    # of all 1645 nodes equal to the scan in file order
+    rs_a = L.ReadSet.from_flat_dev(reads.data_ptr(), cut, order=True)
+    db.reset()
+    rs_a.scan_into(db)
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db.counts_rows(), want)
+    rs_a.close()
+    rs_all = L.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
+    assert rs_all.info()["n_bases"] == reads.numel()
+    db.reset()
+    rs_all.scan_into(db)
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db.counts_rows(), c_all)
+    assert ns.harvest(db).tobytes() == b.tobytes()
+    rs_all.close()
     hot = np.nonzero(b["n_pos"])[0]
     assert 10 <= hot.size <= 40
     valid = np.ones(n_rows, np.uint8)
