@@ -320,6 +320,18 @@ int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **
 int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes);
 int ss_l2_destroy(ss_l2 *h);
 int ss_l2_info(const ss_l2 *h, uint64_t *K, uint32_t *S, uint64_t *words_per_plane);
+/* The O(K) vector bookkeeping of detect_strains on the device (round 4; it was a dozen single-threaded numpy passes over
+ * K rows: 83 ms of a 5 M-row cluster's solve).  ss_l2_set_overlap: overlap_matrix.npz as CSR (int8 K x n_cols), once per
+ * cluster.  ss_l2_prepare (:191-197, 36-38, 402-415): y_host = input_y as int64[K]; col_sel[c] = how often column c is
+ * among the identified clusters' columns (`overlap.A[:, all_cls - 1]`); writes y and y_u = y * ln as uint32[K], the bit
+ * vectors [y > 1], [y_u > 1], [row kept: npp25 <= y <= min(npp75, npp_out)] (W words each) and y of the kept rows (0
+ * elsewhere); out = {kept rows, any y_u > 0, a count negative or beyond 32 bits}.  ss_l2_fold: the fold words of
+ * ss_l2_pattern_stats from the kept-row bit vector and ShuffleSplit's test bits per kept row (host, n_keep words). */
+int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, const int8_t *data, uint32_t n_cols);
+int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel, double npp25, double npp75, double npp_out,
+                  uint32_t *y_dev, uint32_t *yu_dev, uint32_t *G_dev, uint32_t *Gu_dev, uint32_t *keep_dev, uint32_t *ykeep_dev,
+                  uint64_t out[3]);
+int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, uint64_t n_keep, uint32_t *fold_dev);
 /* out1[s] = |X_s & A|, out2[s] = |X_s & A & B|; NULL = all ones.  Serves stat_cov/cal_cov_all
  * (:33-49: A = NULL, B = [y > 1]), get_remainc (:94-108) and get_candidate_arr (:121-134):
  * A = not-yet-used k-mers, B = [y_u > 1] or [y > 1]. */

@@ -128,6 +128,9 @@ SIGNATURES = {
     "ss_l2_info": (i32, [vp, P(u64), P(u32), P(u64)]),
     "ss_l2_popc2": (i32, [vp, vp, vp, vp, vp]),
     "ss_l2_andnot_col": (i32, [vp, u32, vp]),
+    "ss_l2_set_overlap": (i32, [vp, vp, vp, vp, u32]),
+    "ss_l2_prepare": (i32, [vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp]),
+    "ss_l2_fold": (i32, [vp, vp, vp, u64, vp]),
     "ss_l2_quantile_sums": (i32, [vp, vp, vp, u32, C.c_double, C.c_double, vp, vp, vp, vp, vp]),
     "ss_l2_pattern_stats": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "ss_enet_path_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, i32, C.c_double, i32, C.c_double, i32, vp, vp,

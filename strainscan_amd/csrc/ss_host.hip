@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -213,9 +214,11 @@ int ss_memset_dev(void *dst, int byte, uint64_t bytes, void *stream)
 // Restated: MT19937 seeded by init_genrand(seed) (numpy _legacy_seeding for an integer), permutation(n) =
 // Fisher-Yates from the top -- for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j]) -- with
 // random_interval(max) = 32-bit draws masked to the next power of two minus one, redrawn while > max
-// (numpy/random/src/distributions: random_interval; mtrand.pyx: _shuffle_raw).  One thread walks the
-// generator (the splits share ONE stream, in order) and writes the swap partners of a split; worker
-// threads apply the swaps of different splits concurrently (that is where the cache misses are).
+// (numpy/random/src/distributions: random_interval; mtrand.pyx: _shuffle_raw).  Three stages on host threads (round 4:
+// the first two were one, 165 ms for 5 M rows): one thread runs the Mersenne Twister and fills a ring of blocks of
+// tempered words; one walks them in stream order (the splits share ONE stream) through the rejection rule -- a chain of
+// two dependent instructions per word, all that is inherently serial here -- and writes the swap partners of a split;
+// worker threads apply the swaps of different splits concurrently (that is where the cache misses are).
 // Pinned against numpy itself in tests/test_abi_and_host.py and against sklearn's ShuffleSplit golden.
 // ---------------------------------------------------------------------------------------------
 namespace {
@@ -254,6 +257,39 @@ struct MT19937 {
         return out[pos++];
     }
 };
+
+// the generator on a thread of its own: blocks of 624 x 32 tempered words in a ring, consumed in order
+struct MTStream {
+    static constexpr int NB = 8, BLK = 624 * 32;
+    std::vector<uint32_t> ring;
+    std::atomic<uint64_t> produced{0}, consumed{0};
+    std::atomic<bool> stop{false};
+    std::thread th;
+    explicit MTStream(uint32_t seed) : ring((size_t)NB * BLK)
+    {
+        th = std::thread([this, seed] {
+            MT19937 rng(seed);
+            while (!stop.load(std::memory_order_relaxed)) {
+                const uint64_t p = produced.load(std::memory_order_relaxed);
+                if (p - consumed.load(std::memory_order_acquire) >= (uint64_t)NB) { std::this_thread::yield(); continue; }
+                uint32_t *dst = ring.data() + (p % NB) * BLK;
+                for (int b = 0; b < BLK / 624; b++) {
+                    rng.refill();
+                    memcpy(dst + b * 624, rng.out, 624 * 4);
+                }
+                produced.store(p + 1, std::memory_order_release);
+            }
+        });
+    }
+    ~MTStream() { stop = true; th.join(); }
+    // block number `i` (0, 1, 2, ... in order); the block before it is handed back to the producer
+    const uint32_t *block(uint64_t i)
+    {
+        consumed.store(i, std::memory_order_release);
+        while (produced.load(std::memory_order_acquire) <= i) std::this_thread::yield();
+        return ring.data() + (i % NB) * BLK;
+    }
+};
 }  // namespace
 
 int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, uint32_t *bits)
@@ -264,12 +300,24 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         for (uint64_t i = 0; i < n_test; i++) bits[i] = (1u << n_splits) - 1u;      // permutation(1) = [0]
         return SS_OK;
     }
-    MT19937 rng(seed);
-    const unsigned in_flight = std::max(1u, std::min(8u, ss::host_cpus()));
+    MTStream rng(seed);
+    uint64_t blk = 0;
+    const uint32_t *o = rng.block(0);
+    int pos = 0;
+    // swaps of several splits at once: one core each, two stay free for the generator's two threads
+    unsigned in_flight = std::max(1u, std::min(20u, ss::host_cpus() > 3 ? ss::host_cpus() - 2 : 1u));
+    if (const char *e = getenv("SS_SPLIT_IN_FLIGHT")) in_flight = (unsigned)std::max(1, atoi(e));
+    static const bool trace = getenv("SS_SPLIT_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double t_wait = 0;
     std::vector<std::thread> pool((size_t)n_splits);
     std::atomic<int> err(SS_OK);
     for (int f = 0; f < n_splits; f++) {
-        if (f >= (int)in_flight) pool[(size_t)f - in_flight].join();                 // bounds the memory: in_flight x 8 n bytes
+        if (f >= (int)in_flight) {                                                   // bounds the memory: in_flight x 8 n bytes
+            const auto t0 = std::chrono::steady_clock::now();
+            pool[(size_t)f - in_flight].join();
+            t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
         std::vector<uint32_t> *js = new (std::nothrow) std::vector<uint32_t>();
         if (js) { try { js->resize(n); } catch (...) { delete js; js = nullptr; } }
         if (!js) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); continue; }
@@ -281,16 +329,20 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
             const uint64_t lo = (uint64_t)(mask >> 1) + 1;
             // branch-free rejection: every draw is written to J[i]; i moves on only when the draw is accepted
             for (uint64_t i = hi; i >= lo;) {
-                if (rng.pos == 624) rng.refill();
-                const int avail = 624 - rng.pos;
-                const uint32_t *o = rng.out + rng.pos;
-                int k = 0;
-                for (; k < avail && i >= lo; k++) {
-                    const uint32_t v = o[k] & mask;
-                    J[i] = v;
-                    i -= (uint64_t)(v <= (uint32_t)i);
+                if (pos == MTStream::BLK) { o = rng.block(++blk); pos = 0; }
+                // at most `room` words can be consumed before i drops below lo: no bound check on i inside
+                const uint64_t room = i - lo + 1;
+                const int avail = (int)std::min<uint64_t>((uint64_t)(MTStream::BLK - pos), room);
+                const uint32_t *ob = o + pos;
+                uint32_t ii = (uint32_t)i;
+                for (int k = 0; k < avail; k++) {
+                    const uint32_t v = ob[k] & mask;
+                    J[ii] = v;
+                    ii -= (uint32_t)(v <= ii);
                 }
-                rng.pos += k;
+                pos += avail;
+                i = ii;
+                if (ii < (uint32_t)lo) break;           // (only when lo > 0: i is unsigned)
             }
             hi = lo - 1;
         }
@@ -299,13 +351,25 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
             try { x.resize(n); } catch (...) { err = SS_ENOMEM; delete js; return; }
             for (uint64_t i = 0; i < n; i++) x[i] = (uint32_t)i;
             const uint32_t *J = js->data();
-            for (uint64_t i = n - 1; i >= 1; i--) std::swap(x[i], x[J[i]]);
+            // (the partners are known ahead: their cache lines are requested 24 swaps early -- 20 MB of x do not fit L2)
+            uint32_t *xp = x.data();
+            for (uint64_t i = n - 1; i >= 1; i--) {
+                if (i > 24) __builtin_prefetch(&xp[J[i - 24]], 1, 1);
+                const uint32_t j = J[i], a = xp[i];
+                xp[i] = xp[j];
+                xp[j] = a;
+            }
             const uint32_t bit = 1u << f;
             for (uint64_t i = 0; i < n_test; i++) __atomic_fetch_or(&bits[x[i]], bit, __ATOMIC_RELAXED);
             delete js;
         });
     }
+    const double t_gen = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     for (int f = std::max(0, n_splits - (int)in_flight); f < n_splits; f++) pool[(size_t)f].join();
+    if (trace)
+        fprintf(stderr, "[shuffle-split] n = %llu: generator done at %.1f ms (%.1f ms of it waiting for swap threads, %u in flight), all at %.1f ms\n",
+                (unsigned long long)n, t_gen * 1e3, t_wait * 1e3, in_flight,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
     return err;
 }
 

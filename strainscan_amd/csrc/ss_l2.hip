@@ -18,6 +18,8 @@
 // statistics equal the reference's BLAS results to the last bit regardless of summation order.
 #include "ss_common.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <vector>
 
@@ -26,6 +28,12 @@ struct ss_l2 {
     uint32_t S = 0;
     uint64_t W = 0;          // dwords per plane (multiple of 4 for 16-byte loads)
     uint32_t *d_x = nullptr; // [S][W]
+    // overlap_matrix.npz (CSR int8, K x #clusters) for ss_l2_prepare, uploaded once per cluster (ss_l2_set_overlap)
+    int64_t *d_om_ptr = nullptr;
+    int32_t *d_om_idx = nullptr;
+    int8_t *d_om_val = nullptr;
+    uint32_t om_cols = 0;
+    bool has_om = false;
 };
 
 namespace {
@@ -436,9 +444,149 @@ unsigned grid_for(uint64_t work_items, unsigned rows)
     return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, std::max<uint64_t>(cap, 8)));
 }
 
+// ---- the O(K) vectors of detect_strains (identify_strains_L2_Enet_Pscan_new_sp.py:191-197, 36-38, 402-415), one lane per
+// row: ln = the row of overlap_matrix over the identified clusters' columns, summed, values above one zeroed; py_u = py * ln;
+// the bit vectors py > 1 and py_u > 1; the rows the regression keeps (npp25 <= py <= min(npp75, npp_out), compared as doubles
+// like numpy does: a NaN bound keeps every row) and their y.  out[0] = kept rows, out[1] = any py_u > 0, out[2] = a count
+// that does not fit 32 bits or is negative (the caller raises, as the host path did).
+__global__ __launch_bounds__(NT) void l2_prepare_kernel(const long long *__restrict__ y, uint64_t K, const int64_t *__restrict__ om_ptr,
+                                                        const int32_t *__restrict__ om_idx, const int8_t *__restrict__ om_val,
+                                                        const uint8_t *__restrict__ sel, uint32_t n_cols, double npp25, double npp75,
+                                                        double npp_out, uint32_t *__restrict__ y32, uint32_t *__restrict__ yu32,
+                                                        uint32_t *__restrict__ G, uint32_t *__restrict__ Gu, uint32_t *__restrict__ keep,
+                                                        uint32_t *__restrict__ ykeep, unsigned long long *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;          // the grid covers whole 64-row groups of the padded planes
+    const bool in = i < K;
+    const long long v = in ? y[i] : 0;
+    long long ln = 0;
+    if (in && om_ptr) {
+        for (int64_t j = om_ptr[i], e = om_ptr[i + 1]; j < e; j++) {
+            const uint32_t c = (uint32_t)om_idx[j];
+            if (c < n_cols) ln += (long long)om_val[j] * sel[c];
+        }
+    }
+    if (ln > 1) ln = 0;
+    const bool bad = v < 0 || v > 0xFFFFFFFFll || ln < 0;
+    const uint32_t yv = (uint32_t)v, yu = ln == 1 ? yv : 0u;
+    const double d = (double)v;
+    const bool kp = in && !(d < npp25 || d > npp75 || d > npp_out);
+    const uint64_t bg = __ballot(in && yv > 1u), bu = __ballot(yu > 1u), bk = __ballot(kp);
+    if (in) { y32[i] = yv; yu32[i] = yu; ykeep[i] = kp ? yv : 0u; }
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 || lane == 32) {
+        const int sh = lane;                                              // 0 or 32
+        const uint64_t w = i >> 5;
+        G[w] = (uint32_t)(bg >> sh); Gu[w] = (uint32_t)(bu >> sh); keep[w] = (uint32_t)(bk >> sh);
+    }
+    if (lane == 0) {
+        if (bk) atomicAdd(&out[0], (unsigned long long)__popcll(bk));
+        if (__ballot(yu > 0u)) atomicOr(&out[1], 1ull);
+    }
+    if (bad) atomicOr(&out[2], 1ull);
+}
+
+__global__ __launch_bounds__(NT) void l2_popc_words_kernel(const uint32_t *__restrict__ bits, uint64_t W, uint32_t *__restrict__ cnt)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * NT + threadIdx.x;
+    if (w < W) cnt[w] = (uint32_t)__popc(bits[w]);
+}
+// fold word of row i: 0 when the row is not kept, else bit 31 | the test-fold bits of the row's RANK among the kept rows
+// (ShuffleSplit permutes the kept rows: identify_strains_L2_Enet_Pscan_new_sp.py:402-442)
+__global__ __launch_bounds__(NT) void l2_fold_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pre, uint64_t K,
+                                                     const uint32_t *__restrict__ split_bits, uint32_t *__restrict__ fold)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= K) return;
+    const uint32_t w = keep[i >> 5], b = (uint32_t)i & 31u;
+    fold[i] = ((w >> b) & 1u) ? (split_bits[pre[i >> 5] + (uint32_t)__popc(w & ((1u << b) - 1u))] | 0x80000000u) : 0u;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, const int8_t *data, uint32_t n_cols)
+{
+    if (!h || !indptr) return SS_EINVAL;
+    const uint64_t nnz = (uint64_t)indptr[h->K];
+    if (nnz && (!indices || !data)) return SS_EINVAL;
+    hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
+    h->d_om_ptr = nullptr; h->d_om_idx = nullptr; h->d_om_val = nullptr; h->has_om = false;
+    SS_HIP(hipMalloc((void **)&h->d_om_ptr, (h->K + 1) * 8));
+    SS_HIP(hipMalloc((void **)&h->d_om_idx, std::max<uint64_t>(1, nnz) * 4));
+    SS_HIP(hipMalloc((void **)&h->d_om_val, std::max<uint64_t>(1, nnz)));
+    SS_HIP(hipMemcpy(h->d_om_ptr, indptr, (h->K + 1) * 8, hipMemcpyHostToDevice));
+    if (nnz) {
+        SS_HIP(hipMemcpy(h->d_om_idx, indices, nnz * 4, hipMemcpyHostToDevice));
+        SS_HIP(hipMemcpy(h->d_om_val, data, nnz, hipMemcpyHostToDevice));
+    }
+    h->om_cols = n_cols;
+    h->has_om = true;
+    return SS_OK;
+}
+
+int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel, double npp25, double npp75, double npp_out,
+                  uint32_t *y_dev, uint32_t *yu_dev, uint32_t *G_dev, uint32_t *Gu_dev, uint32_t *keep_dev, uint32_t *ykeep_dev,
+                  uint64_t out[3])
+{
+    if (!h || !h->has_om || !out || (h->K && (!y_host || !y_dev || !yu_dev || !G_dev || !Gu_dev || !keep_dev || !ykeep_dev))) return SS_EINVAL;
+    if (h->om_cols && !col_sel) return SS_EINVAL;
+    out[0] = out[1] = out[2] = 0;
+    if (!h->K) return SS_OK;
+    long long *d_y = nullptr;
+    uint8_t *d_sel = nullptr;
+    unsigned long long *d_out = nullptr;
+    int rc = SS_OK;
+    if (hipMalloc((void **)&d_y, h->K * 8) != hipSuccess || hipMalloc((void **)&d_sel, std::max<uint32_t>(1, h->om_cols)) != hipSuccess ||
+        hipMalloc((void **)&d_out, 24) != hipSuccess)
+        rc = SS_ENOMEM;
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpy(d_y, y_host, h->K * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && h->om_cols) e = hipMemcpy(d_sel, col_sel, h->om_cols, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_out, 0, 24);
+        if (e == hipSuccess) {
+            const uint64_t rows = h->W * 32;                                // every word of the padded bit vectors is written
+            hipLaunchKernelGGL(l2_prepare_kernel, dim3((unsigned)((rows + NT - 1) / NT)), dim3(NT), 0, 0, d_y, h->K, h->d_om_ptr, h->d_om_idx,
+                               h->d_om_val, d_sel, h->om_cols, npp25, npp75, npp_out, y_dev, yu_dev, G_dev, Gu_dev, keep_dev, ykeep_dev, d_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, 24, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { ss::set_last_error("ss_l2_prepare", __FILE__, __LINE__, e); rc = SS_EHIP; }
+    }
+    hipFree(d_y); hipFree(d_sel); hipFree(d_out);
+    return rc;
+}
+
+int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, uint64_t n_keep, uint32_t *fold_dev)
+{
+    if (!h || (h->K && (!keep_dev || !fold_dev)) || (n_keep && !split_bits) || n_keep > h->K) return SS_EINVAL;
+    if (!h->K) return SS_OK;
+    uint32_t *d_cnt = nullptr, *d_pre = nullptr, *d_bits = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = SS_OK;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_pre, (int)h->W);
+    if (e != hipSuccess || hipMalloc((void **)&d_cnt, h->W * 4) != hipSuccess || hipMalloc((void **)&d_pre, h->W * 4) != hipSuccess ||
+        hipMalloc((void **)&d_bits, std::max<uint64_t>(1, n_keep) * 4) != hipSuccess || hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess)
+        rc = SS_ENOMEM;
+    if (!rc) {
+        if (n_keep) e = hipMemcpy(d_bits, split_bits, n_keep * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(l2_popc_words_kernel, dim3((unsigned)((h->W + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, h->W, d_cnt);
+            e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_pre, (int)h->W);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(l2_fold_kernel, dim3((unsigned)((h->K + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, d_pre, h->K, d_bits, fold_dev);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { ss::set_last_error("ss_l2_fold", __FILE__, __LINE__, e); rc = SS_EHIP; }
+    }
+    hipFree(d_cnt); hipFree(d_pre); hipFree(d_bits); hipFree(d_tmp);
+    return rc;
+}
 
 int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out)
 {
@@ -533,6 +681,7 @@ int ss_l2_destroy(ss_l2 *h)
 {
     if (!h) return SS_OK;
     hipFree(h->d_x);
+    hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
     delete h;
     return SS_OK;
 }

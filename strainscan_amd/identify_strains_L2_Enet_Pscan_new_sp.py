@@ -43,12 +43,13 @@ def _stat_cov(valid, total):
     return [float(valid / total) if total != 0 else 0, valid, total]
 
 
-def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
-    """Pre_Scan (:228-373) on the device image `img` (strainscan_amd.l2.ClusterImage).
+def pre_scan(img, vec, sid, cutoff, l2, pmode, emode):
+    """Pre_Scan (:228-373) on the device image `img` (strainscan_amd.l2.ClusterImage) and the device vectors `vec`
+    (ClusterImage.prepare: py, py_u = py * ln and their [> 1] bit vectors).
     -> out_columns, out_strain, strain_cov, strain_val, final_src, dominat_avg_depth"""
     S = img.S
     strain_cov, strain_val, strain_remainc, final_src = {}, {}, {}, {}
-    G = img.bits((py > 1) | (py < 0))                 # ic = ix*iy; ic[ic==1]=0; count_nonzero (:36-38)
+    G = vec.G                                          # ic = ix*iy; ic[ic==1]=0; count_nonzero (:36-38); counts are >= 0
     total, valid = img.popc2(None, G)
     cov_arr = np.array([_stat_cov(valid[i], total[i])[0] for i in range(S)], dtype=float)
     default_cov = 0 if (pmode == 1 or emode == 1) else 0.7
@@ -61,9 +62,8 @@ def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
         float_counts = False
         if np.max(cov_arr) < 0.01:
             l2 = 2
-    use_u = bool(np.sum(py_u) > 0)
-    yy = py_u if use_u else py
-    yy_dev = img.u32(yy)
+    use_u = vec.use_u                                  # np.sum(py_u) > 0
+    yy_dev = vec.yu if use_u else vec.y
     if l2 == 2:
         dom = int(np.where(cov_arr == np.max(cov_arr))[0][0])
     else:                                              # optimize_dominat_y (:136-175), all S columns
@@ -83,7 +83,7 @@ def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
 
     nu = img.ones()                                    # not-yet-used k-mers = ~used_kmer
     img.andnot_col(dom, nu)
-    Gu = img.bits(py_u > 1)
+    Gu = vec.Gu
     all_k, chk = img.popc2(nu, Gu)                     # get_remainc (:94-108): once, always with py_u
     for i in range(S):
         if i == dom:
@@ -91,7 +91,7 @@ def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
         ak = int(all_k[i]) if keep[i] else 0
         ck = int(chk[i]) if keep[i] else 0
         strain_remainc[i] = 0 if ak == 0 else ck / ak
-    Gyy = Gu if use_u else img.bits(py > 1)
+    Gyy = Gu if use_u else G
     for _ in range(MAX_PRESCAN_ITER):
         _, check_all = img.popc2(nu, Gyy)              # get_candidate_arr (:121-134)
         check_all = np.where(keep, check_all, 0)
@@ -114,7 +114,7 @@ def pre_scan(img, py, py_u, sid, cutoff, l2, pmode, emode):
     return out_columns, out_strain, strain_cov, strain_val, final_src, depth
 
 
-def enet_cv_fit(img, cols, py, keep_rows, trace=None, split=None):
+def enet_cv_fit(img, cols, vec, trace=None, split=None):
     """ElasticNetCV -> lasso_mpm -> ElasticNet (:433-456) on the selected columns / kept rows.
     -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests.  `split`: a future
     of shuffle_split_test_bits(n, ...) started earlier (the splits depend on the number of kept rows only)."""
@@ -128,17 +128,15 @@ def enet_cv_fit(img, cols, py, keep_rows, trace=None, split=None):
         lap[0] = now
 
     p = len(cols)
-    kept = np.nonzero(keep_rows)[0]
-    n = int(kept.size)
-    y_dev = img.u32(np.where(keep_rows, py, 0))
-    mark("fit_vectors_host")
+    n = vec.n_keep
+    y_dev = vec.ykeep
     bits, n_test = split.result() if split is not None else L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
     mark("wait_for_shuffle_split")
     assert bits.size == n
-    fold = np.zeros(img.K, np.uint32)
-    fold[kept] = bits | np.uint32(1 << 31)
-    mark("fit_vectors_host")
-    stats = img.pattern_stats(cols, y_dev, L2.DevBuf.from_array(fold), CV_NITER)
+    fold = img.fold_words(vec.keep, bits, n)
+    mark("fold_words")
+    stats = img.pattern_stats(cols, y_dev, fold, CV_NITER)
+    fold.close()
     mark("pattern_stats")
     total = stats[CV_NITER]
     Qt, qt, yyt, nt = L2.gram_from_stats(total, p)
@@ -175,35 +173,35 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     if trace is not None:
         trace["timing_ms"] = {}
     new_als = [int(a - 1) for a in all_cls]
-    ln = np.asarray(om.tocsr()[:, new_als].sum(axis=1)).ravel().astype(np.int64)   # :191-197
-    ln[ln > 1] = 0
-    py = np.asarray(input_y).astype(np.int64)
-    py_u = py * ln
     cutoff = msn * ksize
-    with np.errstate(invalid="ignore"):
-        drop = (py < npp25) | (py > npp75) | (py > npp_out)                    # :402-415
-    # ShuffleSplit's 20 permutations (numpy's sequential legacy generator: ~65 ms per million rows) depend on
-    # the NUMBER of kept rows only: for large clusters they run on a host thread while the matrix is packed
-    # and the pre-scan runs on the device
-    n_keep = int(drop.size - np.count_nonzero(drop))
-    split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, n_keep, CV_NITER, TEST_SIZE, 0) \
-        if n_keep >= 200000 else None
     own_img = img is None
     t_pro = time.perf_counter()
     if own_img:
         img = L2.ClusterImage(X)
     t_img = time.perf_counter()
+    vec = None
     try:
+        if img.om_cols is None:
+            img.set_overlap(om)
+        # ln, py_u, the [> 1] masks, the row filter of :402-415: one pass on the device (ss_l2_prepare)
+        vec = img.prepare(np.asarray(input_y), new_als, npp25, npp75, npp_out)
+        t_vec = time.perf_counter()
+        # ShuffleSplit's 20 permutations (numpy's sequential legacy generator) depend on the NUMBER of kept rows only: for
+        # large clusters they run on host threads while the pre-scan runs on the device
+        split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, vec.n_keep, CV_NITER, TEST_SIZE, 0) \
+            if vec.n_keep >= 200000 else None
         out_columns, out_strains, strain_cov, strain_val, final_src, depth = pre_scan(
-            img, py, py_u, sid, cutoff, l2, pmode, emode)
+            img, vec, sid, cutoff, l2, pmode, emode)
         if trace is not None:
             trace["timing_ms"].update(prologue_host=(t_pro - t_begin) * 1e3, image=(t_img - t_pro) * 1e3,
-                                      pre_scan=(time.perf_counter() - t_img) * 1e3)
+                                      vectors=(t_vec - t_img) * 1e3, pre_scan=(time.perf_counter() - t_vec) * 1e3)
         if len(out_columns) == 1:                                              # :379-382
             return dict(zip(out_strains, [1])), dict(zip(out_strains, [depth])), strain_cov, strain_val, final_src
         print("Pre-scan finished, now we will start ElasticNet fitting...")
-        coef = enet_cv_fit(img, out_columns, py, ~drop, trace, split)
+        coef = enet_cv_fit(img, out_columns, vec, trace, split)
     finally:
+        if vec is not None:
+            vec.close()
         if own_img:
             img.close()
     lasso_coef = np.atleast_1d(coef)
@@ -234,6 +232,33 @@ def _l2_cache_path(input_csv, omatrix):
     tag = cache_tag("%s|%d|%d|%s|%d|%d" % (os.path.realpath(input_csv), st1.st_size, st1.st_mtime_ns,
                                                 os.path.realpath(omatrix), st2.st_size, st2.st_mtime_ns))
     return os.path.join(cdir, "l2_%s.bin" % tag)
+
+
+class _CSR:
+    """The arrays of a CSR matrix without scipy's object around them (its constructor checks and copies)."""
+
+    def __init__(self, indptr, indices, data, shape):
+        self.indptr, self.indices, self.data, self.shape = indptr, indices, data, shape
+        self.nnz = int(len(indices))
+
+    def tocsr(self):
+        return self
+
+
+def _load_npz_csr(path):
+    """scipy.sparse.save_npz's file (Recls_withR_new.py:110-112, Build_overlap_matrix_sp.py:89-98) -> _CSR, without building
+    the scipy matrix: its constructor validates and may copy the index arrays (0.5 G entries for a large cluster); the bit
+    packing kernels and ss_l2_set_overlap check what they need themselves.  Anything but canonical CSR goes through scipy."""
+    with np.load(path, allow_pickle=False) as z:
+        fmt = z["format"].item()
+        fmt = fmt.decode() if isinstance(fmt, bytes) else fmt
+        if fmt != "csr":
+            import scipy.sparse as sp
+            m = sp.load_npz(path).tocsr()
+            m.sum_duplicates()
+            return _CSR(m.indptr, m.indices, m.data, m.shape)
+        shape = tuple(int(x) for x in z["shape"])
+        return _CSR(z["indptr"], z["indices"], z["data"], shape)
 
 
 def _write_l2_cache(path, img, om):
@@ -282,9 +307,9 @@ def _read_l2_cache(path):
     indptr, indices, data = take(np.int64, K + 1), take(np.int32, nnz), take(np.int8, nnz)
     if pos[0] != size or (K and int(indptr[K]) != nnz):
         raise ValueError("inconsistent cluster image")
-    import scipy.sparse as sp          # here, not at module load: a run without layer-2 clusters never pays for it
-    om = sp.csr_matrix((np.array(data), np.array(indices), np.array(indptr)), shape=(K, ncls))
-    return L2.ClusterImage.from_planes(planes, K, S), om
+    img = L2.ClusterImage.from_planes(planes, K, S)
+    img.set_overlap(_CSR(indptr, indices, data, (K, ncls)))      # straight from the map to the device: no scipy object
+    return img, None
 
 
 def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_cov, omatrix, all_cls, l2, msn, pmode,
@@ -303,9 +328,8 @@ def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_co
     if img is None:
         # scipy reads the .npz through zipfile (inflate + CRC: ~7 ms per million non-zeros); done once per
         # database, the bit planes and the overlap arrays are then kept as a raw image
-        import scipy.sparse as sp
-        img = L2.ClusterImage(sp.load_npz(input_csv))
-        om = sp.load_npz(omatrix)
+        img = L2.ClusterImage(_load_npz_csr(input_csv))
+        om = _load_npz_csr(omatrix)
         if cache:
             try:
                 _write_l2_cache(cache, img, om)

@@ -41,14 +41,26 @@ class DevBuf:
             pass
 
 
+class Prepared:
+    """Device vectors of one detect_strains call (ClusterImage.prepare): y, yu = y * ln, ykeep (uint32[K]); G = [y > 1],
+    Gu = [yu > 1], keep = [row kept by the filter of :402-415] (bit vectors); n_keep; use_u = any(yu > 0)."""
+
+    def close(self):
+        for n in ("y", "yu", "ykeep", "G", "Gu", "keep"):
+            b = getattr(self, n, None)
+            if b is not None:
+                b.close()
+
+
 class ClusterImage:
     """all_strains_re.npz (CSR int8, K x S, entries 1) as S bit planes in HBM."""
 
     def __init__(self, X_csr):
         _lib.require_gpu()
         X = X_csr.tocsr()
-        X.sum_duplicates()
-        if X.nnz and not np.all(X.data == 1):
+        if hasattr(X, "sum_duplicates"):
+            X.sum_duplicates()                         # (a scipy matrix; the arrays of a .npz are canonical as scipy wrote them)
+        if X.nnz and np.count_nonzero(np.asarray(X.data) != 1):
             raise ValueError("all_strains_re.npz must be binary (Build_kmer_sets_..._sp.py:412-414 writes 1s)")
         self.K, self.S = X.shape
         indptr = np.ascontiguousarray(X.indptr, np.int64)
@@ -60,6 +72,7 @@ class ClusterImage:
         w = C.c_uint64()
         _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
         self.W = int(w.value)
+        self.om_cols = None
 
     @classmethod
     def from_planes(cls, planes, K, S):
@@ -74,10 +87,58 @@ class ClusterImage:
         w = C.c_uint64()
         _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
         self.W = int(w.value)
+        self.om_cols = None
         if planes.size != self.S * self.W:
             self.close()
             raise ValueError("plane array does not match K, S")
         return self
+
+    # -- the O(K) vectors of detect_strains, on the device ---------------------------------------
+    def set_overlap(self, om):
+        """overlap_matrix.npz (scipy CSR, or anything with indptr / indices / data / shape) -> device, once per cluster."""
+        if not hasattr(om, "indptr"):
+            om = om.tocsr()
+        if om.shape[0] != self.K:
+            raise ValueError("overlap matrix has %d rows, the cluster %d" % (om.shape[0], self.K))
+        indptr = np.ascontiguousarray(om.indptr, np.int64)
+        indices = np.ascontiguousarray(om.indices, np.int32)
+        data = np.ascontiguousarray(om.data, np.int8)
+        _lib.check(_lib.lib().ss_l2_set_overlap(self._h, _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(data), int(om.shape[1])),
+                   "ss_l2_set_overlap")
+        self.om_cols = int(om.shape[1])
+        return self
+
+    def prepare(self, y, columns, npp25, npp75, npp_out):
+        """identify_strains_L2_Enet_Pscan_new_sp.py:191-197 + the masks of :36-38 and :402-415 in one pass over the rows.
+        `columns`: the 0-based overlap columns of the identified clusters (as `overlap.A[:, columns]`: repeats count twice,
+        negative numbers from the end).  -> Prepared (device vectors, n_keep, use_u)."""
+        y = np.ascontiguousarray(y, np.int64)
+        if y.size != self.K:
+            raise ValueError("y has %d entries, the cluster %d rows" % (y.size, self.K))
+        sel = np.zeros(max(1, self.om_cols), np.uint8)
+        for c in columns:
+            c = int(c)
+            if c < -self.om_cols or c >= self.om_cols:
+                raise IndexError("index (%d) out of range" % c)      # as scipy's column indexing does
+            sel[c % self.om_cols] += 1
+        v = Prepared()
+        nb = self.W * 4
+        v.y, v.yu, v.ykeep = DevBuf(self.K * 4), DevBuf(self.K * 4), DevBuf(self.K * 4)
+        v.G, v.Gu, v.keep = DevBuf(nb), DevBuf(nb), DevBuf(nb)
+        out = np.zeros(3, np.uint64)
+        _lib.check(_lib.lib().ss_l2_prepare(self._h, _lib.ptr(y), _lib.ptr(sel), float(npp25), float(npp75), float(npp_out),
+                                            v.y.ptr, v.yu.ptr, v.G.ptr, v.Gu.ptr, v.keep.ptr, v.ykeep.ptr, _lib.ptr(out)), "ss_l2_prepare")
+        if out[2]:
+            raise OverflowError("k-mer counts must fit uint32")
+        v.n_keep, v.use_u = int(out[0]), bool(out[1])
+        return v
+
+    def fold_words(self, keep, split_bits, n_keep):
+        split_bits = np.ascontiguousarray(split_bits, np.uint32)
+        assert split_bits.size == n_keep
+        f = DevBuf(self.K * 4)
+        _lib.check(_lib.lib().ss_l2_fold(self._h, keep.ptr, _lib.ptr(split_bits), int(n_keep), f.ptr), "ss_l2_fold")
+        return f
 
     def planes(self):
         out = np.zeros(self.S * self.W, np.uint32)
