@@ -430,6 +430,40 @@ def measure_config3(torch, dev, args, stream):
     t_bin_plain = kernel_ms(lambda: rs.scan_into(db, stream), db)
     equal = equal and bool(np.array_equal(db.counts_rows(), want))
     db.expect_hits(True)
+    # three identified clusters: their tables in ONE pass over the reads (ss_scan_reads_multi) against a scan per table, as
+    # the reference's loop does (Vote_Strain_L2_Lasso_new_sp.py:295-296); the two other tables are other genomes' k-mers
+    others = []
+    for sd in (4, 5):
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(sd)
+        gen2 = torch.randint(0, 4, (G + 200,), generator=g2, device=dev, dtype=torch.uint8)
+        k2, r2, _, _ = _kmer_keys(torch, gen2, torch.arange(0, G, device=dev), dev)
+        kk = torch.stack([k2, r2], 1).reshape(-1).cpu().numpy().view(np.uint64)
+        others.append(_lib.KmerDB(kk, np.ones(kk.size, np.uint8), K, True).expect_hits())
+        del gen2, k2, r2
+    three = [db] + others
+
+    def reset_all():
+        for d_ in three:
+            d_.reset(stream)
+
+    def timed(fn, reps=3):
+        ts = []
+        for _ in range(reps + 1):
+            reset_all()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts[1:]))
+
+    t_sep = timed(lambda: [rs.scan_into(d_, stream) for d_ in three])
+    t_one = timed(lambda: rs.scan_into_many(three, stream))
+    equal3 = bool(np.array_equal(db.counts_rows(), want)) and not others[0].counts_rows().any()
+    for d_ in others:
+        d_.close()
     # the oracle on a sub-sample (checker only)
     n_s = min(n_reads, 200_000)
     threads = max(1, min(orc.lib().orc_omp_threads(), int(_lib.lib().ss_host_cpus())))
@@ -447,6 +481,9 @@ def measure_config3(torch, dev, args, stream):
         file_order=dict(kernel_ms=round(t_file, 3), **fracs(t_file, hits)),
         binned=dict(kernel_ms=round(t_bin, 3), **fracs(t_bin, hits), m_reads_per_s=round(n_reads / t_bin / 1e3, 1)),
         binned_without_lds_combining=dict(kernel_ms=round(t_bin_plain, 3), **fracs(t_bin_plain, hits)),
+        three_tables=dict(one_pass_ms=round(t_one, 3), scan_per_table_ms=round(t_sep, 3), one_table_ms=round(t_bin, 3),
+                          one_pass_over_one_table=round(t_one / t_bin, 3), counts_equal=equal3,
+                          note="the cluster's table + two other genomes' tables of the same size, the same binned reads"),
         counters_added_per_s_binned=round(hits / (t_bin * 1e-3) / 1e9, 1), counters_unit="G hits/s",
         counts_equal_across_orders=equal, parity_on_sample=parity, parity_sample="first %d reads vs oracle orc_count_flat" % n_s,
         bound="VALU issue (profiles/r04_cluster_scan_pmc_summary.txt: 5.4 G wave instructions per launch); a global atomicAdd "

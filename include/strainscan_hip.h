@@ -235,6 +235,10 @@ int ss_reads_destroy(ss_reads *r);
 int ss_reads_info(const ss_reads *r, uint64_t *n_records, uint64_t *n_bases, uint64_t *n_blocks,
                   uint64_t *device_bytes);
 int ss_scan_reads(ss_db *db, const ss_reads *r, void *stream);
+/* The same reads against several tables in ONE pass (the reference's loop over the identified clusters,
+ * Vote_Strain_L2_Lasso_new_sp.py:295-296, re-reads the FASTQ for each, :354-372): equal to ss_scan_reads on each table;
+ * k = 31 tables share the encoding and the minimizer runs of every tile, four tables per launch. */
+int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *r, void *stream);
 
 /* --------------------------------------------------------------------------------------------
  * Host FASTA/FASTQ -> flat base block (what jellyfish's sequence parser feeds its counter).

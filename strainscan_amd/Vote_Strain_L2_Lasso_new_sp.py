@@ -133,11 +133,41 @@ def cluster_counts(input_fq, fq2, cls_db_dir, ksize):
         db.close()
 
 
-def vote_strain_L2(item):
+def cluster_counts_many(input_fq, fq2, cls_db_dirs, ksize, group=16):
+    """cluster_counts for several clusters with ONE pass over the resident reads per `group` tables (the reference's loop
+    :295-296 runs jellyfish over the whole FASTQ once per cluster, :354-372): ss_scan_reads_multi.  -> list of count arrays,
+    in the order of cls_db_dirs.  Without a resident read set (too large for the device) the clusters are scanned one by one."""
+    from .db import fasta_index, resident_reads
+    from . import dist
+    rs = resident_reads([input_fq, fq2]) if len(cls_db_dirs) > 1 else None
+    if rs is None:
+        return [cluster_counts(input_fq, fq2, d, ksize) for d in cls_db_dirs]
+    out = []
+    for g0 in range(0, len(cls_db_dirs), group):
+        dbs = []
+        try:
+            for d in cls_db_dirs[g0:g0 + group]:
+                dbs.append(fasta_index(os.path.join(d, "all_kmer.fasta"), int(ksize), 2).expect_hits())
+            for db in dbs:
+                db.reset()
+            rs.scan_into_many(dbs)
+            if dist.is_distributed():
+                for db in dbs:                       # same order on every rank
+                    dist.allreduce_table(db)
+            _lib.check(_lib.lib().ss_device_sync(), "ss_device_sync")
+            out.extend(db.counts_rows() for db in dbs)
+        finally:
+            for db in dbs:
+                db.close()
+    return out
+
+
+def vote_strain_L2(item, counts=None):
     """:334-438.  item = [input_fq, cluster db dir, out dir, ksize, cls_ab, 'C<id>', cls_cov,
-    all identified cluster ids, l2, msn, pmode, emode, fq2]."""
+    all identified cluster ids, l2, msn, pmode, emode, fq2]; counts: the cluster's k-mer counts when the caller has
+    scanned already (cluster_counts_many)."""
     (input_fq, db_dir, out_dir, ksize, cls_ab, cls, cls_cov, all_cls, l2, msn, pmode, emode, fq2) = item[:13]
-    py_o = remove_1(cluster_counts(input_fq, fq2, db_dir, ksize))
+    py_o = remove_1(cluster_counts(input_fq, fq2, db_dir, ksize) if counts is None else counts)
     npp = py_o[py_o != 0]
     npp25 = 0
     with np.errstate(invalid="ignore"):
@@ -206,13 +236,18 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
         # on every rank, so the loop stays serial there.  SS_L2_THREADS=1 forces the serial loop.
         from . import dist
         nthreads = 1 if dist.is_distributed() else max(1, min(len(todo), int(os.environ.get("SS_L2_THREADS", "4"))))
+        # all clusters' tables in ONE pass over the resident reads (SS_L2_ONE_PASS=0: a scan per cluster, as the
+        # reference does)
+        counts = [None] * len(todo)
+        if len(todo) > 1 and os.environ.get("SS_L2_ONE_PASS", "1") != "0":
+            counts = cluster_counts_many(input_fq, fq2, [item[1] for item in todo], ksize)
         if nthreads == 1:
-            for item in todo:
-                vote_strain_L2(item)
+            for item, c in zip(todo, counts):
+                vote_strain_L2(item, c)
         else:
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="ss-l2") as pool:
-                for fut in [pool.submit(vote_strain_L2, item) for item in todo]:
+                for fut in [pool.submit(vote_strain_L2, item, c) for item, c in zip(todo, counts)]:
                     fut.result()                      # re-raises the first failure, in submission order
         print("- Generate final report ...")
         merge_res(out_dir, res)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ss_db_device_bytes": (u64, [vp]),
     "ss_db_index_info": (i32, [vp, vp]),
     "ss_db_expect_hits": (i32, [vp, i32]),
+    "ss_scan_reads_multi": (i32, [vp, i32, vp, vp]),
     "ss_scan_reset": (i32, [vp, vp]),
     "ss_scan_flat_dev": (i32, [vp, vp, u64, vp]),
     "ss_scan_flat_host": (i32, [vp, cp, u64]),
@@ -409,6 +410,11 @@ class ReadSet:
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(lib().ss_reads_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "ss_reads_info")
         return dict(n_records=a.value, n_bases=b.value, n_blocks=c.value, device_bytes=d.value)
+
+    def scan_into_many(self, kdbs, stream=None):
+        """One pass over the resident reads for several tables (ss_scan_reads_multi); counts as scan_into on each."""
+        arr = (C.c_void_p * len(kdbs))(*[k.handle for k in kdbs])
+        check(lib().ss_scan_reads_multi(arr, len(kdbs), self._h, stream), "ss_scan_reads_multi")
 
     def scan_into(self, kdb, stream=None):
         check(lib().ss_scan_reads(kdb.handle, self._h, stream), "ss_scan_reads")

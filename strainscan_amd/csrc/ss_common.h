@@ -208,6 +208,7 @@ int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_reco
                        int shard_rank = 0, int shard_world = 1);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles, bool binned = false);
+int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, uint64_t n, hipStream_t stream, bool binned);
 // ss_scan_flat_dev for a block whose records ss_reorder.hip has binned by locus (the scan may add hits up in LDS first)
 int scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned);
 }  // namespace ss

@@ -830,4 +830,33 @@ int ss_scan_reads(ss_db *db, const ss_reads *R, void *stream)
     return SS_OK;
 }
 
+// The resident reads against SEVERAL tables in one pass (Vote_Strain_L2_Lasso_new_sp.py:295-296 loops over the identified
+// clusters, :354-372 re-reads the FASTQ for each): tables of the minimizer layout go four at a time through one kernel that
+// makes a tile's codes, minimizers and runs once; anything else is scanned on its own.
+int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *R, void *stream)
+{
+    if (!dbs || n_dbs < 1 || !R) return SS_EINVAL;
+    std::vector<ss_db *> mini;
+    for (int i = 0; i < n_dbs; i++) {
+        if (!dbs[i]) return SS_EINVAL;
+        for (int j = 0; j < i; j++) if (dbs[j] == dbs[i]) return SS_EINVAL;           // a table twice would count twice
+        int k = 0;
+        ss_db_info(dbs[i], nullptr, nullptr, nullptr, &k);
+        if (R->has_cut_record && k != 31) return SS_ERANGE;
+        if (dbs[i]->layout == 1) mini.push_back(dbs[i]);
+        else { int rc = ss_scan_reads(dbs[i], R, stream); if (rc) return rc; }
+    }
+    static const int group = [] { const char *e = getenv("SS_MULTI_MAX"); return e ? std::max(1, std::min(4, atoi(e))) : 4; }();
+    for (size_t g = 0; g < mini.size(); g += (size_t)group) {
+        const int ng = (int)std::min<size_t>((size_t)group, mini.size() - g);
+        for (const auto &sl : R->slabs) {
+            if (!sl.used) continue;
+            int rc = ng == 1 ? ss::scan_flat_dev(mini[g], sl.d, sl.used, stream, sl.binned)
+                             : (sl.used < 31 ? SS_OK : ss::launch_scan_mini_multi(&mini[g], ng, sl.d, sl.used, ss::as_stream(stream), sl.binned));
+            if (rc) return rc;
+        }
+    }
+    return SS_OK;
+}
+
 }  // extern "C"

@@ -290,18 +290,37 @@ __device__ unsigned long long ss_timing[32];
 #define SS_STOP(n)
 #endif
 
+// Several tables in ONE pass over the reads (layer 2: the reference re-reads the FASTQ once per identified cluster,
+// Vote_Strain_L2_Lasso_new_sp.py:295-296,354-372): bases, codes, minimizers and runs of a tile are made once, the page lookups
+// and candidate checks repeat per table.  Up to four tables per launch (the LDS counters keep the table in the two bits above
+// a bucket start's thirty).
+constexpr int MULTI_MAX = 4;
+struct ScanTabs {
+    const uint64_t *mkeys[MULTI_MAX];
+    const uint4 *pages[MULTI_MAX];
+    uint32_t *counts[MULTI_MAX];
+    uint32_t n_pages[MULTI_MAX], cbase[MULTI_MAX];
+    int n;
+};
+
 // SGPRs decide the residency of this kernel: a SIMD admits floor(800 / (ceil(sgprs / 16) * 16 + 16)) waves
 // (MI355X_MICROARCH.md, residency), i.e. 8 waves at <= 80, 7 at <= 96, 6 beyond; VGPRs (58) and LDS (4.9 KB per
 // one-wave workgroup = 32 per CU) allow 8.
 #ifndef SS_NUM_SGPR
 #define SS_NUM_SGPR 80
 #endif
-template <bool ALIGNED, bool BLOOM, bool COMB, int WAVES_PER_SIMD>
+template <bool ALIGNED, bool BLOOM, bool COMB, int WAVES_PER_SIMD, bool MULTI = false>
 __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(SS_NUM_SGPR))) void scan_mini_kernel(
-    const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys,
-    const uint4 *__restrict__ pages, uint32_t n_pages, uint32_t *__restrict__ counts, uint32_t cbase,
-    const uint32_t *__restrict__ bloom, uint32_t bloom_shift, uint32_t xcd_swizzle)
+    const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys0,
+    const uint4 *__restrict__ pages0, uint32_t n_pages0, uint32_t *__restrict__ counts0, uint32_t cbase0,
+    const uint32_t *__restrict__ bloom, uint32_t bloom_shift, uint32_t xcd_swizzle, const ScanTabs tabs)
 {
+    static_assert(!(MULTI && BLOOM), "several tables: no minimizer filter (they are tables that expect hits)");
+    // the table of this pass over the tile's runs (MULTI: tabs.* in turn)
+    const uint64_t *__restrict__ mkeys = mkeys0;
+    const uint4 *__restrict__ pages = pages0;
+    uint32_t *__restrict__ counts = counts0;
+    uint32_t n_pages = n_pages0, cbase = cbase0, tab_key = 0u;
     constexpr int K = 31;                            // 17 m-mers of length 15 per k-mer
     static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
@@ -357,15 +376,20 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #ifdef SS_COMB_STATS
                 { const unsigned long long nz = __popcll(__ballot(c != 0u)); SS_CS(3, nz); }
 #endif
-                if (c) atomicAdd(&counts[C.key[e] - 1u + off], c);
+                if (c) {
+                    const uint32_t k1 = C.key[e] - 1u;
+                    uint32_t *cb = MULTI ? tabs.counts[k1 >> 30] : counts;
+                    atomicAdd(&cb[(k1 & ss::START_MASK) + off], c);
+                }
             }
         }
         if (key) {
             const uint32_t w = C.acc[t][4] >> 8;
             if (w) {
+                uint32_t *cb = MULTI ? tabs.counts[(key - 1u) >> 30] : counts;
 #pragma unroll
                 for (uint32_t o = 0; o < 3; o++)
-                    if ((w >> (8u * o)) & 0xFFu) atomicAdd(&counts[key - 1u + 17u + o], (w >> (8u * o)) & 0xFFu);
+                    if ((w >> (8u * o)) & 0xFFu) atomicAdd(&cb[((key - 1u) & ss::START_MASK) + 17u + o], (w >> (8u * o)) & 0xFFu);
             }
         }
         __syncthreads();
@@ -585,6 +609,15 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         };
 
         SS_T(7);
+        for (int tb = 0; tb < (MULTI ? tabs.n : 1); tb++) {
+        if (MULTI) {
+            mkeys = tabs.mkeys[tb]; pages = tabs.pages[tb]; counts = tabs.counts[tb];
+            n_pages = tabs.n_pages[tb]; cbase = tabs.cbase[tb]; tab_key = (uint32_t)tb << 30;
+            if (tb) {                                   // the found-run queue of the table before has been worked off
+                if (t == 1) S.cnt[1] = 0;
+                __syncthreads();
+            }
+        }
         // ---- phase 2a (databases with a Bloom filter): one probe of an L2-resident bit array kills most of
         // the ~90 % of the runs whose minimizer is not in the database before they cost a random HBM
         // sector each.  Survivors are compacted into q1b (ballot + lane count: one wave per workgroup)
@@ -668,7 +701,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 if (comb_runs + n2 > 255u) { comb_flush(); SS_T(8); }
                 comb_runs += n2;
                 for (uint32_t r = (uint32_t)t; r < n2; r += MT) {
-                    const uint32_t key = (uint32_t)(S.q2[r] >> 32) + 1u;
+                    const uint32_t key = ((uint32_t)(S.q2[r] >> 32) | tab_key) + 1u;
                     uint32_t i = (key * 0x9E3779B1u) >> 26, e = COMB_NONE;
                     static_assert(COMB_NE == 64, "hash: top six bits");
                     for (int pr = 0; pr < 8; pr++) {
@@ -719,6 +752,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 if (scan_page(pages[(uint64_t)page * 4u], page, meta, h, 0u, false)) scan_more(page, meta, h, 0u, false);
             }
         }
+        if (MULTI && tb + 1 < tabs.n) __syncthreads();
+        }   // tables
         SS_T(4);
         __syncthreads();   // queues and codes are rewritten by the next tile
         SS_T(5);
@@ -1031,13 +1066,50 @@ static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stre
     const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
     const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
     static const uint32_t swz = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
+    const ScanTabs none = {};
 #define SS_LAUNCH(A, B, C_) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
-                                               db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz)
+                                               db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none)
     // a table that expects hits (ss_db_expect_hits) skips its Bloom filter: nearly every minimizer of the reads is in it
     if (comb)             { if (aligned) SS_LAUNCH(true, false, true); else SS_LAUNCH(false, false, true); }
     else if (db->d_bloom && !db->expect_hits) { if (aligned) SS_LAUNCH(true, true, false); else SS_LAUNCH(false, true, false); }
     else                  { if (aligned) SS_LAUNCH(true, false, false); else SS_LAUNCH(false, false, false); }
 #undef SS_LAUNCH
+}
+
+// one pass of a flat block against up to MULTI_MAX tables of the minimizer layout (all k = 31)
+int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, uint64_t n, hipStream_t stream, bool binned)
+{
+    if (n_dbs < 1 || n_dbs > MULTI_MAX) return SS_EINVAL;
+    ScanTabs tabs = {};
+    bool expect = true;
+    for (int i = 0; i < n_dbs; i++) {
+        ss_db *db = dbs[i];
+        if (!db || db->layout != 1) return SS_EINVAL;
+        tabs.mkeys[i] = db->d_mkeys;
+        tabs.pages[i] = reinterpret_cast<const uint4 *>(db->d_dir);
+        tabs.counts[i] = db->d_counts;
+        tabs.n_pages[i] = db->n_dir;
+        tabs.cbase[i] = (uint32_t)db->n_mslots;
+        expect = expect && db->expect_hits;
+    }
+    tabs.n = n_dbs;
+    const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
+    static const int comb_env = [] { const char *e = getenv("SS_COMBINE"); return e ? atoi(e) : -1; }();
+    static const uint32_t swz = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
+    const bool comb = expect && (comb_env < 0 ? binned : comb_env != 0);
+    const uint64_t n_tiles = (n + MTILE - 1) / MTILE, units = comb ? (n_tiles + COMB_CH - 1) / COMB_CH : n_tiles;
+    unsigned blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)2048 * 256 * (256 / MT));
+    blocks = (blocks + 7u) & ~7u;
+    const uint8_t *b = (const uint8_t *)bases_dev;
+#define SS_LAUNCH_M(A, C_, LB) hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, LB, true>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles, \
+                                                  tabs.mkeys[0], tabs.pages[0], tabs.n_pages[0], tabs.counts[0], tabs.cbase[0],                \
+                                                  (const uint32_t *)nullptr, 0u, swz, tabs)
+    if (comb) { if (aligned) SS_LAUNCH_M(true, true, 6); else SS_LAUNCH_M(false, true, 6); }
+    else      { if (aligned) SS_LAUNCH_M(true, false, 8); else SS_LAUNCH_M(false, false, 8); }
+#undef SS_LAUNCH_M
+    SS_HIP(hipGetLastError());
+    for (int i = 0; i < n_dbs; i++) dbs[i]->launches++;
+    return SS_OK;
 }
 
 #ifdef SS_COMB_STATS

@@ -102,6 +102,47 @@ def test_end_to_end_reports(golden_dir, l1_dbs, tmp_path):
     _cmp_report((out2 / "final_report.txt").read_text(), g["A_single"]["final_report"], float_cols=(3, 4, 5))
 
 
+def test_three_clusters_one_pass_equals_serial_loop(l1_dbs, tmp_path, monkeypatch):
+    """Three identified multi-strain clusters: their k-mer tables are scanned in ONE pass over the resident reads
+    (ss_scan_reads_multi; the reference's loop, Vote_Strain_L2_Lasso_new_sp.py:295-296, re-reads the FASTQ per cluster)
+    -- every report file equal, byte for byte, to the run that scans cluster by cluster.  Clusters 3 and 5 share a whole
+    segment (the same k-mers in two tables: each table counts them all)."""
+    import shutil
+    from strainscan_amd import StrainScan, _lib
+    info = l1_dbs["A"]
+    db = str(tmp_path / "dbA3")
+    shutil.copytree(info["db_dir"], db)
+    c1 = synth.build_l2_cluster(db, 1, 6, ["GCF_A1", "GCF_A2", "GCF_A3"], [1500, 1200, 1000, 1400, 900],
+                                [[1, 1, 0, 0, 1], [1, 0, 1, 0, 0], [0, 1, 1, 1, 0]], seed=77, shared_with={4: [3]})
+    c3 = synth.build_l2_cluster(db, 3, 6, ["GCF_C1", "GCF_C2"], [1300, 1100, 900], [[1, 1, 0], [1, 0, 1]], seed=78)
+    c5 = synth.build_l2_cluster(db, 5, 6, ["GCF_E1", "GCF_E2", "GCF_E3", "GCF_E4"], [1300, 1000, 1200, 800],
+                                [[1, 1, 0, 0], [1, 0, 1, 0], [1, 0, 0, 1], [0, 1, 1, 0]], seed=78)
+    assert set(c3["kid"]) & set(c5["kid"])                       # segment 0 of both: the same k-mers in two tables
+    g = info["leaf_genome"]
+    mix = [(g[1] + c1["strain_extra"]["GCF_A1"], 18.0), (g[1] + c1["strain_extra"]["GCF_A3"], 7.0),
+           (g[3] + c3["strain_extra"]["GCF_C2"], 12.0), (g[5] + c5["strain_extra"]["GCF_E1"], 10.0),
+           (g[5] + c5["strain_extra"]["GCF_E4"], 6.0), (g[6], 9.0)]
+    fq = tmp_path / "three.fq"
+    fq.write_bytes(synth.simulate_reads(mix, 311))
+    calls = []
+    orig = _lib.ReadSet.scan_into_many
+    monkeypatch.setattr(_lib.ReadSet, "scan_into_many", lambda self, dbs, stream=None: (calls.append(len(dbs)), orig(self, dbs, stream))[1])
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SS_L2_ONE_PASS", mode)
+        out = tmp_path / ("out" + mode)
+        np.random.seed(sc.POISSON_SEED)
+        with contextlib.redirect_stdout(io.StringIO()):
+            StrainScan.main(["-i", str(fq), "-d", db, "-o", str(out)])
+        outs[mode] = {str(p.relative_to(out)): p.read_bytes() for p in sorted(out.rglob("*")) if p.is_file()}
+    assert calls == [3]                                           # one pass for the three tables, none in the serial run
+    assert sorted(k for k in outs["1"] if k.endswith("StrainVote.report")) == ["C1/StrainVote.report", "C3/StrainVote.report", "C5/StrainVote.report"]
+    assert outs["1"] == outs["0"]
+    rep = outs["1"]["final_report.txt"].decode()
+    for name in ("GCF_A1", "\tC1\t", "\tC3\t", "\tC5\t", "GCF_SINGLE6"):       # strains of all three clusters and the singleton
+        assert name in rep, rep
+
+
 def _cmp_report(got, want, float_cols):
     gl, wl = got.strip().split("\n"), want.strip().split("\n")
     assert gl[0] == wl[0]                      # header line, character for character

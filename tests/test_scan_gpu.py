@@ -1151,3 +1151,48 @@ def test_hits_combined_tiny_queues_and_file_order():
     for env in (dict(SS_LIB=tiny), dict(SS_COMBINE="1"), dict(SS_LIB=tiny, SS_COMBINE="1")):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "comb ok" in out.stdout, (env, out.stderr[-2000:])
+
+
+def test_scan_reads_multi_equals_single_scans(L):
+    """ss_scan_reads_multi: several tables in one pass over a resident read set -- counts equal to ss_scan_reads on each
+    (five tables = two launches; tables that overlap in their k-mers; with and without the hit hint; binned and file order;
+    a k = 21 table in the list is scanned on its own)."""
+    import torch
+    cases = [_dense_case(31 + i, 30000, 1) for i in range(4)]
+    kfas = [c[0] for c in cases] + [cases[0][0] + cases[2][0]]            # the fifth table holds the first and the third
+    _, flat = _dense_case(31, 30000, 12000)                                # reads of the first genome ...
+    flat += _dense_case(33, 30000, 6000)[1] + _dense_case(34, 30000, 3000)[1]
+    d = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    for order in (True, False):
+        rs = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=order)
+        for hint in (True, False):
+            dbs = [L.KmerDB.from_text(k, 31, True) for k in kfas]
+            want = []
+            for db in dbs:
+                if hint:
+                    db.expect_hits()
+                rs.scan_into(db)
+                L.check(L.lib().ss_device_sync(), "sync")
+                want.append(db.counts_rows())
+                db.reset()
+            assert want[0].sum() > 400_000 and want[1].sum() < want[0].sum() // 10 and want[2].sum() > 100_000
+            assert want[4].sum() == want[0].sum() + want[2].sum()
+            rs.scan_into_many(dbs)
+            L.check(L.lib().ss_device_sync(), "sync")
+            for db, w in zip(dbs, want):
+                assert np.array_equal(db.counts_rows(), w), (order, hint)
+            # accumulate; and a flat-layout table in the list
+            small = L.KmerDB.from_text(_random_db_and_reads(40, 5000, 10, k=21)[0], 21, True)
+            rs.scan_into(small)
+            L.check(L.lib().ss_device_sync(), "sync")
+            w21 = small.counts_rows()
+            small.reset()
+            rs.scan_into_many([dbs[0], small, dbs[2]])
+            L.check(L.lib().ss_device_sync(), "sync")
+            assert np.array_equal(dbs[0].counts_rows(), 2 * want[0]) and np.array_equal(dbs[2].counts_rows(), 2 * want[2])
+            assert np.array_equal(small.counts_rows(), w21) and np.array_equal(dbs[1].counts_rows(), want[1])
+            with pytest.raises(L.SSError):
+                rs.scan_into_many([dbs[0], dbs[0]])
+            for db in dbs + [small]:
+                db.close()
+        rs.close()
