@@ -117,6 +117,10 @@ typedef int (*ss_gz_chain_fn)(void *msg, uint64_t bytes, int slice, int directio
 int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_chain_fn chain, void *user);
 /* files this process has inflated its share of in range mode, and the slices that came to */
 int ss_gz_range_counters(uint64_t *files, uint64_t *pieces);
+/* Test hooks, switched by this call only (nothing in the environment does): which = 1: plant a wrong block entry in search
+ * chunk `value` of every .gz inflated on the device (0 = off); 2: this process declines .gz inputs on the device (in range mode
+ * it still serves the chain); 3: this rank leaves range mode WITHOUT serving the chain -- what a crashed peer looks like. */
+int ss_test_hook(int which, long long value);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23
  * draws them for ElasticNetCV (identify_strains_L2_Enet_Pscan_new_sp.py:436-442: cv=ShuffleSplit(20, test_size=.5,

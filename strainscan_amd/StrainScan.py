@@ -170,11 +170,18 @@ def cli():
         db.wait_cache_writes()
     except Exception:                       # noqa: B902
         pass
+    if rc is not None and not isinstance(rc, int):      # sys.exit("message"): the message goes to stderr, the code is 1
+        print(rc, file=sys.stderr)
+        rc = 1
     sys.stdout.flush()
     sys.stderr.flush()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # several ranks: the ordinary way out (process group, RCCL)
+    # several ranks: the ordinary way out (process group, RCCL); SS_FAST_EXIT=0: the ordinary way out for one rank as well
+    # (atexit handlers, logging shutdown, temporary files of the caller's own)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("SS_FAST_EXIT", "1") == "0":
         sys.exit(rc)
-    os._exit(rc if isinstance(rc, int) else (0 if rc is None else 1))
+    import logging
+    logging.shutdown()
+    os._exit(rc or 0)
 
 
 if __name__ == "__main__":

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ss_gz_set_policy": (i32, [i32]),
     "ss_gz_set_range": (i32, [i32, i32, u64, GZ_CHAIN_FN, vp]),
     "ss_gz_range_counters": (i32, [P(u64), P(u64)]),
+    "ss_test_hook": (i32, [i32, C.c_longlong]),
     "ss_gz_free": (None, [vp]),
     "ss_gz_inflate_to_file": (i32, [cp, cp, i32, P(u64)]),
     "ss_host_cpus": (i32, []),

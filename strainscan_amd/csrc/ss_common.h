@@ -191,6 +191,7 @@ void gpu_gunzip_done(void *lease);
 // end with the last record that is complete in it, `carry` holds the bytes of the record that began in the slice before
 struct GzPiece { uint64_t at, len, keep; std::vector<uint8_t> carry; };
 bool gz_range_active();
+extern std::atomic<long long> g_hook_entry, g_hook_decline, g_hook_skip_chain;      // ss_test_hook (ss_ginflate.hip)
 bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **lease, int fd, std::vector<GzPiece> *pieces,
                       bool decline = false);      // decline: test hook -- plan the slices, serve the chain, hand nothing back
 int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat);

@@ -224,7 +224,7 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    if (const char *inj = getenv("SS_GZ_INJECT_DECLINE")) if (atoi(inj)) return 1;       // test hook: this process declines
+    if (g_hook_decline.load()) return 1;                       // test hook (ss_test_hook): this process declines
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return 1;
     struct stat sb;
@@ -278,16 +278,25 @@ int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64
         struct stat sb;
         const uint8_t *in = nullptr;
         uint64_t in_n = 0;
-        const bool inj = getenv("SS_GZ_INJECT_DECLINE") && atoi(getenv("SS_GZ_INJECT_DECLINE"));      // test hook: this rank declines
+        bool inj = g_hook_decline.load() != 0;                // test hook: this rank declines
+        std::vector<uint8_t> head;
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 32) {
             in_n = (uint64_t)sb.st_size;
             in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (in == MAP_FAILED) in = nullptr;
+            if (in == MAP_FAILED) {
+                // this rank cannot map the file (its own trouble: address space, a limit): it declines, but it still serves
+                // the chain -- the slices follow from the file's size and the length of the gzip header, which a plain
+                // read of the first bytes gives (a header is a few dozen bytes; 70 KB cover the longest legal one)
+                in = nullptr;
+                head.resize((size_t)std::min<uint64_t>(in_n, 70u << 10));
+                if (pread(fd, head.data(), head.size(), 0) == (ssize_t)head.size()) { in = head.data(); inj = true; }
+            }
         }
         // (a rank that declines still serves the chain -- gpu_gunzip_range sees to that once it knows the slices, which it
-        //  derives from the file's size; a file that cannot be opened is the same failure on every rank)
+        //  derives from the file's size; a file that cannot be opened at all is the same failure on every rank of a node, and
+        //  a rank that is gone altogether ends the others' bounded wait: dist._gz_chain)
         if (in && in[0] == 0x1f && in[1] == 0x8b) ok = gpu_gunzip_range(in, in_n, &d_text, &lease, fd, &pieces, inj);
-        if (in) munmap((void *)in, in_n);
+        if (in && head.empty()) munmap((void *)in, in_n);
         if (fd >= 0) close(fd);
     }
     if (!ok) return 1;

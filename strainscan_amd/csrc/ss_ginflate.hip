@@ -1372,6 +1372,8 @@ namespace ss {
 // trailer; the buffer belongs to the scratch arena of the call and is lent until gpu_gunzip_done(*lease).  false: not
 // handled here (the caller inflates on the host).
 static std::atomic<uint64_t> g_handled{0}, g_declined{0}, g_range_files{0}, g_range_pieces{0};
+// ss_test_hook: nothing in the environment can switch these on
+std::atomic<long long> g_hook_entry{0}, g_hook_decline{0}, g_hook_skip_chain{0};
 
 void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
 
@@ -1407,22 +1409,30 @@ struct RangeRun {
     std::vector<uint32_t> mine;           // my slices, ascending
     size_t duty = 0;                      // mine[duty]: the first slice whose part in the chain is not finished
     bool received = false;                // ... and whether its message has come in
-    bool broken = false;                  // the callback failed: no more chain traffic
+    bool failed = false;                  // a callback failed: this rank declines, status -1 still goes down the chain
+    bool broken = false;                  // a SEND failed: no more chain traffic
     bool inject_decline = false;          // test hook
     ChainMsg msg;                         // the last message received / the one being sent
     std::vector<GzPiece> *pieces = nullptr;
+    // A failed callback (the caller's point-to-point call raised, or its bounded wait ran out: dist._gz_chain) does not end
+    // this rank's part: nothing more is RECEIVED (the outcome is known: declined), but status -1 still goes down the chain
+    // for every slice of this rank, so that the ranks behind it learn it at once instead of each waiting for its own
+    // deadline; only a failed SEND ends the traffic (the peer is gone).
     bool recv_for(uint32_t s)
     {
-        if (s == 0 || broken) return !broken;
-        if (fn(&msg, sizeof(ChainMsg), (int)s, 0, user) != 0) { broken = true; return false; }
+        if (s == 0) return !failed;
+        if (failed) return false;
+        if (fn(&msg, sizeof(ChainMsg), (int)s, 0, user) != 0) { failed = true; msg.status = -1; msg.carry_len = 0; return false; }
         received = true;
         return true;
     }
     bool send_from(uint32_t s)
     {
-        if (s + 1 >= n_slices || broken) return !broken;
-        if (fn(&msg, sizeof(ChainMsg), (int)s, 1, user) != 0) { broken = true; return false; }
-        return true;
+        if (s + 1 >= n_slices) return !failed;
+        if (broken) return false;
+        if (failed) { msg.status = -1; msg.carry_len = 0; }
+        if (fn(&msg, sizeof(ChainMsg), (int)s, 1, user) != 0) { broken = true; failed = true; return false; }
+        return !failed;
     }
     // whatever is left of this rank's part in the chain, as a bystander: receive, pass on that it went wrong
     void abort_chain()
@@ -1456,6 +1466,7 @@ bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **
 {
     std::lock_guard<std::mutex> one(g_range_mu);
     if (!gz_range_active()) return false;
+    if (g_hook_skip_chain.load()) return false;               // test hook: a rank that leaves WITHOUT serving the chain (the peers' bounded wait)
     RangeRun rr;
     rr.rank = (uint32_t)g_range.rank; rr.world = (uint32_t)g_range.world; rr.fn = g_range.fn; rr.user = g_range.user;
     rr.pieces = pieces;
@@ -1470,7 +1481,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // own stream: the two mates of a paired sample are inflated by two host threads, and the legacy default stream would
     // serialise them
     hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return false;
+    const bool have_stream = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;      // (checked once the slices are known:
+    if (!have_stream) st = nullptr;                                                                     //  a rank that fails here still serves the chain)
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -1489,7 +1501,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         const double c1 = now();
         hipStreamSynchronize(st);
         const double c2 = now();
-        hipStreamDestroy(st);
+        if (st) hipStreamDestroy(st);
         if (trace) fprintf(stderr, "[ginflate] cleanup: free %.4f, sync %.4f, stream destroy %.4f s\n", c1 - c0, c2 - c1, now() - c2);
         if (!keep_text) { arena_put(A); A = nullptr; }            // (else the caller holds it, with the text, until gpu_gunzip_done)
     };
@@ -1506,7 +1518,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     };
 #define GI(call) do { if ((call) != hipSuccess) return no(#call); } while (0)
 #define GB(call) do { if (!(call)) return no(#call); } while (0)
-    const uint64_t data_off = gzip_header_len(in, in_n);
+    // (a rank that only serves the chain may hold no more than the first 70 KB of the file: ss_fastq_dev.hip)
+    const uint64_t data_off = gzip_header_len(in, rr && rr->inject_decline ? std::min<uint64_t>(in_n, 70u << 10) : in_n);
     if (!data_off) return no("header");
     // SS_GZ_SPLIT_KB: blocks are entered every so many KB of deflate data (subsync_kernel; 0 = at their starts only)
     uint64_t split_bytes = 12 << 10;
@@ -1531,11 +1544,12 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         rr->n_slices = (n_chunks0 + rr->slice_chunks - 1) / rr->slice_chunks;
         for (uint32_t sl = rr->rank; sl < rr->n_slices; sl += rr->world) rr->mine.push_back(sl);
         if (rr->n_slices < 2) return no("one slice");         // nothing to share out: the whole-file path
-        if (rr->inject_decline) return no("declined on request (test hook)");
+        if (rr->inject_decline) return no("declined on request (test hook, or the file could not be mapped)");
         if (trace) fprintf(stderr, "[ginflate] range mode: rank %u of %u, %u slices of %u chunks, %zu mine\n", rr->rank, rr->world, rr->n_slices,
                            rr->slice_chunks, rr->mine.size());
     }
 
+    if (!have_stream) return no("hipStreamCreateWithFlags");
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
     static const bool no_pread = getenv("SS_GZ_NO_PREAD") != nullptr;
     bool uploaded = false;
@@ -1581,8 +1595,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         hipMemcpyToSymbol(HIP_SYMBOL(g_sync_tries), &tries, 4);
     }
     lap("sync");
-    if (const char *e = getenv("SS_GZ_INJECT_ENTRY")) {      // test hook: a wrong entry (a position inside a block) in chunk <n>
-        const uint64_t c = (uint64_t)atoll(e);
+    if (g_hook_entry.load() > 0) {                           // test hook (ss_test_hook): a wrong entry (a position inside a block) in chunk <n>
+        const uint64_t c = (uint64_t)g_hook_entry.load();
         if (c > 0 && c < n_chunks0) entry[c] = (data_off + c * chunk_bytes) * 8 + 12345 % (chunk_bytes * 8);
     }
     // The file's chunks: one per entry (a chunk of the search without one belongs to its predecessor).  `fresh`: the first
@@ -2308,6 +2322,19 @@ extern "C" int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_
     std::lock_guard<std::mutex> one(ss::g_range_mu);
     ss::g_range.rank = rank; ss::g_range.world = world; ss::g_range.slice_bytes = slice_bytes; ss::g_range.fn = chain; ss::g_range.user = user;
     return SS_OK;
+}
+
+// Test hooks, switched by an explicit call only (never by the environment): 1 = plant a wrong entry in search chunk `value`
+// (0 = off), 2 = this process declines .gz inputs on the device (range mode: it still serves the chain), 3 = this rank leaves
+// range mode without serving the chain (what a crashed peer looks like: the others' bounded wait must end it).
+extern "C" int ss_test_hook(int which, long long value)
+{
+    switch (which) {
+    case 1: ss::g_hook_entry = value; return SS_OK;
+    case 2: ss::g_hook_decline = value; return SS_OK;
+    case 3: ss::g_hook_skip_chain = value; return SS_OK;
+    default: return SS_EINVAL;
+    }
 }
 
 extern "C" int ss_gz_range_counters(uint64_t *files, uint64_t *pieces)

@@ -142,17 +142,35 @@ def rank0_first(fn):
     from . import dist
     if not dist.is_distributed() or not _cache_dir():
         return fn()
+    import torch
     import torch.distributed as td
     rank, _ = dist.rank_world()
+    dev = "cuda" if torch.cuda.is_available() and td.get_backend() == "nccl" else "cpu"
+
+    def agree(ok):
+        """MIN over the ranks of a success flag: doubles as the barrier, and a rank that failed is seen by all (the others
+        would otherwise go on into the scan's collectives with one rank missing, and hang there)."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    out, err = None, None
     if rank == 0:
         try:
             out = fn()
             wait_cache_writes()
-        finally:
-            td.barrier()
-        return out
-    td.barrier()
-    return fn()
+        except BaseException as e:          # noqa: B902 -- raised below, after the other ranks have been told
+            err = e
+    if not agree(err is None):              # rank 0's turn
+        raise err if err is not None else RuntimeError("rank 0 failed while building the database image")
+    if rank != 0:
+        try:
+            out = fn()
+        except BaseException as e:          # noqa: B902
+            err = e
+    if not agree(err is None):              # everybody else's
+        raise err if err is not None else RuntimeError("another rank failed while loading the database image")
+    return out
 
 
 def fasta_index(path, k, upper_keys):

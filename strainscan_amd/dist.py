@@ -211,25 +211,68 @@ def _gz_chain(rank, world):
     on_dev = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
 
+    # Every wait is BOUNDED (SS_GZ_CHAIN_TIMEOUT seconds, default 60): a peer that never sends -- it crashed, or left without
+    # serving the chain -- must not leave this rank in a blocking recv on the loader thread until the backend's own timeout
+    # (10 minutes for NCCL).  After the deadline the call fails, the library declines, passes status -1 on to the ranks behind
+    # this one, and load_agreed moves all ranks to the whole-file path; range mode is not tried again in this process group
+    # (the abandoned receive is still posted).
+    deadline = float(os.environ.get("SS_GZ_CHAIN_TIMEOUT", "60"))
+
+    def wait(work):
+        import threading
+        import time
+        if on_dev:                           # NCCL: the work's event is polled (wait() would only block the stream)
+            t_end = time.monotonic() + deadline
+            while not work.is_completed():
+                if time.monotonic() > t_end:
+                    return False
+                time.sleep(0.0005)
+            work.wait()                      # (completed: raises here if the operation failed)
+            return True
+        # gloo: a point-to-point work only completes inside wait() (is_completed() never turns true on its own), and a wait
+        # WITH a timeout tears the connection to the peer down when it runs out -- the collectives that follow would fail.
+        # So the blocking wait runs on a helper thread and THIS thread waits for it, bounded; after the deadline the helper
+        # is left behind with its posted receive (a daemon thread: it ends with the process)
+        done, failed = threading.Event(), []
+
+        def block():
+            try:
+                work.wait()
+            except BaseException as e:      # noqa: B902
+                failed.append(e)
+            done.set()
+
+        threading.Thread(target=block, name="ss-gz-chain-wait", daemon=True).start()
+        return done.wait(deadline) and not failed
+
     def chain(msg, nbytes, slice_, direction, _user):
         try:
             if on_dev:
                 torch.cuda.set_device(dev)          # (the current device is a property of the thread: this is the loader's)
             host = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(msg)))
             if direction == 1:
-                dist.send(host.to(dev) if on_dev else host, (slice_ + 1) % world)
+                out = host.to(dev) if on_dev else host.clone()
+                ok = wait(dist.isend(out, (slice_ + 1) % world))
             else:
                 box = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                dist.recv(box, (slice_ - 1) % world)
-                host.copy_(box.cpu() if on_dev else box)
-            return 0
+                ok = wait(dist.irecv(box, (slice_ - 1) % world))
+                if ok:
+                    host.copy_(box.cpu() if on_dev else box)
+            if not ok:
+                CHAIN_FAILURES.append((slice_, direction))
+            return 0 if ok else 1
         except BaseException:               # noqa: B902 -- the library breaks the chain off and declines
+            if os.environ.get("SS_INGEST_TRACE"):
+                import traceback
+                traceback.print_exc()
+            CHAIN_FAILURES.append((slice_, direction))
             return 1
 
     return _lib.GZ_CHAIN_FN(chain)
 
 
 _P2P_OK = {}
+CHAIN_FAILURES = []       # (slice, direction) of every chain call that failed or ran out of time in this process
 
 
 def _p2p_works():
@@ -307,6 +350,10 @@ def load_agreed(paths, load, discard=None):
         finally:
             _lib.lib().ss_gz_set_range(0, 1, 0, _lib.NO_CHAIN, None)
         agreed = agree(status)
+        # a chain call that failed or timed out on ANY rank: no more shared inflations in this process group (a receive may
+        # still be posted on some rank; the next file's messages must not meet it)
+        if agree(0 if CHAIN_FAILURES else 1) == 0:
+            _P2P_OK[(dist.get_backend(), dist.get_world_size(), dist.get_rank())] = False
         if agreed == 1:
             return obj
         if obj is not None and discard is not None:

@@ -279,3 +279,57 @@ def test_exchange_touched_sums_the_union(tmp_path, world):
         assert np.array_equal(np.load(tmp_path / ("sum%d.npy" % r)), want)
         assert np.array_equal(np.load(tmp_path / ("flags%d.npy" % r)), union)
         assert int((tmp_path / ("n%d.txt" % r)).read_text()) == n_want
+
+
+def _chain_worker(rank, world, port, out_dir):
+    import ctypes as C
+    import json
+    import time
+    sys.path.insert(0, REPO)
+    os.environ["SS_GZ_CHAIN_TIMEOUT"] = "1.5"
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "store_%d" % port), rank=rank, world_size=world)
+    from strainscan_amd import dist as sdist
+    chain = sdist._gz_chain(rank, world)
+    n = 4096
+    buf = (C.c_uint8 * n)()
+    res = {}
+    # a message travels: the owner of slice 0 (rank 0) sends, the owner of slice 1 (rank 1) receives
+    if rank == 0:
+        for i in range(n):
+            buf[i] = (i * 7 + 3) & 0xFF
+        res["send"] = chain(C.addressof(buf), n, 0, 1, None)
+    elif rank == 1:
+        res["recv"] = chain(C.addressof(buf), n, 1, 0, None)
+        res["payload_ok"] = all(buf[i] == ((i * 7 + 3) & 0xFF) for i in range(n))
+    dist.barrier()
+    # the peer is gone: rank 1 waits for the message of slice 1 + world, which rank 0 never sends -- the call must come back
+    # with a failure after the deadline, not sit in recv
+    if rank == 1:
+        t0 = time.monotonic()
+        res["late"] = chain(C.addressof(buf), n, 1 + world, 0, None)
+        res["waited"] = time.monotonic() - t0
+        res["failures"] = list(sdist.CHAIN_FAILURES)
+    else:
+        time.sleep(4)           # alive, but silent (a peer that has gone away altogether fails the receive at once)
+    with open(os.path.join(out_dir, "chain%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    os._exit(0)             # (a receive is still posted on rank 1: no orderly shutdown of the group)
+
+
+def test_chain_calls_are_bounded(tmp_path):
+    """dist._gz_chain (range mode's point-to-point chain): a message arrives intact; a receive whose sender never sends
+    ends after SS_GZ_CHAIN_TIMEOUT with a failure -- the library then declines and passes status -1 on -- instead of sitting
+    in recv until the backend's own timeout."""
+    import json
+    port = 29500 + (os.getpid() % 2000) + 7
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r0 = json.load(open(tmp_path / "chain0.json"))
+    r1 = json.load(open(tmp_path / "chain1.json"))
+    assert r0["send"] == 0 and r1["recv"] == 0 and r1["payload_ok"] is True
+    assert r1["late"] == 1 and 1.4 <= r1["waited"] < 10 and r1["failures"] == [[3, 0]]

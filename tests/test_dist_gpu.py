@@ -164,6 +164,9 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo", init_method="file://" + os.environ["SS_TEST_STORE"], rank=rank, world_size=world)   # (no fixed port: nothing to collide with)
 from strainscan_amd import dist as sdist, _lib
 job = json.load(open(%(jobs)r))
+for which, name in ((1, "T_INJECT_ENTRY"), (2, "T_INJECT_DECLINE"), (3, "T_SKIP_CHAIN")):      # the test's hooks: an explicit call, not the environment
+    if os.environ.get(name):
+        _lib.check(_lib.lib().ss_test_hook(which, int(os.environ[name])), "ss_test_hook")
 kdb = _lib.KmerDB.from_text(open(job["kfa"], "rb").read(), 31, True)
 nrec, nb = sdist.scan_files_sharded(kdb, job["paths"], allreduce=True)
 counts = kdb.counts_rows()
@@ -174,16 +177,20 @@ a, b, rf, rp = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
 _lib.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b))
 _lib.lib().ss_gz_range_counters(C.byref(rf), C.byref(rp))
 np.save(os.path.join(%(out)r, "counts%%d.npy" %% rank), counts)
-json.dump(dict(nrec=int(nrec), own=int(own), handled=int(a.value), declined=int(b.value), range_files=int(rf.value), range_pieces=int(rp.value)),
+json.dump(dict(nrec=int(nrec), own=int(own), handled=int(a.value), declined=int(b.value), range_files=int(rf.value), range_pieces=int(rp.value),
+               chain_failures=len(sdist.CHAIN_FAILURES)),
           open(os.path.join(%(out)r, "rank%%d.json" %% rank), "w"))
 dist.barrier()
+if sdist.CHAIN_FAILURES:
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)           # (a helper thread still sits in its abandoned receive: no orderly shutdown of the group)
 dist.destroy_process_group()
 '''
 
 
 @pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"), (2, False, "members"),
                                                   (2, True, "range"), (3, True, "range"), (2, False, "entry100"), (2, False, "entry128"), (3, False, "entry129"),
-                                                  (2, False, "bgzip"), (3, False, "bgzip")])
+                                                  (2, False, "bgzip"), (3, False, "bgzip"), (2, False, "gone"), (3, False, "gone")])
 def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     """A pair of .fastq.gz files under torch.distributed; the summed row counts equal the single-process scan of the plain
     text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
@@ -197,7 +204,10 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     dist.load_agreed must move ALL ranks on, in the end to the host inflaters (one inflate into /dev/shm, parse chunks
     shared out), or reads would be counted twice or not at all.  `entryN`: a wrong entry point (a position inside a
     block, test hook) in search chunk N -- inside a slice the chunk in front of it runs over it as in the whole-file path;
-    at a slice's edge (128 = the first chunk of slice 1) the slices no longer meet and the shared inflation is declined."""
+    at a slice's edge (128 = the first chunk of slice 1) the slices no longer meet and the shared inflation is declined.
+    `gone`: rank 1 leaves the shared inflation WITHOUT serving the chain (test hook: what a crashed peer looks like to the
+    others) -- their receives end after SS_GZ_CHAIN_TIMEOUT (3 s here), status -1 travels on, all ranks fall back to the
+    whole-file path, range mode is switched off for the process group; counts as ever."""
     import gzip
     import socket
     from strainscan_amd import _lib as L
@@ -249,12 +259,19 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
         if mode == "whole":
             env["SS_GZ_RANGE"] = "0"
         if mode.startswith("entry"):
-            env["SS_GZ_INJECT_ENTRY"] = mode[5:]
+            env["T_INJECT_ENTRY"] = mode[5:]
         if decline and r == 1:
-            env["SS_GZ_INJECT_DECLINE"] = "1"
+            env["T_INJECT_DECLINE"] = "1"
+        if mode == "gone":                   # rank 1 leaves range mode without serving the chain: the others' bounded wait
+            env["SS_GZ_CHAIN_TIMEOUT"] = "3"
+            if r == 1:
+                env["T_SKIP_CHAIN"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
     errs = [p.communicate(timeout=600)[1].decode()[-6000:] for p in procs]
-    assert all(p.returncode == 0 for p in procs), errs
+    if not all(p.returncode == 0 for p in procs):
+        (tmp_path / "errs.txt").write_text("\n=====\n".join(errs))
+        print("\n=====\n".join(e[-1500:] for e in errs))
+    assert all(p.returncode == 0 for p in procs), [p.returncode for p in procs]
     if os.environ.get("SS_INGEST_TRACE"):
         print("\n".join("rank %d:\n%s" % (r, e) for r, e in enumerate(errs)))
     infos = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
@@ -271,6 +288,9 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
             assert infos[r]["handled"] == 0 if r == 1 else infos[r]["handled"] >= 4
     assert sum(i["nrec"] for i in infos) == n and sum(i["own"] for i in infos) == n
     assert decline or all(i["nrec"] > 0 for i in infos)      # (parse chunks are 24 MB: these small files are one chunk each)
+    if mode == "gone":
+        assert sum(i["chain_failures"] for i in infos) >= 1 and all(i["range_files"] == 0 for i in infos), infos
+        assert all(i["handled"] >= 2 for i in infos)         # the whole-file device path took over (not the host inflaters)
     if mode == "entry100":                                   # run over inside a slice: still shared
         assert all(i["range_files"] == 4 for i in infos)
     if mode in ("range", "bgzip") and not decline:           # every rank inflated about its share, not everything

@@ -287,18 +287,21 @@ def test_a_wrong_entry_point_is_dropped_and_the_chunks_inflated_again(L, tmp_pat
     """The sync search accepts a position where a valid dynamic header parses and a few hundred symbols decode; about
     one candidate in a million that passes lies INSIDE a block (seen on a 264 MB file).  The chunk in front of such an
     entry ends its block behind it: it goes on to the entry after that and the wrong one's chunk is dropped (or, when the
-    symbol region has no room, the two chunks are merged and inflated again).  SS_GZ_INJECT_ENTRY plants a wrong entry:
+    symbol region has no room, the two chunks are merged and inflated again).  ss_test_hook(1, n) plants a wrong entry:
     same text, still verified by CRC-32 and ISIZE."""
     p = tmp_path / "a.fq.gz"
     p.write_bytes(gzip.compress(fastq_text, 6))
     for host_only in (False, True):          # the chunk runs over the wrong entry itself / the host merges the two chunks
         if host_only:
             monkeypatch.setenv("SS_GZ_NO_RUNOVER", "1")
-        for chunk in ("3", "17", "40"):
-            monkeypatch.setenv("SS_GZ_INJECT_ENTRY", chunk)
-            rc, got = _gpu_inflate(L, p)
-            assert rc == SS_OK, (chunk, host_only)
-            assert got == fastq_text, (chunk, host_only)
+        try:
+            for chunk in (3, 17, 40):
+                L.check(L.lib().ss_test_hook(1, chunk), "ss_test_hook")
+                rc, got = _gpu_inflate(L, p)
+                assert rc == SS_OK, (chunk, host_only)
+                assert got == fastq_text, (chunk, host_only)
+        finally:
+            L.lib().ss_test_hook(1, 0)
 
 
 @pytest.mark.parametrize("layout", ["two", "lanes", "small_middle", "small_last", "levels"])
@@ -362,14 +365,14 @@ def test_segments(L, tmp_path, monkeypatch, fastq_text, seg_kb):
     for name, gz in (("one", one), ("four", four), ("bgzf", _bgzf(fastq_text))):
         p = tmp_path / (name + ".gz")
         p.write_bytes(gz)
-        for inject in (None, "5", "33"):
-            if inject:
-                monkeypatch.setenv("SS_GZ_INJECT_ENTRY", inject)
-            else:
-                monkeypatch.delenv("SS_GZ_INJECT_ENTRY", raising=False)
-            rc, got = _gpu_inflate(L, p)
-            assert rc == SS_OK, (name, inject)
-            assert got == fastq_text, (name, inject)
+        try:
+            for inject in (0, 5, 33):
+                L.check(L.lib().ss_test_hook(1, inject), "ss_test_hook")
+                rc, got = _gpu_inflate(L, p)
+                assert rc == SS_OK, (name, inject)
+                assert got == fastq_text, (name, inject)
+        finally:
+            L.lib().ss_test_hook(1, 0)
 
 
 def test_warm_up_then_pinned_upload(L, tmp_path, monkeypatch):
