@@ -202,6 +202,9 @@ __global__ __launch_bounds__(NT) void sel_hist_kernel(const uint32_t *__restrict
                                                       int shift, const SelState *__restrict__ st, uint32_t *hist)
 {
     constexpr int NH = FIRST ? 1 : 2;
+    // (the passes after the first keep TWO histograms per column: 64 KB + a few words -- gfx950's 160 KB of LDS per CU hold two
+    //  such workgroups; a 64 KB-LDS target could not build this, and this library is built for gfx950 only)
+    static_assert(sizeof(uint32_t) * NH * CT * HCOPY * 256 + 1024 <= 80 * 1024, "sel_hist_kernel: two workgroups per CU must fit gfx950's 160 KB of LDS");
     __shared__ uint32_t h[NH][CT][HCOPY][256];
     __shared__ uint32_t s_p[2][CT];
     __shared__ const uint32_t *s_x[CT];

@@ -238,11 +238,23 @@ def _export_image_later(kdb, cdir, img):
 
 
 def cache_tag(text):
-    """Name of a cache entry from the string that identifies it (path | size | mtime | ...): 64 bits of two CRC-32s.  (Not
-    hashlib: importing it costs a fresh CLI process 0.05-0.1 s -- OpenSSL -- for what is a file name.)"""
-    import zlib
+    """Name of a cache entry from the string that identifies it (path | size | mtime | ...): 128 bits of a multiplicative
+    mix over the bytes, two lanes with different odd multipliers (non-linear in the input, unlike a CRC: the tag is the only
+    identity of an entry).  Not hashlib: importing it costs a fresh CLI process 0.05-0.1 s (OpenSSL) for what is a file name;
+    the strings are ~150 bytes."""
     b = text.encode()
-    return "%08x%08x" % (zlib.crc32(b) & 0xFFFFFFFF, zlib.crc32(b[::-1], 0x5EED) & 0xFFFFFFFF)
+    M = (1 << 64) - 1
+    h1, h2 = 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F
+    b += b"\x80" + b"\0" * (-(len(b) + 1) % 8)
+    for i in range(0, len(b), 8):
+        w = int.from_bytes(b[i:i + 8], "little")
+        h1 = ((h1 ^ w) * 0xFF51AFD7ED558CCD) & M
+        h1 ^= h1 >> 32
+        h2 = ((h2 + w) * 0xD6E8FEB86659FD93) & M
+        h2 ^= h2 >> 29
+    h1 = ((h1 ^ len(text)) * 0xC4CEB9FE1A85EC53) & M
+    h2 = ((h2 ^ h1) * 0x9FB21C651E98DF25) & M
+    return "%016x%016x" % (h1 ^ (h1 >> 33), h2 ^ (h2 >> 31))
 
 
 def _cache_dir():
