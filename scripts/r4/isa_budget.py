@@ -1,68 +1,65 @@
 #!/usr/bin/env python3
-"""Static instruction counts of scan_mini_kernel between the SSMARK phase markers of ss_mini.hip, per instantiation.
+"""Static instruction counts of scan_mini_kernel per phase, from the SSMARK labels of ss_mini.hip, per instantiation; with a
+trip-count file (scripts/r4/scan_trips.py on the GPU: tiles, runs, lookups, found runs per launch) the loop bodies are weighted
+and the sum is set beside the measured SQ_INSTS_VALU per tile.
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -S --cuda-device-only strainscan_amd/csrc/ss_mini.hip -o /tmp/ss_mini.s
-    python scripts/r4/isa_budget.py /tmp/ss_mini.s [instantiation substring ...]
-Regions are named by the marker that ENDS them (SS_T(i) closes phase i).  Loop bodies are counted once: the dynamic totals
-(PMC SQ_INSTS_*) divided by the tiles of a launch give the trip-weighted sums to set beside them."""
+    python scripts/r4/isa_budget.py /tmp/ss_mini.s <instantiation substring> [lookup_rounds_per_tile candidate_rounds_per_tile bloom_rounds]
+An instruction belongs to the label that precedes it in the file (the compiler keeps the order of the volatile asm labels;
+blocks it moves elsewhere -- cold paths -- are counted where they land)."""
 import collections
 import re
 import sys
 
-names = {0: "0 load+encode", 1: "1a m-mer keys", 6: "1b minimizers+run starts", 2: "1b merge+walk->q1", 7: "(setup)", 3: "2 bloom+pages",
-         10: "3 comb: begin", 8: "3 comb: flush", 9: "3 comb: claim", 4: "3 candidates+overflow", 5: "end barrier", -1: "prologue", 99: "epilogue"}
-src = open(sys.argv[1]).read().split("\n")
-want = sys.argv[2:]
-cur_k = None
-region = -1
-acc = {}
-order = {}
-for ln in src:
-    m = re.match(r"^(_ZN\S*scan_mini_kernel\S*):", ln)
-    if m:
-        cur_k = m.group(1)
-        region = -1
-        acc[cur_k] = collections.defaultdict(lambda: collections.Counter())
-        order[cur_k] = []
-        continue
-    if cur_k is None:
-        continue
-    if ln.startswith("\t.end_amdhsa_kernel") or ln.strip().startswith(".Lfunc_end"):
-        cur_k = None
-        continue
-    mm = re.search(r"; SSMARK (\d+)", ln)
-    if mm:
-        region = int(mm.group(1)) + 1000      # instructions after marker i belong to the NEXT phase: resolved below
-        continue
-    t = ln.strip()
-    if not t or t.startswith((";", ".")) or t.endswith(":"):
-        continue
-    op = t.split()[0]
-    if op.startswith("v_"):
-        cls = "VALU"
-    elif op.startswith("s_"):
-        cls = "SALU" if not op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_cbranch", "s_branch", "s_endpgm")) else "ctl"
-    elif op.startswith("ds_"):
-        cls = "LDS"
-    elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
-        cls = "VMEM"
-    else:
-        cls = "other"
-    acc[cur_k][region][cls] += 1
-    if region not in order[cur_k]:
-        order[cur_k].append(region)
-# marker i ENDS phase i: instructions after marker a and before marker b belong to b.  Code is laid out mostly in program
-# order, so region "after marker a" is labelled by the next marker in the source order of SS_T calls.
-nxt = {-1: 0, 1000: 1, 1001: 6, 1006: 2, 1002: 7, 1007: 3, 1003: 10, 1010: 8, 1008: 9, 1009: 4, 1004: 5, 1005: 99}
-for k, regs in acc.items():
-    short = re.sub(r"^.*scan_mini_kernelI", "", k)[:16]
-    if want and not any(w in k for w in want):
-        continue
-    print("== %s  (ALIGNED, BLOOM, COMB, waves/SIMD = %s)" % (short, short))
-    tot = collections.Counter()
-    print("%-28s %6s %6s %5s %5s %5s" % ("phase (static, loops once)", "VALU", "SALU", "LDS", "VMEM", "ctl"))
-    for r in order[k]:
-        c = regs[r]
-        ph = nxt.get(r, r)
-        print("%-28s %6d %6d %5d %5d %5d" % (names.get(ph, str(ph)), c["VALU"], c["SALU"], c["LDS"], c["VMEM"], c["ctl"]))
-        tot.update(c)
-    print("%-28s %6d %6d %5d %5d %5d" % ("total", tot["VALU"], tot["SALU"], tot["LDS"], tot["VMEM"], tot["ctl"]))
+NAMES = {-1: "kernel prologue", 20: "0 load + encode (+ next tile's addresses)", 0: "1a m-mer keys", 1: "1b minimizers, run starts, index bytes",
+         6: "1b merge across lanes, prefix sum, walk -> q1", 2: "lambda setup", 7: "2 before the loops", 11: "2a Bloom round (body)",
+         12: "2b lookup round: run -> hash -> page load (body)", 13: "2b lookup round: tags, inline k-mers, found runs (body)",
+         14: "2b round end", 3: "3 before the loop (combiner: claim)", 10: "3 combiner begin", 9: "3 combiner after claim", 8: "3 combiner after flush",
+         15: "3 candidate round (body)", 16: "3 round end + overflow runs", 4: "end of tile barrier", 5: "loop back / epilogue"}
+LOOP = {11: "bloom", 12: "lookup", 13: "lookup", 14: "lookup", 15: "cand", 16: None}
+
+
+def main():
+    src = open(sys.argv[1]).read().split("\n")
+    want = sys.argv[2]
+    trips = dict(lookup=float(sys.argv[3]), cand=float(sys.argv[4]), bloom=float(sys.argv[5])) if len(sys.argv) > 5 else None
+    cur, region = None, -1
+    acc, order = collections.defaultdict(collections.Counter), []
+    for ln in src:
+        m = re.match(r"^(_ZN\S*scan_mini_kernel\S*):", ln)
+        if m:
+            cur = m.group(1) if want in m.group(1) else None
+            region = -1
+            continue
+        if cur is None:
+            continue
+        if ln.strip().startswith(".Lfunc_end"):
+            break
+        mm = re.search(r"; SSMARK (\d+)", ln)
+        if mm:
+            region = int(mm.group(1))
+            continue
+        t = ln.strip()
+        if not t or t.startswith((";", ".")) or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        cls = ("VALU" if op.startswith("v_") else "ctl" if op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_cbranch", "s_branch", "s_endpgm")) else
+               "SALU" if op.startswith("s_") else "LDS" if op.startswith("ds_") else "VMEM" if op.startswith(("global_", "buffer_", "flat_", "scratch_")) else "other")
+        acc[region][cls] += 1
+        if region not in order:
+            order.append(region)
+    print("| phase (label) | VALU | SALU | LDS | VMEM | x per tile | VALU per tile |")
+    print("|---|---|---|---|---|---|---|")
+    tot = 0.0
+    for r in order:
+        c = acc[r]
+        mult = 1.0
+        if trips and LOOP.get(r):
+            mult = trips[LOOP[r]]
+        if r == -1:
+            mult = 0.0
+        tot += c["VALU"] * mult
+        print("| %s | %d | %d | %d | %d | %s | %.0f |" % (NAMES.get(r, str(r)), c["VALU"], c["SALU"], c["LDS"], c["VMEM"], ("%.2f" % mult) if trips else "", c["VALU"] * mult))
+    print("| **sum** | | | | | | **%.0f** |" % tot)
+
+
+main()

@@ -62,6 +62,7 @@
 #include <chrono>
 #include <functional>
 #include <thread>
+#include <type_traits>
 #include <memory>
 #include <vector>
 
@@ -269,12 +270,15 @@ __device__ __forceinline__ uint32_t shift_in_ne(uint32_t m, uint32_t a, uint32_t
 
 #ifdef SS_COMB_STATS
 // debug build: what the combining scan did -- [0] tiles, [1] flushes, [2] entries flushed, [3] counters flushed, [4] found runs,
-// [5] runs without an entry, [6] flushes because the table was full
-__device__ unsigned long long ss_comb_stats[8];
+// [5] runs without an entry, [6] flushes because the table was full; and the trip counts of every scan's loops (for the
+// instruction budget, scripts/r4/isa_budget.py): [8] tiles, [9] runs queued (n1), [10] runs looked up (ns: all, or the Bloom
+// filter's survivors), [11] found runs (n2), [12] lookup rounds, [13] candidate rounds
+__device__ unsigned long long ss_comb_stats[16];
 #define SS_CS(i, v) do { if (t == 0) atomicAdd(&ss_comb_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define SS_CS(i, v)
 #endif
+#define SS_MARK(i) asm volatile("; SSMARK " #i)      // a label in the ISA only (scripts/r4/isa_budget.py)
 #ifdef SS_TIMING
 // debug build: cycles a wave spends between the phase markers, accumulated in registers and flushed once per block
 __device__ unsigned long long ss_timing[32];
@@ -407,6 +411,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, wn);
     }
     for (; tile < tile_end; tile = next_tile(tile)) {
+        SS_MARK(20);
         // ---- phase 0: bases -> 2-bit codes in LDS ------------------------------------------------
         {
             uint32_t code, inv;
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         if (BLOOM) {
             ns = 0;
             for (uint32_t r0 = 0; r0 < n1; r0 += RPL * MT) {
+                SS_T(11);
                 uint32_t meta[RPL], hs[RPL], bw[RPL];
                 bool ok[RPL];
 #pragma unroll
@@ -657,7 +663,9 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #define SS_RPL2 1
 #endif
         constexpr int RPL2 = SS_RPL2;
+        SS_CS(8, 1); SS_CS(9, n1); SS_CS(10, ns); SS_CS(12, (ns + RPL2 * MT - 1) / (RPL2 * MT));
         for (uint32_t i0 = 0; i0 < ns; i0 += RPL2 * MT) {
+            SS_T(12);
             uint32_t meta[RPL2], hs[RPL2], pgi[RPL2];
             uint4 tg[RPL2];
             bool ok[RPL2];
@@ -676,9 +684,11 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 pgi[u] = ss::page_of(hs[u], n_pages);
                 if (ok[u]) tg[u] = pages[(uint64_t)pgi[u] * 4u];
             }
+            SS_T(13);
 #pragma unroll
             for (int u = 0; u < RPL2; u++)
                 if (ok[u] && scan_page(tg[u], pgi[u], meta[u], hs[u], i0 + u * MT + t, true)) scan_more(pgi[u], meta[u], hs[u], i0 + u * MT + t, true);
+            SS_T(14);
         }
         __syncthreads();
         SS_T(3);
@@ -719,11 +729,15 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 __syncthreads();
                 SS_T(9);
             }
-            for (uint32_t g0 = 0; g0 < n2 * 16u; g0 += U3 * MT) {
-                uint32_t pos[U3], bst[U3], mul[U3], cps[U3], ent[U3];
-                uint64_t cnd[U3];
+            SS_CS(11, n2); SS_CS(13, (n2 * 16u + U3 * MT - 1) / (U3 * MT));
+            // U runs' worth of positions per lane and round: all their candidate loads in flight before any compare
+            auto cand_round = [&](auto UC, uint32_t g0) {
+                constexpr int U = decltype(UC)::value;
+                SS_T(15);
+                uint32_t pos[U], bst[U], mul[U], cps[U], ent[U];
+                uint64_t cnd[U];
 #pragma unroll
-                for (int u = 0; u < U3; u++) {
+                for (int u = 0; u < U; u++) {
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
                     const bool v = (g >> 4) < n2;
                     const uint64_t r = S.q2[v ? (g >> 4) : 0u];
@@ -736,9 +750,15 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     ent[u] = COMB ? (uint32_t)C.ent[v ? (g >> 4) : 0u] : COMB_NONE;
                 }
 #pragma unroll
-                for (int u = 0; u < U3; u++)
+                for (int u = 0; u < U; u++)
                     if (cps[u]) settle_item<COMB>(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, ent[u], &C.acc[0][0]);
-            }
+                SS_MARK(16);
+            };
+            // (a tree scan finds ~5 runs per tile = 80 of a round's 256 positions; rounds of 64 for the rest were tried in
+            //  round 4 and change nothing: the empty quarters of a round are branched over)
+            const uint32_t total = n2 * 16u;
+            uint32_t g0 = 0;
+            for (; g0 < total; g0 += U3 * MT) cand_round(std::integral_constant<int, U3>(), g0);
             if (COMB && comb_full) { __syncthreads(); SS_T(4); comb_flush(); SS_T(8); }
         }
         // ---- overflow: runs that did not fit q1 (pathological inputs only) are done in place ------
@@ -1113,11 +1133,11 @@ int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, 
 }
 
 #ifdef SS_COMB_STATS
-extern "C" int ss_debug_comb_stats(unsigned long long *out8, int reset)
+extern "C" int ss_debug_comb_stats(unsigned long long *out8 /* [16] */, int reset)
 {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ss_comb_stats), 64);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ss_comb_stats), z, 64); }
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(ss_comb_stats), 128);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ss_comb_stats), z, 128); }
     return 0;
 }
 #endif
