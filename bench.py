@@ -808,11 +808,11 @@ def main(argv=None):
             rs_loc = _lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
             torch.cuda.synchronize()
             prep.append((time.perf_counter() - t1) * 1e3)
-        # (best of five, like the other phases outside the timed region: the call allocates the new 3 GB slab and frees 0.2 GB of
-        #  scratch, and on a box whose host is busy with other tenants one such driver call now and then takes 60-150 ms --
-        #  seen in three bench runs out of eight, always together with a slower cpu_baseline; all five values are listed, and
-        #  the kernels' share is 3.6 ms: profiles/r03_reorder_kernel_stats.csv)
-        prep_ms = float(np.min(prep))
+        # (the MEDIAN of five is reported as prepare_ms, the best and all five beside it: the call allocates the new 3 GB slab and
+        #  frees 0.2 GB of scratch, and on a box whose host is busy with other tenants one such driver call now and then takes
+        #  60-150 ms -- seen in three bench runs out of eight, always together with a slower cpu_baseline; the kernels' share is
+        #  3.6 ms: profiles/r03_reorder_kernel_stats.csv)
+        prep_ms = float(np.median(prep))
         ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
         def step_rs(i=None):
@@ -846,11 +846,15 @@ def main(argv=None):
             dt2 = float(tt.item())
         k2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
         readset = dict(order="locality (records binned by the minimizer of their first k-mer, ~4 records per bin: ss_reorder.hip)",
-                       prepare_ms=round(prep_ms, 2), prepare_ms_median=round(float(np.median(prep)), 2), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
+                       prepare_ms=round(prep_ms, 2), prepare_ms_best=round(float(np.min(prep)), 2), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
                        value=round(args.reads * world * args.steps / dt2 / 1e6, 3), unit="M reads/s", kernel_ms=round(k2, 3),
                        frac_algorithmic=round(args.reads * BYTES_PER_READ / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                        node_stats_equal=bool(torch.equal(stats, stats2)),
-                       note="what the CLI scans by default (SS_READS_ORDER=file keeps the file order): a sample is parsed and shipped "
+                       policy="always (SS_READS_ORDER=file keeps the file order): binning pays from the SECOND scan of a sample on -- "
+                              "the tree scan and one cluster scan, or the two scans of -b; a sample whose clusters are all single-strain "
+                              "is scanned once and loses prepare_ms - (file-order kernel - binned kernel) per 20 M reads, ~1.5 ms "
+                              "on the sampled shape, beside a text ingest of ~80 ms for the same reads",
+                       note="what the CLI scans by default: a sample is parsed and shipped "
                             "once, binned once (prepare_ms, ~4 % of the text ingest of the same reads), scanned by the tree scan and by "
                             "every cluster scan; the gain grows with the coverage of the sample (these reads cover a 70/20/10 three-strain "
                             "mix ~400/115/60 fold; sweep over 5x / 40x / 400x / a metagenome: profiles/r03_locality_sweep.json)")

@@ -740,10 +740,10 @@ __device__ unsigned g_sync_tries;      // candidates that passed the header chec
 // owns (slice s belongs to rank s mod world) and in the first `look` chunks behind each of them (where its last chunk stops)
 __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in_n, uint64_t data_off, uint64_t chunk_bytes,
                                                   uint32_t n_chunks, uint64_t *entry /* bit position or ~0 */, uint64_t probe, int count_tries,
-                                                  uint32_t slice_chunks, uint32_t rank, uint32_t world, uint32_t look)
+                                                  uint32_t slice_chunks, uint32_t rank, uint32_t world, uint32_t look, uint32_t c0)
 {
     __shared__ WaveState S;
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.x + c0;                       // (c0: the search runs piece by piece while the image arrives)
     const int lane = threadIdx.x & 63;
     if (slice_chunks) {
         const uint32_t sl = c / slice_chunks, within = c % slice_chunks;
@@ -1294,7 +1294,7 @@ void arena_put(Arena *a)
 // one by one (8 GB/s); four threads that pread() 32 MB blocks into pinned buffers of their own and ship them on streams of
 // their own do ~25 GB/s.  The pinned buffers (128 MB a set, at most two sets) are kept like the arenas.
 constexpr uint64_t PIN_BYTES = 32ull << 20;
-constexpr int PIN_N = 4;
+constexpr int PIN_N = 4;      // threads = buffers of a set
 struct PinSet { uint8_t *b[PIN_N] = {nullptr, nullptr, nullptr, nullptr}; };
 std::vector<PinSet *> g_pin_free;
 void pin_destroy(PinSet *p)
@@ -1329,7 +1329,9 @@ void pin_put(PinSet *p)
     }
     pin_destroy(p);
 }
-bool upload_file(int fd, uint64_t n, uint8_t *d_in)
+// `ready(bytes)`: called (serialised, from the upload threads) whenever the PREFIX of the image that has arrived on the device
+// has grown -- the caller starts work on it while the rest is still on its way.
+bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uint64_t)> &ready = nullptr)
 {
     PinSet *pins = pin_get();
     if (!pins) return false;
@@ -1337,27 +1339,59 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in)
     hipGetDevice(&device);
     std::atomic<uint64_t> next(0);
     std::atomic<int> failed(0);
-    // (a file of a few tens of MB: smaller blocks, so that all four threads have some)
-    const uint64_t blk = std::min<uint64_t>(PIN_BYTES, std::max<uint64_t>(4ull << 20, ((n / 8) + (1ull << 20) - 1) & ~((1ull << 20) - 1)));
+    // every thread's pinned buffer is used in two halves: the copy of one block travels while the next is read.  Blocks
+    // of 1/16 of the file (2 MB .. half a buffer), handed out in order, so that the prefix grows steadily
+    const uint64_t half = PIN_BYTES / 2;
+    const uint64_t blk = std::min<uint64_t>(half, std::max<uint64_t>(2ull << 20, ((n / 16) + (1ull << 20) - 1) & ~((1ull << 20) - 1)));
     const uint64_t n_blocks = (n + blk - 1) / blk;
+    std::vector<uint8_t> done((size_t)n_blocks, 0);
+    std::mutex mu;
+    uint64_t prefix = 0;                                     // blocks [0, prefix) are on the device
+    auto finished = [&](uint64_t b) {
+        std::lock_guard<std::mutex> g(mu);
+        done[(size_t)b] = 1;
+        const uint64_t before = prefix;
+        while (prefix < n_blocks && done[(size_t)prefix]) prefix++;
+        if (prefix != before && ready) ready(std::min(n, prefix * blk));
+    };
     std::vector<std::thread> pool;
     for (int t = 0; t < PIN_N; t++)
         pool.emplace_back([&, t] {
             hipStream_t s2 = nullptr;
-            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
-            for (uint64_t b; !failed && (b = next.fetch_add(1)) < n_blocks;) {
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+                failed = 1;
+            }
+            int64_t in_flight[2] = {-1, -1};                  // the block whose copy was last issued from each half
+            int h = 0;
+            for (uint64_t b; !failed && (b = next.fetch_add(1)) < n_blocks; h ^= 1) {
+                if (in_flight[h] >= 0) {                      // this half's earlier copy must have left it
+                    if (hipEventSynchronize(ev[h]) != hipSuccess) { failed = 1; break; }
+                    finished((uint64_t)in_flight[h]);
+                    in_flight[h] = -1;
+                }
                 const uint64_t a = b * blk, len = std::min<uint64_t>(blk, n - a);
+                uint8_t *buf = pins->b[t] + (uint64_t)h * half;
                 uint64_t got = 0;
                 while (got < len) {
-                    const ssize_t r = pread(fd, pins->b[t] + got, len - got, (off_t)(a + got));
+                    const ssize_t r = pread(fd, buf + got, len - got, (off_t)(a + got));
                     if (r <= 0) break;
                     got += (uint64_t)r;
                 }
-                if (got != len || hipMemcpyAsync(d_in + a, pins->b[t], len, hipMemcpyHostToDevice, s2) != hipSuccess ||
-                    hipStreamSynchronize(s2) != hipSuccess)
-                    failed = 1;
+                if (got != len || hipMemcpyAsync(d_in + a, buf, len, hipMemcpyHostToDevice, s2) != hipSuccess ||
+                    hipEventRecord(ev[h], s2) != hipSuccess) { failed = 1; break; }
+                in_flight[h] = (int64_t)b;
             }
-            hipStreamDestroy(s2);
+            for (int q = 0; q < 2; q++) {
+                const int hh = (h + q) & 1;                   // the older copy first
+                if (in_flight[hh] >= 0 && !failed) {
+                    if (hipEventSynchronize(ev[hh]) != hipSuccess) failed = 1;
+                    else finished((uint64_t)in_flight[hh]);
+                }
+            }
+            if (s2) { hipStreamSynchronize(s2); hipStreamDestroy(s2); }
+            for (int q = 0; q < 2; q++) if (ev[q]) hipEventDestroy(ev[q]);
         });
     for (auto &th : pool) th.join();
     pin_put(pins);
@@ -1557,9 +1591,30 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     //  ss_gz_warm_up, or an earlier call -- and then arrives in 8 ms instead of 12-30)
     static const uint64_t pread_env = getenv("SS_GZ_PREAD_MB") ? (uint64_t)atoll(getenv("SS_GZ_PREAD_MB")) << 20 : 0;
     const uint64_t pread_from = pread_env ? pread_env : pin_waiting() ? 32ull << 20 : 256ull << 20;
+    const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
+    uint64_t probe = 512;
+    if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
+    uint32_t c_searched = 0;                                   // search chunks [0, c_searched) have been launched
+    auto search_to = [&](uint32_t c_hi) {
+        if (c_hi > c_searched)
+            hipLaunchKernelGGL(sync_kernel, dim3(c_hi - c_searched), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe,
+                               trace ? 1 : 0, rr ? rr->slice_chunks : 0u, rr ? rr->rank : 0u, rr ? rr->world : 1u, LOOK, c_searched);
+        c_searched = std::max(c_searched, c_hi);
+    };
     if (fd >= 0 && in_n >= pread_from && !no_pread && !rr) {    // (`fd`: the same file; smaller ones are there before the buffers are)
-        GI(hipStreamSynchronize(st));                         // the allocation is stream-ordered
-        uploaded = upload_file(fd, in_n, d_in);
+        GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
+        GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
+        GI(hipStreamSynchronize(st));                         // the allocations are stream-ordered
+        // the sync search runs on the prefix of the image that has arrived (a candidate's probe reads a few KB beyond its chunk)
+        static const bool pipelined = !(getenv("SS_GZ_PIPELINE") && !atoi(getenv("SS_GZ_PIPELINE")));
+        const uint64_t margin = 64 << 10;
+        uploaded = upload_file(fd, in_n, d_in, [&](uint64_t ready) {
+            if (!pipelined || !bgzf.empty()) return;
+            // (runs on an upload thread, which has set the device; calls are serialised by upload_file)
+            const uint64_t usable = ready >= in_n ? in_n : (ready > margin + data_off ? ready - margin - data_off : 0);
+            search_to(ready >= in_n ? n_chunks0 : (uint32_t)std::min<uint64_t>(n_chunks0, usable / chunk_bytes));
+        });
+        if (!uploaded) c_searched = 0;                         // (the image is copied again below: search everything)
     }
     if (!uploaded && rr) {
         // range mode: only this rank's slices travel (+ the search chunks behind each in which its last chunk stops, + the
@@ -1576,15 +1631,11 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     }
     if (!uploaded) GB(h2d(d_in, in, in_n));
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
-    GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
+    if (!d_entry) GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
     lap("input on device");
-    const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
-    uint64_t probe = 512;
-    if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
     std::vector<uint64_t> entry(n_chunks0);
     if (bgzf.empty()) {
-        hipLaunchKernelGGL(sync_kernel, dim3(n_chunks0), dim3(64), 0, st, d_in, in_n - 8, data_off, chunk_bytes, n_chunks0, d_entry, probe, trace ? 1 : 0,
-                           rr ? rr->slice_chunks : 0u, rr ? rr->rank : 0u, rr ? rr->world : 1u, LOOK);
+        search_to(n_chunks0);
         GB(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8));
     }
     if (trace && bgzf.empty()) {
