@@ -859,6 +859,24 @@ def main(argv=None):
                             "every cluster scan; the gain grows with the coverage of the sample (these reads cover a 70/20/10 three-strain "
                             "mix ~400/115/60 fold; sweep over 5x / 40x / 400x / a metagenome: profiles/r03_locality_sweep.json)")
         rs_loc.close()
+        # counters of the BINNED scan (separate --pmc passes, scripts/r4/gpu_pmc_round.sh): reported only while the live
+        # kernel time is within 5 % of the one they were collected at
+        pmc_b = {}
+        pmc_path_b = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path_b) and args.reads == 20_000_000 and args.leaves == 823:
+            with open(pmc_path_b) as f:
+                pmc_b = json.load(f).get("%s:%s:%g:binned" % (os.environ.get("SS_LAYOUT", "mini"), args.db_shape, args.hit_frac), {})
+        ms_b = pmc_b.get("kernel_ms_at_collection")
+        if pmc_b and ms_b and abs(k2 - ms_b) <= 0.05 * ms_b:
+            tr = pmc_b["traffic_gb_per_launch"]
+            comp = (args.reads * (READ_LEN + 2) + 8.0 * hits) / 1e9      # every base once (152 B per binned record) + 8 B per hit
+            readset.update(traffic=tr, traffic_unit="GB per launch", hbm_frac_measured=round(tr / (k2 * 1e-3) / HBM_PEAK_GBS, 4),
+                           compulsory_gb=round(comp, 3), traffic_over_compulsory=round(tr / comp, 2), valu_busy=pmc_b.get("valu_busy"),
+                           valu_insts_per_tile=pmc_b.get("valu_insts_per_tile"), read_requests_per_launch=pmc_b.get("rdreq_per_launch"),
+                           traffic_source=dict(file="profiles/pmc_traffic.json", summary=pmc_b.get("source"), commit=pmc_b.get("commit"),
+                                               kernel_ms_at_collection=ms_b))
+        else:
+            readset.update(traffic=None, traffic_source=(dict(stale=True, kernel_ms_at_collection=ms_b) if pmc_b else None))
 
     achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
     # Counter-derived figures come from separate rocprofv3 --pmc passes of THIS command (scripts/gpu_round.sh writes
