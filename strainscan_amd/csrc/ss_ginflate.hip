@@ -137,15 +137,21 @@ struct WaveState {
 // lanes decode at bp + lane, the headers are read through a small scalar cache (buf / cnt) of the bits at bp.
 // Everything here is called wave-uniformly; LDS operations of one wave execute in order, so no barrier is needed
 // between the lanes' stores and the loads that follow.
+// Positions are RELATIVE to `base` (a bit position of the file, a multiple of a stage's bits, at or below everything the
+// wave will look at) and 32 bits wide (round 4): the window loop compares the position with four limits per window, and
+// 64-bit scalars can only be compared on the VALU (no s_cmp_lt_u64) and cost two SGPRs each -- the loop restored ~30 of them
+// from spill lanes per window.  A wave stays within ~512 MB of its base (SB_CAP); beyond, the position is "past the end".
+constexpr uint32_t SB_CAP = 0xFFF00000u, SB_NEVER = 0xFFFFFFFFu;
 struct SBits {
-    const uint32_t *in;      // global, dword aligned, padded with zeros behind the data
-    uint64_t n;              // bytes of data
-    uint64_t bp;             // next bit
-    uint64_t staged_to;      // dword index up to which the stage holds data: it covers [staged_to - STAGE_DW, staged_to)
+    const uint32_t *in;      // global, dword aligned, padded with zeros behind the data: the dword of relative position 0
+    uint64_t base;           // the file's bit position of relative position 0
+    uint32_t nbits;          // bits of data from `base` on (capped)
+    uint32_t bp;             // next bit
+    uint32_t staged_to;      // dword index up to which the stage holds data: it covers [staged_to - STAGE_DW, staged_to)
     uint64_t buf;            // scalar cache: cnt bits from bp on
     int cnt;
 };
-__device__ __forceinline__ void sb_fill_half(WaveState &S, const SBits &b, uint64_t w0)
+__device__ __forceinline__ void sb_fill_half(WaveState &S, const SBits &b, uint32_t w0)
 {
     // dwords [w0, w0 + HALF_DW) -> stage; w0 is a multiple of HALF_DW
     const int lane = threadIdx.x & 63;
@@ -162,9 +168,9 @@ __device__ __forceinline__ void sb_fill_half(WaveState &S, const SBits &b, uint6
 // the sync search tries positions a few bits apart and finds its data still there)
 __device__ __forceinline__ void sb_stage(WaveState &S, SBits &b)
 {
-    const uint64_t w = b.bp >> 5;
+    const uint32_t w = b.bp >> 5;
     if (w >= b.staged_to || w + STAGE_DW < b.staged_to) {
-        const uint64_t h0 = w & ~(uint64_t)(HALF_DW - 1);
+        const uint32_t h0 = w & ~(uint32_t)(HALF_DW - 1);
         __builtin_amdgcn_wave_barrier();
         sb_fill_half(S, b, h0);
         sb_fill_half(S, b, h0 + HALF_DW);
@@ -176,18 +182,31 @@ __device__ __forceinline__ void sb_stage(WaveState &S, SBits &b)
         }
     }
 }
-__device__ __forceinline__ void sb_init(SBits &b, const uint8_t *p, uint64_t n, uint64_t bitpos)
+// `bitpos`: where the wave starts; `lowest`: the lowest position it will ever seek to (a chunk that begins inside a block
+// goes back to that block's header first)
+__device__ __forceinline__ void sb_init(SBits &b, const uint8_t *p, uint64_t n, uint64_t bitpos, uint64_t lowest = ~0ull)
 {
-    b.in = reinterpret_cast<const uint32_t *>(p); b.n = n;
-    b.bp = bitpos; b.staged_to = 0; b.buf = 0; b.cnt = 0;
+    const uint64_t base_dw = (min(bitpos, lowest) >> 5) & ~(uint64_t)(STAGE_DW - 1);
+    b.in = reinterpret_cast<const uint32_t *>(p) + base_dw;
+    b.base = base_dw << 5;
+    const uint64_t total = n * 8;
+    b.nbits = total <= b.base ? 0u : (uint32_t)min(total - b.base, (uint64_t)SB_CAP);
+    b.bp = (uint32_t)min(bitpos - b.base, (uint64_t)SB_NEVER - 1);
+    b.staged_to = 0; b.buf = 0; b.cnt = 0;
 }
-__device__ __forceinline__ void sb_seek(SBits &b, uint64_t bitpos) { b.bp = bitpos; b.cnt = 0; }
+__device__ __forceinline__ void sb_seek(SBits &b, uint32_t rel) { b.bp = rel; b.cnt = 0; }                      // relative
+// a position of the file -> relative (SB_NEVER: none, or out of this wave's reach)
+__device__ __forceinline__ uint32_t sb_rel(const SBits &b, uint64_t bitpos)
+{
+    return (bitpos == ~0ull || bitpos - b.base >= (uint64_t)SB_CAP) ? SB_NEVER : (uint32_t)(bitpos - b.base);
+}
+__device__ __forceinline__ void sb_seek_abs(SBits &b, uint64_t bitpos) { sb_seek(b, sb_rel(b, bitpos)); }
 // scalar cache: at least 33 bits from bp on.  Every lane reads the same words: telling the compiler so (readfirstlane)
 // keeps the header logic on the scalar unit
 __device__ __forceinline__ void sb_load(WaveState &S, SBits &b)
 {
     sb_stage(S, b);
-    const uint32_t w = (uint32_t)(b.bp >> 5);
+    const uint32_t w = b.bp >> 5;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.stage[w & STAGE_MASK]);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.stage[(w + 1) & STAGE_MASK]);
     const int sh = (int)(b.bp & 31);
@@ -196,7 +215,7 @@ __device__ __forceinline__ void sb_load(WaveState &S, SBits &b)
 }
 __device__ __forceinline__ void sb_need(WaveState &S, SBits &b, int k) { if (b.cnt < k) sb_load(S, b); }      // k <= 33
 __device__ __forceinline__ uint32_t sb_peek(SBits &b, int k) { return (uint32_t)(b.buf & ((1ull << k) - 1)); }
-__device__ __forceinline__ void sb_drop(SBits &b, int k) { b.buf >>= k; b.cnt -= k; b.bp += (uint64_t)k; }
+__device__ __forceinline__ void sb_drop(SBits &b, int k) { b.buf >>= k; b.cnt -= k; b.bp += (uint32_t)k; }
 __device__ __forceinline__ uint32_t sb_get(WaveState &S, SBits &b, int k)      // k <= 32
 {
     sb_need(S, b, k);
@@ -204,8 +223,8 @@ __device__ __forceinline__ uint32_t sb_get(WaveState &S, SBits &b, int k)      /
     sb_drop(b, k);
     return v;
 }
-__device__ __forceinline__ uint64_t sb_bitpos(const SBits &b) { return b.bp; }
-__device__ __forceinline__ bool sb_past_end(const SBits &b) { return b.bp > b.n * 8; }
+__device__ __forceinline__ uint64_t sb_bitpos(const SBits &b) { return b.base + b.bp; }                         // of the file
+__device__ __forceinline__ bool sb_past_end(const SBits &b) { return b.bp > b.nbits; }
 
 // canonical code from the lengths lens[0 .. n) (LDS): 0 complete, 1 incomplete, -1 over-subscribed (nothing built).
 // The 64 lanes hold the lengths of symbols lane, lane + 64, ...; a ballot per code length counts the codes and ranks a
@@ -312,12 +331,12 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
         // the HCLEN 3-bit lengths (at most 57 bits) in one go: lane i takes the i-th
         sb_stage(S, b);
         const int li = threadIdx.x & 63;
-        const uint64_t p = b.bp + 3ull * (uint64_t)li;
-        const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+        const uint32_t p = b.bp + 3u * (uint32_t)li;
+        const uint32_t w = p >> 5, sh = p & 31u;
         const uint32_t d0 = S.stage[w & STAGE_MASK], d1 = S.stage[(w + 1) & STAGE_MASK];
         const uint32_t v = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh) & 7u;
         if (li < hclen) S.lens[c_cl_order[li]] = (uint8_t)v;
-        sb_seek(b, b.bp + 3ull * (uint64_t)hclen);
+        sb_seek(b, b.bp + 3u * (uint32_t)hclen);
     }
     if (__builtin_amdgcn_readfirstlane(huff_build<7, 19, 7>(S.clc, S.lens, 19)) != 0) return false;   // (a call's result arrives in a VGPR)
     // the code lengths themselves, as the block loop decodes its symbols: the 64 lanes decode a code-length symbol (with its
@@ -330,8 +349,8 @@ __device__ bool read_dynamic(WaveState &S, SBits &b, bool &dist_usable)
     uint32_t kraft_lit = 0;
     while (i < total) {
         sb_stage(S, b);
-        const uint64_t p = b.bp + (uint64_t)lane;
-        const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+        const uint32_t p = b.bp + (uint32_t)lane;
+        const uint32_t w = p >> 5, sh = p & 31u;
         const uint32_t d0 = S.stage[w & STAGE_MASK], d1 = S.stage[(w + 1) & STAGE_MASK];
         const uint32_t bits = (uint32_t)((((uint64_t)d1 << 32) | d0) >> sh);
         const uint32_t e = S.clc.tent[bits & 127u];
@@ -422,17 +441,17 @@ __device__ unsigned long long g_gz_t[12];
 constexpr uint32_t RING_REACH = RING - 264;
 struct OutState {
     uint16_t *out;           // null: count only
-    uint64_t cap, n, flushed;
+    uint32_t cap, n, flushed;        // symbols: a chunk's output is far below 2^31 (its region is capped when the state is made)
 #ifdef SS_GZ_TIMING
     uint64_t t[10];
 #endif
 };
-__device__ __forceinline__ void out_flush(WaveState &S, OutState &o, uint64_t upto)
+__device__ __forceinline__ void out_flush(WaveState &S, OutState &o, uint32_t upto)
 {
     const int lane = threadIdx.x & 63;
     GZ_T(tf0);
     __threadfence_block();
-    for (uint64_t i = o.flushed + (uint64_t)lane; i < upto; i += 64) o.out[i] = S.ring[i & (RING - 1)];
+    for (uint32_t i = o.flushed + (uint32_t)lane; i < upto; i += 64) o.out[i] = S.ring[i & (RING - 1)];
     o.flushed = upto;
     GZ_T(tf1);
     GZ_ACC(3, tf0, tf1);
@@ -455,10 +474,10 @@ __device__ __forceinline__ int lane_long(const LHuff<PB, MAXSYM> &h, uint32_t v,
 }
 
 // `len` symbols from `dist` back to position n of the wave's output (the 64 lanes together)
-__device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint64_t n, uint32_t len, uint32_t dist)
+__device__ __forceinline__ void copy_match(WaveState &S, const OutState &o, uint32_t n, uint32_t len, uint32_t dist)
 {
     const int lane = threadIdx.x & 63;
-    const uint32_t n32 = (uint32_t)n;                  // a chunk's output is far below 2^31 symbols
+    const uint32_t n32 = n;
     const bool overlaps = dist < len;                  // (uniform: the division below is rarely reached)
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
@@ -498,20 +517,20 @@ __device__ int block_begin(WaveState &S, SBits &b, OutState &o, BlockCtx &cx)
     cx.bfinal = bfinal;
     cx.dist_usable = true;
     if (btype == 3) return -1;
-    uint64_t n = o.n;
+    uint32_t n = o.n;
 #define GI_RET(v) do { o.n = n; return (v); } while (0)
     if (btype == 0) {
-        sb_seek(b, (b.bp + 7) & ~7ull);
+        sb_seek(b, (b.bp + 7u) & ~7u);
         const uint32_t len = sb_get(S, b, 16), nlen = sb_get(S, b, 16);
         if (sb_past_end(b) || (len ^ 0xFFFFu) != nlen) GI_RET(-2);
-        if (b.bp + 8ull * len > b.n * 8) GI_RET(-3);
+        if (b.bp + 8u * len > b.nbits) GI_RET(-3);
         if (store) {
             if (n + len > o.cap) GI_RET(-9);
             const uint8_t *src = reinterpret_cast<const uint8_t *>(b.in) + (b.bp >> 3);
             uint32_t done = 0;
             while (done < len) {
                 if (n - o.flushed >= 1024) out_flush(S, o, n);
-                const uint32_t take = min(len - done, 1024u - (uint32_t)(n - o.flushed));
+                const uint32_t take = min(len - done, 1024u - (n - o.flushed));
                 for (uint32_t i = (uint32_t)lane; i < take; i += 64) S.ring[(n + i) & (RING - 1)] = src[done + i];
                 n += take;
                 done += take;
@@ -519,7 +538,7 @@ __device__ int block_begin(WaveState &S, SBits &b, OutState &o, BlockCtx &cx)
         } else {
             n += len;
         }
-        sb_seek(b, b.bp + 8ull * len);
+        sb_seek(b, b.bp + 8u * len);
         GI_RET(10 + (int)bfinal);
     }
     GZ_T(th0);
@@ -535,17 +554,17 @@ __device__ int block_begin(WaveState &S, SBits &b, OutState &o, BlockCtx &cx)
 // block, or one that goes on behind an entry it ran over -- any item's first bit) to its end-of-block code.
 // 0 = block done, 1 = final block done, 2 = probe satisfied, 3 = stopped exactly AT mid_target (an item's first bit inside
 // this block: the next chunk's entry), 4 = mid_target lies behind the position and was not an item's first bit, < 0 = error.
-__device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window, const BlockCtx cx, uint64_t probe_symbols, uint64_t stop_bits,
-                          uint64_t mid_target)
+__device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window, const BlockCtx cx, uint64_t probe_symbols, uint32_t stop_bits,
+                          uint32_t mid_target)      // (stop_bits, mid_target: relative positions, sb_rel; SB_NEVER = none)
 {
     const int lane = threadIdx.x & 63;
     const bool store = o.out != nullptr;
     const uint32_t bfinal = cx.bfinal;
     const bool dist_usable = cx.dist_usable;
-    uint64_t n = o.n;
+    uint32_t n = o.n;
     const int lit_maxlen = __builtin_amdgcn_readfirstlane(S.lit.maxlen), dist_maxlen = __builtin_amdgcn_readfirstlane(S.dist.maxlen);
-    const uint64_t probe_end = probe_symbols == ~0ull ? ~0ull : n + probe_symbols;
-    const uint64_t end_bits = b.n * 8;
+    const uint32_t probe_end = probe_symbols >= 0x7FFFFFFFull ? SB_NEVER : n + (uint32_t)probe_symbols;
+    const uint32_t end_bits = b.nbits;
     const uint64_t mine_below = lane ? (~0ull >> (64 - lane)) : 0ull;
     // the window whose far matches are still loading while the next one is decoded (software pipeline: a far match reads
     // what this wave wrote tens of KB ago -- with thousands of waves at work that is HBM or the Infinity Cache, ~2 us)
@@ -580,8 +599,8 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
         // ---- every lane: the item at bp + lane
         uint32_t info, val = 0, mlen = 0;                  // info = bits of the item | F_*; val = literal byte or match distance
         {
-            const uint64_t p = b.bp + (uint64_t)lane;
-            const uint32_t w = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+            const uint32_t p = b.bp + (uint32_t)lane;
+            const uint32_t w = p >> 5, sh = p & 31u;
             const uint32_t d0 = S.stage[w & STAGE_MASK], d1 = S.stage[(w + 1) & STAGE_MASK], d2 = S.stage[(w + 2) & STAGE_MASK];
             uint64_t bits = (((uint64_t)d1 << 32) | d0) >> sh;
             if (sh) bits |= (uint64_t)d2 << (64 - sh);
@@ -624,8 +643,8 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
         uint32_t stop = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)last);
         stop = (stop & (F_EOB | F_BAD)) ? stop : 0u;
         if (stop) { chain &= ~(1ull << last); pos = last; }
-        if (mid_target - b.bp < 64ull && ((chain >> (uint32_t)(mid_target - b.bp)) & 1ull)) {      // the next chunk begins at an item of this window
-            pos = (uint32_t)(mid_target - b.bp);
+        if (mid_target - b.bp < 64u && ((chain >> (mid_target - b.bp)) & 1ull)) {      // the next chunk begins at an item of this window
+            pos = mid_target - b.bp;
             chain &= (1ull << pos) - 1ull;
             stop = 0;
         }
@@ -637,7 +656,7 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
         const uint32_t olen = on ? (is_match ? mlen : 1u) : 0u;
         const uint32_t incl = wave_inclusive_sum(olen);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t at = (uint32_t)n + (incl - olen);   // where this lane's item goes (a chunk's output is far below 2^31 symbols)
+        const uint32_t at = n + (incl - olen);             // where this lane's item goes
         if (known_window && __ballot(is_match && val > at)) GI_OUT(-8);
 #ifdef SS_GZ_TIMING
         o.t[6] += (uint64_t)__popcll(matches); o.t[7] += total; o.t[8] += (uint64_t)__popcll(__ballot(is_match && val > RING_REACH + mlen - 1));
@@ -691,8 +710,8 @@ __device__ int block_body(WaveState &S, SBits &b, OutState &o, bool known_window
                 for (;;) {
                     const int fm = mt ? __ffsll((long long)mt) - 1 : 64;
                     const uint64_t lits = (fm == 64 ? rem : rem & ((1ull << fm) - 1));
-                    if ((lits >> lane) & 1ull) S.ring[(n + (uint64_t)__popcll(lits & mine_below)) & (RING - 1)] = (uint16_t)val;
-                    n += (uint64_t)__popcll(lits);
+                    if ((lits >> lane) & 1ull) S.ring[(n + (uint32_t)__popcll(lits & mine_below)) & (RING - 1)] = (uint16_t)val;
+                    n += (uint32_t)__popcll(lits);
                     if (fm == 64) break;
                     const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mlen, fm), dist = (uint32_t)__builtin_amdgcn_readlane((int)val, fm);
                     if (n - o.flushed >= 1024) out_flush(S, o, n);
@@ -724,12 +743,12 @@ out:
 }
 
 // One block from the current position.  0 = block done, 1 = final block done, 2 = probe satisfied, < 0 = error.
-__device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_window, uint64_t probe_symbols = ~0ull, uint64_t stop_bits = ~0ull)
+__device__ int inflate_block(WaveState &S, SBits &b, OutState &o, bool known_window, uint64_t probe_symbols = ~0ull, uint32_t stop_bits = SB_NEVER)
 {
     BlockCtx cx;
     const int r = block_begin(S, b, o, cx);
     if (r != 0) return r >= 10 ? r - 10 : r;
-    return block_body(S, b, o, known_window, cx, probe_symbols, stop_bits, ~0ull);
+    return block_body(S, b, o, known_window, cx, probe_symbols, stop_bits, SB_NEVER);
 }
 
 __device__ unsigned g_sync_tries;      // candidates that passed the header check and were decoded (trace)
@@ -805,7 +824,7 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
                 // confirm with the whole wave: a complete, valid header (zlib's rules) and SS_GZ_PROBE symbols that decode: a
                 // position inside a block passes this with negligible probability, and if one ever does, the chunk in front
                 // runs over it (inflate_kernel)
-                sb_seek(b, cand);
+                sb_seek_abs(b, cand);
                 OutState o{nullptr, 0, 0, 0};
                 const int r = inflate_block(S, b, o, false, probe);
                 if (count_tries && lane == 0) atomicAdd(&g_sync_tries, 1u);
@@ -861,7 +880,7 @@ __global__ __launch_bounds__(64) void subsync_kernel(const uint8_t *in, uint64_t
     OutState o{nullptr, 0, 0, 0};
     BlockCtx cx;
     const bool usable = block_begin(S, b, o, cx) == 0;
-    const uint64_t body = b.bp;
+    const uint64_t body = sb_bitpos(b);
     const int lit_maxlen = __builtin_amdgcn_readfirstlane(S.lit.maxlen), dist_maxlen = __builtin_amdgcn_readfirstlane(S.dist.maxlen);
     for (uint32_t i = first[blk]; i < first[blk + 1]; i++) {
         uint64_t found = ~0ull;
@@ -871,10 +890,11 @@ __global__ __launch_bounds__(64) void subsync_kernel(const uint8_t *in, uint64_t
             for (int w = 0; w < SUB_WINDOWS; w++) {
                 const uint64_t base = p0 + 64ull * (uint64_t)w;
                 if (base + 192 > lim) break;
-                sb_seek(b, base);
+                sb_seek_abs(b, base);
+                if (b.bp == SB_NEVER) break;                  // (out of this wave's reach: no entry here)
                 sb_stage(S, b);
-                const uint64_t p = base + (uint64_t)lane;
-                const uint32_t wd = (uint32_t)(p >> 5), sh = (uint32_t)p & 31u;
+                const uint32_t p = b.bp + (uint32_t)lane;     // the stage is addressed by relative positions
+                const uint32_t wd = p >> 5, sh = p & 31u;
                 const uint32_t d0 = S.stage[wd & STAGE_MASK], d1 = S.stage[(wd + 1) & STAGE_MASK], d2 = S.stage[(wd + 2) & STAGE_MASK];
                 uint64_t bits = (((uint64_t)d1 << 32) | d0) >> sh;
                 if (sh) bits |= (uint64_t)d2 << (64 - sh);
@@ -916,8 +936,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
     const uint64_t s0 = start[c];
     const bool fresh = (s0 >> 63) != 0;                     // the first chunk of a member: nothing lies in front of it
     const uint64_t first_bit = s0 & ~(1ull << 63);
-    sb_init(b, in, in_n, first_bit);
-    OutState o{sym ? sym + sym_off[c] : nullptr, sym_cap[c], 0, 0};
+    sb_init(b, in, in_n, first_bit, hdr[c]);                 // (hdr[c]: ~0, or the header of the block the chunk begins in -- in front of it)
+    OutState o{sym ? sym + sym_off[c] : nullptr, (uint32_t)min(sym_cap[c], (uint64_t)0x7FFF0000u), 0, 0};
     // A block that ends BEHIND the next chunk's entry: that entry was no block's start (a position inside a block passes the
     // sync search about once in a million candidates).  The chunk simply goes on to the entry after it -- its symbol
     // region (12x its input) has room for two or three chunks of FASTQ -- and says how many entries it ran over; within
@@ -935,11 +955,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
         BlockCtx cx;
         int r;
         if (resume) {                                        // a chunk that begins inside a block: its tables first
-            sb_seek(b, block_at);
+            sb_seek_abs(b, block_at);
             OutState none{nullptr, 0, 0, 0};
             r = block_begin(S, b, none, cx);
             if (r != 0 || first_bit < sb_bitpos(b)) { st = -22; break; }
-            sb_seek(b, first_bit);
+            sb_seek_abs(b, first_bit);
             resume = false;
         } else {
             block_at = sb_bitpos(b);
@@ -949,7 +969,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, uint64_t
             for (;;) {
                 const uint32_t k = c + 1 + skipped;
                 const uint64_t mid = (k < n_chunks && skipped <= max_over && hdr[k] == block_at) ? (start[k] & ~(1ull << 63)) : ~0ull;
-                r = block_body(S, b, o, fresh, cx, ~0ull, hard, mid);
+                r = block_body(S, b, o, fresh, cx, ~0ull, sb_rel(b, hard), sb_rel(b, mid));
                 if (r == 4 && skipped < max_over) { stop_at = stop[c + ++skipped]; continue; }      // not an item's first bit: a wrong entry, run over
                 break;
             }
