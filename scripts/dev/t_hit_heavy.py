@@ -71,10 +71,12 @@ for bits in sys.argv[3:] or ["0"]:
         out["cycles_per_tile"] = {names[i]: round(tm[i] / tiles) for i in names}
     if hasattr(_lib.lib(), "ss_debug_comb_stats"):
         import ctypes
-        st8 = (ctypes.c_ulonglong * 8)()
+        st8 = (ctypes.c_ulonglong * 16)()
         _lib.lib().ss_debug_comb_stats(st8, 1)
         db.reset(stream); rs.scan_into(db, stream)
         _lib.lib().ss_debug_comb_stats(st8, 1)
         out["comb_stats"] = dict(zip(("tiles", "flushes", "entries", "counters", "found_runs", "runs_without_entry", "full_flushes"), list(st8)[:7]))
+        out["per_tile"] = dict(runs=round(st8[9] / max(1, st8[8]), 1), looked_up=round(st8[10] / max(1, st8[8]), 1), found=round(st8[11] / max(1, st8[8]), 1),
+                               lookup_rounds=round(st8[12] / max(1, st8[8]), 2), candidate_rounds=round(st8[13] / max(1, st8[8]), 2))
     rs.close()
 print(out)
