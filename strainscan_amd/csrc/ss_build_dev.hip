@@ -478,7 +478,7 @@ int build_mini_dev(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64
     db->d_bloom = d_bloom;
     db->bloom_bits = d_bloom ? (uint32_t)bits : 0;
     db->device_bytes = n_mslots * 8 + n_slots * 4 + n_alloc * 64 + nr * 5 + bloom_bytes;
-    return SS_OK;
+    return mark_solid(db);
 }
 
 }  // namespace ss

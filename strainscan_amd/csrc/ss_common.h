@@ -169,6 +169,7 @@ void reorder_release();      // the binning scratch kept between calls goes back
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
 // the same index built on the device (ss_build_dev.hip); anything but SS_OK / SS_EKEY: nothing was built, use the host build
 int build_mini_dev(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
+int mark_solid(ss_db *db);      // PG_SOLID flags of the bucket references, after either build (ss_mini.hip)
 using BlockSink = std::function<int(const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream)>;
 int parse_file_parallel(ss_db::Worker *workers, const char *path, int shard_rank, int shard_world,
                         uint64_t *n_records, uint64_t *n_bases, bool *handled, const BlockSink &sink, bool copy = true);

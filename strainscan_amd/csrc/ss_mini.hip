@@ -136,6 +136,7 @@ struct QShared {
     alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
     uint64_t q2[Q1CAP];                // found bucket: bucket start << 32 | multi << 31 | aligned offset mask << 12 | run index (q1b with a
                                        // Bloom filter, q1 without)
+    uint8_t rest[Q1CAP];               // phase 3: the found runs whose bucket is not solid (indices into q2)
     uint32_t cnt[4];                   // [1] = found runs
 #ifdef SS_LDS_PAD
     uint32_t pad[SS_LDS_PAD / 4];      // occupancy experiments only
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             uint32_t i2 = Q1CAP;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
             if (i2 < Q1CAP) {
-                S.q2[i2] = ((uint64_t)bstart << 32) | (multi << 31) | (amask << 12) | ridx;
+                S.q2[i2] = ((uint64_t)(lo & (ss::START_MASK | ss::PG_SOLID)) << 32) | (multi << 31) | (amask << 12) | ridx;      // (bit 62: solid)
             } else {
                 // the queue is full (only with floods of tag collisions), or phase 3 is already
                 // over (runs that overflowed q1): settle this run here, so that no k-mer is ever dropped
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 if (comb_runs + n2 > 255u) { comb_flush(); SS_T(8); }
                 comb_runs += n2;
                 for (uint32_t r = (uint32_t)t; r < n2; r += MT) {
-                    const uint32_t key = ((uint32_t)(S.q2[r] >> 32) | tab_key) + 1u;
+                    const uint32_t key = (((uint32_t)(S.q2[r] >> 32) & ss::START_MASK) | tab_key) + 1u;
                     uint32_t i = (key * 0x9E3779B1u) >> 26, e = COMB_NONE;
                     static_assert(COMB_NE == 64, "hash: top six bits");
                     for (int pr = 0; pr < 8; pr++) {
@@ -730,6 +731,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 SS_T(9);
             }
             SS_CS(11, n2); SS_CS(13, (n2 * 16u + U3 * MT - 1) / (U3 * MT));
+            uint32_t n_rest = 0, n_hit = 0;                // found runs whose bucket is not solid (S.rest from the front); solid runs with
+                                                           // hits for the counters (S.rest from the back: together at most n2 entries)
             // U runs' worth of positions per lane and round: all their candidate loads in flight before any compare
             auto cand_round = [&](auto UC, uint32_t g0) {
                 constexpr int U = decltype(UC)::value;
@@ -739,24 +742,106 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
-                    const bool v = (g >> 4) < n2;
-                    const uint64_t r = S.q2[v ? (g >> 4) : 0u];
+                    const bool v = (g >> 4) < n_rest;
+                    const uint32_t fi = v ? (COMB ? (uint32_t)S.rest[g >> 4] : (g >> 4)) : 0u;      // the found run (index into q2)
+                    const uint64_t r = S.q2[fi];
                     const uint32_t run = BLOOM ? (uint32_t)SB.q1b[(uint32_t)r & 0xFFFu] : S.q1[(uint32_t)r & 0xFFFu];
                     pos[u] = (run & 0xFFFu) + q;
-                    bst[u] = (uint32_t)(r >> 32);
+                    bst[u] = (uint32_t)(r >> 32) & ss::START_MASK;
                     mul[u] = (uint32_t)r >> 31;
                     cps[u] = (v && q < ((run >> 12) & 31u)) ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q) : 0u;
                     cnd[u] = mkeys[cps[u]];
-                    ent[u] = COMB ? (uint32_t)C.ent[v ? (g >> 4) : 0u] : COMB_NONE;
+                    ent[u] = COMB ? (uint32_t)C.ent[fi] : COMB_NONE;
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++)
                     if (cps[u]) settle_item<COMB>(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, ent[u], &C.acc[0][0]);
                 SS_MARK(16);
             };
+            // (only in the combining scans: a tree scan finds ~6 runs per tile, and six lanes walking through this path cost more
+            //  than the 16-lanes-per-run check of 96: contiguous node sets 3.37 -> 3.70 ms with it)
+            // ---- 3a: runs whose bucket is SOLID (PG_SOLID: its k-mers are one stretch of bases), ONE LANE per run: the
+            // stretch is rebuilt from the bucket's first and last candidate key (they overlap), compared with the read's bases
+            // in three words, and a mismatching base strikes the k-mers that cover it.  The other runs are compacted into
+            // S.rest for the 16-lanes-per-run check below.
+            if (!COMB) n_rest = n2;                        // (S.rest is not used: run i is found run i)
+            for (uint32_t r0 = 0; COMB && r0 < n2; r0 += MT) {
+                const uint32_t r = r0 + (uint32_t)t;
+                const bool v = r < n2;
+                const uint64_t q = S.q2[v ? r : 0u];
+                const bool solid = v && ((q >> 62) & 1ull);
+                uint32_t hitmask = 0;                      // this lane's run: its matching k-mers, when they go straight to the counters
+                const uint64_t om = __ballot(v && !solid);
+                if (v && !solid) S.rest[n_rest + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = (uint8_t)r;
+                n_rest += (uint32_t)__popcll(om);
+                if (solid) {
+                    const uint32_t bstart = (uint32_t)(q >> 32) & ss::START_MASK, amask = ((uint32_t)q >> 12) & 0x1FFFFu;
+                    const uint32_t run = BLOOM ? (uint32_t)SB.q1b[(uint32_t)q & 0xFFFu] : S.q1[(uint32_t)q & 0xFFFu];
+                    const uint32_t rpos = run & 0xFFFu, len = (run >> 12) & 31u;
+                    // position p of the run has offset 16 - p: the candidates are the offsets of amask at or above 17 - len
+                    const uint32_t am = amask & ~((1u << (17u - len)) - 1u);
+                    if (am) {
+                        const uint32_t o_hi = 31u - (uint32_t)__clz(am), o_lo = (uint32_t)__ffs(am) - 1u, d = o_hi - o_lo;
+                        const uint32_t slot_a = bstart + 1u + (uint32_t)__popc(amask & ((1u << o_hi) - 1u));      // the first position's k-mer
+                        const uint64_t k1 = mkeys[slot_a], k2 = mkeys[slot_a - d];                                // ... and the last one's
+                        const int32_t P = (int32_t)(rpos + 16u - o_hi);
+                        const uint64_t lo64 = k1 | (k2 << (2u * d));
+                        const uint32_t hi32 = d ? (uint32_t)(k2 >> (64u - 2u * d)) : 0u;
+                        uint32_t x0 = win16_at(S, P) ^ (uint32_t)lo64;
+                        uint32_t x1 = (win16_at(S, P + 16) ^ (uint32_t)(lo64 >> 32)) & (d == 0u ? 0x3FFFFFFFu : 0xFFFFFFFFu);
+                        uint32_t x2 = d >= 2u ? (win16_at(S, P + 32) ^ hi32) & ((1u << (2u * d - 2u)) - 1u) : 0u;
+                        uint32_t match = (2u << d) - 1u;                                                           // k-mers 0 .. d of the stretch
+                        // a base that differs strikes the k-mers covering it: j in [m - 30, m]
+                        x0 = (x0 | (x0 >> 1)) & 0x55555555u; x1 = (x1 | (x1 >> 1)) & 0x55555555u; x2 = (x2 | (x2 >> 1)) & 0x55555555u;
+                        auto strike = [&](uint32_t xb, uint32_t base0) {
+                            while (xb) {
+                                const uint32_t m = base0 + (((uint32_t)__ffs(xb) - 1u) >> 1);
+                                xb &= xb - 1u;
+                                const uint32_t hi = min(m, d), lw = m > 30u ? m - 30u : 0u;
+                                if (lw <= hi) match &= ~(((2u << hi) - 1u) & ~((1u << lw) - 1u));
+                            }
+                        };
+                        strike(x0, 0u); strike(x1, 16u); strike(x2, 32u);
+                        if (match) {
+                            const uint32_t w_ = 1u;
+                            const uint32_t off_a = slot_a - bstart;                                                // k-mer j sits at slot offset off_a - j
+                            const uint32_t e_ = COMB ? (uint32_t)C.ent[r] : COMB_NONE;
+                            if (COMB && e_ != COMB_NONE && off_a < 20u) {
+                                const uint32_t bits = __brev(match) >> (31u - off_a);                              // bit o = the k-mer at slot offset o
+#pragma unroll
+                                for (uint32_t wd = 0; wd < 5; wd++) {
+                                    const uint32_t nib = (bits >> (4u * wd)) & 15u;
+                                    if (nib) atomicAdd(&C.acc[e_][wd], ((nib * 0x00204081u) & 0x01010101u) * w_);
+                                }
+                            } else {
+                                // straight to the counters, but NOT one k-mer after the other from this lane: an atomic costs
+                                // per (instruction, line), and a lane's hits share a line -- the run's result goes back into
+                                // its q2 entry and 16 lanes count it below (3c)
+                                hitmask = match;
+                                S.q2[r] = ((uint64_t)slot_a << 32) | match;
+                            }
+                        }
+                    }
+                }
+                const uint64_t hm = __ballot(hitmask != 0u);
+                if (hitmask) S.rest[Q1CAP - 1u - (n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)))] = (uint8_t)r;
+                n_hit += (uint32_t)__popcll(hm);
+            }
+            if (COMB) __syncthreads();
+            // ---- 3c: the solid runs' hits that go straight to the counters, 16 lanes per run (k-mer 16 of a full stretch: lane 0 again)
+            for (uint32_t g0 = 0; g0 < n_hit * 16u; g0 += MT) {
+                const uint32_t g = g0 + (uint32_t)t;
+                if ((g >> 4) < n_hit) {
+                    const uint64_t e = S.q2[S.rest[Q1CAP - 1u - (g >> 4)]];
+                    const uint32_t j = g & 15u, slot_a = (uint32_t)(e >> 32), mt = (uint32_t)e;
+                    if ((mt >> j) & 1u) atomicAdd(&counts[slot_a - j], 1u);
+                    if (j == 0u && (mt >> 16)) atomicAdd(&counts[slot_a - 16u], 1u);
+                }
+            }
+            // ---- 3b: the other found runs, 16 lanes each
             // (a tree scan finds ~5 runs per tile = 80 of a round's 256 positions; rounds of 64 for the rest were tried in
             //  round 4 and change nothing: the empty quarters of a round are branched over)
-            const uint32_t total = n2 * 16u;
+            const uint32_t total = n_rest * 16u;
             uint32_t g0 = 0;
             for (; g0 < total; g0 += U3 * MT) cand_round(std::integral_constant<int, U3>(), g0);
             if (COMB && comb_full) { __syncthreads(); SS_T(4); comb_flush(); SS_T(8); }
@@ -1076,6 +1161,41 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     SS_HIP(hipMemcpy(db->d_slot_of_row, slot_of_row.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
     SS_HIP(hipMemcpy(db->d_row_valid, row_valid.data(), nr, hipMemcpyHostToDevice));
     lap("5 bloom + upload");
+    return mark_solid(db);
+}
+
+// PG_SOLID for every bucket whose k-mers are one stretch of bases (ss_scan_dev.h): one thread per page slot, after either
+// build has put pages and buckets on the device -- the same flags whichever build made the image.
+__global__ __launch_bounds__(256) void mark_solid_kernel(uint8_t *__restrict__ pages, uint64_t n_page_slots, const uint64_t *__restrict__ mkeys)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_page_slots) return;
+    uint8_t *pp = pages + (i >> 3) * 64;
+    const uint32_t sl = (uint32_t)(i & 7u);
+    if (!(pp[8 + sl] & 0x80u)) return;                                   // an inline k-mer, or empty
+    uint32_t *lo32 = reinterpret_cast<uint32_t *>(pp + 16) + sl;
+    const uint32_t lo = *lo32;
+    if (lo >> 31) return;                                                // several k-mers per offset
+    const uint32_t b = lo & ss::START_MASK;
+    const uint64_t hdr = mkeys[b];
+    const uint32_t mask = (uint32_t)hdr & 0x1FFFFu, cnt = (uint32_t)(hdr >> 32);
+    if ((hdr & ss::HDR_MULTI) || !mask || cnt != (uint32_t)__popc(mask)) return;
+    const uint32_t m = mask >> (__ffs(mask) - 1);
+    if (m & (m + 1u)) return;                                            // a gap in the offsets
+    // slots ascend with the offset; the k-mer of offset o + 1 begins one base before the k-mer of offset o
+    for (uint32_t k = 1; k < cnt; k++)
+        if ((mkeys[b + k] & ((1ull << 60) - 1ull)) != (mkeys[b + k + 1] >> 2)) return;
+    *lo32 = lo | ss::PG_SOLID;
+}
+
+int mark_solid(ss_db *db)
+{
+    if (const char *e = getenv("SS_SOLID")) if (!atoi(e)) return SS_OK;      // A/B: every bucket through the 16-lane check
+    const uint64_t n = (uint64_t)db->n_dir_alloc * ss::PG_SLOTS;
+    if (!n) return SS_OK;
+    hipLaunchKernelGGL(mark_solid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint8_t *)db->d_dir, n, db->d_mkeys);
+    SS_HIP(hipGetLastError());
+    SS_HIP(hipDeviceSynchronize());
     return SS_OK;
 }
 
@@ -1220,7 +1340,7 @@ __global__ void validate_image_kernel(const uint32_t *__restrict__ slot_of_row, 
 }
 
 struct ImageHeader {
-    char magic[8];          // "SSIDX09\0"
+    char magic[8];          // "SSIDX10\0" (10: PG_SOLID flags in the bucket references)
     int32_t k, layout;
     uint64_t n_rows, n_distinct, n_slots, n_buckets, n_mslots, n_inline;
     uint32_t n_dir, bloom_bits, n_dir_alloc, reserved;
@@ -1295,7 +1415,7 @@ int ss_db_export(const ss_db *db, const char *path)
     if (!f) return SS_EIO;
     ImageHeader h;
     memset(&h, 0, sizeof(h));
-    memcpy(h.magic, "SSIDX09", 8);
+    memcpy(h.magic, "SSIDX10", 8);
     h.k = db->k; h.layout = db->layout;
     h.n_rows = db->n_rows; h.n_distinct = db->n_distinct; h.n_slots = db->n_slots; h.n_buckets = db->n_buckets;
     h.n_mslots = db->n_mslots; h.n_inline = db->n_inline;
@@ -1318,7 +1438,7 @@ int ss_db_import(const char *path, ss_db **out)
     if (fd < 0) return SS_EIO;
     ImageHeader h;
     struct stat st;
-    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX09", 8) != 0 ||
+    if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX10", 8) != 0 ||
         h.layout != 1 || h.k != 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_dir_alloc != h.n_dir + h.n_dir / 1024 || h.n_slots != h.n_mslots + (uint64_t)h.n_dir_alloc * 8 ||
         h.n_slots >= 0xFFFFFFF0ull || h.n_mslots >= (uint64_t)ss::START_MASK || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         close(fd);

@@ -58,6 +58,10 @@ constexpr uint32_t PG_MIN_PAGES = 4096;                   // >= 2^11: (page, low
 // first load has just brought into the L1.
 constexpr uint8_t PG_EMPTY_TAG = 0xFF, PG_EMPTY_HI = 0x7F;
 constexpr uint32_t START_MASK = 0x3FFFFFFFu;
+// bit 30 of a bucket reference's lo32 (round 4): the bucket is SOLID -- one database k-mer per offset, the offsets a contiguous
+// range, and the k-mer of offset o + 1 is the k-mer of offset o moved one base to the left: its k-mers are one stretch of
+// cnt + 30 bases (a super-k-mer), and a run of a read is verified against that stretch by ONE lane (ss_mini.hip phase 3a)
+constexpr uint32_t PG_SOLID = 1u << 30;
 // the 16 bases of a k-mer that are not its minimizer: rotate the 62-bit key right by 2 * offset (the minimizer
 // comes to stand in bits 0..29), the upper 32 bits = bases behind the minimizer, then the bases in front of it
 __host__ __device__ __forceinline__ uint32_t flank_of_key(uint64_t key, uint32_t off)
