@@ -486,8 +486,8 @@ def measure_config3(torch, dev, args, stream):
                           note="the cluster's table + two other genomes' tables of the same size, the same binned reads"),
         counters_added_per_s_binned=round(hits / (t_bin * 1e-3) / 1e9, 1), counters_unit="G hits/s",
         counts_equal_across_orders=equal, parity_on_sample=parity, parity_sample="first %d reads vs oracle orc_count_flat" % n_s,
-        bound="VALU issue (profiles/r04_cluster_scan_pmc_summary.txt: 5.4 G wave instructions per launch); a global atomicAdd "
-              "costs one of 27 G line requests/s whatever it carries (profiles/r04_atomics_micro_40MB.txt)")
+        bound="VALU issue (3.3 G wave instructions per launch = 5.5 ms) and 148 M atomic requests of the chip's 27 G (instruction, "
+              "line) per second (profiles/r04_cluster_scan2_pmc_summary.txt, r04_atomics_micro_40MB.txt)")
     rs.close()
     db.close()
     del reads, flat, genome, st
