@@ -799,15 +799,18 @@ def main(argv=None):
     readset = None
     if not args.no_readset and not args.calib_stream:
         prep = []
-        rs_loc = None
+        rs_all = []
         for _ in range(5):                          # first call: first touch of 3 GB of fresh device memory
-            if rs_loc is not None:
-                rs_loc.close()
+            # (the five sets stay alive until all are made: freeing a 3 GB slab right before the next one is allocated --
+            #  which no sample does -- made every other call wait 80-240 ms for the driver on some boxes)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            rs_loc = _lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
+            rs_all.append(_lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True))
             torch.cuda.synchronize()
             prep.append((time.perf_counter() - t1) * 1e3)
+        rs_loc = rs_all.pop()
+        for r_ in rs_all:
+            r_.close()
         # (the MEDIAN of five is reported as prepare_ms, the best and all five beside it: the call allocates the new 3 GB slab and
         #  frees 0.2 GB of scratch, and on a box whose host is busy with other tenants one such driver call now and then takes
         #  60-150 ms -- seen in three bench runs out of eight, always together with a slower cpu_baseline; the kernels' share is

@@ -136,7 +136,6 @@ struct QShared {
     alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
     uint64_t q2[Q1CAP];                // found bucket: bucket start << 32 | multi << 31 | aligned offset mask << 12 | run index (q1b with a
                                        // Bloom filter, q1 without)
-    uint8_t rest[Q1CAP];               // phase 3: the found runs whose bucket is not solid (indices into q2)
     uint32_t cnt[4];                   // [1] = found runs
 #ifdef SS_LDS_PAD
     uint32_t pad[SS_LDS_PAD / 4];      // occupancy experiments only
@@ -166,6 +165,8 @@ struct QComb {
     uint32_t acc[COMB_NE][5];          // byte o = occurrences of the bucket's slot o (1..19; slot 0 is the header)
     uint8_t ent[Q1CAP];                // per found run of the tile: its entry, COMB_NONE = count in global memory
     uint8_t list[COMB_NE];             // flush: the occupied entries
+    uint8_t rest[Q1CAP];               // phase 3: the found runs whose bucket is not solid, from the front; solid runs whose hits
+                                       // go straight to the counters, from the back (indices into q2)
 };
 
 // the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 for (int u = 0; u < U; u++) {
                     const uint32_t g = g0 + u * MT + t, q = g & 15u;
                     const bool v = (g >> 4) < n_rest;
-                    const uint32_t fi = v ? (COMB ? (uint32_t)S.rest[g >> 4] : (g >> 4)) : 0u;      // the found run (index into q2)
+                    const uint32_t fi = v ? (COMB ? (uint32_t)C.rest[g >> 4] : (g >> 4)) : 0u;      // the found run (index into q2)
                     const uint64_t r = S.q2[fi];
                     const uint32_t run = BLOOM ? (uint32_t)SB.q1b[(uint32_t)r & 0xFFFu] : S.q1[(uint32_t)r & 0xFFFu];
                     pos[u] = (run & 0xFFFu) + q;
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 const bool solid = v && ((q >> 62) & 1ull);
                 uint32_t hitmask = 0;                      // this lane's run: its matching k-mers, when they go straight to the counters
                 const uint64_t om = __ballot(v && !solid);
-                if (v && !solid) S.rest[n_rest + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = (uint8_t)r;
+                if (v && !solid) C.rest[n_rest + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = (uint8_t)r;
                 n_rest += (uint32_t)__popcll(om);
                 if (solid) {
                     const uint32_t bstart = (uint32_t)(q >> 32) & ss::START_MASK, amask = ((uint32_t)q >> 12) & 0x1FFFFu;
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     }
                 }
                 const uint64_t hm = __ballot(hitmask != 0u);
-                if (hitmask) S.rest[Q1CAP - 1u - (n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)))] = (uint8_t)r;
+                if (hitmask) C.rest[Q1CAP - 1u - (n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)))] = (uint8_t)r;
                 n_hit += (uint32_t)__popcll(hm);
             }
             if (COMB) __syncthreads();
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             for (uint32_t g0 = 0; g0 < n_hit * 16u; g0 += MT) {
                 const uint32_t g = g0 + (uint32_t)t;
                 if ((g >> 4) < n_hit) {
-                    const uint64_t e = S.q2[S.rest[Q1CAP - 1u - (g >> 4)]];
+                    const uint64_t e = S.q2[C.rest[Q1CAP - 1u - (g >> 4)]];
                     const uint32_t j = g & 15u, slot_a = (uint32_t)(e >> 32), mt = (uint32_t)e;
                     if ((mt >> j) & 1u) atomicAdd(&counts[slot_a - j], 1u);
                     if (j == 0u && (mt >> 16)) atomicAdd(&counts[slot_a - 16u], 1u);
