@@ -549,3 +549,34 @@ def test_documents_name_only_what_the_header_declares():
         names = set(re.findall(r"`(ss_[a-z0-9_]+)", text))
         unknown = sorted(n for n in names if n not in known and n not in stems and not n.endswith("_"))
         assert not unknown, (doc, unknown)
+
+
+def test_cache_tags_and_npz_reader(tmp_path):
+    """db.cache_tag: 128 bits, deterministic, different for inputs that differ in one character or only in length;
+    _load_npz_csr: the arrays of scipy's save_npz file (compressed or not) without building the matrix, anything but CSR
+    through scipy."""
+    import scipy.sparse as sp
+    from strainscan_amd.db import cache_tag
+    from strainscan_amd.identify_strains_L2_Enet_Pscan_new_sp import _load_npz_csr
+    a = cache_tag("/data/db/Tree_database|123456|1700000000000000000|31|1")
+    assert a == cache_tag("/data/db/Tree_database|123456|1700000000000000000|31|1") and len(a) == 32 and int(a, 16) >= 0
+    seen = {a}
+    for other in ("/data/db/Tree_database|123456|1700000000000000000|31|2", "/data/db/Tree_databasf|123456|1700000000000000000|31|1",
+                  "/data/db/Tree_database|123456|1700000000000000000|31|1 ", "", "a", "a\0", "ab"):
+        t = cache_tag(other)
+        assert t not in seen, other
+        seen.add(t)
+    rs = np.random.RandomState(3)
+    m = sp.random(500, 37, density=0.1, format="csr", random_state=rs, dtype=np.float64)
+    m.data[:] = 1
+    m = m.astype(np.int8)
+    for compressed in (True, False):
+        p = str(tmp_path / ("m%d.npz" % compressed))
+        sp.save_npz(p, m, compressed=compressed)
+        c = _load_npz_csr(p)
+        assert c.shape == (500, 37) and c.nnz == m.nnz
+        assert np.array_equal(c.indptr, m.indptr) and np.array_equal(c.indices, m.indices) and np.array_equal(c.data, m.data)
+    p = str(tmp_path / "csc.npz")
+    sp.save_npz(p, m.tocsc())
+    c = _load_npz_csr(p)
+    assert np.array_equal(c.indptr, m.indptr) and np.array_equal(c.indices, m.indices)

@@ -333,3 +333,50 @@ def test_chain_calls_are_bounded(tmp_path):
     r1 = json.load(open(tmp_path / "chain1.json"))
     assert r0["send"] == 0 and r1["recv"] == 0 and r1["payload_ok"] is True
     assert r1["late"] == 1 and 1.4 <= r1["waited"] < 10 and r1["failures"] == [[3, 0]]
+
+
+def _rank0_first_worker(rank, world, port, out_dir, fail_rank):
+    import json
+    sys.path.insert(0, REPO)
+    os.environ["SS_IMAGE_CACHE"] = os.path.join(out_dir, "cache")
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "store_%d" % port), rank=rank, world_size=world)
+    from strainscan_amd import db as ssdb
+    calls = []
+
+    def fn():
+        calls.append(rank)
+        if rank == fail_rank:
+            raise OSError("cannot read the database on rank %d" % rank)
+        return "image"
+
+    res = dict(rank=rank)
+    try:
+        res["out"] = ssdb.rank0_first(fn)
+    except BaseException as e:          # noqa: B902
+        res["error"] = type(e).__name__ + ": " + str(e)
+    res["calls"] = len(calls)
+    # whatever happened, the ranks are still in step: a collective that follows completes on all of them
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    res["after"] = float(t.item())
+    with open(os.path.join(out_dir, "r0f_%d_%d.json" % (fail_rank, rank)), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [0, 2, -1])
+def test_rank0_first_failure_is_raised_on_every_rank(tmp_path, fail_rank):
+    """db.rank0_first (rank 0 builds and exports the image, the others import it): a failure on ANY rank -- rank 0 while it
+    builds, another one while it imports -- is raised on all of them, and nobody is left in a collective alone."""
+    import json
+    port = 29500 + (os.getpid() % 2000) + 11 + fail_rank
+    mp.spawn(_rank0_first_worker, args=(3, port, str(tmp_path), fail_rank), nprocs=3, join=True)
+    res = [json.load(open(tmp_path / ("r0f_%d_%d.json" % (fail_rank, r)))) for r in range(3)]
+    assert all(r["after"] == 3.0 for r in res)
+    if fail_rank < 0:
+        assert all(r.get("out") == "image" and r["calls"] == 1 for r in res)
+    else:
+        assert all("error" in r for r in res), res
+        assert "cannot read the database" in res[fail_rank]["error"]
+        # rank 0 failed: the others never started; another rank failed: everybody had run its turn
+        assert [r["calls"] for r in res] == ([1, 0, 0] if fail_rank == 0 else [1, 1, 1])
