@@ -85,6 +85,17 @@ __global__ void starts_kernel(const uint32_t *__restrict__ newd, const uint32_t 
     if (newg[j]) gStartD[gIdx1[j] - 1] = dIdx1[j] - 1;
 }
 
+// k-mers of the minimizers that own one or two (choose_inline_max)
+__global__ void small_groups_kernel(const uint32_t *__restrict__ gStartD, uint32_t n_groups, unsigned long long *__restrict__ out)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nd = g < n_groups ? gStartD[g + 1] - gStartD[g] : 0u;
+    const uint32_t mine = nd <= 2u ? nd : 0u;
+    unsigned long long sum = mine;
+    for (int o = 32; o; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(out, sum);
+}
+
 __global__ void group_sizes_kernel(const uint32_t *__restrict__ gStartD, uint32_t n_groups, uint32_t inline_max, uint32_t *__restrict__ gslots,
                                    uint32_t *__restrict__ gitems)
 {
@@ -262,8 +273,7 @@ int build_mini_dev(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64
         hipDeviceSynchronize();
         fprintf(stderr, "[build-dev] %-26s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     };
-    uint32_t inline_max = 2;
-    if (const char *e = getenv("SS_INLINE_MAX")) inline_max = (uint32_t)std::max(0, std::min(8, atoi(e)));
+    uint32_t inline_max = 2;                        // (decided once the minimizers' sizes are known: choose_inline_max)
     double lambda = 2.0;
     if (const char *e = getenv("SS_PAGE_LAMBDA")) lambda = std::max(0.25, std::min(7.8, atof(e)));
     Pool P;
@@ -328,6 +338,14 @@ int build_mini_dev(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64
     hipLaunchKernelGGL(starts_kernel, dim3(blocks_for(nv)), dim3(256), 0, 0, newd, newg, dIdx1, gIdx1, nv, dStart, gStartD);
     SS_D(hipMemcpy(dStart + n_dist, &nv, 4, hipMemcpyHostToDevice));
     SS_D(hipMemcpy(gStartD + n_groups, &n_dist, 4, hipMemcpyHostToDevice));
+    {
+        unsigned long long *d_small = reinterpret_cast<unsigned long long *>(gslots), small = 0;      // (scratch: gslots is written next)
+        static_assert(sizeof(unsigned long long) == 8, "two words of gslots");
+        SS_D(hipMemset(d_small, 0, 8));
+        hipLaunchKernelGGL(small_groups_kernel, dim3(blocks_for(n_groups)), dim3(256), 0, 0, gStartD, n_groups, d_small);
+        SS_D(hipMemcpy(&small, d_small, 8, hipMemcpyDeviceToHost));
+        inline_max = choose_inline_max(small, n_dist);
+    }
     hipLaunchKernelGGL(group_sizes_kernel, dim3(blocks_for(n_groups)), dim3(256), 0, 0, gStartD, n_groups, inline_max, gslots, gitems);
     SS_D(hipMemset(gslots + n_groups, 0, 4));
     SS_D(hipMemset(gitems + n_groups, 0, 4));

@@ -912,7 +912,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     unsigned nthreads = std::min<unsigned>(ss::host_cpus(), 32u);
     if (const char *e = getenv("SS_BUILD_THREADS")) nthreads = (unsigned)std::max(1, std::min(64, atoi(e)));   // tests: the image must not depend on it
     uint32_t inline_max = 2;                        // minimizers with at most this many database k-mers keep them in page slots
-    if (const char *e = getenv("SS_INLINE_MAX")) inline_max = (uint32_t)std::max(0, std::min(8, atoi(e)));
+                                                    // (decided below, once the minimizers' sizes are known: choose_inline_max)
     double lambda = 2.0;                            // page items per page on average (eight slots: one page in a thousand full)
     if (const char *e = getenv("SS_PAGE_LAMBDA")) lambda = std::max(0.25, std::min(7.8, atof(e)));   // < 8: the pages must hold all items
     // 1. entries of valid rows with their minimizer
@@ -995,6 +995,15 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
             i = e;
         }
     };
+    {
+        std::atomic<uint64_t> small_a(0), all_a(0);
+        for_partitions([&](int p) {
+            uint64_t sm = 0, al = 0;
+            walk(p, [&](uint64_t, uint64_t, uint32_t nd) { al += nd; if (nd <= 2) sm += nd; });
+            small_a += sm; all_a += al;
+        });
+        inline_max = choose_inline_max(small_a.load(), all_a.load());
+    }
     for_partitions([&](int p) {
         uint64_t ns_ = 0, ni = 0, nm = 0;
         walk(p, [&](uint64_t, uint64_t, uint32_t nd) {

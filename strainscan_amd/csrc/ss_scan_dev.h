@@ -1,6 +1,7 @@
 // Device helpers shared by the scan kernels (flat table: ss_scan.hip, minimizer buckets: ss_mini.hip).
 #pragma once
 #include "ss_common.h"
+#include <stdlib.h>
 
 namespace ss {
 
@@ -62,6 +63,16 @@ constexpr uint32_t START_MASK = 0x3FFFFFFFu;
 // range, and the k-mer of offset o + 1 is the k-mer of offset o moved one base to the left: its k-mers are one stretch of
 // cnt + 30 bases (a super-k-mer), and a run of a read is verified against that stretch by ONE lane (ss_mini.hip phase 3a)
 constexpr uint32_t PG_SOLID = 1u << 30;
+// How many database k-mers of one minimizer are kept INLINE in page slots (more go to a bucket).  Two, where a table's
+// minimizers mostly own one or two k-mers (the sampled node sets of a tree: one sector answers a lookup); NONE, where such
+// minimizers are the exception (every k-mer of a genome: 3 % of them) -- there an inline k-mer's hit is an atomic of its own,
+// one (instruction, line) request per hit, while a bucket's hits share lines and, in a cluster scan, the LDS counters: the
+// cluster scan 7.4 -> 6.5 ms without inline k-mers, a contiguous tree table unchanged (round 4).  SS_INLINE_MAX overrides.
+inline uint32_t choose_inline_max(uint64_t kmers_of_small_minimizers /* <= 2 k-mers */, uint64_t n_distinct)
+{
+    if (const char *e = getenv("SS_INLINE_MAX")) { const int v = atoi(e); return (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }
+    return kmers_of_small_minimizers * 8 < n_distinct ? 0u : 2u;
+}
 // the 16 bases of a k-mer that are not its minimizer: rotate the 62-bit key right by 2 * offset (the minimizer
 // comes to stand in bits 0..29), the upper 32 bits = bases behind the minimizer, then the bases in front of it
 __host__ __device__ __forceinline__ uint32_t flank_of_key(uint64_t key, uint32_t off)
