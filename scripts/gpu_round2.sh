@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${TAG:-sampled}; O=$R/gpurun_out/r2/$TAG; mkdi
 A="${BENCH_ARGS:-}"
 timeout 900 python bench.py $A ${BENCH_EXTRA:-} > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err | cut -c1-200; cut -c1-400 $O/bench.json
 export TMPDIR=/tmp; cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o scan -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-phases --no-readset $A > $O/prof_bench.json 2> $O/prof_bench.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o scan -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-phases --no-readset --no-config3 $A > $O/prof_bench.json 2> $O/prof_bench.err
 f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { cp $f $O/kernel_stats.csv; head -8 $f | cut -c1-160; }
 pmc() {  # name, counters, extra bench args
-  timeout 600 rocprofv3 --pmc $2 --output-format csv -d $O/pmc_$1 -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-phases --no-readset $A $3 > /dev/null 2> $O/pmc_$1.err
+  timeout 600 rocprofv3 --pmc $2 --output-format csv -d $O/pmc_$1 -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-phases --no-readset --no-config3 $A $3 > /dev/null 2> $O/pmc_$1.err
 }
 pmc fetch FETCH_SIZE ""
 pmc write WRITE_SIZE ""

@@ -20,7 +20,7 @@ for d in sorted(glob.glob(os.path.join(O, "pmc_*"))):
             kn = r.get("Kernel_Name", "")
             if "anonymous namespace" not in kn or "at::native" in kn:
                 continue
-            short = kn.split("::")[-1].split("(")[0][:48]
+            short = kn.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1][:48]
             k = (short, r["Counter_Name"])
             acc[k][0] += 1
             acc[k][1] += float(r["Counter_Value"])

@@ -85,13 +85,15 @@ __global__ void starts_kernel(const uint32_t *__restrict__ newd, const uint32_t 
     if (newg[j]) gStartD[gIdx1[j] - 1] = dIdx1[j] - 1;
 }
 
-// k-mers of the minimizers that own one or two (choose_inline_max)
-__global__ void small_groups_kernel(const uint32_t *__restrict__ gStartD, uint32_t n_groups, unsigned long long *__restrict__ out)
+// k-mers of the minimizers that own one or two (choose_inline_max); a grid of a few hundred workgroups strides over the
+// groups: one atomic per wave on ONE word is cheap only when the waves are few
+__global__ __launch_bounds__(256) void small_groups_kernel(const uint32_t *__restrict__ gStartD, uint32_t n_groups, unsigned long long *__restrict__ out)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nd = g < n_groups ? gStartD[g + 1] - gStartD[g] : 0u;
-    const uint32_t mine = nd <= 2u ? nd : 0u;
-    unsigned long long sum = mine;
+    unsigned long long sum = 0;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t nd = gStartD[g + 1] - gStartD[g];
+        sum += nd <= 2u ? nd : 0u;
+    }
     for (int o = 32; o; o >>= 1) sum += __shfl_down(sum, o, 64);
     if ((threadIdx.x & 63) == 0 && sum) atomicAdd(out, sum);
 }
@@ -342,7 +344,7 @@ int build_mini_dev(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64
         unsigned long long *d_small = reinterpret_cast<unsigned long long *>(gslots), small = 0;      // (scratch: gslots is written next)
         static_assert(sizeof(unsigned long long) == 8, "two words of gslots");
         SS_D(hipMemset(d_small, 0, 8));
-        hipLaunchKernelGGL(small_groups_kernel, dim3(blocks_for(n_groups)), dim3(256), 0, 0, gStartD, n_groups, d_small);
+        hipLaunchKernelGGL(small_groups_kernel, dim3(std::min<unsigned>(blocks_for(n_groups), 512u)), dim3(256), 0, 0, gStartD, n_groups, d_small);
         SS_D(hipMemcpy(&small, d_small, 8, hipMemcpyDeviceToHost));
         inline_max = choose_inline_max(small, n_dist);
     }
