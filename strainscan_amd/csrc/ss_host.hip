@@ -258,6 +258,38 @@ struct MT19937 {
     }
 };
 
+// Word buffers of the splits (swap partners, the permutation itself), kept between splits AND between calls: a fresh 20 MB
+// vector per split is zero-filled and page-faulted in by whoever touches it first -- 40 such buffers per call were a third of the
+// generator thread's time.  At most 24 buffers / 512 MB stay pooled (SS_SPLIT_POOL=0: fresh zeroed buffers, for A/B).
+struct WordPool {
+    std::mutex mu;
+    std::vector<std::pair<uint32_t *, uint64_t>> free_;
+    static bool pooled() { static const bool p = !(getenv("SS_SPLIT_POOL") && !atoi(getenv("SS_SPLIT_POOL"))); return p; }      // (A/B)
+    uint32_t *get(uint64_t n)
+    {
+        if (!pooled()) return static_cast<uint32_t *>(calloc(std::max<uint64_t>(n, 1), sizeof(uint32_t)));
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].second >= n) { uint32_t *p = free_[i].first; free_.erase(free_.begin() + (long)i); return p; }
+        }
+        return static_cast<uint32_t *>(malloc(std::max<uint64_t>(n, 1) * sizeof(uint32_t)));
+    }
+    void put(uint32_t *p, uint64_t n)
+    {
+        if (!p) return;
+        if (!pooled()) { free(p); return; }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            uint64_t held = 0;
+            for (auto &f : free_) held += f.second;
+            if (free_.size() < 24 && (held + n) * sizeof(uint32_t) <= (512ull << 20)) { free_.emplace_back(p, n); return; }
+        }
+        free(p);
+    }
+};
+WordPool g_words;
+
 // the generator on a thread of its own: blocks of 624 x 32 tempered words in a ring, consumed in order
 struct MTStream {
     static constexpr int NB = 8, BLK = 624 * 32;
@@ -318,10 +350,8 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
             pool[(size_t)f - in_flight].join();
             t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
-        std::vector<uint32_t> *js = new (std::nothrow) std::vector<uint32_t>();
-        if (js) { try { js->resize(n); } catch (...) { delete js; js = nullptr; } }
-        if (!js) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); continue; }
-        uint32_t *J = js->data();
+        uint32_t *J = g_words.get(n);              // (every entry from n - 1 down to 1 is written below)
+        if (!J) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); continue; }
         for (uint64_t hi = n - 1; hi >= 1;) {                                         // the generator, in stream order
             // all i in (mask >> 1, hi] share the mask: the next power of two above i, minus one
             uint32_t mask = (uint32_t)hi;
@@ -346,13 +376,11 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
             }
             hi = lo - 1;
         }
-        pool[(size_t)f] = std::thread([js, n, n_test, f, bits, &err] {
-            std::vector<uint32_t> x;
-            try { x.resize(n); } catch (...) { err = SS_ENOMEM; delete js; return; }
-            for (uint64_t i = 0; i < n; i++) x[i] = (uint32_t)i;
-            const uint32_t *J = js->data();
+        pool[(size_t)f] = std::thread([J, n, n_test, f, bits, &err] {
+            uint32_t *xp = g_words.get(n);
+            if (!xp) { err = SS_ENOMEM; g_words.put(J, n); return; }
+            for (uint64_t i = 0; i < n; i++) xp[i] = (uint32_t)i;
             // (the partners are known ahead: their cache lines are requested 24 swaps early -- 20 MB of x do not fit L2)
-            uint32_t *xp = x.data();
             for (uint64_t i = n - 1; i >= 1; i--) {
                 if (i > 24) __builtin_prefetch(&xp[J[i - 24]], 1, 1);
                 const uint32_t j = J[i], a = xp[i];
@@ -360,8 +388,9 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
                 xp[j] = a;
             }
             const uint32_t bit = 1u << f;
-            for (uint64_t i = 0; i < n_test; i++) __atomic_fetch_or(&bits[x[i]], bit, __ATOMIC_RELAXED);
-            delete js;
+            for (uint64_t i = 0; i < n_test; i++) __atomic_fetch_or(&bits[xp[i]], bit, __ATOMIC_RELAXED);
+            g_words.put(xp, n);
+            g_words.put(J, n);
         });
     }
     const double t_gen = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
