@@ -798,7 +798,7 @@ def main(argv=None):
     # FILE order.  Binning is paid once per sample at load time; it is timed here (wall clock, allocations included).
     readset = None
     if not args.no_readset and not args.calib_stream:
-        prep = []
+        prep, prep_parts = [], []
         rs_all = []
         for _ in range(5):                          # first call: first touch of 3 GB of fresh device memory
             # (the five sets stay alive until all are made: freeing a 3 GB slab right before the next one is allocated --
@@ -808,6 +808,9 @@ def main(argv=None):
             rs_all.append(_lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True))
             torch.cuda.synchronize()
             prep.append((time.perf_counter() - t1) * 1e3)
+            parts = np.zeros(3)
+            _lib.check(_lib.lib().ss_reads_order_timing(_lib.ptr(parts)), "ss_reads_order_timing")
+            prep_parts.append(parts)
         rs_loc = rs_all.pop()
         for r_ in rs_all:
             r_.close()
@@ -849,7 +852,9 @@ def main(argv=None):
             dt2 = float(tt.item())
         k2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
         readset = dict(order="locality (records binned by the minimizer of their first k-mer, ~4 records per bin: ss_reorder.hip)",
-                       prepare_ms=round(prep_ms, 2), prepare_ms_best=round(float(np.min(prep)), 2), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
+                       prepare_ms=round(prep_ms, 2), prepare_ms_best=round(float(np.min(prep)), 2),
+                       prepare_breakdown_ms=dict(zip(("count_and_prefix", "slab_allocation", "place"), [round(float(x), 2) for x in np.median(np.array(prep_parts), axis=0)]),
+                                                 note="medians of the five calls; slab_allocation is the driver's hipMalloc of the 3 GB output slab"), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
                        value=round(args.reads * world * args.steps / dt2 / 1e6, 3), unit="M reads/s", kernel_ms=round(k2, 3),
                        frac_algorithmic=round(args.reads * BYTES_PER_READ / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                        node_stats_equal=bool(torch.equal(stats, stats2)),

@@ -233,6 +233,9 @@ int ss_ingest_warm_up(void);
 /* A resident read set from a flat base block that is already on the device (copied; order != 0: its records are put
  * in locality order, see below). */
 int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads **out);
+/* Where the last binning of a read set spent its time, in ms: out[0] count pass + prefix over the bins, out[1] the driver's
+ * allocation of the new slab (0.3 ms, or 60-90 ms for 3 GB on a box whose driver clears the memory first), out[2] place pass. */
+int ss_reads_order_timing(double out_ms[3]);
 /* The resident flat blocks copied back to the host, slab after slab (host = NULL: only *len); for tests and debugging. */
 int ss_reads_read_back(const ss_reads *r, char *host, uint64_t cap, uint64_t *len);
 int ss_reads_destroy(ss_reads *r);

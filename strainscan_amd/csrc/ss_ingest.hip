@@ -782,6 +782,13 @@ int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads
     return SS_OK;
 }
 
+int ss_reads_order_timing(double out_ms[3])
+{
+    if (!out_ms) return SS_EINVAL;
+    ss::reorder_timing(out_ms);
+    return SS_OK;
+}
+
 int ss_reads_read_back(const ss_reads *R, char *host, uint64_t cap, uint64_t *len)
 {
     if (!R || !len) return SS_EINVAL;

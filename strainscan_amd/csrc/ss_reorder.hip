@@ -512,6 +512,7 @@ int order_bits(uint64_t n_bytes)
 namespace ss {
 
 static std::mutex g_scr_mu;
+static double g_order_ms[3] = {0, 0, 0};      // the last order_flat_dev: count + prefix, allocation of the new slab, place
 static char *g_scr = nullptr;            // the scratch of the last call (bin cursors, per-tile record tables), kept for the next
 static uint64_t g_scr_cap = 0;
 
@@ -555,8 +556,10 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     SS_R(hipMemcpy(tail, d_hist + n_bins, 16, hipMemcpyDeviceToHost));
     const unsigned long long total = tail[0];
     lap("count + prefix");
+    const auto t_counted = std::chrono::steady_clock::now();
     const uint64_t cap = std::max<uint64_t>((total + 15) & ~15ull, 16);
     SS_R(hipMalloc((void **)&d_new, cap));
+    const auto t_alloc = std::chrono::steady_clock::now();
     lap("new slab");
     hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), pad2, 0, src, n, d_hist, d_cnt, d_tab, d_new);
     if (tail[1]) hipLaunchKernelGGL(place_again_kernel, dim3(nb), dim3(256), 0, 0, src, n, bits, d_hist, d_cnt, d_new);
@@ -564,6 +567,14 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     SS_R(hipGetLastError());
     SS_R(hipDeviceSynchronize());
     lap("place");
+    {
+        // where the call's time went (ss_reads_order_timing): the driver's allocation of the new slab is not the kernels' time,
+        // and on some boxes a fresh 3 GB allocation takes 60-90 ms
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::lock_guard<std::mutex> g(g_scr_mu);
+        g_order_ms[0] = ms(t_begin, t_counted); g_order_ms[1] = ms(t_counted, t_alloc); g_order_ms[2] = ms(t_alloc, t_end);
+    }
 #undef SS_R
     {
         std::lock_guard<std::mutex> g(g_scr_mu);
@@ -572,6 +583,12 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     if (d_scr) hipFree(d_scr);
     *out_d = d_new; *out_used = cap; *out_cap = cap;
     return SS_OK;
+}
+
+void reorder_timing(double out[3])
+{
+    std::lock_guard<std::mutex> g(g_scr_mu);
+    for (int i = 0; i < 3; i++) out[i] = g_order_ms[i];
 }
 
 void reorder_release()
