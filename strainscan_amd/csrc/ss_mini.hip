@@ -106,6 +106,12 @@ struct Ent {
 //            references go to q2
 //   phase 3  16 lanes per found bucket, one per position: candidate slot from the run's offset mask
 //            -> 64-bit compare -> atomicAdd
+// Round 4, template switches of the same kernel:
+//   COMB     tables that expect hits (ss_db_expect_hits: a layer-2 cluster table) scanned by a BINNED read set: a workgroup
+//            takes four consecutive tiles, hits are added up in an LDS table keyed by the bucket (QComb) and flushed with one
+//            atomic per non-zero counter; found runs of SOLID buckets (PG_SOLID) are verified by one lane each (phase 3a),
+//            the others by 16 lanes (3b)
+//   MULTI    up to four tables in one pass (ss_scan_reads_multi): phases 0-1b once per tile, phases 2-3 per table
 // ---------------------------------------------------------------------------------------------
 // threads per workgroup of this kernel = one wave
 #ifndef SS_NT
