@@ -1299,6 +1299,19 @@ Arena *arena_get(uint64_t cap_chunks, uint64_t sym_elems)
     if (!ok) { arena_destroy(a); return nullptr; }
     return a;
 }
+// a waiting arena that needs no allocation for this call (then nothing has to ask the driver how much memory is left: 1-2 ms)
+Arena *arena_take_if_fits(uint64_t cap_chunks, uint64_t sym_elems, uint64_t text_cap)
+{
+    std::lock_guard<std::mutex> g(g_arena_mu);
+    for (size_t i = g_arena_free.size(); i-- > 0;) {
+        Arena *a = g_arena_free[i];
+        if (a->cap_chunks >= cap_chunks && a->sym_elems >= sym_elems && a->text_cap >= text_cap) {
+            g_arena_free.erase(g_arena_free.begin() + (long)i);
+            return a;
+        }
+    }
+    return nullptr;
+}
 void arena_put(Arena *a)
 {
     if (!a) return;
@@ -1311,16 +1324,26 @@ void arena_put(Arena *a)
 }
 
 // A large file image on its way to the device: copied out of a mapping of the page cache the runtime faults the pages in
-// one by one (8 GB/s); four threads that pread() 32 MB blocks into pinned buffers of their own and ship them on streams of
-// their own do ~25 GB/s.  The pinned buffers (128 MB a set, at most two sets) are kept like the arenas.
-constexpr uint64_t PIN_BYTES = 32ull << 20;
-constexpr int PIN_N = 4;      // threads = buffers of a set
-struct PinSet { uint8_t *b[PIN_N] = {nullptr, nullptr, nullptr, nullptr}; };
+// one by one (8 GB/s); eight threads that pread() blocks of a few MB into pinned buffers of their own and ship them on streams
+// of their own do ~25 GB/s.  The pinned buffers (128 MB a set, at most two sets) are kept like the arenas.
+constexpr uint64_t PIN_BYTES = 16ull << 20;
+constexpr int PIN_N = 8;      // threads = buffers of a set (128 MB a set); each with a stream and two events of its own, made
+                              // with the set (a stream costs 2-3 ms to make: as much as the upload of 30 MB)
+struct PinSet
+{
+    uint8_t *b[PIN_N] = {};
+    hipStream_t s[PIN_N] = {};
+    hipEvent_t ev[PIN_N][2] = {};
+};
 std::vector<PinSet *> g_pin_free;
 void pin_destroy(PinSet *p)
 {
     if (!p) return;
-    for (int i = 0; i < PIN_N; i++) if (p->b[i]) hipHostFree(p->b[i]);
+    for (int i = 0; i < PIN_N; i++) {
+        if (p->s[i]) { hipStreamSynchronize(p->s[i]); hipStreamDestroy(p->s[i]); }
+        for (int q = 0; q < 2; q++) if (p->ev[i][q]) hipEventDestroy(p->ev[i][q]);
+        if (p->b[i]) hipHostFree(p->b[i]);
+    }
     delete p;
 }
 PinSet *pin_get()
@@ -1331,8 +1354,19 @@ PinSet *pin_get()
     }
     PinSet *p = new (std::nothrow) PinSet();
     if (!p) return nullptr;
+    int device = 0;
+    hipGetDevice(&device);
+    std::atomic<int> bad(0);
+    std::vector<std::thread> th;                              // (~10 ms a buffer, ~3-13 ms a stream: all at the same time)
     for (int i = 0; i < PIN_N; i++)
-        if (hipHostMalloc((void **)&p->b[i], PIN_BYTES, hipHostMallocDefault) != hipSuccess) { pin_destroy(p); return nullptr; }
+        th.emplace_back([p, i, device, &bad] {
+            if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void **)&p->b[i], PIN_BYTES, hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&p->ev[i][0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev[i][1], hipEventDisableTiming) != hipSuccess)
+                bad = 1;
+        });
+    for (auto &t : th) t.join();
+    if (bad) { pin_destroy(p); return nullptr; }
     return p;
 }
 bool pin_waiting()
@@ -1353,8 +1387,14 @@ void pin_put(PinSet *p)
 // has grown -- the caller starts work on it while the rest is still on its way.
 bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uint64_t)> &ready = nullptr)
 {
+    static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3; };
     PinSet *pins = pin_get();
     if (!pins) return false;
+    const double t_pins = since();
+    std::atomic<int> streams_up(0);
+    double t_streams = 0, t_first = 0;
     int device = 0;
     hipGetDevice(&device);
     std::atomic<uint64_t> next(0);
@@ -1372,17 +1412,17 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
         done[(size_t)b] = 1;
         const uint64_t before = prefix;
         while (prefix < n_blocks && done[(size_t)prefix]) prefix++;
+        if (trace && before == 0 && prefix) t_first = since();
         if (prefix != before && ready) ready(std::min(n, prefix * blk));
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < PIN_N; t++)
+    static const int n_threads = getenv("SS_GZ_UPLOAD_THREADS") ? std::max(1, std::min(PIN_N, atoi(getenv("SS_GZ_UPLOAD_THREADS")))) : PIN_N;
+    for (int t = 0; t < n_threads; t++)
         pool.emplace_back([&, t] {
-            hipStream_t s2 = nullptr;
-            hipEvent_t ev[2] = {nullptr, nullptr};
-            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
-                failed = 1;
-            }
+            hipStream_t s2 = pins->s[t];
+            hipEvent_t *ev = pins->ev[t];
+            if (hipSetDevice(device) != hipSuccess) failed = 1;
+            if (trace && streams_up.fetch_add(1) + 1 == n_threads) t_streams = since();
             int64_t in_flight[2] = {-1, -1};                  // the block whose copy was last issued from each half
             int h = 0;
             for (uint64_t b; !failed && (b = next.fetch_add(1)) < n_blocks; h ^= 1) {
@@ -1410,11 +1450,13 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
                     else finished((uint64_t)in_flight[hh]);
                 }
             }
-            if (s2) { hipStreamSynchronize(s2); hipStreamDestroy(s2); }
-            for (int q = 0; q < 2; q++) if (ev[q]) hipEventDestroy(ev[q]);
+            hipStreamSynchronize(s2);                       // (a failure may leave a copy in flight: the buffers go back to the pool)
         });
     for (auto &th : pool) th.join();
     pin_put(pins);
+    if (trace)
+        fprintf(stderr, "[ginflate] upload: %llu blocks of %.1f MB; buffers %.2f ms, threads up %.2f, first block %.2f, all %.2f\n", (unsigned long long)n_blocks,
+                blk / 1048576.0, t_pins, t_streams, t_first, since());
     return !failed;
 }
 
@@ -1430,6 +1472,36 @@ static std::atomic<uint64_t> g_handled{0}, g_declined{0}, g_range_files{0}, g_ra
 std::atomic<long long> g_hook_entry{0}, g_hook_decline{0}, g_hook_skip_chain{0};
 
 void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
+
+// The streams of the calls, kept (making one and destroying it was 0.6 ms of every call), and the stream-ordered allocator
+// told to keep what a call frees (SS_GZ_POOL_KEEP_MB, 1 GB) instead of handing it back to the driver at the next synchronisation.
+static std::vector<hipStream_t> g_stream_free;
+static hipStream_t call_stream_get()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int device = 0;
+        hipMemPool_t pool = nullptr;
+        uint64_t keep = (getenv("SS_GZ_POOL_KEEP_MB") ? (uint64_t)atoll(getenv("SS_GZ_POOL_KEEP_MB")) : 1024ull) << 20;
+        if (hipGetDevice(&device) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess)
+            hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    });
+    {
+        std::lock_guard<std::mutex> g(g_arena_mu);
+        if (!g_stream_free.empty()) { hipStream_t s = g_stream_free.back(); g_stream_free.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
+}
+static void call_stream_put(hipStream_t s)                   // (synchronised by the caller)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> g(g_arena_mu);
+        if (g_stream_free.size() < 4) { g_stream_free.push_back(s); return; }
+    }
+    hipStreamDestroy(s);
+}
 
 // ---- several ranks share ONE gzip member (ss_gz_set_range) -------------------------------------------------------------------
 // The deflate data is cut into slices of `slice_chunks` search chunks; slice s belongs to rank s mod world.  A rank looks
@@ -1534,9 +1606,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     // own stream: the two mates of a paired sample are inflated by two host threads, and the legacy default stream would
     // serialise them
-    hipStream_t st = nullptr;
-    const bool have_stream = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;      // (checked once the slices are known:
-    if (!have_stream) st = nullptr;                                                                     //  a rank that fails here still serves the chain)
+    hipStream_t st = call_stream_get();
+    const bool have_stream = st != nullptr;                  // (checked once the slices are known: a rank that fails here still serves the chain)
     const auto t_begin = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!trace) return;
@@ -1555,8 +1626,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         const double c1 = now();
         hipStreamSynchronize(st);
         const double c2 = now();
-        if (st) hipStreamDestroy(st);
-        if (trace) fprintf(stderr, "[ginflate] cleanup: free %.4f, sync %.4f, stream destroy %.4f s\n", c1 - c0, c2 - c1, now() - c2);
+        call_stream_put(st);
+        if (trace) fprintf(stderr, "[ginflate] cleanup: free %.4f, sync %.4f, stream back %.4f s\n", c1 - c0, c2 - c1, now() - c2);
         if (!keep_text) { arena_put(A); A = nullptr; }            // (else the caller holds it, with the text, until gpu_gunzip_done)
     };
     auto no = [&](const char *why, long long a = 0) {
@@ -1625,6 +1696,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
         GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
         GI(hipStreamSynchronize(st));                         // the allocations are stream-ordered
+        lap("stage allocated");
         // the sync search runs on the prefix of the image that has arrived (a candidate's probe reads a few KB beyond its chunk)
         static const bool pipelined = !(getenv("SS_GZ_PIPELINE") && !atoi(getenv("SS_GZ_PIPELINE")));
         const uint64_t margin = 64 << 10;
@@ -1632,7 +1704,11 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             if (!pipelined || !bgzf.empty()) return;
             // (runs on an upload thread, which has set the device; calls are serialised by upload_file)
             const uint64_t usable = ready >= in_n ? in_n : (ready > margin + data_off ? ready - margin - data_off : 0);
-            search_to(ready >= in_n ? n_chunks0 : (uint32_t)std::min<uint64_t>(n_chunks0, usable / chunk_bytes));
+            // in pieces of a quarter of the file: a piece takes as long as its slowest chunk (one wave each, ~0.6 ms) and the
+            // pieces of a stream run one after another -- sixteen of them finished 6 ms after the last block had arrived
+            static const uint32_t pieces = getenv("SS_GZ_PIECES") ? (uint32_t)std::max(1, atoi(getenv("SS_GZ_PIECES"))) : 4;
+            const uint32_t c_hi = ready >= in_n ? n_chunks0 : (uint32_t)std::min<uint64_t>(n_chunks0, usable / chunk_bytes);
+            if (c_hi == n_chunks0 || c_hi >= c_searched + (n_chunks0 + pieces - 1) / pieces) search_to(c_hi);
         });
         if (!uploaded) c_searched = 0;                         // (the image is copied again below: search everything)
     }
@@ -1813,12 +1889,15 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         while (guess < in_n) guess += 1ull << 32;
         text_cap = (guess <= 16 * in_n ? guess : 3 * in_n) + 64;
         if (rr) text_cap = text_cap / rr->n_slices * rr->mine.size() * 13 / 10 + (1ull << 20);      // this rank's share (it grows when short)
-        size_t mem_free = 0, mem_total = 0;
-        GI(hipMemGetInfo(&mem_free, &mem_total));
-        const uint64_t need = 2 * text_cap + sym_elems * 2 + cap_chunks * WSIZE * 5 + (256ull << 20);
-        if (need > mem_free / 2) return no("device memory", (long long)(need >> 20));
+        A = arena_take_if_fits(cap_chunks, sym_elems, text_cap);
+        if (!A) {
+            size_t mem_free = 0, mem_total = 0;
+            GI(hipMemGetInfo(&mem_free, &mem_total));
+            const uint64_t need = 2 * text_cap + sym_elems * 2 + cap_chunks * WSIZE * 5 + (256ull << 20);
+            if (need > mem_free / 2) return no("device memory", (long long)(need >> 20));
+        }
     }
-    A = arena_get(cap_chunks, sym_elems);
+    if (!A) A = arena_get(cap_chunks, sym_elems);
     if (!A) return no("scratch");
     if (A->text_cap < text_cap) {
         if (A->text) hipFree(A->text);
@@ -2330,6 +2409,12 @@ extern "C" int ss_gz_gpu_release(void)
         pins.swap(g_pin_free);
     }
     for (PinSet *p : pins) pin_destroy(p);
+    std::vector<hipStream_t> streams;
+    {
+        std::lock_guard<std::mutex> g(g_arena_mu);
+        streams.swap(ss::g_stream_free);
+    }
+    for (hipStream_t q : streams) hipStreamDestroy(q);
     ss::reorder_release();
     return SS_OK;
 }
