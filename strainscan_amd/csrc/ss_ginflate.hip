@@ -1402,7 +1402,8 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
     // every thread's pinned buffer is used in two halves: the copy of one block travels while the next is read.  Blocks
     // of 1/16 of the file (2 MB .. half a buffer), handed out in order, so that the prefix grows steadily
     const uint64_t half = PIN_BYTES / 2;
-    const uint64_t blk = std::min<uint64_t>(half, std::max<uint64_t>(2ull << 20, ((n / 16) + (1ull << 20) - 1) & ~((1ull << 20) - 1)));
+    const uint64_t div = getenv("SS_GZ_UPLOAD_DIV") ? (uint64_t)std::max(1, atoi(getenv("SS_GZ_UPLOAD_DIV"))) : 16;
+    const uint64_t blk = std::min<uint64_t>(half, std::max<uint64_t>(2ull << 20, ((n / div) + (1ull << 20) - 1) & ~((1ull << 20) - 1)));
     const uint64_t n_blocks = (n + blk - 1) / blk;
     std::vector<uint8_t> done((size_t)n_blocks, 0);
     std::mutex mu;
@@ -1416,7 +1417,7 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
         if (prefix != before && ready) ready(std::min(n, prefix * blk));
     };
     std::vector<std::thread> pool;
-    static const int n_threads = getenv("SS_GZ_UPLOAD_THREADS") ? std::max(1, std::min(PIN_N, atoi(getenv("SS_GZ_UPLOAD_THREADS")))) : PIN_N;
+    const int n_threads = getenv("SS_GZ_UPLOAD_THREADS") ? std::max(1, std::min(PIN_N, atoi(getenv("SS_GZ_UPLOAD_THREADS")))) : PIN_N;
     for (int t = 0; t < n_threads; t++)
         pool.emplace_back([&, t] {
             hipStream_t s2 = pins->s[t];
@@ -1430,6 +1431,10 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
                     if (hipEventSynchronize(ev[h]) != hipSuccess) { failed = 1; break; }
                     finished((uint64_t)in_flight[h]);
                     in_flight[h] = -1;
+                }
+                if (in_flight[h ^ 1] >= 0 && hipEventQuery(ev[h ^ 1]) == hipSuccess) {      // (the other half's: reported as soon as it is seen,
+                    finished((uint64_t)in_flight[h ^ 1]);                                     //  the caller works on the prefix that has arrived)
+                    in_flight[h ^ 1] = -1;
                 }
                 const uint64_t a = b * blk, len = std::min<uint64_t>(blk, n - a);
                 uint8_t *buf = pins->b[t] + (uint64_t)h * half;
@@ -1704,11 +1709,16 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             if (!pipelined || !bgzf.empty()) return;
             // (runs on an upload thread, which has set the device; calls are serialised by upload_file)
             const uint64_t usable = ready >= in_n ? in_n : (ready > margin + data_off ? ready - margin - data_off : 0);
-            // in pieces of a quarter of the file: a piece takes as long as its slowest chunk (one wave each, ~0.6 ms) and the
-            // pieces of a stream run one after another -- sixteen of them finished 6 ms after the last block had arrived
-            static const uint32_t pieces = getenv("SS_GZ_PIECES") ? (uint32_t)std::max(1, atoi(getenv("SS_GZ_PIECES"))) : 4;
+            // SS_GZ_PIECES > 1: the search starts on the prefix that has arrived, in that many pieces.  Measured (26 loads of each
+            // setting interleaved in one process, a pair of 66 MB files): 1 piece -- upload, then search -- 26.0 ms, 2 pieces 26.3,
+            // 4 pieces 27.0, 8 pieces 28.4: the search is bound by the chip's throughput (4.5 ms for the pair), a piece takes as
+            // long as its slowest chunk, and the pieces of a stream run one after another.  So: off.
+            const uint32_t pieces = getenv("SS_GZ_PIECES") ? (uint32_t)std::max(1, atoi(getenv("SS_GZ_PIECES"))) : 1;
             const uint32_t c_hi = ready >= in_n ? n_chunks0 : (uint32_t)std::min<uint64_t>(n_chunks0, usable / chunk_bytes);
-            if (c_hi == n_chunks0 || c_hi >= c_searched + (n_chunks0 + pieces - 1) / pieces) search_to(c_hi);
+            if (c_hi == n_chunks0 || c_hi >= c_searched + (n_chunks0 + pieces - 1) / pieces) {
+                if (trace) fprintf(stderr, "[ginflate] search to chunk %u of %u at %.4f s\n", c_hi, n_chunks0, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+                search_to(c_hi);
+            }
         });
         if (!uploaded) c_searched = 0;                         // (the image is copied again below: search everything)
     }
