@@ -9,8 +9,14 @@
 
 #include <zlib.h>
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
+#define SS_HOST_X86 1
+#endif
+
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <string>
 #include <chrono>
 #include <thread>
@@ -214,49 +220,72 @@ int ss_memset_dev(void *dst, int byte, uint64_t bytes, void *stream)
 // Restated: MT19937 seeded by init_genrand(seed) (numpy _legacy_seeding for an integer), permutation(n) =
 // Fisher-Yates from the top -- for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j]) -- with
 // random_interval(max) = 32-bit draws masked to the next power of two minus one, redrawn while > max
-// (numpy/random/src/distributions: random_interval; mtrand.pyx: _shuffle_raw).  Three stages on host threads (round 4:
-// the first two were one, 165 ms for 5 M rows): one thread runs the Mersenne Twister and fills a ring of blocks of
-// tempered words; one walks them in stream order (the splits share ONE stream) through the rejection rule -- a chain of
-// two dependent instructions per word, all that is inherently serial here -- and writes the swap partners of a split;
-// worker threads apply the swaps of different splits concurrently (that is where the cache misses are).
+// (numpy/random/src/distributions: random_interval; mtrand.pyx: _shuffle_raw).
+// What the splits share is ONE word stream: where a split's words begin depends on how many draws the splits before it had
+// to repeat.  So one thread walks the stream and only COUNTS (64 words per step on AVX-512 hosts, see reject64_avx512; a
+// compare and an add-with-carry per word elsewhere), and hands every split's worker a snapshot of the generator (22 KB: its
+// state and the block it is in) at the split's first word; the worker goes through the same words again, this time keeping the accepted draws -- a few
+// thousand at a time, in its L1 -- and applies the swaps (the cache misses of a split are its own).  Round 3: one thread did
+// everything, 165 ms for 5 M rows x 20 splits; round 4: generator thread -> rejection thread -> swap threads with 20 MB of swap
+// partners per split between them, 114 ms (bound first by the compare chain, then by the generator's lines crossing between
+// two CCDs and 400 MB of partners going through memory); now 24 ms for the walk + one worker's 12 ms behind it on the
+// GPU boxes' EPYC 9575F (16 CPUs granted).
 // Pinned against numpy itself in tests/test_abi_and_host.py and against sklearn's ShuffleSplit golden.
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct MT19937 {
-    uint32_t mt[624], out[624];
-    int pos;
-    explicit MT19937(uint32_t seed)
-    {
-        mt[0] = seed;
-        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
-        pos = 624;
+// MT19937 as a LINEAR recurrence over a buffer: x[0..623] = the state, x[624 + n] = x[n + 397] ^ twist(x[n], x[n + 1]) -- the
+// in-place generator unrolled; output word n of the stream = temper(x[624 + n]).  A word depends on words 227 and more
+// places behind it, so the loop vectorises; with AVX2 it runs 2.4 x as fast as with the baseline SSE2.
+__attribute__((always_inline)) inline uint32_t mt_temper(uint32_t y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+__attribute__((always_inline)) inline void mt_extend_body(uint32_t *x, int n_new)
+{
+#pragma clang loop vectorize(assume_safety)
+    for (int n = 0; n < n_new; n++) {
+        const uint32_t y = (x[n] & 0x80000000u) | (x[n + 1] & 0x7fffffffu);
+        x[624 + n] = x[n + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
     }
-    void refill()                       // the next 624 words, tempered
-    {
-        auto tw = [](uint32_t u, uint32_t v, uint32_t m) {
-            const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
-            return m ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
-        };
-        int i = 0;
-        for (; i < 624 - 397; i++) mt[i] = tw(mt[i], mt[i + 1], mt[i + 397]);
-        for (; i < 623; i++) mt[i] = tw(mt[i], mt[i + 1], mt[i - (624 - 397)]);
-        mt[623] = tw(mt[623], mt[0], mt[396]);
-        for (i = 0; i < 624; i++) {
-            uint32_t y = mt[i];
-            y ^= y >> 11;
-            y ^= (y << 7) & 0x9d2c5680u;
-            y ^= (y << 15) & 0xefc60000u;
-            y ^= y >> 18;
-            out[i] = y;
-        }
-        pos = 0;
-    }
-    inline uint32_t next()
-    {
-        if (pos == 624) refill();
-        return out[pos++];
-    }
-};
+}
+__attribute__((always_inline)) inline void mt_temper_body(uint32_t *x, int n)
+{
+    for (int i = 0; i < n; i++) x[i] = mt_temper(x[i]);
+}
+#ifdef SS_HOST_X86
+__attribute__((target("avx2"))) void mt_extend_avx2(uint32_t *x, int n_new)
+{
+    // (vector width 8 <= 227: no lane reads what another lane of the same step writes)
+    for (int n0 = 0; n0 < n_new; n0 += 224) mt_extend_body(x + n0, std::min(224, n_new - n0));
+}
+__attribute__((target("avx2"))) void mt_temper_avx2(uint32_t *x, int n) { mt_temper_body(x, n); }
+#endif
+void mt_extend_base(uint32_t *x, int n_new)
+{
+    for (int n0 = 0; n0 < n_new; n0 += 224) mt_extend_body(x + n0, std::min(224, n_new - n0));
+}
+void mt_temper_base(uint32_t *x, int n) { mt_temper_body(x, n); }
+bool host_simd_allowed() { static const bool on = !(getenv("SS_SPLIT_SIMD") && !atoi(getenv("SS_SPLIT_SIMD"))); return on; }      // (A/B)
+void mt_extend(uint32_t *x, int n_new)
+{
+#ifdef SS_HOST_X86
+    static const bool avx2 = __builtin_cpu_supports("avx2") && host_simd_allowed();
+    if (avx2) return mt_extend_avx2(x, n_new);
+#endif
+    mt_extend_base(x, n_new);
+}
+void mt_temper_all(uint32_t *x, int n)
+{
+#ifdef SS_HOST_X86
+    static const bool avx2 = __builtin_cpu_supports("avx2") && host_simd_allowed();
+    if (avx2) return mt_temper_avx2(x, n);
+#endif
+    mt_temper_base(x, n);
+}
 
 // Word buffers of the splits (swap partners, the permutation itself), kept between splits AND between calls: a fresh 20 MB
 // vector per split is zero-filled and page-faulted in by whoever touches it first -- 40 such buffers per call were a third of the
@@ -290,39 +319,167 @@ struct WordPool {
 };
 WordPool g_words;
 
-// the generator on a thread of its own: blocks of 624 x 32 tempered words in a ring, consumed in order
-struct MTStream {
-    static constexpr int NB = 8, BLK = 624 * 32;
-    std::vector<uint32_t> ring;
-    std::atomic<uint64_t> produced{0}, consumed{0};
-    std::atomic<bool> stop{false};
-    std::thread th;
-    explicit MTStream(uint32_t seed) : ring((size_t)NB * BLK)
+// The word stream, generated where it is consumed: 624 x 8 words at a time behind a copy of the 624 words before them, in a
+// buffer that stays in the consumer's L1/L2.  `raw`: the words are handed out UNTEMPERED (the 64-words-per-step consumer tempers
+// them in its vector registers).  Plain data: a copy is a snapshot from which the same words come again.
+struct MTWords {
+    static constexpr int BLK = 624 * 8;
+    uint32_t hist[624];                       // the last 624 words generated, untempered (at first: init_genrand(seed))
+    uint32_t x[624 + BLK];
+    int pos = BLK;                            // next unread word of x + 624 (BLK: the block is used up)
+    bool raw;
+    MTWords(uint32_t seed, bool raw_) : raw(raw_)
     {
-        th = std::thread([this, seed] {
-            MT19937 rng(seed);
-            while (!stop.load(std::memory_order_relaxed)) {
-                const uint64_t p = produced.load(std::memory_order_relaxed);
-                if (p - consumed.load(std::memory_order_acquire) >= (uint64_t)NB) { std::this_thread::yield(); continue; }
-                uint32_t *dst = ring.data() + (p % NB) * BLK;
-                for (int b = 0; b < BLK / 624; b++) {
-                    rng.refill();
-                    memcpy(dst + b * 624, rng.out, 624 * 4);
-                }
-                produced.store(p + 1, std::memory_order_release);
-            }
-        });
+        hist[0] = seed;
+        for (int i = 1; i < 624; i++) hist[i] = 1812433253u * (hist[i - 1] ^ (hist[i - 1] >> 30)) + (uint32_t)i;
     }
-    ~MTStream() { stop = true; th.join(); }
-    // block number `i` (0, 1, 2, ... in order); the block before it is handed back to the producer
-    const uint32_t *block(uint64_t i)
+    // the unread words of the current block (a new block when none is left): at least one, at most BLK
+    const uint32_t *words(int *avail)
     {
-        consumed.store(i, std::memory_order_release);
-        while (produced.load(std::memory_order_acquire) <= i) std::this_thread::yield();
-        return ring.data() + (i % NB) * BLK;
+        if (pos == BLK) {
+            memcpy(x, hist, sizeof(hist));
+            mt_extend(x, BLK);
+            memcpy(hist, x + BLK, sizeof(hist));
+            if (!raw) mt_temper_all(x + 624, BLK);
+            pos = 0;
+        }
+        *avail = BLK - pos;
+        return x + 624 + pos;
     }
 };
 }  // namespace
+
+// The rejection rule over a stretch of the word stream, 64 words per step (AVX-512).  i is the row the next accepted draw
+// belongs to; a draw v is accepted when v <= i.  Within a step i falls by at most 63, so v <= i - 63 is accepted and v > i
+// rejected whatever happened to the words before it -- the dependent chain is ONE count per 64 words instead of a compare and
+// an add-with-carry per word.  A draw inside that band of 63 values (one word in 2^k / 64, k >= 17 here) sends the step to
+// the scalar rule.  The words arrive untempered and are tempered here.  STORE: the accepted draws are written in stream
+// order to out[0 ..] (up to 15 words of slack behind them); otherwise they are only counted.
+// Returns the words consumed (a multiple of 64, <= n_words); *i_io falls by the draws accepted.
+extern "C++" {
+#ifdef SS_HOST_X86
+template <bool STORE>
+__attribute__((target("avx512f,popcnt"))) static int reject64_avx512(const uint32_t *w, int n_words, uint32_t mask, uint32_t *i_io, uint32_t *out)
+{
+    const uint32_t i0 = *i_io;
+    uint32_t c = 0;                                            // draws accepted so far
+    const __m512i vmask = _mm512_set1_epi32((int)mask), t7 = _mm512_set1_epi32((int)0x9d2c5680u), t15 = _mm512_set1_epi32((int)0xefc60000u);
+    int k = 0;
+    for (; k + 64 <= n_words; k += 64) {
+        const uint32_t i = i0 - c;
+        const __m512i hi = _mm512_set1_epi32((int)i), lo = _mm512_set1_epi32((int)(i - 63u));
+        __m512i v[4];
+        __mmask16 a[4];
+        unsigned unsure = 0;
+        for (int q = 0; q < 4; q++) {
+            __m512i y = _mm512_loadu_si512((const void *)(w + k + 16 * q));
+            y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+            y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 7), t7, 0x78);       // a ^ (b & c)
+            y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 15), t15, 0x78);
+            y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+            v[q] = _mm512_and_si512(y, vmask);
+            a[q] = _mm512_cmple_epu32_mask(v[q], lo);
+            unsure |= (unsigned)(a[q] ^ _mm512_cmple_epu32_mask(v[q], hi));
+        }
+        if (__builtin_expect(unsure != 0, 0)) {
+            uint32_t ii = i;
+            for (int q = 0; q < 64; q++) {
+                const uint32_t x = mt_temper(w[k + q]) & mask;
+                if (STORE) out[i0 - ii] = x;
+                ii -= (uint32_t)(x <= ii);
+            }
+            c = i0 - ii;
+            continue;
+        }
+        for (int q = 0; q < 4; q++) {
+            if (STORE) _mm512_storeu_si512((void *)(out + c), _mm512_maskz_compress_epi32(a[q], v[q]));
+            c += (uint32_t)__builtin_popcount((unsigned)a[q]);
+        }
+    }
+    *i_io = i0 - c;
+    return k;
+}
+#endif
+
+namespace {
+// One split's walk over the word stream: permutation(n) = Fisher-Yates from the top, row i = n - 1 .. 1 takes the first draw
+// (masked to the next power of two above i, minus one) that is <= i as its partner.  STORE: the partners go to
+// sink(partners, count) in stream order, a few thousand at a time (`buf`: CH + BLK + 16 words); otherwise the stream is only
+// moved past the split's words -- that is all the splits have in common, the rest of a split's work is its own.
+constexpr uint32_t SPLIT_CH = 2048;
+template <bool STORE, bool SIMD, class Sink>
+void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink)
+{
+    uint32_t fill = 0;
+    for (uint64_t hi = n - 1; hi >= 1;) {
+        // all i in (mask >> 1, hi] share the mask: the next power of two above i, minus one
+        uint32_t mask = (uint32_t)hi;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint64_t lo = (uint64_t)(mask >> 1) + 1;
+        for (uint64_t i = hi; i >= lo;) {
+            // at most `room` words can be consumed before i drops below lo: no bound check on i inside
+            const uint64_t room = i - lo + 1;
+            int avail = 0;
+            const uint32_t *ob = rng.words(&avail);
+            avail = (int)std::min<uint64_t>((uint64_t)avail, room);
+            const int taken = avail;
+            uint32_t ii = (uint32_t)i;
+#ifdef SS_HOST_X86
+            if (SIMD && lo >= 65536 && avail >= 64) {
+                const int used = reject64_avx512<STORE>(ob, avail, mask, &ii, buf + fill);
+                if (STORE) fill += (uint32_t)i - ii;
+                ob += used;
+                avail -= used;
+            }
+#endif
+            // branch-free rejection: every draw is written to its row's place; the row moves on only when the draw is accepted
+            const uint32_t i1 = ii;
+            for (int k = 0; k < avail; k++) {
+                const uint32_t v = (SIMD ? mt_temper(ob[k]) : ob[k]) & mask;
+                if (STORE) buf[fill + (i1 - ii)] = v;
+                ii -= (uint32_t)(v <= ii);
+            }
+            if (STORE) {
+                fill += i1 - ii;
+                if (fill >= SPLIT_CH) { sink((const uint32_t *)buf, fill); fill = 0; }
+            }
+            rng.pos += taken;
+            i = ii;
+            if (ii < (uint32_t)lo) break;           // (only when lo > 0: i is unsigned)
+        }
+        hi = lo - 1;
+    }
+    if (STORE && fill) sink((const uint32_t *)buf, fill);
+}
+
+// the swaps of one split, on a thread of its own, from a snapshot of the stream at the split's first word
+template <bool SIMD>
+int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, int f, uint32_t *bits)
+{
+    uint32_t *xp = g_words.get(n);
+    std::unique_ptr<uint32_t[]> buf(new (std::nothrow) uint32_t[SPLIT_CH + MTWords::BLK + 16]);
+    if (!xp || !buf) { g_words.put(xp, n); return SS_ENOMEM; }
+    static const bool no_swap = getenv("SS_SPLIT_NO_SWAP") != nullptr;      // (timing of everything but the swaps: the result is wrong)
+    for (uint64_t i = 0; i < n; i++) xp[i] = (uint32_t)i;
+    uint64_t i = n - 1;
+    walk_split<true, SIMD>(*rng, n, buf.get(), [&](const uint32_t *p, uint32_t cnt) {
+        if (no_swap) { i -= cnt; return; }
+        // (the partners are known ahead: their cache lines are requested 24 swaps early -- 20 MB of x do not fit L2)
+        for (uint32_t k = 0; k < std::min(24u, cnt); k++) __builtin_prefetch(&xp[p[k]], 1, 1);
+        for (uint32_t k = 0; k < cnt; k++, i--) {
+            if (k + 24 < cnt) __builtin_prefetch(&xp[p[k + 24]], 1, 1);
+            const uint32_t j = p[k], a = xp[i];
+            xp[i] = xp[j];
+            xp[j] = a;
+        }
+    });
+    const uint32_t bit = 1u << f;
+    for (uint64_t q = 0; q < n_test; q++) __atomic_fetch_or(&bits[xp[q]], bit, __ATOMIC_RELAXED);
+    g_words.put(xp, n);
+    return SS_OK;
+}
+}  // namespace
+}  // extern "C++"
 
 int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, uint32_t *bits)
 {
@@ -332,72 +489,45 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         for (uint64_t i = 0; i < n_test; i++) bits[i] = (1u << n_splits) - 1u;      // permutation(1) = [0]
         return SS_OK;
     }
-    MTStream rng(seed);
-    uint64_t blk = 0;
-    const uint32_t *o = rng.block(0);
-    int pos = 0;
-    // swaps of several splits at once: one core each, two stay free for the generator's two threads
+    // swaps of several splits at once: one core each, two stay free
     unsigned in_flight = std::max(1u, std::min(20u, ss::host_cpus() > 3 ? ss::host_cpus() - 2 : 1u));
     if (const char *e = getenv("SS_SPLIT_IN_FLIGHT")) in_flight = (unsigned)std::max(1, atoi(e));
     static const bool trace = getenv("SS_SPLIT_TRACE") != nullptr;
+#ifdef SS_HOST_X86
+    static const bool simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("popcnt") && host_simd_allowed();
+#else
+    static const bool simd = false;
+#endif
     const auto t_begin = std::chrono::steady_clock::now();
     double t_wait = 0;
+    std::unique_ptr<MTWords> rng(new (std::nothrow) MTWords(seed, simd));
+    if (!rng) return SS_ENOMEM;
     std::vector<std::thread> pool((size_t)n_splits);
     std::atomic<int> err(SS_OK);
     for (int f = 0; f < n_splits; f++) {
-        if (f >= (int)in_flight) {                                                   // bounds the memory: in_flight x 8 n bytes
+        if (f >= (int)in_flight) {                                                   // bounds the memory: in_flight x 4 n bytes
             const auto t0 = std::chrono::steady_clock::now();
             pool[(size_t)f - in_flight].join();
             t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
-        uint32_t *J = g_words.get(n);              // (every entry from n - 1 down to 1 is written below)
-        if (!J) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); continue; }
-        for (uint64_t hi = n - 1; hi >= 1;) {                                         // the generator, in stream order
-            // all i in (mask >> 1, hi] share the mask: the next power of two above i, minus one
-            uint32_t mask = (uint32_t)hi;
-            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-            const uint64_t lo = (uint64_t)(mask >> 1) + 1;
-            // branch-free rejection: every draw is written to J[i]; i moves on only when the draw is accepted
-            for (uint64_t i = hi; i >= lo;) {
-                if (pos == MTStream::BLK) { o = rng.block(++blk); pos = 0; }
-                // at most `room` words can be consumed before i drops below lo: no bound check on i inside
-                const uint64_t room = i - lo + 1;
-                const int avail = (int)std::min<uint64_t>((uint64_t)(MTStream::BLK - pos), room);
-                const uint32_t *ob = o + pos;
-                uint32_t ii = (uint32_t)i;
-                for (int k = 0; k < avail; k++) {
-                    const uint32_t v = ob[k] & mask;
-                    J[ii] = v;
-                    ii -= (uint32_t)(v <= ii);
-                }
-                pos += avail;
-                i = ii;
-                if (ii < (uint32_t)lo) break;           // (only when lo > 0: i is unsigned)
-            }
-            hi = lo - 1;
-        }
-        pool[(size_t)f] = std::thread([J, n, n_test, f, bits, &err] {
-            uint32_t *xp = g_words.get(n);
-            if (!xp) { err = SS_ENOMEM; g_words.put(J, n); return; }
-            for (uint64_t i = 0; i < n; i++) xp[i] = (uint32_t)i;
-            // (the partners are known ahead: their cache lines are requested 24 swaps early -- 20 MB of x do not fit L2)
-            for (uint64_t i = n - 1; i >= 1; i--) {
-                if (i > 24) __builtin_prefetch(&xp[J[i - 24]], 1, 1);
-                const uint32_t j = J[i], a = xp[i];
-                xp[i] = xp[j];
-                xp[j] = a;
-            }
-            const uint32_t bit = 1u << f;
-            for (uint64_t i = 0; i < n_test; i++) __atomic_fetch_or(&bits[xp[i]], bit, __ATOMIC_RELAXED);
-            g_words.put(xp, n);
-            g_words.put(J, n);
+        // the split's worker starts from a snapshot of the stream at the split's first word and goes through the split's draws
+        // itself; this thread only moves the stream past them (the next split begins where this one's last accepted draw was)
+        MTWords *snap = new (std::nothrow) MTWords(*rng);
+        if (!snap) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); break; }
+        pool[(size_t)f] = std::thread([snap, n, n_test, f, bits, &err] {
+            const int rc = simd ? split_worker<true>(std::unique_ptr<MTWords>(snap), n, n_test, f, bits) : split_worker<false>(std::unique_ptr<MTWords>(snap), n, n_test, f, bits);
+            if (rc != SS_OK) err = rc;
         });
+        if (f + 1 < n_splits) {
+            if (simd) walk_split<false, true>(*rng, n, nullptr, [](const uint32_t *, uint32_t) {});
+            else walk_split<false, false>(*rng, n, nullptr, [](const uint32_t *, uint32_t) {});
+        }
     }
     const double t_gen = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    for (int f = std::max(0, n_splits - (int)in_flight); f < n_splits; f++) pool[(size_t)f].join();
+    for (auto &th : pool) if (th.joinable()) th.join();
     if (trace)
-        fprintf(stderr, "[shuffle-split] n = %llu: generator done at %.1f ms (%.1f ms of it waiting for swap threads, %u in flight), all at %.1f ms\n",
-                (unsigned long long)n, t_gen * 1e3, t_wait * 1e3, in_flight,
+        fprintf(stderr, "[shuffle-split] n = %llu: stream walked at %.1f ms (%.1f ms of it waiting for swap threads, %u in flight, %s), all at %.1f ms\n",
+                (unsigned long long)n, t_gen * 1e3, t_wait * 1e3, in_flight, simd ? "64 words per step" : "word by word",
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
     return err;
 }

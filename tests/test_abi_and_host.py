@@ -11,6 +11,7 @@ import gzip
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -262,7 +263,28 @@ def test_shuffle_split_native_equals_numpy():
         a, _ = l2.shuffle_split_test_bits(5003, splits, frac, 42)
         b, _ = l2.shuffle_split_test_bits_numpy(5003, splits, frac, 42)
         assert np.array_equal(a, b), (splits, frac)
+    # the 64-words-per-step walk (AVX-512 hosts) takes over where a level's rows are >= 65536: sizes around its first levels
+    # (a draw inside the band of 63 values it cannot decide sends a step to the scalar rule: 3 % of the steps at that level)
+    for n in (131072, 131073, 131137, 262143, 262145, 1000003):
+        for seed in (0, 77):
+            a, na = l2.shuffle_split_test_bits(n, 20, 0.1, seed)
+            b, nb = l2.shuffle_split_test_bits_numpy(n, 20, 0.1, seed)
+            assert na == nb and np.array_equal(a, b), (n, seed)
     assert l2._lib.lib().ss_shuffle_split_bits(10, 32, 5, 0, None) != 0          # more than 31 splits: refused
+
+
+def test_shuffle_split_word_by_word_walk():
+    """... and the same with SS_SPLIT_SIMD=0 (read once per process): the word-by-word walk a host without AVX-512 takes."""
+    import subprocess
+    code = ("import numpy as np\nfrom strainscan_amd import l2\n"
+            "for n in (5003, 131073, 300001):\n"
+            "    a, na = l2.shuffle_split_test_bits(n, 20, 0.1, 5)\n"
+            "    b, nb = l2.shuffle_split_test_bits_numpy(n, 20, 0.1, 5)\n"
+            "    assert na == nb and np.array_equal(a, b), n\n"
+            "print('walk ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SS_SPLIT_SIMD="0"), cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "walk ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_reader_grammar_cuts_and_gz(tmp_path):
