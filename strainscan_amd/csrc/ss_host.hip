@@ -263,6 +263,21 @@ __attribute__((target("avx2"))) void mt_extend_avx2(uint32_t *x, int n_new)
     for (int n0 = 0; n0 < n_new; n0 += 224) mt_extend_body(x + n0, std::min(224, n_new - n0));
 }
 __attribute__((target("avx2"))) void mt_temper_avx2(uint32_t *x, int n) { mt_temper_body(x, n); }
+// 16 words per step: three loads, a bit select, a shift, a test and two xors (one masked).  A step reads x[n .. n + 412],
+// all of it written at least 14 steps earlier.
+__attribute__((target("avx512f"))) void mt_extend_avx512(uint32_t *x, int n_new)
+{
+    const __m512i up = _mm512_set1_epi32((int)0x80000000u), mag = _mm512_set1_epi32((int)0x9908b0dfu), one = _mm512_set1_epi32(1);
+    int n = 0;
+    for (; n + 16 <= n_new; n += 16) {
+        const __m512i a = _mm512_loadu_si512((const void *)(x + n)), b = _mm512_loadu_si512((const void *)(x + n + 1));
+        const __m512i m = _mm512_loadu_si512((const void *)(x + n + 397));
+        const __m512i y = _mm512_ternarylogic_epi32(up, a, b, 0xCA);              // up ? a : b
+        const __m512i r = _mm512_xor_si512(m, _mm512_srli_epi32(y, 1));
+        _mm512_storeu_si512((void *)(x + 624 + n), _mm512_mask_xor_epi32(r, _mm512_test_epi32_mask(y, one), r, mag));
+    }
+    if (n < n_new) mt_extend_body(x + n, n_new - n);           // (fewer than 16 words: far below the distance of 227)
+}
 #endif
 void mt_extend_base(uint32_t *x, int n_new)
 {
@@ -273,7 +288,9 @@ bool host_simd_allowed() { static const bool on = !(getenv("SS_SPLIT_SIMD") && !
 void mt_extend(uint32_t *x, int n_new)
 {
 #ifdef SS_HOST_X86
+    static const bool avx512 = __builtin_cpu_supports("avx512f") && host_simd_allowed();
     static const bool avx2 = __builtin_cpu_supports("avx2") && host_simd_allowed();
+    if (avx512) return mt_extend_avx512(x, n_new);
     if (avx2) return mt_extend_avx2(x, n_new);
 #endif
     mt_extend_base(x, n_new);
@@ -454,7 +471,7 @@ void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink)
 
 // the swaps of one split, on a thread of its own, from a snapshot of the stream at the split's first word
 template <bool SIMD>
-int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, int f, uint32_t *bits)
+int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, uint64_t *bitmap)
 {
     uint32_t *xp = g_words.get(n);
     std::unique_ptr<uint32_t[]> buf(new (std::nothrow) uint32_t[SPLIT_CH + MTWords::BLK + 16]);
@@ -473,10 +490,42 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, int 
             xp[j] = a;
         }
     });
-    const uint32_t bit = 1u << f;
-    for (uint64_t q = 0; q < n_test; q++) __atomic_fetch_or(&bits[xp[q]], bit, __ATOMIC_RELAXED);
+    // the test set as a bitmap of the split's own (n / 8 bytes: it stays in this core's L2; atomic ORs into the shared
+    // 32-bit words -- half of the rows, from every worker at once -- were as long as the swaps)
+    memset(bitmap, 0, ((n + 63) / 64) * sizeof(uint64_t));
+    for (uint64_t q = 0; q < n_test; q++) bitmap[xp[q] >> 6] |= 1ull << (xp[q] & 63u);
     g_words.put(xp, n);
     return SS_OK;
+}
+// rows [64 g0, 64 g1) of the result from the splits' bitmaps: bit f of bits[r] = bit r of bitmap f
+#ifdef SS_HOST_X86
+__attribute__((target("avx512f"))) void merge_bitmaps_avx512(const uint64_t *bm, uint64_t words, int n_splits, uint64_t g0, uint64_t g1, uint64_t n, uint32_t *bits)
+{
+    for (uint64_t g = g0; g < g1; g++) {
+        __m512i acc[4] = {_mm512_setzero_si512(), _mm512_setzero_si512(), _mm512_setzero_si512(), _mm512_setzero_si512()};
+        for (int f = 0; f < n_splits; f++) {
+            const uint64_t w = bm[(uint64_t)f * words + g];
+            const __m512i bit = _mm512_set1_epi32((int)(1u << f));
+            for (int q = 0; q < 4; q++) acc[q] = _mm512_mask_or_epi32(acc[q], (__mmask16)(w >> (16 * q)), acc[q], bit);
+        }
+        if (g * 64 + 64 <= n) {
+            for (int q = 0; q < 4; q++) _mm512_storeu_si512((void *)(bits + g * 64 + 16 * q), acc[q]);
+        } else {
+            alignas(64) uint32_t t[64];
+            for (int q = 0; q < 4; q++) _mm512_store_si512((void *)(t + 16 * q), acc[q]);
+            for (uint64_t r = g * 64; r < n; r++) bits[r] = t[r - g * 64];
+        }
+    }
+}
+#endif
+void merge_bitmaps_base(const uint64_t *bm, uint64_t words, int n_splits, uint64_t g0, uint64_t g1, uint64_t n, uint32_t *bits)
+{
+    for (uint64_t g = g0; g < g1; g++) {
+        uint32_t t[64] = {0};
+        for (int f = 0; f < n_splits; f++)
+            for (uint64_t w = bm[(uint64_t)f * words + g]; w; w &= w - 1) t[__builtin_ctzll(w)] |= 1u << f;
+        for (uint64_t r = g * 64; r < std::min(n, g * 64 + 64); r++) bits[r] = t[r - g * 64];
+    }
 }
 }  // namespace
 }  // extern "C++"
@@ -484,9 +533,8 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, int 
 int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, uint32_t *bits)
 {
     if (n_splits < 1 || n_splits > 31 || n_test > n || n > 0xFFFFFFFFull || (n && !bits)) return SS_EINVAL;
-    if (n) memset(bits, 0, n * sizeof(uint32_t));
     if (n < 2) {
-        for (uint64_t i = 0; i < n_test; i++) bits[i] = (1u << n_splits) - 1u;      // permutation(1) = [0]
+        if (n) bits[0] = n_test ? (1u << n_splits) - 1u : 0u;                         // permutation(1) = [0]
         return SS_OK;
     }
     // swaps of several splits at once: one core each, two stay free
@@ -501,8 +549,11 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
     const auto t_begin = std::chrono::steady_clock::now();
     double t_wait = 0;
     std::unique_ptr<MTWords> rng(new (std::nothrow) MTWords(seed, simd));
-    if (!rng) return SS_ENOMEM;
+    const uint64_t bm_words = (n + 63) / 64;
+    uint64_t *bm = reinterpret_cast<uint64_t *>(g_words.get(2 * bm_words * (uint64_t)n_splits));      // (every worker clears its own)
+    if (!rng || !bm) { g_words.put(reinterpret_cast<uint32_t *>(bm), 2 * bm_words * (uint64_t)n_splits); return SS_ENOMEM; }
     std::vector<std::thread> pool((size_t)n_splits);
+    std::vector<std::pair<double, double>> t_worker((size_t)n_splits);             // (trace: when every worker began and ended)
     std::atomic<int> err(SS_OK);
     for (int f = 0; f < n_splits; f++) {
         if (f >= (int)in_flight) {                                                   // bounds the memory: in_flight x 4 n bytes
@@ -514,9 +565,12 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         // itself; this thread only moves the stream past them (the next split begins where this one's last accepted draw was)
         MTWords *snap = new (std::nothrow) MTWords(*rng);
         if (!snap) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); break; }
-        pool[(size_t)f] = std::thread([snap, n, n_test, f, bits, &err] {
-            const int rc = simd ? split_worker<true>(std::unique_ptr<MTWords>(snap), n, n_test, f, bits) : split_worker<false>(std::unique_ptr<MTWords>(snap), n, n_test, f, bits);
+        uint64_t *my_bm = bm + (uint64_t)f * bm_words;
+        pool[(size_t)f] = std::thread([snap, n, n_test, f, my_bm, &err, &t_worker, t_begin] {
+            const double w0 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            const int rc = simd ? split_worker<true>(std::unique_ptr<MTWords>(snap), n, n_test, my_bm) : split_worker<false>(std::unique_ptr<MTWords>(snap), n, n_test, my_bm);
             if (rc != SS_OK) err = rc;
+            t_worker[(size_t)f] = {w0, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()};
         });
         if (f + 1 < n_splits) {
             if (simd) walk_split<false, true>(*rng, n, nullptr, [](const uint32_t *, uint32_t) {});
@@ -525,10 +579,32 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
     }
     const double t_gen = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     for (auto &th : pool) if (th.joinable()) th.join();
+    const double t_workers = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    if (err == SS_OK) {
+        // bits[r] = the r-th bits of the splits' bitmaps, row ranges in parallel
+        const unsigned parts = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(in_flight, bm_words / 1024));
+        std::vector<std::thread> mt;
+        for (unsigned q = 0; q < parts; q++) {
+            const uint64_t g0 = bm_words * q / parts, g1 = bm_words * (q + 1) / parts;
+            mt.emplace_back([=] {
+#ifdef SS_HOST_X86
+                if (simd) return merge_bitmaps_avx512(bm, bm_words, n_splits, g0, g1, n, bits);
+#endif
+                merge_bitmaps_base(bm, bm_words, n_splits, g0, g1, n, bits);
+            });
+        }
+        for (auto &th : mt) th.join();
+    }
+    g_words.put(reinterpret_cast<uint32_t *>(bm), 2 * bm_words * (uint64_t)n_splits);
     if (trace)
-        fprintf(stderr, "[shuffle-split] n = %llu: stream walked at %.1f ms (%.1f ms of it waiting for swap threads, %u in flight, %s), all at %.1f ms\n",
-                (unsigned long long)n, t_gen * 1e3, t_wait * 1e3, in_flight, simd ? "64 words per step" : "word by word",
+        fprintf(stderr, "[shuffle-split] n = %llu: stream walked at %.1f ms (%.1f ms of it waiting for swap threads, %u in flight, %s), workers done at %.1f ms, all at %.1f ms\n",
+                (unsigned long long)n, t_gen * 1e3, t_wait * 1e3, in_flight, simd ? "64 words per step" : "word by word", t_workers * 1e3,
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3);
+    if (trace && n >= 1000000) {
+        fprintf(stderr, "[shuffle-split] workers (begin + duration, ms):");
+        for (auto &w : t_worker) fprintf(stderr, " %.0f+%.0f", w.first * 1e3, (w.second - w.first) * 1e3);
+        fprintf(stderr, "\n");
+    }
     return err;
 }
 
