@@ -337,7 +337,10 @@ int ss_l2_info(const ss_l2 *h, uint64_t *K, uint32_t *S, uint64_t *words_per_pla
  * among the identified clusters' columns (`overlap.A[:, all_cls - 1]`); writes y and y_u = y * ln as uint32[K], the bit
  * vectors [y > 1], [y_u > 1], [row kept: npp25 <= y <= min(npp75, npp_out)] (W words each) and y of the kept rows (0
  * elsewhere); out = {kept rows, any y_u > 0, a count negative or beyond 32 bits}.  ss_l2_fold: the fold words of
- * ss_l2_pattern_stats from the kept-row bit vector and ShuffleSplit's test bits per kept row (host, n_keep words). */
+ * ss_l2_pattern_stats from the kept-row bit vector and ShuffleSplit's test bits per kept row (host, n_keep words).
+ * ss_l2_count_keep: out[0] of ss_l2_prepare from y alone, on host threads (2 ms for 5 M rows): ShuffleSplit depends on the
+ * number of kept rows only and is the longest step of a large cluster's solve -- it starts before y is on the device. */
+int ss_l2_count_keep(const int64_t *y_host, uint64_t K, double npp25, double npp75, double npp_out, uint64_t *n_keep);
 int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, const int8_t *data, uint32_t n_cols);
 int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel, double npp25, double npp75, double npp_out,
                   uint32_t *y_dev, uint32_t *yu_dev, uint32_t *G_dev, uint32_t *Gu_dev, uint32_t *keep_dev, uint32_t *ykeep_dev,

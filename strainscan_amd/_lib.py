@@ -134,6 +134,7 @@ SIGNATURES = {
     "ss_l2_set_overlap": (i32, [vp, vp, vp, vp, u32]),
     "ss_l2_prepare": (i32, [vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp]),
     "ss_l2_fold": (i32, [vp, vp, vp, u64, vp]),
+    "ss_l2_count_keep": (i32, [vp, u64, C.c_double, C.c_double, C.c_double, vp]),
     "ss_l2_quantile_sums": (i32, [vp, vp, vp, u32, C.c_double, C.c_double, vp, vp, vp, vp, vp]),
     "ss_l2_pattern_stats": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "ss_enet_path_gram": (i32, [vp, vp, vp, vp, vp, i32, i32, vp, i32, C.c_double, i32, C.c_double, i32, vp, vp,

@@ -21,6 +21,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 struct ss_l2 {
@@ -560,6 +561,29 @@ int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel,
     }
     hipFree(d_y); hipFree(d_sel); hipFree(d_out);
     return rc;
+}
+
+// the row filter of l2_prepare_kernel (same comparison, as doubles) counted on host threads
+int ss_l2_count_keep(const int64_t *y_host, uint64_t K, double npp25, double npp75, double npp_out, uint64_t *n_keep)
+{
+    if (!n_keep || (K && !y_host)) return SS_EINVAL;
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(8u, ss::host_cpus()), K >> 18));
+    std::vector<uint64_t> part(nt, 0);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            uint64_t c = 0;
+            for (uint64_t i = K * t / nt, e = K * (t + 1) / nt; i < e; i++) {
+                const double d = (double)y_host[i];
+                c += !(d < npp25 || d > npp75 || d > npp_out);
+            }
+            part[t] = c;
+        });
+    for (auto &x : th) x.join();
+    uint64_t total = 0;
+    for (uint64_t c : part) total += c;
+    *n_keep = total;
+    return SS_OK;
 }
 
 int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, uint64_t n_keep, uint32_t *fold_dev)

@@ -183,13 +183,18 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     try:
         if img.om_cols is None:
             img.set_overlap(om)
-        # ln, py_u, the [> 1] masks, the row filter of :402-415: one pass on the device (ss_l2_prepare)
-        vec = img.prepare(np.asarray(input_y), new_als, npp25, npp75, npp_out)
+        # ShuffleSplit's 20 permutations (numpy's sequential legacy generator) depend on the NUMBER of rows the filter of
+        # :402-415 keeps, and that on y and the three bounds only: counted on the host (2 ms for 5 M rows), so that for large
+        # clusters the permutations -- the longest step of the solve -- run on host threads from here on, while y travels
+        # to the device and the pre-scan runs there
+        y64 = np.ascontiguousarray(input_y, np.int64)
+        n_keep = L2.count_keep(y64, npp25, npp75, npp_out)
+        split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, n_keep, CV_NITER, TEST_SIZE, 0) if n_keep >= 200000 else None
+        # ln, py_u, the [> 1] masks, the row filter: one pass on the device (ss_l2_prepare)
+        vec = img.prepare(y64, new_als, npp25, npp75, npp_out)
+        if vec.n_keep != n_keep:
+            raise RuntimeError("row filter: %d rows kept on the device, %d on the host" % (vec.n_keep, n_keep))
         t_vec = time.perf_counter()
-        # ShuffleSplit's 20 permutations (numpy's sequential legacy generator) depend on the NUMBER of kept rows only: for
-        # large clusters they run on host threads while the pre-scan runs on the device
-        split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, vec.n_keep, CV_NITER, TEST_SIZE, 0) \
-            if vec.n_keep >= 200000 else None
         out_columns, out_strains, strain_cov, strain_val, final_src, depth = pre_scan(
             img, vec, sid, cutoff, l2, pmode, emode)
         if trace is not None:

@@ -271,6 +271,16 @@ def alpha_grid(q_total, n, l1_ratio=0.5, eps=1e-3, n_alphas=50):
     return np.logspace(np.log10(alpha_max * eps), np.log10(alpha_max), num=n_alphas)[::-1]
 
 
+def count_keep(y, npp25, npp75, npp_out):
+    """How many rows identify_strains_L2_Enet_Pscan_new_sp.py:402-415 keeps: npp25 <= y <= min(npp75, npp_out), compared as
+    doubles (a NaN bound keeps every row) -- what ClusterImage.prepare reports as n_keep, from y alone on host threads."""
+    y = np.ascontiguousarray(y, np.int64)
+    out = np.zeros(1, np.uint64)
+    _lib.check(_lib.lib().ss_l2_count_keep(_lib.ptr(y), int(y.size), float(npp25), float(npp75), float(npp_out), _lib.ptr(out)),
+               "ss_l2_count_keep")
+    return int(out[0])
+
+
 def shuffle_split_test_bits(n, n_splits=20, test_size=0.5, seed=0):
     """ShuffleSplit(n_splits, test_size, random_state=seed) -> (uint32[n], n_test): bit f of entry i = row i is in
     the test set of fold f.  The permutations are numpy's legacy RandomState.permutation (sklearn calls it); the

@@ -273,6 +273,20 @@ def test_shuffle_split_native_equals_numpy():
     assert l2._lib.lib().ss_shuffle_split_bits(10, 32, 5, 0, None) != 0          # more than 31 splits: refused
 
 
+def test_count_keep_equals_numpy():
+    """ss_l2_count_keep = the row filter of identify_strains_L2_Enet_Pscan_new_sp.py:402-415 as numpy evaluates it on doubles
+    (NaN bounds keep every row), from y alone on host threads; detect_core checks it against the device's count on every call."""
+    from strainscan_amd import l2
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 1000, 700001):
+        y = rng.integers(0, 300, n).astype(np.int64)
+        for b in ((10.0, 150.0, 120.0), (float("nan"), 150.0, 1e9), (0.0, 1e9, float("nan")), (5.0, 5.0, 5.0), (7.5, 7.4, 9.0)):
+            d = y.astype(np.float64)
+            with np.errstate(invalid="ignore"):
+                want = int((~((d < b[0]) | (d > b[1]) | (d > b[2]))).sum())
+            assert l2.count_keep(y, *b) == want, (n, b)
+
+
 def test_shuffle_split_word_by_word_walk():
     """... and the same with SS_SPLIT_SIMD=0 (read once per process): the word-by-word walk a host without AVX-512 takes."""
     import subprocess
