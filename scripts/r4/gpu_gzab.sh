@@ -19,11 +19,9 @@ for f in range(2):
 for pr in [subprocess.Popen(["gzip", "-6", "-f", p]) for p in paths]: pr.wait()
 gz = [p + ".gz" for p in paths]
 _lib.warm_up(gz=2)
-variants = [dict(SS_GZ_PIECES="1", SS_GZ_UPLOAD_DIV="16"), dict(SS_GZ_PIECES="4", SS_GZ_UPLOAD_DIV="16"), dict(SS_GZ_PIECES="4", SS_GZ_UPLOAD_DIV="32"),
-            dict(SS_GZ_PIECES="2", SS_GZ_UPLOAD_DIV="32"), dict(SS_GZ_PIECES="1", SS_GZ_UPLOAD_DIV="16", SS_GZ_UPLOAD_THREADS="4"),
-            dict(SS_GZ_PIECES="8", SS_GZ_UPLOAD_DIV="32")]
+variants = [dict(SS_GZ_UPLOAD_THREADS="2"), dict(SS_GZ_UPLOAD_THREADS="3"), dict(SS_GZ_UPLOAD_THREADS="4"), dict(SS_GZ_UPLOAD_THREADS="6"), dict(SS_GZ_UPLOAD_THREADS="8")]
 times = [[] for _ in variants]
-for it in range(26):
+for it in range(41):
     for vi, v in enumerate(variants):
         for k in ("SS_GZ_PIECES", "SS_GZ_UPLOAD_DIV", "SS_GZ_UPLOAD_THREADS"): os.environ.pop(k, None)
         os.environ.update(v)
@@ -32,6 +30,6 @@ for it in range(26):
         if it: times[vi].append(dt * 1e3)
 for v, t in zip(variants, times):
     t = sorted(t)
-    print("%-70s min %.1f  q1 %.1f  median %.1f  q3 %.1f ms" % (v, t[0], t[len(t) // 4], t[len(t) // 2], t[3 * len(t) // 4]))
+    print("%-40s min %.1f  q1 %.1f  median %.1f  q3 %.1f  p90 %.1f  max %.1f ms" % (v, t[0], t[len(t) // 4], t[len(t) // 2], t[3 * len(t) // 4], t[9 * len(t) // 10], t[-1]))
 import shutil; shutil.rmtree(base)
 PY

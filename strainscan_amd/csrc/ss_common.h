@@ -194,9 +194,16 @@ void gpu_gunzip_done(void *lease);
 struct GzPiece { uint64_t at, len, keep; std::vector<uint8_t> carry; };
 bool gz_range_active();
 extern std::atomic<long long> g_hook_entry, g_hook_decline, g_hook_skip_chain;      // ss_test_hook (ss_ginflate.hip)
+// The files of a load go down the chain in the order of their paths (the messages of one pair of ranks are matched in order): a
+// file draws a ticket (in path order, before its thread starts), its first chain call waits for the files before it to have
+// finished THEIR chain traffic, and gz_range_pass hands the turn on (idempotent; waits for the turn itself if the file never
+// used it).  What a file does before its first chain call -- upload, search, the inflation of its first slice -- runs beside
+// the chain of the file in front of it: both mates of a pair are in flight on every rank.
+uint64_t gz_range_ticket();
+void gz_range_pass(uint64_t ticket);
 bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **lease, int fd, std::vector<GzPiece> *pieces,
-                      bool decline = false);      // decline: test hook -- plan the slices, serve the chain, hand nothing back
-int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat);
+                      uint64_t ticket, bool decline = false);      // decline: test hook -- plan the slices, serve the chain, hand nothing back
+int gz_fastq_pieces_dev(const char *path, uint64_t ticket, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat);
 int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char **d_flat, uint64_t *flat_len, uint64_t *flat_cap,
                          uint64_t *n_records, char **text, uint64_t *text_len);
 // every gzip input of a call through gz_fastq_to_flat_dev, one host thread per file: `flat(i, d_flat, len, cap, n_records)`

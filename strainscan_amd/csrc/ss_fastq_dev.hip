@@ -264,8 +264,9 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
 // the sequence lines of each piece become a flat block handed to `flat`.  0 = done (every record that begins in this rank's
 // slices has been handed over), 1 = declined (nothing usable was handed over: the caller reports SS_EAGAIN and all ranks
 // settle for another path).
-int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat)
+int gz_fastq_pieces_dev(const char *path, uint64_t ticket, const std::function<int(char *, uint64_t, uint64_t, uint64_t)> &flat)
 {
+    struct Turn { uint64_t t; ~Turn() { gz_range_pass(t); } } turn{ticket};      // (whichever way this file leaves: the next one's chain may start)
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -295,7 +296,7 @@ int gz_fastq_pieces_dev(const char *path, const std::function<int(char *, uint64
         // (a rank that declines still serves the chain -- gpu_gunzip_range sees to that once it knows the slices, which it
         //  derives from the file's size; a file that cannot be opened at all is the same failure on every rank of a node, and
         //  a rank that is gone altogether ends the others' bounded wait: dist._gz_chain)
-        if (in && in[0] == 0x1f && in[1] == 0x8b) ok = gpu_gunzip_range(in, in_n, &d_text, &lease, fd, &pieces, inj);
+        if (in && in[0] == 0x1f && in[1] == 0x8b) ok = gpu_gunzip_range(in, in_n, &d_text, &lease, fd, &pieces, ticket, inj);
         if (in && head.empty()) munmap((void *)in, in_n);
         if (fd >= 0) close(fd);
     }

@@ -39,6 +39,7 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -1533,6 +1534,27 @@ struct ChainMsg {
     uint8_t window[WSIZE];
     uint8_t carry[CARRY_MAX];
 };
+// the order in which the files of a load use the chain (ss_common.h: gz_range_ticket)
+static std::mutex g_turn_mu;
+static std::condition_variable g_turn_cv;
+static uint64_t g_turn_issued = 0, g_turn_serving = 0;
+uint64_t gz_range_ticket()
+{
+    std::lock_guard<std::mutex> g(g_turn_mu);
+    return g_turn_issued++;
+}
+static void gz_range_wait(uint64_t ticket)                   // (returns at once for the holder of the turn and for tickets already passed)
+{
+    std::unique_lock<std::mutex> g(g_turn_mu);
+    g_turn_cv.wait(g, [&] { return g_turn_serving >= ticket; });
+}
+void gz_range_pass(uint64_t ticket)
+{
+    std::unique_lock<std::mutex> g(g_turn_mu);
+    g_turn_cv.wait(g, [&] { return g_turn_serving >= ticket; });
+    if (g_turn_serving == ticket) { g_turn_serving++; g_turn_cv.notify_all(); }
+}
+
 struct RangeRun {
     uint32_t rank = 0, world = 1, slice_chunks = 0, n_slices = 0;
     ss_gz_chain_fn fn = nullptr;
@@ -1549,10 +1571,12 @@ struct RangeRun {
     // this rank's part: nothing more is RECEIVED (the outcome is known: declined), but status -1 still goes down the chain
     // for every slice of this rank, so that the ranks behind it learn it at once instead of each waiting for its own
     // deadline; only a failed SEND ends the traffic (the peer is gone).
+    uint64_t ticket = 0;                  // this file's place in the order in which the files of a load use the chain
     bool recv_for(uint32_t s)
     {
         if (s == 0) return !failed;
         if (failed) return false;
+        gz_range_wait(ticket);
         if (fn(&msg, sizeof(ChainMsg), (int)s, 0, user) != 0) { failed = true; msg.status = -1; msg.carry_len = 0; return false; }
         received = true;
         return true;
@@ -1562,6 +1586,7 @@ struct RangeRun {
         if (s + 1 >= n_slices) return !failed;
         if (broken) return false;
         if (failed) { msg.status = -1; msg.carry_len = 0; }
+        gz_range_wait(ticket);
         if (fn(&msg, sizeof(ChainMsg), (int)s, 1, user) != 0) { broken = true; failed = true; return false; }
         return !failed;
     }
@@ -1578,7 +1603,7 @@ struct RangeRun {
         }
     }
 };
-static std::mutex g_range_mu;            // one file at a time goes down the chain
+static std::mutex g_range_mu;            // (guards g_range)
 static struct { int rank = 0, world = 1; uint64_t slice_bytes = 0; ss_gz_chain_fn fn = nullptr; void *user = nullptr; } g_range;
 
 bool gz_range_active() { return g_range.world > 1 && g_range.fn != nullptr; }
@@ -1593,17 +1618,22 @@ bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len
 // This rank's slices of the file: *text_dev holds their texts back to back, `pieces` says where each lies, what came down
 // the chain in front of it (the bytes of a record that began in the slice before) and where its last complete record
 // ends.  false: declined (the chain has been served all the same).
-bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **lease, int fd, std::vector<GzPiece> *pieces, bool decline)
+bool gpu_gunzip_range(const uint8_t *in, uint64_t in_n, char **text_dev, void **lease, int fd, std::vector<GzPiece> *pieces, uint64_t ticket, bool decline)
 {
-    std::lock_guard<std::mutex> one(g_range_mu);
-    if (!gz_range_active()) return false;
-    if (g_hook_skip_chain.load()) return false;               // test hook: a rank that leaves WITHOUT serving the chain (the peers' bounded wait)
     RangeRun rr;
-    rr.rank = (uint32_t)g_range.rank; rr.world = (uint32_t)g_range.world; rr.fn = g_range.fn; rr.user = g_range.user;
+    {
+        std::lock_guard<std::mutex> one(g_range_mu);
+        if (!gz_range_active()) return false;
+        rr.rank = (uint32_t)g_range.rank; rr.world = (uint32_t)g_range.world; rr.fn = g_range.fn; rr.user = g_range.user;
+    }
+    if (g_hook_skip_chain.load()) return false;               // test hook: a rank that leaves WITHOUT serving the chain (the peers' bounded wait)
+    rr.ticket = ticket;
     rr.pieces = pieces;
     rr.inject_decline = decline;
     uint64_t n = 0;
-    return gpu_gunzip_impl(in, in_n, text_dev, &n, lease, fd, &rr);
+    const bool ok = gpu_gunzip_impl(in, in_n, text_dev, &n, lease, fd, &rr);
+    gz_range_pass(ticket);                                    // (this file's chain traffic is over, whatever came of it)
+    return ok;
 }
 
 static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd, RangeRun *rr)

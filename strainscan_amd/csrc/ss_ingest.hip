@@ -383,15 +383,32 @@ int gz_inputs_on_device(const char *const *paths, int n_paths, int shard_rank, i
     }
     if (gz.empty()) return SS_OK;
     if (gz_range_active() && gz_policy() == 1) {
-        // the ranks share every file's inflation (ss_gz_set_range): one file after the other, in the order of the paths (the
-        // chain of messages between the ranks is per file); a rank keeps all records that begin in its slices
+        // the ranks share every file's inflation (ss_gz_set_range); a rank keeps all records that begin in its slices.  The
+        // chain of messages between the ranks is per file and the files use it in the order of the paths (gz_range_ticket), but
+        // the files are in flight together: while one file's messages travel, the next one's slices are uploaded and inflated
+        int device = 0;
+        hipGetDevice(&device);
+        std::mutex mu;
         int rc = SS_OK;
-        for (int i : gz) {
-            const int r = gz_fastq_pieces_dev(paths[i], [&](char *d, uint64_t len, uint64_t cap, uint64_t nrec) { return flat(i, d, len, cap, nrec); });
-            if (r == 0) done[i] = 1;
-            else if (r == 1) rc = SS_EAGAIN;          // (the chain of the remaining files is still served: every rank goes through all of them)
-            else if (rc == SS_OK) rc = r;
+        std::vector<uint64_t> ticket;
+        for (size_t q = 0; q < gz.size(); q++) ticket.push_back(gz_range_ticket());
+        static const bool serial = getenv("SS_GZ_RANGE_SERIAL") != nullptr;      // (A/B: one file after the other, as before)
+        std::vector<std::thread> pool;
+        for (size_t q = 0; q < gz.size(); q++) {
+            auto one = [&, q] {
+                const int i = gz[q];
+                hipSetDevice(device);
+                const int r = gz_fastq_pieces_dev(paths[i], ticket[q], [&, i](char *d, uint64_t len, uint64_t cap, uint64_t nrec) { return flat(i, d, len, cap, nrec); });
+                std::lock_guard<std::mutex> g(mu);
+                if (r == 0) done[i] = 1;
+                else if (r == 1) rc = SS_EAGAIN;      // (the chain of the remaining files is still served: every rank goes through all of them)
+                else if (rc == SS_OK) rc = r;
+            };
+            if (serial) one();
+            else pool.emplace_back(one);
+            if (!serial && pool.size() == 2 && q + 1 < gz.size()) { pool.front().join(); pool.erase(pool.begin()); }      // two files in flight: a pair
         }
+        for (auto &th : pool) th.join();
         return rc;
     }
     int device = 0;
