@@ -19,11 +19,11 @@ for f in range(2):
 for pr in [subprocess.Popen(["gzip", "-6", "-f", p]) for p in paths]: pr.wait()
 gz = [p + ".gz" for p in paths]
 _lib.warm_up(gz=2)
-variants = [dict(SS_GZ_UPLOAD_THREADS="2"), dict(SS_GZ_UPLOAD_THREADS="3"), dict(SS_GZ_UPLOAD_THREADS="4"), dict(SS_GZ_UPLOAD_THREADS="6"), dict(SS_GZ_UPLOAD_THREADS="8")]
+variants = [dict(SS_GZ_UPLOAD_TURNS="0"), dict(SS_GZ_UPLOAD_TURNS="1"), dict(SS_GZ_UPLOAD_TURNS="1", SS_READS_ORDER="file")]
 times = [[] for _ in variants]
 for it in range(41):
     for vi, v in enumerate(variants):
-        for k in ("SS_GZ_PIECES", "SS_GZ_UPLOAD_DIV", "SS_GZ_UPLOAD_THREADS"): os.environ.pop(k, None)
+        for k in ("SS_GZ_PIECES", "SS_GZ_UPLOAD_DIV", "SS_GZ_UPLOAD_THREADS", "SS_GZ_UPLOAD_TURNS", "SS_READS_ORDER"): os.environ.pop(k, None)
         os.environ.update(v)
         t0 = time.perf_counter(); rs = _lib.ReadSet(gz); _lib.check(_lib.lib().ss_device_sync(), "sync"); dt = time.perf_counter() - t0
         rs.close()

@@ -1167,6 +1167,43 @@ __global__ __launch_bounds__(64) void crc_kernel(const uint8_t *text, const uint
     crc[s] = k ^ 0xFFFFFFFFu;
 }
 
+// The same for the members of a file, segments of 2^lg bytes from every member's first byte: segment s belongs to the member
+// m with first[m] <= s < first[m + 1] (binary search: a bgzip file has thousands) and begins (s - first[m]) << lg bytes into it.
+// Nothing but the member table travels to the device (the list of segments was 12 bytes per 4 KB of text, and three
+// pageable copies in front of the kernel); the byte table is made here.
+struct CrcMember { uint64_t at, len, first; };
+__global__ __launch_bounds__(64) void crc_members_kernel(const uint8_t *text, const CrcMember *mem, uint32_t n_mem, uint64_t n_seg, int lg, uint32_t *crc)
+{
+    __shared__ uint32_t tab[256];
+    for (int i = threadIdx.x; i < 256; i += 64) {
+        uint32_t k = (uint32_t)i;
+        for (int j = 0; j < 8; j++) k = (k & 1u) ? 0xEDB88320u ^ (k >> 1) : k >> 1;
+        tab[i] = k;
+    }
+    __syncthreads();
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    uint32_t lo = 0, hi = n_mem - 1;                         // the last member whose first segment is <= s
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (mem[mid].first <= s) lo = mid; else hi = mid - 1;
+    }
+    const uint64_t a0 = (s - mem[lo].first) << lg;
+    uint64_t i = mem[lo].at + a0;
+    const uint64_t e = i + min((uint64_t)1 << lg, mem[lo].len - a0);
+    uint32_t k = 0xFFFFFFFFu;
+    for (; i < e && (i & 3); i++) k = tab[(k ^ text[i]) & 0xFFu] ^ (k >> 8);
+    for (; i + 4 <= e; i += 4) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(text + i);
+        k = tab[(k ^ w) & 0xFFu] ^ (k >> 8);
+        k = tab[(k ^ (w >> 8)) & 0xFFu] ^ (k >> 8);
+        k = tab[(k ^ (w >> 16)) & 0xFFu] ^ (k >> 8);
+        k = tab[(k ^ (w >> 24)) & 0xFFu] ^ (k >> 8);
+    }
+    for (; i < e; i++) k = tab[(k ^ text[i]) & 0xFFu] ^ (k >> 8);
+    crc[s] = k ^ 0xFFFFFFFFu;
+}
+
 // GF(2) operator "append seg zero bytes" for CRC-32 (zlib's crc32_combine builds it anew for every call; here all segments
 // but the last have the same length, so it is built once)
 uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
@@ -1391,6 +1428,12 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
     static const bool trace = getenv("SS_INGEST_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3; };
+    // one file at a time on the link: the files of a call would otherwise arrive together, late, and their searches start together;
+    // in turn the first one is searched while the second one travels (SS_GZ_UPLOAD_TURNS=0: together, for A/B)
+    static std::mutex link;
+    const bool turns = !(getenv("SS_GZ_UPLOAD_TURNS") && !atoi(getenv("SS_GZ_UPLOAD_TURNS")));
+    std::unique_lock<std::mutex> my_turn(link, std::defer_lock);
+    if (turns) my_turn.lock();
     PinSet *pins = pin_get();
     if (!pins) return false;
     const double t_pins = since();
@@ -2376,27 +2419,22 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // CRC-32 by segments of 4 KB from every member's first byte, combined on the host with ONE precomputed operator
     constexpr int SEG_LOG2 = 12;
     const uint64_t seg = 1ull << SEG_LOG2;
-    std::vector<uint64_t> seg_at;
-    std::vector<uint32_t> seg_len;
-    for (const Member &m : members)
-        for (uint64_t a0 = 0; a0 < m.len; a0 += seg) { seg_at.push_back(m.at + a0); seg_len.push_back((uint32_t)std::min<uint64_t>(seg, m.len - a0)); }
-    const uint64_t nseg = seg_at.size();
-    std::vector<uint32_t> tab(256);
-    for (uint32_t i = 0; i < 256; i++) { uint32_t k = i; for (int j = 0; j < 8; j++) k = (k & 1u) ? 0xEDB88320u ^ (k >> 1) : k >> 1; tab[i] = k; }
-    uint64_t *d_seg_at = nullptr;
-    uint32_t *d_seg_len = nullptr;
-    GI(hipMallocAsync((void **)&d_tab, 1024 + std::max<uint64_t>(1, nseg) * 12, st));      // table | segment starts | lengths
-    d_seg_at = reinterpret_cast<uint64_t *>(d_tab + 256);
-    d_seg_len = reinterpret_cast<uint32_t *>(d_seg_at + nseg);
-    GB(h2d(d_tab, tab.data(), 1024));
-    if (nseg) {
-        GB(h2d(d_seg_at, seg_at.data(), nseg * 8));
-        GB(h2d(d_seg_len, seg_len.data(), nseg * 4));
+    std::vector<CrcMember> cm;
+    uint64_t nseg = 0;
+    for (const Member &m : members) {
+        if (!m.len) continue;                                  // (an empty member has no segment: its CRC is that of nothing)
+        cm.push_back(CrcMember{m.at, m.len, nseg});
+        nseg += (m.len + seg - 1) >> SEG_LOG2;
     }
+    GI(hipMallocAsync((void **)&d_tab, std::max<size_t>(16, cm.size() * sizeof(CrcMember)), st));      // (the member table)
     GI(hipMallocAsync((void **)&d_crc, std::max<uint64_t>(1, nseg) * 4, st));
-    if (nseg) hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, d_text, d_seg_at, d_seg_len, nseg, d_tab, d_crc);
     std::vector<uint32_t> crcs(std::max<uint64_t>(1, nseg));
-    if (nseg) GB(d2h(crcs.data(), d_crc, nseg * 4));
+    if (nseg) {
+        GB(h2d(d_tab, cm.data(), cm.size() * sizeof(CrcMember)));
+        hipLaunchKernelGGL(crc_members_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, d_text, reinterpret_cast<const CrcMember *>(d_tab), (uint32_t)cm.size(), nseg,
+                           SEG_LOG2, d_crc);
+        GB(d2h(crcs.data(), d_crc, nseg * 4));
+    }
     bool crc_ok = true;
     {
         uint32_t op[32];
@@ -2409,7 +2447,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         for (const Member &m : members) {
             uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
             for (uint64_t a0 = 0; a0 < m.len; a0 += seg, si++) {
-                const uint64_t l = seg_len[si];
+                const uint64_t l = std::min<uint64_t>(seg, m.len - a0);
                 if (l == seg) crc = opt[crc & 0xFF] ^ opt[256 + ((crc >> 8) & 0xFF)] ^ opt[512 + ((crc >> 16) & 0xFF)] ^ opt[768 + (crc >> 24)] ^ crcs[si];
                 else crc = (uint32_t)crc32_combine(crc, crcs[si], (z_off_t)l);
             }

@@ -619,10 +619,12 @@ int reads_order_for_locality(ss_reads *R, bool force)
     if (!R) return SS_EINVAL;
     if (!force && !reads_order_wanted()) return SS_OK;
     uint64_t bytes = 0;
+    // (asked ONCE: the driver takes ~1 ms to answer, as long as the binning of a 1 M-read file; every slab replaces one of about its size)
+    size_t mem_free = 0, mem_total = 0;
+    const bool known = hipMemGetInfo(&mem_free, &mem_total) == hipSuccess;
     for (auto &sl : R->slabs) {
-        size_t mem_free = 0, mem_total = 0;
         // (the binned copy lives beside the slab until it replaces it: a slab that leaves no room for that stays in file order)
-        const bool room = hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_free > sl.used + sl.used / 8 + (1ull << 30);
+        const bool room = known && mem_free > sl.used + sl.used / 8 + (1ull << 30);
         if (sl.used >= 64 && (room || force)) {
             char *d = nullptr;
             uint64_t used = 0, cap = 0;
