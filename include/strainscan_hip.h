@@ -195,6 +195,9 @@ int ss_db_expect_hits(ss_db *db, int expect);
  *                      copies with kernels; synchronous
  *   ss_scan_files    : FASTA/FASTQ files (plain or .gz), parsed on the host the way jellyfish
  *                      reads them (multi-line records, '+'/'@' quality lines), then scanned
+ *                      (on streams of the parser's own: the call first waits for what is pending on
+ *                      the default stream -- an ss_scan_reset(db, NULL) just before it)
+ *   ss_scan_reset    : zeroes the counters, asynchronously on `stream`
  * ------------------------------------------------------------------------------------------ */
 int ss_scan_reset(ss_db *db, void *stream);
 int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream);

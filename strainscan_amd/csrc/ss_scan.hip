@@ -502,6 +502,11 @@ int ss_scan_files_shard(ss_db *db, const char *const *paths, int n_paths, int sh
                         uint64_t *n_bases)
 {
     if (!db || !paths || n_paths < 1 || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return SS_EINVAL;
+    // The chunks are scanned on the parse workers' streams, which are NON-BLOCKING: nothing orders them behind what the caller
+    // put on the default stream before this call -- ss_scan_reset's memset above all (ss_scan_reset(db, NULL) only enqueues
+    // it).  On a busy device (three ranks sharing one GPU in the tests) the memset was seen to run AFTER the first chunk's
+    // scan, once in ~30 runs: a small file is one chunk, one rank's whole share, and all its counts were gone.
+    SS_HIP(hipStreamSynchronize(nullptr));
     uint64_t recs = 0, total = 0;
     const char *seq_env = getenv("SS_INGEST");
     const bool allow_parallel = !(seq_env && !strcmp(seq_env, "sequential"));
