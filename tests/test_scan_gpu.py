@@ -241,6 +241,36 @@ def test_parallel_ingest_equals_sequential(L, tmp_path):
         db.close()
 
 
+def test_scan_files_waits_for_a_pending_reset(L, tmp_path):
+    """ss_scan_reset(db, NULL) only ENQUEUES its memset on the default stream; ss_scan_files copies and scans on streams of
+    its own (the table's two staging streams for a small file, the parse workers' for a large one), which are non-blocking:
+    nothing orders them behind the default stream.  With the default stream busy -- here a few large fills put in front of
+    the reset; in the wild three ranks sharing one GPU, where the 3-rank identify test lost a rank's whole share of the
+    counts once in ~15 runs -- the memset ran AFTER the scans.  ss_scan_files waits for the default stream first."""
+    from strainscan_amd import l2
+    kfa, flat = _random_db_and_reads(41, 40000, 30000)
+    seqs = [r for r in flat.split(b"\n") if r]
+    small = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(seqs[:4000]))      # ~1 MB: the sequential reader
+    large = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(seqs)) * 3          # ~25 MB: the parse workers
+    busy = l2.DevBuf(6 << 30)
+    for name, blob in (("small.fq", small), ("large.fq", large)):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        db = L.KmerDB.from_text(kfa, 31, True)
+        db.scan_files([str(p)])
+        want = db.counts_rows().copy()
+        assert want.sum() > 1000
+        for _ in range(3):
+            L.check(L.lib().ss_device_sync(), "ss_device_sync")
+            for _ in range(6):                         # ~1-2 ms each on the default stream, in front of the reset
+                L.check(L.lib().ss_memset_dev(busy.ptr, 7, busy.nbytes, None), "ss_memset_dev")
+            db.reset()
+            db.scan_files([str(p)])
+            assert np.array_equal(db.counts_rows(), want), name
+        db.close()
+    busy.close()
+
+
 def test_resident_read_set_and_shards(L, tmp_path):
     """ss_reads: parse once, scan many; the blocks of shard r/w are disjoint and cover the input
     (what every rank holds in a multi-GPU run), for the worker-thread path and for the gz reader."""
