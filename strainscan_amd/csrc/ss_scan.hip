@@ -427,6 +427,7 @@ int ss_scan_flat_host(ss_db *db, const char *bases, uint64_t n)
     if (!db || (n && !bases)) return SS_EINVAL;
     int rc = ensure_staging(db);
     if (rc) return rc;
+    SS_HIP(hipStreamSynchronize(nullptr));      // (the staging streams are non-blocking: a reset pending on the default stream, see ss_scan_files_shard)
     // Chunks overlap by k-1 bytes: a k-mer starting in the last k-1 bytes of chunk A is invalid
     // there (it runs past the end) and is counted exactly once in chunk B.
     const uint64_t ov = (uint64_t)db->k - 1;

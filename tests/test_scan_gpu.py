@@ -267,6 +267,17 @@ def test_scan_files_waits_for_a_pending_reset(L, tmp_path):
             db.reset()
             db.scan_files([str(p)])
             assert np.array_equal(db.counts_rows(), want), name
+        if name == "small.fq":                         # ... and ss_scan_flat_host (the same staging streams)
+            seq = b"".join(r + b"\n" for r in seqs[:4000])
+            db.reset()
+            db.scan_flat(seq)
+            want_flat = db.counts_rows().copy()
+            L.check(L.lib().ss_device_sync(), "ss_device_sync")
+            for _ in range(6):
+                L.check(L.lib().ss_memset_dev(busy.ptr, 7, busy.nbytes, None), "ss_memset_dev")
+            db.reset()
+            db.scan_flat(seq)
+            assert want_flat.sum() > 1000 and np.array_equal(db.counts_rows(), want_flat)
         db.close()
     busy.close()
 
