@@ -189,6 +189,9 @@ bool gz_on_gpu();
 int gz_policy();                         // ss_gz_set_policy: 0 device then host, 1 device or SS_EAGAIN, 2 host
 bool gpu_gunzip(const uint8_t *in, uint64_t in_n, char **text_dev, uint64_t *len, void **lease, int fd);      // the text is lent until ...
 void gpu_gunzip_done(void *lease);
+// a non-blocking stream for the length of a call, from a small pool (making and destroying one is ~0.6 ms); handed back synchronised
+hipStream_t call_stream_get();
+void call_stream_put(hipStream_t s);
 // range mode (ss_gz_set_range): this rank's slices of a member.  text[at, at + len) is a slice's text, its first `keep` bytes
 // end with the last record that is complete in it, `carry` holds the bytes of the record that began in the slice before
 struct GzPiece { uint64_t at, len, keep; std::vector<uint8_t> carry; };

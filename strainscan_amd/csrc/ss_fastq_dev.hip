@@ -137,8 +137,8 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, int shard_rank, int s
                            uint64_t *flat_cap, uint64_t *n_records)
 {
     if (n == 0) return 1;
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return SS_EHIP;
+    hipStream_t st = call_stream_get();
+    if (!st) return SS_EHIP;
     const uint64_t n_tiles = (n + TB - 1) / TB;
     uint64_t *d_counts = nullptr, *d_base = nullptr, *d_ls = nullptr, *d_len1 = nullptr, *d_off = nullptr;
     uint32_t *d_bad = nullptr;
@@ -148,7 +148,7 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, int shard_rank, int s
         void *scratch[] = {d_counts, d_base, d_ls, d_len1, d_off, d_bad, d_tmp};
         for (void *q : scratch) if (q) hipFreeAsync(q, st);
         hipStreamSynchronize(st);
-        hipStreamDestroy(st);
+        call_stream_put(st);
         if (r != 0 && flat) hipFree(flat);
         return r;
     };

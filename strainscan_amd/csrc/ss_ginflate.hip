@@ -1525,7 +1525,7 @@ void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
 // The streams of the calls, kept (making one and destroying it was 0.6 ms of every call), and the stream-ordered allocator
 // told to keep what a call frees (SS_GZ_POOL_KEEP_MB, 1 GB) instead of handing it back to the driver at the next synchronisation.
 static std::vector<hipStream_t> g_stream_free;
-static hipStream_t call_stream_get()
+hipStream_t call_stream_get()
 {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1542,7 +1542,7 @@ static hipStream_t call_stream_get()
     hipStream_t s = nullptr;
     return hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess ? s : nullptr;
 }
-static void call_stream_put(hipStream_t s)                   // (synchronised by the caller)
+void call_stream_put(hipStream_t s)                          // (synchronised by the caller)
 {
     if (!s) return;
     {
