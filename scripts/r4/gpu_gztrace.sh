@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4_gz; mkdir -p $O; cd $R
-for T in 4 1 8; do
+for T in 1; do
 SS_GZ_PIECES=$T timeout 600 python - <<'PY' > $O/trace_$T.txt 2>&1
 import os, sys, time, subprocess
 sys.path.insert(0, '.')
@@ -26,5 +26,5 @@ for it in range(8):
     print("load %d: %.1f ms" % (it, dt * 1e3), flush=True); rs.close()
 import shutil; shutil.rmtree(base)
 PY
-echo pieces $T; grep -v "amdgpu.ids" $O/trace_$T.txt | grep -E "^load|upload:|search to|input on device" | tail -24
+echo pieces $T; grep -v "amdgpu.ids" $O/trace_$T.txt | awk "/^load 5/{f=1;next} /^load 6/{f=0} f" | grep -v "candidate\|entries\|segments\|amdgpu\|reorder" | cut -c1-150
 done

@@ -1301,6 +1301,8 @@ struct Arena {
     uint32_t *todo = nullptr;
     uint8_t *text = nullptr;              // the text of the call that holds the arena (lent to the caller until gpu_gunzip_done)
     uint64_t text_cap = 0;
+    void *late_free[4] = {nullptr, nullptr, nullptr, nullptr};      // the call's stage and lists: given back when the text is (the
+                                                                     // frees took ~1 ms beside another thread's allocations, in front of the caller's work)
 };
 std::mutex g_arena_mu;
 std::vector<Arena *> g_arena_free;
@@ -1309,6 +1311,7 @@ void arena_destroy(Arena *a)
     if (!a) return;
     void *q[] = {a->sym, a->map[0], a->map[1], a->meta, a->status, a->win, a->gwin, a->prev, a->todo, a->text};
     for (void *x : q) if (x) hipFree(x);
+    for (void *x : a->late_free) if (x) hipFreeAsync(x, nullptr);
     delete a;
 }
 Arena *arena_get(uint64_t cap_chunks, uint64_t sym_elems)
@@ -1520,7 +1523,16 @@ static std::atomic<uint64_t> g_handled{0}, g_declined{0}, g_range_files{0}, g_ra
 // ss_test_hook: nothing in the environment can switch these on
 std::atomic<long long> g_hook_entry{0}, g_hook_decline{0}, g_hook_skip_chain{0};
 
-void gpu_gunzip_done(void *lease) { arena_put(static_cast<Arena *>(lease)); }
+void gpu_gunzip_done(void *lease)
+{
+    Arena *a = static_cast<Arena *>(lease);
+    if (a)
+        for (void *&q : a->late_free) {
+            if (q) hipFreeAsync(q, nullptr);                 // (last used on the call's stream, which was synchronised before the text was handed out)
+            q = nullptr;
+        }
+    arena_put(a);
+}
 
 // The streams of the calls, kept (making one and destroying it was 0.6 ms of every call), and the stream-ordered allocator
 // told to keep what a call frees (SS_GZ_POOL_KEEP_MB, 1 GB) instead of handing it back to the driver at the next synchronisation.
@@ -1700,7 +1712,11 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         auto now = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         const double c0 = now();
         void *scratch[] = {d_in, d_entry, d_crc, d_tab};
-        for (void *q : scratch) if (q) hipFreeAsync(q, st);
+        for (int q = 0; q < 4; q++) {
+            if (!scratch[q]) continue;
+            if (keep_text && A) A->late_free[q] = scratch[q];      // (freed by gpu_gunzip_done)
+            else hipFreeAsync(scratch[q], st);
+        }
         const double c1 = now();
         hipStreamSynchronize(st);
         const double c2 = now();
