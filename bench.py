@@ -857,7 +857,10 @@ def main(argv=None):
         readset = dict(order="locality (records binned by the minimizer of their first k-mer, ~4 records per bin: ss_reorder.hip)",
                        prepare_ms=round(prep_ms, 2), prepare_ms_best=round(float(np.min(prep)), 2),
                        prepare_breakdown_ms=dict(zip(("count_and_prefix", "slab_allocation", "place"), [round(float(x), 2) for x in np.median(np.array(prep_parts), axis=0)]),
-                                                 note="medians of the five calls; slab_allocation is the driver's hipMalloc of the 3 GB output slab"), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
+                                                 note="medians of the five calls; slab_allocation is the driver's hipMalloc of the 3 GB output slab: 0.25-0.35 ms as a "
+                                                      "rule, 60-150 ms per call on some boxes (all five calls then); prepare_ms_kernels = count_and_prefix + place, "
+                                                      "the binning's own work"),
+                       prepare_ms_kernels=round(float(np.median(np.array(prep_parts), axis=0)[[0, 2]].sum()), 2), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
                        value=round(args.reads * world * args.steps / dt2 / 1e6, 3), unit="M reads/s", kernel_ms=round(k2, 3),
                        frac_algorithmic=round(args.reads * BYTES_PER_READ / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                        node_stats_equal=bool(torch.equal(stats, stats2)),
