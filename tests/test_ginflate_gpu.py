@@ -377,7 +377,8 @@ def test_segments(L, tmp_path, monkeypatch, fastq_text, seg_kb):
 
 def test_warm_up_then_pinned_upload(L, tmp_path, monkeypatch):
     """ss_gz_warm_up makes the pinned upload buffers ahead of time (the CLI's warm-up thread); a file of 32 MB or more then
-    travels through them (four pread threads, blocks of n / 8) instead of being copied out of the mapping: the same records
+    travels through them (eight pread threads with a stream each, blocks of n / 16, the files of a call one after the other on
+    the link) instead of being copied out of the mapping: the same records
     (SS_READS_ORDER=file: as they stand in the file)."""
     monkeypatch.setenv("SS_READS_ORDER", "file")
     assert L.lib().ss_gz_warm_up(2) == SS_OK
