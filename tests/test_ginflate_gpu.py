@@ -395,3 +395,13 @@ def test_warm_up_then_pinned_upload(L, tmp_path, monkeypatch):
     want, n_rec = L.fastx_to_flat(t)
     assert n_rec == 330000
     assert [r for r in got.split(b"\n") if r] == [r for r in want.split(b"\n") if r]
+    # ... and as the two mates of a pair: both files in flight, one after the other on the link, a set of buffers each
+    p2 = tmp_path / "w2.fq.gz"
+    p2.write_bytes(gzip.compress(t, 1))
+    assert p2.stat().st_size >= (32 << 20)
+    rs = L.ReadSet([str(p), str(p2)])
+    assert rs.info()["n_records"] == 2 * 330000
+    got2 = rs.read_back()
+    rs.close()
+    assert _counters(L)[0] == h0 + 3
+    assert sorted(r for r in got2.split(b"\n") if r) == sorted([r for r in want.split(b"\n") if r] * 2)
