@@ -286,19 +286,24 @@ def _p2p_works():
         rank, world = dist.get_rank(), dist.get_world_size()
         on_dev = dist.get_backend() == "nccl"
         dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
-        ok = 1
-        try:
-            out = torch.full((1,), rank, dtype=torch.int32, device=dev)
-            box = torch.empty(1, dtype=torch.int32, device=dev)
-            reqs = [dist.isend(out, (rank + 1) % world), dist.irecv(box, (rank - 1) % world)]
-            for r in reqs:
-                r.wait()
-            ok = int(int(box.item()) == (rank - 1) % world)
-        except BaseException:               # noqa: B902
-            ok = 0
-        t = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        _P2P_OK[key] = bool(int(t.item()))
+        agreed = False
+        for attempt in range(2):            # (the first point-to-point traffic of a group sets its connections up: one more try,
+            ok = 1                          #  taken by all ranks together -- they all see the same MIN)
+            try:
+                out = torch.full((1,), rank + 1000 * attempt, dtype=torch.int32, device=dev)
+                box = torch.empty(1, dtype=torch.int32, device=dev)
+                reqs = [dist.isend(out, (rank + 1) % world), dist.irecv(box, (rank - 1) % world)]
+                for r in reqs:
+                    r.wait()
+                ok = int(int(box.item()) == (rank - 1) % world + 1000 * attempt)
+            except BaseException:           # noqa: B902
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            agreed = bool(int(t.item()))
+            if agreed:
+                break
+        _P2P_OK[key] = agreed
     return _P2P_OK[key]
 
 
