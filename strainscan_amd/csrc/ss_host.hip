@@ -476,11 +476,9 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, uint
     uint32_t *xp = g_words.get(n);
     std::unique_ptr<uint32_t[]> buf(new (std::nothrow) uint32_t[SPLIT_CH + MTWords::BLK + 16]);
     if (!xp || !buf) { g_words.put(xp, n); return SS_ENOMEM; }
-    static const bool no_swap = getenv("SS_SPLIT_NO_SWAP") != nullptr;      // (timing of everything but the swaps: the result is wrong)
     for (uint64_t i = 0; i < n; i++) xp[i] = (uint32_t)i;
     uint64_t i = n - 1;
     walk_split<true, SIMD>(*rng, n, buf.get(), [&](const uint32_t *p, uint32_t cnt) {
-        if (no_swap) { i -= cnt; return; }
         // (the partners are known ahead: their cache lines are requested 24 swaps early -- 20 MB of x do not fit L2)
         for (uint32_t k = 0; k < std::min(24u, cnt); k++) __builtin_prefetch(&xp[p[k]], 1, 1);
         for (uint32_t k = 0; k < cnt; k++, i--) {
