@@ -3,7 +3,7 @@
 # database, 20 M resident reads and some allocation churn, as in bench.py)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-for mode in late early; do
+for mode in late early early_then_release; do
 MODE=$mode timeout 400 python - <<'PY' 2>&1 | grep -v amdgpu
 import os, sys, time, subprocess
 sys.path.insert(0, '.')
@@ -26,8 +26,10 @@ del small, flat
 def load():
     t0 = time.perf_counter(); rs = _lib.ReadSet(gz); _lib.check(_lib.lib().ss_device_sync(), "sync"); dt = time.perf_counter() - t0
     rs.close(); return dt * 1e3
-if mode == "early":
+if mode.startswith("early"):
     _lib.warm_up(gz=2); load(); load()
+if mode == "early_then_release":     # the arenas, pinned buffers and pooled streams go; what the stream-ordered allocator keeps stays
+    _lib.check(_lib.lib().ss_gz_gpu_release(), "release")
 spec = bench.make_db(torch, dev, 103, seed=20231013)
 reads = bench.make_reads(torch, dev, spec, 20_000_000, seed=2, hit_frac=0.05)
 churn = [torch.empty(1 << 30, dtype=torch.uint8, device=dev) for _ in range(6)]
