@@ -479,10 +479,13 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, uint
     for (uint64_t i = 0; i < n; i++) xp[i] = (uint32_t)i;
     uint64_t i = n - 1;
     walk_split<true, SIMD>(*rng, n, buf.get(), [&](const uint32_t *p, uint32_t cnt) {
-        // (the partners are known ahead: their cache lines are requested 24 swaps early -- 20 MB of x do not fit L2)
-        for (uint32_t k = 0; k < std::min(24u, cnt); k++) __builtin_prefetch(&xp[p[k]], 1, 1);
+        // (the partners are known ahead: their cache lines are requested early -- 20 MB of x do not fit L2)
+        // (... 64 swaps early: 24 / 48 / 64 / 96 / 128 ahead gave workers of 10 / 8 / 8 / 8 / 7 ms and the whole call 29.9 / 27.2 / 27.4 /
+        //  28.3 / 27.8 ms on the boxes' EPYC 9575F)
+        static const uint32_t PD = getenv("SS_SPLIT_PREFETCH") ? (uint32_t)std::max(1, atoi(getenv("SS_SPLIT_PREFETCH"))) : 64u;
+        for (uint32_t k = 0; k < std::min(PD, cnt); k++) __builtin_prefetch(&xp[p[k]], 1, 1);
         for (uint32_t k = 0; k < cnt; k++, i--) {
-            if (k + 24 < cnt) __builtin_prefetch(&xp[p[k + 24]], 1, 1);
+            if (k + PD < cnt) __builtin_prefetch(&xp[p[k + PD]], 1, 1);
             const uint32_t j = p[k], a = xp[i];
             xp[i] = xp[j];
             xp[j] = a;
