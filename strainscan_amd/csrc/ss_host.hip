@@ -222,7 +222,7 @@ int ss_memset_dev(void *dst, int byte, uint64_t bytes, void *stream)
 // random_interval(max) = 32-bit draws masked to the next power of two minus one, redrawn while > max
 // (numpy/random/src/distributions: random_interval; mtrand.pyx: _shuffle_raw).
 // What the splits share is ONE word stream: where a split's words begin depends on how many draws the splits before it had
-// to repeat.  So one thread walks the stream and only COUNTS (64 words per step on AVX-512 hosts, see reject64_avx512; a
+// to repeat.  So one thread walks the stream and only COUNTS (64 words per step on AVX-512 hosts, see reject_avx512; a
 // compare and an add-with-carry per word elsewhere), and hands every split's worker a snapshot of the generator (22 KB: its
 // state and the block it is in) at the split's first word; the worker goes through the same words again, this time keeping the accepted draws -- a few
 // thousand at a time, in its L1 -- and applies the swaps (the cache misses of a split are its own).  Round 3: one thread did
@@ -369,26 +369,28 @@ struct MTWords {
 // The rejection rule over a stretch of the word stream, 64 words per step (AVX-512).  i is the row the next accepted draw
 // belongs to; a draw v is accepted when v <= i.  Within a step i falls by at most 63, so v <= i - 63 is accepted and v > i
 // rejected whatever happened to the words before it -- the dependent chain is ONE count per 64 words instead of a compare and
-// an add-with-carry per word.  A draw inside that band of 63 values (one word in 2^k / 64, k >= 17 here) sends the step to
+// an add-with-carry per word.  A draw inside that band of 63 values (one word in 2^k / 64, k >= 14 here) sends the step to
 // the scalar rule.  The words arrive untempered and are tempered here.  STORE: the accepted draws are written in stream
 // order to out[0 ..] (up to 15 words of slack behind them); otherwise they are only counted.
-// Returns the words consumed (a multiple of 64, <= n_words); *i_io falls by the draws accepted.
+// Returns the words consumed (a multiple of the step, <= n_words); *i_io falls by the draws accepted.
 extern "C++" {
 #ifdef SS_HOST_X86
-template <bool STORE>
-__attribute__((target("avx512f,popcnt"))) static int reject64_avx512(const uint32_t *w, int n_words, uint32_t mask, uint32_t *i_io, uint32_t *out)
+template <bool STORE, int NV>            // NV vectors of 16 words per step: 4 (a band of 63 values)
+__attribute__((target("avx512f,popcnt"))) static int reject_avx512(const uint32_t *w, int n_words, uint32_t mask, uint32_t *i_io, uint32_t *out)
 {
+    constexpr int STEP = 16 * NV;
     const uint32_t i0 = *i_io;
     uint32_t c = 0;                                            // draws accepted so far
     const __m512i vmask = _mm512_set1_epi32((int)mask), t7 = _mm512_set1_epi32((int)0x9d2c5680u), t15 = _mm512_set1_epi32((int)0xefc60000u);
     int k = 0;
-    for (; k + 64 <= n_words; k += 64) {
+    for (; k + STEP <= n_words; k += STEP) {
         const uint32_t i = i0 - c;
-        const __m512i hi = _mm512_set1_epi32((int)i), lo = _mm512_set1_epi32((int)(i - 63u));
-        __m512i v[4];
-        __mmask16 a[4];
+        const __m512i hi = _mm512_set1_epi32((int)i), lo = _mm512_set1_epi32((int)(i - (uint32_t)(STEP - 1)));
+        __m512i v[NV];
+        __mmask16 a[NV];
         unsigned unsure = 0;
-        for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) {
             __m512i y = _mm512_loadu_si512((const void *)(w + k + 16 * q));
             y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
             y = _mm512_ternarylogic_epi32(y, _mm512_slli_epi32(y, 7), t7, 0x78);       // a ^ (b & c)
@@ -400,7 +402,7 @@ __attribute__((target("avx512f,popcnt"))) static int reject64_avx512(const uint3
         }
         if (__builtin_expect(unsure != 0, 0)) {
             uint32_t ii = i;
-            for (int q = 0; q < 64; q++) {
+            for (int q = 0; q < STEP; q++) {
                 const uint32_t x = mt_temper(w[k + q]) & mask;
                 if (STORE) out[i0 - ii] = x;
                 ii -= (uint32_t)(x <= ii);
@@ -408,7 +410,8 @@ __attribute__((target("avx512f,popcnt"))) static int reject64_avx512(const uint3
             c = i0 - ii;
             continue;
         }
-        for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int q = 0; q < NV; q++) {
             if (STORE) _mm512_storeu_si512((void *)(out + c), _mm512_maskz_compress_epi32(a[q], v[q]));
             c += (uint32_t)__builtin_popcount((unsigned)a[q]);
         }
@@ -442,12 +445,17 @@ void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink)
             const int taken = avail;
             uint32_t ii = (uint32_t)i;
 #ifdef SS_HOST_X86
-            if (SIMD && lo >= 65536 && avail >= 64) {
-                const int used = reject64_avx512<STORE>(ob, avail, mask, &ii, buf + fill);
-                if (STORE) fill += (uint32_t)i - ii;
+            // (from rows of 8192 on: below, more than a third of the steps meet a draw inside the band and fall back to the scalar
+            //  rule anyway; with the levels up to 131072 walked word by word, as at first, those 2.6 % of the rows were 8 ms of a
+            //  19 ms walk -- tempering on the scalar unit is 8 cycles a word)
+            // (steps of 128 words -- NV = 8 -- for the large levels: the walk 24.1 instead of 18.0 ms on the boxes' EPYC 9575F, slower
+            //  on a Xeon too: not the chain through the count but the work per word is what a step costs)
+            if (SIMD && lo >= 8192 && avail >= 64) {
+                const int used = reject_avx512<STORE, 4>(ob, avail, mask, &ii, buf + fill + ((uint32_t)i - ii));
                 ob += used;
                 avail -= used;
             }
+            if (SIMD && STORE) fill += (uint32_t)i - ii;
 #endif
             // branch-free rejection: every draw is written to its row's place; the row moves on only when the draw is accepted
             const uint32_t i1 = ii;

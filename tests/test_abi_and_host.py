@@ -263,9 +263,9 @@ def test_shuffle_split_native_equals_numpy():
         a, _ = l2.shuffle_split_test_bits(5003, splits, frac, 42)
         b, _ = l2.shuffle_split_test_bits_numpy(5003, splits, frac, 42)
         assert np.array_equal(a, b), (splits, frac)
-    # the 64-words-per-step walk (AVX-512 hosts) takes over where a level's rows are >= 65536: sizes around its first levels
-    # (a draw inside the band of 63 values it cannot decide sends a step to the scalar rule: 3 % of the steps at that level)
-    for n in (131072, 131073, 131137, 262143, 262145, 1000003):
+    # the 64-words-per-step walk (AVX-512 hosts) takes over where a level's rows are >= 8192: sizes around its first levels
+    # (a draw inside the band of 63 values it cannot decide sends a step to the scalar rule: a third of the steps at that level)
+    for n in (16383, 16384, 16385, 16449, 20000, 32769, 131072, 131073, 131137, 262143, 262145, 1000003):
         for seed in (0, 77):
             a, na = l2.shuffle_split_test_bits(n, 20, 0.1, seed)
             b, nb = l2.shuffle_split_test_bits_numpy(n, 20, 0.1, seed)
@@ -291,7 +291,7 @@ def test_shuffle_split_word_by_word_walk():
     """... and the same with SS_SPLIT_SIMD=0 (read once per process): the word-by-word walk a host without AVX-512 takes."""
     import subprocess
     code = ("import numpy as np\nfrom strainscan_amd import l2\n"
-            "for n in (5003, 131073, 300001):\n"
+            "for n in (5003, 16385, 131073, 300001):\n"
             "    a, na = l2.shuffle_split_test_bits(n, 20, 0.1, 5)\n"
             "    b, nb = l2.shuffle_split_test_bits_numpy(n, 20, 0.1, 5)\n"
             "    assert na == nb and np.array_equal(a, b), n\n"
