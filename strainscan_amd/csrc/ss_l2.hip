@@ -458,9 +458,9 @@ __global__ __launch_bounds__(NT) void l2_prepare_kernel(const long long *__restr
                                                         const uint8_t *__restrict__ sel, uint32_t n_cols, double npp25, double npp75,
                                                         double npp_out, uint32_t *__restrict__ y32, uint32_t *__restrict__ yu32,
                                                         uint32_t *__restrict__ G, uint32_t *__restrict__ Gu, uint32_t *__restrict__ keep,
-                                                        uint32_t *__restrict__ ykeep, unsigned long long *__restrict__ out)
+                                                        uint32_t *__restrict__ ykeep, unsigned long long *__restrict__ out, uint64_t W)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;          // the grid covers whole 64-row groups of the padded planes
+    const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;          // the grid covers every word of the padded planes
     const bool in = i < K;
     const long long v = in ? y[i] : 0;
     long long ln = 0;
@@ -475,17 +475,20 @@ __global__ __launch_bounds__(NT) void l2_prepare_kernel(const long long *__restr
     const uint32_t yv = (uint32_t)v, yu = ln == 1 ? yv : 0u;
     const double d = (double)v;
     const bool kp = in && !(d < npp25 || d > npp75 || d > npp_out);
-    const uint64_t bg = __ballot(in && yv > 1u), bu = __ballot(yu > 1u), bk = __ballot(kp);
+    // all four ballots with the whole wave active: np.sum(py_u) > 0 (:279-286, :331) is over EVERY row
+    const uint64_t bg = __ballot(in && yv > 1u), bu = __ballot(yu > 1u), bk = __ballot(kp), bp = __ballot(yu > 0u);
     if (in) { y32[i] = yv; yu32[i] = yu; ykeep[i] = kp ? yv : 0u; }
     const int lane = threadIdx.x & 63;
     if (lane == 0 || lane == 32) {
         const int sh = lane;                                              // 0 or 32
         const uint64_t w = i >> 5;
-        G[w] = (uint32_t)(bg >> sh); Gu[w] = (uint32_t)(bu >> sh); keep[w] = (uint32_t)(bk >> sh);
+        if (w < W) {                                                      // W is a multiple of 4, a block covers 8 words
+            G[w] = (uint32_t)(bg >> sh); Gu[w] = (uint32_t)(bu >> sh); keep[w] = (uint32_t)(bk >> sh);
+        }
     }
     if (lane == 0) {
         if (bk) atomicAdd(&out[0], (unsigned long long)__popcll(bk));
-        if (__ballot(yu > 0u)) atomicOr(&out[1], 1ull);
+        if (bp) atomicOr(&out[1], 1ull);
     }
     if (bad) atomicOr(&out[2], 1ull);
 }
@@ -506,13 +509,42 @@ __global__ __launch_bounds__(NT) void l2_fold_kernel(const uint32_t *__restrict_
     fold[i] = ((w >> b) & 1u) ? (split_bits[pre[i >> 5] + (uint32_t)__popc(w & ((1u << b) - 1u))] | 0x80000000u) : 0u;
 }
 
+// a CSR row-pointer array as the kernels walk it: starts at 0, never decreases, ends at (and so never exceeds) nnz.
+// A truncated or damaged .npz fails here (SS_EINVAL) instead of sending a kernel past the index arrays.
+__global__ __launch_bounds__(NT) void csr_ptr_check_kernel(const int64_t *__restrict__ ptr, uint64_t K, int64_t nnz, int *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
+    if (i > K) return;
+    const int64_t a = ptr[i];
+    bool b = a < 0 || a > nnz;
+    if (i == 0) b = b || a != 0;
+    if (i < K) b = b || ptr[i + 1] < a;
+    if (b) atomicOr(bad, 1);
+}
+
+int csr_ptr_check(const int64_t *d_ptr, uint64_t K, int64_t nnz)
+{
+    int *d_bad = nullptr, bad = 0;
+    if (nnz < 0) return SS_EINVAL;
+    if (hipMalloc((void **)&d_bad, 4) != hipSuccess) return SS_ENOMEM;
+    int rc = SS_OK;
+    if (hipMemset(d_bad, 0, 4) != hipSuccess) rc = SS_EHIP;
+    else {
+        hipLaunchKernelGGL(csr_ptr_check_kernel, dim3((unsigned)((K + 1 + NT - 1) / NT)), dim3(NT), 0, 0, d_ptr, K, nnz, d_bad);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+        else if (bad) rc = SS_EINVAL;
+    }
+    hipFree(d_bad);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
 
 int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, const int8_t *data, uint32_t n_cols)
 {
-    if (!h || !indptr) return SS_EINVAL;
+    if (!h || !indptr || indptr[h->K] < 0) return SS_EINVAL;
     const uint64_t nnz = (uint64_t)indptr[h->K];
     if (nnz && (!indices || !data)) return SS_EINVAL;
     hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
@@ -521,6 +553,11 @@ int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, c
     SS_HIP(hipMalloc((void **)&h->d_om_idx, std::max<uint64_t>(1, nnz) * 4));
     SS_HIP(hipMalloc((void **)&h->d_om_val, std::max<uint64_t>(1, nnz)));
     SS_HIP(hipMemcpy(h->d_om_ptr, indptr, (h->K + 1) * 8, hipMemcpyHostToDevice));
+    if (const int rc = csr_ptr_check(h->d_om_ptr, h->K, (int64_t)nnz)) {
+        hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
+        h->d_om_ptr = nullptr; h->d_om_idx = nullptr; h->d_om_val = nullptr;
+        return rc;
+    }
     if (nnz) {
         SS_HIP(hipMemcpy(h->d_om_idx, indices, nnz * 4, hipMemcpyHostToDevice));
         SS_HIP(hipMemcpy(h->d_om_val, data, nnz, hipMemcpyHostToDevice));
@@ -553,7 +590,7 @@ int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel,
         if (e == hipSuccess) {
             const uint64_t rows = h->W * 32;                                // every word of the padded bit vectors is written
             hipLaunchKernelGGL(l2_prepare_kernel, dim3((unsigned)((rows + NT - 1) / NT)), dim3(NT), 0, 0, d_y, h->K, h->d_om_ptr, h->d_om_idx,
-                               h->d_om_val, d_sel, h->om_cols, npp25, npp75, npp_out, y_dev, yu_dev, G_dev, Gu_dev, keep_dev, ykeep_dev, d_out);
+                               h->d_om_val, d_sel, h->om_cols, npp25, npp75, npp_out, y_dev, yu_dev, G_dev, Gu_dev, keep_dev, ykeep_dev, d_out, h->W);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpy(out, d_out, 24, hipMemcpyDeviceToHost);
@@ -617,7 +654,7 @@ int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_b
 
 int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out)
 {
-    if (!out || !indptr || (indptr[K] && !indices)) return SS_EINVAL;
+    if (!out || !indptr || indptr[K] < 0 || (indptr[K] && !indices)) return SS_EINVAL;
     ss_l2 *h = new (std::nothrow) ss_l2();
     if (!h) return SS_ENOMEM;
     h->K = K;
@@ -638,6 +675,8 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
                hipMemcpy(d_ptr, indptr, (K + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
                (nnz && hipMemcpy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
         rc = SS_EHIP;
+    } else if ((rc = csr_ptr_check(d_ptr, K, (int64_t)nnz)) != SS_OK) {
+        // (a row pointer array the pack kernels could not walk safely)
     } else if (K) {
         const bool force_atomic = getenv("SS_L2_PACK_ATOMIC") != nullptr;                 // tests: the general kernel
         int redo = 1;

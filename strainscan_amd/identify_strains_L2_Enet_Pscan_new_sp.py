@@ -12,6 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from . import _lib
 from . import l2 as L2
 
 CV_NITER = 20        # :433
@@ -240,11 +241,24 @@ def _l2_cache_path(input_csv, omatrix):
 
 
 class _CSR:
-    """The arrays of a CSR matrix without scipy's object around them (its constructor checks and copies)."""
+    """The arrays of a CSR matrix without scipy's object around them (its constructor checks and copies).  What scipy's
+    constructor would refuse is refused here (sizes: O(1)) and by the native side on the device (ss_l2_create /
+    ss_l2_set_overlap: the row pointers start at 0, never decrease and end at nnz; every column index is in range)."""
 
     def __init__(self, indptr, indices, data, shape):
         self.indptr, self.indices, self.data, self.shape = indptr, indices, data, shape
         self.nnz = int(len(indices))
+        if len(shape) != 2 or shape[0] < 0 or shape[1] < 0:
+            raise ValueError("CSR shape must be (rows, columns), got %r" % (shape,))
+        if len(indptr) != shape[0] + 1:
+            raise ValueError("index pointer size (%d) should be (%d)" % (len(indptr), shape[0] + 1))
+        if len(data) != self.nnz:
+            raise ValueError("indices and data should have the same size")
+        if int(indptr[0]) != 0:
+            raise ValueError("index pointer should start with 0")
+        if int(indptr[-1]) != self.nnz:
+            raise ValueError("Last value of index pointer should be less than the size of index and data arrays"
+                             if int(indptr[-1]) > self.nnz else "index pointer ends before the index and data arrays")
 
     def tocsr(self):
         return self
@@ -263,7 +277,10 @@ def _load_npz_csr(path):
             m.sum_duplicates()
             return _CSR(m.indptr, m.indices, m.data, m.shape)
         shape = tuple(int(x) for x in z["shape"])
-        return _CSR(z["indptr"], z["indices"], z["data"], shape)
+        indptr, indices = z["indptr"], z["indices"]
+        if indptr.ndim != 1 or indices.ndim != 1 or indptr.dtype.kind != "i" or indices.dtype.kind != "i":
+            raise ValueError("%s: CSR index arrays must be one-dimensional integers" % path)
+        return _CSR(indptr, indices, z["data"], shape)
 
 
 def _write_l2_cache(path, img, om):
@@ -313,7 +330,11 @@ def _read_l2_cache(path):
     if pos[0] != size or (K and int(indptr[K]) != nnz):
         raise ValueError("inconsistent cluster image")
     img = L2.ClusterImage.from_planes(planes, K, S)
-    img.set_overlap(_CSR(indptr, indices, data, (K, ncls)))      # straight from the map to the device: no scipy object
+    try:
+        img.set_overlap(_CSR(indptr, indices, data, (K, ncls)))  # straight from the map to the device: no scipy object
+    except BaseException:
+        img.close()
+        raise
     return img, None
 
 
@@ -328,7 +349,7 @@ def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_co
     if cache:
         try:
             img, om = _read_l2_cache(cache)
-        except (OSError, ValueError):
+        except (OSError, ValueError, _lib.SSError):              # unreadable or damaged image: rebuild from the .npz files
             img = None
     if img is None:
         # scipy reads the .npz through zipfile (inflate + CRC: ~7 ms per million non-zeros); done once per

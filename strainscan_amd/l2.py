@@ -66,8 +66,13 @@ class ClusterImage:
         indptr = np.ascontiguousarray(X.indptr, np.int64)
         indices = np.ascontiguousarray(X.indices, np.int32)
         h = C.c_void_p()
-        _lib.check(_lib.lib().ss_l2_create(_lib.ptr(indptr), _lib.ptr(indices), self.K, self.S, C.byref(h)),
-                   "ss_l2_create")
+        if indptr.size != self.K + 1 or (self.K >= 0 and int(indptr[-1]) != indices.size):
+            raise ValueError("CSR arrays do not match the shape (%d row pointers for %d rows, %d indices for nnz %d)"
+                             % (indptr.size, self.K, indices.size, int(indptr[-1]) if indptr.size else -1))
+        rc = _lib.lib().ss_l2_create(_lib.ptr(indptr), _lib.ptr(indices), self.K, self.S, C.byref(h))
+        if rc == _lib.SS_EINVAL:             # what scipy's constructor refuses: row pointers out of order, a column >= S
+            raise ValueError("all_strains_re.npz is not a valid CSR matrix (row pointers or column indices out of range)")
+        _lib.check(rc, "ss_l2_create")
         self._h = h
         w = C.c_uint64()
         _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
@@ -103,8 +108,12 @@ class ClusterImage:
         indptr = np.ascontiguousarray(om.indptr, np.int64)
         indices = np.ascontiguousarray(om.indices, np.int32)
         data = np.ascontiguousarray(om.data, np.int8)
-        _lib.check(_lib.lib().ss_l2_set_overlap(self._h, _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(data), int(om.shape[1])),
-                   "ss_l2_set_overlap")
+        if indptr.size != self.K + 1 or int(indptr[-1]) != indices.size or indices.size != data.size:
+            raise ValueError("overlap matrix: CSR arrays do not match the shape")
+        rc = _lib.lib().ss_l2_set_overlap(self._h, _lib.ptr(indptr), _lib.ptr(indices), _lib.ptr(data), int(om.shape[1]))
+        if rc == _lib.SS_EINVAL:
+            raise ValueError("overlap_matrix.npz is not a valid CSR matrix (row pointers out of order or out of range)")
+        _lib.check(rc, "ss_l2_set_overlap")
         self.om_cols = int(om.shape[1])
         return self
 
@@ -115,12 +124,15 @@ class ClusterImage:
         y = np.ascontiguousarray(y, np.int64)
         if y.size != self.K:
             raise ValueError("y has %d entries, the cluster %d rows" % (y.size, self.K))
+        if self.om_cols is None:
+            raise RuntimeError("ClusterImage.prepare before set_overlap: the overlap matrix of the cluster is not on the device")
         sel = np.zeros(max(1, self.om_cols), np.uint8)
         for c in columns:
             c = int(c)
-            if c < -self.om_cols or c >= self.om_cols:
+            if c < -self.om_cols or c >= self.om_cols:       # (also every index into a matrix of 0 columns)
                 raise IndexError("index (%d) out of range" % c)      # as scipy's column indexing does
-            sel[c % self.om_cols] += 1
+            c %= self.om_cols
+            sel[c] = min(2, int(sel[c]) + 1)                 # a column taken twice already makes ln > 1 -> 0: saturate, never wrap
         v = Prepared()
         nb = self.W * 4
         v.y, v.yu, v.ykeep = DevBuf(self.K * 4), DevBuf(self.K * 4), DevBuf(self.K * 4)

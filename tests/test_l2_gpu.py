@@ -519,3 +519,111 @@ def test_enet_cd_residual_form(golden_dir):
         assert abs(gap - go) <= 1e-6 * max(1.0, abs(go))
         if p == 3:
             assert w[1] == 0.0
+
+
+def _dev_u32(buf, n):
+    from strainscan_amd import _lib
+    out = np.zeros(n, np.uint32)
+    if n:
+        _lib.check(_lib.lib().ss_memcpy_d2h(_lib.ptr(out), buf.ptr, n * 4, None), "ss_memcpy_d2h")
+    return out
+
+
+@pytest.mark.parametrize("K", [1, 63, 100, 1100, 4096, 70_001])
+def test_prepare_vectors_vs_numpy(K):
+    """ss_l2_prepare against identify_strains_L2_Enet_Pscan_new_sp.py:191-197, 36-38, 402-415 in numpy, with the only
+    rows of ln == 1 and y > 0 placed where i % 64 != 0: `use_u` (np.sum(py_u) > 0, :279-286, :331) is over every row, not
+    over the rows a wave's first lane holds (the round-4 kernel took that ballot under `lane == 0`).  K = 100 and 1100 give
+    a word count W that is 4 mod 8, where the last workgroup's upper waves lie beyond the bit vectors."""
+    import scipy.sparse as sp
+    from strainscan_amd import l2
+    rs = np.random.RandomState(K)
+    S, C_ = 3, 5
+    X = sp.csr_matrix((rs.random_sample((K, S)) < 0.5).astype(np.int8))
+    y = rs.randint(0, 40, size=K).astype(np.int64)
+    y[rs.random_sample(K) < 0.3] = 0
+    O = np.zeros((K, C_), np.int8)
+    O[:, 0] = 1
+    O[:, 2] = 1                                        # ln = 2 -> 0 everywhere ...
+    lone = [i for i in range(K) if i % 64 not in (0, 32) and i % 7 == 3][:3] or ([K - 1] if K > 1 and (K - 1) % 64 else [])
+    for i in lone:                                     # ... except on a few rows no first lane of a (half-)wave holds
+        O[i, 2] = 0
+        y[i] = max(int(y[i]), 2)
+    img = l2.ClusterImage(X)
+    assert img.W % 4 == 0
+    with pytest.raises(RuntimeError):
+        img.prepare(y, [0, 2], 0, 30, 30)              # before set_overlap: said so, no TypeError
+    img.set_overlap(sp.csr_matrix(O))
+    for cols in ([0, 2], [0], [0, 0], [0, 1, 4], [-5, -3], [0] * 300):
+        ln = O[:, cols].astype(np.int64).sum(axis=1)
+        ln[ln > 1] = 0
+        yu = y * ln
+        keep = (y >= 3) & (y <= 30)
+        v = img.prepare(y, cols, 3, 30, 31)
+        assert np.array_equal(_dev_u32(v.y, K), y.astype(np.uint32))
+        assert np.array_equal(_dev_u32(v.yu, K), yu.astype(np.uint32)), cols
+        assert np.array_equal(_dev_u32(v.ykeep, K), np.where(keep, y, 0).astype(np.uint32))
+        for buf, mask in ((v.G, y > 1), (v.Gu, yu > 1), (v.keep, keep)):
+            want = np.zeros(img.W * 4, np.uint8)
+            pk = np.packbits(mask, bitorder="little")
+            want[:pk.size] = pk
+            assert np.array_equal(_dev_u32(buf, img.W).view(np.uint8), want), cols
+        assert v.n_keep == int(keep.sum())
+        assert v.use_u == bool(yu.sum() > 0), (cols, lone)
+        v.close()
+    if lone:
+        v = img.prepare(y, [0, 2], 0, 1e9, 1e9)
+        assert v.use_u is True
+        v.close()
+    with pytest.raises(IndexError):
+        img.prepare(y, [C_], 0, 30, 30)
+    img.close()
+
+
+def test_damaged_csr_files_raise_value_error(tmp_path):
+    """What scipy's csr_matrix constructor refused before the .npz arrays went to the device unwrapped: a short row-pointer
+    array, row pointers past the index array, a decreasing row pointer, a column index beyond S -- ValueError, no kernel walks
+    out of the arrays.  A cluster image cache holding such arrays is ignored."""
+    import scipy.sparse as sp
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    from strainscan_amd import l2
+    rs = np.random.RandomState(3)
+    K, S = 5000, 6
+    X = sp.csr_matrix((rs.random_sample((K, S)) < 0.4).astype(np.int8))
+    O = sp.csr_matrix((rs.random_sample((K, 4)) < 0.3).astype(np.int8))
+
+    def save(name, indptr, indices, data, shape):
+        p = str(tmp_path / name)
+        np.savez(p, format=np.array("csr"), shape=np.array(shape), indptr=indptr, indices=indices, data=data)
+        return p
+
+    good = save("good.npz", X.indptr, X.indices, X.data, X.shape)
+    c = m._load_npz_csr(good)
+    img = l2.ClusterImage(c)
+    assert np.array_equal(img.planes(), l2.ClusterImage(X).planes())
+    for name, ip, ix, dt in (("short_ptr", X.indptr[:-7], X.indices, X.data),
+                             ("ptr_past_end", X.indptr, X.indices[:-5], X.data[:-5]),
+                             ("data_short", X.indptr, X.indices, X.data[:-1]),
+                             ("ptr_not_from_0", X.indptr + 1, np.append(X.indices, 0), np.append(X.data, 1))):
+        with pytest.raises(ValueError):
+            m._load_npz_csr(save(name + ".npz", ip, ix, dt, X.shape))
+    dec = X.indptr.copy()
+    dec[100] = dec[101] + 2
+    assert np.any(np.diff(dec) < 0)
+    with pytest.raises(ValueError):
+        l2.ClusterImage(m._load_npz_csr(save("decreasing.npz", dec, X.indices, X.data, X.shape)))
+    neg = X.indptr.copy()
+    neg[1] = -4
+    with pytest.raises(ValueError):
+        l2.ClusterImage(m._CSR(neg, X.indices, X.data, X.shape))
+    col = X.indices.copy()
+    col[11] = S
+    with pytest.raises(ValueError):
+        l2.ClusterImage(m._CSR(X.indptr, col, X.data, X.shape))
+    od = O.indptr.copy()
+    od[K // 2] = od[-1] + 3
+    with pytest.raises(ValueError):
+        img.set_overlap(m._CSR(od, O.indices, O.data, O.shape))
+    assert img.om_cols is None
+    img.set_overlap(m._CSR(O.indptr, O.indices, O.data, O.shape))
+    img.close()
