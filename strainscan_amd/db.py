@@ -159,14 +159,14 @@ def rank0_first(fn):
         try:
             out = fn()
             wait_cache_writes()
-        except BaseException as e:          # noqa: B902 -- raised below, after the other ranks have been told
-            err = e
+        except Exception as e:              # raised below, after the other ranks have been told; KeyboardInterrupt /
+            err = e                         # SystemExit leave at once (a rank on its way out must not enter a collective)
     if not agree(err is None):              # rank 0's turn
         raise err if err is not None else RuntimeError("rank 0 failed while building the database image")
     if rank != 0:
         try:
             out = fn()
-        except BaseException as e:          # noqa: B902
+        except Exception as e:
             err = e
     if not agree(err is None):              # everybody else's
         raise err if err is not None else RuntimeError("another rank failed while loading the database image")
