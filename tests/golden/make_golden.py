@@ -172,6 +172,35 @@ def main():
                             for r in entry["runs"]][:4])
     dump_json("l1_search.json", l1)
 
+    # ---------------------------------------------------------------- single search() steps from a hand-made state
+    steps = {}
+    for stname, (sname, modname, cut, override, pend) in sc.L1_STEPS.items():
+        mod = {"identify": identify, "identify_low_mem": identify_low_mem}[modname]
+        tdb = os.path.join(infos[sc.L1_SAMPLES[sname][0]]["db_dir"], "Tree_database")
+        fq = os.path.join(scratch, sname + ".fq")
+        tree, _ = mod.read_tree_structure(tdb)
+        for n in tree.all_nodes():
+            n.data = [-1, -1, -1, -1, -1]
+        mod.get_node_label(tdb, tree)
+        for nid, (cat, acc) in override.items():
+            tree.get_node(nid).data[0] = cat
+            tree.get_node(nid).data[1] = acc
+        mr = mod.jellyfish_count((fq, ""), tdb)
+        pending = [[tree.get_node(i) for i in g] for g in pend]
+        length, cov, abundance, res_temp, qp = {}, {}, {}, [], []
+        args = [pending, mr, tdb, set(mr.keys()), length, cov, abundance, cut[0], cut[2], [], tree.leaves(), res_temp, tree,
+                {}]
+        if modname == "identify":
+            args.append(qp)
+        _, err, out = run_captured(mod.search, *args)
+        steps[stname] = dict(
+            error=err, pending=[[n.identifier for n in g] for g in pending], res_temp=[n.identifier for n in res_temp],
+            qualified_parents=[n.identifier for n in qp], data={n.identifier: list(n.data) for n in tree.all_nodes()},
+            length={n.identifier: v for n, v in length.items()}, cov={n.identifier: v for n, v in cov.items()},
+            abundance={n.identifier: v for n, v in abundance.items()}, stdout=out.splitlines())
+        print("step", stname, err, steps[stname]["pending"], steps[stname]["res_temp"])
+    dump_json("l1_search_steps.json", steps)
+
     # ---------------------------------------------------------------- F4/F5: detect_strains
     import scipy.sparse as sp
     from sklearn.linear_model import ElasticNetCV as _ENCV, ElasticNet as _EN

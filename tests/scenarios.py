@@ -77,6 +77,38 @@ L1_DBS = {
     # (a pickled treelib.Tree, identify.py:19-21); the one node is root and leaf at once
     "D": dict(parent={1: None}, sites={1: 2600}, seed=14, singleton={}, clusters={1: ["GCF_U1", "GCF_U2", "GCF_U3"]},
               reconstructed=[], overlaps=[], single_cluster=True),
+    # round 5: the branches of the walk the samples above never reach.
+    # E: weak ROOT (identify.py:252-261, 400 rows: weak under both modules' thresholds); node 9 is 'o1' and visited while
+    #    `results` is empty ('o1' -> 1, :290-291); 11 is weak in identify.py only, so with leaf 4 reported the unique path
+    #    of get_ancestor_ab(11) holds 0 valid k-mers -> -1 (:163-164), while identify_low_mem.py (11 is label 1, both
+    #    children 'o2' there) takes the rescaling branch label == 1 (:320-321, 338-340); leaf 1 (400 rows) is weak in
+    #    identify_low_mem.py only: its children list [] goes into `pending` and the next search() raises IndexError
+    "E": dict(parent=PARENT_T11,
+              sites={1: 200, 2: 1800, 3: 1000, 4: 2200, 5: 1200, 6: 1300, 7: 200, 8: 1600, 9: 1200, 10: 1500, 11: 300},
+              seed=15, singleton={4: "GCF_E4ONLY"},
+              clusters={1: ["GCF_A1", "GCF_A2"], 2: ["GCF_B1", "GCF_B2"], 3: ["GCF_C1", "GCF_C2"],
+                        5: ["GCF_E1", "GCF_E2"], 6: ["GCF_F1", "GCF_F2"]},
+              reconstructed=[5, 6, 9], overlaps=[(3, 5, 0, 900), (3, 6, 0, 1000)]),
+    # F: both children of a STRONG parent reconstructed and left with < 1000 private k-mers once leaf 3 is reported:
+    #    [1, 2] come back 'o1','o1' -> label 1 (rescaled to the ancestor's abundance), [5, 6] 'o2','o1' -> label 2 with
+    #    x = the 'o1' node (:322-328, 341-342); identify_low_mem.py sees 'o2','o2' twice
+    "F": dict(parent=PARENT_T11,
+              sites={1: 1400, 2: 1200, 3: 1000, 4: 2200, 5: 2500, 6: 1200, 7: 2000, 8: 1600, 9: 1200, 10: 1500, 11: 1500},
+              seed=16, singleton={},
+              clusters={1: ["GCF_A1", "GCF_A2"], 2: ["GCF_B1", "GCF_B2"], 3: ["GCF_C1", "GCF_C2"], 4: ["GCF_D1", "GCF_D2"],
+                        5: ["GCF_E1", "GCF_E2"], 6: ["GCF_F1", "GCF_F2"]},
+              reconstructed=[1, 2, 5, 6],
+              overlaps=[(3, 1, 0, 1000), (3, 2, 0, 900), (3, 5, 0, 2100), (3, 6, 0, 900)]),
+    # G: nodes whose every kmer.fa row carries an N -- node_length.txt says 1200 / 1400 rows (label 1), no row is valid:
+    #    length == 0 (:298-303).  Internal node 11 comes FIRST in its group ([11, 4]: creation order), so with 4
+    #    reconstructed and leaf 3 reported the labels are [(11, 1), (11, 0), (4, 'o1')] -> `0 in set` -> label 2, x = 4
+    #    ('o2' and y = 4 under identify_low_mem.py); leaf 1 pushes [] and the next search() raises IndexError
+    "G": dict(parent=PARENT_T11,
+              sites={1: 700, 2: 1800, 3: 1000, 4: 1400, 5: 1700, 6: 1600, 7: 2000, 8: 1600, 9: 1200, 10: 1500, 11: 600},
+              seed=17, singleton={},
+              clusters={1: ["GCF_A1", "GCF_A2"], 2: ["GCF_B1", "GCF_B2"], 3: ["GCF_C1", "GCF_C2"], 4: ["GCF_D1", "GCF_D2"],
+                        5: ["GCF_E1", "GCF_E2"], 6: ["GCF_F1", "GCF_F2"]},
+              reconstructed=[4], overlaps=[(3, 4, 0, 1100)], invalid_nodes=[1, 11]),
 }
 
 # samples: name -> (db, [(leaf or ('path', node) or ('random', length), depth)], read seed)
@@ -93,10 +125,37 @@ L1_SAMPLES = {
     "D_one": ("D", [(1, 9.0)], 231),
     "D_low": ("D", [(1, 0.5)], 232),
     "D_none": ("D", [(("random", 40000), 5.0)], 233),
+    # round 5 (see the databases E, F, G above)
+    "E_mix": ("E", [(3, 12.0), (4, 6.0), (5, 5.0), (6, 4.0)], 241),
+    "E_weakleaf": ("E", [(2, 8.0), (3, 5.0)], 242),
+    "F_mix": ("F", [(3, 12.0), (1, 6.0), (2, 5.0), (5, 6.0), (6, 4.0)], 251),
+    # a third / a quarter of every node on two leaves' paths at 10x: both leaves fail the weighted coverage cutoff 0.4,
+    # nothing is reported, and the best `alternative` (leaf 4) is taken after res_node_proc ran a SECOND time on the
+    # stale loop variable j = leaf 1 and succeeded (identify.py:459-470: label == 1 with j != r)
+    "F_slices": ("F", [(("slice", 4, 0.0, 0.35), 10.0), (("slice", 1, 0.0, 0.25), 10.0)], 252),
+    "G_mix": ("G", [(3, 12.0), (4, 6.0), (5, 5.0)], 261),
+    "G_zero_leaf": ("G", [(3, 10.0), (2, 7.0)], 262),
 }
 
 CUTOFFS = [[0.1, 0.4, 1], [0.05, 0.05, 1], [0.01, 0.05, 1], [0.005, 0.01, 1]]   # StrainScan.py:196-216
 POISSON_SEED = 4321
+
+# Single search() steps from a hand-made state (identify.py:231-372 / identify_low_mem.py:218-354 called directly by
+# make_golden.py).  The "both weak" branch (identify.py:264-273) tests `group[0].data[1] == 0`; access flags start at -1
+# and only a rejected LEAF is ever set to 0, after its group has left `pending` for good (a group enters `pending` once:
+# children are pushed when their parent is processed, every later push is guarded or belongs to this very branch) -- so
+# identify_cluster() can never take it.  The function is still there and its fall-through is behaviour, so it
+# is pinned at the function: category / access of some nodes overridden, `pending` given, one call, everything it touched
+# recorded.  name -> (sample, module, cutoff, {node: [category, access]}, pending as node ids)
+L1_STEPS = {
+    # two weak siblings, a third group waiting: the branch pushes both children lists and drops the group, falls through,
+    # the weak loop pushes the children AGAIN and the final `del pending[0]` removes the waiting group [11, 4]
+    "both_weak_third_group": ("E_mix", "identify", [0.1, 0.4, 1], {9: [0, 0], 3: [0, -1]}, [[9, 3], [11, 4]]),
+    # only group[0] is tested: the second node is strong, is matched and reported; nothing else waits, so the final
+    # delete removes the first children list the branch itself had pushed
+    "both_weak_second_strong": ("E_mix", "identify", [0.1, 0.4, 1], {11: [0, 0]}, [[11, 4]]),
+    "both_weak_low_mem": ("E_mix", "identify_low_mem", [0.05, 0.05, 1], {5: [0, 0]}, [[5, 6], [9, 3], [11, 4]]),
+}
 
 
 def build_l1(name, root_dir):
@@ -104,7 +163,7 @@ def build_l1(name, root_dir):
     db_dir = os.path.join(root_dir, "DB_" + name)
     info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["seed"], spec.get("singleton"),
                              spec.get("clusters"), spec.get("reconstructed", ()), spec.get("overlaps", ()),
-                             single_cluster=spec.get("single_cluster", False))
+                             single_cluster=spec.get("single_cluster", False), invalid_nodes=spec.get("invalid_nodes", ()))
     info["db_dir"] = db_dir
     return info
 
@@ -118,6 +177,9 @@ def sample_reads(info, sample_name):
             g = synth.rand_seq(rs, src[1])
         elif isinstance(src, tuple) and src[0] == "path":
             g = b"".join(info["node_seq"][i] for i in info["tree"].path(src[1]))
+        elif isinstance(src, tuple) and src[0] == "slice":           # the same fraction of every node on the leaf's path
+            g = b"N".join(info["node_seq"][i][int(src[2] * len(info["node_seq"][i])):int(src[3] * len(info["node_seq"][i]))]
+                          for i in info["tree"].path(src[1]))
         else:
             g = info["leaf_genome"][src]
         gd.append((g, depth))

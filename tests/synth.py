@@ -99,7 +99,7 @@ def treelib_pickle(parent, protocol=None):
 
 
 def build_l1_db(db_dir, parent, sites, seed, singleton=None, clusters=None, reconstructed=(),
-                overlaps=(), extra_rows=(), single_cluster=False):
+                overlaps=(), extra_rows=(), single_cluster=False, invalid_nodes=()):
     """Write <db_dir>/Tree_database.  Returns dict(tree, node_seq, leaf_genome, row_of_node).
 
     parent        {id: parent or None}; leaves must be 1..C, the root C+1, internal ids so that
@@ -111,6 +111,8 @@ def build_l1_db(db_dir, parent, sites, seed, singleton=None, clusters=None, reco
     reconstructed iterable of node ids
     overlaps      [(leaf_i, node_j, a, b)]: sites [a,b) of node_j also occur in leaf_i's genome
     extra_rows    [(position, text)] raw rows spliced into kmer.fa (not listed in any node)
+    invalid_nodes node ids whose every kmer.fa row carries an 'N': jellyfish never dumps them, so the node's valid
+                  length is 0 while node_length.txt still counts the rows (identify.py:298-303)
     """
     rs = np.random.RandomState(seed)
     singleton = singleton or {}
@@ -127,6 +129,8 @@ def build_l1_db(db_dir, parent, sites, seed, singleton=None, clusters=None, reco
         idx = []
         for p in range(sites[i]):
             km = s[p:p + K]
+            if i in invalid_nodes:
+                km = km[:15] + b"N" + km[16:]
             idx.append(len(rows)); rows.append(km)
             idx.append(len(rows)); rows.append(revcomp(km))
         row_of_node[i] = idx

@@ -139,3 +139,74 @@ def test_single_cluster_tree_pkl(tmp_path):
     p.write_bytes(pickle.dumps({"_nodes": {}}))
     with pytest.raises(ValueError):
         T.load_tree_pkl(str(p))
+
+
+def _run_step(spec, l1_dbs, l1_reads):
+    """One Walk.search() call from the hand-made state of a tests/scenarios.py L1_STEPS entry -> what make_golden.py
+    recorded from the reference's search()."""
+    from strainscan_amd import cst
+    sname, modname, cut, override, pend = spec
+    low_mem = modname == "identify_low_mem"
+    tdb = os.path.join(l1_dbs[sc.L1_SAMPLES[sname][0]]["db_dir"], "Tree_database")
+    pv = hl.OracleProvider(tdb, [l1_reads[sname][1]], upper=not low_mem)
+    lines = []
+    w = cst.Walk(pv, tdb, list(cut), cst.Params(low_mem=low_mem), out=lambda *a: lines.append(" ".join(str(x) for x in a)))
+    for nid, (cat, acc) in override.items():
+        w.tree.get_node(nid).data[0] = cat
+        w.tree.get_node(nid).data[1] = acc
+    w.pending[:] = [[w.tree.get_node(i) for i in g] for g in pend]
+    res_temp, err = [], None
+    try:
+        w.search(res_temp)
+    except Exception as e:
+        err = type(e).__name__
+    return dict(error=err, pending=[[n.identifier for n in g] for g in w.pending], res_temp=[n.identifier for n in res_temp],
+                qualified_parents=[n.identifier for n in w.qualified_parents],
+                data={str(n.identifier): list(n.data) for n in w.tree.all_nodes()},
+                length={str(n.identifier): v for n, v in w.length.items()}, cov={str(n.identifier): v for n, v in w.cov.items()},
+                abundance={str(n.identifier): v for n, v in w.abundance.items()}, stdout="\n".join(lines).splitlines())
+
+
+@pytest.mark.parametrize("stname", list(sc.L1_STEPS))
+def test_search_step_matches_reference(stname, golden_dir, l1_dbs, l1_reads):
+    """The "both weak" branch (identify.py:264-273) cannot be reached through identify_cluster (tests/scenarios.py says
+    why), so the reference's search() was called on a hand-made state and everything it touched recorded."""
+    with open(os.path.join(golden_dir, "l1_search_steps.json")) as f:
+        want = json.load(f)[stname]
+    got = _run_step(sc.L1_STEPS[stname], l1_dbs, l1_reads)
+    for key in ("error", "pending", "res_temp", "qualified_parents", "data"):
+        assert got[key] == want[key], (stname, key, got[key], want[key])
+    for key in ("length", "cov", "abundance"):
+        assert sorted(got[key]) == sorted(want[key]), (stname, key)
+        for n, v in want[key].items():
+            assert abs(float(got[key][n]) - float(v)) <= 1e-9 * max(1.0, abs(float(v))), (stname, key, n)
+    gl = [ln for ln in got["stdout"] if ln.strip()]
+    wl = [ln for ln in want["stdout"] if ln.strip()]
+    assert len(gl) == len(wl), (gl, wl)
+    for a, b in zip(gl, wl):
+        assert a == b or hl.parse_trace(a) == hl.parse_trace(b) != [], (a, b)
+
+
+# Statements of strainscan_amd/cst.py no scenario has to reach, each with its reason (fragments of the line text).
+CST_ALLOW = (
+    # ImageProvider is the device-side adapter: exercised by every -m gpu identification test, not here
+    "self.img", "image.node_stats()", 's["length"]',
+)
+
+
+def test_every_statement_of_the_walk_is_pinned(golden, golden_dir, l1_dbs, l1_reads):
+    """Coverage gate: under the golden scenarios -- the 18 samples x 4 cutoffs x 2 modules, the
+    three hand-made search() steps, the binomial table -- every statement of cst.py executes, so every branch of the walk
+    has been compared with what the reference did in the same situation.  A new branch without a scenario fails here."""
+    from strainscan_amd import cst
+    from tests import covgate
+    path = cst.__file__
+    with covgate.LineTrace(path) as tr:
+        for sname in sc.L1_SAMPLES:
+            test_walk_matches_reference(sname, golden, l1_dbs, l1_reads)
+        for stname in sc.L1_STEPS:
+            test_search_step_matches_reference(stname, golden_dir, l1_dbs, l1_reads)
+        assert cst.binom_sf(-1, 5, 0.995) == 1.0 and cst.binom_sf(5, 5, 0.995) == 0.0
+    miss = covgate.unvisited(tr, path, CST_ALLOW)
+    assert not miss, "statements of cst.py no golden scenario reaches:\n" + "\n".join("%d: %s" % m for m in miss)
+    assert len(CST_ALLOW) <= 5

@@ -627,3 +627,40 @@ def test_damaged_csr_files_raise_value_error(tmp_path):
     assert img.om_cols is None
     img.set_overlap(m._CSR(O.indptr, O.indices, O.data, O.shape))
     img.close()
+
+
+# Statements of the two layer-2 mirrors that no scenario has to reach, each with its reason (fragments of the line text).
+VOTE_ALLOW = ()
+DETECT_ALLOW = ()
+
+
+def test_every_statement_of_the_l2_mirrors_is_pinned(golden, golden_dir, l1_dbs, tmp_path, monkeypatch):
+    """Coverage gate for Vote_Strain_L2_Lasso_new_sp.py and
+    identify_strains_L2_Enet_Pscan_new_sp.py: under the golden layer-2 cases, the end-to-end reports and the multi-cluster
+    runs of this file every statement executes; a branch added without a scenario fails here."""
+    from strainscan_amd import Vote_Strain_L2_Lasso_new_sp as vote
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as det
+    from tests import covgate
+    with covgate.LineTrace(vote.__file__, det.__file__) as tr:
+        for name in sc.L2_CASES:
+            test_detect_strains(name, golden)
+        for sub, fn in (("e2e", lambda p: test_end_to_end_reports(golden_dir, l1_dbs, p)),
+                        ("three", lambda p: test_three_clusters_one_pass_equals_serial_loop(l1_dbs, p, monkeypatch)),
+                        ("cache", lambda p: test_cluster_image_cache(p, monkeypatch)),
+                        ("threads", lambda p: test_l2_batch_threads_equal_serial(p, monkeypatch)),
+                        ("bad", test_damaged_csr_files_raise_value_error),
+                        ("branches", lambda p: _l2_branch_scenarios(p, monkeypatch))):
+            d = tmp_path / sub
+            d.mkdir()
+            fn(d)
+    miss_v = covgate.unvisited(tr, vote.__file__, VOTE_ALLOW)
+    miss_d = covgate.unvisited(tr, det.__file__, DETECT_ALLOW)
+    msg = "\n".join(["Vote_Strain_L2_Lasso_new_sp.py:"] + ["%d: %s" % m for m in miss_v] +
+                    ["identify_strains_L2_Enet_Pscan_new_sp.py:"] + ["%d: %s" % m for m in miss_d])
+    assert not miss_v and not miss_d, "statements no layer-2 scenario reaches:\n" + msg
+    assert len(VOTE_ALLOW) <= 5 and len(DETECT_ALLOW) <= 5
+
+
+def _l2_branch_scenarios(tmp_path, monkeypatch):
+    """Scenarios that exist only to take the branches of the layer-2 mirrors the golden cases leave out; each compares
+    with the oracle's restatement or with the reference's documented behaviour."""

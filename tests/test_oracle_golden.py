@@ -66,13 +66,17 @@ def test_l1_counts_and_node_profiles(golden_dir, l1_dbs, l1_reads):
         # flat-stream counter (the format the device consumes) agrees with the FASTQ walker
         flat = synth.flat_bases_from_fastx(reads)
         rows = kfa.split(b"\n")[1::2]
-        keys = np.array([orc.encode_kmer(r.decode()) for r in rows], np.uint64)
-        assert np.array_equal(orc.count_flat(keys, 31, flat, threads=2), counts)
+        ok = np.array([b"N" not in r for r in rows])                       # database G: rows with an N are no keys at all
+        keys = np.array([orc.encode_kmer(r.decode()) for r, o in zip(rows, ok) if o], np.uint64)
+        assert np.array_equal(orc.count_flat(keys, 31, flat, threads=2), counts[ok]) and not counts[~ok].any()
         # root line of the reference's stdout trace: abundance | cov  length  (identify.py:240)
         run = g[sname]["runs"][0]
         assert run["module"] == "identify" and run["cutoff"] == [0.1, 0.4, 1]
         root = info["tree"].root
         tr = [t for t in run["trace"] if t[0] == root][0]
+        if tr[1:] == ["weak"]:                           # database E: a weak root is not matched at all (:252-261)
+            assert len(info["row_of_node"][root]) < 1000
+            continue
         st = orc.match_node(counts, valid, np.array(info["row_of_node"][root]))
         cov = st["n_kept"] / st["length"]
         ab = st["sum_kept"] / st["n_kept"] if (st["n_kept"] and cov >= 0.1) else 0.0
