@@ -8,7 +8,6 @@ over the whole read set (:354-372); here that is one device scan against the clu
 table, followed by strainscan_amd.identify_strains_L2_Enet_Pscan_new_sp.detect_strains.
 """
 import os
-import re
 import shutil
 from collections import defaultdict
 
@@ -251,7 +250,3 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
                     fut.result()                      # re-raises the first failure, in submission order
         print("- Generate final report ...")
         merge_res(out_dir, res)
-
-
-def parse_name(filename):
-    return re.split(r"\.", filename)[0]

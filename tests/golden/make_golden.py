@@ -333,6 +333,25 @@ def main():
                            final_report=open(os.path.join(outdir, "final_report.txt")).read())
     dump_json("e2e_reports.json", e2e)
 
+    # ---------------------------------------------------------------- vote_strain_L2_batch on hand-made layer-1 results
+    dbb, reads = sc.l2_batch_inputs(scratch)
+    fq = os.path.join(scratch, "l2_batch.fq")
+    open(fq, "wb").write(reads)
+    batch = dict(sha256=synth.sha256_of(reads), cases={})
+    for name, (res, l2_, emode) in sc.L2_BATCH_CASES.items():
+        outdir = os.path.join(scratch, "l2b_" + name)
+        os.makedirs(outdir)
+        _, err, _ = run_captured(vote.vote_strain_L2_batch, fq, "", dbb, outdir, 31, {k: dict(v) for k, v in res.items()},
+                                 l2_, 40, 0, emode)
+        files = {}
+        for r_, _, fs in os.walk(outdir):
+            for f_ in fs:
+                p_ = os.path.join(r_, f_)
+                files[os.path.relpath(p_, outdir)] = open(p_).read()
+        batch["cases"][name] = dict(error=err, files=files)
+        print("L2 batch", name, err, sorted(files))
+    dump_json("l2_batch.json", batch)
+
     # ---------------------------------------------------------------- seqpy.revcomp (oracle/_ref)
     refso = os.path.join(REPO, "oracle", "_ref")
     if os.path.isdir(refso):

@@ -233,3 +233,44 @@ def l2_case(name):
 
 
 L2_CASES = ["one", "two", "two_out", "three", "three_l2", "emode", "lowcov", "many"]
+
+
+# ------------------------------------------------------------------------------------------------
+# vote_strain_L2_batch on hand-made layer-1 results: the branches of Vote_Strain_L2_Lasso_new_sp.py:247-311, 417-438
+# the end-to-end samples leave out (one identified cluster -> `cp`; a strain below the evidence bar with and without
+# -e; a cluster whose regression comes back all zero -> no report, skipped by merge_res; a cluster without reads ->
+# the IndexError of np.percentile([]) at identify_strains_L2_Enet_Pscan_new_sp.py:114)
+# ------------------------------------------------------------------------------------------------
+def l2_batch_inputs(root):
+    """-> (db_dir, FASTQ bytes).  Clusters 1-4 of 5 have k-mer sets; 1: two strains at 16x / 6x, 2: one strain at 0.6x,
+    3: two strains at 30x / 11x plus 13 of its k-mers repeated 5000 times (reads of exactly 31 bases), 4: no reads."""
+    db = os.path.join(root, "dbL2B")
+    pres = [[1, 1, 0, 0, 1], [1, 0, 1, 0, 0], [0, 1, 1, 1, 0]]
+    c1 = synth.build_l2_cluster(db, 1, 5, ["GCF_1_0", "GCF_1_1", "GCF_1_2"], [1500, 1200, 1000, 1400, 900], pres, seed=81)
+    c2 = synth.build_l2_cluster(db, 2, 5, ["GCF_2_0", "GCF_2_1", "GCF_2_2"], [1500, 1200, 1000, 1400, 900], pres, seed=82)
+    c3 = synth.build_l2_cluster(db, 3, 5, ["GCF_3_0", "GCF_3_1"], [1300, 1100, 900], [[1, 1, 0], [1, 0, 1]], seed=83)
+    synth.build_l2_cluster(db, 4, 5, ["GCF_4_0", "GCF_4_1"], [1200, 1000, 800], [[1, 1, 0], [1, 0, 1]], seed=84)
+    mix = [(c1["strain_extra"]["GCF_1_0"], 16.0), (c1["strain_extra"]["GCF_1_2"], 6.0), (c2["strain_extra"]["GCF_2_1"], 0.6),
+           (c3["strain_extra"]["GCF_3_0"], 30.0), (c3["strain_extra"]["GCF_3_1"], 11.0)]
+    reads = synth.simulate_reads(mix, 505)
+    rs = np.random.RandomState(99)
+    kms = list(c3["kid"])
+    pick = [kms[i] for i in rs.choice(len(kms), 13, replace=False)]
+    reads += b"".join(b"@o%d\n%s\n+\n%s\n" % (i, km.encode(), b"I" * 31) * 5000 for i, km in enumerate(pick))
+    return db, reads
+
+
+def _l1_entry(cid, strain=0):
+    return dict(strain=strain, cls_ab=20.0 + cid, cls_cov=0.9, cls_per=0.25, s_ab=(4.0 if strain else 0),
+                cls_covered_num=10, cls_total_num=12)
+
+
+# name -> (layer-1 result dict, l2, emode)
+L2_BATCH_CASES = {
+    "one_cluster": ({1: _l1_entry(1)}, 0, 0),
+    "mixed": ({1: _l1_entry(1), 2: _l1_entry(2), 5: _l1_entry(5, "GCF_single")}, 1, 0),
+    "mixed_emode": ({1: _l1_entry(1), 2: _l1_entry(2), 5: _l1_entry(5, "GCF_single")}, 1, 1),
+    "empty_res": ({1: _l1_entry(1), 3: _l1_entry(3)}, 0, 0),
+    "no_reads": ({1: _l1_entry(1), 4: _l1_entry(4)}, 0, 0),
+    "only_no_reads": ({4: _l1_entry(4)}, 0, 0),
+}
