@@ -10,13 +10,17 @@ mix (strand 50/50, 0.5 % substitutions), all resident in HBM before the timed re
 orientations independently, rows scattered over kmer.fa -- what the reference's builder writes for a
 node above its cap (Build_tree.py:590-591); --db-shape contiguous keeps every k-mer of a stretch.
 
-One step = one pass of the hot path over the whole read batch on each GPU:
-    reset counters -> encode+probe+count kernel over the flat base block -> harvest (non-zero
+One step = one pass of the hot path over the whole read batch on each GPU, over the sample as the
+PRODUCT keeps it resident (records binned by the minimizer of their first k-mer at load time,
+ss_reorder.hip; `prepare` reports that once-per-sample cost and the rates including it):
+    reset counters -> encode+probe+count kernel over the resident read set -> harvest (non-zero
     counters to their node-list positions) -> [N > 1: RCCL exchange of the touched nodes' counts]
     -> per-node reductions (length / covered / outlier-cut sums for all 1645 nodes).
-`value` = reads of all ranks / max-over-ranks step time.  Weak scaling: every rank scans its
+`value` = reads of all ranks / max-over-ranks step time.  `file_order` = the same steps over the
+flat block in file order (--no-readset makes that the headline).  Weak scaling: every rank scans its
 own 20 M-read shard (reads shard, the table is replicated).  `python bench.py --gpus N` starts the
-N ranks itself; under torchrun it checks WORLD_SIZE == N.
+N ranks itself; under torchrun it checks WORLD_SIZE == N; at N > 1 `check.parity_across_ranks`
+compares the exchanged node statistics of a sample of every rank's reads with the oracle.
 
 Extra objects on the JSON line:
   roofline     -- the scan kernel against the HBM roof: algorithmic bytes per launch
@@ -565,6 +569,59 @@ def measure_config3(torch, dev, args, stream):
     return out
 
 
+def parity_across_ranks(torch, dist, dev, args, db, nodes, db_spec, reads, stream, rank, world, ssdist, n_sample=100_000):
+    """N > 1: an independent correctness signal for the sharded path, after the timed region.  Every rank runs the product's
+    step (binned resident set -> scan -> harvest -> exchange of the touched nodes -> node reductions) over its FIRST
+    `n_sample` reads; the ranks all-gather those blocks (15 MB each); rank 0 counts the concatenation with the oracle
+    (orc_count_flat: the checker, never the thing measured), reduces every node with orc_match_node and compares all
+    node statistics with the exchanged ones.  -> dict on rank 0 (None elsewhere)."""
+    from strainscan_amd import _lib
+    n_s = int(min(args.reads, n_sample))
+    block = reads[: n_s * (READ_LEN + 1)]
+    rs = _lib.ReadSet.from_flat_dev(block.data_ptr(), block.numel(), order=True)
+    stats = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
+    state = dict(nodes.__dict__)
+    ok = False
+    for _ in range(3):                                # the first exchange of a sample may only size the buffer
+        db.reset(stream)
+        rs.scan_into(db, stream)
+        nodes.harvest_dev(db, stream)
+        pe = ssdist.exchange_touched(nodes, stream=stream)
+        nodes.reduce_touched_dev(stats.data_ptr(), stream)
+        torch.cuda.synchronize()
+        if pe.complete():
+            ok = True
+            break
+    rs.close()
+    nodes.__dict__.update({k: v for k, v in state.items() if k == "_pack_cap"})     # the timed sample's buffer size stays
+    gathered = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(gathered, block.contiguous())
+    out = None
+    if rank == 0:
+        from oracle import oracle as orc
+        t0 = time.perf_counter()
+        flat = torch.cat(gathered).cpu().numpy()
+        threads = max(1, min(orc.lib().orc_omp_threads(), int(_lib.lib().ss_host_cpus())))
+        counts = orc.count_flat(db_spec["okeys"], K, flat, threads)
+        valid = np.ones(counts.size, np.uint8)
+        st = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
+        rows, off = db_spec["rows"].astype(np.int64), db_spec["row_off"].astype(np.int64)
+        bad = []
+        for h in range(db_spec["n_nodes"]):
+            o = orc.match_node(counts, valid, rows[off[h]:off[h + 1]])
+            got = (int(st[h]["length"]), int(st[h]["n_pos"]), int(st[h]["n_kept"]), int(st[h]["sum_kept"]))
+            want = (o["length"], o["n_pos"], o["n_kept"], o["sum_kept"])
+            if got != want or (o["n_pos"] and int(st[h]["median2"]) != int(round(2 * o["median"]))):
+                bad.append(h)
+        out = dict(ok=bool(ok and not bad), reads_per_rank=n_s, ranks=world, nodes_compared=int(db_spec["n_nodes"]),
+                   nodes_with_hits=int((st["n_pos"] > 0).sum()), total_hits=int(counts.astype(np.int64).sum()),
+                   nodes_differing=bad[:10], exchange_complete=bool(ok), oracle_s=round(time.perf_counter() - t0, 2),
+                   what="every rank: the product's step over its first %d reads; rank 0: oracle orc_count_flat + orc_match_node "
+                        "over the all-gathered blocks of all ranks vs the exchanged node statistics" % n_s)
+    del gathered
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -582,7 +639,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = sized for ~15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the untimed phase breakdown (text -> HBM, walk)")
-    ap.add_argument("--no-readset", action="store_true", help="skip the extra measurement over the product's resident read set")
+    ap.add_argument("--no-readset", action="store_true", help="time the flat block in FILE order as the headline (no binned resident read set; `value` up to round 4)")
     ap.add_argument("--phase-reads", type=int, default=4_000_000, help="reads of the FASTQ sample written for the phase breakdown")
     ap.add_argument("--gz-reads", type=int, default=1_000_000, help="reads of the .fastq.gz pair of the phase breakdown (0 = skip)")
     ap.add_argument("--no-config3", action="store_true", help="skip the cluster_scan / l2_solve blocks (BASELINE configs[3])")
@@ -710,98 +767,24 @@ def main(argv=None):
     log("[bench] reads: %d x %d bp = %.2f GB in HBM (%.1f s)" % (args.reads, READ_LEN, reads.numel() / 1e9,
                                                                  time.time() - t0))
 
-    # One step = reset the counters -> scan kernel -> harvest (one streaming pass over the counters: the non-zero ones
-    # go to their node-list positions, their nodes are flagged) -> [N > 1: RCCL exchange of the touched nodes: flags
-    # MAX-all-reduced, their segments packed, SUM-all-reduced, unpacked] -> per-node reductions.
+    # One step = reset the counters -> scan kernel over the sample AS THE PRODUCT KEEPS IT RESIDENT (ss_reads: records binned by
+    # the minimizer of their first k-mer when the sample is loaded, ss_reorder.hip -- strainscan_amd/db.py resident_reads, what
+    # every scan of identify_cluster / vote_strain_L2 runs over) -> harvest (one streaming pass over the counters: the non-zero
+    # ones go to their node-list positions, their nodes are flagged) -> [N > 1: RCCL exchange of the touched nodes: flags
+    # MAX-all-reduced, their segments packed, SUM-all-reduced, unpacked] -> per-node reductions.  The binning belongs to the
+    # LOAD of a sample (once, whatever the number of scans): timed before the timed region and reported as `prepare`, with
+    # the rate a sample of one, two and three scans sees.  The same steps over the block in FILE order (what `value` was up
+    # to round 4) are timed afterwards and reported as `file_order`.
     from strainscan_amd import dist as ssdist
     nodes.bind(db)
     stats = torch.zeros(db_spec["n_nodes"] * 32, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(5)) for _ in range(args.steps)]
     exchange = world > 1 or self_group
     packed = dict(n=0, cap=0, pending=[])
+    binned = not args.no_readset and not args.calib_stream
 
-    def step(i=None):
-        db.reset(stream)
-        if i is not None:
-            ev[i][0].record()
-        db.scan_flat_dev(reads.data_ptr(), reads.numel(), stream)
-        if i is not None:
-            ev[i][1].record()
-        nodes.harvest_dev(db, stream)
-        if i is not None:
-            ev[i][2].record()
-        if exchange:
-            # no host round trip inside: the packed buffer's size was decided by the previous exchange of this node set
-            packed["pending"].append(ssdist.exchange_touched(nodes, stream=stream))
-        if i is not None:
-            ev[i][3].record()
-        nodes.reduce_touched_dev(stats.data_ptr(), stream)
-        if i is not None:
-            ev[i][4].record()
-
-    def settle_exchanges():
-        """After a synchronisation: did every exchange carry all its counts?  (The first one of a node set sizes the buffer;
-        NodeSet.harvest repeats such a scan's harvest + exchange, here the steps are simply run again.)"""
-        ok = True
-        for pe in packed["pending"]:
-            ok = pe.complete() and ok
-            packed["n"], packed["cap"] = pe.total(), pe.cap
-        packed["pending"] = []
-        return ok
-
-    if exchange:
-        step()
-        torch.cuda.synchronize()
-        settle_exchanges()                       # learns the buffer size for this sample
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if exchange and not settle_exchanges():
-        raise SystemExit("bench.py: the exchange buffer did not settle during warm-up")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_per_step = dt / args.steps * 1e3
-    reads_per_s = args.reads * world * args.steps / dt
-    if exchange and not settle_exchanges():
-        raise SystemExit("bench.py: an exchange inside the timed region did not carry all counts")
-    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    harvest_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    exch_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))     # N > 1: flags + pack + all-reduce + unpack
-    reduce_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in ev]))   # node reductions
-    tail_ms = exch_ms + reduce_ms
-    st_np = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
-    # the counters of the last step are still in the table (a step resets them at its start): whole-table checksum,
-    # and the harvest path against the row-gather path it replaces (ss_counts_rows_dev + ss_nodes_reduce_dev)
-    counts_rows = torch.zeros(n_rows, dtype=torch.int32, device=dev)
-    db.counts_rows_dev(counts_rows.data_ptr(), stream)
-    hits = int(counts_rows.to(torch.int64).sum().item())
-    stats2 = torch.zeros_like(stats)
-    if exchange:
-        ssdist.allreduce_counts(counts_rows)
-    nodes.reduce_dev(counts_rows.data_ptr(), db.row_valid_dev, stats2.data_ptr(), stream)
-    torch.cuda.synchronize()
-    harvest_equals_gather = bool(torch.equal(stats, stats2))
-
-    # The same steps over the sample as the PRODUCT keeps it resident (ss_reads: records binned by the minimizer of their first
-    # k-mer at load time, ss_reorder.hip -- the loader's default), reported beside `value`, which stays the scan of the block in
-    # FILE order.  Binning is paid once per sample at load time; it is timed here (wall clock, allocations included).
-    readset = None
-    if not args.no_readset and not args.calib_stream:
-        prep, prep_parts = [], []
+    rs_loc, prep, prep_parts = None, [], []
+    if binned:
         rs_all = []
         for _ in range(5):                          # first call: first touch of 3 GB of fresh device memory
             # (the five sets stay alive until all are made: freeing a 3 GB slab right before the next one is allocated --
@@ -817,118 +800,184 @@ def main(argv=None):
         rs_loc = rs_all.pop()
         for r_ in rs_all:
             r_.close()
-        # (the MEDIAN of five is reported as prepare_ms, the best and all five beside it: the call allocates the new 3 GB slab and
-        #  frees 0.2 GB of scratch, and on a box whose host is busy with other tenants one such driver call now and then takes
-        #  60-150 ms -- seen in three bench runs out of eight, always together with a slower cpu_baseline; the kernels' share is
-        #  3.6 ms: profiles/r03_reorder_kernel_stats.csv)
-        prep_ms = float(np.median(prep))
-        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-        def step_rs(i=None):
+    def make_step(scan, ev, out_stats):
+        def step(i=None):
             db.reset(stream)
             if i is not None:
-                ev2[i][0].record()
-            rs_loc.scan_into(db, stream)
+                ev[i][0].record()
+            scan()
             if i is not None:
-                ev2[i][1].record()
+                ev[i][1].record()
             nodes.harvest_dev(db, stream)
+            if i is not None:
+                ev[i][2].record()
             if exchange:
+                # no host round trip inside: the packed buffer's size was decided by the previous exchange of this node set
                 packed["pending"].append(ssdist.exchange_touched(nodes, stream=stream))
-            nodes.reduce_touched_dev(stats2.data_ptr(), stream)
+            if i is not None:
+                ev[i][3].record()
+            nodes.reduce_touched_dev(out_stats.data_ptr(), stream)
+            if i is not None:
+                ev[i][4].record()
+        return step
 
+    def settle_exchanges():
+        """After a synchronisation: did every exchange carry all its counts?  (The first one of a node set sizes the buffer;
+        NodeSet.harvest repeats such a scan's harvest + exchange, here the steps are simply run again.)"""
+        ok = True
+        for pe in packed["pending"]:
+            ok = pe.complete() and ok
+            packed["n"], packed["cap"] = pe.total(), pe.cap
+        packed["pending"] = []
+        return ok
+
+    def run_timed(scan, out_stats):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over the ranks.
+        -> (seconds, mean ms of scan kernel / harvest / exchange / node reductions from HIP events on the launch stream)"""
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(5)) for _ in range(args.steps)]
+        step = make_step(scan, ev, out_stats)
+        if exchange:
+            step()
+            torch.cuda.synchronize()
+            settle_exchanges()                       # learns the buffer size for this sample
         for _ in range(args.warmup):
-            step_rs()
+            step()
+        torch.cuda.synchronize()
+        if exchange and not settle_exchanges():
+            raise SystemExit("bench.py: the exchange buffer did not settle during warm-up")
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        t0 = time.perf_counter()
         for i in range(args.steps):
-            step_rs(i)
+            step(i)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
+        dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt2 = float(tt.item())
-        k2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
-        readset = dict(order="locality (records binned by the minimizer of their first k-mer, ~4 records per bin: ss_reorder.hip)",
-                       prepare_ms=round(prep_ms, 2), prepare_ms_best=round(float(np.min(prep)), 2),
-                       prepare_breakdown_ms=dict(zip(("count_and_prefix", "slab_allocation", "place"), [round(float(x), 2) for x in np.median(np.array(prep_parts), axis=0)]),
-                                                 note="medians of the five calls; slab_allocation is the driver's hipMalloc of the 3 GB output slab: 0.25-0.35 ms as a "
-                                                      "rule, 60-150 ms per call on some boxes (all five calls then); prepare_ms_kernels = count_and_prefix + place, "
-                                                      "the binning's own work"),
-                       prepare_ms_kernels=round(float(np.median(np.array(prep_parts), axis=0)[[0, 2]].sum()), 2), prepare_ms_first_call=round(prep[0], 2), prepare_ms_all=[round(x, 2) for x in prep], ms_per_step=round(dt2 / args.steps * 1e3, 3),
-                       value=round(args.reads * world * args.steps / dt2 / 1e6, 3), unit="M reads/s", kernel_ms=round(k2, 3),
-                       frac_algorithmic=round(args.reads * BYTES_PER_READ / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                       node_stats_equal=bool(torch.equal(stats, stats2)),
-                       policy="always (SS_READS_ORDER=file keeps the file order): binning pays from the SECOND scan of a sample on -- "
-                              "the tree scan and one cluster scan, or the two scans of -b; a sample whose clusters are all single-strain "
-                              "is scanned once and loses prepare_ms - (file-order kernel - binned kernel) per 20 M reads, ~1.5 ms "
-                              "on the sampled shape, beside a text ingest of ~80 ms for the same reads",
-                       note="what the CLI scans by default: a sample is parsed and shipped "
-                            "once, binned once (prepare_ms, ~4 % of the text ingest of the same reads), scanned by the tree scan and by "
-                            "every cluster scan; the gain grows with the coverage of the sample (these reads cover a 70/20/10 three-strain "
-                            "mix ~400/115/60 fold; sweep over 5x / 40x / 400x / a metagenome: profiles/r03_locality_sweep.json)")
-        rs_loc.close()
-        # counters of the BINNED scan (separate --pmc passes, scripts/r4/gpu_pmc_round.sh): reported only while the live
-        # kernel time is within 5 % of the one they were collected at
-        pmc_b = {}
-        pmc_path_b = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path_b) and args.reads == 20_000_000 and args.leaves == 823:
-            with open(pmc_path_b) as f:
-                pmc_b = json.load(f).get("%s:%s:%g:binned" % (os.environ.get("SS_LAYOUT", "mini"), args.db_shape, args.hit_frac), {})
-        ms_b = pmc_b.get("kernel_ms_at_collection")
-        if pmc_b and ms_b and abs(k2 - ms_b) <= 0.05 * ms_b:
-            tr = pmc_b["traffic_gb_per_launch"]
-            comp = (args.reads * (READ_LEN + 2) + 8.0 * hits) / 1e9      # every base once (152 B per binned record) + 8 B per hit
-            readset.update(traffic=tr, traffic_unit="GB per launch", hbm_frac_measured=round(tr / (k2 * 1e-3) / HBM_PEAK_GBS, 4),
-                           compulsory_gb=round(comp, 3), traffic_over_compulsory=round(tr / comp, 2), valu_busy=pmc_b.get("valu_busy"),
-                           valu_insts_per_tile=pmc_b.get("valu_insts_per_tile"), read_requests_per_launch=pmc_b.get("rdreq_per_launch"),
-                           traffic_source=dict(file="profiles/pmc_traffic.json", summary=pmc_b.get("source"), commit=pmc_b.get("commit"),
-                                               kernel_ms_at_collection=ms_b))
-        else:
-            readset.update(traffic=None, traffic_source=(dict(stale=True, kernel_ms_at_collection=ms_b) if pmc_b else None))
+            dt = float(tt.item())
+        if exchange and not settle_exchanges():
+            raise SystemExit("bench.py: an exchange inside the timed region did not carry all counts")
+        return dt, [float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev])) for j in range(4)]
 
-    achieved = args.reads * BYTES_PER_READ / (kern_ms * 1e-3) / 1e9
-    # Counter-derived figures come from separate rocprofv3 --pmc passes of THIS command (scripts/gpu_round.sh writes
-    # profiles/pmc_traffic.json, one entry per database shape and hit fraction, with the commit they were taken at):
-    # PMC collection serialises kernels and cannot run inside the timed region.
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    pmc_key = "%s:%s:%g" % (layout, args.db_shape, args.hit_frac)
-    if os.path.exists(pmc_path) and args.reads == 20_000_000 and args.leaves == 823:
-        with open(pmc_path) as f:
-            pmc = json.load(f).get(pmc_key, {})
-    # ... and they describe THIS kernel only while it still runs as it did when they were collected: if the live kernel time
-    # has moved by more than 5 % from the one recorded with them, they are not reported (traffic = null)
-    pmc_ms = pmc.get("kernel_ms_at_collection")
-    pmc_stale = bool(pmc) and pmc_ms is not None and abs(kern_ms - pmc_ms) > 0.05 * pmc_ms
-    if pmc_stale:
-        log("[bench] profiles/pmc_traffic.json[%s] was collected at %.3f ms per launch, the kernel now takes %.3f ms: counters not reported"
-            % (pmc_key, pmc_ms, kern_ms))
-        pmc = dict(stale=True, kernel_ms_at_collection=pmc_ms, source=pmc.get("source"), commit=pmc.get("commit"))
-    traffic = pmc.get("traffic_gb_per_launch")
-    compulsory_gb = (reads.numel() + 8.0 * hits) / 1e9          # every base once + 4 B read + 4 B write per hit
-    roofline = dict(bound="hbm", kernel="scan_mini_kernel" if layout == "mini" else "scan_kernel",
-                    achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_unit="GB per launch",
-                    kernel_ms=round(kern_ms, 3), bytes_per_read=BYTES_PER_READ,
-                    frac_algorithmic=round(achieved / HBM_PEAK_GBS, 5),
-                    hbm_frac_measured=(round(traffic / (kern_ms * 1e-3) / HBM_PEAK_GBS, 4) if traffic else None),
-                    compulsory_gb=round(compulsory_gb, 3),
-                    traffic_over_compulsory=(round(traffic / compulsory_gb, 2) if traffic else None),
-                    valu_busy=pmc.get("valu_busy"),
-                    random_sectors=dict(
-                        note="what bounds the lookups: random 64-byte sectors, ~55 G/s on this chip from any footprint beyond "
-                             "the L2 (scripts/micro/randsec.hip, profiles/r02_randsec.txt)",
-                        peak_gsectors_s=RANDOM_SECTOR_PEAK_G,
-                        read_requests_per_launch=pmc.get("rdreq_per_launch"),
-                        achieved_gsectors_s=(round(pmc["rdreq_per_launch"] / (kern_ms * 1e-3) / 1e9, 1) if pmc.get("rdreq_per_launch") else None)),
-                    traffic_source=(dict(file="profiles/pmc_traffic.json", key=pmc_key, summary=pmc.get("source"),
-                                         commit=pmc.get("commit"), kernel_ms_at_collection=pmc_ms, stale=pmc_stale) if pmc else None))
+    def scan_file():
+        db.scan_flat_dev(reads.data_ptr(), reads.numel(), stream)
+
+    def scan_binned():
+        rs_loc.scan_into(db, stream)
+
+    dt, (kern_ms, harvest_ms, exch_ms, reduce_ms) = run_timed(scan_binned if binned else scan_file, stats)
+    ms_per_step = dt / args.steps * 1e3
+    reads_per_s = args.reads * world * args.steps / dt
+    tail_ms = exch_ms + reduce_ms
+    st_np = stats.cpu().numpy().view(_lib.NODE_STAT_DTYPE)
+    # the counters of the last step are still in the table (a step resets them at its start): whole-table checksum,
+    # and the harvest path against the row-gather path it replaces (ss_counts_rows_dev + ss_nodes_reduce_dev)
+    counts_rows = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    db.counts_rows_dev(counts_rows.data_ptr(), stream)
+    hits = int(counts_rows.to(torch.int64).sum().item())
+    stats2 = torch.zeros_like(stats)
+    if exchange:
+        ssdist.allreduce_counts(counts_rows)
+    nodes.reduce_dev(counts_rows.data_ptr(), db.row_valid_dev, stats2.data_ptr(), stream)
+    torch.cuda.synchronize()
+    harvest_equals_gather = bool(torch.equal(stats, stats2))
+
+    def pmc_entry(key):
+        """Counter-derived figures come from separate rocprofv3 --pmc passes of THIS command (scripts/gpu_round.sh writes
+        profiles/pmc_traffic.json, one entry per database shape, hit fraction and read order, with the commit they were taken
+        at): PMC collection serialises kernels and cannot run inside the timed region."""
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(path) and args.reads == 20_000_000 and args.leaves == 823:
+            with open(path) as f:
+                return json.load(f).get(key, {})
+        return {}
+
+    def roofline_of(k_ms, pmc, pmc_key, bytes_per_record):
+        """The scan kernel against the HBM roof by SURVEY 8(d)'s model (1110 algorithmic bytes per read), with the measured
+        side beside it.  The counters describe THIS kernel only while it still runs as it did when they were collected: if
+        the live kernel time has moved by more than 5 % from the one recorded with them they are not reported."""
+        achieved = args.reads * BYTES_PER_READ / (k_ms * 1e-3) / 1e9
+        pmc_ms = pmc.get("kernel_ms_at_collection")
+        stale = bool(pmc) and pmc_ms is not None and abs(k_ms - pmc_ms) > 0.05 * pmc_ms
+        if stale:
+            log("[bench] profiles/pmc_traffic.json[%s] was collected at %.3f ms per launch, the kernel now takes %.3f ms: counters not reported"
+                % (pmc_key, pmc_ms, k_ms))
+            pmc = dict(source=pmc.get("source"), commit=pmc.get("commit"))
+        traffic = pmc.get("traffic_gb_per_launch")
+        compulsory_gb = (args.reads * bytes_per_record + 8.0 * hits) / 1e9      # every base once + 4 B read + 4 B write per hit
+        frac = achieved / HBM_PEAK_GBS
+        hbm_meas = round(traffic / (k_ms * 1e-3) / HBM_PEAK_GBS, 4) if traffic else None
+        rf = dict(bound="hbm", kernel="scan_mini_kernel" if layout == "mini" else "scan_kernel",
+                  achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(frac, 5), traffic=traffic,
+                  traffic_unit="GB per launch", kernel_ms=round(k_ms, 3), bytes_per_read=BYTES_PER_READ,
+                  frac_algorithmic=round(frac, 5), hbm_frac_measured=hbm_meas, compulsory_gb=round(compulsory_gb, 3),
+                  traffic_over_compulsory=(round(traffic / compulsory_gb, 2) if traffic else None),
+                  valu_busy=pmc.get("valu_busy"), valu_insts_per_tile=pmc.get("valu_insts_per_tile"),
+                  random_sectors=dict(
+                      note="what bounds the lookups of a scan in file order: random 64-byte sectors, ~55 G/s on this chip from "
+                           "any footprint beyond the L2 (scripts/micro/randsec.hip, profiles/r02_randsec.txt)",
+                      peak_gsectors_s=RANDOM_SECTOR_PEAK_G, read_requests_per_launch=pmc.get("rdreq_per_launch"),
+                      achieved_gsectors_s=(round(pmc["rdreq_per_launch"] / (k_ms * 1e-3) / 1e9, 1) if pmc.get("rdreq_per_launch") else None)),
+                  traffic_source=(dict(file="profiles/pmc_traffic.json", key=pmc_key, summary=pmc.get("source"), commit=pmc.get("commit"),
+                                       kernel_ms_at_collection=pmc_ms, stale=stale) if pmc else None))
+        # SURVEY 8(d) prices a read at 120 probes x 8 B; a minimizer index answers the ~9 k-mers of a run with ONE lookup,
+        # so on a fast shape the model's bytes exceed what any kernel would move and `frac` stops being a fraction of a roof
+        rf["model_saturated"] = bool(frac > 0.9 and (hbm_meas is None or hbm_meas < 0.6 * frac))
+        if rf["model_saturated"]:
+            rf["model_note"] = ("8(d)'s 1110 B per read is saturated by the minimizer index on this shape: the work is done (counts checked "
+                                "in this run) with far fewer bytes; what bounds the kernel is VALU issue (valu_busy), measured HBM use is "
+                                "hbm_frac_measured")
+        return rf
+
+    pmc_base = "%s:%s:%g" % (layout, args.db_shape, args.hit_frac)
+    head_key = pmc_base + (":binned" if binned else "")
+    roofline = roofline_of(kern_ms, pmc_entry(head_key), head_key, READ_LEN + (2 if binned else 1))
+    roofline["read_order"] = "binned (the product's resident read set)" if binned else "file"
+
+    prepare, file_order = None, None
+    if binned:
+        prep_ms = float(np.median(prep))
+        parts_med = np.median(np.array(prep_parts), axis=0)
+        step_s = dt / args.steps
+
+        def with_prepare(n_scans):
+            return round(args.reads * world / (step_s + prep_ms * 1e-3 / n_scans) / 1e6, 1)
+
+        # (the MEDIAN of five is reported, the best and all five beside it: the call allocates the new 3 GB slab and frees 0.2 GB
+        #  of scratch, and on a box whose host is busy with other tenants one such driver call now and then takes 60-150 ms)
+        prepare = dict(what="binning of the resident records by the minimizer of their first k-mer, ~4 records per bin (ss_reorder.hip)",
+                       charged="once per sample, at load time, outside the timed steps",
+                       ms=round(prep_ms, 2), ms_best=round(float(np.min(prep)), 2), ms_first_call=round(prep[0], 2), ms_all=[round(x, 2) for x in prep],
+                       ms_kernels=round(float(parts_med[[0, 2]].sum()), 2),
+                       breakdown_ms=dict(zip(("count_and_prefix", "slab_allocation", "place"), [round(float(x), 2) for x in parts_med])),
+                       scans_per_sample=dict(note="the tree scan, + one scan per group of <= 4 identified multi-strain clusters "
+                                                  "(ss_scan_reads_multi), + 2 more with -b (identify_low_depth.py:119,124)",
+                                             all_clusters_single_strain=1, one_to_four_multi_strain_clusters=2, low_depth_b=3),
+                       m_reads_per_s_including_prepare={"1_scan": with_prepare(1), "2_scans": with_prepare(2), "3_scans": with_prepare(3)},
+                       policy="always (SS_READS_ORDER=file keeps the file order): binning pays from the SECOND scan of a sample on; a "
+                              "sample scanned once loses prepare.ms - (file_order.ms_per_step - ms_per_step), beside a text ingest of "
+                              "~80 ms for the same reads")
+        stats_f = torch.zeros_like(stats)
+        dt_f, (k_f, h_f, x_f, r_f) = run_timed(scan_file, stats_f)
+        torch.cuda.synchronize()
+        file_order = dict(what="the same steps over the flat block in FILE order (`value` up to round 4; SS_READS_ORDER=file)",
+                          ms_per_step=round(dt_f / args.steps * 1e3, 3), value=round(args.reads * world * args.steps / dt_f / 1e6, 3),
+                          unit="M reads/s", node_stats_equal=bool(torch.equal(stats, stats_f)),
+                          roofline=roofline_of(k_f, pmc_entry(pmc_base), pmc_base, READ_LEN + 1),
+                          step_breakdown_ms=dict(scan_kernel=round(k_f, 3), harvest=round(h_f, 3),
+                                                 exchange=round(x_f, 3) if exchange else None, node_reduce=round(r_f, 3)))
+    parity_ranks = None
+    if world > 1:
+        parity_ranks = parity_across_ranks(torch, dist, dev, args, db, nodes, db_spec, reads, stream, rank, world, ssdist)
+    if rs_loc is not None:
+        rs_loc.close()
+        rs_loc = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
@@ -963,8 +1012,14 @@ def main(argv=None):
             cpu["sample_8_threads"] = "first %d reads" % n8
         # and use it as a checker on that sample (never the other way round)
         db.reset(stream)
-        db.scan_flat_dev(reads.data_ptr(), n_s * (READ_LEN + 1), stream)
-        torch.cuda.synchronize()
+        if binned:                                   # through what the product scans: the binned resident set of the sample
+            sub = _lib.ReadSet.from_flat_dev(reads.data_ptr(), n_s * (READ_LEN + 1), order=True)
+            sub.scan_into(db, stream)
+            torch.cuda.synchronize()
+            sub.close()
+        else:
+            db.scan_flat_dev(reads.data_ptr(), n_s * (READ_LEN + 1), stream)
+            torch.cuda.synchronize()
         chk = db.counts_rows()
         cpu["parity_on_sample"] = bool(np.array_equal(chk, got))
 
@@ -999,12 +1054,15 @@ def main(argv=None):
                                index=dict(pages=info.get("n_dir"), bucket_slots=info.get("n_mslots"), inline_kmers=info.get("n_inline"),
                                           filter_bits=info.get("filter_bits"), device_gb=round(info["device_bytes"] / 1e9, 3)),
                                table_layout=layout,
+                               read_order=("binned resident read set (what the product scans: strainscan_amd/db.py resident_reads)" if binned
+                                           else "file order (flat block)"),
                                parallelism="reads sharded x%d, table replicated, all-reduce of the touched nodes' hit counts" % world),
-                   roofline=roofline, cpu_baseline=cpu, phases=phases, resident_read_set=readset,
+                   roofline=roofline, cpu_baseline=cpu, phases=phases, prepare=prepare, file_order=file_order,
                    cluster_scan=(config3 or {}).get("cluster_scan"), l2_solve=(config3 or {}).get("l2_solve"),
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
-                              harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"]),
+                              harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"],
+                              parity_across_ranks=parity_ranks),
                    step_breakdown_ms=dict(scan_kernel=round(kern_ms, 3), harvest=round(harvest_ms, 3),
                                           exchange=round(exch_ms, 3) if exchange else None, node_reduce=round(reduce_ms, 3)))
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

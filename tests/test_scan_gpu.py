@@ -856,8 +856,17 @@ def test_bench_line_contract_and_exchange_path():
         assert len(lines) == 1
         d = json.loads(lines[0])
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                    "dtype", "data", "config", "roofline", "cpu_baseline", "phases", "e2e_reads_per_s", "cluster_scan", "l2_solve"):
+                    "dtype", "data", "config", "roofline", "cpu_baseline", "phases", "e2e_reads_per_s", "cluster_scan", "l2_solve",
+                    "prepare", "file_order"):
             assert key in d, key
+        # the headline is the path the product runs: the binned resident read set; file order beside it, the binning's
+        # once-per-sample cost and the rates that include it
+        assert d["config"]["read_order"].startswith("binned") and d["roofline"]["read_order"].startswith("binned")
+        fo, pr = d["file_order"], d["prepare"]
+        assert fo["node_stats_equal"] is True and fo["value"] > 0 and fo["roofline"]["kernel_ms"] > 0
+        assert pr["ms"] > 0 and len(pr["ms_all"]) == 5 and pr["scans_per_sample"]["all_clusters_single_strain"] == 1
+        assert pr["m_reads_per_s_including_prepare"]["1_scan"] < pr["m_reads_per_s_including_prepare"]["3_scans"] < d["value"]
+        assert abs(d["value"] - 300000 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
         # BASELINE configs[3] beside the headline: the cluster scan (both read orders, counts equal, oracle on a sub-sample)
         # and the layer-2 solve (phases, abundances against the oracle on a sub-sample of the rows)
         cs, l2s = d["cluster_scan"], d["l2_solve"]
@@ -886,6 +895,11 @@ def test_bench_line_contract_and_exchange_path():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["check"]["harvest_equals_gather"] is True
     assert d["check"]["exchanged_counts"] > 0 and d["cpu_baseline"] is None
+    # ... and an independent correctness signal at N > 1: the exchanged node statistics of every rank's first reads against
+    # the oracle over the all-gathered blocks
+    par = d["check"]["parity_across_ranks"]
+    assert par["ok"] is True and par["ranks"] == 2 and par["nodes_compared"] == 45 and par["nodes_with_hits"] > 0 and par["total_hits"] > 0
+    assert par["exchange_complete"] is True and par["nodes_differing"] == []
     assert abs(d["value"] - 2 * 300000 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
     # what a first 8-GPU run needs: the all-reduce phase reported on its own, the exchange buffer sized without a host
     # round trip (and large enough: the counts all travelled), rank 0's index image imported by the other ranks
