@@ -185,6 +185,12 @@ int ss_db_index_info(const ss_db *db, uint64_t out[8]);
  * for a resident read set in locality order, add the hits of neighbouring reads up in LDS before they go to the counters
  * (ss_mini.hip: a global atomic costs the same whatever it carries, 27 G line requests/s on MI355X). */
 int ss_db_expect_hits(ss_db *db, int expect);
+/* What the scan of a binned resident read set (ss_reads) learnt about a table nobody has flagged: the set's first 8192
+ * tiles run through the plain kernel and report their found runs; at 8 per tile and above the rest of the set goes through
+ * the combining kernel (hits added up in LDS).  out[0] = serial of the read set last probed (0: none yet), [1] = 1 when the
+ * combining kernel was chosen, [2] = found runs per tile, times 1000.  One probe per (read set, table); no reference
+ * counterpart (jellyfish has one counting loop). */
+int ss_db_probe_info(const ss_db *db, uint64_t out[3]);
 
 /* --------------------------------------------------------------------------------------------
  * The scan  (the `jellyfish count` + `dump -c` pair of identify.py:82-87,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ss_db_device_bytes": (u64, [vp]),
     "ss_db_index_info": (i32, [vp, vp]),
     "ss_db_expect_hits": (i32, [vp, i32]),
+    "ss_db_probe_info": (i32, [vp, vp]),
     "ss_scan_reads_multi": (i32, [vp, i32, vp, vp]),
     "ss_scan_reset": (i32, [vp, vp]),
     "ss_scan_flat_dev": (i32, [vp, vp, u64, vp]),
@@ -337,6 +338,12 @@ class KmerDB:
         """Hint: most read k-mers are in this table (a layer-2 cluster table)."""
         check(lib().ss_db_expect_hits(self._h, 1 if expect else 0), "ss_db_expect_hits")
         return self
+
+    def probe_info(self):
+        """What the last binned scan's probe found for this table: dict(set, comb, runs_per_tile)."""
+        out = np.zeros(3, np.uint64)
+        check(lib().ss_db_probe_info(self._h, ptr(out)), "ss_db_probe_info")
+        return dict(set=int(out[0]), comb=bool(out[1]), runs_per_tile=float(out[2]) / 1000.0)
 
     def reset(self, stream=None):
         check(lib().ss_scan_reset(self._h, stream), "ss_scan_reset")

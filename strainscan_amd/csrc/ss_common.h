@@ -89,6 +89,9 @@ struct ss_db {
     uint64_t n_buckets = 0;
     uint32_t *d_counts = nullptr;      // [n_slots] occurrences per slot (accumulated by scans)
     int expect_hits = 0;               // ss_db_expect_hits: most read k-mers are in the table (a layer-2 cluster table)
+    uint64_t probe_set = 0;            // the resident read set (ss_reads::serial) whose first tiles were last probed against this
+    int probe_comb = 0;                // table, and what they said: add the hits up in LDS (ss_mini.hip choose_comb)
+    double probe_runs_per_tile = 0;    // found runs per tile of that probe (ss_db_info_ex)
     uint32_t *d_slot_of_row = nullptr; // [n_rows]   slot owning row i, SS_NO_SLOT if none
     uint8_t *d_row_valid = nullptr;    // [n_rows]   1 iff row i is a key of match_results
     // pinned staging for host-resident base blocks
@@ -123,6 +126,8 @@ struct ss_reads {
     uint64_t n_records = 0, n_bases = 0, device_bytes = 0, n_blocks = 0;
     bool has_cut_record = false;      // a record longer than a block was cut with a 30-base overlap (k = 31 only)
     uint64_t first_slab = 0;          // size of the first slab (estimate from the file sizes)
+    uint64_t serial = next_serial();  // names this set: a table remembers which set it was last probed with
+    static uint64_t next_serial() { static std::atomic<uint64_t> c{0}; return ++c; }
 
     static uint64_t padded(uint64_t len) { return (len + 1 + 15) & ~15ull; }
     // a flat block that is already on the device (hipMalloc'ed, padded as above) becomes a slab of its own
@@ -220,8 +225,9 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
 int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_records, uint64_t *n_bases, bool *handled,
                        int shard_rank = 0, int shard_world = 1);
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
-                     uint64_t n_tiles, bool binned = false);
+                     uint64_t n_tiles, bool binned = false, uint64_t set_id = 0);
 int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, uint64_t n, hipStream_t stream, bool binned);
 // ss_scan_flat_dev for a block whose records ss_reorder.hip has binned by locus (the scan may add hits up in LDS first)
-int scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned);
+// (set_id: ss_reads::serial of the resident set the block belongs to, 0 = none)
+int scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned, uint64_t set_id = 0);
 }  // namespace ss

@@ -848,7 +848,7 @@ int ss_scan_reads(ss_db *db, const ss_reads *R, void *stream)
     if (R->has_cut_record && k != 31) return SS_ERANGE;   // cut records carry a 30-base overlap
     for (const auto &sl : R->slabs) {
         if (!sl.used) continue;
-        int rc = ss::scan_flat_dev(db, sl.d, sl.used, stream, sl.binned);
+        int rc = ss::scan_flat_dev(db, sl.d, sl.used, stream, sl.binned, R->serial);
         if (rc) return rc;
     }
     return SS_OK;
@@ -875,7 +875,7 @@ int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *R, void *s
         const int ng = (int)std::min<size_t>((size_t)group, mini.size() - g);
         for (const auto &sl : R->slabs) {
             if (!sl.used) continue;
-            int rc = ng == 1 ? ss::scan_flat_dev(mini[g], sl.d, sl.used, stream, sl.binned)
+            int rc = ng == 1 ? ss::scan_flat_dev(mini[g], sl.d, sl.used, stream, sl.binned, R->serial)
                              : (sl.used < 31 ? SS_OK : ss::launch_scan_mini_multi(&mini[g], ng, sl.d, sl.used, ss::as_stream(stream), sl.binned));
             if (rc) return rc;
         }

@@ -276,6 +276,9 @@ __device__ __forceinline__ uint32_t shift_in_ne(uint32_t m, uint32_t a, uint32_t
     return m;
 }
 
+// found runs of a probe launch (choose_comb), 64 words so that the tiles' single atomics do not queue on one address
+__device__ uint32_t ss_probe_runs[64];
+
 #ifdef SS_COMB_STATS
 // debug build: what the combining scan did -- [0] tiles, [1] flushes, [2] entries flushed, [3] counters flushed, [4] found runs,
 // [5] runs without an entry, [6] flushes because the table was full; and the trip counts of every scan's loops (for the
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
     // ONE 4 MB L2 instead of eight.  (The grid is a multiple of 8 then; every XCD gets the same number of tiles.)
     // A workgroup takes CH consecutive tiles, then the next CH `stride` chunks further on (CH = 1: a plain grid stride)
     uint64_t tile = (uint64_t)blockIdx.x * CH, tile_end = n_tiles, stride = gridDim.x, tile0 = 0;
-    if (xcd_swizzle) {
+    if (xcd_swizzle & 1u) {
         const uint64_t per = (((n_tiles + 7) >> 3) + CH - 1) / CH * CH, x = blockIdx.x & 7u;
         stride = gridDim.x >> 3;
         tile0 = x * per;
@@ -711,6 +714,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #endif
             constexpr int U3 = SS_U3;
             const uint32_t n2 = min(S.cnt[1], (uint32_t)Q1CAP);
+            // a probe launch (choose_comb: the first tiles of a binned set against a table nobody has flagged) reports its found runs
+            if (!COMB && (xcd_swizzle & 2u) && t == 0) atomicAdd(&ss_probe_runs[blockIdx.x & 63u], n2);
             bool comb_full = false;
             if (COMB) {
                 // every found run claims the LDS entry of its bucket (the runs of a locus' reads share theirs); a byte
@@ -1217,11 +1222,12 @@ int mark_solid(ss_db *db)
 
 template <int LB>
 static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stream, const uint8_t *bases, uint64_t n,
-                      uint64_t n_tiles, ss_db *db)
+                      uint64_t n_tiles, ss_db *db, bool probe = false)
 {
     const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
     const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
-    static const uint32_t swz = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
+    static const uint32_t swz0 = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
+    const uint32_t swz = swz0 | (probe ? 2u : 0u);
     const ScanTabs none = {};
 #define SS_LAUNCH(A, B, C_) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
                                                db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none)
@@ -1287,10 +1293,23 @@ extern "C" int ss_debug_timing(unsigned long long *out32, int reset)
 }
 #endif
 
-int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
-                     uint64_t n_tiles, bool binned)
+// Which kernel scans a BINNED block (ss_reorder.hip: the reads of a locus lie together) against this table: the plain one,
+// whose every hit is a global atomic, or the combining one (COMB: the hits of four consecutive tiles are added up in LDS
+// first).  With few hits the plain kernel is the faster (tree tables at their usual 5 % of the read k-mers: 3.8 vs 4.5 ms
+// per 20 M reads on sampled node sets, 2.7 vs 3.2 on contiguous ones); with many, the same-address atomics of a locus'
+// reads queue up and the combining one wins by up to 3x (half of the read k-mers in the table: 17.1 -> 10.6 ms sampled,
+// 14.8 -> 4.9 contiguous; file order 14.1 / 10.2; profiles/r05_ab_log.md 1).  The caller's flag (ss_db_expect_hits: the table of
+// an identified cluster) is a hint that saves the probe; every other table is asked: its first PROBE_TILES tiles run
+// through the plain kernel with the probe bit set -- they count for real, the main launch starts behind them -- and
+// report their found runs (minimizers of the reads that have a bucket in the table); at PROBE_RUNS_PER_TILE and above
+// the rest of the block, and every later block of the same read set, goes through the combining kernel.  One probe per
+// (read set, table): ~40 us and one stream synchronisation on the first scan of a sample against a table.
+constexpr uint64_t PROBE_TILES = 8192;          // one wave per tile: one round of the chip's 8192 wave slots
+constexpr double PROBE_RUNS_PER_TILE = 8.0;     // measured crossover: 4 (plain wins by 15 %) ... 8-10 (even) ... 16 (COMB by 30 %)
+static std::mutex probe_mu;                     // the probe's device words are one set per process
+
+static int launch_plain_or_comb(ss_db *db, bool comb, bool probe, const uint8_t *b, uint64_t n, uint64_t n_tiles, hipStream_t stream)
 {
-    const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
     static int lb = -1, bpc = 0;
     if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
         const char *e = getenv("SS_MINI_LB");
@@ -1298,27 +1317,57 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
         const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
         bpc = g ? atoi(g) : 0;
     }
-    n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 62 x 16 positions
+    const bool aligned = (((uintptr_t)b) & 15) == 0;
     // grid-stride over tiles with MANY more blocks than fit the chip: short blocks start at scattered times, so
     // the waves sharing a SIMD stop marching through their ALU and memory phases in step.  Measured with 8 waves
     // per SIMD resident (20 M reads = 3.04 M tiles; blocks = x * 1024): x = 8 (one round of resident blocks)
     // 4.03 ms, 32: 3.76, 128: 3.59, 512: 3.55, 2048 (1.5 tiles per block): 3.50, 4096 (one tile each): 3.51
-    // hits added up in LDS before they go to the counters (QComb): tables that expect hits, reads binned by locus
-    // (SS_COMBINE=0 never, =1 for every scan of such a table)
-    static const int comb_env = [] { const char *e = getenv("SS_COMBINE"); return e ? atoi(e) : -1; }();
-    const bool comb = db->expect_hits && (comb_env < 0 ? binned : comb_env != 0);
     const uint64_t units = comb ? (n_tiles + COMB_CH - 1) / COMB_CH : n_tiles;
-    blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
+    unsigned blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
     blocks = (blocks + 7u) & ~7u;                           // a multiple of 8: the same number of workgroups on every XCD
-    const uint8_t *b = (const uint8_t *)bases_dev;
     // (the combining variant needs 71 VGPRs: at 8 waves per SIMD it would spill four of them to scratch)
     switch (lb ? lb : comb ? 6 : 8) {
-    case 4: launch_lb<4>(aligned, comb, blocks, stream, b, n, n_tiles, db); break;
-    case 6: launch_lb<6>(aligned, comb, blocks, stream, b, n, n_tiles, db); break;
-    default: launch_lb<8>(aligned, comb, blocks, stream, b, n, n_tiles, db); break;
+    case 4: launch_lb<4>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe); break;
+    case 6: launch_lb<6>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe); break;
+    default: launch_lb<8>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe); break;
     }
     SS_HIP(hipGetLastError());
     return SS_OK;
+}
+
+int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned /*blocks*/,
+                     uint64_t n_tiles, bool binned, uint64_t set_id)
+{
+    n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 62 x 16 positions
+    const uint8_t *b = (const uint8_t *)bases_dev;
+    // SS_COMBINE (A/B runs and tests): 0 never, 1 every scan of a table that expects hits -- binned or not --, 2 every binned scan
+    static const int comb_env = [] { const char *e = getenv("SS_COMBINE"); return e ? atoi(e) : -1; }();
+    bool comb = false;
+    if (comb_env >= 0) comb = comb_env == 2 ? binned : (db->expect_hits && comb_env != 0);
+    else if (!binned) comb = false;
+    else if (db->expect_hits) comb = true;
+    else if (set_id && db->probe_set == set_id) comb = db->probe_comb != 0;
+    else if (n_tiles >= 4 * PROBE_TILES) {
+        std::lock_guard<std::mutex> g(probe_mu);
+        uint32_t runs[64];
+        void *sym = nullptr;
+        SS_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(ss_probe_runs)));
+        SS_HIP(hipMemsetAsync(sym, 0, sizeof(runs), stream));
+        int rc = launch_plain_or_comb(db, false, true, b, n, PROBE_TILES, stream);      // (n: the last tile's k-mers reach beyond it)
+        if (rc) return rc;
+        SS_HIP(hipMemcpyAsync(runs, sym, sizeof(runs), hipMemcpyDeviceToHost, stream));
+        SS_HIP(hipStreamSynchronize(stream));
+        uint64_t total = 0;
+        for (uint32_t r : runs) total += r;
+        db->probe_runs_per_tile = (double)total / (double)PROBE_TILES;
+        comb = db->probe_runs_per_tile >= PROBE_RUNS_PER_TILE;
+        db->probe_comb = comb;
+        db->probe_set = set_id;
+        b += PROBE_TILES * (uint64_t)MTILE;                 // (a multiple of 16 bytes: the alignment of the block is kept)
+        n -= PROBE_TILES * (uint64_t)MTILE;
+        n_tiles -= PROBE_TILES;
+    }
+    return launch_plain_or_comb(db, comb, false, b, n, n_tiles, stream);
 }
 
 }  // namespace ss

@@ -393,11 +393,20 @@ int ss_db_expect_hits(ss_db *db, int expect)
     return SS_OK;
 }
 
+int ss_db_probe_info(const ss_db *db, uint64_t out[3])
+{
+    if (!db || !out) return SS_EINVAL;
+    out[0] = db->probe_set;
+    out[1] = db->probe_comb ? 1 : 0;
+    out[2] = (uint64_t)(db->probe_runs_per_tile * 1000.0 + 0.5);
+    return SS_OK;
+}
+
 int ss_scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream) { return ss::scan_flat_dev(db, bases_dev, n, stream, false); }
 
 }  // extern "C"
 
-int ss::scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned)
+int ss::scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned, uint64_t set_id)
 {
     if (!db || (n && !bases_dev)) return SS_EINVAL;
     if (n < (uint64_t)db->k) return SS_OK;
@@ -405,7 +414,7 @@ int ss::scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream
     const uint64_t max_blocks = (uint64_t)cu_count() * 8;
     const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, max_blocks);
     if (db->layout == 1) {
-        int rc = ss::launch_scan_mini(db, bases_dev, n, ss::as_stream(stream), blocks, n_tiles, binned);
+        int rc = ss::launch_scan_mini(db, bases_dev, n, ss::as_stream(stream), blocks, n_tiles, binned, set_id);
         if (rc == SS_OK) db->launches++;
         return rc;
     }

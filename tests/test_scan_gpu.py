@@ -1208,6 +1208,64 @@ def test_hits_combined_tiny_queues_and_file_order():
         assert out.returncode == 0 and "comb ok" in out.stdout, (env, out.stderr[-2000:])
 
 
+@pytest.mark.parametrize("shape,hit_frac,want_comb", [("sampled", 0.5, True), ("contiguous", 0.3, True), ("sampled", 0.02, False),
+                                                       ("contiguous", 0.03, False)])
+def test_combining_kernel_chosen_from_the_data(L, shape, hit_frac, want_comb):
+    """A TREE table (no ss_db_expect_hits) under a binned read set: the first 8192 tiles of the set run through the plain
+    kernel and report their found runs, the rest goes through the combining kernel when they are many (ss_mini.hip
+    choose: >= 8 per tile) -- a hit-heavy tree table is no longer at the mercy of a flag only layer 2 sets.  Counts equal
+    the file-order scan's whichever kernel ran (the probe tiles count for real, the main launch starts behind them), equal
+    the oracle's on the first reads; one probe per (read set, table): a second scan of the same set reuses the answer, a new
+    set asks again; a flagged table is never probed."""
+    import torch
+    import bench
+    from oracle import oracle as orc
+    dev = torch.device("cuda", 0)
+    spec = bench.make_db(torch, dev, 23, seed=77, lo_sites=2000, hi_sites=9000, shape=shape, hit_frac=hit_frac)
+    n_reads = 450_000                                           # 68 M positions = 68 K tiles: more than four probes' worth
+    reads = bench.make_reads(torch, dev, spec, n_reads, seed=5, hit_frac=hit_frac)
+    db = L.KmerDB(spec["keys"], np.ones(spec["keys"].size, np.uint8), 31, True)
+    assert db.probe_info() == dict(set=0, comb=False, runs_per_tile=0.0)
+    db.scan_flat_dev(reads.data_ptr(), reads.numel())
+    L.check(L.lib().ss_device_sync(), "sync")
+    want = db.counts_rows()
+    assert db.probe_info()["set"] == 0                          # file order: nothing to decide
+    rs = L.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
+    for rep in range(2):
+        db.reset()
+        rs.scan_into(db)
+        L.check(L.lib().ss_device_sync(), "sync")
+        assert np.array_equal(db.counts_rows(), want), (shape, hit_frac, rep)
+        pi = db.probe_info()
+        assert pi["set"] != 0 and pi["comb"] is want_comb, pi
+        assert (pi["runs_per_tile"] >= 8.0) is want_comb
+        if rep == 0:
+            first = pi
+        else:
+            assert pi == first                                  # the second scan of the set did not ask again
+    rs2 = L.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
+    db.reset()
+    rs2.scan_into(db)
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db.counts_rows(), want) and db.probe_info()["set"] not in (0, first["set"])
+    # the oracle on the first reads, through a set small enough that NO probe runs (fewer than four probes' worth of tiles)
+    n_s = 40_000
+    got = orc.count_flat(spec["okeys"], 31, reads[: n_s * 151].cpu().numpy(), 4)
+    sub = L.ReadSet.from_flat_dev(reads.data_ptr(), n_s * 151, order=True)
+    before = db.probe_info()
+    db.reset()
+    sub.scan_into(db)
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db.counts_rows(), got) and db.probe_info() == before
+    # a flagged table: the hint decides, nobody asks
+    db2 = L.KmerDB(spec["keys"], np.ones(spec["keys"].size, np.uint8), 31, True).expect_hits()
+    rs.scan_into(db2)
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db2.counts_rows(), want) and db2.probe_info()["set"] == 0
+    for x in (rs, rs2, sub, db, db2):
+        x.close()
+
+
 def test_scan_reads_multi_equals_single_scans(L):
     """ss_scan_reads_multi: several tables in one pass over a resident read set -- counts equal to ss_scan_reads on each
     (five tables = two launches; tables that overlap in their k-mers; with and without the hit hint; binned and file order;
