@@ -435,6 +435,7 @@ def measure_config3(torch, dev, args, stream):
     db.expect_hits(False)
     t_bin_plain = kernel_ms(lambda: rs.scan_into(db, stream), db)
     equal = equal and bool(np.array_equal(db.counts_rows(), want))
+    probe_plain = db.probe_info()
     db.expect_hits(True)
     # three identified clusters: their tables in ONE pass over the reads (ss_scan_reads_multi) against a scan per table, as
     # the reference's loop does (Vote_Strain_L2_Lasso_new_sp.py:295-296); the two other tables are other genomes' k-mers
@@ -486,7 +487,9 @@ def measure_config3(torch, dev, args, stream):
         hits=hits, hits_per_read=round(hits / n_reads, 1),
         file_order=dict(kernel_ms=round(t_file, 3), **fracs(t_file, hits)),
         binned=dict(kernel_ms=round(t_bin, 3), **fracs(t_bin, hits), m_reads_per_s=round(n_reads / t_bin / 1e3, 1)),
-        binned_without_lds_combining=dict(kernel_ms=round(t_bin_plain, 3), **fracs(t_bin_plain, hits)),
+        binned_unflagged=dict(kernel_ms=round(t_bin_plain, 3), **fracs(t_bin_plain, hits), probe=probe_plain,
+                              note="the same table without ss_db_expect_hits: the read set's first 8192 tiles report their found runs and "
+                                   "the scan picks the combining kernel itself (ss_db_probe_info)"),
         three_tables=dict(one_pass_ms=round(t_one, 3), scan_per_table_ms=round(t_sep, 3), one_table_ms=round(t_bin, 3),
                           one_pass_over_one_table=round(t_one / t_bin, 3), counts_equal=equal3,
                           note="the cluster's table + two other genomes' tables of the same size, the same binned reads"),

@@ -168,6 +168,7 @@ constexpr int COMB_CH = 4;             // consecutive tiles per workgroup
 constexpr uint32_t COMB_NONE = 0xFFu;
 struct QComb {
     uint32_t key[COMB_NE];             // bucket start + 1, 0 = free
+    uint32_t nrun[COMB_NE];            // found runs that took this entry since the last flush (a byte counter holds 255)
     uint32_t acc[COMB_NE][5];          // byte o = occurrences of the bucket's slot o (1..19; slot 0 is the header)
     uint8_t ent[Q1CAP];                // per found run of the tile: its entry, COMB_NONE = count in global memory
     uint8_t list[COMB_NE];             // flush: the occupied entries
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
     uint32_t comb_runs = 0;                          // found runs added to the LDS counters since their last flush
     if (COMB) {
         C.key[t] = 0u;
+        C.nrun[t] = 0u;
 #pragma unroll
         for (int w = 0; w < 5; w++) C.acc[t][w] = 0u;
     }
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         __syncthreads();
         if (key) {
             C.key[t] = 0u;
+            C.nrun[t] = 0u;
 #pragma unroll
             for (int w = 0; w < 5; w++) C.acc[t][w] = 0u;
         }
@@ -719,9 +722,11 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             bool comb_full = false;
             if (COMB) {
                 // every found run claims the LDS entry of its bucket (the runs of a locus' reads share theirs); a byte
-                // counter takes at most one from a run, so the table is flushed before 255 runs have gone into it
+                // counter takes at most one from a run and an ENTRY takes 255 runs between two flushes (round 5: counted per
+                // entry -- a bucket sees the ~7 reads of its locus per tile; the bound used to be 255 runs for the whole table,
+                // a flush every 2.4 tiles), the run that finds its entry full counts in global memory like one without an entry.
+                // The table is flushed when the workgroup leaves its CH consecutive tiles (the next ones are other loci).
                 SS_T(10);
-                if (comb_runs + n2 > 255u) { comb_flush(); SS_T(8); }
                 comb_runs += n2;
                 for (uint32_t r = (uint32_t)t; r < n2; r += MT) {
                     const uint32_t key = (((uint32_t)(S.q2[r] >> 32) & ss::START_MASK) | tab_key) + 1u;
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     static_assert(COMB_NE == 64, "hash: top six bits");
                     for (int pr = 0; pr < 8; pr++) {
                         const uint32_t old = atomicCAS(&C.key[i], 0u, key);
-                        if (old == 0u || old == key) { e = i; break; }
+                        if (old == 0u || old == key) { e = atomicAdd(&C.nrun[i], 1u) < 255u ? i : COMB_NONE; break; }
                         i = (i + 1u) & (COMB_NE - 1u);
                     }
                     C.ent[r] = (uint8_t)e;
@@ -874,6 +879,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         SS_T(4);
         __syncthreads();   // queues and codes are rewritten by the next tile
         SS_T(5);
+        if (COMB && CH > 1 && comb_runs && ((tile + 1 - tile0) % CH) == 0) { comb_flush(); SS_T(8); }      // the chunk ends: other loci next
     }
     if (COMB && comb_runs) comb_flush();
 #ifdef SS_TIMING
@@ -1229,7 +1235,8 @@ static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stre
     static const uint32_t swz0 = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
     const uint32_t swz = swz0 | (probe ? 2u : 0u);
     const ScanTabs none = {};
-#define SS_LAUNCH(A, B, C_) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
+    // (the combining variant needs 79 VGPRs: there is no 8-waves-per-SIMD build of it -- it carried 32 bytes of scratch)
+#define SS_LAUNCH(A, B, C_) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (C_ && LB > 6) ? 6 : LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
                                                db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none)
     // a table that expects hits (ss_db_expect_hits) skips its Bloom filter: nearly every minimizer of the reads is in it
     if (comb)             { if (aligned) SS_LAUNCH(true, false, true); else SS_LAUNCH(false, false, true); }

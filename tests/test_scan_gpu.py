@@ -871,7 +871,7 @@ def test_bench_line_contract_and_exchange_path():
         # and the layer-2 solve (phases, abundances against the oracle on a sub-sample of the rows)
         cs, l2s = d["cluster_scan"], d["l2_solve"]
         assert cs["counts_equal_across_orders"] is True and cs["parity_on_sample"] is True and cs["hits"] > 0
-        for k_ in ("file_order", "binned", "binned_without_lds_combining"):
+        for k_ in ("file_order", "binned", "binned_unflagged"):
             assert cs[k_]["kernel_ms"] > 0 and 0 < cs[k_]["frac"] < cs[k_]["frac_with_hit_bytes"]
         assert l2s["prescan_equal"] is True and l2s["abundance_max_abs_diff"] < 1e-5 and l2s["wall_ms"] > 0
         assert len(l2s["selected"]) >= 2 and "pattern_stats" in l2s["phases_ms"] and "pre_scan" in l2s["phases_ms"]
