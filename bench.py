@@ -543,6 +543,31 @@ def measure_config3(torch, dev, args, stream):
     t0 = time.perf_counter()
     L2.shuffle_split_test_bits(trace["n_rows"], 20, 0.5, 0)
     split_ms = (time.perf_counter() - t0) * 1e3
+    # four clusters of this size solved at once, as vote_strain_L2_batch does on its "ss-l2" threads once cluster_counts_many
+    # has every cluster's counts (Vote_Strain_L2_Lasso_new_sp.py:295-296 is a serial loop): the same bit planes, four samples
+    from concurrent.futures import ThreadPoolExecutor
+    ys4 = [y] + [np.where((v := rs_.poisson(lam * f)) == 1, 0, v).astype(np.int64) for f in (0.8, 1.3, 0.6)]
+    npp4 = [float(np.median(v[v != 0]) * 1000) for v in ys4]
+
+    def solve_one(i):
+        img_ = L2.ClusterImage.from_planes(planes, Kc, S)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                return m.detect_core(None, om, ids, ys4[i].copy(), K, 0, npp4[i], npp4[i], 0.9, [1], 0, 40, 0, 0, img=img_)
+        finally:
+            img_.close()
+
+    walls4, res4 = [], None
+    with ThreadPoolExecutor(max_workers=4, thread_name_prefix="ss-l2") as pool4:
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res4 = list(pool4.map(solve_one, range(4)))
+            walls4.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter()
+    one_by_one = [solve_one(i) for i in range(4)]
+    serial4_ms = (time.perf_counter() - t0) * 1e3
+    same4 = all([dict(a) for a in r_a] == [dict(b) for b in r_b] for r_a, r_b in zip(res4, one_by_one))
     # sub-sample of the rows through the product and through the oracle
     Ks = min(Kc, args.l2_check_rows)
     Xs = sp.csr_matrix(pres[:, seg[:Ks]].T.astype(np.int8))
@@ -565,6 +590,10 @@ def measure_config3(torch, dev, args, stream):
         wall_note="median of the calls (the first one warms buffers up); phases_ms are the last call's",
         phases_ms={k_: round(v, 2) for k_, v in tm.items()},
         shuffle_split_generator_ms=round(split_ms, 2),
+        four_clusters=dict(wall_ms=round(sorted(walls4)[len(walls4) // 2], 2), wall_ms_all=[round(w, 2) for w in walls4],
+                           one_by_one_ms=round(serial4_ms, 2), equal_to_one_by_one=bool(same4),
+                           note="four samples of the same %d x %d cluster solved at once on four host threads (image upload from "
+                                "the host planes included in each), against the same four one after the other" % (Kc, S)),
         selected=list(res[0].keys()), rel=[round(float(v), 6) for v in res[0].values()],
         abundance_max_abs_diff=float(np.abs(got - rel).max()),
         prescan_equal=bool(names == list(r2[2].keys()) and {k_: int(v) for k_, v in r2[3].items()} == {k_: int(v) for k_, v in sval.items()}),

@@ -18,6 +18,7 @@
 #include <atomic>
 #include <memory>
 #include <string>
+#include <condition_variable>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -427,15 +428,17 @@ namespace {
 // sink(partners, count) in stream order, a few thousand at a time (`buf`: CH + BLK + 16 words); otherwise the stream is only
 // moved past the split's words -- that is all the splits have in common, the rest of a split's work is its own.
 constexpr uint32_t SPLIT_CH = 2048;
+// `stop` (>= 1): the walk ends once row `stop` has its partner -- a worker needs the rows from n - 1 down to n_test only (see
+// split_worker); the walker of the shared stream passes 1 and goes through all of them.
 template <bool STORE, bool SIMD, class Sink>
-void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink)
+void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink, uint64_t stop = 1)
 {
     uint32_t fill = 0;
-    for (uint64_t hi = n - 1; hi >= 1;) {
+    for (uint64_t hi = n - 1; hi >= stop;) {
         // all i in (mask >> 1, hi] share the mask: the next power of two above i, minus one
         uint32_t mask = (uint32_t)hi;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        const uint64_t lo = (uint64_t)(mask >> 1) + 1;
+        const uint64_t lo = std::max<uint64_t>((uint64_t)(mask >> 1) + 1, stop);
         for (uint64_t i = hi; i >= lo;) {
             // at most `room` words can be consumed before i drops below lo: no bound check on i inside
             const uint64_t room = i - lo + 1;
@@ -486,6 +489,10 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, uint
     if (!xp || !buf) { g_words.put(xp, n); return SS_ENOMEM; }
     for (uint64_t i = 0; i < n; i++) xp[i] = (uint32_t)i;
     uint64_t i = n - 1;
+    // Fisher-Yates from the top: the swap of row i touches row i and a row below it, so once i has gone below n_test the swaps
+    // only move elements about INSIDE the first n_test places -- the test SET, all the caller asks for, is complete when row
+    // n_test has been placed.  The worker stops its walk and its swaps there (round 5: half of both; only the walker of the
+    // shared stream has to pass the remaining words, to know where the next split begins).
     walk_split<true, SIMD>(*rng, n, buf.get(), [&](const uint32_t *p, uint32_t cnt) {
         // (the partners are known ahead: their cache lines are requested early -- 20 MB of x do not fit L2)
         // (... 64 swaps early: 24 / 48 / 64 / 96 / 128 ahead gave workers of 10 / 8 / 8 / 8 / 7 ms and the whole call 29.9 / 27.2 / 27.4 /
@@ -498,7 +505,7 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, uint
             xp[i] = xp[j];
             xp[j] = a;
         }
-    });
+    }, std::max<uint64_t>(1, n_test));
     // the test set as a bitmap of the split's own (n / 8 bytes: it stays in this core's L2; atomic ORs into the shared
     // 32-bit words -- half of the rows, from every worker at once -- were as long as the swaps)
     memset(bitmap, 0, ((n + 63) / 64) * sizeof(uint64_t));
@@ -539,6 +546,21 @@ void merge_bitmaps_base(const uint64_t *bm, uint64_t words, int n_splits, uint64
 }  // namespace
 }  // extern "C++"
 
+namespace {
+// Host cores shared between the ShuffleSplit calls of one process (round 5: the clusters of a sample are solved at once, each
+// call = one walker of the shared stream + a swap thread per split): a thread takes a core for as long as it computes, so that
+// four calls do not put 4 x 15 threads on 16 cores and slow each other's walkers -- the critical path -- down.
+struct CoreSlots {
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_ = (int)std::max(2u, ss::host_cpus());
+    void take() { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return free_ > 0; }); free_--; }
+    void give() { { std::lock_guard<std::mutex> g(mu); free_++; } cv.notify_one(); }
+};
+CoreSlots g_cores;
+struct CoreGuard { CoreGuard() { g_cores.take(); } ~CoreGuard() { g_cores.give(); } };
+}  // namespace
+
 int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, uint32_t *bits)
 {
     if (n_splits < 1 || n_splits > 31 || n_test > n || n > 0xFFFFFFFFull || (n && !bits)) return SS_EINVAL;
@@ -564,10 +586,13 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
     std::vector<std::thread> pool((size_t)n_splits);
     std::vector<std::pair<double, double>> t_worker((size_t)n_splits);             // (trace: when every worker began and ended)
     std::atomic<int> err(SS_OK);
+    std::unique_ptr<CoreGuard> walker_core(new CoreGuard());                          // the walker's own core, until the stream is walked
     for (int f = 0; f < n_splits; f++) {
         if (f >= (int)in_flight) {                                                   // bounds the memory: in_flight x 4 n bytes
             const auto t0 = std::chrono::steady_clock::now();
+            walker_core.reset();                                                     // (a thread that waits holds no core)
             pool[(size_t)f - in_flight].join();
+            walker_core.reset(new CoreGuard());
             t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
         // the split's worker starts from a snapshot of the stream at the split's first word and goes through the split's draws
@@ -576,6 +601,7 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         if (!snap) { err = SS_ENOMEM; pool[(size_t)f] = std::thread([] {}); break; }
         uint64_t *my_bm = bm + (uint64_t)f * bm_words;
         pool[(size_t)f] = std::thread([snap, n, n_test, f, my_bm, &err, &t_worker, t_begin] {
+            CoreGuard core;
             const double w0 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             const int rc = simd ? split_worker<true>(std::unique_ptr<MTWords>(snap), n, n_test, my_bm) : split_worker<false>(std::unique_ptr<MTWords>(snap), n, n_test, my_bm);
             if (rc != SS_OK) err = rc;
@@ -587,6 +613,7 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         }
     }
     const double t_gen = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    walker_core.reset();
     for (auto &th : pool) if (th.joinable()) th.join();
     const double t_workers = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (err == SS_OK) {

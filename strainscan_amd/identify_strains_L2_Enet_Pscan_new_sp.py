@@ -19,7 +19,10 @@ CV_NITER = 20        # :433
 NALPHA = 50          # :434
 MAX_NITER = 5000     # :435
 TEST_SIZE = 0.5      # :436
-_SPLIT_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ss-shufflesplit")
+# one ShuffleSplit per cluster being solved (vote_strain_L2_batch runs up to four clusters at once on its "ss-l2" threads): the
+# walks over the shared stream are one core each and independent, so N clusters wait for the longest walk, not for the sum
+# (round 5; the native side hands out the host's cores between the calls: ss_host.hip CoreSlots)
+_SPLIT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ss-shufflesplit")
 MAX_PRESCAN_ITER = 15  # :302
 
 

@@ -365,6 +365,33 @@ def test_detect_core_at_config3_size(case):
         assert "S003" in res and "S057" in res          # both near-duplicates are reported
 
 
+def test_four_clusters_solved_at_once_equal_one_by_one():
+    """Four large clusters (500 k rows each: the ShuffleSplit of each runs on the split pool, n_keep >= 200 000) solved
+    concurrently on four host threads -- as vote_strain_L2_batch does -- give what they give one after the other: the
+    splits of different clusters share nothing but the host's cores (ss_host.hip CoreSlots)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    cases = []
+    for i, (K, depths) in enumerate(((500_000, {3: 30.0, 17: 11.0}), (430_001, {5: 22.0, 9: 9.0, 30: 4.0}), (611_777, {1: 14.0, 2: 7.0}),
+                                     (500_000, {8: 40.0, 33: 6.0}))):
+        X, O, ids, y = _big_cluster(K, 40, depths, seed=20 + i, G=48)
+        cases.append((X.tocsr(), O, ids, y, float(np.median(y[y != 0]) * 1000)))
+
+    def solve(c):
+        X, O, ids, y, npp = c
+        tr = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = m.detect_core(X, O, ids, y.copy(), 31, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=tr)
+        return [dict(x) for x in out], tr["alphas_"].tolist(), tr["mse_path_"].tolist(), tr["n_rows"]
+
+    serial = [solve(c) for c in cases]
+    assert all(s[3] >= 200_000 and len(s[0][0]) >= 2 for s in serial)
+    for _ in range(2):
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            together = list(pool.map(solve, cases))
+        assert together == serial
+
+
 @pytest.mark.parametrize("p,n_folds", [(1, 20), (3, 20), (5, 20), (6, 20), (4, 30), (7, 20), (11, 5), (12, 3)])
 def test_pattern_stats_both_kernels(p, n_folds):
     """ss_l2_pattern_stats against numpy: {count, sum y, sum y^2} per p-bit row pattern for every fold's test half and for
