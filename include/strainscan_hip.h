@@ -355,6 +355,17 @@ int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel,
                   uint32_t *y_dev, uint32_t *yu_dev, uint32_t *G_dev, uint32_t *Gu_dev, uint32_t *keep_dev, uint32_t *ykeep_dev,
                   uint64_t out[3]);
 int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, uint64_t n_keep, uint32_t *fold_dev);
+/* ShuffleSplit(n_splits, test_size, random_state = seed) of scikit-learn (identify_strains_L2_Enet_Pscan_new_sp.py:433-442) with the
+ * swaps on the device: the host walks the one sequential MT19937 word stream of the 20 permutations on a thread of its own and
+ * hands each split's partners of the rows n - 1 .. n_test to the device, which finds every row's final element without
+ * replaying the swap chain (ss_host.hip).  start returns at once; wait joins, synchronises and gives uint32[n] ON THE
+ * DEVICE: bit f of entry e = row e is in the TRAINING half of split f (the test half is its complement).  1 <= n_test < n.
+ * ss_l2_fold_train is ss_l2_fold with these bits (no host copy of the splits at all). */
+typedef struct ss_split ss_split;
+int ss_split_dev_start(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, ss_split **out);
+int ss_split_dev_wait(ss_split *s, const uint32_t **train_bits_dev, double *walk_ms);
+int ss_split_dev_free(ss_split *s);
+int ss_l2_fold_train(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *train_bits_dev, uint64_t n_keep, int n_splits, uint32_t *fold_dev);
 /* out1[s] = |X_s & A|, out2[s] = |X_s & A & B|; NULL = all ones.  Serves stat_cov/cal_cov_all
  * (:33-49: A = NULL, B = [y > 1]), get_remainc (:94-108) and get_candidate_arr (:121-134):
  * A = not-yet-used k-mers, B = [y_u > 1] or [y > 1]. */

@@ -135,6 +135,10 @@ SIGNATURES = {
     "ss_l2_set_overlap": (i32, [vp, vp, vp, vp, u32]),
     "ss_l2_prepare": (i32, [vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp]),
     "ss_l2_fold": (i32, [vp, vp, vp, u64, vp]),
+    "ss_l2_fold_train": (i32, [vp, vp, vp, u64, i32, vp]),
+    "ss_split_dev_start": (i32, [u64, i32, u64, C.c_uint32, vp]),
+    "ss_split_dev_wait": (i32, [vp, vp, vp]),
+    "ss_split_dev_free": (i32, [vp]),
     "ss_l2_count_keep": (i32, [vp, u64, C.c_double, C.c_double, C.c_double, vp]),
     "ss_l2_quantile_sums": (i32, [vp, vp, vp, u32, C.c_double, C.c_double, vp, vp, vp, vp, vp]),
     "ss_l2_pattern_stats": (i32, [vp, vp, i32, vp, vp, i32, vp]),

@@ -8,6 +8,7 @@
 #include <unistd.h>
 
 #include <zlib.h>
+#include <hipcub/hipcub.hpp>
 
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 #include <immintrin.h>
@@ -430,11 +431,13 @@ namespace {
 constexpr uint32_t SPLIT_CH = 2048;
 // `stop` (>= 1): the walk ends once row `stop` has its partner -- a worker needs the rows from n - 1 down to n_test only (see
 // split_worker); the walker of the shared stream passes 1 and goes through all of them.
-template <bool STORE, bool SIMD, class Sink>
-void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink, uint64_t stop = 1)
+// DIRECT (with STORE): `buf` is the whole output -- room for every partner of the rows walked + SPLIT_CH + BLK + 16 words --, nothing
+// is handed to the sink before the end (the caller reads the count there).  `start`: the first row (default n - 1).
+template <bool STORE, bool SIMD, bool DIRECT = false, class Sink>
+void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink, uint64_t stop = 1, uint64_t start = ~0ull)
 {
-    uint32_t fill = 0;
-    for (uint64_t hi = n - 1; hi >= stop;) {
+    uint64_t fill = 0;
+    for (uint64_t hi = start == ~0ull ? n - 1 : start; hi >= stop;) {
         // all i in (mask >> 1, hi] share the mask: the next power of two above i, minus one
         uint32_t mask = (uint32_t)hi;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
@@ -458,7 +461,7 @@ void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink, uint64_t s
                 ob += used;
                 avail -= used;
             }
-            if (SIMD && STORE) fill += (uint32_t)i - ii;
+            if (SIMD && STORE) fill += (uint64_t)((uint32_t)i - ii);
 #endif
             // branch-free rejection: every draw is written to its row's place; the row moves on only when the draw is accepted
             const uint32_t i1 = ii;
@@ -469,7 +472,7 @@ void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink, uint64_t s
             }
             if (STORE) {
                 fill += i1 - ii;
-                if (fill >= SPLIT_CH) { sink((const uint32_t *)buf, fill); fill = 0; }
+                if (!DIRECT && fill >= SPLIT_CH) { sink((const uint32_t *)buf, (uint32_t)fill); fill = 0; }
             }
             rng.pos += taken;
             i = ii;
@@ -477,7 +480,7 @@ void walk_split(MTWords &rng, uint64_t n, uint32_t *buf, Sink &&sink, uint64_t s
         }
         hi = lo - 1;
     }
-    if (STORE && fill) sink((const uint32_t *)buf, fill);
+    if (STORE && fill) sink((const uint32_t *)buf, (uint32_t)fill);
 }
 
 // the swaps of one split, on a thread of its own, from a snapshot of the stream at the split's first word
@@ -642,6 +645,236 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
         fprintf(stderr, "\n");
     }
     return err;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ShuffleSplit with the swaps on the device (round 5).  The host walks the word stream -- that chain is the specification's:
+// one sequential MT19937 stream through 20 permutations -- and writes down, for each split, the partners j of the rows
+// i = n - 1 .. n_test (the test SET is complete there, see split_worker).  The swaps themselves, a dependent chain through a
+// 20 MB array per split that took a host core 5-10 ms per split (20 splits: the host's cores were what four clusters solved
+// at once waited for), are not replayed at all.  Step k (row i_k = n - 1 - k, partner j_k) moves into place i_k, for good, the
+// element that lay at j_k: the one the most recent earlier step t < k with j_t = j_k left there -- which is what lay at ITS
+// row i_t just before, and so on back -- or j_k itself when no step touched the place before.  "Most recent earlier step with
+// the same partner" is the neighbour after a stable sort of the steps by partner; a place is the partner of ln 2 steps on
+// average, so the walk back is a step or two.  Per split: one radix sort of n / 2 (partner, step) pairs, three small kernels,
+// one atomicOr per row of the training half.  Output: bit f of train[e] = row e is in the TRAINING half of split f.
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+constexpr uint32_t SD_NONE = 0xFFFFFFFFu;
+constexpr int SD_NB = 3;                      // partner buffers in flight between the walker and the device
+
+__global__ __launch_bounds__(256) void sd_iota_kernel(uint32_t *v, uint32_t m)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < m) v[k] = k;
+}
+// rank[step] = its place in the sorted order; last[p] = place of the LAST step (largest k) with partner p
+__global__ __launch_bounds__(256) void sd_index_kernel(const uint32_t *__restrict__ js, const uint32_t *__restrict__ ks, uint32_t m,
+                                                       uint32_t *__restrict__ rank, uint32_t *__restrict__ last)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= m) return;
+    rank[ks[r]] = r;
+    if (r + 1 == m || js[r + 1] != js[r]) last[js[r]] = r;
+}
+__global__ __launch_bounds__(256) void sd_clear_last_kernel(const uint32_t *__restrict__ js, uint32_t m, uint32_t *__restrict__ last)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r < m) last[js[r]] = SD_NONE;
+}
+__global__ __launch_bounds__(256) void sd_resolve_kernel(const uint32_t *__restrict__ js, const uint32_t *__restrict__ ks, const uint32_t *__restrict__ rank,
+                                                         const uint32_t *__restrict__ last, uint32_t m, uint32_t n, uint32_t bit,
+                                                         uint32_t *__restrict__ train)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t r = rank[k], p = js[r];
+    uint32_t e = p;
+    if (r > 0 && js[r - 1] == p) {
+        uint32_t t = ks[r - 1];                                  // the step that last put something at p: what lay at ITS row?
+        for (;;) {
+            const uint32_t pos = n - 1u - t, g = last[pos];
+            if (g == SD_NONE) { e = pos; break; }
+            uint32_t t2 = ks[g];                                 // (every step with partner pos is at or before step t)
+            if (t2 == t) {                                       // step t swapped its row with itself: the one before it
+                if (g > 0 && js[g - 1] == pos) t2 = ks[g - 1];
+                else { e = pos; break; }
+            }
+            t = t2;
+        }
+    }
+    atomicOr(&train[e], bit);
+}
+}  // namespace
+
+struct ss_split {
+    uint64_t n = 0, n_test = 0, m = 0;
+    int n_splits = 0;
+    uint32_t seed = 0;
+    std::thread th;
+    std::atomic<int> rc{SS_OK};
+    std::atomic<bool> cancel{false};      // ss_split_dev_free before the walk is over (the pre-scan found one strain: no regression)
+    hipStream_t stream = nullptr;
+    uint32_t *d_train = nullptr, *d_j[SD_NB] = {nullptr, nullptr, nullptr}, *h_j[SD_NB] = {nullptr, nullptr, nullptr};
+    hipEvent_t copied[SD_NB] = {nullptr, nullptr, nullptr};
+    uint32_t *d_iota = nullptr, *d_js = nullptr, *d_ks = nullptr, *d_rank = nullptr, *d_last = nullptr;
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    double walk_ms = 0, total_ms = 0;
+    int device = 0;
+};
+
+namespace {
+// pinned partner buffers are kept between calls (hipHostMalloc of 10 MB takes a millisecond; a solve uses three)
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<uint32_t *, uint64_t>> free_;
+    uint32_t *get(uint64_t words)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].second >= words) { uint32_t *p = free_[i].first; free_.erase(free_.begin() + (long)i); return p; }
+        }
+        void *p = nullptr;
+        return hipHostMalloc(&p, words * 4, hipHostMallocDefault) == hipSuccess ? (uint32_t *)p : nullptr;
+    }
+    void put(uint32_t *p, uint64_t words)
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            uint64_t held = 0;
+            for (auto &f : free_) held += f.second;
+            if (free_.size() < 12 && (held + words) * 4 <= (256ull << 20)) { free_.emplace_back(p, words); return; }
+        }
+        hipHostFree(p);
+    }
+};
+PinnedPool g_pinned;
+
+void split_dev_free_buffers(ss_split *s)
+{
+    const uint64_t cap = s->m + SPLIT_CH + MTWords::BLK + 64;
+    for (int b = 0; b < SD_NB; b++) {
+        g_pinned.put(s->h_j[b], cap);
+        s->h_j[b] = nullptr;
+        hipFree(s->d_j[b]);
+        s->d_j[b] = nullptr;
+        if (s->copied[b]) hipEventDestroy(s->copied[b]);
+        s->copied[b] = nullptr;
+    }
+    hipFree(s->d_iota); hipFree(s->d_js); hipFree(s->d_ks); hipFree(s->d_rank); hipFree(s->d_last); hipFree(s->d_tmp);
+    s->d_iota = s->d_js = s->d_ks = s->d_rank = s->d_last = nullptr;
+    s->d_tmp = nullptr;
+}
+
+template <bool SIMD>
+void split_dev_walk(ss_split *s)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (hipSetDevice(s->device) != hipSuccess) { s->rc = SS_EHIP; return; }
+    std::unique_ptr<CoreGuard> core(new CoreGuard());
+    std::unique_ptr<MTWords> rng(new (std::nothrow) MTWords(s->seed, SIMD));
+    if (!rng) { s->rc = SS_ENOMEM; return; }
+    const uint32_t m = (uint32_t)s->m, n = (uint32_t)s->n;
+    const unsigned grid = (m + 255u) / 256u;
+    int bits = 1;
+    while ((1ull << bits) < s->n) bits++;
+    bool used[SD_NB] = {false, false, false};
+    for (int f = 0; f < s->n_splits && s->rc == SS_OK && !s->cancel; f++) {
+        const int b = f % SD_NB;
+        if (used[b]) {                                   // the copy that read this pinned buffer three splits ago
+            core.reset();
+            if (hipEventSynchronize(s->copied[b]) != hipSuccess) { s->rc = SS_EHIP; break; }
+            core.reset(new CoreGuard());
+        }
+        uint64_t got = 0;
+        walk_split<true, SIMD, true>(*rng, s->n, s->h_j[b], [&](const uint32_t *, uint32_t cnt) { got = cnt; }, s->n_test);
+        if (got != s->m) { s->rc = SS_ERANGE; break; }
+        hipError_t e = hipMemcpyAsync(s->d_j[b], s->h_j[b], (uint64_t)m * 4, hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) e = hipEventRecord(s->copied[b], s->stream);
+        used[b] = true;
+        size_t tb = s->tmp_bytes;
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(s->d_tmp, tb, s->d_j[b], s->d_js, s->d_iota, s->d_ks, (int)m, 0, bits, s->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(sd_index_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_js, s->d_ks, m, s->d_rank, s->d_last);
+            hipLaunchKernelGGL(sd_resolve_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_js, s->d_ks, s->d_rank, s->d_last, m, n, 1u << f, s->d_train);
+            hipLaunchKernelGGL(sd_clear_last_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_js, m, s->d_last);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) { ss::set_last_error("ss_split_dev", __FILE__, __LINE__, e); s->rc = SS_EHIP; break; }
+        // the rest of the split's rows: only to know where the next split's words begin
+        if (f + 1 < s->n_splits && s->n_test > 1) walk_split<false, SIMD>(*rng, s->n, nullptr, [](const uint32_t *, uint32_t) {}, 1, s->n_test - 1);
+    }
+    s->walk_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3;
+}
+}  // namespace
+}  // extern "C++"
+
+int ss_split_dev_start(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed, ss_split **out)
+{
+    if (!out || n_splits < 1 || n_splits > 31 || n_test < 1 || n_test >= n || n > 0x7FFFFFFFull) return SS_EINVAL;
+    ss_split *s = new (std::nothrow) ss_split();
+    if (!s) return SS_ENOMEM;
+    s->n = n; s->n_test = n_test; s->m = n - n_test; s->n_splits = n_splits; s->seed = seed;
+    hipGetDevice(&s->device);
+    const uint64_t cap = s->m + SPLIT_CH + MTWords::BLK + 64;
+    int bits = 1;
+    while ((1ull << bits) < n) bits++;
+    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int b = 0; b < SD_NB && ok; b++) {
+        s->h_j[b] = g_pinned.get(cap);
+        ok = s->h_j[b] && hipMalloc((void **)&s->d_j[b], s->m * 4) == hipSuccess && hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->d_js, s->d_js, s->d_ks, s->d_ks, (int)s->m, 0, bits) == hipSuccess;
+    ok = ok && hipMalloc((void **)&s->d_train, n * 4) == hipSuccess && hipMalloc((void **)&s->d_iota, s->m * 4) == hipSuccess &&
+         hipMalloc((void **)&s->d_js, s->m * 4) == hipSuccess && hipMalloc((void **)&s->d_ks, s->m * 4) == hipSuccess &&
+         hipMalloc((void **)&s->d_rank, s->m * 4) == hipSuccess && hipMalloc((void **)&s->d_last, n * 4) == hipSuccess &&
+         hipMalloc(&s->d_tmp, std::max<size_t>(s->tmp_bytes, 16)) == hipSuccess;
+    if (ok) {
+        ok = hipMemsetAsync(s->d_train, 0, n * 4, s->stream) == hipSuccess && hipMemsetAsync(s->d_last, 0xFF, n * 4, s->stream) == hipSuccess;
+        hipLaunchKernelGGL(sd_iota_kernel, dim3((unsigned)((s->m + 255) / 256)), dim3(256), 0, s->stream, s->d_iota, (uint32_t)s->m);
+        ok = ok && hipGetLastError() == hipSuccess;
+    }
+    if (!ok) {
+        split_dev_free_buffers(s);
+        hipFree(s->d_train);
+        if (s->stream) hipStreamDestroy(s->stream);
+        delete s;
+        return SS_ENOMEM;
+    }
+#ifdef SS_HOST_X86
+    const bool simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("popcnt") && host_simd_allowed();
+#else
+    const bool simd = false;
+#endif
+    s->th = std::thread([=] { if (simd) split_dev_walk<true>(s); else split_dev_walk<false>(s); });
+    *out = s;
+    return SS_OK;
+}
+
+int ss_split_dev_wait(ss_split *s, const uint32_t **train_bits_dev, double *walk_ms)
+{
+    if (!s) return SS_EINVAL;
+    if (s->th.joinable()) s->th.join();
+    if (s->stream && hipStreamSynchronize(s->stream) != hipSuccess && s->rc == SS_OK) s->rc = SS_EHIP;
+    split_dev_free_buffers(s);                          // only the result stays
+    if (train_bits_dev) *train_bits_dev = s->d_train;
+    if (walk_ms) *walk_ms = s->walk_ms;
+    return s->rc;
+}
+
+int ss_split_dev_free(ss_split *s)
+{
+    if (!s) return SS_OK;
+    s->cancel = true;
+    ss_split_dev_wait(s, nullptr, nullptr);
+    hipFree(s->d_train);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return SS_OK;
 }
 
 int ss_revcomp(const char *in, char *out, uint64_t n)

@@ -500,13 +500,14 @@ __global__ __launch_bounds__(NT) void l2_popc_words_kernel(const uint32_t *__res
 }
 // fold word of row i: 0 when the row is not kept, else bit 31 | the test-fold bits of the row's RANK among the kept rows
 // (ShuffleSplit permutes the kept rows: identify_strains_L2_Enet_Pscan_new_sp.py:402-442)
+// (inv: 0 when split_bits are the TEST bits; the mask of the folds when they are the TRAINING bits of ss_split_dev_*)
 __global__ __launch_bounds__(NT) void l2_fold_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pre, uint64_t K,
-                                                     const uint32_t *__restrict__ split_bits, uint32_t *__restrict__ fold)
+                                                     const uint32_t *__restrict__ split_bits, uint32_t inv, uint32_t *__restrict__ fold)
 {
     const uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x;
     if (i >= K) return;
     const uint32_t w = keep[i >> 5], b = (uint32_t)i & 31u;
-    fold[i] = ((w >> b) & 1u) ? (split_bits[pre[i >> 5] + (uint32_t)__popc(w & ((1u << b) - 1u))] | 0x80000000u) : 0u;
+    fold[i] = ((w >> b) & 1u) ? (((split_bits[pre[i >> 5] + (uint32_t)__popc(w & ((1u << b) - 1u))] ^ inv) & 0x7FFFFFFFu) | 0x80000000u) : 0u;
 }
 
 // a CSR row-pointer array as the kernels walk it: starts at 0, never decreases, ends at (and so never exceeds) nnz.
@@ -623,7 +624,22 @@ int ss_l2_count_keep(const int64_t *y_host, uint64_t K, double npp25, double npp
     return SS_OK;
 }
 
+static int l2_fold_impl(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, bool bits_on_device, uint32_t inv, uint64_t n_keep,
+                        uint32_t *fold_dev);
+
 int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, uint64_t n_keep, uint32_t *fold_dev)
+{
+    return l2_fold_impl(h, keep_dev, split_bits, false, 0u, n_keep, fold_dev);
+}
+
+int ss_l2_fold_train(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *train_bits_dev, uint64_t n_keep, int n_splits, uint32_t *fold_dev)
+{
+    if (n_splits < 1 || n_splits > 31) return SS_EINVAL;
+    return l2_fold_impl(h, keep_dev, train_bits_dev, true, (1u << n_splits) - 1u, n_keep, fold_dev);
+}
+
+static int l2_fold_impl(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_bits, bool bits_on_device, uint32_t inv, uint64_t n_keep,
+                        uint32_t *fold_dev)
 {
     if (!h || (h->K && (!keep_dev || !fold_dev)) || (n_keep && !split_bits) || n_keep > h->K) return SS_EINVAL;
     if (!h->K) return SS_OK;
@@ -633,16 +649,18 @@ int ss_l2_fold(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t *split_b
     int rc = SS_OK;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_pre, (int)h->W);
     if (e != hipSuccess || hipMalloc((void **)&d_cnt, h->W * 4) != hipSuccess || hipMalloc((void **)&d_pre, h->W * 4) != hipSuccess ||
-        hipMalloc((void **)&d_bits, std::max<uint64_t>(1, n_keep) * 4) != hipSuccess || hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess)
+        (!bits_on_device && hipMalloc((void **)&d_bits, std::max<uint64_t>(1, n_keep) * 4) != hipSuccess) ||
+        hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess)
         rc = SS_ENOMEM;
     if (!rc) {
-        if (n_keep) e = hipMemcpy(d_bits, split_bits, n_keep * 4, hipMemcpyHostToDevice);
+        if (n_keep && !bits_on_device) e = hipMemcpy(d_bits, split_bits, n_keep * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(l2_popc_words_kernel, dim3((unsigned)((h->W + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, h->W, d_cnt);
             e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_pre, (int)h->W);
         }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(l2_fold_kernel, dim3((unsigned)((h->K + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, d_pre, h->K, d_bits, fold_dev);
+            hipLaunchKernelGGL(l2_fold_kernel, dim3((unsigned)((h->K + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, d_pre, h->K,
+                               bits_on_device ? split_bits : d_bits, inv, fold_dev);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipDeviceSynchronize();

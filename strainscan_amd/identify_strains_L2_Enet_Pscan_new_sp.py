@@ -8,7 +8,6 @@ passes become bit-plane popcounts and masked radix selects on the MI355X
 (strainscan_amd/csrc/ss_l2.hip) and scikit-learn's ElasticNetCV / ElasticNet become a Gram
 coordinate descent on exact per-pattern statistics (ss_enet.hip); see SURVEY.md Appendix B/C.
 """
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -19,10 +18,7 @@ CV_NITER = 20        # :433
 NALPHA = 50          # :434
 MAX_NITER = 5000     # :435
 TEST_SIZE = 0.5      # :436
-# one ShuffleSplit per cluster being solved (vote_strain_L2_batch runs up to four clusters at once on its "ss-l2" threads): the
-# walks over the shared stream are one core each and independent, so N clusters wait for the longest walk, not for the sum
-# (round 5; the native side hands out the host's cores between the calls: ss_host.hip CoreSlots)
-_SPLIT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="ss-shufflesplit")
+SPLIT_DEV_MIN = 200000   # rows from which ShuffleSplit's swaps run on the device (L2.SplitDev); below, the host does all of it in < 2 ms
 MAX_PRESCAN_ITER = 15  # :302
 
 
@@ -120,8 +116,8 @@ def pre_scan(img, vec, sid, cutoff, l2, pmode, emode):
 
 def enet_cv_fit(img, cols, vec, trace=None, split=None):
     """ElasticNetCV -> lasso_mpm -> ElasticNet (:433-456) on the selected columns / kept rows.
-    -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests.  `split`: a future
-    of shuffle_split_test_bits(n, ...) started earlier (the splits depend on the number of kept rows only)."""
+    -> coef (float64[p]).  `trace` (dict) receives alphas_, mse_path_, alpha for tests.  `split`: an L2.SplitDev
+    started earlier (the splits depend on the number of kept rows only)."""
     import time
     lap = [time.perf_counter()]
     tm = trace.setdefault("timing_ms", {}) if trace is not None else {}
@@ -134,11 +130,16 @@ def enet_cv_fit(img, cols, vec, trace=None, split=None):
     p = len(cols)
     n = vec.n_keep
     y_dev = vec.ykeep
-    bits, n_test = split.result() if split is not None else L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
-    mark("wait_for_shuffle_split")
-    assert bits.size == n
-    fold = img.fold_words(vec.keep, bits, n)
-    mark("fold_words")
+    if split is not None:                     # started in detect_core: the host walks the word stream, the device does the swaps
+        fold = img.fold_words_train(vec.keep, split, n)
+        tm["shuffle_split_walk"] = split.walk_ms
+        mark("wait_for_shuffle_split_and_fold_words")
+    else:
+        bits, n_test = L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
+        mark("shuffle_split_host")
+        assert bits.size == n
+        fold = img.fold_words(vec.keep, bits, n)
+        mark("fold_words")
     stats = img.pattern_stats(cols, y_dev, fold, CV_NITER)
     fold.close()
     mark("pattern_stats")
@@ -183,7 +184,7 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     if own_img:
         img = L2.ClusterImage(X)
     t_img = time.perf_counter()
-    vec = None
+    vec = split = None
     try:
         if img.om_cols is None:
             img.set_overlap(om)
@@ -193,7 +194,7 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
         # to the device and the pre-scan runs there
         y64 = np.ascontiguousarray(input_y, np.int64)
         n_keep = L2.count_keep(y64, npp25, npp75, npp_out)
-        split = _SPLIT_POOL.submit(L2.shuffle_split_test_bits, n_keep, CV_NITER, TEST_SIZE, 0) if n_keep >= 200000 else None
+        split = L2.SplitDev(n_keep, CV_NITER, TEST_SIZE, 0) if n_keep >= SPLIT_DEV_MIN and L2.SplitDev.usable(n_keep, TEST_SIZE) else None
         # ln, py_u, the [> 1] masks, the row filter: one pass on the device (ss_l2_prepare)
         vec = img.prepare(y64, new_als, npp25, npp75, npp_out)
         if vec.n_keep != n_keep:
@@ -211,6 +212,8 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
     finally:
         if vec is not None:
             vec.close()
+        if split is not None:
+            split.close()
         if own_img:
             img.close()
     lasso_coef = np.atleast_1d(coef)

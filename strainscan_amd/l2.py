@@ -152,6 +152,13 @@ class ClusterImage:
         _lib.check(_lib.lib().ss_l2_fold(self._h, keep.ptr, _lib.ptr(split_bits), int(n_keep), f.ptr), "ss_l2_fold")
         return f
 
+    def fold_words_train(self, keep, split, n_keep):
+        """fold_words from a SplitDev: its training bits never leave the device."""
+        assert split.n == n_keep
+        f = DevBuf(self.K * 4)
+        _lib.check(_lib.lib().ss_l2_fold_train(self._h, keep.ptr, split.wait(), int(n_keep), split.n_splits, f.ptr), "ss_l2_fold_train")
+        return f
+
     def planes(self):
         out = np.zeros(self.S * self.W, np.uint32)
         _lib.check(_lib.lib().ss_l2_export_planes(self._h, _lib.ptr(out)), "ss_l2_export_planes")
@@ -291,6 +298,49 @@ def count_keep(y, npp25, npp75, npp_out):
     _lib.check(_lib.lib().ss_l2_count_keep(_lib.ptr(y), int(y.size), float(npp25), float(npp75), float(npp_out), _lib.ptr(out)),
                "ss_l2_count_keep")
     return int(out[0])
+
+
+class SplitDev:
+    """ShuffleSplit(n_splits, test_size, random_state=seed) with the swaps on the device (ss_split_dev_*): starts at once on a
+    native thread -- the splits depend on the number of rows only --, wait() -> device pointer to uint32[n] whose bit f says
+    "row is in the TRAINING half of split f" (the test half is the complement), n_test."""
+
+    def __init__(self, n, n_splits=20, test_size=0.5, seed=0):
+        _lib.require_gpu()
+        self.n, self.n_splits = int(n), int(n_splits)
+        self.n_test = int(math.ceil(test_size * self.n))
+        self._h = C.c_void_p()
+        self.walk_ms = None
+        _lib.check(_lib.lib().ss_split_dev_start(self.n, self.n_splits, self.n_test, int(seed), C.byref(self._h)), "ss_split_dev_start")
+
+    @staticmethod
+    def usable(n, test_size=0.5):
+        n_test = int(math.ceil(test_size * int(n)))
+        return 1 <= n_test < int(n) < 2**31
+
+    def wait(self):
+        p, ms = C.c_void_p(), C.c_double()
+        _lib.check(_lib.lib().ss_split_dev_wait(self._h, C.byref(p), C.byref(ms)), "ss_split_dev_wait")
+        self.walk_ms = float(ms.value)
+        return p
+
+    def train_bits(self):
+        """The result on the host (tests)."""
+        p = self.wait()
+        out = np.zeros(self.n, np.uint32)
+        _lib.check(_lib.lib().ss_memcpy_d2h(_lib.ptr(out), p, self.n * 4, None), "ss_memcpy_d2h")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().ss_split_dev_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shuffle_split_test_bits(n, n_splits=20, test_size=0.5, seed=0):

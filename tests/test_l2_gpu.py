@@ -833,3 +833,28 @@ def test_l2_batch_matches_reference(name, tmp_path, monkeypatch):
             _cmp_report(files[rel], text, float_cols=(3, 4, 5, 6))
         else:
             _cmp_report(files[rel], text, float_cols=(3, 4, 5, 6, 8, 9))
+
+
+@pytest.mark.parametrize("n,frac,splits,seed", [(2, 0.5, 20, 0), (3, 0.5, 20, 0), (10, 0.5, 20, 0), (11, 0.5, 20, 0), (1000, 0.5, 20, 0),
+                                                (4097, 0.5, 20, 0), (250_001, 0.5, 20, 0), (1_000_003, 0.5, 20, 0), (5003, 0.1, 7, 42),
+                                                (5003, 0.9, 31, 42), (300_000, 0.25, 5, 7), (2_500_000, 0.5, 20, 0)])
+def test_shuffle_split_on_the_device_equals_numpy(n, frac, splits, seed):
+    """ss_split_dev_*: the host walks the word stream, the device finds every training row's element without replaying the
+    swap chain (ss_host.hip) -- against numpy.random.RandomState(seed).permutation itself, split by split, bit for bit:
+    sizes around the levels of the rejection sampler, odd sizes, other test fractions and seeds, 31 splits; a training half
+    always holds exactly n - n_test rows."""
+    from strainscan_amd import l2
+    want, n_test = l2.shuffle_split_test_bits_numpy(n, splits, frac, seed)
+    sp = l2.SplitDev(n, splits, frac, seed)
+    assert sp.n_test == n_test
+    train = sp.train_bits()
+    mask = np.uint32((1 << splits) - 1)
+    assert not (train & ~mask).any()
+    assert np.array_equal((~train) & mask, want), (n, frac, splits, seed)
+    for f in range(splits):
+        assert int(((train >> np.uint32(f)) & 1).sum()) == n - n_test
+    assert sp.walk_ms is not None and sp.walk_ms >= 0
+    sp.close()
+    sp2 = l2.SplitDev(n, splits, frac, seed)            # abandoned before its walk is over: freed without a result
+    sp2.close()
+    assert not l2.SplitDev.usable(1, 0.5) and not l2.SplitDev.usable(5, 0.0) and l2.SplitDev.usable(2, 0.5)
