@@ -552,21 +552,20 @@ def measure_config3(torch, dev, args, stream):
     def solve_one(i):
         img_ = L2.ClusterImage.from_planes(planes, Kc, S)
         try:
-            with contextlib.redirect_stdout(io.StringIO()):
-                return m.detect_core(None, om, ids, ys4[i].copy(), K, 0, npp4[i], npp4[i], 0.9, [1], 0, 40, 0, 0, img=img_)
+            return m.detect_core(None, om, ids, ys4[i].copy(), K, 0, npp4[i], npp4[i], 0.9, [1], 0, 40, 0, 0, img=img_)
         finally:
             img_.close()
 
     walls4, res4 = [], None
-    with ThreadPoolExecutor(max_workers=4, thread_name_prefix="ss-l2") as pool4:
-        for _ in range(4):
+    with contextlib.redirect_stdout(io.StringIO()), ThreadPoolExecutor(max_workers=4, thread_name_prefix="ss-l2") as pool4:
+        for _ in range(4):                      # (the redirection is process-wide: once, around the threads)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res4 = list(pool4.map(solve_one, range(4)))
             walls4.append((time.perf_counter() - t0) * 1e3)
-    t0 = time.perf_counter()
-    one_by_one = [solve_one(i) for i in range(4)]
-    serial4_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        one_by_one = [solve_one(i) for i in range(4)]
+        serial4_ms = (time.perf_counter() - t0) * 1e3
     same4 = all([dict(a) for a in r_a] == [dict(b) for b in r_b] for r_a, r_b in zip(res4, one_by_one))
     # sub-sample of the rows through the product and through the oracle
     Ks = min(Kc, args.l2_check_rows)

@@ -41,15 +41,15 @@ imgs = [L2.ClusterImage.from_planes(planes, Kc, S) for _ in range(4)]
 def solve(i):
     tr = {}
     t0 = time.perf_counter()
-    with contextlib.redirect_stdout(io.StringIO()):
-        m.detect_core(None, om, ids, ys[i].copy(), 31, 0, npp[i], npp[i], 0.9, [1], 0, 40, 0, 0, trace=tr, img=imgs[i])
+    m.detect_core(None, om, ids, ys[i].copy(), 31, 0, npp[i], npp[i], 0.9, [1], 0, 40, 0, 0, trace=tr, img=imgs[i])
     return round((time.perf_counter() - t0) * 1e3, 1), {k: round(v, 1) for k, v in tr["timing_ms"].items()}
 
 for rep in range(4):
     with ThreadPoolExecutor(max_workers=T) as pool:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = list(pool.map(solve, range(4)))
+        with contextlib.redirect_stdout(io.StringIO()):          # (once, around the threads: the redirection is process-wide)
+            out = list(pool.map(solve, range(4)))
         wall = (time.perf_counter() - t0) * 1e3
     print("rep %d: wall %.1f ms" % (rep, wall))
     for o in out:

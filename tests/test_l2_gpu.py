@@ -380,16 +380,16 @@ def test_four_clusters_solved_at_once_equal_one_by_one():
     def solve(c):
         X, O, ids, y, npp = c
         tr = {}
-        with contextlib.redirect_stdout(io.StringIO()):
-            out = m.detect_core(X, O, ids, y.copy(), 31, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=tr)
+        out = m.detect_core(X, O, ids, y.copy(), 31, 0, npp, npp, 0.9, [1], 0, 40, 0, 0, trace=tr)
         return [dict(x) for x in out], tr["alphas_"].tolist(), tr["mse_path_"].tolist(), tr["n_rows"]
 
-    serial = [solve(c) for c in cases]
-    assert all(s[3] >= 200_000 and len(s[0][0]) >= 2 for s in serial)
-    for _ in range(2):
-        with ThreadPoolExecutor(max_workers=4) as pool:
-            together = list(pool.map(solve, cases))
-        assert together == serial
+    with contextlib.redirect_stdout(io.StringIO()):              # (process-wide: once, around the threads)
+        serial = [solve(c) for c in cases]
+        assert all(s[3] >= 200_000 and len(s[0][0]) >= 2 for s in serial)
+        for _ in range(2):
+            with ThreadPoolExecutor(max_workers=4) as pool:
+                together = list(pool.map(solve, cases))
+            assert together == serial
 
 
 @pytest.mark.parametrize("p,n_folds", [(1, 20), (3, 20), (5, 20), (6, 20), (4, 30), (7, 20), (11, 5), (12, 3)])
@@ -684,7 +684,7 @@ def test_every_statement_of_the_l2_mirrors_is_pinned(golden, golden_dir, l1_dbs,
                         ("cache", lambda p: test_cluster_image_cache(p, monkeypatch)),
                         ("threads", lambda p: test_l2_batch_threads_equal_serial(p, monkeypatch)),
                         ("bad", test_damaged_csr_files_raise_value_error),
-                        ("branches", lambda p: _l2_branch_scenarios(p, monkeypatch))):
+                        ("branches", lambda p: _l2_branch_scenarios(p, monkeypatch, golden))):
             d = tmp_path / sub
             d.mkdir()
             fn(d)
@@ -696,13 +696,18 @@ def test_every_statement_of_the_l2_mirrors_is_pinned(golden, golden_dir, l1_dbs,
     assert len(VOTE_ALLOW) <= 5 and len(DETECT_ALLOW) <= 5
 
 
-def _l2_branch_scenarios(tmp_path, monkeypatch):
+def _l2_branch_scenarios(tmp_path, monkeypatch, golden_l2):
     """Scenarios that exist only to take the branches of the layer-2 mirrors the cases above leave out."""
     import pickle
     import scipy.sparse as sp
     from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
     from strainscan_amd import db as ssdb
     g, _ = _batch_golden()
+    # the golden cases once more with ShuffleSplit's swaps on the device (L2.SplitDev: large clusters only by default)
+    monkeypatch.setattr(m, "SPLIT_DEV_MIN", 1)
+    for name in sc.L2_CASES:
+        test_detect_strains(name, golden_l2)
+    monkeypatch.undo()
     for name in sc.L2_BATCH_CASES:
         d = tmp_path / ("batch_" + name)
         d.mkdir()
