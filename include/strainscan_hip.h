@@ -52,6 +52,12 @@ int ss_stream_sync(void *stream);
 /* device memory helpers for callers that do not bring their own allocator */
 int ss_dev_alloc(void **dptr, uint64_t bytes);
 int ss_dev_free(void *dptr);
+/* Stream-ordered twins on the CALLING THREAD's stream (hipStreamPerThread), from the device's memory pool: what layer 2 uses
+ * for its per-call vectors, so that clusters solved on several host threads do not meet in hipFree's device-wide
+ * synchronisation.  A buffer must be freed by the thread that used it last (strainscan_amd/l2.py DevBuf falls back to
+ * ss_dev_free otherwise). */
+int ss_dev_alloc_async(void **dptr, uint64_t bytes);
+int ss_dev_free_async(void *dptr);
 int ss_memcpy_h2d(void *dst_dev, const void *src, uint64_t bytes, void *stream);
 int ss_memcpy_d2h(void *dst, const void *src_dev, uint64_t bytes, void *stream);
 int ss_memset_dev(void *dst_dev, int byte, uint64_t bytes, void *stream);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "ss_device_sync": (i32, []),
     "ss_stream_sync": (i32, [vp]),
     "ss_dev_alloc": (i32, [P(vp), u64]),
+    "ss_dev_alloc_async": (i32, [P(vp), u64]),
+    "ss_dev_free_async": (i32, [vp]),
     "ss_dev_free": (i32, [vp]),
     "ss_memcpy_h2d": (i32, [vp, vp, u64, vp]),
     "ss_memcpy_d2h": (i32, [vp, vp, u64, vp]),

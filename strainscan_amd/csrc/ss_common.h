@@ -227,6 +227,22 @@ int scan_text_parallel(ss_db *db, const char *text, uint64_t n, uint64_t *n_reco
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned blocks,
                      uint64_t n_tiles, bool binned = false, uint64_t set_id = 0);
 int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, uint64_t n, hipStream_t stream, bool binned);
+// Layer 2 (ss_l2.hip, ss_enet.hip) works on the CALLING THREAD's own stream and takes its temporaries from the stream-ordered
+// pool (round 5): the clusters of a sample are solved on several host threads at once, and on the legacy default stream every
+// synchronous copy of one thread waited for the kernels of all the others, every hipFree for the whole device (four 5 M-row
+// clusters: 36 ms each in the O(K) vector pass that takes 5.5 ms alone).  Buffers that live in a handle stay with hipMalloc.
+namespace l2s {
+inline hipStream_t stream() { return hipStreamPerThread; }
+hipError_t dmalloc(void **p, size_t n);          // (ss_host.hip: sets the pool's release threshold once)
+inline hipError_t dfree(void *p) { return p ? hipFreeAsync(p, stream()) : hipSuccess; }
+inline hipError_t copy(void *d, const void *s_, size_t n, hipMemcpyKind k)
+{
+    const hipError_t e = hipMemcpyAsync(d, s_, n, k, stream());
+    return e != hipSuccess ? e : hipStreamSynchronize(stream());
+}
+inline hipError_t set(void *d, int v, size_t n) { return hipMemsetAsync(d, v, n, stream()); }
+inline hipError_t sync() { return hipStreamSynchronize(stream()); }
+}  // namespace l2s
 // ss_scan_flat_dev for a block whose records ss_reorder.hip has binned by locus (the scan may add hits up in LDS first)
 // (set_id: ss_reads::serial of the resident set the block belongs to, 0 = none)
 int scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned, uint64_t set_id = 0);

@@ -312,27 +312,27 @@ int ss_enet_path_gram(const double *Q, const double *q, const double *yy, const 
     unsigned long long *d_ts = nullptr;
     int rc = SS_OK;
     const size_t na = (size_t)F * n_alphas;
-    if (hipMalloc((void **)&d_in, sizeof(FoldIn) * F) != hipSuccess || hipMalloc((void **)&d_alphas, 8 * n_alphas) != hipSuccess ||
-        hipMalloc((void **)&d_mse, 8 * na) != hipSuccess || hipMalloc((void **)&d_coefs, 8 * na * p) != hipSuccess ||
-        hipMalloc((void **)&d_gaps, 8 * na) != hipSuccess || hipMalloc((void **)&d_iters, 4 * na) != hipSuccess ||
-        (test_stats && hipMalloc((void **)&d_ts, (size_t)F * M * 24) != hipSuccess))
+    if (ss::l2s::dmalloc((void **)&d_in, sizeof(FoldIn) * F) != hipSuccess || ss::l2s::dmalloc((void **)&d_alphas, 8 * n_alphas) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_mse, 8 * na) != hipSuccess || ss::l2s::dmalloc((void **)&d_coefs, 8 * na * p) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_gaps, 8 * na) != hipSuccess || ss::l2s::dmalloc((void **)&d_iters, 4 * na) != hipSuccess ||
+        (test_stats && ss::l2s::dmalloc((void **)&d_ts, (size_t)F * M * 24) != hipSuccess))
         rc = SS_ENOMEM;
     if (!rc) {
-        hipMemcpy(d_in, in.data(), sizeof(FoldIn) * F, hipMemcpyHostToDevice);
-        hipMemcpy(d_alphas, alphas, 8 * n_alphas, hipMemcpyHostToDevice);
-        hipMemset(d_gaps, 0, 8 * na);
-        if (test_stats) hipMemcpy(d_ts, test_stats, (size_t)F * M * 24, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(enet_path_kernel, dim3(F), dim3(64), 0, 0, d_in, p, d_alphas, n_alphas, l1_ratio, max_iter,
+        ss::l2s::copy(d_in, in.data(), sizeof(FoldIn) * F, hipMemcpyHostToDevice);
+        ss::l2s::copy(d_alphas, alphas, 8 * n_alphas, hipMemcpyHostToDevice);
+        ss::l2s::set(d_gaps, 0, 8 * na);
+        if (test_stats) ss::l2s::copy(d_ts, test_stats, (size_t)F * M * 24, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(enet_path_kernel, dim3(F), dim3(64), 0, ss::l2s::stream(), d_in, p, d_alphas, n_alphas, l1_ratio, max_iter,
                            tol, positive, d_ts, M, d_mse, d_coefs, d_iters, d_gaps);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess && test_stats) e = hipMemcpy(mse, d_mse, 8 * na, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && coefs) e = hipMemcpy(coefs, d_coefs, 8 * na * p, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && iters) e = hipMemcpy(iters, d_iters, 4 * na, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && gaps) e = hipMemcpy(gaps, d_gaps, 8 * na, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = ss::l2s::sync();
+        if (e == hipSuccess && test_stats) e = ss::l2s::copy(mse, d_mse, 8 * na, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && coefs) e = ss::l2s::copy(coefs, d_coefs, 8 * na * p, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && iters) e = ss::l2s::copy(iters, d_iters, 4 * na, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && gaps) e = ss::l2s::copy(gaps, d_gaps, 8 * na, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { ss::set_last_error("ss_enet_path_gram", __FILE__, __LINE__, e); rc = SS_EHIP; }
     }
-    hipFree(d_in); hipFree(d_alphas); hipFree(d_mse); hipFree(d_coefs); hipFree(d_gaps); hipFree(d_iters); hipFree(d_ts);
+    ss::l2s::dfree(d_in); ss::l2s::dfree(d_alphas); ss::l2s::dfree(d_mse); ss::l2s::dfree(d_coefs); ss::l2s::dfree(d_gaps); ss::l2s::dfree(d_iters); ss::l2s::dfree(d_ts);
     return rc;
 }
 
@@ -354,38 +354,38 @@ int ss_enet_cd(const double *X, const double *y, uint64_t N, int p, double l1, d
     int rc = SS_OK;
     hipError_t e = hipSuccess;
 #define CD(call) do { if (e == hipSuccess) e = (call); } while (0)
-    if (hipMalloc((void **)&d_X, (uint64_t)p * N * 8) != hipSuccess || hipMalloc((void **)&d_y, N * 8) != hipSuccess ||
-        hipMalloc((void **)&d_R, N * 8) != hipSuccess || hipMalloc((void **)&d_part, (uint64_t)(p + 2) * blocks * 8) != hipSuccess ||
-        hipMalloc((void **)&d_st, sizeof(CdState)) != hipSuccess)
+    if (ss::l2s::dmalloc((void **)&d_X, (uint64_t)p * N * 8) != hipSuccess || ss::l2s::dmalloc((void **)&d_y, N * 8) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_R, N * 8) != hipSuccess || ss::l2s::dmalloc((void **)&d_part, (uint64_t)(p + 2) * blocks * 8) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_st, sizeof(CdState)) != hipSuccess)
         rc = SS_ENOMEM;
     double gap = 0.0;
     int n_iter = 0;
     if (!rc) {
-        CD(hipMemcpy(d_X, X, (uint64_t)p * N * 8, hipMemcpyHostToDevice));
-        CD(hipMemcpy(d_y, y, N * 8, hipMemcpyHostToDevice));
-        CD(hipMemcpy(d_st, &h, sizeof h, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(cd_prep_kernel, dim3(blocks), dim3(CD_THREADS), 0, 0, d_X, d_y, N, p, d_st, d_R, d_part);
-        hipLaunchKernelGGL(cd_sum_kernel, dim3(1), dim3(CD_THREADS), 0, 0, d_part, p + 1, blocks, d_st, 1);
-        CD(hipMemcpy(&h, d_st, sizeof h, hipMemcpyDeviceToHost));
+        CD(ss::l2s::copy(d_X, X, (uint64_t)p * N * 8, hipMemcpyHostToDevice));
+        CD(ss::l2s::copy(d_y, y, N * 8, hipMemcpyHostToDevice));
+        CD(ss::l2s::copy(d_st, &h, sizeof h, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cd_prep_kernel, dim3(blocks), dim3(CD_THREADS), 0, ss::l2s::stream(), d_X, d_y, N, p, d_st, d_R, d_part);
+        hipLaunchKernelGGL(cd_sum_kernel, dim3(1), dim3(CD_THREADS), 0, ss::l2s::stream(), d_part, p + 1, blocks, d_st, 1);
+        CD(ss::l2s::copy(&h, d_st, sizeof h, hipMemcpyDeviceToHost));
         const double yy = h.red[p];
         const double d_w_tol = tol;
         tol *= yy;
         gap = tol + 1.0;
         for (n_iter = 0; n_iter < max_iter && e == hipSuccess; n_iter++) {
-            hipLaunchKernelGGL(cd_clear_pending_kernel, dim3(1), dim3(1), 0, 0, d_st, 1);
+            hipLaunchKernelGGL(cd_clear_pending_kernel, dim3(1), dim3(1), 0, ss::l2s::stream(), d_st, 1);
             for (int j = 0; j < p; j++) {
                 if (h.norm[j] == 0.0) continue;
-                hipLaunchKernelGGL(cd_step_kernel, dim3(blocks), dim3(CD_THREADS), 0, 0, d_X, N, j, d_st, d_R, d_part);
-                hipLaunchKernelGGL(cd_update_kernel, dim3(1), dim3(CD_THREADS), 0, 0, d_part, blocks, j, l1, l2, positive, d_st);
+                hipLaunchKernelGGL(cd_step_kernel, dim3(blocks), dim3(CD_THREADS), 0, ss::l2s::stream(), d_X, N, j, d_st, d_R, d_part);
+                hipLaunchKernelGGL(cd_update_kernel, dim3(1), dim3(CD_THREADS), 0, ss::l2s::stream(), d_part, blocks, j, l1, l2, positive, d_st);
             }
             CdState s2;
-            CD(hipMemcpy(&s2, d_st, sizeof s2, hipMemcpyDeviceToHost));
+            CD(ss::l2s::copy(&s2, d_st, sizeof s2, hipMemcpyDeviceToHost));
             if (e != hipSuccess) break;
             if (s2.w_max == 0.0 || s2.d_w_max / s2.w_max < d_w_tol || n_iter == max_iter - 1) {
-                hipLaunchKernelGGL(cd_gap_kernel, dim3(blocks), dim3(CD_THREADS), 0, 0, d_X, d_y, N, p, d_st, d_R, d_part);
-                hipLaunchKernelGGL(cd_sum_kernel, dim3(1), dim3(CD_THREADS), 0, 0, d_part, p + 2, blocks, d_st, 0);
-                hipLaunchKernelGGL(cd_clear_pending_kernel, dim3(1), dim3(1), 0, 0, d_st, 0);
-                CD(hipMemcpy(&s2, d_st, sizeof s2, hipMemcpyDeviceToHost));
+                hipLaunchKernelGGL(cd_gap_kernel, dim3(blocks), dim3(CD_THREADS), 0, ss::l2s::stream(), d_X, d_y, N, p, d_st, d_R, d_part);
+                hipLaunchKernelGGL(cd_sum_kernel, dim3(1), dim3(CD_THREADS), 0, ss::l2s::stream(), d_part, p + 2, blocks, d_st, 0);
+                hipLaunchKernelGGL(cd_clear_pending_kernel, dim3(1), dim3(1), 0, ss::l2s::stream(), d_st, 0);
+                CD(ss::l2s::copy(&s2, d_st, sizeof s2, hipMemcpyDeviceToHost));
                 if (e != hipSuccess) break;
                 double dual = 0.0, w_norm2 = 0.0, l1_norm = 0.0;
                 for (int j = 0; j < p; j++) {
@@ -412,7 +412,7 @@ int ss_enet_cd(const double *X, const double *y, uint64_t N, int p, double l1, d
         if (e != hipSuccess) { ss::set_last_error("ss_enet_cd", __FILE__, __LINE__, e); rc = SS_EHIP; }
     }
 #undef CD
-    hipFree(d_X); hipFree(d_y); hipFree(d_R); hipFree(d_part); hipFree(d_st);
+    ss::l2s::dfree(d_X); ss::l2s::dfree(d_y); ss::l2s::dfree(d_R); ss::l2s::dfree(d_part); ss::l2s::dfree(d_st);
     if (!rc) {
         for (int j = 0; j < p; j++) w[j] = h.w[j];
         if (gap_out) *gap_out = gap;

@@ -191,6 +191,30 @@ int ss_set_device(int dev) { SS_HIP(hipSetDevice(dev)); return SS_OK; }
 int ss_device_sync(void) { SS_HIP(hipDeviceSynchronize()); return SS_OK; }
 int ss_stream_sync(void *stream) { SS_HIP(hipStreamSynchronize(ss::as_stream(stream))); return SS_OK; }
 
+}  // extern "C"
+hipError_t ss::l2s::dmalloc(void **p, size_t n)
+{
+    static std::once_flag once;
+    std::call_once(once, [] {              // keep up to 2 GB of freed temporaries in the pool instead of returning them at every synchronisation
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        uint64_t keep = 2ull << 30;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+            hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    });
+    return hipMallocAsync(p, n ? n : 1, stream());
+}
+extern "C" {
+/* stream-ordered twins of ss_dev_alloc / ss_dev_free on the calling thread's stream (layer 2's temporaries) */
+int ss_dev_alloc_async(void **dptr, uint64_t bytes)
+{
+    if (!dptr) return SS_EINVAL;
+    SS_HIP(ss::l2s::dmalloc(dptr, bytes));
+    SS_HIP(ss::l2s::sync());               // the allocation has happened: the memory may be used from any stream
+    return SS_OK;
+}
+int ss_dev_free_async(void *dptr) { SS_HIP(ss::l2s::dfree(dptr)); return SS_OK; }
+
 int ss_dev_alloc(void **dptr, uint64_t bytes)
 {
     if (!dptr) return SS_EINVAL;

@@ -527,15 +527,15 @@ int csr_ptr_check(const int64_t *d_ptr, uint64_t K, int64_t nnz)
 {
     int *d_bad = nullptr, bad = 0;
     if (nnz < 0) return SS_EINVAL;
-    if (hipMalloc((void **)&d_bad, 4) != hipSuccess) return SS_ENOMEM;
+    if (ss::l2s::dmalloc((void **)&d_bad, 4) != hipSuccess) return SS_ENOMEM;
     int rc = SS_OK;
-    if (hipMemset(d_bad, 0, 4) != hipSuccess) rc = SS_EHIP;
+    if (ss::l2s::set(d_bad, 0, 4) != hipSuccess) rc = SS_EHIP;
     else {
-        hipLaunchKernelGGL(csr_ptr_check_kernel, dim3((unsigned)((K + 1 + NT - 1) / NT)), dim3(NT), 0, 0, d_ptr, K, nnz, d_bad);
-        if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+        hipLaunchKernelGGL(csr_ptr_check_kernel, dim3((unsigned)((K + 1 + NT - 1) / NT)), dim3(NT), 0, ss::l2s::stream(), d_ptr, K, nnz, d_bad);
+        if (hipGetLastError() != hipSuccess || ss::l2s::copy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
         else if (bad) rc = SS_EINVAL;
     }
-    hipFree(d_bad);
+    ss::l2s::dfree(d_bad);
     return rc;
 }
 
@@ -553,15 +553,15 @@ int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, c
     SS_HIP(hipMalloc((void **)&h->d_om_ptr, (h->K + 1) * 8));
     SS_HIP(hipMalloc((void **)&h->d_om_idx, std::max<uint64_t>(1, nnz) * 4));
     SS_HIP(hipMalloc((void **)&h->d_om_val, std::max<uint64_t>(1, nnz)));
-    SS_HIP(hipMemcpy(h->d_om_ptr, indptr, (h->K + 1) * 8, hipMemcpyHostToDevice));
+    SS_HIP(ss::l2s::copy(h->d_om_ptr, indptr, (h->K + 1) * 8, hipMemcpyHostToDevice));
     if (const int rc = csr_ptr_check(h->d_om_ptr, h->K, (int64_t)nnz)) {
         hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
         h->d_om_ptr = nullptr; h->d_om_idx = nullptr; h->d_om_val = nullptr;
         return rc;
     }
     if (nnz) {
-        SS_HIP(hipMemcpy(h->d_om_idx, indices, nnz * 4, hipMemcpyHostToDevice));
-        SS_HIP(hipMemcpy(h->d_om_val, data, nnz, hipMemcpyHostToDevice));
+        SS_HIP(ss::l2s::copy(h->d_om_idx, indices, nnz * 4, hipMemcpyHostToDevice));
+        SS_HIP(ss::l2s::copy(h->d_om_val, data, nnz, hipMemcpyHostToDevice));
     }
     h->om_cols = n_cols;
     h->has_om = true;
@@ -580,24 +580,24 @@ int ss_l2_prepare(const ss_l2 *h, const int64_t *y_host, const uint8_t *col_sel,
     uint8_t *d_sel = nullptr;
     unsigned long long *d_out = nullptr;
     int rc = SS_OK;
-    if (hipMalloc((void **)&d_y, h->K * 8) != hipSuccess || hipMalloc((void **)&d_sel, std::max<uint32_t>(1, h->om_cols)) != hipSuccess ||
-        hipMalloc((void **)&d_out, 24) != hipSuccess)
+    if (ss::l2s::dmalloc((void **)&d_y, h->K * 8) != hipSuccess || ss::l2s::dmalloc((void **)&d_sel, std::max<uint32_t>(1, h->om_cols)) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_out, 24) != hipSuccess)
         rc = SS_ENOMEM;
     hipError_t e = hipSuccess;
     if (!rc) {
-        e = hipMemcpy(d_y, y_host, h->K * 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess && h->om_cols) e = hipMemcpy(d_sel, col_sel, h->om_cols, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(d_out, 0, 24);
+        e = ss::l2s::copy(d_y, y_host, h->K * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && h->om_cols) e = ss::l2s::copy(d_sel, col_sel, h->om_cols, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = ss::l2s::set(d_out, 0, 24);
         if (e == hipSuccess) {
             const uint64_t rows = h->W * 32;                                // every word of the padded bit vectors is written
-            hipLaunchKernelGGL(l2_prepare_kernel, dim3((unsigned)((rows + NT - 1) / NT)), dim3(NT), 0, 0, d_y, h->K, h->d_om_ptr, h->d_om_idx,
+            hipLaunchKernelGGL(l2_prepare_kernel, dim3((unsigned)((rows + NT - 1) / NT)), dim3(NT), 0, ss::l2s::stream(), d_y, h->K, h->d_om_ptr, h->d_om_idx,
                                h->d_om_val, d_sel, h->om_cols, npp25, npp75, npp_out, y_dev, yu_dev, G_dev, Gu_dev, keep_dev, ykeep_dev, d_out, h->W);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpy(out, d_out, 24, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = ss::l2s::copy(out, d_out, 24, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { ss::set_last_error("ss_l2_prepare", __FILE__, __LINE__, e); rc = SS_EHIP; }
     }
-    hipFree(d_y); hipFree(d_sel); hipFree(d_out);
+    ss::l2s::dfree(d_y); ss::l2s::dfree(d_sel); ss::l2s::dfree(d_out);
     return rc;
 }
 
@@ -648,25 +648,25 @@ static int l2_fold_impl(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t
     size_t tmp_bytes = 0;
     int rc = SS_OK;
     hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_pre, (int)h->W);
-    if (e != hipSuccess || hipMalloc((void **)&d_cnt, h->W * 4) != hipSuccess || hipMalloc((void **)&d_pre, h->W * 4) != hipSuccess ||
-        (!bits_on_device && hipMalloc((void **)&d_bits, std::max<uint64_t>(1, n_keep) * 4) != hipSuccess) ||
-        hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess)
+    if (e != hipSuccess || ss::l2s::dmalloc((void **)&d_cnt, h->W * 4) != hipSuccess || ss::l2s::dmalloc((void **)&d_pre, h->W * 4) != hipSuccess ||
+        (!bits_on_device && ss::l2s::dmalloc((void **)&d_bits, std::max<uint64_t>(1, n_keep) * 4) != hipSuccess) ||
+        ss::l2s::dmalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)) != hipSuccess)
         rc = SS_ENOMEM;
     if (!rc) {
-        if (n_keep && !bits_on_device) e = hipMemcpy(d_bits, split_bits, n_keep * 4, hipMemcpyHostToDevice);
+        if (n_keep && !bits_on_device) e = ss::l2s::copy(d_bits, split_bits, n_keep * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(l2_popc_words_kernel, dim3((unsigned)((h->W + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, h->W, d_cnt);
-            e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_pre, (int)h->W);
+            hipLaunchKernelGGL(l2_popc_words_kernel, dim3((unsigned)((h->W + NT - 1) / NT)), dim3(NT), 0, ss::l2s::stream(), keep_dev, h->W, d_cnt);
+            e = hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_pre, (int)h->W, ss::l2s::stream());
         }
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(l2_fold_kernel, dim3((unsigned)((h->K + NT - 1) / NT)), dim3(NT), 0, 0, keep_dev, d_pre, h->K,
+            hipLaunchKernelGGL(l2_fold_kernel, dim3((unsigned)((h->K + NT - 1) / NT)), dim3(NT), 0, ss::l2s::stream(), keep_dev, d_pre, h->K,
                                bits_on_device ? split_bits : d_bits, inv, fold_dev);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = ss::l2s::sync();
         if (e != hipSuccess) { ss::set_last_error("ss_l2_fold", __FILE__, __LINE__, e); rc = SS_EHIP; }
     }
-    hipFree(d_cnt); hipFree(d_pre); hipFree(d_bits); hipFree(d_tmp);
+    ss::l2s::dfree(d_cnt); ss::l2s::dfree(d_pre); ss::l2s::dfree(d_bits); ss::l2s::dfree(d_tmp);
     return rc;
 }
 
@@ -685,13 +685,13 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
     int *d_bad = nullptr;
     int rc = SS_OK, bad = 0;
     const uint64_t xbytes = std::max<uint64_t>(1, (uint64_t)S) * h->W * 4;
-    if (hipMalloc((void **)&h->d_x, xbytes) != hipSuccess || hipMalloc((void **)&d_ptr, (K + 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&d_idx, std::max<uint64_t>(1, nnz) * 4) != hipSuccess ||
-        hipMalloc((void **)&d_bad, 4) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_x, xbytes) != hipSuccess || ss::l2s::dmalloc((void **)&d_ptr, (K + 1) * 8) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_idx, std::max<uint64_t>(1, nnz) * 4) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_bad, 4) != hipSuccess) {
         rc = SS_ENOMEM;
-    } else if (hipMemset(h->d_x, 0, xbytes) != hipSuccess || hipMemset(d_bad, 0, 4) != hipSuccess ||
-               hipMemcpy(d_ptr, indptr, (K + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
-               (nnz && hipMemcpy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+    } else if (ss::l2s::set(h->d_x, 0, xbytes) != hipSuccess || ss::l2s::set(d_bad, 0, 4) != hipSuccess ||
+               ss::l2s::copy(d_ptr, indptr, (K + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+               (nnz && ss::l2s::copy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
         rc = SS_EHIP;
     } else if ((rc = csr_ptr_check(d_ptr, K, (int64_t)nnz)) != SS_OK) {
         // (a row pointer array the pack kernels could not walk safely)
@@ -700,26 +700,26 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
         int redo = 1;
         const bool no_span = getenv("SS_L2_PACK_WALK") != nullptr;                    // A/B and tests: the row-walk kernel
         if (!force_atomic && !no_span && S <= PACK_SMAX) {
-            hipLaunchKernelGGL(pack_csr_span_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), (size_t)S * 8 + 65 * 8, 0, d_ptr, d_idx, K, S,
+            hipLaunchKernelGGL(pack_csr_span_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), (size_t)S * 8 + 65 * 8, ss::l2s::stream(), d_ptr, d_idx, K, S,
                                h->W, h->d_x, d_bad);
-            if (hipGetLastError() != hipSuccess || hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            if (hipGetLastError() != hipSuccess || ss::l2s::copy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
             else if (bad) rc = SS_EINVAL;
             redo = 0;
         } else if (!force_atomic) {
-            hipLaunchKernelGGL(pack_csr_sorted_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
+            hipLaunchKernelGGL(pack_csr_sorted_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ss::l2s::stream(), d_ptr, d_idx, K, S,
                                h->W, h->d_x, d_bad);
-            if (hipMemcpy(&redo, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            if (ss::l2s::copy(&redo, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
         }
         if (!rc && redo) {
-            hipMemset(d_bad, 0, 4);
-            hipMemset(h->d_x, 0, xbytes);
-            hipLaunchKernelGGL(pack_csr_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, 0, d_ptr, d_idx, K, S,
+            ss::l2s::set(d_bad, 0, 4);
+            ss::l2s::set(h->d_x, 0, xbytes);
+            hipLaunchKernelGGL(pack_csr_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ss::l2s::stream(), d_ptr, d_idx, K, S,
                                h->W, h->d_x, d_bad);
-            if (hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            if (ss::l2s::copy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
             else if (bad) rc = SS_EINVAL;
         }
     }
-    hipFree(d_ptr); hipFree(d_idx); hipFree(d_bad);
+    ss::l2s::dfree(d_ptr); ss::l2s::dfree(d_idx); ss::l2s::dfree(d_bad);
     if (rc) { hipFree(h->d_x); delete h; return rc; }
     *out = h;
     return SS_OK;
@@ -744,8 +744,8 @@ int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **
             if (pl[w]) { delete h; return SS_EINVAL; }
     }
     if (hipMalloc((void **)&h->d_x, xbytes) != hipSuccess) { delete h; return SS_ENOMEM; }
-    if ((K == 0 && hipMemset(h->d_x, 0, xbytes) != hipSuccess) ||
-        (K && words && hipMemcpy(h->d_x, planes, words * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+    if ((K == 0 && ss::l2s::set(h->d_x, 0, xbytes) != hipSuccess) ||
+        (K && words && ss::l2s::copy(h->d_x, planes, words * 4, hipMemcpyHostToDevice) != hipSuccess)) {
         hipFree(h->d_x);
         delete h;
         return SS_EHIP;
@@ -757,7 +757,7 @@ int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **
 int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes)
 {
     if (!h || (!planes && h->S)) return SS_EINVAL;
-    if (h->S) SS_HIP(hipMemcpy(planes, h->d_x, (uint64_t)h->S * h->W * 4, hipMemcpyDeviceToHost));
+    if (h->S) SS_HIP(ss::l2s::copy(planes, h->d_x, (uint64_t)h->S * h->W * 4, hipMemcpyDeviceToHost));
     return SS_OK;
 }
 
@@ -784,13 +784,13 @@ int ss_l2_popc2(const ss_l2 *h, const uint32_t *A_dev, const uint32_t *B_dev, ui
     if (!h || !out1 || !out2) return SS_EINVAL;
     if (!h->S) return SS_OK;
     unsigned long long *d = nullptr;
-    SS_HIP(hipMalloc((void **)&d, (uint64_t)h->S * 16));
-    hipMemset(d, 0, (uint64_t)h->S * 16);
-    hipLaunchKernelGGL(popc2_kernel, dim3(grid_for(h->W / 4, h->S), h->S), dim3(NT), 0, 0, h->d_x, h->W, A_dev, B_dev,
+    SS_HIP(ss::l2s::dmalloc((void **)&d, (uint64_t)h->S * 16));
+    ss::l2s::set(d, 0, (uint64_t)h->S * 16);
+    hipLaunchKernelGGL(popc2_kernel, dim3(grid_for(h->W / 4, h->S), h->S), dim3(NT), 0, ss::l2s::stream(), h->d_x, h->W, A_dev, B_dev,
                        d, d + h->S);
-    hipError_t e = hipMemcpy(out1, d, (uint64_t)h->S * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out2, d + h->S, (uint64_t)h->S * 8, hipMemcpyDeviceToHost);
-    hipFree(d);
+    hipError_t e = ss::l2s::copy(out1, d, (uint64_t)h->S * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = ss::l2s::copy(out2, d + h->S, (uint64_t)h->S * 8, hipMemcpyDeviceToHost);
+    ss::l2s::dfree(d);
     if (e != hipSuccess) { ss::set_last_error("ss_l2_popc2", __FILE__, __LINE__, e); return SS_EHIP; }
     return SS_OK;
 }
@@ -798,7 +798,7 @@ int ss_l2_popc2(const ss_l2 *h, const uint32_t *A_dev, const uint32_t *B_dev, ui
 int ss_l2_andnot_col(const ss_l2 *h, uint32_t col, uint32_t *nu_dev)
 {
     if (!h || !nu_dev || col >= h->S) return SS_EINVAL;
-    hipLaunchKernelGGL(andnot_col_kernel, dim3((unsigned)std::min<uint64_t>((h->W + 255) / 256, 2048)), dim3(256), 0, 0,
+    hipLaunchKernelGGL(andnot_col_kernel, dim3((unsigned)std::min<uint64_t>((h->W + 255) / 256, 2048)), dim3(256), 0, ss::l2s::stream(),
                        h->d_x, h->W, col, nu_dev);
     SS_HIP(hipGetLastError());
     return SS_OK;
@@ -815,40 +815,40 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
     SelState *d_st = nullptr;
     unsigned long long *d_out = nullptr;
     int rc = SS_OK;
-    if (hipMalloc((void **)&d_cols, ncols * 4) != hipSuccess || hipMalloc((void **)&d_hist, (uint64_t)ncols * 2048) != hipSuccess ||
-        hipMalloc((void **)&d_st, ncols * sizeof(SelState)) != hipSuccess ||
-        hipMalloc((void **)&d_out, (uint64_t)ncols * 16) != hipSuccess)
+    if (ss::l2s::dmalloc((void **)&d_cols, ncols * 4) != hipSuccess || ss::l2s::dmalloc((void **)&d_hist, (uint64_t)ncols * 2048) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_st, ncols * sizeof(SelState)) != hipSuccess ||
+        ss::l2s::dmalloc((void **)&d_out, (uint64_t)ncols * 16) != hipSuccess)
         rc = SS_ENOMEM;
     if (!rc) {
-        hipMemcpy(d_cols, cols, ncols * 4, hipMemcpyHostToDevice);
-        hipMemset(d_hist, 0, (uint64_t)ncols * 2048);
-        hipMemset(d_st, 0, ncols * sizeof(SelState));
-        hipMemset(d_out, 0, (uint64_t)ncols * 16);
+        ss::l2s::copy(d_cols, cols, ncols * 4, hipMemcpyHostToDevice);
+        ss::l2s::set(d_hist, 0, (uint64_t)ncols * 2048);
+        ss::l2s::set(d_st, 0, ncols * sizeof(SelState));
+        ss::l2s::set(d_out, 0, (uint64_t)ncols * 16);
         const unsigned ctiles = (ncols + CT - 1) / CT;
         const dim3 grid(grid_for((h->K + 3) / 4, ctiles), ctiles);      // one lane per four rows, CT columns per workgroup
         // the radix passes start at the highest byte that is non-zero in any value (k-mer counts are small numbers:
         // usually ONE pass instead of four, each of which reads the bit planes and gathers y for every set bit)
         uint32_t *d_max = reinterpret_cast<uint32_t *>(d_out), ymax = 0;       // d_out is zero and unused until sel_sum_kernel
-        hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)std::min<uint64_t>((h->K + 1023) / 1024, 512)), dim3(256), 0, 0, y_dev, h->K, d_max);
+        hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)std::min<uint64_t>((h->K + 1023) / 1024, 512)), dim3(256), 0, ss::l2s::stream(), y_dev, h->K, d_max);
         hipError_t e0 = hipGetLastError();
-        if (e0 == hipSuccess) e0 = hipMemcpy(&ymax, d_max, 4, hipMemcpyDeviceToHost);
-        if (e0 == hipSuccess) e0 = hipMemset(d_max, 0, 4);
+        if (e0 == hipSuccess) e0 = ss::l2s::copy(&ymax, d_max, 4, hipMemcpyDeviceToHost);
+        if (e0 == hipSuccess) e0 = ss::l2s::set(d_max, 0, 4);
         if (e0 != hipSuccess) {             // without the maximum the passes cannot be shortened safely: report, do not guess
             ss::set_last_error("ss_l2_quantile_sums (max of y)", __FILE__, __LINE__, e0);
-            hipFree(d_cols); hipFree(d_hist); hipFree(d_st); hipFree(d_out);
+            ss::l2s::dfree(d_cols); ss::l2s::dfree(d_hist); ss::l2s::dfree(d_st); ss::l2s::dfree(d_out);
             return SS_EHIP;
         }
         const int top = ymax >> 24 ? 24 : ymax >> 16 ? 16 : ymax >> 8 ? 8 : 0;
         for (int shift = top; shift >= 0; shift -= 8) {
-            if (shift == top) hipLaunchKernelGGL((sel_hist_kernel<true>), grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, ncols, shift, d_st, d_hist);
-            else hipLaunchKernelGGL((sel_hist_kernel<false>), grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, ncols, shift, d_st, d_hist);
-            hipLaunchKernelGGL(sel_pick_kernel, dim3((ncols + 63) / 64), dim3(64), 0, 0, (int)(shift == top), q_lo, q_hi, d_st, d_hist, ncols);
+            if (shift == top) hipLaunchKernelGGL((sel_hist_kernel<true>), grid, dim3(NT), 0, ss::l2s::stream(), h->d_x, h->W, h->K, y_dev, d_cols, ncols, shift, d_st, d_hist);
+            else hipLaunchKernelGGL((sel_hist_kernel<false>), grid, dim3(NT), 0, ss::l2s::stream(), h->d_x, h->W, h->K, y_dev, d_cols, ncols, shift, d_st, d_hist);
+            hipLaunchKernelGGL(sel_pick_kernel, dim3((ncols + 63) / 64), dim3(64), 0, ss::l2s::stream(), (int)(shift == top), q_lo, q_hi, d_st, d_hist, ncols);
         }
-        hipLaunchKernelGGL(sel_sum_kernel, grid, dim3(NT), 0, 0, h->d_x, h->W, h->K, y_dev, d_cols, ncols, d_st, d_out);
+        hipLaunchKernelGGL(sel_sum_kernel, grid, dim3(NT), 0, ss::l2s::stream(), h->d_x, h->W, h->K, y_dev, d_cols, ncols, d_st, d_out);
         std::vector<SelState> st(ncols);
         std::vector<unsigned long long> o((size_t)ncols * 2);
-        hipError_t e = hipMemcpy(st.data(), d_st, ncols * sizeof(SelState), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(o.data(), d_out, (uint64_t)ncols * 16, hipMemcpyDeviceToHost);
+        hipError_t e = ss::l2s::copy(st.data(), d_st, ncols * sizeof(SelState), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = ss::l2s::copy(o.data(), d_out, (uint64_t)ncols * 16, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { ss::set_last_error("ss_l2_quantile_sums", __FILE__, __LINE__, e); rc = SS_EHIP; }
         else
             for (uint32_t i = 0; i < ncols; i++) {
@@ -859,7 +859,7 @@ int ss_l2_quantile_sums(const ss_l2 *h, const uint32_t *y_dev, const uint32_t *c
                 if (sum_in) sum_in[i] = o[(size_t)i * 2 + 1];
             }
     }
-    hipFree(d_cols); hipFree(d_hist); hipFree(d_st); hipFree(d_out);
+    ss::l2s::dfree(d_cols); ss::l2s::dfree(d_hist); ss::l2s::dfree(d_st); ss::l2s::dfree(d_out);
     return rc;
 }
 
@@ -873,18 +873,18 @@ int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint3
     const uint64_t n = (uint64_t)(n_folds + 1) * M * 3;
     uint32_t *d_cols = nullptr;
     unsigned long long *d_stats = nullptr;
-    SS_HIP(hipMalloc((void **)&d_cols, 16 * 4));
-    if (hipMalloc((void **)&d_stats, n * 8) != hipSuccess) { hipFree(d_cols); return SS_ENOMEM; }
+    SS_HIP(ss::l2s::dmalloc((void **)&d_cols, 16 * 4));
+    if (ss::l2s::dmalloc((void **)&d_stats, n * 8) != hipSuccess) { ss::l2s::dfree(d_cols); return SS_ENOMEM; }
     uint32_t c16[16] = {0};
     for (int i = 0; i < p; i++) c16[i] = cols[i];
-    hipMemcpy(d_cols, c16, 64, hipMemcpyHostToDevice);
-    hipMemset(d_stats, 0, n * 8);
+    ss::l2s::copy(d_cols, c16, 64, hipMemcpyHostToDevice);
+    ss::l2s::set(d_stats, 0, n * 8);
     static const bool per_group = getenv("SS_L2_STATS_PER_GROUP") != nullptr;       // A/B and tests: the general kernel
     const size_t once_bytes = (size_t)(n_folds + 1) * M * 24;                        // one copy of the tables of the one-pass kernel
     if (p <= 6 && once_bytes <= 32 * 1024 && !per_group) {
         const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(512, (h->K + 64 * (NT / 64) - 1) / (64 * (NT / 64))));
         const int copies = once_bytes * 8 <= 64 * 1024 ? 8 : once_bytes * 4 <= 64 * 1024 ? 4 : 2;
-#define SS_ONCE(C) hipLaunchKernelGGL((pattern_stats_once_kernel<C>), dim3(blocks), dim3(NT), once_bytes * C, 0, h->d_x, h->W, h->K, d_cols, \
+#define SS_ONCE(C) hipLaunchKernelGGL((pattern_stats_once_kernel<C>), dim3(blocks), dim3(NT), once_bytes * C, ss::l2s::stream(), h->d_x, h->W, h->K, d_cols, \
                                       p, y_dev, fold_dev, n_folds, d_stats)
         if (copies == 8) SS_ONCE(8); else if (copies == 4) SS_ONCE(4); else SS_ONCE(2);
 #undef SS_ONCE
@@ -892,11 +892,11 @@ int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint3
         const int use_lds = (M * 24 <= 48 * 1024) ? 1 : 0;   // p <= 11
         const size_t lds = use_lds ? (size_t)M * 24 : 0;
         hipLaunchKernelGGL(pattern_stats_kernel, dim3(grid_for(h->W, (unsigned)n_folds + 1), (unsigned)n_folds + 1), dim3(NT),
-                           lds, 0, h->d_x, h->W, h->K, d_cols, p, y_dev, fold_dev, n_folds, d_stats, use_lds);
+                           lds, ss::l2s::stream(), h->d_x, h->W, h->K, d_cols, p, y_dev, fold_dev, n_folds, d_stats, use_lds);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpy(stats, d_stats, n * 8, hipMemcpyDeviceToHost);
-    hipFree(d_cols); hipFree(d_stats);
+    if (e == hipSuccess) e = ss::l2s::copy(stats, d_stats, n * 8, hipMemcpyDeviceToHost);
+    ss::l2s::dfree(d_cols); ss::l2s::dfree(d_stats);
     if (e != hipSuccess) { ss::set_last_error("ss_l2_pattern_stats", __FILE__, __LINE__, e); return SS_EHIP; }
     return SS_OK;
 }

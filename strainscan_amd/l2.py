@@ -14,12 +14,16 @@ from . import _lib
 
 
 class DevBuf:
-    """A device allocation owned by Python (freed on close/GC)."""
+    """A device allocation owned by Python (freed on close/GC): from the stream-ordered pool, on the calling thread's stream --
+    layer 2 works there (csrc/ss_common.h l2s), and clusters solved on several host threads must not meet in hipFree's
+    device-wide synchronisation.  Freed by another thread (the garbage collector's), it goes the synchronous way."""
 
     def __init__(self, nbytes):
+        import threading
         self.ptr = C.c_void_p()
         self.nbytes = int(nbytes)
-        _lib.check(_lib.lib().ss_dev_alloc(C.byref(self.ptr), max(16, self.nbytes)), "ss_dev_alloc")
+        self._owner = threading.get_ident()
+        _lib.check(_lib.lib().ss_dev_alloc_async(C.byref(self.ptr), max(16, self.nbytes)), "ss_dev_alloc_async")
 
     @classmethod
     def from_array(cls, a):
@@ -31,7 +35,11 @@ class DevBuf:
 
     def close(self):
         if self.ptr:
-            _lib.lib().ss_dev_free(self.ptr)
+            import threading
+            if threading.get_ident() == self._owner:
+                _lib.lib().ss_dev_free_async(self.ptr)
+            else:
+                _lib.lib().ss_dev_free(self.ptr)
             self.ptr = None
 
     def __del__(self):
