@@ -141,37 +141,33 @@ def make_db(torch, dev, n_leaves, seed, lo_sites=500, hi_sites=15000, shape="con
                 n_nodes=n_nodes, shape=shape)
 
 
-def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
-    """Reads of a three-strain mix.  A strain genome = the node sequences on its root->leaf path
-    (these are the reads' database hits) + private filler so that about `hit_frac` of the read
-    k-mers are database k-mers, as for a 5 Mb genome against its ~1e5 path k-mers."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    rs = np.random.RandomState(seed)
-    n_nodes = db["n_nodes"]
-    genomes = []
-    leaves = rs.choice(np.arange(n_nodes // 2, n_nodes), size=len(mix), replace=False)
-    for leaf in leaves:
-        path = []
-        i = int(leaf)
-        while True:
-            path.append(i)
-            if i == 0:
-                break
-            i = (i - 1) // 2
-        parts = [db["codes"][int(db["seq_off"][p]):int(db["seq_off"][p + 1])] for p in path[::-1]]
-        core = torch.cat(parts)
-        n_db = sum(int(db["sites"][p]) for p in path)                 # database k-mers per orientation on the path
-        n_fill = max(0, int(n_db / hit_frac) - int(core.numel()))
-        filler = torch.randint(0, 4, (n_fill,), generator=g, device=dev, dtype=torch.uint8)
-        # interleave core pieces into the filler so hits are spread over the genome
-        chunks = list(torch.tensor_split(filler, len(parts)))
-        genomes.append(torch.cat([x for pair in zip(chunks, parts) for x in pair]))
+def path_genome(torch, dev, db, leaf, hit_frac, g):
+    """A strain genome of the leaf `leaf` (heap index): the node sequences on its root->leaf path (these are the reads' database
+    hits) + private filler so that about `hit_frac` of the read k-mers are database k-mers, as for a 5 Mb genome against its
+    ~1e5 path k-mers; the core pieces are interleaved into the filler so that the hits are spread over the genome."""
+    path = []
+    i = int(leaf)
+    while True:
+        path.append(i)
+        if i == 0:
+            break
+        i = (i - 1) // 2
+    parts = [db["codes"][int(db["seq_off"][p]):int(db["seq_off"][p + 1])] for p in path[::-1]]
+    core = torch.cat(parts)
+    n_db = sum(int(db["sites"][p]) for p in path)                 # database k-mers per orientation on the path
+    n_fill = max(0, int(n_db / hit_frac) - int(core.numel()))
+    filler = torch.randint(0, 4, (n_fill,), generator=g, device=dev, dtype=torch.uint8)
+    chunks = list(torch.tensor_split(filler, len(parts)))
+    return torch.cat([x for pair in zip(chunks, parts) for x in pair])
+
+
+def reads_of(torch, dev, genomes, counts, g):
+    """counts[i] reads of READ_LEN bases from genomes[i] (code tensors 0..3): uniform starts, strand 50/50, 0.5 % substitutions;
+    the strains interleaved (a FASTQ is not sorted by source genome).  -> flat uint8 block, one record per READ_LEN + 1 bytes."""
+    n_reads = int(sum(int(c) for c in counts))
     asc = torch.tensor([65, 67, 84, 71], dtype=torch.uint8, device=dev)      # device codes 0..3 -> A C T G
     out = torch.empty(n_reads * (READ_LEN + 1), dtype=torch.uint8, device=dev)
     view = out.view(n_reads, READ_LEN + 1)
-    counts = (np.array(mix) * n_reads).astype(np.int64)
-    counts[0] += n_reads - counts.sum()
     ar = torch.arange(READ_LEN, device=dev)
     row = 0
     chunk = 1 << 20
@@ -190,10 +186,21 @@ def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
             row += m
             done += m
     view[:, READ_LEN] = 10
-    # interleave the strains (a FASTQ is not sorted by source genome)
     perm = torch.randperm(n_reads, generator=g, device=dev)
-    out = view[perm].contiguous().view(-1)
-    return out
+    return view[perm].contiguous().view(-1)
+
+
+def make_reads(torch, dev, db, n_reads, seed, hit_frac, mix=(0.7, 0.2, 0.1)):
+    """Reads of a three-strain mix (path_genome of three random leaves, reads_of)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rs = np.random.RandomState(seed)
+    n_nodes = db["n_nodes"]
+    leaves = rs.choice(np.arange(n_nodes // 2, n_nodes), size=len(mix), replace=False)
+    genomes = [path_genome(torch, dev, db, leaf, hit_frac, g) for leaf in leaves]
+    counts = (np.array(mix) * n_reads).astype(np.int64)
+    counts[0] += n_reads - counts.sum()
+    return reads_of(torch, dev, genomes, counts, g)
 
 
 def heap_to_id(h, C):
@@ -202,9 +209,11 @@ def heap_to_id(h, C):
     return C + 1 + h if h < C - 1 else h - (C - 1) + 1
 
 
-def write_tree_files(db_spec, C, tdir):
+def write_tree_files(db_spec, C, tdir, multi=None):
     """The small text files of a Tree_database (tree_structure.txt, node_length.txt, reconstructed_nodes.txt,
-    hclsMap_95_recls.txt; Build_tree.py:494-526,664-673) for the synthetic tree -- what the host walk reads."""
+    hclsMap_95_recls.txt; Build_tree.py:494-526,664-673) for the synthetic tree -- what the host walk reads.
+    multi: {leaf id: [strain names]} -- clusters of several strains (no 4th column in tree_structure.txt)."""
+    multi = multi or {}
     os.makedirs(os.path.join(tdir, "overlapping_info"), exist_ok=True)
     n_nodes = db_spec["n_nodes"]
     per_node = np.diff(db_spec["row_off"].astype(np.int64))
@@ -214,12 +223,13 @@ def write_tree_files(db_spec, C, tdir):
             h = i - (C + 1) if i > C else i - 1 + (C - 1)
             par = "N" if h == 0 else str(heap_to_id((h - 1) // 2, C))
             ch = "N" if h >= C - 1 else "%d %d" % tuple(sorted((heap_to_id(2 * h + 1, C), heap_to_id(2 * h + 2, C))))
-            f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, "strain_%d" % i if h >= C - 1 else ""))
+            f.write("%d\t%s\t%s\t%s\n" % (i, par, ch, "strain_%d" % i if h >= C - 1 and i not in multi else ""))
             g.write("%d\t%d\n" % (i, int(per_node[h])))
     open(os.path.join(tdir, "reconstructed_nodes.txt"), "w").close()
     with open(os.path.join(tdir, "hclsMap_95_recls.txt"), "w") as f:
         for leaf in range(1, C + 1):
-            f.write("%d\t1\tstrain_%d\n" % (leaf, leaf))
+            names = multi.get(leaf) or ["strain_%d" % leaf]
+            f.write("%d\t%d\t%s\n" % (leaf, len(names), ",".join(names)))
 
 
 def write_fastq(reads_dev, n_reads, path, noisy_quality_seed=None):

@@ -74,14 +74,8 @@ def identify_with_ladder(in_fq, tdb, ldep, mdb):
 
 def _clock(what):
     """SS_CLI_TRACE=1: seconds since the interpreter started, at the CLI's milestones."""
-    if os.environ.get("SS_CLI_TRACE"):
-        import time
-        try:
-            import psutil
-            t0 = psutil.Process().create_time()
-        except Exception:                   # noqa: B902
-            t0 = time.time()
-        sys.stderr.write("[cli] %-28s %.3f s after process start\n" % (what, time.time() - t0))
+    from ._lib import cli_clock
+    cli_clock(what)
 
 
 def main(argv=None):

@@ -240,6 +240,7 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
         counts = [None] * len(todo)
         if len(todo) > 1 and os.environ.get("SS_L2_ONE_PASS", "1") != "0":
             counts = cluster_counts_many(input_fq, fq2, [item[1] for item in todo], ksize)
+            _lib.cli_clock("cluster tables scanned (%d)" % len(todo))
         if nthreads == 1:
             for item, c in zip(todo, counts):
                 vote_strain_L2(item, c)
@@ -248,5 +249,6 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
             with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="ss-l2") as pool:
                 for fut in [pool.submit(vote_strain_L2, item, c) for item, c in zip(todo, counts)]:
                     fut.result()                      # re-raises the first failure, in submission order
+        _lib.cli_clock("clusters solved (%d)" % len(todo))
         print("- Generate final report ...")
         merge_res(out_dir, res)

@@ -19,6 +19,20 @@ NO_CHAIN = C.cast(None, GZ_CHAIN_FN)
 ROW_VALID, ROW_LOWER = 1, 2
 
 
+def cli_clock(what):
+    """SS_CLI_TRACE=1: seconds since the interpreter started, at the milestones of a run (stderr).  scripts/bench_cli_l2.py
+    reads these lines to say where a fresh `strainscan` process spends its time."""
+    if os.environ.get("SS_CLI_TRACE"):
+        import sys
+        import time
+        try:
+            import psutil
+            t0 = psutil.Process().create_time()
+        except Exception:                   # noqa: B902
+            t0 = time.time()
+        sys.stderr.write("[cli] %-44s %.3f s after process start\n" % (what, time.time() - t0))
+
+
 class SSError(RuntimeError):
     def __init__(self, code, where=""):
         self.code = code
