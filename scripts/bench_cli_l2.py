@@ -121,12 +121,16 @@ def run_cli(args, env):
         m = CLOCK_RE.match(ln.strip())
         if m:
             marks.append((m.group(1).strip(), float(m.group(2))))
-    phases, prev = {}, 0.0
+    # (the milestones count from the process's creation time as psutil reads it, which is off by a constant against this
+    #  process's clock: only their differences are used; what comes before main() is the wall time minus the rest)
+    phases, prev = {}, None
     for name, t in marks:
-        phases[name] = round(t - prev, 3)
+        if prev is not None:
+            phases[name] = round(t - prev, 3)
         prev = t
-    return dict(wall_s=round(wall, 3), rc=r.returncode, milestones_s={k_: v for k_, v in marks}, between_milestones_s=phases,
-                stderr_tail=None if r.returncode == 0 else r.stderr[-600:])
+    if marks:
+        phases = dict({"interpreter, imports, HIP start (wall - the rest)": round(wall - (marks[-1][1] - marks[0][1]), 3)}, **phases)
+    return dict(wall_s=round(wall, 3), rc=r.returncode, phases_s=phases, stderr_tail=None if r.returncode == 0 else r.stderr[-600:])
 
 
 def main():
