@@ -424,3 +424,123 @@ def revcomp(s: bytes) -> bytes:
     out = C.create_string_buffer(len(s))
     lib().orc_revcomp(s, out, len(s))
     return out.raw
+
+
+# ---------------------------------------------------------------------------------------------
+# The serial layer-2 pipeline of the reference, end to end (small cases): detect_strains
+# (identify_strains_L2_Enet_Pscan_new_sp.py:177-478), vote_strain_L2's report
+# (Vote_Strain_L2_Lasso_new_sp.py:334-438) and merge_res (:116-170), from the pieces above.
+# Pinned to the reference's own report files (tests/golden/e2e_reports.json, l2_batch.json) in
+# tests/test_oracle_golden.py; the -m gpu tests compare the product's reports of other samples with it.
+# ---------------------------------------------------------------------------------------------
+def detect_strains(X, O, sid, y, ksize, npp25, npp75, npp_out, all_cls, l2, msn, pmode=0, emode=0):
+    """X: dense K x S 0/1, O: dense K x n_clusters 0/1, y int64[K] (1s already zeroed).
+    -> (res, res2, strain_cov, strain_val, final_src) like the reference."""
+    X = np.asarray(X).astype(np.int64)
+    y = np.asarray(y, np.int64)
+    om = np.asarray(O).astype(np.int64)[:, [int(a - 1) for a in all_cls]]
+    ln = om.sum(axis=1)
+    ln[ln > 1] = 0                                                   # :191-197
+    cols, names, scov, sval, fsrc, depth = prescan(X, y, y * ln, sid, msn * ksize, l2, pmode, emode)
+    if len(cols) == 1:                                               # :379-382
+        return {names[0]: 1}, {names[0]: depth}, scov, sval, fsrc
+    keep = ~((y < npp25) | (y > npp75) | (y > npp_out))              # :402-415 (a NaN bound keeps every row)
+    Xs, ys = X[keep][:, cols], y[keep]
+    alphas, mse = enet_cv(Xs, ys)
+    alpha, _, _ = lasso_mpm(alphas, mse)
+    coef = np.atleast_1d(enet_fit(Xs, ys, alpha))
+    if not np.sum(coef) == 0:                                        # :465-471
+        return dict(zip(names, list(coef / np.sum(coef)))), dict(zip(names, list(coef))), scov, sval, fsrc
+    return {}, {}, scov, sval, fsrc
+
+
+STRAINVOTE_HEADER = ("Strain_ID\tStrain_Name\tCluster_ID\tRelative_Abundance_Inside_Cluster\tPredicted_Depth (Enet)\t"
+                     "Predicted_Depth (Ab*cls_depth)\tCoverage\tCoverd/Total_kmr\tValid_kmr\tRemain_Coverage\tCV\tExist_Evidence\n")
+
+
+def vote_cluster(counts, X, O, sid, ksize, cls_ab, cls, all_cls, l2, msn, pmode=0, emode=0):
+    """Vote_...:384-438 given the cluster's k-mer counts ordered by k-mer id: y = counts with 1s zeroed (remove_1 :312-322),
+    npp_outlier = 1000 x median of the non-zero counts (:403-414), detect_strains, the report text ('' when nothing came back)."""
+    y = np.asarray(counts, np.int64).copy()
+    y[y == 1] = 0
+    nz = y[y != 0]
+    with np.errstate(invalid="ignore"):
+        npp_out = np.median(nz) * 1000 if nz.size else float("nan")
+    res, res2, scov, sval, fsrc = detect_strains(X, O, sid, y, int(ksize), 0, npp_out, npp_out, all_cls, l2, msn, pmode, emode)
+    if len(res) == 0:
+        return ""
+    nr = sorted(res.items(), key=lambda d: d[1], reverse=True)
+    tdep = sum(res2[n[0]] for n in nr)
+    out = [STRAINVOTE_HEADER]
+    for c, n in enumerate(nr, 1):
+        name = n[0]
+        body = ("\t" + cls + "\t" + str(n[1]) + "\t" + str(res2[name]) + "\t" + str((res2[name] / tdep) * cls_ab) + "\t" +
+                str(scov[name][0]) + "\t" + str(scov[name][1]) + "/" + str(scov[name][2]) + "\t" + str(sval[name]) + "\t" + str(fsrc[name]))
+        if n[1] > 0.02 and scov[name][0] > 0.7:
+            out.append(str(c) + "\t" + name + body + "\t*\n")
+        elif emode == 1:
+            out.append(str(c) + "\t" + name + " (With_ExtraRegion_covered)" + body + "\t\n")
+        else:
+            out.append(str(c) + "\t" + name + body + "\t\n")
+    return "".join(out)
+
+
+def merge_reports(res, reports):
+    """merge_res (:116-170): res = layer 1's dict, reports = {cluster id: StrainVote.report text or ''} -> final_report.txt text."""
+    dinfo, total = {}, 0.0
+    for r in res:
+        if not res[r]["strain"] == 0:
+            s = res[r]["strain"]
+            total += float(res[r]["s_ab"])
+            dinfo[s] = dict(cid="C" + str(r), pde="NA", pda=float(res[r]["s_ab"]), cov=float(res[r]["cls_cov"]),
+                            ct=str(res[r]["cls_covered_num"]) + "/" + str(res[r]["cls_total_num"]))
+        else:
+            text = reports.get(r, "")
+            if not text:
+                continue
+            pda = pde = 0.0
+            tem = []
+            for line in text.split("\n")[1:]:
+                if not line.strip():
+                    break
+                ele = line.strip().split("\t")
+                pda += float(ele[5])
+                pde += float(ele[4])
+                dinfo[ele[1]] = dict(cid=ele[2], pde=str(ele[4]), pda=float(ele[5]), cov=str(ele[6]), ct=str(ele[7]))
+                tem.append(ele[1])
+            if len(tem) == 1:
+                total += pde
+                dinfo[tem[0]]["pda"] = float(dinfo[tem[0]]["pde"])
+            else:
+                total += pda
+    fr = sorted(((s, d["pda"] / total) for s, d in dinfo.items()), key=lambda d: d[1], reverse=True)
+    out = ["ID\tStrain_Name\tCluster_ID\tRelative_Abundance\tPredicted_Depth (Enet)\tPredicted_Depth (Ab*cls_depth)\tCoverage\tCoverd/Total_kmr\n"]
+    for c, (s, ab) in enumerate(fr, 1):
+        d = dinfo[s]
+        out.append(str(c) + "\t" + s + "\t" + d["cid"] + "\t" + str(ab) + "\t" + str(d["pde"]) + "\t" + str(d["pda"]) + "\t" +
+                   str(d["cov"]) + "\t" + d["ct"] + "\n")
+    return "".join(out)
+
+
+def vote_batch(db_dir, reads, res, ksize=31, l2=0, msn=40, pmode=0, emode=0):
+    """vote_strain_L2_batch (:247-311) on a database directory written by tests/synth.py (small clusters: the matrices are made
+    dense) -> {relative path: text} of the report files the reference would write.  Exceptions propagate like the reference's."""
+    import pickle
+    import scipy.sparse as sp
+    multi = [r for r in res if res[r]["strain"] == 0]
+    reports = {}
+    for r in (list(res) if len(res) == 1 else multi):
+        cd = os.path.join(db_dir, "Kmer_Sets_L2", "Kmer_Sets", "C" + str(r))
+        kfa = open(os.path.join(cd, "all_kmer.fasta"), "rb").read()
+        counts, _ = jellyfish_count(kfa, reads, k=int(ksize), upper=False)
+        X = sp.load_npz(os.path.join(cd, "all_strains_re.npz")).toarray()
+        O = sp.load_npz(os.path.join(cd, "overlap_matrix.npz")).toarray()
+        sid = pickle.load(open(os.path.join(cd, "id2strain_re.pkl"), "rb"))
+        reports[r] = vote_cluster(counts, X, O, sid, ksize, res[r]["cls_ab"], "C" + str(r), list(res.keys()), l2, msn, pmode, emode)
+    files = {"C%s/StrainVote.report" % r: t for r, t in reports.items() if t}
+    if len(res) == 1:
+        if files:
+            files["final_report.txt"] = next(iter(files.values()))                      # `cp` at :273
+    else:
+        files["final_report.txt"] = merge_reports(res, reports)
+    return files

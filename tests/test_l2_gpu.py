@@ -141,6 +141,17 @@ def test_three_clusters_one_pass_equals_serial_loop(l1_dbs, tmp_path, monkeypatc
     rep = outs["1"]["final_report.txt"].decode()
     for name in ("GCF_A1", "\tC1\t", "\tC3\t", "\tC5\t", "GCF_SINGLE6"):       # strains of all three clusters and the singleton
         assert name in rep, rep
+    # ... and equal to the SERIAL ORACLE PIPELINE on the same files (oracle.vote_batch: the reference's loop restated in numpy /
+    # C and pinned to the reference's own report files in tests/test_oracle_golden.py): every report, field by field
+    from oracle import oracle as orc
+    from strainscan_amd import identify
+    np.random.seed(sc.POISSON_SEED)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cls = identify.identify_cluster((str(fq), ""), db + "/Tree_database", [0.1, 0.4, 1])
+    want = orc.vote_batch(db, [fq.read_bytes()], {k: dict(v) for k, v in cls.items()}, 31, 0, 40, 0, 0)
+    assert sorted(want) == sorted(outs["1"])
+    for rel, text in want.items():
+        _cmp_report(outs["1"][rel].decode(), text, float_cols=(3, 4, 5, 6) if rel == "final_report.txt" else (3, 4, 5, 6, 8, 9))
 
 
 def _cmp_report(got, want, float_cols):

@@ -181,3 +181,38 @@ def test_prescan_packed_equals_prescan():
         yu[rs.random_sample(K) < 0.2] = 0
         for l2, pm, em in ((0, 0, 0), (1, 0, 0), (0, 0, 1), (0, 1, 0)):
             assert orc.prescan(X.toarray(), y, yu, ids, 1240, l2, pm, em) == orc.prescan_packed(X, y, yu, ids, 1240, l2, pm, em)
+
+
+def _cmp_report_text(got, want, float_cols, tol=1e-5):
+    gl, wl = got.strip().split("\n"), want.strip().split("\n")
+    assert len(gl) == len(wl) and gl[0] == wl[0], (got, want)
+    for a, b in zip(gl[1:], wl[1:]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert len(fa) == len(fb), (a, b)
+        for i, (x, y) in enumerate(zip(fa, fb)):
+            if i in float_cols and x != y:
+                assert abs(float(x) - float(y)) <= tol * max(1.0, abs(float(y))), (i, a, b)
+            else:
+                assert x == y, (i, a, b)
+
+
+@pytest.mark.parametrize("name", list(sc.L2_BATCH_CASES))
+def test_oracle_vote_batch_equals_reference_reports(name, golden_dir, tmp_path):
+    """The oracle's serial layer-2 pipeline (oracle.vote_batch = jellyfish_count + remove_1 + detect_strains + report + merge_res,
+    restated from Vote_Strain_L2_Lasso_new_sp.py:116-170, 247-311, 334-438) writes the reference's own report files: the six
+    hand-made layer-1 results of tests/scenarios.py, including the exception of the cluster without reads."""
+    g = _load(golden_dir, "l2_batch.json")
+    dbb, reads = sc.l2_batch_inputs(str(tmp_path))
+    assert synth.sha256_of(reads) == g["sha256"]
+    res, l2, emode = sc.L2_BATCH_CASES[name]
+    want = g["cases"][name]
+    err, files = None, {}
+    try:
+        files = orc.vote_batch(dbb, [reads], {k: dict(v) for k, v in res.items()}, 31, l2, 40, 0, emode)
+    except Exception as e:
+        err = type(e).__name__
+    assert err == want["error"]
+    if err is None:
+        assert sorted(files) == sorted(want["files"])
+        for rel, text in want["files"].items():
+            _cmp_report_text(files[rel], text, (3, 4, 5, 6) if rel == "final_report.txt" and name != "one_cluster" else (3, 4, 5, 6, 8, 9))
