@@ -688,6 +688,7 @@ def parse_args(argv=None):
     ap.add_argument("--l2-rows", type=int, default=5_000_000)
     ap.add_argument("--l2-strains", type=int, default=300)
     ap.add_argument("--l2-check-rows", type=int, default=400_000)
+    ap.add_argument("--no-cli-e2e", action="store_true", help="skip the cli_e2e block (the whole CLI with layer 2 on the path, reduced size)")
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
     return ap.parse_args(argv)
@@ -1079,6 +1080,24 @@ def main(argv=None):
         del reads
         torch.cuda.empty_cache()
         config3 = measure_config3(torch, dev, args, stream)
+    cli_e2e = None
+    if rank == 0 and world == 1 and not args.no_cli_e2e and not args.calib_stream:
+        # what a user runs, reduced to a few seconds: fresh `strainscan` processes on a 63-cluster tree with three multi-strain
+        # clusters (layer 2 on the path), 2 M reads from text; the full configs[3] shape: scripts/bench_cli_l2.py, profiles/r05_cli_l2_*
+        torch.cuda.empty_cache()
+        from scripts import bench_cli_l2
+        t1 = time.perf_counter()
+        try:
+            c = bench_cli_l2.run(2_000_000, [(400_000, 60), (200_000, 40), (100_000, 30)], "text", 63, per_cluster=False)
+            cli_e2e = dict(workload="63-cluster tree, three multi-strain clusters with layer-2 k-mer sets (%s), %d reads from a FASTQ text pair"
+                                    % (", ".join(c["clusters"]), c["n_reads"]),
+                           fresh_process=[dict(label=r_["label"], wall_s=r_["wall_s"], phases_s=r_["phases_s"], rc=r_["rc"]) for r_ in c["cli_fresh_process"]],
+                           in_process=c.get("in_process"), all_expected_strains_reported=c.get("all_expected_strains_reported"),
+                           strains_in_sample=c.get("strains_in_sample"), block_s=round(time.perf_counter() - t1, 1),
+                           full_size="scripts/bench_cli_l2.py (202 clusters / 1627 strains, clusters of 5 M x 300 / 2 M x 120 / 1 M x 60, 20-50 M reads, "
+                                     "text and .gz): profiles/r05_cli_l2_*.json")
+        except Exception as e:                      # noqa: B902 -- the headline does not depend on this block
+            cli_e2e = dict(error="%s: %s" % (type(e).__name__, e))
     if rank == 0:
         out = dict(metric="M reads/sec vs 1433-strain E. coli DB", value=round(reads_per_s / 1e6, 3),
                    unit="M reads/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -1099,7 +1118,7 @@ def main(argv=None):
                                            else "file order (flat block)"),
                                parallelism="reads sharded x%d, table replicated, all-reduce of the touched nodes' hit counts" % world),
                    roofline=roofline, cpu_baseline=cpu, phases=phases, prepare=prepare, file_order=file_order,
-                   cluster_scan=(config3 or {}).get("cluster_scan"), l2_solve=(config3 or {}).get("l2_solve"),
+                   cluster_scan=(config3 or {}).get("cluster_scan"), l2_solve=(config3 or {}).get("l2_solve"), cli_e2e=cli_e2e,
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
                               harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"],

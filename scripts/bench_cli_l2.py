@@ -134,13 +134,17 @@ def run_cli(args, env):
 
 
 def main():
-    import torch
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
     shapes = [tuple(int(x) for x in c.split("x")) for c in (sys.argv[2] if len(sys.argv) > 2 else "5000000x300,2000000x120,1000000x60").split(",")]
     mode = sys.argv[3] if len(sys.argv) > 3 else "text"
     C = int(sys.argv[4]) if len(sys.argv) > 4 else 202
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    print(json.dumps(run(n_reads, shapes, mode, C)))
+
+
+def run(n_reads, shapes, mode="text", C=202, per_cluster=True):
+    """-> the dict main() prints (bench.py calls this with a reduced configuration for its `cli_e2e` block)."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
     base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "ss_cli_l2_%d" % os.getpid())
     os.makedirs(base)
     env = dict(os.environ, SS_IMAGE_CACHE=os.path.join(base, "cache"), STRAINSCAN_QUIET="1")
@@ -239,7 +243,7 @@ def main():
         out["in_process"] = ph
         # one cluster at a time, warm: scan, counts to the host, y, the solve (vote_strain_L2's own steps)
         per = []
-        for c in todo:
+        for c in (todo if per_cluster else []):
             cd = base + "/Kmer_Sets_L2/Kmer_Sets/C" + str(c)
             t1 = time.perf_counter()
             cnt = vote.cluster_counts(fq[0], fq[1], cd, 31)
@@ -258,7 +262,7 @@ def main():
         out["per_cluster_warm"] = per
     finally:
         shutil.rmtree(base, ignore_errors=True)
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

@@ -875,6 +875,9 @@ def test_bench_line_contract_and_exchange_path():
             assert cs[k_]["kernel_ms"] > 0 and 0 < cs[k_]["frac"] < cs[k_]["frac_with_hit_bytes"]
         assert l2s["prescan_equal"] is True and l2s["abundance_max_abs_diff"] < 1e-5 and l2s["wall_ms"] > 0
         assert l2s["four_clusters"]["equal_to_one_by_one"] is True and l2s["four_clusters"]["wall_ms"] > 0
+        ce = d["cli_e2e"]
+        assert "error" not in ce and ce["all_expected_strains_reported"] is True and len(ce["fresh_process"]) == 3
+        assert all(r_["rc"] == 0 and r_["wall_s"] > 0 and "clusters solved (3)" in r_["phases_s"] for r_ in ce["fresh_process"])
         assert len(l2s["selected"]) >= 2 and "pattern_stats" in l2s["phases_ms"] and "pre_scan" in l2s["phases_ms"]
         assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["db_shape"] == shape and d["vs_baseline"] is None
         rf = d["roofline"]
