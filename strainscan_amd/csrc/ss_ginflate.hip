@@ -7,7 +7,7 @@
 //               entry: the 64 lanes test 64 consecutive bit positions at a time with a register-only header check
 //               (non-final dynamic block, complete code-length code); a survivor's header is parsed by the whole wave
 //               (code lengths decoded lane-parallel, canonical codes built with ballots: the Kraft sums reject it
-//               before a table is written) and SS_GZ_PROBE symbols are decoded.
+//               before a table is written) and 512 symbols are decoded.
 //   A2 subsync  a block is entered every SS_GZ_SPLIT_KB (12 KB) of deflate data as well: Huffman-coded data synchronises
 //               itself, so a wave that decodes from any bit inside a block with the block's tables -- all 64 bit offsets of
 //               a window as hypotheses -- is left with ONE offset after a few windows: an item's first bit, an entry.
@@ -27,7 +27,7 @@
 // CRC-32 and ISIZE of EVERY member match (lanes joined with `cat` are found member by member: the chunk that meets a
 // final block finds trailer and header behind it).  A wrong entry (a position inside a block that passed A) shows as the
 // chunk before it running past it and is dropped.  A bgzip file (BGZF: every member names its size) needs no search: its
-// members are the chunks.  Anything else (a chunk that expands more than SS_GZ_RATIO times, a damaged file) returns "not handled" and the caller inflates on the host
+// members are the chunks.  Anything else (a chunk that expands more than 12 times, a damaged file) returns "not handled" and the caller inflates on the host
 // (ss_pgz.hip, libdeflate, zlib), so a wrong text cannot get through.
 #include "ss_common.h"
 
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
                 const int l = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 const uint64_t cand = lo + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)q, l);
-                // confirm with the whole wave: a complete, valid header (zlib's rules) and SS_GZ_PROBE symbols that decode: a
+                // confirm with the whole wave: a complete, valid header (zlib's rules) and 512 symbols that decode: a
                 // position inside a block passes this with negligible probability, and if one ever does, the chunk in front
                 // runs over it (inflate_kernel)
                 sb_seek_abs(b, cand);
@@ -1432,9 +1432,9 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() * 1e3; };
     // one file at a time on the link: the files of a call would otherwise arrive together, late, and their searches start together;
-    // in turn the first one is searched while the second one travels (SS_GZ_UPLOAD_TURNS=0: together, for A/B)
+    // in turn the first one is searched while the second one travels
     static std::mutex link;
-    const bool turns = !(getenv("SS_GZ_UPLOAD_TURNS") && !atoi(getenv("SS_GZ_UPLOAD_TURNS")));
+    constexpr bool turns = true;
     std::unique_lock<std::mutex> my_turn(link, std::defer_lock);
     if (turns) my_turn.lock();
     PinSet *pins = pin_get();
@@ -1449,7 +1449,7 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
     // every thread's pinned buffer is used in two halves: the copy of one block travels while the next is read.  Blocks
     // of 1/16 of the file (2 MB .. half a buffer), handed out in order, so that the prefix grows steadily
     const uint64_t half = PIN_BYTES / 2;
-    const uint64_t div = getenv("SS_GZ_UPLOAD_DIV") ? (uint64_t)std::max(1, atoi(getenv("SS_GZ_UPLOAD_DIV"))) : 16;
+    constexpr uint64_t div = 16;
     const uint64_t blk = std::min<uint64_t>(half, std::max<uint64_t>(2ull << 20, ((n / div) + (1ull << 20) - 1) & ~((1ull << 20) - 1)));
     const uint64_t n_blocks = (n + blk - 1) / blk;
     std::vector<uint8_t> done((size_t)n_blocks, 0);
@@ -1464,7 +1464,7 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
         if (prefix != before && ready) ready(std::min(n, prefix * blk));
     };
     std::vector<std::thread> pool;
-    const int n_threads = getenv("SS_GZ_UPLOAD_THREADS") ? std::max(1, std::min(PIN_N, atoi(getenv("SS_GZ_UPLOAD_THREADS")))) : PIN_N;
+    const int n_threads = PIN_N;
     for (int t = 0; t < n_threads; t++)
         pool.emplace_back([&, t] {
             hipStream_t s2 = pins->s[t];
@@ -1535,7 +1535,7 @@ void gpu_gunzip_done(void *lease)
 }
 
 // The streams of the calls, kept (making one and destroying it was 0.6 ms of every call), and the stream-ordered allocator
-// told to keep what a call frees (SS_GZ_POOL_KEEP_MB, 1 GB) instead of handing it back to the driver at the next synchronisation.
+// told to keep what a call frees (1 GB) instead of handing it back to the driver at the next synchronisation.
 static std::vector<hipStream_t> g_stream_free;
 hipStream_t call_stream_get()
 {
@@ -1543,7 +1543,7 @@ hipStream_t call_stream_get()
     std::call_once(once, [] {
         int device = 0;
         hipMemPool_t pool = nullptr;
-        uint64_t keep = (getenv("SS_GZ_POOL_KEEP_MB") ? (uint64_t)atoll(getenv("SS_GZ_POOL_KEEP_MB")) : 1024ull) << 20;
+        uint64_t keep = 1024ull << 20;
         if (hipGetDevice(&device) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess)
             hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     });
@@ -1745,7 +1745,6 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     if (const char *e = getenv("SS_GZ_SPLIT_KB")) split_bytes = (uint64_t)std::max<long long>(0, atoll(e)) << 10;
     uint64_t chunk_bytes = split_bytes ? 16 << 10 : 32 << 10, ratio = 12, seg_bytes = 128ull << 20;      // (split: every block's start should be found)
     if (const char *e = getenv("SS_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));
-    if (const char *e = getenv("SS_GZ_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
     if (const char *e = getenv("SS_GZ_SEG_KB")) seg_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) << 10;      // (tests: many segments)
     const uint64_t data_n = in_n - 8 - data_off;
     seg_bytes = std::max(seg_bytes, 8 * chunk_bytes);
@@ -1770,15 +1769,13 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
 
     if (!have_stream) return no("hipStreamCreateWithFlags");
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
-    static const bool no_pread = getenv("SS_GZ_NO_PREAD") != nullptr;
+    constexpr bool no_pread = false;
     bool uploaded = false;
     // (pinned buffers cost ~40 ms to make: a file of less than 256 MB takes that way only when a set is there already --
     //  ss_gz_warm_up, or an earlier call -- and then arrives in 8 ms instead of 12-30)
-    static const uint64_t pread_env = getenv("SS_GZ_PREAD_MB") ? (uint64_t)atoll(getenv("SS_GZ_PREAD_MB")) << 20 : 0;
-    const uint64_t pread_from = pread_env ? pread_env : pin_waiting() ? 32ull << 20 : 256ull << 20;
+    const uint64_t pread_from = pin_waiting() ? 32ull << 20 : 256ull << 20;
     const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
     uint64_t probe = 512;
-    if (const char *e = getenv("SS_GZ_PROBE")) probe = (uint64_t)atoll(e);
     uint32_t c_searched = 0;                                   // search chunks [0, c_searched) have been launched
     auto search_to = [&](uint32_t c_hi) {
         if (c_hi > c_searched)
@@ -1792,17 +1789,17 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         GI(hipStreamSynchronize(st));                         // the allocations are stream-ordered
         lap("stage allocated");
         // the sync search runs on the prefix of the image that has arrived (a candidate's probe reads a few KB beyond its chunk)
-        static const bool pipelined = !(getenv("SS_GZ_PIPELINE") && !atoi(getenv("SS_GZ_PIPELINE")));
+        constexpr bool pipelined = true;
         const uint64_t margin = 64 << 10;
         uploaded = upload_file(fd, in_n, d_in, [&](uint64_t ready) {
             if (!pipelined || !bgzf.empty()) return;
             // (runs on an upload thread, which has set the device; calls are serialised by upload_file)
             const uint64_t usable = ready >= in_n ? in_n : (ready > margin + data_off ? ready - margin - data_off : 0);
-            // SS_GZ_PIECES > 1: the search starts on the prefix that has arrived, in that many pieces.  Measured (26 loads of each
+            // (round 4, pieces > 1: the search starts on the prefix that has arrived, in that many pieces.  Measured (26 loads of each
             // setting interleaved in one process, a pair of 66 MB files): 1 piece -- upload, then search -- 26.0 ms, 2 pieces 26.3,
             // 4 pieces 27.0, 8 pieces 28.4: the search is bound by the chip's throughput (4.5 ms for the pair), a piece takes as
             // long as its slowest chunk, and the pieces of a stream run one after another.  So: off.
-            const uint32_t pieces = getenv("SS_GZ_PIECES") ? (uint32_t)std::max(1, atoi(getenv("SS_GZ_PIECES"))) : 1;
+            constexpr uint32_t pieces = 1;
             const uint32_t c_hi = ready >= in_n ? n_chunks0 : (uint32_t)std::min<uint64_t>(n_chunks0, usable / chunk_bytes);
             if (c_hi == n_chunks0 || c_hi >= c_searched + (n_chunks0 + pieces - 1) / pieces) {
                 if (trace) fprintf(stderr, "[ginflate] search to chunk %u of %u at %.4f s\n", c_hi, n_chunks0, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
@@ -2102,7 +2099,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         std::vector<uint32_t> todo;                                // empty = all chunks
         uint32_t consumed_ph = 0;
         // Two things show only when the chunks have been inflated:
-        //  * An entry is a position where a valid dynamic header parses and SS_GZ_PROBE symbols decode -- a position INSIDE a
+        //  * An entry is a position where a valid dynamic header parses and 512 symbols decode -- a position INSIDE a
         //    block passes that about once in a million candidates (every bit string decodes under a complete code).  The
         //    chunk in front of it ends a block BEHIND it and goes on to the entry after it (inflate_kernel); the wrong
         //    entry's chunk is dropped.  (No room left in its symbol region, or more than two in a row: -21, the two

@@ -332,14 +332,12 @@ void mt_temper_all(uint32_t *x, int n)
 
 // Word buffers of the splits (swap partners, the permutation itself), kept between splits AND between calls: a fresh 20 MB
 // vector per split is zero-filled and page-faulted in by whoever touches it first -- 40 such buffers per call were a third of the
-// generator thread's time.  At most 24 buffers / 512 MB stay pooled (SS_SPLIT_POOL=0: fresh zeroed buffers, for A/B).
+// generator thread's time.  At most 24 buffers / 512 MB stay pooled.
 struct WordPool {
     std::mutex mu;
     std::vector<std::pair<uint32_t *, uint64_t>> free_;
-    static bool pooled() { static const bool p = !(getenv("SS_SPLIT_POOL") && !atoi(getenv("SS_SPLIT_POOL"))); return p; }      // (A/B)
     uint32_t *get(uint64_t n)
     {
-        if (!pooled()) return static_cast<uint32_t *>(calloc(std::max<uint64_t>(n, 1), sizeof(uint32_t)));
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < free_.size(); i++)
@@ -350,7 +348,6 @@ struct WordPool {
     void put(uint32_t *p, uint64_t n)
     {
         if (!p) return;
-        if (!pooled()) { free(p); return; }
         {
             std::lock_guard<std::mutex> g(mu);
             uint64_t held = 0;
@@ -524,7 +521,7 @@ int split_worker(std::unique_ptr<MTWords> rng, uint64_t n, uint64_t n_test, uint
         // (the partners are known ahead: their cache lines are requested early -- 20 MB of x do not fit L2)
         // (... 64 swaps early: 24 / 48 / 64 / 96 / 128 ahead gave workers of 10 / 8 / 8 / 8 / 7 ms and the whole call 29.9 / 27.2 / 27.4 /
         //  28.3 / 27.8 ms on the boxes' EPYC 9575F)
-        static const uint32_t PD = getenv("SS_SPLIT_PREFETCH") ? (uint32_t)std::max(1, atoi(getenv("SS_SPLIT_PREFETCH"))) : 64u;
+        constexpr uint32_t PD = 64u;
         for (uint32_t k = 0; k < std::min(PD, cnt); k++) __builtin_prefetch(&xp[p[k]], 1, 1);
         for (uint32_t k = 0; k < cnt; k++, i--) {
             if (k + PD < cnt) __builtin_prefetch(&xp[p[k + PD]], 1, 1);
@@ -597,7 +594,6 @@ int ss_shuffle_split_bits(uint64_t n, int n_splits, uint64_t n_test, uint32_t se
     }
     // swaps of several splits at once: one core each, two stay free
     unsigned in_flight = std::max(1u, std::min(20u, ss::host_cpus() > 3 ? ss::host_cpus() - 2 : 1u));
-    if (const char *e = getenv("SS_SPLIT_IN_FLIGHT")) in_flight = (unsigned)std::max(1, atoi(e));
     static const bool trace = getenv("SS_SPLIT_TRACE") != nullptr;
 #ifdef SS_HOST_X86
     static const bool simd = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("popcnt") && host_simd_allowed();

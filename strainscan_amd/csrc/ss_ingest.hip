@@ -30,10 +30,10 @@
 
 namespace {
 
-// bytes of text per work item (SS_INGEST_CHUNK_MB overrides).  4, 8, 12 and 24 MB parse at the same steady rate
+// bytes of text per work item.  4, 8, 12 and 24 MB parse at the same steady rate
 // (230-270 M reads/s with 20 threads); smaller chunks mean less pinned and private buffer memory to set up and
 // touch for the first time in a process (20 x 27 MB at 24 MB chunks)
-const uint64_t CHUNK = (getenv("SS_INGEST_CHUNK_MB") && atoi(getenv("SS_INGEST_CHUNK_MB")) > 0 ? (uint64_t)atoi(getenv("SS_INGEST_CHUNK_MB")) : 8ull) << 20;
+const uint64_t CHUNK = 8ull << 20;
 
 struct Line { uint64_t s, e; };   // [s, e) without the '\n'; s == npos when absent
 
@@ -392,7 +392,7 @@ int gz_inputs_on_device(const char *const *paths, int n_paths, int shard_rank, i
         int rc = SS_OK;
         std::vector<uint64_t> ticket;
         for (size_t q = 0; q < gz.size(); q++) ticket.push_back(gz_range_ticket());
-        static const bool serial = getenv("SS_GZ_RANGE_SERIAL") != nullptr;      // (A/B: one file after the other, as before)
+        constexpr bool serial = false;
         std::vector<std::thread> pool;
         for (size_t q = 0; q < gz.size(); q++) {
             auto one = [&, q] {
@@ -440,7 +440,7 @@ int scan_file_parallel(ss_db *db, const char *path, uint64_t *n_records, uint64_
 {
     // SS_INGEST_ZEROCOPY=1: the kernel streams the flat block straight out of the pinned host buffer
     // (every base is read once, with 16-byte loads) instead of waiting for a DMA copy of it
-    static const bool zero_copy = getenv("SS_INGEST_ZEROCOPY") && atoi(getenv("SS_INGEST_ZEROCOPY")) != 0;
+    constexpr bool zero_copy = false;
     return parse_file_parallel(db->workers, path, shard_rank, shard_world, n_records, n_bases, handled,
                                [db](const char *h_buf, char *d_buf, uint64_t len, hipStream_t stream) {
                                    return ss_scan_flat_dev(db, zero_copy ? h_buf : d_buf, len, stream);
@@ -513,8 +513,8 @@ int parse_text_parallel(ss_db::Worker *workers, const char *t, uint64_t n, const
     std::atomic<uint64_t> recs(0), bases(0);
     std::atomic<int> err(SS_OK);
     // chunks are pread() into a private buffer before parsing: parsing the mapping directly takes a minor page
-    // fault every 4 KB (1.2 M faults per 5 GB) and runs at half the rate.  SS_INGEST_PREAD=0 parses the mapping.
-    const bool use_pread = path && !(getenv("SS_INGEST_PREAD") && atoi(getenv("SS_INGEST_PREAD")) == 0);
+    // fault every 4 KB (1.2 M faults per 5 GB) and runs at half the rate.
+    const bool use_pread = path != nullptr;
     const int fd2 = use_pread ? open(path, O_RDONLY) : -1;
     if (use_pread && fd2 < 0) return SS_EIO;
     int device = 0;
@@ -870,7 +870,7 @@ int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *R, void *s
         if (dbs[i]->layout == 1) mini.push_back(dbs[i]);
         else { int rc = ss_scan_reads(dbs[i], R, stream); if (rc) return rc; }
     }
-    static const int group = [] { const char *e = getenv("SS_MULTI_MAX"); return e ? std::max(1, std::min(4, atoi(e))) : 4; }();
+    constexpr int group = 4;
     for (size_t g = 0; g < mini.size(); g += (size_t)group) {
         const int ng = (int)std::min<size_t>((size_t)group, mini.size() - g);
         for (const auto &sl : R->slabs) {

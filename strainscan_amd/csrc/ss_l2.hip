@@ -879,9 +879,8 @@ int ss_l2_pattern_stats(const ss_l2 *h, const uint32_t *cols, int p, const uint3
     for (int i = 0; i < p; i++) c16[i] = cols[i];
     ss::l2s::copy(d_cols, c16, 64, hipMemcpyHostToDevice);
     ss::l2s::set(d_stats, 0, n * 8);
-    static const bool per_group = getenv("SS_L2_STATS_PER_GROUP") != nullptr;       // A/B and tests: the general kernel
     const size_t once_bytes = (size_t)(n_folds + 1) * M * 24;                        // one copy of the tables of the one-pass kernel
-    if (p <= 6 && once_bytes <= 32 * 1024 && !per_group) {
+    if (p <= 6 && once_bytes <= 32 * 1024) {
         const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(512, (h->K + 64 * (NT / 64) - 1) / (64 * (NT / 64))));
         const int copies = once_bytes * 8 <= 64 * 1024 ? 8 : once_bytes * 4 <= 64 * 1024 ? 4 : 2;
 #define SS_ONCE(C) hipLaunchKernelGGL((pattern_stats_once_kernel<C>), dim3(blocks), dim3(NT), once_bytes * C, ss::l2s::stream(), h->d_x, h->W, h->K, d_cols, \

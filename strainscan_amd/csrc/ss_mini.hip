@@ -1217,7 +1217,6 @@ __global__ __launch_bounds__(256) void mark_solid_kernel(uint8_t *__restrict__ p
 
 int mark_solid(ss_db *db)
 {
-    if (const char *e = getenv("SS_SOLID")) if (!atoi(e)) return SS_OK;      // A/B: every bucket through the 16-lane check
     const uint64_t n = (uint64_t)db->n_dir_alloc * ss::PG_SLOTS;
     if (!n) return SS_OK;
     hipLaunchKernelGGL(mark_solid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint8_t *)db->d_dir, n, db->d_mkeys);
@@ -1232,7 +1231,7 @@ static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stre
 {
     const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
     const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
-    static const uint32_t swz0 = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
+    constexpr uint32_t swz0 = 1u;
     const uint32_t swz = swz0 | (probe ? 2u : 0u);
     const ScanTabs none = {};
     // (the combining variant needs 79 VGPRs: there is no 8-waves-per-SIMD build of it -- it carried 32 bytes of scratch)
@@ -1264,7 +1263,7 @@ int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, 
     tabs.n = n_dbs;
     const bool aligned = (((uintptr_t)bases_dev) & 15) == 0;
     static const int comb_env = [] { const char *e = getenv("SS_COMBINE"); return e ? atoi(e) : -1; }();
-    static const uint32_t swz = [] { const char *e = getenv("SS_MINI_XCD"); return (uint32_t)(e ? atoi(e) != 0 : 1); }();
+    constexpr uint32_t swz = 1u;
     const bool comb = expect && (comb_env < 0 ? binned : comb_env != 0);
     const uint64_t n_tiles = (n + MTILE - 1) / MTILE, units = comb ? (n_tiles + COMB_CH - 1) / COMB_CH : n_tiles;
     unsigned blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)2048 * 256 * (256 / MT));
@@ -1317,27 +1316,17 @@ static std::mutex probe_mu;                     // the probe's device words are 
 
 static int launch_plain_or_comb(ss_db *db, bool comb, bool probe, const uint8_t *b, uint64_t n, uint64_t n_tiles, hipStream_t stream)
 {
-    static int lb = -1, bpc = 0;
-    if (lb < 0) {   // tuning knobs for A/B measurements: register budget and blocks per CU
-        const char *e = getenv("SS_MINI_LB");
-        lb = e ? atoi(e) : 0;
-        const char *g = getenv("SS_MINI_BLOCKS_PER_CU");
-        bpc = g ? atoi(g) : 0;
-    }
     const bool aligned = (((uintptr_t)b) & 15) == 0;
     // grid-stride over tiles with MANY more blocks than fit the chip: short blocks start at scattered times, so
     // the waves sharing a SIMD stop marching through their ALU and memory phases in step.  Measured with 8 waves
     // per SIMD resident (20 M reads = 3.04 M tiles; blocks = x * 1024): x = 8 (one round of resident blocks)
     // 4.03 ms, 32: 3.76, 128: 3.59, 512: 3.55, 2048 (1.5 tiles per block): 3.50, 4096 (one tile each): 3.51
     const uint64_t units = comb ? (n_tiles + COMB_CH - 1) / COMB_CH : n_tiles;
-    unsigned blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)(bpc > 0 ? bpc : 2048) * 256 * (256 / MT));
+    unsigned blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)2048 * 256 * (256 / MT));
     blocks = (blocks + 7u) & ~7u;                           // a multiple of 8: the same number of workgroups on every XCD
     // (the combining variant needs 71 VGPRs: at 8 waves per SIMD it would spill four of them to scratch)
-    switch (lb ? lb : comb ? 6 : 8) {
-    case 4: launch_lb<4>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe); break;
-    case 6: launch_lb<6>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe); break;
-    default: launch_lb<8>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe); break;
-    }
+    if (comb) launch_lb<6>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe);
+    else launch_lb<8>(aligned, comb, blocks, stream, b, n, n_tiles, db, probe);
     SS_HIP(hipGetLastError());
     return SS_OK;
 }

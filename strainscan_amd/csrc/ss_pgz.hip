@@ -234,7 +234,7 @@ struct alignas(128) Out {           // one per thread, written on every symbol: 
             q = mremap(p, cap * 2, ncap * 2, MREMAP_MAYMOVE);
             if (q == MAP_FAILED) return false;
         }
-        if (!getenv("SS_PGZ_NOHUGE")) madvise(q, ncap * 2, MADV_HUGEPAGE);
+        madvise(q, ncap * 2, MADV_HUGEPAGE);
         p = (uint16_t *)q;
         cap = ncap;
         return true;
@@ -495,7 +495,7 @@ bool parallel_gunzip(const uint8_t *in, uint64_t in_n, unsigned threads, uint64_
     if (ta && ta->alloc) mem = ta->alloc(text_cap, ta->ctx);
     else if (posix_memalign(&mem, 2u << 20, text_cap) != 0) mem = nullptr;
     if (!mem) return say("no memory for the text", text_cap);
-    if (!getenv("SS_PGZ_NOHUGE")) madvise(mem, text_cap, MADV_HUGEPAGE);
+    madvise(mem, text_cap, MADV_HUGEPAGE);
     uint8_t *out = (uint8_t *)mem;
     auto drop_text = [&] { if (ta && ta->release) ta->release(mem, text_cap, ta->ctx); else free(mem); };
 

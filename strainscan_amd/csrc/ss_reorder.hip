@@ -14,7 +14,7 @@
 // buys nothing over BINS of a few thousand reads.  Round 2 sorted (hipcub radix sort of 20 M (key, record) pairs, five
 // passes over per-record arrays, a gather copy at 1.3 TB/s: 9.7 ms per 20 M reads); now the records are binned in two
 // streaming passes over the slab, with no per-record array at all:
-//   bin  = top SS_ORDER_BITS (12) bits of h = mix30(minimizer of the record's first 31 bases) -- the hash that addresses the
+//   bin  = top 12 to 22 bits (order_bits) of h = mix30(minimizer of the record's first 31 bases) -- the hash that addresses the
 //          index pages (ss_mini.hip), so a bin's FIRST lookups also walk the page table in ascending order;
 //          records without a first k-mer (shorter, or a non-ACGT base in it) go to one extra bin at the end
 //   pass 1  count_kernel: find the record starts of a 4 KB tile (16 bytes per lane, SWAR newline masks), the end of each
@@ -49,7 +49,7 @@ constexpr int CH = SS_ORDER_CH;             // bytes of a slab owned by one lane
 constexpr int RB = 256 * CH;                // ... and by one workgroup (16 KB: what bounds these passes is the chain of dependent
                                             // round trips of a workgroup -- load, neighbours, key bytes, atomic -- not its instructions)
 constexpr int HALO = 512;                   // bytes behind the tile searched (in parallel) for the end of its last record
-constexpr int MAX_BITS = 23;                // (SS_ORDER_BITS; a table entry has 24 bits for the bin; the default stays at or below 22)
+static_assert(22 <= 23, "a table entry has 24 bits for the bin; order_bits stays at or below 22");
 constexpr uint32_t NO_NL = 0xFFFFFFFFu;     // "no newline" as a tile-relative position
 constexpr int TCAP = 2 * CH;                // record starts per tile that the record table holds (reads of ~125 bases and more)
 
@@ -497,11 +497,9 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(unsigned long long *__
 }
 
 // bin width: about four records per bin for the block at hand (reads that share their first minimizer then sit in the
-// same scan tile or the next), 12 bits at least, 22 at most (4 M counters = 32 MB); SS_ORDER_BITS overrides
+// same scan tile or the next), 12 bits at least, 22 at most (4 M counters = 32 MB)
 int order_bits(uint64_t n_bytes)
 {
-    static const int forced = [] { const char *e = getenv("SS_ORDER_BITS"); return e ? std::min(MAX_BITS, std::max(1, atoi(e))) : 0; }();
-    if (forced) return forced;
     int bits = 12;
     while (bits < 22 && (n_bytes / 152) >> (bits + 2)) bits++;
     return bits;
@@ -547,7 +545,7 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     uint32_t *d_cnt = (uint32_t *)(d_scr + o_cnt);
     unsigned long long *d_tab = (unsigned long long *)(d_scr + o_tab);
     SS_R(hipMemsetAsync(d_hist, 0, o_sums, 0));
-    static const unsigned pad1 = getenv("SS_ORDER_PAD1") ? atoi(getenv("SS_ORDER_PAD1")) : 0, pad2 = getenv("SS_ORDER_PAD2") ? atoi(getenv("SS_ORDER_PAD2")) : 0;
+    constexpr unsigned pad1 = 0, pad2 = 0;
     hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(256), pad1, 0, src, n, bits, d_hist, d_cnt, d_tab, d_hist + n_bins + 1);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, 0, d_sums, nsb, d_hist + n_bins);

@@ -302,12 +302,10 @@ int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int
     SS_TRY(hipMemcpy(ctr, d_ctr, sizeof(ctr), hipMemcpyDeviceToHost));
     db->n_distinct = ctr[0];
     {
-        // Bloom filter over the k-mers when it fits an XCD's L2 with >= 8 bits per k-mer (cluster tables); SS_FLAT_BLOOM_BITS=0
-        // disables, = n forces 2^n bits
+        // Bloom filter over the k-mers when it fits an XCD's L2 with >= 8 bits per k-mer (cluster tables)
         int bits = 12;
         while (bits < 25 && (1ull << bits) < 16 * db->n_distinct) bits++;
         if ((1ull << bits) < 8 * db->n_distinct) bits = 0;
-        if (const char *e = getenv("SS_FLAT_BLOOM_BITS")) bits = atoi(e);
         if (bits >= 10 && bits <= 30 && db->n_distinct) {
             SS_TRY(hipMalloc((void **)&db->d_bloom, (1ull << bits) / 8));
             SS_TRY(hipMemset(db->d_bloom, 0, (1ull << bits) / 8));

@@ -95,7 +95,7 @@ def prefetch_reads(paths):
     torch.distributed both sides run collectives, whose order must be the same on every rank); a failure here is raised
     again by the load that follows."""
     from . import dist
-    if dist.is_distributed() or os.environ.get("SS_PREFETCH_READS", "1") == "0":
+    if dist.is_distributed():
         return None
     ps = [p for p in paths if p]
     if not ps or not all(os.path.exists(p) for p in ps):

@@ -616,3 +616,27 @@ def test_cache_tags_and_npz_reader(tmp_path):
     sp.save_npz(p, m.tocsc())
     c = _load_npz_csr(p)
     assert np.array_equal(c.indptr, m.indptr) and np.array_equal(c.indices, m.indices)
+
+
+def test_every_environment_variable_is_documented():
+    """INTEGRATION.md section F lists every SS_* / STRAINSCAN_* variable the native sources and the package read, and nothing
+    that is not read any more: a new knob without a line there -- default, reader, what it can change -- fails here."""
+    import re
+    src = {}
+    for d, pat in ((os.path.join(REPO, "strainscan_amd", "csrc"), r'getenv\("((?:SS|STRAINSCAN)_[A-Z0-9_]+)"\)'),
+                   (os.path.join(REPO, "strainscan_amd"), r'["\']((?:SS|STRAINSCAN)_[A-Z0-9_]+)["\']')):
+        for fn in sorted(os.listdir(d)):
+            if not fn.endswith((".hip", ".h", ".py")):
+                continue
+            text = open(os.path.join(d, fn)).read()
+            for m in re.finditer(pat, text):
+                src.setdefault(m.group(1), set()).add(fn)
+    status_codes = {n for n in src if re.fullmatch(r"SS_(OK|E[A-Z]+)", n)}          # (names of the int status codes in _lib.py)
+    read = set(src) - status_codes - {"SS_BENCH_SHARE_GPU"}
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## F. Environment variables"):]
+    table = "\n".join(ln for ln in sec.splitlines() if ln.startswith("| `"))
+    listed = set(re.findall(r"`((?:SS|STRAINSCAN)_[A-Z0-9_]+)`", table))
+    assert read - listed == set(), "read but not documented: %s" % sorted((v, sorted(src[v])) for v in read - listed)
+    assert listed - read == set(), "documented but no longer read: %s" % sorted(listed - read)
+    assert len(read) <= 45
