@@ -232,7 +232,7 @@ int gz_fastq_to_flat_dev(const char *path, int shard_rank, int shard_world, char
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < (1 << 20)) { close(fd); return 1; }
     const uint64_t in_n = (uint64_t)sb.st_size;
     // (a plain mapping, copied by one thread: a populated mapping, a read into memory and four copy threads were all
-    //  slower -- 0.157 / 0.233 / 0.144 s against 0.129 s for a pair of 290 MB files, scripts/dev/t_gz_input_ab.py)
+    //  slower -- 0.157 / 0.233 / 0.144 s against 0.129 s for a pair of 290 MB files, scripts/archive/dev/t_gz_input_ab.py)
     const uint8_t *in = (const uint8_t *)mmap(nullptr, in_n, PROT_READ, MAP_PRIVATE, fd, 0);
     if (in == MAP_FAILED) { close(fd); return 1; }
     char *d_text = nullptr;

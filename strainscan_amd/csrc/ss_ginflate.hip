@@ -1290,7 +1290,7 @@ std::vector<Bgzf> bgzf_members(const uint8_t *p, uint64_t n)
 
 // Scratch of one call, kept for the next one: the per-segment symbol streams, window maps and chunk arrays.  (Allocating
 // and freeing tens of GB per file is what this replaces: on this platform a large hipMalloc that follows a large hipFree
-// can take 1.6 s -- scripts/dev/t_bigalloc.py -- and a 1 GB .gz needed 28 GB of symbols in one piece.)  At most two are
+// can take 1.6 s -- scripts/archive/dev/t_bigalloc.py -- and a 1 GB .gz needed 28 GB of symbols in one piece.)  At most two are
 // kept (the two mates of a pair are inflated concurrently), ~4.5 GB each, until the process ends.
 struct Arena {
     uint64_t cap_chunks = 0, sym_elems = 0;

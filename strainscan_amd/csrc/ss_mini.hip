@@ -283,14 +283,14 @@ __device__ uint32_t ss_probe_runs[64];
 #ifdef SS_COMB_STATS
 // debug build: what the combining scan did -- [0] tiles, [1] flushes, [2] entries flushed, [3] counters flushed, [4] found runs,
 // [5] runs without an entry, [6] flushes because the table was full; and the trip counts of every scan's loops (for the
-// instruction budget, scripts/r4/isa_budget.py): [8] tiles, [9] runs queued (n1), [10] runs looked up (ns: all, or the Bloom
+// instruction budget, scripts/archive/r4/isa_budget.py): [8] tiles, [9] runs queued (n1), [10] runs looked up (ns: all, or the Bloom
 // filter's survivors), [11] found runs (n2), [12] lookup rounds, [13] candidate rounds
 __device__ unsigned long long ss_comb_stats[16];
 #define SS_CS(i, v) do { if (t == 0) atomicAdd(&ss_comb_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define SS_CS(i, v)
 #endif
-#define SS_MARK(i) asm volatile("; SSMARK " #i)      // a label in the ISA only (scripts/r4/isa_budget.py)
+#define SS_MARK(i) asm volatile("; SSMARK " #i)      // a label in the ISA only (scripts/archive/r4/isa_budget.py)
 #ifdef SS_TIMING
 // debug build: cycles a wave spends between the phase markers, accumulated in registers and flushed once per block
 __device__ unsigned long long ss_timing[32];
