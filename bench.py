@@ -688,6 +688,8 @@ def parse_args(argv=None):
     ap.add_argument("--l2-rows", type=int, default=5_000_000)
     ap.add_argument("--l2-strains", type=int, default=300)
     ap.add_argument("--l2-check-rows", type=int, default=400_000)
+    ap.add_argument("--no-file-order", action="store_true", help="skip the second timing over the block in file order (profiling runs: "
+                    "every launch of the scan kernel is then a launch of the headline step)")
     ap.add_argument("--no-cli-e2e", action="store_true", help="skip the cli_e2e block (the whole CLI with layer 2 on the path, reduced size)")
     ap.add_argument("--calib-stream", action="store_true",
                     help="PMC calibration: every base is 'N' (the kernel only streams the block: known bytes)")
@@ -1005,6 +1007,7 @@ def main(argv=None):
                        policy="always (SS_READS_ORDER=file keeps the file order): binning pays from the SECOND scan of a sample on; a "
                               "sample scanned once loses prepare.ms - (file_order.ms_per_step - ms_per_step), beside a text ingest of "
                               "~80 ms for the same reads")
+    if binned and not args.no_file_order:
         stats_f = torch.zeros_like(stats)
         dt_f, (k_f, h_f, x_f, r_f) = run_timed(scan_file, stats_f)
         torch.cuda.synchronize()
