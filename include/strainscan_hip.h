@@ -343,6 +343,11 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
  * array (S * W dwords) from a handle: the host keeps it as a per-cluster image so that later runs skip
  * decompressing and re-packing all_strains_re.npz. */
 int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **out);
+/* A cluster image file of this package (the cache strainscan_amd writes beside SS_IMAGE_CACHE: bit planes + the overlap matrix's
+ * CSR arrays at the given 64-byte-aligned offsets) straight to the device: planes AND overlap in one upload through pinned
+ * buffers; equivalent to ss_l2_create_planes + ss_l2_set_overlap on the same arrays, same checks.  SS_EINVAL: not such a file. */
+int ss_l2_import(const char *path, uint64_t K, uint32_t S, uint64_t off_planes, uint64_t off_ptr, uint64_t off_idx, uint64_t off_val,
+                 uint64_t nnz, uint32_t n_cols, ss_l2 **out);
 int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes);
 int ss_l2_destroy(ss_l2 *h);
 int ss_l2_info(const ss_l2 *h, uint64_t *K, uint32_t *S, uint64_t *words_per_plane);

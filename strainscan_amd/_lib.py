@@ -150,6 +150,7 @@ SIGNATURES = {
     "ss_l2_andnot_col": (i32, [vp, u32, vp]),
     "ss_l2_set_overlap": (i32, [vp, vp, vp, vp, u32]),
     "ss_l2_prepare": (i32, [vp, vp, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp, vp, vp, vp]),
+    "ss_l2_import": (i32, [C.c_char_p, u64, C.c_uint32, u64, u64, u64, u64, u64, C.c_uint32, vp]),
     "ss_l2_fold": (i32, [vp, vp, vp, u64, vp]),
     "ss_l2_fold_train": (i32, [vp, vp, vp, u64, i32, vp]),
     "ss_split_dev_start": (i32, [u64, i32, u64, C.c_uint32, vp]),

@@ -243,6 +243,8 @@ inline hipError_t copy(void *d, const void *s_, size_t n, hipMemcpyKind k)
 inline hipError_t set(void *d, int v, size_t n) { return hipMemsetAsync(d, v, n, stream()); }
 inline hipError_t sync() { return hipStreamSynchronize(stream()); }
 }  // namespace l2s
+// a whole file into device memory through the pinned upload buffers of the .gz path (ss_ginflate.hip)
+bool upload_file_to_device(int fd, uint64_t n, uint8_t *d_dst);
 // ss_scan_flat_dev for a block whose records ss_reorder.hip has binned by locus (the scan may add hits up in LDS first)
 // (set_id: ss_reads::serial of the resident set the block belongs to, 0 = none)
 int scan_flat_dev(ss_db *db, const void *bases_dev, uint64_t n, void *stream, bool binned, uint64_t set_id = 0);

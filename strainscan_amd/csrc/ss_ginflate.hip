@@ -1516,6 +1516,9 @@ bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uin
 
 namespace ss {
 
+// (the same way in for other whole files: ss_l2_import's cluster images)
+bool upload_file_to_device(int fd, uint64_t n, uint8_t *d_dst) { return upload_file(fd, n, d_dst); }
+
 // The file image `in` (host) inflated on the device.  true: *text_dev holds *len bytes, every member verified against its
 // trailer; the buffer belongs to the scratch arena of the call and is lent until gpu_gunzip_done(*lease).  false: not
 // handled here (the caller inflates on the host).

@@ -19,6 +19,9 @@
 #include "ss_common.h"
 
 #include <hipcub/hipcub.hpp>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <thread>
@@ -35,6 +38,7 @@ struct ss_l2 {
     int8_t *d_om_val = nullptr;
     uint32_t om_cols = 0;
     bool has_om = false;
+    uint8_t *d_blob = nullptr; // ss_l2_import: ONE allocation holding the cluster image file; the pointers above point into it
 };
 
 namespace {
@@ -523,6 +527,18 @@ __global__ __launch_bounds__(NT) void csr_ptr_check_kernel(const int64_t *__rest
     if (b) atomicOr(bad, 1);
 }
 
+// bits beyond row K in the last words of a plane (a plane has W words for K rows)
+__global__ __launch_bounds__(NT) void planes_padding_check_kernel(const uint32_t *__restrict__ x, uint64_t K, uint32_t S, uint64_t W, int *__restrict__ bad)
+{
+    const uint32_t s = blockIdx.x * NT + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t *pl = x + (uint64_t)s * W;
+    const uint64_t full = K >> 5, rem = K & 31;
+    bool b = rem && (pl[full] >> rem);
+    for (uint64_t w = full + (rem ? 1 : 0); w < W; w++) b = b || pl[w] != 0u;
+    if (b) atomicOr(bad, 1);
+}
+
 int csr_ptr_check(const int64_t *d_ptr, uint64_t K, int64_t nnz)
 {
     int *d_bad = nullptr, bad = 0;
@@ -764,9 +780,63 @@ int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes)
 int ss_l2_destroy(ss_l2 *h)
 {
     if (!h) return SS_OK;
-    hipFree(h->d_x);
-    hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
+    if (h->d_blob) hipFree(h->d_blob);
+    else { hipFree(h->d_x); hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val); }
     delete h;
+    return SS_OK;
+}
+
+// The cluster image file of strainscan_amd (identify_strains_L2_Enet_Pscan_new_sp.py _write_l2_cache: bit planes, then the
+// overlap matrix's CSR arrays, each at a 64-byte boundary of the file) straight to the device: the whole file travels through
+// the pinned upload buffers of the .gz path (ss_ginflate.hip upload_file: four threads, ~40 GB/s from the page cache) into ONE
+// allocation, and the handle's pointers point into it.  Through a memory map and pageable copies the 253 MB of a 5 M x 300
+// cluster took 25 ms of the 70 its vote takes; this way ~7.  The caller gives the layout it read from the file's header;
+// everything the other constructors check is checked here too (padding bits of the planes, row pointers, sizes).
+int ss_l2_import(const char *path, uint64_t K, uint32_t S, uint64_t off_planes, uint64_t off_ptr, uint64_t off_idx, uint64_t off_val,
+                 uint64_t nnz, uint32_t n_cols, ss_l2 **out)
+{
+    if (!path || !out || K > 0x7FFFFFFFFFull) return SS_EINVAL;
+    const uint64_t W = std::max<uint64_t>(4, ((K + 31) / 32 + 3) & ~3ull);
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return SS_EIO;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); return SS_EIO; }
+    const uint64_t n = (uint64_t)sb.st_size;
+    auto inside = [&](uint64_t off, uint64_t bytes) { return (off & 63) == 0 && off <= n && bytes <= n - off; };
+    if (!inside(off_planes, (uint64_t)S * W * 4) || !inside(off_ptr, (K + 1) * 8) || !inside(off_idx, nnz * 4) || !inside(off_val, nnz)) { close(fd); return SS_EINVAL; }
+    ss_l2 *h = new (std::nothrow) ss_l2();
+    if (!h) { close(fd); return SS_ENOMEM; }
+    h->K = K; h->S = S; h->W = W;
+    int rc = SS_OK;
+    if (hipMalloc((void **)&h->d_blob, n + 64) != hipSuccess) rc = SS_ENOMEM;
+    else if (!ss::upload_file_to_device(fd, n, h->d_blob)) rc = SS_EIO;
+    close(fd);
+    if (!rc) {
+        h->d_x = reinterpret_cast<uint32_t *>(h->d_blob + off_planes);
+        h->d_om_ptr = reinterpret_cast<int64_t *>(h->d_blob + off_ptr);
+        h->d_om_idx = reinterpret_cast<int32_t *>(h->d_blob + off_idx);
+        h->d_om_val = reinterpret_cast<int8_t *>(h->d_blob + off_val);
+        h->om_cols = n_cols;
+        // the padding bits of every plane must be zero (popcounts run over whole words), the row pointers in order and ending at nnz
+        int *d_bad = nullptr, bad = 0;
+        if (ss::l2s::dmalloc((void **)&d_bad, 4) != hipSuccess) rc = SS_ENOMEM;
+        else {
+            ss::l2s::set(d_bad, 0, 4);
+            if (S && K) hipLaunchKernelGGL(planes_padding_check_kernel, dim3((unsigned)((S + NT - 1) / NT)), dim3(NT), 0, ss::l2s::stream(), h->d_x, K, S, W, d_bad);
+            hipLaunchKernelGGL(csr_ptr_check_kernel, dim3((unsigned)((K + 1 + NT - 1) / NT)), dim3(NT), 0, ss::l2s::stream(), h->d_om_ptr, K, (int64_t)nnz, d_bad);
+            if (hipGetLastError() != hipSuccess || ss::l2s::copy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            else if (bad) rc = SS_EINVAL;
+            ss::l2s::dfree(d_bad);
+        }
+        if (!rc) {
+            int64_t last = 0;                                  // (csr_ptr_check_kernel: never above nnz; here: exactly nnz)
+            if (ss::l2s::copy(&last, h->d_om_ptr + K, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SS_EHIP;
+            else if ((uint64_t)last != nnz) rc = SS_EINVAL;
+        }
+        h->has_om = rc == SS_OK;
+    }
+    if (rc) { hipFree(h->d_blob); delete h; return rc; }
+    *out = h;
     return SS_OK;
 }
 

@@ -317,31 +317,25 @@ def _read_l2_cache(path):
     """-> (ClusterImage, overlap CSR) from the raw image: one memory map, no decompression, no bit packing."""
     import os
     size = os.path.getsize(path)
-    mm = np.memmap(path, dtype=np.uint8, mode="r")
-    if size < 56 or bytes(mm[:8]) != _L2_MAGIC:
+    with open(path, "rb") as f:
+        head = f.read(56)
+    if size < 56 or len(head) < 56 or head[:8] != _L2_MAGIC:
         raise ValueError("not a cluster image")
-    K, S, W, ncls, nnz, _ = (int(x) for x in np.frombuffer(mm[8:56], np.uint64))
-    pos = [56]
-
-    def take(dtype, n):
-        o = _pad64(pos[0])
-        nb = n * np.dtype(dtype).itemsize
+    K, S, W, ncls, nnz, _ = (int(x) for x in np.frombuffer(head[8:56], np.uint64))
+    if W != max(4, ((K + 31) // 32 + 3) & ~3) or S > 0xFFFFFFFF or ncls > 0xFFFFFFFF:
+        raise ValueError("inconsistent cluster image")
+    pos, offs = 56, []
+    for nb in (S * W * 4, (K + 1) * 8, nnz * 4, nnz):
+        o = _pad64(pos)
         if o + nb > size:
             raise ValueError("truncated cluster image")
-        pos[0] = o + nb
-        return mm[o:o + nb].view(dtype)
-
-    planes = take(np.uint32, S * W)
-    indptr, indices, data = take(np.int64, K + 1), take(np.int32, nnz), take(np.int8, nnz)
-    if pos[0] != size or (K and int(indptr[K]) != nnz):
+        offs.append(o)
+        pos = o + nb
+    if pos != size:
         raise ValueError("inconsistent cluster image")
-    img = L2.ClusterImage.from_planes(planes, K, S)
-    try:
-        img.set_overlap(_CSR(indptr, indices, data, (K, ncls)))  # straight from the map to the device: no scipy object
-    except BaseException:
-        img.close()
-        raise
-    return img, None
+    # the whole file goes to the device in one upload through pinned buffers (ss_l2_import: planes + the overlap matrix's
+    # arrays, checked there: padding bits, row pointers in order and ending at nnz)
+    return L2.ClusterImage.from_image_file(path, K, S, offs, nnz, ncls), None
 
 
 def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_cov, omatrix, all_cls, l2, msn, pmode,

@@ -7,6 +7,7 @@ O(K) vector bookkeeping (bit packing of y-derived masks) and O(S) decisions.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -104,6 +105,26 @@ class ClusterImage:
         if planes.size != self.S * self.W:
             self.close()
             raise ValueError("plane array does not match K, S")
+        return self
+
+    @classmethod
+    def from_image_file(cls, path, K, S, offsets, nnz, n_cols):
+        """The package's own cluster image file (planes + overlap CSR at `offsets` = [planes, indptr, indices, data]) straight
+        to the device: ss_l2_import.  A file that is not what its header says -> ValueError."""
+        _lib.require_gpu()
+        self = cls.__new__(cls)
+        self.K, self.S = int(K), int(S)
+        h = C.c_void_p()
+        rc = _lib.lib().ss_l2_import(os.fsencode(path), self.K, self.S, int(offsets[0]), int(offsets[1]), int(offsets[2]), int(offsets[3]),
+                                     int(nnz), int(n_cols), C.byref(h))
+        if rc == _lib.SS_EINVAL:
+            raise ValueError("inconsistent cluster image")
+        _lib.check(rc, "ss_l2_import")
+        self._h = h
+        w = C.c_uint64()
+        _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
+        self.W = int(w.value)
+        self.om_cols = int(n_cols)
         return self
 
     # -- the O(K) vectors of detect_strains, on the device ---------------------------------------
