@@ -767,6 +767,9 @@ def _l2_branch_scenarios(tmp_path, monkeypatch, golden_l2):
     K = int(hdr[0])
     for what, blob in (("foreign file", b"NOTANIMG" + raw[8:]),
                        ("indptr[K] != the header's nnz", _bump_indptr_end(raw, hdr)),
+                       ("a word count W that does not follow from K", raw[:8] + np.array([hdr[0], hdr[1], hdr[2] + 4, hdr[3], hdr[4], hdr[5]], np.uint64).tobytes() + raw[56:]),
+                       ("bytes behind the last array", raw + b"\0" * 64),
+                       ("a plane with bits beyond row K", _set_padding_bit(raw, hdr)),
                        ("row pointers out of order", _swap_indptr(raw, hdr))):
         path.write_bytes(blob)
         assert [dict(x) for x in run_files()] == want, what                         # ignored, rebuilt from the .npz files
@@ -787,6 +790,15 @@ def _l2_image_offsets(hdr):
     o_pl = pad(56)
     o_ip = pad(o_pl + S * W * 4)
     return o_ip, K, nnz
+
+
+def _set_padding_bit(raw, hdr):
+    """a bit beyond row K in the first plane's last word (K is not a multiple of 32 in the golden cases)"""
+    K, S, W = (int(x) for x in hdr[:3])
+    body = bytearray(raw)
+    o = ((56 + 63) & ~63) + (W - 1) * 4
+    body[o + 3] |= 0x80
+    return bytes(body)
 
 
 def _bump_indptr_end(raw, hdr):
