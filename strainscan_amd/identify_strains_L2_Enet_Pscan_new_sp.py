@@ -194,7 +194,11 @@ def detect_core(X, om, sid, input_y, ksize, npp25, npp75, npp_out, cls_cov, all_
         # to the device and the pre-scan runs there
         y64 = np.ascontiguousarray(input_y, np.int64)
         n_keep = L2.count_keep(y64, npp25, npp75, npp_out)
-        split = L2.SplitDev(n_keep, CV_NITER, TEST_SIZE, 0) if n_keep >= SPLIT_DEV_MIN and L2.SplitDev.usable(n_keep, TEST_SIZE) else None
+        if n_keep >= SPLIT_DEV_MIN and L2.SplitDev.usable(n_keep, TEST_SIZE):
+            try:
+                split = L2.SplitDev(n_keep, CV_NITER, TEST_SIZE, 0)
+            except _lib.SSError:                  # no room for its buffers on the device: the host does the whole of it
+                split = None
         # ln, py_u, the [> 1] masks, the row filter: one pass on the device (ss_l2_prepare)
         vec = img.prepare(y64, new_als, npp25, npp75, npp_out)
         if vec.n_keep != n_keep:

@@ -718,6 +718,13 @@ def _l2_branch_scenarios(tmp_path, monkeypatch, golden_l2):
     monkeypatch.setattr(m, "SPLIT_DEV_MIN", 1)
     for name in sc.L2_CASES:
         test_detect_strains(name, golden_l2)
+    # ... and when the device has no room for its buffers: the host does the whole of it, same results
+    from strainscan_amd import _lib as L_, l2 as l2mod
+
+    def no_room(self, *a, **k):
+        raise L_.SSError(L_.SS_ENOMEM, "ss_split_dev_start")
+    monkeypatch.setattr(l2mod.SplitDev, "__init__", no_room)
+    test_detect_strains("three", golden_l2)
     monkeypatch.undo()
     for name in sc.L2_BATCH_CASES:
         d = tmp_path / ("batch_" + name)
