@@ -43,6 +43,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <functional>
+#include <future>
 
 namespace {
 
@@ -1711,7 +1713,9 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     uint64_t *d_entry = nullptr;
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
     Arena *A = nullptr;
+    std::future<Arena *> ahead;                               // (a large file: the arena allocated while the image travels)
     auto cleanup = [&](bool keep_text) {
+        if (ahead.valid()) arena_put(ahead.get());            // (a call that leaves before it took the arena over)
         auto now = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         const double c0 = now();
         void *scratch[] = {d_in, d_entry, d_crc, d_tab};
@@ -1751,6 +1755,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     if (const char *e = getenv("SS_GZ_SEG_KB")) seg_bytes = std::max<uint64_t>(64, (uint64_t)atoll(e)) << 10;      // (tests: many segments)
     const uint64_t data_n = in_n - 8 - data_off;
     seg_bytes = std::max(seg_bytes, 8 * chunk_bytes);
+    constexpr size_t SEG_CHUNKS = 16384;                      // chunks of a segment at most
     const uint64_t n_chunks0_ = std::max<uint64_t>(1, (data_n + chunk_bytes - 1) / chunk_bytes);
     if (n_chunks0_ > 0x7FFFFFF0ull) return no("size");
     const uint32_t n_chunks0 = (uint32_t)n_chunks0_;
@@ -1771,6 +1776,41 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     }
 
     if (!have_stream) return no("hipStreamCreateWithFlags");
+    auto text_guess = [&] {
+        const uint8_t *t8 = in + in_n - 8;
+        uint64_t guess = (uint64_t)t8[4] | (uint64_t)t8[5] << 8 | (uint64_t)t8[6] << 16 | (uint64_t)t8[7] << 24;      // ISIZE of the last member
+        while (guess < in_n) guess += 1ull << 32;
+        return (guess <= 16 * in_n ? guess : 3 * in_n) + 64;
+    };
+    // A LARGE file (round 5): its scratch arena and text buffer are allocated on a thread of their own WHILE the image travels --
+    // sized by what a segment can need at most (SEG_CHUNKS chunks, seg_bytes of data) instead of what this file's largest one
+    // does, which is known only after the search.  A fresh process is handed new device memory at ~25 GB/s: for a 3.4 GB file
+    // (4 GB of symbols + 7.7 GB of text) that was 0.14-0.38 s of waiting between the search and the first segment.
+    const bool big = fd >= 0 && !rr && in_n >= (256ull << 20);
+    if (big) {
+        int device = 0;
+        hipGetDevice(&device);
+        const uint64_t ub_chunks = SEG_CHUNKS + 80;
+        const uint64_t ub_need = (seg_bytes + chunk_bytes + SEG_CHUNKS) * ratio + SEG_CHUNKS * 4096;
+        const uint64_t ub_sym = ub_need + ub_need / 4 + 64 * (4096 + 64 * ratio), ub_text = text_guess();
+        ahead = std::async(std::launch::async, [=]() -> Arena * {
+            if (hipSetDevice(device) != hipSuccess) return nullptr;
+            Arena *a = arena_take_if_fits(ub_chunks, ub_sym, ub_text);
+            if (!a) {
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return nullptr;
+                if (2 * ub_text + ub_sym * 2 + ub_chunks * WSIZE * 5 + (256ull << 20) + in_n > mem_free / 2) return nullptr;      // (decided below, with the real sizes)
+                a = arena_get(ub_chunks, ub_sym);
+            }
+            if (a && a->text_cap < ub_text) {
+                if (a->text) hipFree(a->text);
+                a->text = nullptr;
+                a->text_cap = 0;
+                if (hipMalloc((void **)&a->text, ub_text) == hipSuccess) a->text_cap = ub_text;
+            }
+            return a;
+        });
+    }
     GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
     constexpr bool no_pread = false;
     bool uploaded = false;
@@ -1963,7 +2003,6 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // The chunks are inflated SEGMENT by segment (seg_bytes of deflate data, 128 MB): the scratch stays a few GB whatever
     // the file's size, and the text of one segment is complete -- bytes -- before the next one starts, so the 32 KB in
     // front of a segment's first chunk are simply the end of the text so far.
-    constexpr size_t SEG_CHUNKS = 16384;
     auto segment_end = [&](size_t gi) {
         size_t gj = gi + 1;
         while (gj < G.size() && (G[gj].start - G[gi].start) / 8 < seg_bytes && gj - gi < SEG_CHUNKS) gj++;
@@ -1982,13 +2021,14 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     const uint64_t sym_elems = need_sym + need_sym / 4 + 64 * (4096 + 64 * ratio);      // (+ what run-over and further members add)
     if (sym_elems * 2 > (24ull << 30)) return no("segment", (long long)(sym_elems >> 20));      // (GBs without a single block start)
     uint64_t text_cap;
+    if (ahead.valid()) {
+        A = ahead.get();
+        if (A && (A->cap_chunks < cap_chunks || A->sym_elems < sym_elems)) { arena_put(A); A = nullptr; }      // (cannot happen: the bounds are bounds)
+    }
     {
-        const uint8_t *t8 = in + in_n - 8;
-        uint64_t guess = (uint64_t)t8[4] | (uint64_t)t8[5] << 8 | (uint64_t)t8[6] << 16 | (uint64_t)t8[7] << 24;      // ISIZE of the last member
-        while (guess < in_n) guess += 1ull << 32;
-        text_cap = (guess <= 16 * in_n ? guess : 3 * in_n) + 64;
+        text_cap = text_guess();
         if (rr) text_cap = text_cap / rr->n_slices * rr->mine.size() * 13 / 10 + (1ull << 20);      // this rank's share (it grows when short)
-        A = arena_take_if_fits(cap_chunks, sym_elems, text_cap);
+        if (!A) A = arena_take_if_fits(cap_chunks, sym_elems, text_cap);
         if (!A) {
             size_t mem_free = 0, mem_total = 0;
             GI(hipMemGetInfo(&mem_free, &mem_total));
