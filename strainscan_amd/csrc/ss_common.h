@@ -231,6 +231,8 @@ int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, 
 // pool (round 5): the clusters of a sample are solved on several host threads at once, and on the legacy default stream every
 // synchronous copy of one thread waited for the kernels of all the others, every hipFree for the whole device (four 5 M-row
 // clusters: 36 ms each in the O(K) vector pass that takes 5.5 ms alone).  Buffers that live in a handle stay with hipMalloc.
+// the stream-ordered pool keeps at least `bytes` of what its users free (raised, never lowered: ss_host.hip)
+void pool_keep_at_least(uint64_t bytes);
 namespace l2s {
 inline hipStream_t stream() { return hipStreamPerThread; }
 hipError_t dmalloc(void **p, size_t n);          // (ss_host.hip: sets the pool's release threshold once)

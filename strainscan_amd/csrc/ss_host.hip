@@ -192,16 +192,22 @@ int ss_device_sync(void) { SS_HIP(hipDeviceSynchronize()); return SS_OK; }
 int ss_stream_sync(void *stream) { SS_HIP(hipStreamSynchronize(ss::as_stream(stream))); return SS_OK; }
 
 }  // extern "C"
+void ss::pool_keep_at_least(uint64_t bytes)
+{
+    static std::mutex mu;
+    static uint64_t now = 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (bytes <= now) return;
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess &&
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &bytes) == hipSuccess)
+        now = bytes;
+}
 hipError_t ss::l2s::dmalloc(void **p, size_t n)
 {
     static std::once_flag once;
-    std::call_once(once, [] {              // keep up to 2 GB of freed temporaries in the pool instead of returning them at every synchronisation
-        int dev = 0;
-        hipMemPool_t pool = nullptr;
-        uint64_t keep = 2ull << 30;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
-            hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    });
+    std::call_once(once, [] { ss::pool_keep_at_least(2ull << 30); });      // freed temporaries stay in the pool instead of going back at every synchronisation
     return hipMallocAsync(p, n ? n : 1, stream());
 }
 extern "C" {
