@@ -206,9 +206,9 @@ def run(n_reads, shapes, mode="text", C=202, per_cluster=True):
         odir = os.path.join(base, "out")
         args = ["-i", fq[0], "-j", fq[1], "-d", base, "-o", odir]
         runs = []
-        for label in ("nothing_cached", "images_cached", "images_cached_again") + tuple(os.environ.get("SS_CLI_EXTRA_RUNS", "").split()):
+        for label in ("nothing_cached", "images_cached", "images_cached_again"):
             shutil.rmtree(odir, ignore_errors=True)
-            res = run_cli(args, dict(env, **{k_: "1" for k_ in label.split("+") if k_.startswith("SS_")}))
+            res = run_cli(args, env)
             res["label"] = label
             runs.append(res)
         out["cli_fresh_process"] = runs

@@ -1426,43 +1426,6 @@ void pin_put(PinSet *p)
     }
     pin_destroy(p);
 }
-// Device buffers for file images, kept between calls and -- what they are for -- made AHEAD of a call by the CLI's warm-up
-// thread (ss_gz_warm_up_bytes) while the interpreter still imports: a fresh process is handed new device memory at ~25 GB/s,
-// and the first 3.4 GB image travelled at 11 GB/s where the same upload does 59 GB/s into memory that is mapped already.
-// A call that finds the warm-up still at work WAITS for it (the two must not both allocate: measured, that is slower than
-// no warm-up at all).  At most two buffers / 16 GB stay parked.
-struct ParkedImage { uint8_t *p; uint64_t bytes; };
-std::mutex g_park_mu;
-std::condition_variable g_park_cv;
-std::vector<ParkedImage> g_parked;
-int g_parking = 0;                                            // warm-ups in progress
-uint8_t *park_take(uint64_t bytes, uint64_t *got)
-{
-    std::unique_lock<std::mutex> g(g_park_mu);
-    for (;;) {
-        for (size_t i = 0; i < g_parked.size(); i++)
-            if (g_parked[i].bytes >= bytes) {
-                uint8_t *p = g_parked[i].p;
-                *got = g_parked[i].bytes;
-                g_parked.erase(g_parked.begin() + (long)i);
-                return p;
-            }
-        if (!g_parking) return nullptr;
-        g_park_cv.wait(g);
-    }
-}
-void park_put(uint8_t *p, uint64_t bytes)
-{
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> g(g_park_mu);
-        uint64_t held = 0;
-        for (auto &q : g_parked) held += q.bytes;
-        if (g_parked.size() < 2 && held + bytes <= (16ull << 30)) { g_parked.push_back({p, bytes}); g_park_cv.notify_all(); return; }
-    }
-    hipFree(p);
-}
-
 // `ready(bytes)`: called (serialised, from the upload threads) whenever the PREFIX of the image that has arrived on the device
 // has grown -- the caller starts work on it while the rest is still on its way.
 bool upload_file(int fd, uint64_t n, uint8_t *d_in, const std::function<void(uint64_t)> &ready = nullptr)
@@ -1745,12 +1708,11 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
     Arena *A = nullptr;
     std::future<Arena *> ahead;                               // (a large file: the arena allocated while the image travels)
-    uint64_t d_in_parked = 0;                                 // d_in came from the parked image buffers (its size): it goes back there
     auto cleanup = [&](bool keep_text) {
         if (ahead.valid()) arena_put(ahead.get());            // (a call that leaves before it took the arena over)
         auto now = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         const double c0 = now();
-        void *scratch[] = {d_in_parked ? nullptr : d_in, d_entry, d_crc, d_tab};
+        void *scratch[] = {d_in, d_entry, d_crc, d_tab};
         for (int q = 0; q < 4; q++) {
             if (!scratch[q]) continue;
             if (keep_text && A) A->late_free[q] = scratch[q];      // (freed by gpu_gunzip_done)
@@ -1758,7 +1720,6 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         }
         const double c1 = now();
         hipStreamSynchronize(st);
-        if (d_in_parked) { park_put(d_in, d_in_parked); d_in = nullptr; d_in_parked = 0; }      // (nothing reads the image any more)
         const double c2 = now();
         call_stream_put(st);
         if (trace) fprintf(stderr, "[ginflate] cleanup: free %.4f, sync %.4f, stream back %.4f s\n", c1 - c0, c2 - c1, now() - c2);
@@ -1844,8 +1805,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             return a;
         });
     }
-    if (big) d_in = park_take(in_n + 8192, &d_in_parked);      // (made ahead by the warm-up thread, or left by an earlier call)
-    if (!d_in) GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));      // the stage is filled 1 KB at a time, up to 2 KB ahead
+    GI(hipMallocAsync((void **)&d_in, in_n + 8192, st));                 // the stage is filled 1 KB at a time, up to 2 KB ahead
     constexpr bool no_pread = false;
     bool uploaded = false;
     // (pinned buffers cost ~40 ms to make: a file of less than 256 MB takes that way only when a set is there already --
@@ -2626,24 +2586,29 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
     return SS_OK;
 }
 
-// ... and device memory for the images of the (at most two, large) files that are about to arrive: parked image buffers, see
-// park_take.  The CLI's warm-up thread calls this while the interpreter is still importing modules.
+// ... and device memory for the images of the files that are about to arrive (round 5): a fresh process is handed new device
+// memory slowly -- the first 3.4 GB image travelled at 11 GB/s where the same upload does 59 GB/s once the pool holds the memory --
+// so the CLI's warm-up thread takes the images' bytes from the stream-ordered pool and gives them back to it (the pool keeps them)
+// while the interpreter is still importing modules.  At most 16 GB.
 extern "C" int ss_gz_warm_up_bytes(const uint64_t *file_bytes, int n_files)
 {
     if (n_files < 0 || (n_files && !file_bytes)) return SS_EINVAL;
     uint64_t total = 0;
-    for (int i = 0; i < std::min(n_files, 2); i++) total += file_bytes[i] + 8192;
+    for (int i = 0; i < n_files; i++) total += file_bytes[i] + 8192;
     if (!total || total > (16ull << 30)) return SS_OK;
-    { std::lock_guard<std::mutex> g(g_park_mu); g_parking++; }
+    ss::pool_keep_at_least(total + (2ull << 30));
+    hipStream_t st = ss::call_stream_get();
+    if (!st) return SS_EHIP;
+    std::vector<void *> got;
     int rc = SS_OK;
-    for (int i = 0; i < std::min(n_files, 2) && !rc; i++) {
-        if (file_bytes[i] < (256ull << 20)) continue;         // (small images do not take this way)
-        uint8_t *p = nullptr;
-        if (hipMalloc((void **)&p, file_bytes[i] + 8192) != hipSuccess) rc = SS_ENOMEM;
-        else park_put(p, file_bytes[i] + 8192);
+    for (int i = 0; i < n_files && !rc; i++) {
+        void *p = nullptr;
+        if (hipMallocAsync(&p, file_bytes[i] + 8192, st) != hipSuccess) rc = SS_ENOMEM;
+        else { got.push_back(p); hipMemsetAsync(p, 0, 64, st); }
     }
-    { std::lock_guard<std::mutex> g(g_park_mu); g_parking--; }
-    g_park_cv.notify_all();
+    for (void *p : got) hipFreeAsync(p, st);
+    hipStreamSynchronize(st);
+    ss::call_stream_put(st);
     return rc;
 }
 
