@@ -268,7 +268,7 @@ def measure_gz_ingest(reads, n_pair, base):
     out = dict(reads=2 * n_pair, files=2, gz_mb=round(sum(os.path.getsize(p) for p in gz) / 1e6, 1), gzip_level=6,
                compress_s=round(time.perf_counter() - t0, 1), host_cpus=int(_lib.lib().ss_host_cpus()))
     prev = os.environ.get("SS_GZ_GPU")
-    _lib.warm_up(gz=2, gz_paths=gz)       # (as the CLI does on its warm-up thread when it is given .gz files: the pinned upload buffers, the images' device memory)
+    _lib.warm_up(gz=2)       # (as the CLI does on its warm-up thread when it is given .gz files: the pinned upload buffers)
     try:
         for mode, key in (("1", "device_ms"), ("0", "host_inflaters_ms")):
             os.environ["SS_GZ_GPU"] = mode

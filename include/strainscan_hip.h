@@ -101,9 +101,6 @@ int ss_gz_gpu_release(void);
  * calls this on its warm-up thread): a file of 32 MB or more then travels through them (8 ms instead of 12-30 per 66 MB);
  * without them only files of 256 MB or more make their own. */
 int ss_gz_warm_up(int n_files);
-/* ... and the device memory of the file images that are about to be uploaded (sizes of the .gz files in bytes): taken from the
- * stream-ordered pool and given back to it, so that the uploads find it mapped.  No effect on results; at most 16 GB. */
-int ss_gz_warm_up_bytes(const uint64_t *file_bytes, int n_files);
 /* Who inflates the .gz inputs of the next ss_reads_load / ss_scan_files* calls of this process: 0 (default) the device, and
  * the host inflaters for whatever it declines; 1 the device or NOBODY -- a declined input makes the call return SS_EAGAIN
  * with nothing loaded; 2 the host inflaters.  The two paths give a rank different shares of the reads (blocks of 4096

@@ -46,9 +46,9 @@ try:
         assert all(q.wait() == 0 for q in pr)
     print("gzip -%s: %.1f s, %d MB" % (lvl, time.perf_counter() - t0, sum(os.path.getsize(p) for p in gz) >> 20), flush=True)
     if os.environ.get("SS_GZ_FRESH"):                # a FRESH process per load, as the CLI is one: traces of its first (only) load
-        code = ("import sys, time; sys.path.insert(0, %r); t0 = time.perf_counter(); from strainscan_amd import _lib; _lib.warm_up(gz=2, gz_paths=%r); t1 = time.perf_counter();"
+        code = ("import sys, time; sys.path.insert(0, %r); t0 = time.perf_counter(); from strainscan_amd import _lib; _lib.warm_up(gz=2); t1 = time.perf_counter();"
                 "rs = _lib.ReadSet(%r); _lib.check(_lib.lib().ss_device_sync(), 'sync'); t2 = time.perf_counter();"
-                "print('fresh process: import + warm_up %%.3f s, load %%.3f s = %%.1f M reads/s' %% (t1 - t0, t2 - t1, %d / (t2 - t1) / 1e6), flush=True); import os; os._exit(0)" % (ROOT, gz, gz, n))
+                "print('fresh process: import + warm_up %%.3f s, load %%.3f s = %%.1f M reads/s' %% (t1 - t0, t2 - t1, %d / (t2 - t1) / 1e6), flush=True); import os; os._exit(0)" % (ROOT, gz, n))
         for i in range(loads):
             r_ = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
             print(r_.stdout.strip(), flush=True)

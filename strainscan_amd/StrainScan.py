@@ -18,8 +18,8 @@ if __name__ == "__main__" or os.path.basename(sys.argv[0] or "") in ("strainscan
         from . import _lib
         # (plain-text reads in a single process: the parse threads' pinned buffers too; .gz inputs never use them, they have
         #  upload buffers of their own)
-        gz = [a for a in sys.argv[1:] if a.endswith(".gz")]
-        _lib.warm_up(ingest=int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not gz, gz=min(len(gz), 2), gz_paths=gz[:2])
+        n_gz = sum(a.endswith(".gz") for a in sys.argv[1:])
+        _lib.warm_up(ingest=int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not n_gz, gz=min(n_gz, 2))
 
     threading.Thread(target=_early, name="ss-gpu-warm-up", daemon=True).start()
 

@@ -114,7 +114,6 @@ SIGNATURES = {
     "ss_scan_kernel_launches": (u64, [vp]),
     "ss_ingest_warm_up": (i32, []),
     "ss_gz_warm_up": (i32, [i32]),
-    "ss_gz_warm_up_bytes": (i32, [vp, i32]),
     "ss_reads_load": (i32, [P(cp), i32, i32, i32, P(vp)]),
     "ss_reads_from_flat_dev": (i32, [vp, u64, i32, P(vp)]),
     "ss_reads_read_back": (i32, [vp, vp, u64, P(u64)]),
@@ -202,19 +201,17 @@ def lib():
         return _load()
 
 
-def warm_up(ingest=False, gz=0, gz_paths=()):
+def warm_up(ingest=False, gz=0):
     """Load the library and start the HIP runtime (0.1-0.2 s in a fresh process); `ingest`: also the one-time costs of the
     first read of plain-text files (pinned parse buffers, streams: another 0.1 s); `gz`: the pinned upload buffers of that
-    many .gz inputs, `gz_paths`: device memory for their images -- the CLI calls this on a worker thread while the interpreter
-    is still importing modules and parsing arguments."""
+    many .gz inputs -- the CLI calls this on a worker thread while the interpreter is still importing modules and parsing
+    arguments."""
     try:
         if device_count() > 0 and ingest:
             lib().ss_ingest_warm_up()
         if device_count() > 0 and gz:
             lib().ss_gz_warm_up(int(gz))
-            sizes = np.array([os.path.getsize(p) for p in gz_paths if os.path.isfile(p)], np.uint64)
-            if sizes.size:
-                lib().ss_gz_warm_up_bytes(ptr(sizes), int(sizes.size))
+
     except Exception:                       # noqa: B902 -- whoever needs the GPU next gets the real error
         pass
 

@@ -2586,32 +2586,6 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
     return SS_OK;
 }
 
-// ... and device memory for the images of the files that are about to arrive (round 5): a fresh process is handed new device
-// memory slowly -- the first 3.4 GB image travelled at 11 GB/s where the same upload does 59 GB/s once the pool holds the memory --
-// so the CLI's warm-up thread takes the images' bytes from the stream-ordered pool and gives them back to it (the pool keeps them)
-// while the interpreter is still importing modules.  At most 16 GB.
-extern "C" int ss_gz_warm_up_bytes(const uint64_t *file_bytes, int n_files)
-{
-    if (n_files < 0 || (n_files && !file_bytes)) return SS_EINVAL;
-    uint64_t total = 0;
-    for (int i = 0; i < n_files; i++) total += file_bytes[i] + 8192;
-    if (!total || total > (16ull << 30)) return SS_OK;
-    ss::pool_keep_at_least(total + (2ull << 30));
-    hipStream_t st = ss::call_stream_get();
-    if (!st) return SS_EHIP;
-    std::vector<void *> got;
-    int rc = SS_OK;
-    for (int i = 0; i < n_files && !rc; i++) {
-        void *p = nullptr;
-        if (hipMallocAsync(&p, file_bytes[i] + 8192, st) != hipSuccess) rc = SS_ENOMEM;
-        else { got.push_back(p); hipMemsetAsync(p, 0, 64, st); }
-    }
-    for (void *p : got) hipFreeAsync(p, st);
-    hipStreamSynchronize(st);
-    ss::call_stream_put(st);
-    return rc;
-}
-
 // the pinned upload buffers of `n_files` concurrent .gz inputs (at most two sets are kept), made ahead of time
 extern "C" int ss_gz_warm_up(int n_files)
 {
