@@ -690,45 +690,36 @@ namespace {
 constexpr uint32_t SD_NONE = 0xFFFFFFFFu;
 constexpr int SD_NB = 3;                      // partner buffers in flight between the walker and the device
 
-__global__ __launch_bounds__(256) void sd_iota_kernel(uint32_t *v, uint32_t m)
+// link[k] = the step that had partner j[k] last before this kernel's thread k came by (any order): a list per place
+__global__ __launch_bounds__(256) void sd_link_kernel(const uint32_t *__restrict__ j, uint32_t m, uint32_t *__restrict__ head, uint32_t *__restrict__ link)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < m) v[k] = k;
+    if (k < m) link[k] = atomicExch(&head[j[k]], k);
 }
-// rank[step] = its place in the sorted order; last[p] = place of the LAST step (largest k) with partner p
-__global__ __launch_bounds__(256) void sd_index_kernel(const uint32_t *__restrict__ js, const uint32_t *__restrict__ ks, uint32_t m,
-                                                       uint32_t *__restrict__ rank, uint32_t *__restrict__ last)
+__global__ __launch_bounds__(256) void sd_clear_kernel(const uint32_t *__restrict__ j, uint32_t m, uint32_t *__restrict__ head)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= m) return;
-    rank[ks[r]] = r;
-    if (r + 1 == m || js[r + 1] != js[r]) last[js[r]] = r;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < m) head[j[k]] = SD_NONE;
 }
-__global__ __launch_bounds__(256) void sd_clear_last_kernel(const uint32_t *__restrict__ js, uint32_t m, uint32_t *__restrict__ last)
+// the most recent step before `before` among the steps whose partner is place p (its list: a member or two)
+__device__ __forceinline__ uint32_t sd_latest_before(const uint32_t *__restrict__ head, const uint32_t *__restrict__ link, uint32_t p, uint32_t before)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r < m) last[js[r]] = SD_NONE;
+    uint32_t best = SD_NONE;
+    for (uint32_t c = head[p]; c != SD_NONE; c = link[c])
+        if (c < before && (best == SD_NONE || c > best)) best = c;
+    return best;
 }
-__global__ __launch_bounds__(256) void sd_resolve_kernel(const uint32_t *__restrict__ js, const uint32_t *__restrict__ ks, const uint32_t *__restrict__ rank,
-                                                         const uint32_t *__restrict__ last, uint32_t m, uint32_t n, uint32_t bit,
-                                                         uint32_t *__restrict__ train)
+__global__ __launch_bounds__(256) void sd_resolve_kernel(const uint32_t *__restrict__ j, const uint32_t *__restrict__ head, const uint32_t *__restrict__ link,
+                                                         uint32_t m, uint32_t n, uint32_t bit, uint32_t *__restrict__ train)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= m) return;
-    const uint32_t r = rank[k], p = js[r];
-    uint32_t e = p;
-    if (r > 0 && js[r - 1] == p) {
-        uint32_t t = ks[r - 1];                                  // the step that last put something at p: what lay at ITS row?
-        for (;;) {
-            const uint32_t pos = n - 1u - t, g = last[pos];
-            if (g == SD_NONE) { e = pos; break; }
-            uint32_t t2 = ks[g];                                 // (every step with partner pos is at or before step t)
-            if (t2 == t) {                                       // step t swapped its row with itself: the one before it
-                if (g > 0 && js[g - 1] == pos) t2 = ks[g - 1];
-                else { e = pos; break; }
-            }
-            t = t2;
-        }
+    uint32_t e = j[k];
+    // what lay at j[k] when step k took it: what the most recent earlier step with that partner left there -- the old content of ITS
+    // row, that is what the most recent step before IT with that row as partner left there -- ... -- or the place's own number
+    for (uint32_t t = sd_latest_before(head, link, e, k); t != SD_NONE;) {
+        e = n - 1u - t;
+        t = sd_latest_before(head, link, e, t);
     }
     atomicOr(&train[e], bit);
 }
@@ -744,9 +735,7 @@ struct ss_split {
     hipStream_t stream = nullptr;
     uint32_t *d_train = nullptr, *d_j[SD_NB] = {nullptr, nullptr, nullptr}, *h_j[SD_NB] = {nullptr, nullptr, nullptr};
     hipEvent_t copied[SD_NB] = {nullptr, nullptr, nullptr};
-    uint32_t *d_iota = nullptr, *d_js = nullptr, *d_ks = nullptr, *d_rank = nullptr, *d_last = nullptr;
-    void *d_tmp = nullptr;
-    size_t tmp_bytes = 0;
+    uint32_t *d_head = nullptr, *d_link = nullptr;
     double walk_ms = 0, total_ms = 0;
     int device = 0;
 };
@@ -791,9 +780,8 @@ void split_dev_free_buffers(ss_split *s)
         if (s->copied[b]) hipEventDestroy(s->copied[b]);
         s->copied[b] = nullptr;
     }
-    hipFree(s->d_iota); hipFree(s->d_js); hipFree(s->d_ks); hipFree(s->d_rank); hipFree(s->d_last); hipFree(s->d_tmp);
-    s->d_iota = s->d_js = s->d_ks = s->d_rank = s->d_last = nullptr;
-    s->d_tmp = nullptr;
+    hipFree(s->d_head); hipFree(s->d_link);
+    s->d_head = s->d_link = nullptr;
 }
 
 template <bool SIMD>
@@ -806,8 +794,6 @@ void split_dev_walk(ss_split *s)
     if (!rng) { s->rc = SS_ENOMEM; return; }
     const uint32_t m = (uint32_t)s->m, n = (uint32_t)s->n;
     const unsigned grid = (m + 255u) / 256u;
-    int bits = 1;
-    while ((1ull << bits) < s->n) bits++;
     bool used[SD_NB] = {false, false, false};
     for (int f = 0; f < s->n_splits && s->rc == SS_OK && !s->cancel; f++) {
         const int b = f % SD_NB;
@@ -822,12 +808,10 @@ void split_dev_walk(ss_split *s)
         hipError_t e = hipMemcpyAsync(s->d_j[b], s->h_j[b], (uint64_t)m * 4, hipMemcpyHostToDevice, s->stream);
         if (e == hipSuccess) e = hipEventRecord(s->copied[b], s->stream);
         used[b] = true;
-        size_t tb = s->tmp_bytes;
-        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(s->d_tmp, tb, s->d_j[b], s->d_js, s->d_iota, s->d_ks, (int)m, 0, bits, s->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(sd_index_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_js, s->d_ks, m, s->d_rank, s->d_last);
-            hipLaunchKernelGGL(sd_resolve_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_js, s->d_ks, s->d_rank, s->d_last, m, n, 1u << f, s->d_train);
-            hipLaunchKernelGGL(sd_clear_last_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_js, m, s->d_last);
+            hipLaunchKernelGGL(sd_link_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_j[b], m, s->d_head, s->d_link);
+            hipLaunchKernelGGL(sd_resolve_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_j[b], s->d_head, s->d_link, m, n, 1u << f, s->d_train);
+            hipLaunchKernelGGL(sd_clear_kernel, dim3(grid), dim3(256), 0, s->stream, s->d_j[b], m, s->d_head);
             e = hipGetLastError();
         }
         if (e != hipSuccess) { ss::set_last_error("ss_split_dev", __FILE__, __LINE__, e); s->rc = SS_EHIP; break; }
@@ -847,23 +831,14 @@ int ss_split_dev_start(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed,
     s->n = n; s->n_test = n_test; s->m = n - n_test; s->n_splits = n_splits; s->seed = seed;
     hipGetDevice(&s->device);
     const uint64_t cap = s->m + SPLIT_CH + MTWords::BLK + 64;
-    int bits = 1;
-    while ((1ull << bits) < n) bits++;
     bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
     for (int b = 0; b < SD_NB && ok; b++) {
         s->h_j[b] = g_pinned.get(cap);
         ok = s->h_j[b] && hipMalloc((void **)&s->d_j[b], s->m * 4) == hipSuccess && hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && hipcub::DeviceRadixSort::SortPairs(nullptr, s->tmp_bytes, s->d_js, s->d_js, s->d_ks, s->d_ks, (int)s->m, 0, bits) == hipSuccess;
-    ok = ok && hipMalloc((void **)&s->d_train, n * 4) == hipSuccess && hipMalloc((void **)&s->d_iota, s->m * 4) == hipSuccess &&
-         hipMalloc((void **)&s->d_js, s->m * 4) == hipSuccess && hipMalloc((void **)&s->d_ks, s->m * 4) == hipSuccess &&
-         hipMalloc((void **)&s->d_rank, s->m * 4) == hipSuccess && hipMalloc((void **)&s->d_last, n * 4) == hipSuccess &&
-         hipMalloc(&s->d_tmp, std::max<size_t>(s->tmp_bytes, 16)) == hipSuccess;
-    if (ok) {
-        ok = hipMemsetAsync(s->d_train, 0, n * 4, s->stream) == hipSuccess && hipMemsetAsync(s->d_last, 0xFF, n * 4, s->stream) == hipSuccess;
-        hipLaunchKernelGGL(sd_iota_kernel, dim3((unsigned)((s->m + 255) / 256)), dim3(256), 0, s->stream, s->d_iota, (uint32_t)s->m);
-        ok = ok && hipGetLastError() == hipSuccess;
-    }
+    ok = ok && hipMalloc((void **)&s->d_train, n * 4) == hipSuccess && hipMalloc((void **)&s->d_head, n * 4) == hipSuccess &&
+         hipMalloc((void **)&s->d_link, s->m * 4) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(s->d_train, 0, n * 4, s->stream) == hipSuccess && hipMemsetAsync(s->d_head, 0xFF, n * 4, s->stream) == hipSuccess;
     if (!ok) {
         split_dev_free_buffers(s);
         hipFree(s->d_train);
