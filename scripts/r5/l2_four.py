@@ -6,6 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
+if os.environ.get('L2_SWITCH'):
+    sys.setswitchinterval(float(os.environ['L2_SWITCH']))
 import scipy.sparse as sp
 from concurrent.futures import ThreadPoolExecutor
 from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m, l2 as L2

@@ -831,7 +831,11 @@ int ss_split_dev_start(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed,
     s->n = n; s->n_test = n_test; s->m = n - n_test; s->n_splits = n_splits; s->seed = seed;
     hipGetDevice(&s->device);
     const uint64_t cap = s->m + SPLIT_CH + MTWords::BLK + 64;
-    bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess;
+    // the LOWEST stream priority: the splits are needed only when the pre-scan is over, and the pre-scan's many small kernels
+    // (and those of the other clusters being solved) should not queue behind 2.5 M-thread resolve launches
+    int pr_least = 0, pr_greatest = 0;
+    hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+    bool ok = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, pr_least) == hipSuccess;
     for (int b = 0; b < SD_NB && ok; b++) {
         s->h_j[b] = g_pinned.get(cap);
         ok = s->h_j[b] && hipMalloc((void **)&s->d_j[b], s->m * 4) == hipSuccess && hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming) == hipSuccess;
