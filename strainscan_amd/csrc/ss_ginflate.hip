@@ -1708,9 +1708,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     uint32_t *d_crc = nullptr, *d_tab = nullptr;
     Arena *A = nullptr;
     std::future<Arena *> ahead;                               // (a large file: the arena allocated while the image travels)
-    std::thread up_thread;                                    // (a large file: its upload, while this thread inflates what has arrived)
     auto cleanup = [&](bool keep_text) {
-        if (up_thread.joinable()) up_thread.join();           // (the image buffer is freed below)
         if (ahead.valid()) arena_put(ahead.get());            // (a call that leaves before it took the arena over)
         auto now = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
         const double c0 = now();
@@ -1782,19 +1780,13 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // sized by what a segment can need at most (SEG_CHUNKS chunks, seg_bytes of data) instead of what this file's largest one
     // does, which is known only after the search.  A fresh process is handed new device memory at ~25 GB/s: for a 3.4 GB file
     // (4 GB of symbols + 7.7 GB of text) that was 0.14-0.38 s of waiting between the search and the first segment.
-    // (SS_GZ_BIG_KB, tests: the size from which a file takes the large-file way -- arena ahead, segments inflated while the image
-    //  still travels -- so that small test files run it)
-    static const uint64_t big_bytes = getenv("SS_GZ_BIG_KB") ? (uint64_t)std::max<long long>(1, atoll(getenv("SS_GZ_BIG_KB"))) << 10 : 256ull << 20;
-    const bool big = fd >= 0 && !rr && in_n >= big_bytes;
-    // `hdr`: ~0, or -- an entry INSIDE a block (subsync_kernel) -- where that block's header is.
-    struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; uint64_t hdr = ~0ull; };
-    const uint64_t ub_chunks = SEG_CHUNKS + 80;
-    const uint64_t ub_need = (seg_bytes + chunk_bytes + SEG_CHUNKS) * ratio + SEG_CHUNKS * 4096;
-    const uint64_t ub_sym = ub_need + ub_need / 4 + 64 * (4096 + 64 * ratio);
+    const bool big = fd >= 0 && !rr && in_n >= (256ull << 20);
     if (big) {
         int device = 0;
         hipGetDevice(&device);
-        const uint64_t ub_text = text_guess();
+        const uint64_t ub_chunks = SEG_CHUNKS + 80;
+        const uint64_t ub_need = (seg_bytes + chunk_bytes + SEG_CHUNKS) * ratio + SEG_CHUNKS * 4096;
+        const uint64_t ub_sym = ub_need + ub_need / 4 + 64 * (4096 + 64 * ratio), ub_text = text_guess();
         ahead = std::async(std::launch::async, [=]() -> Arena * {
             if (hipSetDevice(device) != hipSuccess) return nullptr;
             Arena *a = arena_take_if_fits(ub_chunks, ub_sym, ub_text);
@@ -1820,16 +1812,6 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     //  ss_gz_warm_up, or an earlier call -- and then arrives in 8 ms instead of 12-30)
     const uint64_t pread_from = pin_waiting() ? 32ull << 20 : 256ull << 20;
     const std::vector<Bgzf> bgzf = bgzf_members(in, in_n);            // a bgzip file: its members ARE the chunks, no search
-    // A LARGE file that is not bgzip (round 5): its segments are inflated WHILE the rest of the image still travels.  The upload
-    // runs on a thread of its own; this thread follows the prefix that has arrived: searches the new chunks for entries, enters the
-    // blocks between them, and works a segment off as soon as the chunks it may touch (its own, the look-ahead entries behind it,
-    // what a chunk may run over) are on the device.  Before, the device idled for the whole upload -- 0.13 s of a 0.45 s load of two
-    // 1.4 GB files, 0.3-0.4 s of a fresh process's 1.4 s for two 3.4 GB files.
-    const bool inc = big && bgzf.empty();
-    std::mutex up_mu;
-    std::condition_variable up_cv;
-    uint64_t up_ready = 0;
-    bool up_done = false, up_ok = false;
     uint64_t probe = 512;
     uint32_t c_searched = 0;                                   // search chunks [0, c_searched) have been launched
     auto search_to = [&](uint32_t c_hi) {
@@ -1838,24 +1820,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                                trace ? 1 : 0, rr ? rr->slice_chunks : 0u, rr ? rr->rank : 0u, rr ? rr->world : 1u, LOOK, c_searched);
         c_searched = std::max(c_searched, c_hi);
     };
-    if (inc) {
-        GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
-        GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
-        GI(hipStreamSynchronize(st));                         // the allocations are stream-ordered
-        lap("stage allocated");
-        int device = 0;
-        hipGetDevice(&device);
-        up_thread = std::thread([&, device] {
-            bool ok = hipSetDevice(device) == hipSuccess;
-            ok = ok && upload_file(fd, in_n, d_in, [&](uint64_t ready) {
-                { std::lock_guard<std::mutex> g(up_mu); up_ready = ready; }
-                up_cv.notify_all();
-            });
-            { std::lock_guard<std::mutex> g(up_mu); up_ok = ok; up_done = true; }
-            up_cv.notify_all();
-        });
-        uploaded = true;                                       // (as far as the code below is concerned: wait_ready follows the prefix)
-    } else if (fd >= 0 && in_n >= pread_from && !no_pread && !rr) {    // (`fd`: the same file; smaller ones are there before the buffers are)
+    if (fd >= 0 && in_n >= pread_from && !no_pread && !rr) {    // (`fd`: the same file; smaller ones are there before the buffers are)
         GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
         GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
         GI(hipStreamSynchronize(st));                         // the allocations are stream-ordered
@@ -1896,54 +1861,21 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     if (!uploaded) GB(h2d(d_in, in, in_n));
     GI(hipMemsetAsync(d_in + in_n, 0, 8192, st));
     if (!d_entry) GI(hipMallocAsync((void **)&d_entry, (uint64_t)n_chunks0 * 8, st));
-    if (!inc) lap("input on device");
+    lap("input on device");
     std::vector<uint64_t> entry(n_chunks0);
-    // (large files) bytes [0, upto) of the image are on the device; an upload that failed is repeated as one plain copy
-    auto wait_ready = [&](uint64_t upto) -> bool {
-        upto = std::min(upto, in_n);
-        bool failed = false;
-        {
-            std::unique_lock<std::mutex> g(up_mu);
-            up_cv.wait(g, [&] { return up_ready >= upto || up_done; });
-            failed = up_done && !up_ok;
-        }
-        if (failed) {
-            if (up_thread.joinable()) up_thread.join();
-            if (!h2d(d_in, in, in_n) || hipStreamSynchronize(st) != hipSuccess) return false;
-            std::lock_guard<std::mutex> g(up_mu);
-            up_ok = true;
-            up_ready = in_n;
-        }
-        return true;
-    };
-    uint32_t c_known = 0;                                      // (large files) the entries of search chunks [0, c_known) are on the host
-    auto learn_to = [&](uint32_t c_hi) -> bool {
-        c_hi = std::min(c_hi, n_chunks0);
-        if (c_hi <= c_known) return true;
-        // (a candidate's probe reads a few KB beyond its chunk)
-        if (!wait_ready(c_hi == n_chunks0 ? in_n : data_off + (uint64_t)c_hi * chunk_bytes + (64u << 10))) return false;
-        search_to(c_hi);
-        if (!d2h(entry.data() + c_known, d_entry + c_known, (uint64_t)(c_hi - c_known) * 8)) return false;
-        if (g_hook_entry.load() > 0) {                       // test hook (ss_test_hook): a wrong entry in chunk <n>
-            const uint64_t c = (uint64_t)g_hook_entry.load();
-            if (c > 0 && c >= c_known && c < c_hi) entry[c] = (data_off + c * chunk_bytes) * 8 + 12345 % (chunk_bytes * 8);
-        }
-        c_known = c_hi;
-        return true;
-    };
-    if (bgzf.empty() && !inc) {
+    if (bgzf.empty()) {
         search_to(n_chunks0);
         GB(d2h(entry.data(), d_entry, (uint64_t)n_chunks0 * 8));
     }
-    if (trace && bgzf.empty() && !inc) {
+    if (trace && bgzf.empty()) {
         unsigned tries = 0;
         hipMemcpyFromSymbol(&tries, HIP_SYMBOL(g_sync_tries), 4);
         fprintf(stderr, "[ginflate] %u chunks, %u candidate blocks decoded\n", n_chunks0, tries);
         tries = 0;
         hipMemcpyToSymbol(HIP_SYMBOL(g_sync_tries), &tries, 4);
     }
-    if (!inc) lap("sync");
-    if (!inc && g_hook_entry.load() > 0) {                   // test hook (ss_test_hook): a wrong entry (a position inside a block) in chunk <n>
+    lap("sync");
+    if (g_hook_entry.load() > 0) {                           // test hook (ss_test_hook): a wrong entry (a position inside a block) in chunk <n>
         const uint64_t c = (uint64_t)g_hook_entry.load();
         if (c > 0 && c < n_chunks0) entry[c] = (data_off + c * chunk_bytes) * 8 + 12345 % (chunk_bytes * 8);
     }
@@ -1951,6 +1883,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     // chunk of a gzip member (nothing in front of it); `last`: it ends with the member's final block, the trailer follows
     // at `trailer`.
     // `hdr`: ~0, or -- an entry INSIDE a block (subsync_kernel) -- where that block's header is.
+    struct Chunk { uint64_t start; bool fresh, last; uint64_t trailer; uint64_t hdr = ~0ull; };
     std::vector<Chunk> G;
     struct Seg { size_t gi, gj, n_ph; uint32_t slice; uint64_t hdr_bit; };
     std::vector<Seg> segs;                                   // range mode: one segment per slice of this rank, its look-ahead entries behind it
@@ -1989,8 +1922,6 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
             }
             segs.push_back(sg);
         }
-    } else if (inc) {
-        // (the chunks come as the image arrives: `extend` below)
     } else if (bgzf.empty()) {
         for (uint32_t c = 0; c < n_chunks0; c++)
             if (entry[c] != ~0ull) G.push_back(Chunk{entry[c], c == 0, false, 0});
@@ -2000,84 +1931,10 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         for (const Bgzf &m : bgzf) G.push_back(Chunk{m.data * 8, true, true, m.trailer});
         if (trace) fprintf(stderr, "[ginflate] bgzip: %zu members\n", bgzf.size());
     }
-    if (!inc) {
-        entry.clear();
-        entry.shrink_to_fit();
-    }
+    entry.clear();
+    entry.shrink_to_fit();
     uint32_t n_sub = 0;
-    // the entries INSIDE the blocks of chunks [i0, i1) of `src` (subsync_kernel): a block [its start, the next entry) of more than
-    // 2 x split_bytes is entered at equidistant places as well (at most eight pieces); the chunks and what was found -> `dst`
-    auto enter_blocks = [&](const std::vector<Chunk> &src, size_t i0, size_t i1, std::vector<Chunk> &dst) -> bool {
-        std::vector<uint64_t> b_hdr, s_from, s_lim;
-        std::vector<uint32_t> b_first, s_of;
-        for (size_t i = i0; i < i1 && split_bytes; i++) {
-            const uint64_t endb = i + 1 < src.size() ? src[i + 1].start : (in_n - 8) * 8;
-            const uint64_t len = endb - src[i].start, pieces = std::min<uint64_t>(8, len / (split_bytes * 8));
-            if (pieces < 2) continue;
-            b_hdr.push_back(src[i].start);
-            b_first.push_back((uint32_t)s_of.size());
-            for (uint64_t j = 1; j < pieces; j++) { s_from.push_back(src[i].start + len * j / pieces); s_lim.push_back(endb); s_of.push_back((uint32_t)i); }
-        }
-        const size_t ns = s_of.size(), nb = b_hdr.size();
-        b_first.push_back((uint32_t)ns);
-        std::vector<uint64_t> got(ns);
-        if (ns) {
-            uint64_t *d_sub = nullptr;                         // block headers | from | limit | entries | first (u32)
-            if (hipMallocAsync((void **)&d_sub, nb * 8 + ns * 8 * 3 + (nb + 1) * 4, st) != hipSuccess) return false;
-            uint64_t *d_bh = d_sub, *d_from = d_sub + nb, *d_lim = d_from + ns, *d_ent = d_lim + ns;
-            uint32_t *d_first = reinterpret_cast<uint32_t *>(d_ent + ns);
-            const bool ok = h2d(d_bh, b_hdr.data(), nb * 8) && h2d(d_from, s_from.data(), ns * 8) && h2d(d_lim, s_lim.data(), ns * 8) &&
-                            h2d(d_first, b_first.data(), (nb + 1) * 4);
-            if (ok) hipLaunchKernelGGL(subsync_kernel, dim3((unsigned)nb), dim3(64), 0, st, d_in, in_n - 8, d_bh, d_first, d_from, d_lim, (uint32_t)nb, d_ent);
-            const bool ok2 = ok && d2h(got.data(), d_ent, ns * 8);
-            hipFreeAsync(d_sub, st);
-            if (!ok2) return false;
-        }
-        size_t k = 0;
-        for (size_t i = i0; i < i1; i++) {
-            dst.push_back(src[i]);
-            uint64_t prev = src[i].start;
-            for (; k < ns && s_of[k] == i; k++) {
-                if (got[k] == ~0ull || got[k] <= prev || got[k] + 256 >= s_lim[k]) continue;      // (none found, or two searches met in one place)
-                Chunk sub{got[k], false, src[i].last, src[i].trailer, src[i].start};
-                dst.back().last = false;                       // the member's final block ends the LAST piece
-                dst.back().trailer = 0;
-                dst.push_back(sub);
-                prev = got[k];
-                n_sub++;
-            }
-        }
-        return true;
-    };
-    // (large files) the chunk list grows with the image: every entry below byte `byte_hi` of the file is in G when this returns
-    // (entries = raw chunks; a raw chunk goes into G, with the entries inside its block, once its successor is known)
-    std::vector<Chunk> raw;
-    size_t raw_done = 0;
-    uint32_t c_raw = 0;
-    bool all_known = false;
-    auto extend = [&](uint64_t byte_hi) -> bool {
-        const uint64_t c64 = byte_hi <= data_off ? 0 : (byte_hi - data_off + chunk_bytes - 1) / chunk_bytes;
-        const uint32_t c_want = (uint32_t)std::min<uint64_t>(n_chunks0, c64);
-        if (c_want > c_raw) {
-            if (!learn_to(c_want)) return false;
-            for (uint32_t c = c_raw; c < c_want; c++)
-                if (entry[c] != ~0ull) raw.push_back(Chunk{entry[c], c == 0, false, 0});
-            c_raw = c_want;
-        }
-        if (c_raw == n_chunks0 && !all_known) {
-            if (raw.empty()) return false;
-            raw.back().last = true;
-            raw.back().trailer = in_n - 8;
-            all_known = true;
-        }
-        const size_t lim = all_known ? raw.size() : (raw.empty() ? 0 : raw.size() - 1);
-        if (lim > raw_done) {
-            if (!enter_blocks(raw, raw_done, lim, G)) return false;
-            raw_done = lim;
-        }
-        return true;
-    };
-    if (split_bytes && !is_bgzf && !G.empty() && !inc) {
+    if (split_bytes && !is_bgzf && !G.empty()) {
         // ---- entries inside the blocks: a block [its start, the next entry) of more than 2 x split_bytes is entered at
         //      equidistant places as well (at most eight pieces; range mode: the look-ahead entries stay whole)
         std::vector<uint64_t> b_hdr, s_from, s_lim;
@@ -2146,7 +2003,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         return gj;
     };
     uint64_t need_sym = 0, need_chunks = 0;                   // the largest segment decides the scratch
-    for (size_t gi = 0, si = 0; gi < G.size() && !inc; si++) {
+    for (size_t gi = 0, si = 0; gi < G.size(); si++) {
         const size_t gj = rr ? segs[si].gj : segment_end(gi);
         const bool more = rr ? segs[si].n_ph > 0 : gj < G.size();
         const uint64_t bytes = ((more ? G[gj].start : G[gj - 1].last ? G[gj - 1].trailer * 8 : (in_n - 8) * 8) - G[gi].start) / 8;
@@ -2154,9 +2011,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         need_chunks = std::max<uint64_t>(need_chunks, gj - gi);
         gi = rr ? (si + 1 < segs.size() ? segs[si + 1].gi : G.size()) : gj;
     }
-    // (a large file: what a segment can need at most -- its segments are not known yet)
-    const uint64_t cap_chunks = inc ? ub_chunks : need_chunks + 80;
-    const uint64_t sym_elems = inc ? ub_sym : need_sym + need_sym / 4 + 64 * (4096 + 64 * ratio);      // (+ what run-over and further members add)
+    const uint64_t cap_chunks = need_chunks + 80;
+    const uint64_t sym_elems = need_sym + need_sym / 4 + 64 * (4096 + 64 * ratio);      // (+ what run-over and further members add)
     if (sym_elems * 2 > (24ull << 30)) return no("segment", (long long)(sym_elems >> 20));      // (GBs without a single block start)
     uint64_t text_cap;
     if (ahead.valid()) {
@@ -2189,7 +2045,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
     lap("buffers");
     uint64_t *d_start = A->meta, *d_stop = A->meta + cap_chunks, *d_off = A->meta + 2ull * cap_chunks, *d_cap = A->meta + 3ull * cap_chunks,
              *d_len = A->meta + 4ull * cap_chunks, *d_end = A->meta + 5ull * cap_chunks, *d_toff = A->meta + 6ull * cap_chunks, *d_hdr = A->meta + 7ull * cap_chunks;
-    const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : (n_sub || (inc && split_bytes)) ? 4u : 2u;      // (test hook: wrong entries are then handled by the host only)
+    const uint32_t max_over = getenv("SS_GZ_NO_RUNOVER") ? 0u : n_sub ? 4u : 2u;      // (test hook: wrong entries are then handled by the host only)
     struct Member { uint64_t at, len; uint32_t crc, isize; bool open; uint32_t crc0; uint64_t len0; };      // crc0, len0: range mode -- the member's part in the slices before
     std::vector<Member> members;
     uint64_t total = 0, last_end_bit = 0;
@@ -2235,19 +2091,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         return true;
     };
     size_t seg_i = 0;
-    // (large files) what must be known and on the device before a segment starts: its chunks, the entries behind them that a chunk
-    // may run over or stop at (eight at least, unless the file ends)
-    const uint64_t inc_slack = std::max<uint64_t>(64 * chunk_bytes, std::min<uint64_t>(8ull << 20, seg_bytes));
-    for (size_t gi = 0;;) {
-        if (inc) {
-            uint64_t upto = (gi < G.size() ? G[gi].start / 8 : data_off + (uint64_t)c_raw * chunk_bytes) + seg_bytes + inc_slack;
-            for (;;) {
-                if (!extend(upto)) return no("chunks of a large file");
-                if (all_known || (gi < G.size() && G.size() >= segment_end(gi) + 8)) break;
-                upto += inc_slack;
-            }
-        }
-        if (gi >= G.size()) break;
+    for (size_t gi = 0; gi < G.size();) {
         // ---- the segment's chunks [gi, gj) and up to two look-ahead entries behind them (what a chunk may run over)
         const size_t gj = rr ? segs[seg_i].gj : segment_end(gi);
         const size_t ph_end = rr ? gj + segs[seg_i].n_ph : std::min(G.size(), gj + 2);
@@ -2726,14 +2570,12 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
         if (r <= 0) break;
         got += (uint64_t)r;
     }
-    if (got != buf.size()) { close(fd); return SS_EIO; }
+    close(fd);
+    if (got != buf.size()) return SS_EIO;
     char *d = nullptr;
     uint64_t n = 0;
     void *lease = nullptr;
-    // (the descriptor goes along: a file of the large-file size -- SS_GZ_BIG_KB in the tests -- is uploaded from it in blocks)
-    const bool done = ss::gpu_gunzip(buf.data(), buf.size(), &d, &n, &lease, fd);
-    close(fd);
-    if (!done) return SS_ERANGE;
+    if (!ss::gpu_gunzip(buf.data(), buf.size(), &d, &n, &lease, -1)) return SS_ERANGE;
     char *h = (char *)malloc(std::max<uint64_t>(n, 1));
     if (!h) { ss::gpu_gunzip_done(lease); return SS_ENOMEM; }
     const hipError_t e = n ? hipMemcpy(h, d, n, hipMemcpyDeviceToHost) : hipSuccess;
