@@ -990,8 +990,10 @@ def main(argv=None):
         parts_med = np.median(np.array(prep_parts), axis=0)
         step_s = dt / args.steps
 
-        def with_prepare(n_scans):
-            return round(args.reads * world / (step_s + prep_ms * 1e-3 / n_scans) / 1e6, 1)
+        def with_prepare(n_scans, ms=None):
+            return round(args.reads * world / (step_s + (prep_ms if ms is None else ms) * 1e-3 / n_scans) / 1e6, 1)
+
+        kern_only = float(parts_med[[0, 2]].sum())
 
         # (the MEDIAN of five is reported, the best and all five beside it: the call allocates the new 3 GB slab and frees 0.2 GB
         #  of scratch, and on a box whose host is busy with other tenants one such driver call now and then takes 60-150 ms)
@@ -1004,6 +1006,12 @@ def main(argv=None):
                                                   "(ss_scan_reads_multi), + 2 more with -b (identify_low_depth.py:119,124)",
                                              all_clusters_single_strain=1, one_to_four_multi_strain_clusters=2, low_depth_b=3),
                        m_reads_per_s_including_prepare={"1_scan": with_prepare(1), "2_scans": with_prepare(2), "3_scans": with_prepare(3)},
+                       m_reads_per_s_including_prepare_kernels={"1_scan": with_prepare(1, kern_only), "2_scans": with_prepare(2, kern_only),
+                                                                "3_scans": with_prepare(3, kern_only)},
+                       driver_allocation_ms=round(float(parts_med[1]), 2), driver_allocation_slow=bool(parts_med[1] > 5.0),
+                       driver_note="ms is wall time: the binning's two kernels (ms_kernels) + the driver's hipMalloc of the 3 GB output slab, which takes "
+                                   "0.3 ms on most boxes and 60-150 ms on some (every call then: freshly freed device memory is handed out slowly); "
+                                   "m_reads_per_s_including_prepare uses ms, ..._kernels the kernels alone",
                        policy="always (SS_READS_ORDER=file keeps the file order): binning pays from the SECOND scan of a sample on; a "
                               "sample scanned once loses prepare.ms - (file_order.ms_per_step - ms_per_step), beside a text ingest of "
                               "~80 ms for the same reads")
