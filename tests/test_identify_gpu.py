@@ -252,3 +252,39 @@ def test_config4_low_depth_cli(shape, tmp_path, monkeypatch):
     for name in ("keys", "flags", "rows", "offs", "urows", "uoffs"):
         assert np.array_equal(getattr(cached, name), getattr(fresh, name)), name
     ssdb.clear_cache()
+
+
+@pytest.mark.parametrize("stname", list(sc.L1_STEPS))
+def test_search_step_on_the_device(stname, golden_dir, l1_dbs, l1_reads):
+    """The hand-made search() states of tests/scenarios.py L1_STEPS (the "both weak" branch, identify.py:264-273, which
+    identify_cluster itself can never take) through the DEVICE provider: the tree image, the resident reads' scan and
+    cst.ImageProvider instead of the oracle's counts -- against what the reference's search() did."""
+    from strainscan_amd import cst, db as ssdb, identify, identify_low_mem
+    with open(os.path.join(golden_dir, "l1_search_steps.json")) as f:
+        want = json.load(f)[stname]
+    sname, modname, cut, override, pend = sc.L1_STEPS[stname]
+    mod = {"identify": identify, "identify_low_mem": identify_low_mem}[modname]
+    tdb = os.path.join(l1_dbs[sc.L1_SAMPLES[sname][0]]["db_dir"], "Tree_database")
+    img = ssdb.tree_image(tdb, mod._UPPER_KEYS)
+    img.scan([l1_reads[sname][0]])
+    lines = []
+    w = cst.Walk(cst.ImageProvider(img), tdb, list(cut), mod._PARAMS, out=lambda *a: lines.append(" ".join(str(x) for x in a)))
+    for nid, (cat, acc) in override.items():
+        w.tree.get_node(nid).data[0] = cat
+        w.tree.get_node(nid).data[1] = acc
+    w.pending[:] = [[w.tree.get_node(i) for i in g] for g in pend]
+    res_temp, err = [], None
+    try:
+        w.search(res_temp)
+    except Exception as e:
+        err = type(e).__name__
+    assert err == want["error"]
+    assert [[n.identifier for n in g] for g in w.pending] == want["pending"]
+    assert [n.identifier for n in res_temp] == want["res_temp"]
+    assert [n.identifier for n in w.qualified_parents] == want["qualified_parents"]
+    assert {str(n.identifier): list(n.data) for n in w.tree.all_nodes()} == want["data"]
+    for key, got in (("length", w.length), ("cov", w.cov), ("abundance", w.abundance)):
+        got = {str(n.identifier): v for n, v in got.items()}
+        assert sorted(got) == sorted(want[key]), (stname, key)
+        for n, v in want[key].items():
+            assert abs(float(got[n]) - float(v)) <= 1e-9 * max(1.0, abs(float(v))), (stname, key, n)
