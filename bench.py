@@ -1026,7 +1026,7 @@ def main(argv=None):
                           step_breakdown_ms=dict(scan_kernel=round(k_f, 3), harvest=round(h_f, 3),
                                                  exchange=round(x_f, 3) if exchange else None, node_reduce=round(r_f, 3)))
     parity_ranks = None
-    if world > 1:
+    if world > 1 or self_group:                  # (a one-rank group, SS_BENCH_FORCE_EXCHANGE: the same collectives over RCCL)
         parity_ranks = parity_across_ranks(torch, dist, dev, args, db, nodes, db_spec, reads, stream, rank, world, ssdist)
     if rs_loc is not None:
         rs_loc.close()

@@ -889,6 +889,8 @@ def test_bench_line_contract_and_exchange_path():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][-1])
     assert d["check"]["harvest_equals_gather"] is True and d["check"]["exchanged_counts"] > 0 and d["n_gpus"] == 1
+    par1 = d["check"]["parity_across_ranks"]                    # the all-gather + oracle check of N > 1, over RCCL in a one-rank group
+    assert par1["ok"] is True and par1["ranks"] == 1 and par1["nodes_with_hits"] > 0 and par1["nodes_differing"] == []
     # `--gpus 2` without a launcher: the parent spawns two rank processes and relays rank 0's line.  On this one-GPU box
     # both ranks share the device and the group runs over gloo (SS_BENCH_SHARE_GPU); everything else is the N > 1 path:
     # per-rank reads, barrier + max-over-ranks timing, exchange of the touched nodes, whole-job reads/s.
