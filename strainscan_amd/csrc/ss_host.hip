@@ -775,12 +775,13 @@ void split_dev_free_buffers(ss_split *s)
     for (int b = 0; b < SD_NB; b++) {
         g_pinned.put(s->h_j[b], cap);
         s->h_j[b] = nullptr;
-        hipFree(s->d_j[b]);
-        s->d_j[b] = nullptr;
+        if (s->d_j[b]) hipFreeAsync(s->d_j[b], s->stream);      // (stream-ordered, from the pool: no device-wide synchronisation beside
+        s->d_j[b] = nullptr;                                    //  the other clusters being solved)
         if (s->copied[b]) hipEventDestroy(s->copied[b]);
         s->copied[b] = nullptr;
     }
-    hipFree(s->d_head); hipFree(s->d_link);
+    if (s->d_head) hipFreeAsync(s->d_head, s->stream);
+    if (s->d_link) hipFreeAsync(s->d_link, s->stream);
     s->d_head = s->d_link = nullptr;
 }
 
@@ -838,15 +839,20 @@ int ss_split_dev_start(uint64_t n, int n_splits, uint64_t n_test, uint32_t seed,
     bool ok = hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, pr_least) == hipSuccess;
     for (int b = 0; b < SD_NB && ok; b++) {
         s->h_j[b] = g_pinned.get(cap);
-        ok = s->h_j[b] && hipMalloc((void **)&s->d_j[b], s->m * 4) == hipSuccess && hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming) == hipSuccess;
+        ok = s->h_j[b] && hipMallocAsync((void **)&s->d_j[b], s->m * 4, s->stream) == hipSuccess &&
+             hipEventCreateWithFlags(&s->copied[b], hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && hipMalloc((void **)&s->d_train, n * 4) == hipSuccess && hipMalloc((void **)&s->d_head, n * 4) == hipSuccess &&
-         hipMalloc((void **)&s->d_link, s->m * 4) == hipSuccess;
+    if (ok) ss::pool_keep_at_least(2ull << 30);
+    ok = ok && hipMallocAsync((void **)&s->d_train, n * 4, s->stream) == hipSuccess && hipMallocAsync((void **)&s->d_head, n * 4, s->stream) == hipSuccess &&
+         hipMallocAsync((void **)&s->d_link, s->m * 4, s->stream) == hipSuccess;
     if (ok) ok = hipMemsetAsync(s->d_train, 0, n * 4, s->stream) == hipSuccess && hipMemsetAsync(s->d_head, 0xFF, n * 4, s->stream) == hipSuccess;
     if (!ok) {
-        split_dev_free_buffers(s);
-        hipFree(s->d_train);
-        if (s->stream) hipStreamDestroy(s->stream);
+        if (s->stream) {
+            split_dev_free_buffers(s);
+            if (s->d_train) hipFreeAsync(s->d_train, s->stream);
+            hipStreamSynchronize(s->stream);
+            hipStreamDestroy(s->stream);
+        }
         delete s;
         return SS_ENOMEM;
     }
@@ -876,8 +882,9 @@ int ss_split_dev_free(ss_split *s)
     if (!s) return SS_OK;
     s->cancel = true;
     ss_split_dev_wait(s, nullptr, nullptr);
-    hipFree(s->d_train);
-    if (s->stream) hipStreamDestroy(s->stream);
+    // (the training bits were last read on the caller's stream, by ss_l2_fold_train: freed in that stream's order)
+    if (s->d_train) hipFreeAsync(s->d_train, hipStreamPerThread);
+    if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
     delete s;
     return SS_OK;
 }
