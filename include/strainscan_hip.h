@@ -95,8 +95,13 @@ int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len);
 int ss_gz_gpu_counters(uint64_t *handled, uint64_t *declined);
 /* The device inflater keeps its scratch (symbol streams, window maps, the text buffer: ~6-12 GB, at most two sets; its
  * pinned upload buffers) for the next call, the binning of resident reads its 0.2 GB -- large allocations are slow to come
- * by on this platform; this hands all of it back. */
+ * by on this platform; this hands all of it back, and the large device blocks kept by ss_dev_big_blocks' stash. */
 int ss_gz_gpu_release(void);
+/* Device blocks of 256 MB and more that a load is done with -- the text of a large .gz, the file-order slab that binning has
+ * replaced, the slabs of a destroyed read set -- are kept (at most three, 24 GB) and handed to the next large request of this
+ * process (slabs, binned slabs, .gz texts) instead of going back to the driver, which hands fresh device memory out at
+ * ~25 GB/s (ss_host.hip ss::big_take).  out[0] = blocks kept now, out[1] = their bytes, out[2] = requests served from kept blocks. */
+int ss_dev_big_blocks(uint64_t out[3]);
 /* The pinned upload buffers of n_files (<= 2) concurrent .gz inputs, made ahead of time (~40 ms a set; a command-line process
  * calls this on its warm-up thread): a file of 32 MB or more then travels through them (8 ms instead of 12-30 per 66 MB);
  * without them only files of 256 MB or more make their own. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ss_gz_inflate_gpu": (i32, [cp, P(vp), P(u64)]),
     "ss_gz_gpu_counters": (i32, [P(u64), P(u64)]),
     "ss_gz_gpu_release": (i32, []),
+    "ss_dev_big_blocks": (i32, [P(u64)]),
     "ss_gz_set_policy": (i32, [i32]),
     "ss_gz_set_range": (i32, [i32, i32, u64, GZ_CHAIN_FN, vp]),
     "ss_gz_range_counters": (i32, [P(u64), P(u64)]),

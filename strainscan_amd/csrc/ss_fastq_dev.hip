@@ -195,7 +195,7 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, int shard_rank, int s
     FQ(hipStreamSynchronize(st));
     if (bad) return done(1);
     const uint64_t cap = ss_reads::padded(total);
-    if (hipMalloc((void **)&flat, cap) != hipSuccess) return done(SS_ENOMEM);
+    if (ss::big_malloc((void **)&flat, cap) != hipSuccess) return done(SS_ENOMEM);
     hipLaunchKernelGGL(fq_copy_kernel, dim3((unsigned)((n_rec + 15) / 16)), dim3(256), 0, st, d_text, d_ls, d_len1, d_off, n_rec, flat);
     hipLaunchKernelGGL(fq_pad_kernel, dim3(1), dim3(64), 0, st, flat, total, cap);
     FQ(hipGetLastError());

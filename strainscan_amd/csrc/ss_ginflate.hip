@@ -1358,7 +1358,8 @@ Arena *arena_take_if_fits(uint64_t cap_chunks, uint64_t sym_elems, uint64_t text
 void arena_put(Arena *a)
 {
     if (!a) return;
-    if (a->text_cap > (6ull << 30)) { hipFree(a->text); a->text = nullptr; a->text_cap = 0; }      // (not kept: the text of a very large file)
+    if (a->text_cap > (6ull << 30)) { ss::big_put(a->text, a->text_cap); a->text = nullptr; a->text_cap = 0; }      // (not kept here: the text of a very large file
+                                                                                                                      //  becomes a slab of the read set, ss::big_take)
     {
         std::lock_guard<std::mutex> g(g_arena_mu);
         if (g_arena_free.size() < 2) { g_arena_free.push_back(a); return; }
@@ -1800,7 +1801,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                 if (a->text) hipFree(a->text);
                 a->text = nullptr;
                 a->text_cap = 0;
-                if (hipMalloc((void **)&a->text, ub_text) == hipSuccess) a->text_cap = ub_text;
+                if (ss::big_malloc((void **)&a->text, ub_text) == hipSuccess) a->text_cap = ub_text;
             }
             return a;
         });
@@ -2036,7 +2037,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         if (A->text) hipFree(A->text);
         A->text = nullptr;
         A->text_cap = 0;
-        GI(hipMalloc((void **)&A->text, text_cap));
+        GI(ss::big_malloc((void **)&A->text, text_cap));
         A->text_cap = text_cap;
     } else {
         text_cap = A->text_cap;
@@ -2544,6 +2545,7 @@ extern "C" int ss_gz_gpu_release(void)
     }
     for (hipStream_t q : streams) hipStreamDestroy(q);
     ss::reorder_release();
+    ss::big_release();
     return SS_OK;
 }
 

@@ -204,6 +204,66 @@ void ss::pool_keep_at_least(uint64_t bytes)
         hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &bytes) == hipSuccess)
         now = bytes;
 }
+namespace {
+struct BigBlock { void *p; uint64_t cap; };
+std::mutex g_big_mu;
+std::vector<BigBlock> g_big;
+uint64_t g_big_served = 0;
+constexpr uint64_t BIG_MIN = 256ull << 20, BIG_TOTAL = 24ull << 30;
+constexpr size_t BIG_N = 3;
+}
+void *ss::big_take(uint64_t bytes)
+{
+    if (bytes < BIG_MIN) return nullptr;
+    std::lock_guard<std::mutex> g(g_big_mu);
+    size_t best = g_big.size();
+    for (size_t i = 0; i < g_big.size(); i++)
+        if (g_big[i].cap >= bytes && g_big[i].cap <= bytes / 2 * 5 && (best == g_big.size() || g_big[i].cap < g_big[best].cap)) best = i;
+    if (best == g_big.size()) return nullptr;
+    void *p = g_big[best].p;
+    g_big.erase(g_big.begin() + (long)best);
+    g_big_served++;
+    return p;
+}
+void ss::big_put(void *p, uint64_t cap)
+{
+    if (!p) return;
+    if (cap >= BIG_MIN) {
+        std::lock_guard<std::mutex> g(g_big_mu);
+        uint64_t held = 0;
+        for (const auto &b : g_big) held += b.cap;
+        if (g_big.size() < BIG_N && held + cap <= BIG_TOTAL) { g_big.push_back({p, cap}); return; }
+    }
+    hipFree(p);
+}
+void ss::big_release()
+{
+    std::vector<BigBlock> all;
+    {
+        std::lock_guard<std::mutex> g(g_big_mu);
+        all.swap(g_big);
+    }
+    for (const auto &b : all) hipFree(b.p);
+}
+hipError_t ss::big_malloc(void **p, uint64_t bytes)
+{
+    if ((*p = big_take(bytes)) != nullptr) return hipSuccess;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        big_release();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+extern "C" int ss_dev_big_blocks(uint64_t out[3])
+{
+    if (!out) return SS_EINVAL;
+    std::lock_guard<std::mutex> g(g_big_mu);
+    out[0] = g_big.size(); out[1] = 0; out[2] = g_big_served;
+    for (const auto &b : g_big) out[1] += b.cap;
+    return SS_OK;
+}
 hipError_t ss::l2s::dmalloc(void **p, size_t n)
 {
     static std::once_flag once;

@@ -825,7 +825,7 @@ int ss_reads_read_back(const ss_reads *R, char *host, uint64_t cap, uint64_t *le
 int ss_reads_destroy(ss_reads *R)
 {
     if (!R) return SS_OK;
-    for (auto &sl : R->slabs) hipFree(sl.d);
+    for (auto &sl : R->slabs) ss::big_put(sl.d, sl.cap);      // (the large ones are kept for the next sample of this process)
     delete R;
     return SS_OK;
 }

@@ -556,7 +556,7 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     lap("count + prefix");
     const auto t_counted = std::chrono::steady_clock::now();
     const uint64_t cap = std::max<uint64_t>((total + 15) & ~15ull, 16);
-    SS_R(hipMalloc((void **)&d_new, cap));
+    SS_R(ss::big_malloc((void **)&d_new, cap));
     const auto t_alloc = std::chrono::steady_clock::now();
     lap("new slab");
     hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), pad2, 0, src, n, d_hist, d_cnt, d_tab, d_new);
@@ -628,7 +628,7 @@ int reads_order_for_locality(ss_reads *R, bool force)
             uint64_t used = 0, cap = 0;
             const int rc = order_flat_dev(sl.d, sl.used, &d, &used, &cap);
             if (rc) return rc;
-            hipFree(sl.d);
+            ss::big_put(sl.d, sl.cap);                    // (kept for the next slab's binned copy)
             sl.d = d; sl.used = used; sl.cap = cap; sl.binned = true;
         }
         bytes += sl.cap;

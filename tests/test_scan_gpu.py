@@ -1315,3 +1315,51 @@ def test_scan_reads_multi_equals_single_scans(L):
             for db in dbs + [small]:
                 db.close()
         rs.close()
+
+
+def test_large_device_blocks_are_kept_for_the_next_request(L):
+    """ss_dev_big_blocks (ss_host.hip ss::big_take / big_put): the slab of a destroyed read set of 256 MB and more stays with
+    the process and becomes the next large request's memory (a fresh process is handed device memory at ~25 GB/s); a file-order
+    set loaded into a kept block and a binned set placed in one count like the scan of the caller's block; small blocks go
+    straight back; ss_gz_gpu_release returns what is kept."""
+    import ctypes as C
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+
+    def kept():
+        out = (C.c_uint64 * 3)()
+        L.check(L.lib().ss_dev_big_blocks(out), "ss_dev_big_blocks")
+        return int(out[0]), int(out[1]), int(out[2])
+
+    assert L.lib().ss_gz_gpu_release() == 0
+    assert kept()[:2] == (0, 0)
+    spec = bench.make_db(torch, dev, 23, seed=78, lo_sites=2000, hi_sites=9000, hit_frac=0.05)
+    n_reads = 1_900_000                                         # 287 MB of records: above the 256 MB that are kept
+    reads = bench.make_reads(torch, dev, spec, n_reads, seed=6, hit_frac=0.05)
+    assert reads.numel() >= 256 << 20
+    db = L.KmerDB(spec["keys"], np.ones(spec["keys"].size, np.uint8), 31, True)
+    db.scan_flat_dev(reads.data_ptr(), reads.numel())
+    L.check(L.lib().ss_device_sync(), "sync")
+    want = db.counts_rows()
+    assert want.sum() > 0
+    served0 = kept()[2]
+    small = L.ReadSet.from_flat_dev(reads.data_ptr(), 151 * 10000, order=True)
+    small.close()
+    assert kept()[:2] == (0, 0)                                 # 1.5 MB: back to the driver
+    for order in (True, False, True):
+        before = kept()
+        rs = L.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=order)
+        after = kept()
+        if before[0]:
+            assert after[0] == before[0] - 1 and after[2] == before[2] + 1, (order, before, after)      # the kept block was used
+        db.reset()
+        rs.scan_into(db)
+        L.check(L.lib().ss_device_sync(), "sync")
+        assert np.array_equal(db.counts_rows(), want), order
+        rs.close()
+        n, held, _ = kept()
+        assert n == 1 and held >= reads.numel(), (order, n, held)
+    assert kept()[2] == served0 + 2
+    assert L.lib().ss_gz_gpu_release() == 0
+    assert kept()[:2] == (0, 0)
