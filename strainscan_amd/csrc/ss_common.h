@@ -115,7 +115,7 @@ struct ss_db {
 #include <mutex>
 
 // A sample's reads resident in HBM (ss_ingest.hip loads them, ss_reorder.hip orders them for locality).
-namespace ss { hipError_t big_malloc(void **p, uint64_t bytes); void big_put(void *p, uint64_t cap); }      // (below)
+namespace ss { hipError_t big_malloc(void **p, uint64_t bytes, uint64_t *got = nullptr); void big_put(void *p, uint64_t cap); }      // (below)
 struct ss_reads {
     // Blocks live back to back in a few large device slabs; every block is followed by at least one '\n'
     // and padded with '\n' to a multiple of 16 bytes, so a slab is itself one flat base block: one scan
@@ -151,7 +151,7 @@ struct ss_reads {
             Slab sl;
             sl.cap = std::max<uint64_t>(need, slabs.empty() ? std::max<uint64_t>(first_slab, 64ull << 20) : 512ull << 20);
             const auto t0 = std::chrono::steady_clock::now();
-            if (ss::big_malloc((void **)&sl.d, sl.cap) != hipSuccess) return nullptr;
+            if (ss::big_malloc((void **)&sl.d, sl.cap, &sl.cap) != hipSuccess) return nullptr;
             if (getenv("SS_INGEST_TRACE"))
                 fprintf(stderr, "[ingest] slab of %.0f MB: %.4f s\n", sl.cap / 1e6,
                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -251,10 +251,10 @@ inline hipError_t sync() { return hipStreamSynchronize(stream()); }
 // ~25 GB/s and a 50 M-read .gz pair asked for ~47 GB of it, a third of that for blocks that replace each other (ss_host.hip).
 // big_take: a kept block of at least `bytes` (and at most 2.5 x), or nullptr; the caller owns it and gives it back with
 // big_put or hipFree.  big_put keeps blocks of 256 MB and more, at most three and 24 GB, and frees what it does not keep.
-void *big_take(uint64_t bytes);
+void *big_take(uint64_t bytes, uint64_t *cap = nullptr);      // *cap: what the block really holds (the caller keeps that, for the next big_put)
 void big_put(void *p, uint64_t cap);
 void big_release();                                      // everything kept goes back to the driver (ss_gz_gpu_release)
-hipError_t big_malloc(void **p, uint64_t bytes);         // big_take, else hipMalloc (which, failing, is tried again after big_release)
+hipError_t big_malloc(void **p, uint64_t bytes, uint64_t *got);      // big_take, else hipMalloc (which, failing, is tried again after big_release); *got >= bytes
 // a whole file into device memory through the pinned upload buffers of the .gz path (ss_ginflate.hip)
 bool upload_file_to_device(int fd, uint64_t n, uint8_t *d_dst);
 // ss_scan_flat_dev for a block whose records ss_reorder.hip has binned by locus (the scan may add hits up in LDS first)

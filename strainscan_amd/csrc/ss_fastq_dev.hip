@@ -195,7 +195,8 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, int shard_rank, int s
     FQ(hipStreamSynchronize(st));
     if (bad) return done(1);
     const uint64_t cap = ss_reads::padded(total);
-    if (ss::big_malloc((void **)&flat, cap) != hipSuccess) return done(SS_ENOMEM);
+    uint64_t real_cap = cap;                             // (a kept block may be larger)
+    if (ss::big_malloc((void **)&flat, cap, &real_cap) != hipSuccess) return done(SS_ENOMEM);
     hipLaunchKernelGGL(fq_copy_kernel, dim3((unsigned)((n_rec + 15) / 16)), dim3(256), 0, st, d_text, d_ls, d_len1, d_off, n_rec, flat);
     hipLaunchKernelGGL(fq_pad_kernel, dim3(1), dim3(64), 0, st, flat, total, cap);
     FQ(hipGetLastError());
@@ -203,7 +204,7 @@ int fastq_text_to_flat_dev(const char *d_text, uint64_t n, int shard_rank, int s
 #undef FQ
     *d_flat = flat;
     *flat_len = total;
-    *flat_cap = cap;
+    *flat_cap = real_cap;
     // this rank's records: the blocks b = rank, rank + world, ... of SHARD_RECORDS records (the last one may be short)
     uint64_t own = 0;
     const uint64_t blk = 1ull << SHARD_LOG2, n_blk = (n_rec + blk - 1) / blk;

@@ -1801,7 +1801,8 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
                 if (a->text) hipFree(a->text);
                 a->text = nullptr;
                 a->text_cap = 0;
-                if (ss::big_malloc((void **)&a->text, ub_text) == hipSuccess) a->text_cap = ub_text;
+                uint64_t got = ub_text;
+                if (ss::big_malloc((void **)&a->text, ub_text, &got) == hipSuccess) a->text_cap = got;
             }
             return a;
         });
@@ -2037,7 +2038,7 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         if (A->text) hipFree(A->text);
         A->text = nullptr;
         A->text_cap = 0;
-        GI(ss::big_malloc((void **)&A->text, text_cap));
+        GI(ss::big_malloc((void **)&A->text, text_cap, &text_cap));
         A->text_cap = text_cap;
     } else {
         text_cap = A->text_cap;

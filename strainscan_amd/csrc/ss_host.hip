@@ -212,7 +212,7 @@ uint64_t g_big_served = 0;
 constexpr uint64_t BIG_MIN = 256ull << 20, BIG_TOTAL = 24ull << 30;
 constexpr size_t BIG_N = 3;
 }
-void *ss::big_take(uint64_t bytes)
+void *ss::big_take(uint64_t bytes, uint64_t *cap)
 {
     if (bytes < BIG_MIN) return nullptr;
     std::lock_guard<std::mutex> g(g_big_mu);
@@ -221,6 +221,7 @@ void *ss::big_take(uint64_t bytes)
         if (g_big[i].cap >= bytes && g_big[i].cap <= bytes / 2 * 5 && (best == g_big.size() || g_big[i].cap < g_big[best].cap)) best = i;
     if (best == g_big.size()) return nullptr;
     void *p = g_big[best].p;
+    if (cap) *cap = g_big[best].cap;
     g_big.erase(g_big.begin() + (long)best);
     g_big_served++;
     return p;
@@ -245,9 +246,10 @@ void ss::big_release()
     }
     for (const auto &b : all) hipFree(b.p);
 }
-hipError_t ss::big_malloc(void **p, uint64_t bytes)
+hipError_t ss::big_malloc(void **p, uint64_t bytes, uint64_t *got)
 {
-    if ((*p = big_take(bytes)) != nullptr) return hipSuccess;
+    if (got) *got = bytes;
+    if ((*p = big_take(bytes, got)) != nullptr) return hipSuccess;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();

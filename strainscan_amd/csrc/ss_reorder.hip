@@ -556,7 +556,8 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     lap("count + prefix");
     const auto t_counted = std::chrono::steady_clock::now();
     const uint64_t cap = std::max<uint64_t>((total + 15) & ~15ull, 16);
-    SS_R(ss::big_malloc((void **)&d_new, cap));
+    uint64_t real_cap = cap;                             // (a kept block may be larger)
+    SS_R(ss::big_malloc((void **)&d_new, cap, &real_cap));
     const auto t_alloc = std::chrono::steady_clock::now();
     lap("new slab");
     hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), pad2, 0, src, n, d_hist, d_cnt, d_tab, d_new);
@@ -579,7 +580,7 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
         if (!g_scr || g_scr_cap < scr_cap) { std::swap(g_scr, d_scr); std::swap(g_scr_cap, scr_cap); }
     }
     if (d_scr) hipFree(d_scr);
-    *out_d = d_new; *out_used = cap; *out_cap = cap;
+    *out_d = d_new; *out_used = cap; *out_cap = real_cap;
     return SS_OK;
 }
 
