@@ -11,6 +11,7 @@ KeyError as at :88.
 from . import cst
 from . import identify as _id
 from .db import tree_image
+from .identify import del_outlier, match_node, piecewise  # noqa: F401  (identify_low_mem.py:93-127: the same three functions)
 from .tree import read_tree_structure  # noqa: F401
 
 _PARAMS = cst.Params(low_mem=True)

@@ -205,13 +205,6 @@ class ClusterImage:
             pass
 
     # -- bit vectors over the K rows ------------------------------------------------------------
-    def bits(self, mask):
-        """bool[K] -> device bit vector (W dwords, bit k%32 of word k/32)."""
-        packed = np.packbits(np.asarray(mask, bool), bitorder="little")
-        buf = np.zeros(self.W * 4, np.uint8)
-        buf[:packed.size] = packed
-        return DevBuf.from_array(buf)
-
     def ones(self):
         return DevBuf.from_array(np.full(self.W * 4, 0xFF, np.uint8))
 

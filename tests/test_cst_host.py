@@ -141,6 +141,87 @@ def test_single_cluster_tree_pkl(tmp_path):
         T.load_tree_pkl(str(p))
 
 
+def _old_treelib_pickle(parent, order, root_key=True, extra=None, protocol=2):
+    """`pickle.dumps` of a treelib <= 1.5 Tree (nodes carry _bpointer / _fpointer) with the node dict in `order`."""
+    import pickle
+    import sys
+    import types
+    mods = {n: types.ModuleType(n) for n in ("treelib", "treelib.tree", "treelib.node")}
+    NodeC = type("Node", (object,), {"__module__": "treelib.node"})
+    TreeC = type("Tree", (object,), {"__module__": "treelib.tree"})
+    mods["treelib.node"].Node = NodeC
+    mods["treelib.tree"].Tree = TreeC
+    nodes = {}
+    for i in order:
+        n = NodeC()
+        n.__dict__.update(_identifier=i, _tag=i, expanded=True, _bpointer=parent[i], _fpointer=[], data=None)
+        nodes[i] = n
+    for i in sorted(parent):
+        if parent[i] is not None and parent[i] in nodes and i in nodes:
+            nodes[parent[i]]._fpointer.append(i)
+    nodes.update(extra or {})
+    t = TreeC()
+    t.__dict__.update(_nodes=nodes, root=[i for i in parent if parent[i] is None][0] if root_key else None)
+    saved = {n: sys.modules.get(n) for n in mods}
+    sys.modules.update(mods)
+    try:
+        return pickle.dumps(t, protocol)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                del sys.modules[n]
+            else:
+                sys.modules[n] = m
+
+
+def test_tree_container_and_older_pickles(tmp_path):
+    """strainscan_amd/tree.py beside the paths the goldens take: the container's own rules (one root, unique ids, a
+    parent must exist, `Node.__lt__` on the tag as at identify.py:205) and tree.pkl files written by treelib <= 1.5
+    (_bpointer / _fpointer), with the node dict in any order; broken files are refused with a ValueError."""
+    from strainscan_amd import tree as T
+    from tests import scenarios as sc
+    t = T.Tree()
+    r = t.create_node(5)
+    a, b = t.create_node(2, parent=5), t.create_node(9, parent=5)
+    assert len(t) == 3 and t.root is r and not r.is_leaf() and a.is_leaf() and a < b and not b < a and repr(a) == "Node(2)"
+    assert t.siblings(5) == [] and t.siblings(2) == [b] and t.children(2) == [] and t.is_ancestor(5, 9) and not t.is_ancestor(2, 9)
+    assert sorted([b, a])[0] is a and t.paths_to_leaves() == [[5, 2], [5, 9]] and t.get_node(7) is None
+    with pytest.raises(ValueError):
+        t.create_node(2, parent=5)                             # treelib: DuplicatedNodeIdError
+    with pytest.raises(ValueError):
+        t.create_node(11)                                      # treelib: MultipleRootError
+    with pytest.raises(KeyError):
+        t.create_node(12, parent=40)
+    parent = sc.PARENT_T11
+    ids = sorted(parent, key=lambda i: (parent[i] is not None, i))
+    p = tmp_path / "old.pkl"
+    for order in (ids, ids[::-1], ids[3:] + ids[:3]):          # the root is not the dict's first key in two of them
+        p.write_bytes(_old_treelib_pickle(parent, order))
+        tr = T.load_tree_pkl(str(p))
+        assert tr.root.identifier == 7 and tr.all_nodes()[0].identifier == 7 and len(tr) == 11
+        assert {n.identifier: (n.parent.identifier if n.parent else None) for n in tr.all_nodes()} == parent
+        assert [c.identifier for c in tr.children(8)] == [3, 9]                     # the successor list's order
+        assert sorted(n.identifier for n in tr.leaves()) == [1, 2, 3, 4, 5, 6]
+    # no `root` attribute: the node without a parent is the root
+    p.write_bytes(_old_treelib_pickle(parent, ids, root_key=False))
+    assert T.load_tree_pkl(str(p)).root.identifier == 7
+    # a node whose parent is not in the file; an entry that is no Node
+    broken = dict(parent)
+    broken[3] = 99
+    p.write_bytes(_old_treelib_pickle(broken, ids))
+    with pytest.raises(ValueError, match="without a path to the root"):
+        T.load_tree_pkl(str(p))
+    p.write_bytes(_old_treelib_pickle(parent, ids, extra={12: "not a node"}))
+    with pytest.raises(ValueError, match="is not a treelib.Node"):
+        T.load_tree_pkl(str(p))
+    # a state given as (dict, slots) -- what a class with __slots__ and a __dict__ pickles to
+    o = T._PickledNode()
+    o.__setstate__(({"_identifier": 4}, {"_bpointer": 8}))
+    assert o.state == {"_identifier": 4, "_bpointer": 8}
+    o.__setstate__((None, {"_bpointer": 8}))
+    assert o.state == {"_bpointer": 8}
+
+
 def _run_step(spec, l1_dbs, l1_reads):
     """One Walk.search() call from the hand-made state of a tests/scenarios.py L1_STEPS entry -> what make_golden.py
     recorded from the reference's search()."""

@@ -47,12 +47,94 @@ def test_identify_cluster(sname, golden, l1_dbs, l1_reads):
             hl.assert_result_equal(res, run["result"], tag)
         got_tr = hl.parse_trace(text)
         assert [g[0] for g in got_tr] == [w[0] for w in run["trace"]], tag
+        for g, w in zip(got_tr, run["trace"]):               # abundance | coverage, valid length of every visited node: the device's
+            assert len(g) == len(w), (tag, g, w)             # per-node statistics as the reference printed them (%f)
+            if len(w) == 4:
+                assert abs(g[1] - w[1]) < 2e-6 and abs(g[2] - w[2]) < 2e-6 and g[3] == w[3], (tag, g, w)
     res, err, _ = _run(identify_low_depth.identify_ranks, (fq, ""), tdb)
     want = golden[sname]["ranks"]
     assert err == want["error"]
     assert [a for a, _ in res] == [a for a, _ in want["result"]]
     for (a, b), (_, wb) in zip(res, want["result"]):
         assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+
+
+@pytest.mark.parametrize("modname", ["identify", "identify_low_mem"])
+@pytest.mark.parametrize("sname", ["A_mix3", "B_mix"])
+def test_reference_helpers_under_their_own_names(modname, sname, golden, l1_dbs, l1_reads):
+    """What a caller of the reference's modules finds besides identify_cluster (identify.py:73-136 and :45-70,
+    identify_low_mem.py:67-127): jellyfish_count -> match_results (here a read-only view over the device's counts: the
+    mapping protocol of the dict it replaces, zero counts included, rows with a non-ACGT k-mer absent), match_node,
+    del_outlier, piecewise, get_node_label.  Against the real jellyfish's counts (sha256 in the golden file) and against
+    the per-node lines the reference printed while it searched: a node that is not a reconstructed one prints
+    piecewise(match_node(...)) with abundances below the cutoff set to 0 (identify.py:297-314)."""
+    import importlib
+    from strainscan_amd import identify
+    from strainscan_amd.tree import read_tree_structure
+    from tests import synth
+    mod = importlib.import_module("strainscan_amd." + modname)
+    dbn = sc.L1_SAMPLES[sname][0]
+    info = l1_dbs[dbn]
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    fq = l1_reads[sname][0]
+    mr = mod.jellyfish_count((fq, ""), tdb)
+    g = golden[sname]
+    if modname == "identify":                                  # (the golden counts are identify.py's: upper-cased keys)
+        cnt = np.zeros(info["n_rows"], np.uint32)
+        for k_, v_ in mr.items():
+            cnt[k_] = v_
+        assert synth.sha256_of(cnt.tobytes()) == g["counts_sha256"]
+        assert len(mr) == g["n_valid"] and int(cnt.sum()) == g["counts_sum"]
+    keys = list(mr)
+    assert len(keys) == len(mr) == len(mr.keys()) and all(k in mr for k in keys[:50])
+    assert -1 not in mr and info["n_rows"] not in mr and mr.get(info["n_rows"], "none") == "none"
+    missing = sorted(set(range(info["n_rows"])) - set(keys))
+    if missing:                                                # an N row of kmer.fa is no key (identify.py:93-95)
+        with pytest.raises(KeyError):
+            mr[missing[0]]
+        assert mr.get(missing[0]) is None
+    assert mr.get(keys[0]) == mr[keys[0]] and dict(zip(keys[:20], [mr[k] for k in keys[:20]])) == dict(list(mr.items())[:20])
+    # the same string form of the input as the reference's callers use (StrainScan.py:182: a tuple; identify.py:75-76 joins it)
+    assert identify._paths("a.fq  b.fq") == ["a.fq", "b.fq"] and identify._paths(("a.fq", "")) == ["a.fq"]
+    tree, _ = read_tree_structure(tdb)
+    for n in tree.all_nodes():
+        n.data = [-1] * 5                                       # identify.py:406-407
+    mod.get_node_label(tdb, tree)
+    with open(os.path.join(tdb, "node_length.txt")) as f:
+        flen = {int(a): int(b) for a, b in (ln.split() for ln in f if ln.strip())}
+    weak, strong = (500, 1500) if modname == "identify_low_mem" else (1000, 3000)
+    leaves = {n.identifier for n in tree.leaves()}
+    for n in tree.all_nodes():
+        lab, ln = n.data[0], flen[n.identifier]
+        if isinstance(lab, str):
+            assert lab == ("o1" if ln < strong else "o2")
+        elif ln < weak:
+            assert lab == (1 if (modname == "identify" and n.identifier in leaves) else 0), (n.identifier, lab, ln)
+        else:
+            assert lab == (1 if ln < strong else 2)
+    checked = 0
+    for run in g["runs"]:
+        if run["module"] != modname or run["error"] is not None:
+            continue
+        cov_cut, _, ab_cut = run["cutoff"]
+        for w in run["trace"]:
+            lab = tree.get_node(w[0]).data[0]
+            if len(w) != 4 or isinstance(lab, str) or lab == 0:
+                continue
+            length, prof = mod.match_node(mr, tdb, w[0], set(keys))
+            assert length == w[3], (w, length)
+            if length == 0:
+                continue
+            cov = len(prof) / length
+            ab = mod.piecewise(cov_cut, cov, lab, prof)
+            ab = 0 if ab < ab_cut else ab
+            assert abs(cov - w[2]) < 2e-6 and abs(ab - w[1]) < 2e-6, (run["cutoff"], w, cov, ab)
+            checked += 1
+    assert checked >= 3
+    # del_outlier: values at or above 100 x the median go (identify.py:106-112); a median of x.5 compares as a float
+    assert mod.del_outlier([1, 1, 2, 2, 150]) == [1, 1, 2, 2, 150]          # median 2: cutoff 200
+    assert mod.del_outlier([1, 1, 1, 2, 100, 250]) == [1, 1, 1, 2, 100]     # median 1.5: cutoff 150
+    assert mod.del_outlier([1, 1, 100]) == [1, 1]                           # at the cutoff: dropped
 
 
 def test_gz_and_pair_inputs(l1_dbs, l1_reads, tmp_path):
@@ -138,6 +220,31 @@ def test_identify_cluster_from_files_cold_and_cached(tmp_path, monkeypatch):
     assert dict(second) == dict(first)
     assert np.array_equal(ssdb.tree_image(tdir, True).counts, counts_first)
     ssdb.clear_cache()
+    # damaged cache files are ignored, the image is built from the database again (and the files written again): another
+    # magic, a cut file, a header whose sizes do not add up -- for the tree arrays; a cut file and a flipped header field for the index image
+    cdir = tmp_path / "cache"
+    for damage in ("magic", "cut", "header", "index_cut", "index_header"):
+        ssdb.wait_cache_writes()
+        name = [f for f in sorted(os.listdir(cdir)) if f.startswith("index" if damage.startswith("index") else "tree_")][0]
+        raw = (cdir / name).read_bytes()
+        if damage == "magic":
+            bad = b"NOTATREE" + raw[8:]
+        elif damage in ("cut", "index_cut"):
+            bad = raw[: len(raw) * 2 // 3]
+        elif damage == "header":
+            bad = raw[:24] + (int.from_bytes(raw[24:32], "little") + 1).to_bytes(8, "little") + raw[32:]      # n_total + 1
+        else:
+            bad = raw[:16] + bytes(b ^ 0x5A for b in raw[16:24]) + raw[24:]
+        (cdir / name).write_bytes(bad)
+        if damage in ("magic", "cut", "header"):
+            with pytest.raises(ValueError, match={"magic": "not a tree cache", "cut": "truncated", "header": "inconsistent"}[damage]):
+                ssdb._read_tree_cache(str(cdir / name))
+        ssdb.clear_cache()
+        again = identify.identify_cluster((fq[0], fq[1]), tdir, [0.1, 0.4, 1])
+        assert dict(again) == dict(first), damage
+        assert np.array_equal(ssdb.tree_image(tdir, True).counts, counts_first), damage
+        ssdb.wait_cache_writes()
+        ssdb.clear_cache()
     # the same sample as a .fastq.gz pair: inflated and reduced to its sequence lines on the device (the default), and with
     # the host inflaters: same result, same counts
     import ctypes as C

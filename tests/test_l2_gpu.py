@@ -645,6 +645,10 @@ def test_damaged_csr_files_raise_value_error(tmp_path):
                              ("ptr_not_from_0", X.indptr + 1, np.append(X.indices, 0), np.append(X.data, 1))):
         with pytest.raises(ValueError):
             m._load_npz_csr(save(name + ".npz", ip, ix, dt, X.shape))
+    with pytest.raises(ValueError, match="one-dimensional integers"):
+        m._load_npz_csr(save("float_ptr.npz", X.indptr.astype(np.float64), X.indices, X.data, X.shape))
+    with pytest.raises(ValueError, match="one-dimensional integers"):
+        m._load_npz_csr(save("two_d.npz", X.indptr, X.indices.reshape(1, -1), X.data, X.shape))
     dec = X.indptr.copy()
     dec[100] = dec[101] + 2
     assert np.any(np.diff(dec) < 0)
@@ -665,6 +669,86 @@ def test_damaged_csr_files_raise_value_error(tmp_path):
     assert img.om_cols is None
     img.set_overlap(m._CSR(O.indptr, O.indices, O.data, O.shape))
     img.close()
+
+
+def test_cluster_image_refuses_what_does_not_fit():
+    """strainscan_amd/l2.py's own checks, each the counterpart of something numpy / scipy would have raised in the reference's
+    dense arithmetic: a k-mer x strain matrix with an entry that is not 1, arrays that do not have the shape's sizes, an overlap
+    matrix or a count vector of another cluster, counts beyond uint32 (the reference's int64 y times an int8 matrix has no such
+    bound: refused loudly, never wrapped), planes of the wrong size; a sparse matrix that is not CSR yet is converted."""
+    import scipy.sparse as sp
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    from strainscan_amd import l2
+    rs = np.random.RandomState(5)
+    K, S = 3000, 5
+    Xd = (rs.random_sample((K, S)) < 0.4).astype(np.int8)
+    X = sp.csr_matrix(Xd)
+    twos = Xd.copy()
+    twos[17, 2] = 2
+    with pytest.raises(ValueError, match="must be binary"):
+        l2.ClusterImage(sp.csr_matrix(twos))
+
+    class Raw:                                                    # CSR arrays from somewhere else than _load_npz_csr (which checks them itself)
+        def __init__(self, indptr, indices, data, shape):
+            self.indptr, self.indices, self.data, self.shape, self.nnz = indptr, indices, data, shape, len(indices)
+
+        def tocsr(self):
+            return self
+
+    with pytest.raises(ValueError, match="do not match the shape"):
+        l2.ClusterImage(Raw(X.indptr[:-3], X.indices, X.data, X.shape))
+    with pytest.raises(ValueError, match="do not match the shape"):
+        l2.ClusterImage(Raw(X.indptr, X.indices[:-2], X.data[:-2], X.shape))
+    with pytest.raises(ValueError, match="CSR shape"):
+        m._CSR(X.indptr, X.indices, X.data, (K,))
+    with pytest.raises(ValueError, match="CSR shape"):
+        m._CSR(X.indptr, X.indices, X.data, (K, -1))
+    img = l2.ClusterImage(sp.coo_matrix(Xd))                      # (converted: all_strains_re.npz is CSR, but any scipy matrix will do)
+    planes = img.planes()
+    assert np.array_equal(planes, l2.ClusterImage(X).planes())
+    with pytest.raises(ValueError, match="plane array"):
+        l2.ClusterImage.from_planes(planes[:-1], K, S)
+    again = l2.ClusterImage.from_planes(planes, K, S)
+    assert np.array_equal(again.planes(), planes)
+    again.close()
+    Od = (rs.random_sample((K, 3)) < 0.3).astype(np.int8)
+    y = rs.randint(0, 50, K).astype(np.int64)
+    with pytest.raises(RuntimeError, match="before set_overlap"):
+        img.prepare(y, [0], 0, 1e9, 1e9)
+    with pytest.raises(ValueError, match="overlap matrix has"):
+        img.set_overlap(sp.csr_matrix(Od[:-1]))
+    O = sp.csr_matrix(Od)
+    with pytest.raises(ValueError, match="do not match the shape"):
+        img.set_overlap(Raw(O.indptr, O.indices, O.data[:-1], O.shape))
+    assert img.om_cols is None
+    img.set_overlap(sp.coo_matrix(Od))                            # not CSR yet: converted
+    assert img.om_cols == 3
+    with pytest.raises(ValueError, match="y has"):
+        img.prepare(y[:-1], [0], 0, 1e9, 1e9)
+    with pytest.raises(IndexError):
+        img.prepare(y, [3], 0, 1e9, 1e9)
+    with pytest.raises(IndexError):
+        img.prepare(y, [-4], 0, 1e9, 1e9)
+    big = y.copy()
+    big[K - 1] = 1 << 32
+    with pytest.raises(OverflowError):
+        img.prepare(big, [0], 0, 1e9, 1e9)
+    with pytest.raises(OverflowError):
+        img.u32(big)
+    with pytest.raises(OverflowError):
+        img.u32(-y - 1)
+    v = img.prepare(y, [-1, 0], 0, 1e9, 1e9)                      # a negative column counts from the end, as overlap.A[:, cols] does
+    ln = Od[:, [2, 0]].sum(1)
+    ln[ln > 1] = 0
+    assert v.use_u == bool((y * ln).sum() > 0)
+    v.close()
+    img.close()
+    # sklearn's _alpha_grid when X'y is all zeros: fifty times the resolution of a double (linear_model/_coordinate_descent.py:
+    # "if alpha_max <= np.finfo(float).resolution"), not a log-space from zero
+    g = l2.alpha_grid(np.zeros(4), 1000)
+    assert g.shape == (50,) and np.all(g == np.finfo(float).resolution)
+    g = l2.alpha_grid(np.array([0.0, 250.0, -500.0]), 1000)
+    assert g.shape == (50,) and g[0] == pytest.approx(1.0) and g[-1] == pytest.approx(1e-3) and np.all(np.diff(g) < 0)
 
 
 # Statements of the two layer-2 mirrors that no scenario has to reach, each with its reason (fragments of the line text).
