@@ -1996,6 +1996,17 @@ static bool gpu_gunzip_impl(const uint8_t *in, uint64_t in_n, char **text_dev, u
         lap("sub-entries");
     }
 
+    // What a wave decodes alone is the stretch from its entry to the next.  Entries are dynamic blocks' starts (and places inside
+    // them): zlib, pigz and libdeflate begin one every 16-300 KB, but a stream of stored or fixed-Huffman blocks only (level 0,
+    // Z_FIXED, some hardware compressors) has none, and ONE wave would then decode the whole file -- minutes of a kernel that looks
+    // like a hang.  Such a file goes to the host inflaters, which read it at memory speed.
+    if (!rr && !is_bgzf) {
+        constexpr uint64_t LONELY_BYTES = 8ull << 20;
+        uint64_t longest = 0;
+        for (size_t i = 0; i < G.size(); i++)
+            longest = std::max(longest, ((i + 1 < G.size() ? G[i + 1].start : (in_n - 8) * 8) - G[i].start) / 8);
+        if (longest > LONELY_BYTES) return no("a stretch of deflate data without a dynamic block's start (MB)", (long long)(longest >> 20));
+    }
     // The chunks are inflated SEGMENT by segment (seg_bytes of deflate data, 128 MB): the scratch stays a few GB whatever
     // the file's size, and the text of one segment is complete -- bytes -- before the next one starts, so the 32 KB in
     // front of a segment's first chunk are simply the end of the text so far.

@@ -7,6 +7,7 @@ expands beyond its symbol budget) is DECLINED with SS_ERANGE, never answered wro
 with SS_GZ_GPU=1 counts exactly like the plain text."""
 import ctypes as C
 import gzip
+import time
 import os
 import zlib
 
@@ -167,6 +168,47 @@ def test_declines_instead_of_answering_wrongly(L, tmp_path, fastq_text):
         assert rc == SS_ERANGE, name
         declined += 1
     assert _counters(L)[1] == d0 + declined
+
+
+def test_streams_without_dynamic_blocks_go_to_the_host(L, tmp_path, fastq_text):
+    """The device inflater enters a stream at the starts of DYNAMIC blocks (and at places inside them).  A member made of stored
+    blocks only (level 0) has none: one wave would copy all of it alone -- a stretch of more than 8 MB without an entry is declined
+    (SS_ERANGE) at the entry list and the host inflaters take the file.  A member of fixed-Huffman blocks only (Z_FIXED) has no
+    dynamic block either, but it is entered INSIDE its first block (all its blocks share the fixed tables, so the places found
+    there are items' first bits): either the exact text or a decline, and quickly."""
+    import zlib
+    txt = fastq_text * ((48 << 20) // len(fastq_text) + 1)      # whole records, ~50 MB (the window is 32 KB: a repeat 12 MB back is no match)
+
+    def member(data, level, strategy):
+        c = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+        return c.compress(data) + c.flush()
+
+    stored = member(txt, 0, zlib.Z_DEFAULT_STRATEGY)
+    fixed = member(txt, 6, zlib.Z_FIXED)
+    assert len(stored) > (40 << 20) and len(fixed) > (9 << 20)
+    _, d0 = _counters(L)
+    for name, data in (("stored", stored), ("fixed", fixed)):
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(data)
+        assert gzip.decompress(data) == txt
+        t0 = time.perf_counter()
+        rc, got = _gpu_inflate(L, p)
+        took = time.perf_counter() - t0
+        if name == "stored":
+            assert rc == SS_ERANGE and took < 5.0, (name, rc, took)      # declined at the entry list, not after a wave has worked through it
+        else:
+            assert (rc == SS_OK and got == txt) or rc == SS_ERANGE, (name, rc)
+            assert took < 20.0, (name, took)
+    assert _counters(L)[1] >= d0 + 1
+    small = member(txt[: 3 << 20], 6, zlib.Z_FIXED)
+    p = tmp_path / "fixed_small.gz"
+    p.write_bytes(small)
+    rc, got = _gpu_inflate(L, p)
+    assert rc == SS_ERANGE or got == txt[: 3 << 20]
+    # the resident read set of such a file: the host inflaters' text, the same records
+    rs_h = L.ReadSet([str(tmp_path / "fixed.gz")])
+    assert rs_h.info()["n_records"] == txt.count(b"\n") // 4
+    rs_h.close()
 
 
 def _kmer_fa(seed, n_rows):
