@@ -27,7 +27,8 @@
 // CRC-32 and ISIZE of EVERY member match (lanes joined with `cat` are found member by member: the chunk that meets a
 // final block finds trailer and header behind it).  A wrong entry (a position inside a block that passed A) shows as the
 // chunk before it running past it and is dropped.  A bgzip file (BGZF: every member names its size) needs no search: its
-// members are the chunks.  Anything else (a chunk that expands more than 12 times, a damaged file) returns "not handled" and the caller inflates on the host
+// members are the chunks.  Anything else (a chunk that expands more than 12 times, more than 8 MB of deflate data without a dynamic
+// block's start -- stored blocks only --, a damaged file) returns "not handled" and the caller inflates on the host
 // (ss_pgz.hip, libdeflate, zlib), so a wrong text cannot get through.
 #include "ss_common.h"
 
