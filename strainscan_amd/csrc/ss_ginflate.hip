@@ -793,13 +793,14 @@ __global__ __launch_bounds__(64) void sync_kernel(const uint8_t *in, uint64_t in
         const uint32_t w = ahead;
         ahead = word_at(p0 + 512);                          // (the input is padded by 8 KB)
         const uint64_t pl = p0 + 8ull * (uint64_t)lane;
-        uint32_t m8 = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t h = w >> j;
-            const bool t = (h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u;
-            m8 |= (t ? 1u : 0u) << j;
-        }
+        // all eight positions of the byte at once, bit j of every term = the test at position j: BFINAL = 0 and BTYPE = 2 are
+        // "bits j, j + 1 clear, bit j + 2 set"; a five-bit field (LSB first) is 30 or 31 iff its upper four bits are all set:
+        // HLIT at j + 3 .. j + 7, HDIST at j + 8 .. j + 12 (bit 19 of the word at most)
+        const uint32_t nw = ~w;
+        const uint32_t type_ok = nw & (nw >> 1) & (w >> 2);
+        const uint32_t hlit_big = (w >> 4) & (w >> 5) & (w >> 6) & (w >> 7);
+        const uint32_t hdist_big = (w >> 9) & (w >> 10) & (w >> 11) & (w >> 12);
+        uint32_t m8 = type_ok & ~hlit_big & ~hdist_big & 0xFFu;
         if (pl >= hi) m8 = 0;
         const uint32_t cnt = (uint32_t)__popc(m8);
         const uint32_t incl = wave_inclusive_sum(cnt);
