@@ -587,6 +587,26 @@ def test_documents_name_only_what_the_header_declares():
         assert not unknown, (doc, unknown)
 
 
+def test_documents_cite_only_tests_and_files_that_exist():
+    """DESIGN.md's row-by-row map of SURVEY.md 8 (and every other `test_...` the documents name) points at tests of this suite;
+    the `profiles/...` and `scripts/...` files DESIGN.md, README.md and INTEGRATION.md name are in the tree."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = set()
+    for f in glob.glob(os.path.join(root, "tests", "test_*.py")):
+        have |= set(re.findall(r"^def (test_[a-z0-9_]+)", open(f).read(), re.M))
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")):
+        text = open(os.path.join(root, doc)).read()
+        cited = set(re.findall(r"`(?:tests/test_[a-z_]+\.py::)?(test_[a-z0-9_]+)`", text))
+        missing = sorted(t for t in cited if t not in have and not os.path.exists(os.path.join(root, "tests", t + ".py")))
+        assert not missing, (doc, missing)
+        for path in set(re.findall(r"`((?:profiles|scripts|tests|oracle|include|docs)/[A-Za-z0-9_./-]+\.[a-z]{1,4})`", text)):
+            if any(ch in path for ch in "*{<") or "_ref/" in path:
+                continue
+            assert os.path.exists(os.path.join(root, path)), (doc, path)
+
+
 def test_cache_tags_and_npz_reader(tmp_path):
     """db.cache_tag: 128 bits, deterministic, different for inputs that differ in one character or only in length;
     _load_npz_csr: the arrays of scipy's save_npz file (compressed or not) without building the matrix, anything but CSR
