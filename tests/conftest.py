@@ -40,3 +40,19 @@ def l1_reads(l1_dbs, tmp_path_factory):
             f.write(reads)
         out[sname] = (p, reads)
     return out
+
+
+@pytest.fixture(scope="session")
+def mid_dbs(tmp_path_factory):
+    """The configs[0]-shaped database of tests/scenarios_mid.py (53 clusters / 157 strains / 105 nodes), with and without
+    the Memory_DB marker, and its samples' FASTQ files: {"DB_M": info, "DB_Mmem": info, "reads": {name: (path, bytes)}}."""
+    from tests import scenarios_mid as sm
+    root = str(tmp_path_factory.mktemp("ss_mid"))
+    out = {"DB_M": sm.build_mid(root), "DB_Mmem": sm.build_mid(root, memory_db=True), "reads": {}}
+    for sname in sm.mid_samples(out["DB_M"]):
+        reads = sm.mid_reads(out["DB_M"], sname)
+        p = os.path.join(root, sname + ".fq")
+        with open(p, "wb") as f:
+            f.write(reads)
+        out["reads"][sname] = (p, reads)
+    return out

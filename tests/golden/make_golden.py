@@ -92,6 +92,136 @@ def run_captured(fn, *a, **kw):
     return res, err, buf.getvalue()
 
 
+def _patch_sklearn(l2mod, captured):
+    """The reference module's two sklearn names replaced by subclasses that record what the fits produced."""
+    from sklearn.linear_model import ElasticNetCV as _ENCV, ElasticNet as _EN
+
+    class CapCV(_ENCV):
+        def fit(self, X, y):
+            r = super().fit(X, y)
+            captured["alphas_"] = np.array(self.alphas_)
+            captured["mse_path_"] = np.array(self.mse_path_)
+            captured["n_rows"] = int(len(y))
+            captured["p"] = int(np.asarray(X).shape[1])
+            return r
+
+    class CapEN(_EN):
+        def fit(self, X, y):
+            r = super().fit(X, y)
+            captured["alpha"] = float(self.alpha)
+            captured["coef_"] = np.array(self.coef_)
+            captured["n_iter_"] = int(np.max(self.n_iter_))
+            return r
+
+    l2mod.ElasticNetCV = CapCV
+    l2mod.ElasticNet = CapEN
+
+
+def _reference_cli(scratch, argv, seed):
+    """The reference's own StrainScan.py (copied to scratch next to library/: it imports `library.*` relative to the
+    CWD, StrainScan.py:5-7) as a child process under this interpreter, numpy's global generator seeded first (the
+    Poisson draw of adjust_profile, identify.py:214, is unseeded).  -> (return code, stdout)."""
+    root = os.path.join(scratch, "ref")
+    if not os.path.exists(os.path.join(root, "StrainScan.py")):
+        shutil.copy(os.path.join(REF, "StrainScan.py"), root)
+    drv = ("import sys, runpy, numpy, warnings; warnings.filterwarnings('ignore'); sys.path.insert(0, %r); "
+           "numpy.random.seed(%d); sys.argv = ['StrainScan.py'] + %r; runpy.run_path('StrainScan.py', run_name='__main__')"
+           % (os.path.join(HERE, "_standin"), seed, list(argv)))
+    r = subprocess.run([sys.executable, "-c", drv], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+
+def mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth):
+    """configs[0]'s shape (53 clusters / 157 strains / 105 nodes, SE reads): layer 1 under every cutoff and both
+    modules, identify_ranks, and the reference's command line end to end (tests/scenarios_mid.py)."""
+    from tests import scenarios_mid as sm
+    infos = {"DB_M": sm.build_mid(scratch), "DB_Mmem": sm.build_mid(scratch, memory_db=True)}
+    info = infos["DB_M"]
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    l1 = {}
+    fqs = {}
+    for sname in sm.mid_samples(info):
+        reads = sm.mid_reads(info, sname)
+        fq = os.path.join(scratch, sname + ".fq")
+        open(fq, "wb").write(reads)
+        fqs[sname] = fq
+        entry = dict(sha256=synth.sha256_of(kfa, reads), n_reads=reads.count(b"\n") // 4, runs=[])
+        mr = identify.jellyfish_count((fq, ""), tdb)
+        cnt = np.zeros(info["n_rows"], np.int64)
+        for k_, v_ in mr.items():
+            cnt[k_] = v_
+        entry["counts_sha256"] = synth.sha256_of(cnt.astype(np.uint32).tobytes())
+        entry["counts_sum"] = int(cnt.sum())
+        entry["n_valid"] = len(mr)
+        for cut in sc.CUTOFFS:
+            for modname, mod in (("identify", identify), ("identify_low_mem", identify_low_mem)):
+                np.random.seed(sc.POISSON_SEED)
+                res, err, out = run_captured(mod.identify_cluster, (fq, ""), tdb, list(cut))
+                entry["runs"].append(dict(module=modname, cutoff=cut, error=err,
+                                          result=None if res is None else {int(k): dict(v) for k, v in res.items()},
+                                          trace=parse_trace(out)))
+        res, err, out = run_captured(identify_low_depth.identify_ranks, (fq, ""), tdb)
+        entry["ranks"] = dict(error=err, result=None if res is None else [[int(a), float(b)] for a, b in res])
+        l1[sname] = entry
+        print("mid L1", sname, [(r["module"], r["cutoff"][0], r["error"], sorted((r["result"] or {}).keys()))
+                                for r in entry["runs"]][:4])
+    dump_json("mid_l1.json", l1)
+
+    flow = {}
+    for name, (sname, dbn, extra) in sm.MID_FLOW.items():
+        outdir = os.path.join(scratch, "flow_" + name)
+        rc, out, errtxt = _reference_cli(scratch, ["-i", fqs[sname], "-d", infos[dbn]["db_dir"], "-o", outdir] + extra,
+                                         sc.POISSON_SEED)
+        files = {}
+        for r_, _, fs in os.walk(outdir):
+            for f_ in fs:
+                p_ = os.path.join(r_, f_)
+                files[os.path.relpath(p_, outdir)] = open(p_).read()
+        cls_line = [ln for ln in out.splitlines() if ln.startswith("defaultdict(")]
+        tb = [ln for ln in errtxt.splitlines() if re.match(r"^[A-Za-z_.]*(Error|Exception)\b", ln)]
+        flow[name] = dict(sample=sname, db=dbn, argv=extra, returncode=rc, error=(tb[-1].split(":")[0] if tb else None),
+                          cls_dict=cls_line[-1][cls_line[-1].index("{"):-1] if cls_line else None,
+                          trace=parse_trace(out), messages=[ln for ln in out.splitlines() if ln.startswith(("- ", "Warning"))],
+                          files=files)
+        print("mid flow", name, rc, flow[name]["error"], sorted(files))
+    dump_json("mid_flow.json", flow)
+
+
+def l2_big_section(scratch, l2mod, captured, synth):
+    """detect_strains on clusters of 40-56 strains x 230-300 k k-mers with 7-11 strains present."""
+    import scipy.sparse as sp
+    from tests import scenarios_mid as sm
+    big, arrays = {}, {}
+    for name in sm.L2_BIG:
+        case = sm.l2_big_case(name)
+        cd = os.path.join(scratch, "l2big_" + name)
+        os.makedirs(cd)
+        sp.save_npz(os.path.join(cd, "X.npz"), case["X"])
+        sp.save_npz(os.path.join(cd, "O.npz"), case["O"])
+        pickle.dump(case["ids"], open(os.path.join(cd, "ids.pkl"), "wb"))
+        captured.clear()
+        out, err, _ = run_captured(
+            l2mod.detect_strains, os.path.join(cd, "X.npz"), case["y"].copy(), os.path.join(cd, "ids.pkl"),
+            case["ksize"], case["npp25"], case["npp75"], case["npp_out"], case["cls_cov"],
+            os.path.join(cd, "O.npz"), case["all_cls"], case["l2"], case["msn"], case["pmode"], case["emode"])
+        ent = dict(sha256=synth.sha256_of(case["X"].indptr.tobytes(), case["X"].indices.tobytes(),
+                                          case["O"].indptr.tobytes(), case["O"].indices.tobytes(), case["y"].tobytes()),
+                   error=err, K=int(case["X"].shape[0]), S=int(case["X"].shape[1]))
+        if out is not None:
+            res, res2, scov, sval, fsrc = out
+            ent.update(res=res, res2=res2, strain_cov=scov, strain_val=sval, final_src=fsrc, order=list(scov.keys()))
+        if "alphas_" in captured:
+            ent.update(alpha=captured["alpha"], n_rows=captured["n_rows"], p=captured["p"], n_iter=captured["n_iter_"])
+            arrays[name + "_alphas"] = captured["alphas_"]
+            arrays[name + "_mse_path"] = captured["mse_path_"]
+            arrays[name + "_coef"] = captured["coef_"]
+        big[name] = ent
+        print("L2 big", name, err, ent.get("p"), ent.get("res"))
+    dump_json("l2_big.json", big)
+    np.savez_compressed(os.path.join(HERE, "l2_big_arrays.npz"), **arrays)
+
+
 def main():
     from tests import scenarios as sc
     from tests import synth
@@ -104,6 +234,16 @@ def main():
     import identify_low_depth
     import identify_strains_L2_Enet_Pscan_new_sp as l2mod
     import Vote_Strain_L2_Lasso_new_sp as vote
+
+    only = sys.argv[1] if len(sys.argv) > 1 else "all"          # all | mid (the round-6 sections alone: ~10 min)
+    if only == "mid":
+        import scipy.sparse as sp
+        captured = {}
+        _patch_sklearn(l2mod, captured)
+        mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
+        l2_big_section(scratch, l2mod, captured, synth)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
 
     # ---------------------------------------------------------------- F1: raw counts
     c = sc.f1_case()
@@ -203,28 +343,8 @@ def main():
 
     # ---------------------------------------------------------------- F4/F5: detect_strains
     import scipy.sparse as sp
-    from sklearn.linear_model import ElasticNetCV as _ENCV, ElasticNet as _EN
     captured = {}
-
-    class CapCV(_ENCV):
-        def fit(self, X, y):
-            r = super().fit(X, y)
-            captured["alphas_"] = np.array(self.alphas_)
-            captured["mse_path_"] = np.array(self.mse_path_)
-            captured["n_rows"] = int(len(y))
-            captured["p"] = int(np.asarray(X).shape[1])
-            return r
-
-    class CapEN(_EN):
-        def fit(self, X, y):
-            r = super().fit(X, y)
-            captured["alpha"] = float(self.alpha)
-            captured["coef_"] = np.array(self.coef_)
-            captured["n_iter_"] = int(np.max(self.n_iter_))
-            return r
-
-    l2mod.ElasticNetCV = CapCV
-    l2mod.ElasticNet = CapEN
+    _patch_sklearn(l2mod, captured)
     l2 = {}
     arrays = {}
     for name in sc.L2_CASES:
@@ -351,6 +471,10 @@ def main():
         batch["cases"][name] = dict(error=err, files=files)
         print("L2 batch", name, err, sorted(files))
     dump_json("l2_batch.json", batch)
+
+    # ---------------------------------------------------------------- round 6: configs[0]'s shape, whole flow + big clusters
+    mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
+    l2_big_section(scratch, l2mod, captured, synth)
 
     # ---------------------------------------------------------------- seqpy.revcomp (oracle/_ref)
     refso = os.path.join(REPO, "oracle", "_ref")
