@@ -765,7 +765,11 @@ def main(argv=None):
     self_group = world == 1 and bool(os.environ.get("SS_BENCH_FORCE_EXCHANGE") or os.environ.get("SS_BENCH_FORCE_PIPELINE"))
     if world > 1 or self_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:          # a one-rank group of its own (a launcher always sets the port): any free port,
+            import socket                            # so that two such jobs on one box do not meet
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -1034,6 +1038,17 @@ def main(argv=None):
     if rs_loc is not None:
         rs_loc.close()
         rs_loc = None
+    # what decides the END-TO-END rate of an N-GPU node (not the scan): the FASTQ parse threads each rank takes out of the CPUs
+    # the ranks share (ss_ingest_threads: min(20, usable CPUs / LOCAL_WORLD_SIZE); ~21 M reads/s of plain text per thread)
+    import ctypes
+    nthr = ctypes.c_int()
+    _lib.check(_lib.lib().ss_ingest_threads(ctypes.byref(nthr)), "ss_ingest_threads")
+    host = dict(cpus_usable=int(_lib.lib().ss_host_cpus()), local_world=int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
+                parse_threads_per_rank=[int(nthr.value)])
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, int(nthr.value))
+        host["parse_threads_per_rank"] = [int(x) for x in got]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
@@ -1131,7 +1146,7 @@ def main(argv=None):
                                read_order=("binned resident read set (what the product scans: strainscan_amd/db.py resident_reads)" if binned
                                            else "file order (flat block)"),
                                parallelism="reads sharded x%d, table replicated, all-reduce of the touched nodes' hit counts" % world),
-                   roofline=roofline, cpu_baseline=cpu, phases=phases, prepare=prepare, file_order=file_order,
+                   roofline=roofline, cpu_baseline=cpu, phases=phases, prepare=prepare, file_order=file_order, host=host,
                    cluster_scan=(config3 or {}).get("cluster_scan"), l2_solve=(config3 or {}).get("l2_solve"), cli_e2e=cli_e2e,
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),

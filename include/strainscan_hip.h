@@ -102,6 +102,10 @@ int ss_gz_gpu_release(void);
  * process (slabs, binned slabs, .gz texts) instead of going back to the driver, which hands fresh device memory out at
  * ~25 GB/s (ss_host.hip ss::big_take).  out[0] = blocks kept now, out[1] = their bytes, out[2] = requests served from kept blocks. */
 int ss_dev_big_blocks(uint64_t out[3]);
+/* A block is tagged with the device it lives on and is only ever served to a request made under that device (ss_set_device).
+ * A caller that shares the GPU with other allocators (torch, another library) and wants the kept blocks back in the driver's
+ * hands calls this: every kept block is hipFree'd.  (ss_gz_gpu_release does the same and more.) */
+int ss_dev_big_release(void);
 /* The pinned upload buffers of n_files (<= 2) concurrent .gz inputs, made ahead of time (~40 ms a set; a command-line process
  * calls this on its warm-up thread): a file of 32 MB or more then travels through them (8 ms instead of 12-30 per 66 MB);
  * without them only files of 256 MB or more make their own. */
@@ -250,6 +254,9 @@ int ss_reads_load(const char *const *paths, int n_paths, int shard_rank, int sha
 /* The one-time costs of the first ss_reads_load of a process (pinned parse buffers, streams: ~0.1 s), paid ahead of time --
  * a command-line process calls it on a worker thread while the interpreter starts up. */
 int ss_ingest_warm_up(void);
+/* FASTQ parse threads a load of this process uses: min(20, CPUs this process may use / LOCAL_WORLD_SIZE) -- the cgroup quota
+ * counts, and the ranks of one node (one process per GPU under torchrun) share it; SS_INGEST_THREADS overrides. */
+int ss_ingest_threads(int *n);
 /* A resident read set from a flat base block that is already on the device (copied; order != 0: its records are put
  * in locality order, see below). */
 int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads **out);
@@ -258,9 +265,16 @@ int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads
 int ss_reads_order_timing(double out_ms[3]);
 /* The resident flat blocks copied back to the host, slab after slab (host = NULL: only *len); for tests and debugging. */
 int ss_reads_read_back(const ss_reads *r, char *host, uint64_t cap, uint64_t *len);
+/* Lifetime: ss_scan_reads / ss_scan_reads_multi are asynchronous on the caller's stream and read the set's slabs.  Destroying
+ * a set WAITS for the device (hipDeviceSynchronize) before its slabs are given up -- the large ones are kept for the next load
+ * of this process (ss_dev_big_blocks), the rest go back to the driver -- so a scan still in flight on any stream finishes on
+ * intact bases, as it did when the slabs were hipFree'd.  The counters of the scan belong to the ss_db, not to the read set. */
 int ss_reads_destroy(ss_reads *r);
 int ss_reads_info(const ss_reads *r, uint64_t *n_records, uint64_t *n_bases, uint64_t *n_blocks,
                   uint64_t *device_bytes);
+/* Asynchronous on `stream`, with one exception: the FIRST scan of a (read set, table) pair whose table was not announced
+ * with ss_db_expect_hits probes the set's first tiles and waits for their answer (one stream synchronisation, ~40 us of
+ * kernel) before it launches the rest -- that call cannot be captured into a hipGraph; every later scan of the pair can. */
 int ss_scan_reads(ss_db *db, const ss_reads *r, void *stream);
 /* The same reads against several tables in ONE pass (the reference's loop over the identified clusters,
  * Vote_Strain_L2_Lasso_new_sp.py:295-296, re-reads the FASTQ for each, :354-372): equal to ss_scan_reads on each table;
@@ -350,7 +364,8 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
 int ss_l2_create_planes(const uint32_t *planes, uint64_t K, uint32_t S, ss_l2 **out);
 /* A cluster image file of this package (the cache strainscan_amd writes beside SS_IMAGE_CACHE: bit planes + the overlap matrix's
  * CSR arrays at the given 64-byte-aligned offsets) straight to the device: planes AND overlap in one upload through pinned
- * buffers; equivalent to ss_l2_create_planes + ss_l2_set_overlap on the same arrays, same checks.  SS_EINVAL: not such a file. */
+ * buffers; equivalent to ss_l2_create_planes + ss_l2_set_overlap on the same arrays, same checks.  SS_EINVAL: not such a file.
+ * (The handle's overlap arrays live inside that one allocation: ss_l2_set_overlap on an imported handle is SS_EINVAL.) */
 int ss_l2_import(const char *path, uint64_t K, uint32_t S, uint64_t off_planes, uint64_t off_ptr, uint64_t off_idx, uint64_t off_val,
                  uint64_t nnz, uint32_t n_cols, ss_l2 **out);
 int ss_l2_export_planes(const ss_l2 *h, uint32_t *planes);

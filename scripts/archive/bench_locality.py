@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# ARCHIVED (round 6): the SS_ORDER_BITS knob this script sweeps was removed from the library in round 5 -- the bin width is
+# chosen from the data now -- so its A/B legs all measure the same configuration.  Kept as the record of how
+# profiles/r03_locality_sweep.json was made.
 """Locality order of a resident read set (ss_reorder.hip): what it costs and what it buys, over the coverage of the sample.
 
     bench_locality.py [sampled|contiguous] [--bits 0] [--out profiles/r03_locality_sweep.json]

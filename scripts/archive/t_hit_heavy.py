@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# ARCHIVED (round 6): the SS_ORDER_BITS knob this script sweeps was removed from the library in round 5 -- the bin width is
+# chosen from the data now -- so its A/B legs all measure the same configuration.  Kept as the record of how
+# profiles/r03_locality_sweep.json was made.
 """A layer-2-like scan: a cluster table holding EVERY k-mer (both orientations) of a genome, reads of that genome at high
 coverage -- nearly every read k-mer is a table k-mer.  Scan kernel time in file order and binned (ss_reorder.hip).
     t_hit_heavy.py [genome bases = 1000000] [reads = 4000000]"""

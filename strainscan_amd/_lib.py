@@ -79,6 +79,7 @@ SIGNATURES = {
     "ss_gz_gpu_counters": (i32, [P(u64), P(u64)]),
     "ss_gz_gpu_release": (i32, []),
     "ss_dev_big_blocks": (i32, [P(u64)]),
+    "ss_dev_big_release": (i32, []),
     "ss_gz_set_policy": (i32, [i32]),
     "ss_gz_set_range": (i32, [i32, i32, u64, GZ_CHAIN_FN, vp]),
     "ss_gz_range_counters": (i32, [P(u64), P(u64)]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "ss_counts_load_rows_dev": (i32, [vp, vp, vp]),
     "ss_scan_kernel_launches": (u64, [vp]),
     "ss_ingest_warm_up": (i32, []),
+    "ss_ingest_threads": (i32, [P(i32)]),
     "ss_gz_warm_up": (i32, [i32]),
     "ss_reads_load": (i32, [P(cp), i32, i32, i32, P(vp)]),
     "ss_reads_from_flat_dev": (i32, [vp, u64, i32, P(vp)]),

@@ -63,6 +63,7 @@ inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 // A container with 16 CPUs of quota on a 256-thread host runs 64 busy threads SLOWER than 16 (CFS throttles the
 // whole group once the quota of a period is spent).
 unsigned host_cpus();
+unsigned ingest_threads();      // FASTQ parse threads of this process: its share of host_cpus() (LOCAL_WORLD_SIZE), at most 20 (ss_ingest.hip)
 
 }  // namespace ss
 

@@ -205,7 +205,7 @@ void ss::pool_keep_at_least(uint64_t bytes)
         now = bytes;
 }
 namespace {
-struct BigBlock { void *p; uint64_t cap; };
+struct BigBlock { void *p; uint64_t cap; int dev; };      // dev: the device the block lives on -- a block is only ever served there
 std::mutex g_big_mu;
 std::vector<BigBlock> g_big;
 uint64_t g_big_served = 0;
@@ -215,10 +215,12 @@ constexpr size_t BIG_N = 3;
 void *ss::big_take(uint64_t bytes, uint64_t *cap)
 {
     if (bytes < BIG_MIN) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> g(g_big_mu);
     size_t best = g_big.size();
     for (size_t i = 0; i < g_big.size(); i++)
-        if (g_big[i].cap >= bytes && g_big[i].cap <= bytes / 2 * 5 && (best == g_big.size() || g_big[i].cap < g_big[best].cap)) best = i;
+        if (g_big[i].dev == dev && g_big[i].cap >= bytes && g_big[i].cap <= bytes / 2 * 5 && (best == g_big.size() || g_big[i].cap < g_big[best].cap)) best = i;
     if (best == g_big.size()) return nullptr;
     void *p = g_big[best].p;
     if (cap) *cap = g_big[best].cap;
@@ -230,10 +232,15 @@ void ss::big_put(void *p, uint64_t cap)
 {
     if (!p) return;
     if (cap >= BIG_MIN) {
+        // The caller's contract (ss_common.h): nothing in flight still touches the block -- hipFree would have waited for the
+        // device, keeping a block does not, so the callers that cannot know (ss_reads_destroy) synchronise first.
+        hipPointerAttribute_t at;
+        int dev = -1;
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device; else (void)hipGetLastError();
         std::lock_guard<std::mutex> g(g_big_mu);
         uint64_t held = 0;
         for (const auto &b : g_big) held += b.cap;
-        if (g_big.size() < BIG_N && held + cap <= BIG_TOTAL) { g_big.push_back({p, cap}); return; }
+        if (dev >= 0 && g_big.size() < BIG_N && held + cap <= BIG_TOTAL) { g_big.push_back({p, cap, dev}); return; }
     }
     hipFree(p);
 }
@@ -266,6 +273,7 @@ extern "C" int ss_dev_big_blocks(uint64_t out[3])
     for (const auto &b : g_big) out[1] += b.cap;
     return SS_OK;
 }
+extern "C" int ss_dev_big_release(void) { ss::big_release(); return SS_OK; }
 hipError_t ss::l2s::dmalloc(void **p, size_t n)
 {
     static std::once_flag once;
@@ -800,6 +808,8 @@ struct ss_split {
     uint32_t *d_head = nullptr, *d_link = nullptr;
     double walk_ms = 0, total_ms = 0;
     int device = 0;
+    std::thread::id user;                 // the thread that took the result (ss_split_dev_wait with a pointer): its stream reads d_train
+    bool used = false;
 };
 
 namespace {
@@ -967,7 +977,7 @@ int ss_split_dev_wait(ss_split *s, const uint32_t **train_bits_dev, double *walk
     if (s->th.joinable()) s->th.join();
     if (s->stream && hipStreamSynchronize(s->stream) != hipSuccess && s->rc == SS_OK) s->rc = SS_EHIP;
     split_dev_free_buffers(s);                          // only the result stays
-    if (train_bits_dev) *train_bits_dev = s->d_train;
+    if (train_bits_dev) { *train_bits_dev = s->d_train; s->user = std::this_thread::get_id(); s->used = true; }      // (the thread whose stream will read the bits)
     if (walk_ms) *walk_ms = s->walk_ms;
     return s->rc;
 }
@@ -977,8 +987,13 @@ int ss_split_dev_free(ss_split *s)
     if (!s) return SS_OK;
     s->cancel = true;
     ss_split_dev_wait(s, nullptr, nullptr);
-    // (the training bits were last read on the caller's stream, by ss_l2_fold_train: freed in that stream's order)
-    if (s->d_train) hipFreeAsync(s->d_train, hipStreamPerThread);
+    // The training bits were last read on the per-thread stream of the thread that asked for them (ss_l2_fold_train): freed in
+    // that stream's order when this IS that thread; from any other thread (a garbage collector's) the per-thread stream is a
+    // different one and orders nothing, so the free waits for the device instead.
+    if (s->d_train) {
+        if (!s->used || s->user == std::this_thread::get_id()) hipFreeAsync(s->d_train, hipStreamPerThread);
+        else hipFree(s->d_train);
+    }
     if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
     delete s;
     return SS_OK;

@@ -112,7 +112,29 @@ unsigned host_cpus()
     }();
     return cached;
 }
+
+// Parse threads of ONE process.  Measured on the MI355X host: ~21 M reads/s per thread up to ~20 threads, falling beyond 24.
+// Several ranks on one node (torchrun sets LOCAL_WORLD_SIZE) share the node's CPUs -- and its cgroup quota, host_cpus() --
+// so each takes its share: 8 ranks on 16 CPUs of quota run 2 parse threads each, not 8 x 20 threads that the scheduler
+// throttles as a group.  SS_INGEST_THREADS overrides (per process).
+unsigned ingest_threads()
+{
+    if (const char *e = getenv("SS_INGEST_THREADS")) return (unsigned)std::max(1, atoi(e));
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());      // (one process: as measured, the quota notwithstanding --
+    if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {                   //  parse threads spend half their time in pread and copies)
+        const int w = atoi(lw);
+        if (w > 1) n = std::max(2u, host_cpus() / (unsigned)w);
+    }
+    return std::min(n, 20u);
+}
 }  // namespace ss
+
+extern "C" int ss_ingest_threads(int *n)
+{
+    if (!n) return SS_EINVAL;
+    *n = (int)ss::ingest_threads();
+    return SS_OK;
+}
 
 namespace ss {
 
@@ -505,8 +527,7 @@ int parse_text_parallel(ss_db::Worker *workers, const char *t, uint64_t n, const
     // parse threads: each owns a text buffer, a pinned buffer, a device buffer and a stream.  Measured on
     // the MI355X host (scripts/bench_e2e.py): 21 M reads/s per thread up to ~20 threads (256 M reads/s =
     // 79 GB/s of FASTQ text, 39 GB/s over PCIe), falling again beyond 24.  SS_INGEST_THREADS overrides.
-    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 20u);
-    if (const char *e = getenv("SS_INGEST_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));
+    unsigned nthreads = ss::ingest_threads();
     nthreads = std::min<unsigned>(nthreads, (unsigned)ss_db::MAX_WORKERS);
     nthreads = (unsigned)std::min<size_t>(nthreads, n_chunks);
     std::atomic<size_t> next(0);
@@ -621,8 +642,7 @@ extern "C" {
 int ss_ingest_warm_up(void)
 {
     std::lock_guard<std::mutex> pool_lock(g_read_workers_mu);
-    unsigned nthreads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 20u);
-    if (const char *e = getenv("SS_INGEST_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));
+    unsigned nthreads = ss::ingest_threads();
     nthreads = std::min<unsigned>(nthreads, (unsigned)ss_db::MAX_WORKERS);
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return SS_ENODEV;
@@ -825,7 +845,11 @@ int ss_reads_read_back(const ss_reads *R, char *host, uint64_t cap, uint64_t *le
 int ss_reads_destroy(ss_reads *R)
 {
     if (!R) return SS_OK;
-    for (auto &sl : R->slabs) ss::big_put(sl.d, sl.cap);      // (the large ones are kept for the next sample of this process)
+    // The large slabs are kept for the next sample of this process (ss::big_put) instead of going back to the driver.  hipFree
+    // waited for everything in flight on the device; keeping a block does not, and ss_scan_reads is asynchronous on the CALLER's
+    // stream, which this library cannot name -- so the wait is made here, once per read set, exactly where hipFree made it.
+    if (!R->slabs.empty()) (void)hipDeviceSynchronize();
+    for (auto &sl : R->slabs) ss::big_put(sl.d, sl.cap);
     delete R;
     return SS_OK;
 }

@@ -564,6 +564,7 @@ int ss_l2_set_overlap(ss_l2 *h, const int64_t *indptr, const int32_t *indices, c
     if (!h || !indptr || indptr[h->K] < 0) return SS_EINVAL;
     const uint64_t nnz = (uint64_t)indptr[h->K];
     if (nnz && (!indices || !data)) return SS_EINVAL;
+    if (h->d_blob) return SS_EINVAL;      // a handle from ss_l2_import: its overlap arrays live inside the image's one allocation
     hipFree(h->d_om_ptr); hipFree(h->d_om_idx); hipFree(h->d_om_val);
     h->d_om_ptr = nullptr; h->d_om_idx = nullptr; h->d_om_val = nullptr; h->has_om = false;
     SS_HIP(hipMalloc((void **)&h->d_om_ptr, (h->K + 1) * 8));

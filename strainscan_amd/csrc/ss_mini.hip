@@ -1314,6 +1314,15 @@ constexpr uint64_t PROBE_TILES = 8192;          // one wave per tile: one round 
 constexpr double PROBE_RUNS_PER_TILE = 8.0;     // measured crossover: 4 (plain wins by 15 %) ... 8-10 (even) ... 16 (COMB by 30 %)
 static std::mutex probe_mu;                     // the probe's device words are one set per process
 
+// (the probe's verdict is read and written under probe_mu: two threads may scan the same table)
+static bool probe_known(ss_db *db, uint64_t set_id, bool *comb)
+{
+    std::lock_guard<std::mutex> g(probe_mu);
+    if (db->probe_set != set_id) return false;
+    *comb = db->probe_comb != 0;
+    return true;
+}
+
 static int launch_plain_or_comb(ss_db *db, bool comb, bool probe, const uint8_t *b, uint64_t n, uint64_t n_tiles, hipStream_t stream)
 {
     const bool aligned = (((uintptr_t)b) & 15) == 0;
@@ -1342,8 +1351,11 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
     if (comb_env >= 0) comb = comb_env == 2 ? binned : (db->expect_hits && comb_env != 0);
     else if (!binned) comb = false;
     else if (db->expect_hits) comb = true;
-    else if (set_id && db->probe_set == set_id) comb = db->probe_comb != 0;
+    else if (set_id && probe_known(db, set_id, &comb)) {}
     else if (n_tiles >= 4 * PROBE_TILES) {
+        // The first scan of a (read set, table) pair makes ONE stream synchronisation here (~40 us of probe tiles, a memset and a
+        // 256-byte copy back): ss_scan_reads is asynchronous from the second scan of the pair on, and this first launch cannot
+        // be captured into a hipGraph (include/strainscan_hip.h says so at ss_scan_reads).
         std::lock_guard<std::mutex> g(probe_mu);
         uint32_t runs[64];
         void *sym = nullptr;

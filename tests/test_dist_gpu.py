@@ -3,7 +3,8 @@ own torch.distributed rank (backend gloo -- RCCL refuses two ranks on one device
 parses and scans only ITS share of the reads (ss_reads_load / ss_scan_files_shard with shard_rank, shard_world) and
 the product's collectives -- dist.exchange_touched for the tree's node statistics, dist.allreduce_table where single
 rows are needed -- must reproduce the reference's golden results (tests/golden/l1_search.json) bit for bit, as the
-single-process run does.  This is BASELINE.json configs[2]'s code path at world sizes 2 and 3."""
+single-process run does.  This is BASELINE.json configs[2]'s code path at world sizes 2, 3 and 8 (eight ranks on one
+device: the rehearsal of an 8-GPU node that was never available), plus the configs[0]-shaped 105-node database."""
 import json
 import os
 import subprocess
@@ -87,7 +88,7 @@ def _spawn(world, jobs, tmp_path):
     return [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_identify_equals_golden(world, golden_dir, l1_dbs, l1_reads, tmp_path):
     from tests import hostlogic as hl
     from oracle import oracle as orc
@@ -153,6 +154,47 @@ def test_sharded_identify_equals_golden(world, golden_dir, l1_dbs, l1_reads, tmp
     assert any_rows            # B_mix's Poisson branch asked for single rows: the full row vector was all-reduced there
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_sharded_mid_identify_equals_golden(world, golden_dir, mid_dbs, tmp_path):
+    """The configs[0]-shaped database (53 clusters / 157 strains / 105 nodes, tests/scenarios_mid.py) with the reads sharded
+    over 3 and 8 ranks: every rank ends with the reference's own result dict, visit order and identify_ranks scores
+    (tests/golden/mid_l1.json, recorded from the real reference)."""
+    from tests import hostlogic as hl
+    with open(os.path.join(golden_dir, "mid_l1.json")) as f:
+        golden = json.load(f)
+    tdb = os.path.join(mid_dbs["DB_M"]["db_dir"], "Tree_database")
+    jobs, wants = [], []
+    for sname in ("M_mix", "M_recon", "M_low2"):
+        for run in golden[sname]["runs"]:
+            if run["cutoff"] not in ([0.1, 0.4, 1], [0.05, 0.05, 1]):
+                continue
+            jobs.append(dict(module=run["module"], seed=sc.POISSON_SEED, fq=[mid_dbs["reads"][sname][0], ""], tdb=tdb, cutoff=run["cutoff"],
+                             stream=(len(jobs) % 3 == 1), ranks=(len(jobs) % 4 == 0)))
+            wants.append((sname, run))
+    outs = _spawn(world, jobs, tmp_path)
+    ev = [o.pop()["index_events"] for o in outs]
+    assert ev[0]["built"] >= 1 and all(e["built"] == 0 and e["imported"] >= 1 for e in ev[1:]), ev
+    for ji, (sname, run) in enumerate(wants):
+        recs_ = [o[ji] for o in outs]
+        for r in recs_[1:]:
+            assert r["result"] == recs_[0]["result"] and r["stats"] == recs_[0]["stats"] and r["error"] == recs_[0]["error"]
+        got = recs_[0]
+        tag = (world, sname, run["module"], run["cutoff"])
+        assert got["error"] == run["error"], (tag, got["text"][-300:])
+        hl.assert_result_equal({int(k): v for k, v in got["result"].items()}, run["result"], tag)
+        got_tr = hl.parse_trace(got["text"])
+        assert [g[0] for g in got_tr] == [w[0] for w in run["trace"]], tag
+        for a, w in zip(got_tr, run["trace"]):
+            if len(w) == 4:
+                assert abs(a[1] - w[1]) < 2e-6 and abs(a[2] - w[2]) < 2e-6 and a[3] == w[3], (tag, a, w)
+        if "ranks" in got:
+            want_r = golden[sname]["ranks"]
+            assert got["ranks"]["error"] == want_r["error"]
+            assert [a for a, _ in got["ranks"]["result"]] == [a for a, _ in want_r["result"]]
+            for (_, b), (_, wb) in zip(got["ranks"]["result"], want_r["result"]):
+                assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+
+
 GZ_WORKER = r'''
 import ctypes as C, json, os, sys
 import numpy as np
@@ -190,7 +232,8 @@ dist.destroy_process_group()
 
 @pytest.mark.parametrize("world,decline,mode", [(2, False, "range"), (3, False, "range"), (2, False, "whole"), (3, False, "members"), (2, False, "members"),
                                                   (2, True, "range"), (3, True, "range"), (2, False, "entry100"), (2, False, "entry128"), (3, False, "entry129"),
-                                                  (2, False, "bgzip"), (3, False, "bgzip"), (2, False, "gone"), (3, False, "gone")])
+                                                  (2, False, "bgzip"), (3, False, "bgzip"), (2, False, "gone"), (3, False, "gone"),
+                                                  (8, False, "range"), (8, False, "bgzip"), (8, True, "range")])
 def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     """A pair of .fastq.gz files under torch.distributed; the summed row counts equal the single-process scan of the plain
     text, the ranks' record counts add up, and the device inflater (not the host's) did the work.
@@ -254,7 +297,7 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SS_TEST_STORE=str(tmp_path / ("store_%d" % port)))
         env.pop("SS_GZ_GPU", None)
-        env["SS_GZ_SLICE_KB"] = "256"
+        env["SS_GZ_SLICE_KB"] = "256" if world < 8 else "64"      # (eight ranks: ~16 slices per file, two per rank, 8 x 2 hops of the chain)
         env["SS_GZ_CHUNK"] = "4096"          # (search chunks of 4 KB: slices of 128 of them, three or so per file)
         if mode == "whole":
             env["SS_GZ_RANGE"] = "0"

