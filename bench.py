@@ -852,8 +852,10 @@ def main(argv=None):
         for r_ in rs_all:
             r_.close()
 
-    def make_step(scan, ev, out_stats):
+    def make_step(scan, ev, out_stats, before=None, after=None):
         def step(i=None):
+            if before is not None:
+                before()
             db.reset(stream)
             if i is not None:
                 ev[i][0].record()
@@ -871,6 +873,8 @@ def main(argv=None):
             nodes.reduce_touched_dev(out_stats.data_ptr(), stream)
             if i is not None:
                 ev[i][4].record()
+            if after is not None:
+                after()
         return step
 
     def settle_exchanges():
@@ -883,11 +887,11 @@ def main(argv=None):
         packed["pending"] = []
         return ok
 
-    def run_timed(scan, out_stats):
+    def run_timed(scan, out_stats, before=None, after=None):
         """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; the MAX over the ranks.
         -> (seconds, mean ms of scan kernel / harvest / exchange / node reductions from HIP events on the launch stream)"""
         ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(5)) for _ in range(args.steps)]
-        step = make_step(scan, ev, out_stats)
+        step = make_step(scan, ev, out_stats, before, after)
         if exchange:
             step()
             torch.cuda.synchronize()
@@ -922,7 +926,36 @@ def main(argv=None):
     def scan_binned():
         rs_loc.scan_into(db, stream)
 
-    dt, (kern_ms, harvest_ms, exch_ms, reduce_ms) = run_timed(scan_binned if binned else scan_file, stats)
+    # THE HEADLINE STEP (round 6): everything a sample's reads go through from the moment they are resident in file order --
+    # the binning of the records (ss_reorder.hip: what ss_reads_load does once per sample), the tree scan of the binned set,
+    # harvest, [exchange,] node reductions.  One scan per sample is the WORST case for the binning (configs[1]'s flow makes
+    # two or more: tree scan + the identified clusters' scan, with -b two more); the rate over an already binned set -- `value`
+    # of round 5, the limit for many scans -- is `resident_binned`, the steps in file order without any binning `file_order`.
+    sample = {}
+
+    def bin_sample():
+        sample["rs"] = _lib.ReadSet.from_flat_dev(reads.data_ptr(), reads.numel(), order=True)
+
+    def scan_sample():
+        sample["rs"].scan_into(db, stream)
+
+    def drop_sample():
+        sample.pop("rs").close()                     # (waits for the step's kernels: ss_reads_destroy's lifetime rule; the slab is kept for the next step)
+
+    resident_binned = None
+    if binned:
+        dt, (kern_ms, harvest_ms, exch_ms, reduce_ms) = run_timed(scan_sample, stats, bin_sample, drop_sample)
+        stats_b = torch.zeros_like(stats)
+        dt_b, (k_b, h_b, x_b, r_b) = run_timed(scan_binned, stats_b)
+        torch.cuda.synchronize()
+        resident_binned = dict(what="the same steps over a read set that was binned BEFORE the clock started (`value` of round 5): what every scan "
+                                    "after a sample's first costs, the limit for many scans per sample",
+                               ms_per_step=round(dt_b / args.steps * 1e3, 3), value=round(args.reads * world * args.steps / dt_b / 1e6, 3),
+                               unit="M reads/s", node_stats_equal=bool(torch.equal(stats, stats_b)),
+                               step_breakdown_ms=dict(scan_kernel=round(k_b, 3), harvest=round(h_b, 3),
+                                                      exchange=round(x_b, 3) if exchange else None, node_reduce=round(r_b, 3)))
+    else:
+        dt, (kern_ms, harvest_ms, exch_ms, reduce_ms) = run_timed(scan_file, stats)
     ms_per_step = dt / args.steps * 1e3
     reads_per_s = args.reads * world * args.steps / dt
     tail_ms = exch_ms + reduce_ms
@@ -979,6 +1012,13 @@ def main(argv=None):
                                        kernel_ms_at_collection=pmc_ms, stale=stale) if pmc else None))
         # SURVEY 8(d) prices a read at 120 probes x 8 B; a minimizer index answers the ~9 k-mers of a run with ONE lookup,
         # so on a fast shape the model's bytes exceed what any kernel would move and `frac` stops being a fraction of a roof
+        # what the counters say bounds the kernel: with measured HBM use below half of the model's fraction the kernel does not sit on
+        # the HBM roof at all -- it sits on VALU issue (valu_busy 0.93 at collection) -- and says so; frac stays SURVEY 8(d)'s model
+        if hbm_meas is not None and hbm_meas < 0.5 * frac:
+            rf["bound"] = "valu"
+            rf["bound_note"] = ("hbm_frac_measured %.2f < 0.5 x frac %.2f: the minimizer index answers ~9 probes with one sector, so the kernel is bound by "
+                                "VALU issue (valu_busy, valu_insts_per_tile), not by HBM; achieved / peak / frac are SURVEY 8(d)'s algorithmic-byte "
+                                "model against the HBM peak" % (hbm_meas, frac))
         rf["model_saturated"] = bool(frac > 0.9 and (hbm_meas is None or hbm_meas < 0.6 * frac))
         if rf["model_saturated"]:
             rf["model_note"] = ("8(d)'s 1110 B per read is saturated by the minimizer index on this shape: the work is done (counts checked "
@@ -995,7 +1035,7 @@ def main(argv=None):
     if binned:
         prep_ms = float(np.median(prep))
         parts_med = np.median(np.array(prep_parts), axis=0)
-        step_s = dt / args.steps
+        step_s = dt_b / args.steps                   # a step over the binned resident set; + prepare / n for a sample of n scans
 
         def with_prepare(n_scans, ms=None):
             return round(args.reads * world / (step_s + (prep_ms if ms is None else ms) * 1e-3 / n_scans) / 1e6, 1)
@@ -1005,14 +1045,15 @@ def main(argv=None):
         # (the MEDIAN of five is reported, the best and all five beside it: the call allocates the new 3 GB slab and frees 0.2 GB
         #  of scratch, and on a box whose host is busy with other tenants one such driver call now and then takes 60-150 ms)
         prepare = dict(what="binning of the resident records by the minimizer of their first k-mer, ~4 records per bin (ss_reorder.hip)",
-                       charged="once per sample, at load time, outside the timed steps",
+                       charged="once per sample; INSIDE every timed step of the headline (a step = a sample scanned once), measured on its own here",
                        ms=round(prep_ms, 2), ms_best=round(float(np.min(prep)), 2), ms_first_call=round(prep[0], 2), ms_all=[round(x, 2) for x in prep],
                        ms_kernels=round(float(parts_med[[0, 2]].sum()), 2),
                        breakdown_ms=dict(zip(("count_and_prefix", "slab_allocation", "place"), [round(float(x), 2) for x in parts_med])),
                        scans_per_sample=dict(note="the tree scan, + one scan per group of <= 4 identified multi-strain clusters "
                                                   "(ss_scan_reads_multi), + 2 more with -b (identify_low_depth.py:119,124)",
                                              all_clusters_single_strain=1, one_to_four_multi_strain_clusters=2, low_depth_b=3),
-                       m_reads_per_s_including_prepare={"1_scan": with_prepare(1), "2_scans": with_prepare(2), "3_scans": with_prepare(3)},
+                       m_reads_per_s_including_prepare={"1_scan": with_prepare(1), "2_scans": with_prepare(2), "3_scans": with_prepare(3),
+                                                        "note": "resident_binned's step + prepare.ms / n; `value` is the measured 1-scan case"},
                        m_reads_per_s_including_prepare_kernels={"1_scan": with_prepare(1, kern_only), "2_scans": with_prepare(2, kern_only),
                                                                 "3_scans": with_prepare(3, kern_only)},
                        driver_allocation_ms=round(float(parts_med[1]), 2), driver_allocation_slow=bool(parts_med[1] > 5.0),
@@ -1143,16 +1184,21 @@ def main(argv=None):
                                index=dict(pages=info.get("n_dir"), bucket_slots=info.get("n_mslots"), inline_kmers=info.get("n_inline"),
                                           filter_bits=info.get("filter_bits"), device_gb=round(info["device_bytes"] / 1e9, 3)),
                                table_layout=layout,
-                               read_order=("binned resident read set (what the product scans: strainscan_amd/db.py resident_reads)" if binned
-                                           else "file order (flat block)"),
+                               read_order=("binned resident read set (what the product scans: strainscan_amd/db.py resident_reads); the binning "
+                                           "itself is inside every timed step" if binned else "file order (flat block)"),
+                               step=("binning of the file-order records + tree scan + harvest%s + node reductions: a sample scanned ONCE, everything "
+                                     "included (resident_binned: the same without the binning; file_order: no binning at all)"
+                                     % (" + exchange" if exchange else "") if binned else "tree scan + harvest + node reductions in file order"),
                                parallelism="reads sharded x%d, table replicated, all-reduce of the touched nodes' hit counts" % world),
-                   roofline=roofline, cpu_baseline=cpu, phases=phases, prepare=prepare, file_order=file_order, host=host,
+                   roofline=roofline, cpu_baseline=cpu, phases=phases, prepare=prepare, resident_binned=resident_binned,
+                   file_order=file_order, host=host,
                    cluster_scan=(config3 or {}).get("cluster_scan"), l2_solve=(config3 or {}).get("l2_solve"), cli_e2e=cli_e2e,
                    e2e_reads_per_s=(phases or {}).get("e2e_reads_per_s"),
                    check=dict(total_hits=hits, nodes_with_hits=int((st_np["n_pos"] > 0).sum()),
                               harvest_equals_gather=harvest_equals_gather, exchanged_counts=packed["n"],
                               parity_across_ranks=parity_ranks),
-                   step_breakdown_ms=dict(scan_kernel=round(kern_ms, 3), harvest=round(harvest_ms, 3),
+                   step_breakdown_ms=dict(binning=(round(ms_per_step - kern_ms - harvest_ms - exch_ms - reduce_ms, 3) if binned else None),
+                                          scan_kernel=round(kern_ms, 3), harvest=round(harvest_ms, 3),
                                           exchange=round(exch_ms, 3) if exchange else None, node_reduce=round(reduce_ms, 3)))
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or self_group:

@@ -263,6 +263,10 @@ int ss_reads_from_flat_dev(const void *flat_dev, uint64_t n, int order, ss_reads
 /* Where the last binning of a read set spent its time, in ms: out[0] count pass + prefix over the bins, out[1] the driver's
  * allocation of the new slab (0.3 ms, or 60-90 ms for 3 GB on a box whose driver clears the memory first), out[2] place pass. */
 int ss_reads_order_timing(double out_ms[3]);
+/* Slabs this process has binned so far: out[0] through the passes for records of ONE length (every record of the slab as long
+ * as its first: a sequencer's 150-base reads; the count pass checks every record and a single exception sends the slab through
+ * the general passes), out[1] through the general passes (ragged records).  SS_ORDER_FIXED=0 switches the former off. */
+int ss_reads_order_counters(uint64_t out[2]);
 /* The resident flat blocks copied back to the host, slab after slab (host = NULL: only *len); for tests and debugging. */
 int ss_reads_read_back(const ss_reads *r, char *host, uint64_t cap, uint64_t *len);
 /* Lifetime: ss_scan_reads / ss_scan_reads_multi are asynchronous on the caller's stream and read the set's slabs.  Destroying

@@ -124,6 +124,7 @@ SIGNATURES = {
     "ss_reads_info": (i32, [vp, P(u64), P(u64), P(u64), P(u64)]),
     "ss_scan_reads": (i32, [vp, vp, vp]),
     "ss_reads_order_timing": (i32, [vp]),
+    "ss_reads_order_counters": (i32, [P(u64)]),
     "ss_fastx_to_flat": (i32, [cp, u64, vp, P(u64), P(u64)]),
     "ss_reader_open": (i32, [P(cp), i32, P(vp)]),
     "ss_reader_set_overlap": (i32, [vp, i32]),

@@ -173,6 +173,7 @@ namespace ss {
 int reads_order_for_locality(ss_reads *R, bool force = false);
 int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used, uint64_t *out_cap);
 void reorder_release();
+void reorder_counters(uint64_t out[2]);      // slabs binned by the one-length passes / by the general ones, in this process
 void reorder_timing(double out[3]);      // the last binning call: count + prefix, slab allocation, place (ms)      // the binning scratch kept between calls goes back to the device (ss_gz_gpu_release)
 int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int upper_keys);
 // the same index built on the device (ss_build_dev.hip); anything but SS_OK / SS_EKEY: nothing was built, use the host build

@@ -826,6 +826,13 @@ int ss_reads_order_timing(double out_ms[3])
     return SS_OK;
 }
 
+int ss_reads_order_counters(uint64_t out[2])
+{
+    if (!out) return SS_EINVAL;
+    ss::reorder_counters(out);
+    return SS_OK;
+}
+
 int ss_reads_read_back(const ss_reads *R, char *host, uint64_t cap, uint64_t *len)
 {
     if (!R || !len) return SS_EINVAL;

@@ -240,7 +240,7 @@ __device__ __forceinline__ uint32_t tile_round(const char *__restrict__ b, uint6
 #ifndef SS_SLOT_ALIGN
 #define SS_SLOT_ALIGN 8u
 #endif
-__device__ __forceinline__ uint32_t slot_of(uint32_t len) { return (len + 1u + (SS_SLOT_ALIGN - 1u)) & ~(SS_SLOT_ALIGN - 1u); }     // record + '\n', padded to 8 bytes
+__host__ __device__ __forceinline__ uint32_t slot_of(uint32_t len) { return (len + 1u + (SS_SLOT_ALIGN - 1u)) & ~(SS_SLOT_ALIGN - 1u); }     // record + '\n', padded to 8 bytes
 
 // ---- pass 1: bytes per bin, and the tile's record table -----------------------------------------------------------------
 __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80))) void count_kernel(const char *__restrict__ b, uint64_t n, int bits, unsigned long long *__restrict__ hist,
@@ -438,6 +438,81 @@ __global__ __launch_bounds__(256) void place_again_kernel(const char *__restrict
     }
 }
 
+// ---- records of ONE length (what a sequencer writes: every read 150 bases) ---------------------------------------------
+// The general passes above spend their time finding out where records begin and end -- newline masks, a suffix minimum
+// over the tile, a halo, record tables in LDS, a binary search per copied piece: chains of dependent round trips that hold
+// them at 2.4-2.5 TB/s (profiles/r05_sampled_kernel_stats.csv: 1.28 + 2.43 ms per 20 M reads).  When every record of the
+// slab has the same length L (the slab is n_rec x (L + 1) bytes, the first newline says L) record i starts at i * (L + 1)
+// and nothing has to be found: a WAVE owns 64 consecutive records (9.7 KB for L = 150), no LDS, no barrier.
+//   count_fixed   streams the wave's span in 16-byte pieces and CHECKS it -- a newline at offset L of every record and
+//                 nowhere else; one violation anywhere sets a flag and the caller runs the general passes instead -- and
+//                 every lane keys its own record from its first 32 bytes (in cache by then); bin sizes by atomicAdd, the
+//                 record's bin kept (4 bytes per record) for the second pass
+//   place_fixed   the returning atomicAdd on the bin's cursor is issued first; while it is on its way the lanes load the
+//                 span's pieces (numbered across the wave: consecutive lanes, consecutive 16 bytes); the destination of
+//                 a piece's record comes from the owning lane by a wave shuffle; aligned stores, padded with '\n'
+constexpr uint32_t FIX_MIN_L = 32, FIX_MAX_L = 1023;
+
+__global__ __launch_bounds__(256, 8) void count_fixed_kernel(const char *__restrict__ b, uint64_t n, uint64_t n_rec, uint32_t L, uint32_t magic_l1, int bits,
+                                                             unsigned long long *__restrict__ hist, uint32_t *__restrict__ bins,
+                                                             unsigned long long *__restrict__ not_fixed)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    if (r0 >= n_rec) return;
+    const uint32_t L1 = L + 1u, nr = (uint32_t)min((uint64_t)64, n_rec - r0), span = nr * L1;
+    const uint64_t base = r0 * L1;
+    bool bad = false;
+    for (uint32_t off = (uint32_t)lane * 16u; off < span; off += 1024u) {
+        const uint32_t m = nl_mask16(load16_nl(b, base + off, n));
+        const uint32_t pos = off - __umulhi(off, magic_l1) * L1;           // offset of the piece's first byte within its record
+        const uint32_t valid = span - off >= 16u ? 0xFFFFu : (1u << (span - off)) - 1u;
+        const uint32_t want = L - pos < 16u ? 1u << (L - pos) : 0u;        // (L >= 32: at most one record end in 16 bytes)
+        bad |= ((m ^ want) & valid) != 0u;
+    }
+    if (r0 + nr == n_rec) {                                                // behind the last record: newlines only (padding)
+        for (uint64_t i = base + span + (uint32_t)lane; i < n; i += 64) bad |= b[i] != '\n';
+    }
+    if (__ballot(bad)) { if (lane == 0) atomicOr(not_fixed, 1ull); return; }
+    if ((uint32_t)lane < nr) {
+        const uint32_t bin = record_bin(b, base + (uint64_t)lane * L1, L, bits);      // (s + 32 <= s + L + 1 <= n)
+        bins[r0 + lane] = bin;
+        atomicAdd(&hist[bin], (unsigned long long)slot_of(L));
+    }
+}
+
+constexpr int FPRE = 5;                     // pieces a lane has in flight: 64 lanes x 5 = the 640 pieces of 64 records of 150 bases
+__global__ __launch_bounds__(256, 8) void place_fixed_kernel(const char *__restrict__ b, uint64_t n, uint64_t n_rec, uint32_t L, uint32_t magic_p,
+                                                             unsigned long long *__restrict__ cursor, const uint32_t *__restrict__ bins,
+                                                             char *__restrict__ dst)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    if (r0 >= n_rec) return;
+    const uint32_t L1 = L + 1u, nr = (uint32_t)min((uint64_t)64, n_rec - r0), slot = slot_of(L), P = (slot + 15u) >> 4, total = nr * P;
+    const uint64_t base = r0 * L1;
+    unsigned long long d0 = 0;
+    if ((uint32_t)lane < nr) d0 = atomicAdd(&cursor[bins[r0 + lane]], (unsigned long long)slot);      // (answer needed at the stores)
+    for (uint32_t p0 = 0; p0 < total; p0 += 64u * FPRE) {
+        uint4 v[FPRE];
+        uint32_t rec[FPRE], off[FPRE];
+#pragma unroll
+        for (int r = 0; r < FPRE; r++) {
+            const uint32_t p = p0 + (uint32_t)lane + 64u * r;
+            rec[r] = min(__umulhi(p, magic_p), nr - 1u);
+            off[r] = (p - rec[r] * P) * 16u;
+            v[r] = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+            if (p < total && L > off[r]) v[r] = load16_nl(b, base + (uint64_t)rec[r] * L1 + off[r], n);
+        }
+#pragma unroll
+        for (int r = 0; r < FPRE; r++) {
+            const uint32_t p = p0 + (uint32_t)lane + 64u * r;
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)d0, (int)rec[r], 64), hi = (uint32_t)__shfl((int)(uint32_t)(d0 >> 32), (int)rec[r], 64);
+            if (p < total) store_piece(dst, (((uint64_t)hi << 32) | lo) + off[r], v[r], L, slot, off[r]);
+        }
+    }
+}
+
 // ---- exclusive prefix over the bin sizes (up to 4 M of them): block sums, their prefix, local prefixes ----------------------
 constexpr int SCAN_PER = 4096;              // entries per workgroup of 1024 threads
 
@@ -510,6 +585,7 @@ int order_bits(uint64_t n_bytes)
 namespace ss {
 
 static std::mutex g_scr_mu;
+static uint64_t g_order_n[2] = {0, 0};        // slabs binned by the one-length passes / by the general ones (ss_reads_order_counters)
 static double g_order_ms[3] = {0, 0, 0};      // the last order_flat_dev: count + prefix, allocation of the new slab, place
 static char *g_scr = nullptr;            // the scratch of the last call (bin cursors, per-tile record tables), kept for the next
 static uint64_t g_scr_cap = 0;
@@ -531,7 +607,22 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     const unsigned nb = (unsigned)((n + RB - 1) / RB), nsb = (n_bins + SCAN_PER - 1) / SCAN_PER;
     // one allocation for the scratch: bin sizes / cursors (+ total), block sums of the prefix, per-tile record counts and table
     const uint64_t o_sums = ((uint64_t)n_bins + 2) * 8, o_cnt = o_sums + (((uint64_t)nsb + 1) * 8), o_tab = (o_cnt + (uint64_t)nb * 4 + 255) & ~255ull;
-    const uint64_t scratch = o_tab + (uint64_t)nb * TCAP * 8;
+    // records of one length: the first newline says which; the count pass checks every record against it
+    uint32_t fix_L = 0;
+    uint64_t n_rec = 0;
+    static const bool fixed_allowed = [] { const char *e = getenv("SS_ORDER_FIXED"); return !(e && !strcmp(e, "0")); }();
+    if (fixed_allowed && n >= 64) {
+        char head[FIX_MAX_L + 2];
+        const size_t hn = (size_t)std::min<uint64_t>(n, sizeof(head));
+        if (hipMemcpy(head, src, hn, hipMemcpyDeviceToHost) != hipSuccess) { ss::set_last_error("hipMemcpy", __FILE__, __LINE__, hipGetLastError()); return SS_EHIP; }
+        const void *nl = memchr(head, '\n', hn);
+        if (nl) {
+            const uint32_t L = (uint32_t)((const char *)nl - head);
+            if (L >= FIX_MIN_L && L <= FIX_MAX_L && n / (L + 1) >= 1 && n - (n / (L + 1)) * (L + 1) < 64) { fix_L = L; n_rec = n / (L + 1); }
+        }
+    }
+    // (the record table of the general passes and the 4-byte bins of the one-length passes share a region: whichever is larger)
+    const uint64_t scratch = o_tab + std::max<uint64_t>((uint64_t)nb * TCAP * 8, (n_rec * 4 + 255) & ~255ull);
     char *d_scr = nullptr, *d_new = nullptr;
 #define SS_R(call) do { if ((call) != hipSuccess) { ss::set_last_error(#call, __FILE__, __LINE__, hipGetLastError()); hipFree(d_scr); hipFree(d_new); return SS_EHIP; } } while (0)
     // (the scratch of the call before is kept -- 0.19 GB for 20 M reads --: two driver calls fewer per sample)
@@ -544,14 +635,30 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     unsigned long long *d_hist = (unsigned long long *)d_scr, *d_sums = (unsigned long long *)(d_scr + o_sums);
     uint32_t *d_cnt = (uint32_t *)(d_scr + o_cnt);
     unsigned long long *d_tab = (unsigned long long *)(d_scr + o_tab);
-    SS_R(hipMemsetAsync(d_hist, 0, o_sums, 0));
     constexpr unsigned pad1 = 0, pad2 = 0;
-    hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(256), pad1, 0, src, n, bits, d_hist, d_cnt, d_tab, d_hist + n_bins + 1);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, 0, d_sums, nsb, d_hist + n_bins);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
-    unsigned long long tail[2] = {0, 0};                 // bytes of the new slab, tiles that did not fit the table
-    SS_R(hipMemcpy(tail, d_hist + n_bins, 16, hipMemcpyDeviceToHost));
+    unsigned long long tail[2] = {0, 0};                 // bytes of the new slab; tiles that did not fit the table / "not of one length"
+    bool fixed = false;
+    if (fix_L) {
+        const uint32_t L1 = fix_L + 1u, P = (::slot_of(fix_L) + 15u) >> 4;
+        const unsigned nbf = (unsigned)((n_rec + 255) / 256);
+        SS_R(hipMemsetAsync(d_hist, 0, o_sums, 0));
+        hipLaunchKernelGGL(count_fixed_kernel, dim3(nbf), dim3(256), 0, 0, src, n, n_rec, fix_L, (uint32_t)(((1ull << 32) + L1 - 1) / L1), bits, d_hist,
+                           (uint32_t *)d_tab, d_hist + n_bins + 1);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, 0, d_sums, nsb, d_hist + n_bins);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
+        SS_R(hipMemcpy(tail, d_hist + n_bins, 16, hipMemcpyDeviceToHost));
+        fixed = tail[1] == 0;                            // (else: some record is shorter or longer after all -- the general passes)
+        (void)P;
+    }
+    if (!fixed) {
+        SS_R(hipMemsetAsync(d_hist, 0, o_sums, 0));
+        hipLaunchKernelGGL(count_kernel, dim3(nb), dim3(256), pad1, 0, src, n, bits, d_hist, d_cnt, d_tab, d_hist + n_bins + 1);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, 0, d_sums, nsb, d_hist + n_bins);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(1024), 0, 0, d_hist, n_bins, d_sums);
+        SS_R(hipMemcpy(tail, d_hist + n_bins, 16, hipMemcpyDeviceToHost));
+    }
     const unsigned long long total = tail[0];
     lap("count + prefix");
     const auto t_counted = std::chrono::steady_clock::now();
@@ -560,8 +667,14 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
     SS_R(ss::big_malloc((void **)&d_new, cap, &real_cap));
     const auto t_alloc = std::chrono::steady_clock::now();
     lap("new slab");
-    hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), pad2, 0, src, n, d_hist, d_cnt, d_tab, d_new);
-    if (tail[1]) hipLaunchKernelGGL(place_again_kernel, dim3(nb), dim3(256), 0, 0, src, n, bits, d_hist, d_cnt, d_new);
+    if (fixed) {
+        const uint32_t P = (::slot_of(fix_L) + 15u) >> 4;
+        hipLaunchKernelGGL(place_fixed_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, 0, src, n, n_rec, fix_L, (uint32_t)(((1ull << 32) + P - 1) / P),
+                           d_hist, (const uint32_t *)d_tab, d_new);
+    } else {
+        hipLaunchKernelGGL(place_kernel, dim3(nb), dim3(256), pad2, 0, src, n, d_hist, d_cnt, d_tab, d_new);
+        if (tail[1]) hipLaunchKernelGGL(place_again_kernel, dim3(nb), dim3(256), 0, 0, src, n, bits, d_hist, d_cnt, d_new);
+    }
     if (cap > total) SS_R(hipMemsetAsync(d_new + total, '\n', cap - total, 0));
     SS_R(hipGetLastError());
     SS_R(hipDeviceSynchronize());
@@ -573,6 +686,7 @@ int order_flat_dev(const char *src, uint64_t n, char **out_d, uint64_t *out_used
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         std::lock_guard<std::mutex> g(g_scr_mu);
         g_order_ms[0] = ms(t_begin, t_counted); g_order_ms[1] = ms(t_counted, t_alloc); g_order_ms[2] = ms(t_alloc, t_end);
+        g_order_n[fixed ? 0 : 1]++;
     }
 #undef SS_R
     {
@@ -588,6 +702,12 @@ void reorder_timing(double out[3])
 {
     std::lock_guard<std::mutex> g(g_scr_mu);
     for (int i = 0; i < 3; i++) out[i] = g_order_ms[i];
+}
+
+void reorder_counters(uint64_t out[2])
+{
+    std::lock_guard<std::mutex> g(g_scr_mu);
+    out[0] = g_order_n[0]; out[1] = g_order_n[1];
 }
 
 void reorder_release()

@@ -258,7 +258,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     lut = np.frombuffer(b"ACGT", np.uint8)
     rows = lut[rs.randint(0, 4, (30000, 31))]
     kfa = b"".join(b">1\n" + r.tobytes() + b"\n" for r in rows)
-    n = 50000
+    n = 50000 if world < 8 else 160000      # (eight ranks: files of ~8 MB = 16 slices of the smallest size there is, 128 search chunks)
+    lvl = 6 if world < 8 else 1
     reads = lut[rs.randint(0, 4, (n, 150))]
     for i in range(0, n, 2):
         o = rs.randint(0, 119)
@@ -270,7 +271,7 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     plain = tmp_path / "all.fq"
     plain.write_bytes(b"".join(fq))
     p1, p2 = tmp_path / "s_1.fq.gz", tmp_path / "s_2.fq.gz"
-    p1.write_bytes(gzip.compress(b"".join(fq[:half]), 6))
+    p1.write_bytes(gzip.compress(b"".join(fq[:half]), lvl))
     if mode == "bgzip":
         from tests.test_ginflate_gpu import _bgzf
         p1.write_bytes(_bgzf(b"".join(fq[:half])))
@@ -279,8 +280,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
         q = half + (n - half) // 3
         p2.write_bytes(gzip.compress(b"".join(fq[half:q]), 6) + gzip.compress(b"".join(fq[q:]), 1))
     else:
-        p2.write_bytes(gzip.compress(b"".join(fq[half:]), 6))
-    assert min(p1.stat().st_size, p2.stat().st_size) > (1 << 20)
+        p2.write_bytes(gzip.compress(b"".join(fq[half:]), lvl))
+    assert min(p1.stat().st_size, p2.stat().st_size) > ((1 << 20) if world < 8 else (7 << 20))
     db = L.KmerDB.from_text(kfa, 31, True)
     db.scan_files([str(plain)])
     want = db.counts_rows().copy()
@@ -297,7 +298,8 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SS_TEST_STORE=str(tmp_path / ("store_%d" % port)))
         env.pop("SS_GZ_GPU", None)
-        env["SS_GZ_SLICE_KB"] = "256" if world < 8 else "64"      # (eight ranks: ~16 slices per file, two per rank, 8 x 2 hops of the chain)
+        env["SS_GZ_SLICE_KB"] = "256" if world < 8 else "64"      # (a slice is 128 search chunks at least: 512 KB; eight ranks: ~16 slices per
+                                                                  #  file, two per rank, 8 x 2 hops of the chain)
         env["SS_GZ_CHUNK"] = "4096"          # (search chunks of 4 KB: slices of 128 of them, three or so per file)
         if mode == "whole":
             env["SS_GZ_RANGE"] = "0"

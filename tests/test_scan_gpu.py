@@ -859,13 +859,16 @@ def test_bench_line_contract_and_exchange_path():
                     "dtype", "data", "config", "roofline", "cpu_baseline", "phases", "e2e_reads_per_s", "cluster_scan", "l2_solve",
                     "prepare", "file_order"):
             assert key in d, key
-        # the headline is the path the product runs: the binned resident read set; file order beside it, the binning's
-        # once-per-sample cost and the rates that include it
+        # the headline step is a sample scanned ONCE, everything included: binning of the file-order records + scan of the binned set
+        # + harvest + node reductions; beside it the steps over an already binned set (round 5's headline) and in file order
         assert d["config"]["read_order"].startswith("binned") and d["roofline"]["read_order"].startswith("binned")
-        fo, pr = d["file_order"], d["prepare"]
+        assert d["config"]["step"].startswith("binning of the file-order records")
+        fo, pr, rb = d["file_order"], d["prepare"], d["resident_binned"]
         assert fo["node_stats_equal"] is True and fo["value"] > 0 and fo["roofline"]["kernel_ms"] > 0
+        assert rb["node_stats_equal"] is True and rb["value"] > d["value"] and rb["ms_per_step"] < d["ms_per_step"]
+        assert d["step_breakdown_ms"]["binning"] > 0
         assert pr["ms"] > 0 and len(pr["ms_all"]) == 5 and pr["scans_per_sample"]["all_clusters_single_strain"] == 1
-        assert pr["m_reads_per_s_including_prepare"]["1_scan"] < pr["m_reads_per_s_including_prepare"]["3_scans"] < d["value"]
+        assert pr["m_reads_per_s_including_prepare"]["1_scan"] < pr["m_reads_per_s_including_prepare"]["3_scans"] < rb["value"]
         assert abs(d["value"] - 300000 / (d["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * d["value"]
         # BASELINE configs[3] beside the headline: the cluster scan (both read orders, counts equal, oracle on a sub-sample)
         # and the layer-2 solve (phases, abundances against the oracle on a sub-sample of the rows)
@@ -881,7 +884,7 @@ def test_bench_line_contract_and_exchange_path():
         assert len(l2s["selected"]) >= 2 and "pattern_stats" in l2s["phases_ms"] and "pre_scan" in l2s["phases_ms"]
         assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["db_shape"] == shape and d["vs_baseline"] is None
         rf = d["roofline"]
-        assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0
+        assert rf["bound"] in ("hbm", "valu") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0
         assert d["cpu_baseline"]["parity_on_sample"] is True and d["cpu_baseline"]["kind"] == "port"
         assert d["check"]["harvest_equals_gather"] is True and d["check"]["total_hits"] > 0
         assert d["phases"]["clusters_found"] == 3 and d["phases"]["l1_host_ms"] > 0 and d["e2e_reads_per_s"] > 0
@@ -1421,7 +1424,7 @@ def test_destroying_a_read_set_waits_for_the_scan_in_flight(L):
     spec = bench.make_db(torch, dev, 23, seed=79, lo_sites=2000, hi_sites=9000, hit_frac=0.05)
     n_reads = 1_900_000
     reads_a = bench.make_reads(torch, dev, spec, n_reads, seed=7, hit_frac=0.3)
-    reads_b = bench.make_reads(torch, dev, spec, n_reads, seed=8, hit_frac=0.0)       # no hit at all: a race shows as lost counts
+    reads_b = bench.make_reads(torch, dev, spec, n_reads, seed=8, hit_frac=0.002)     # next to no hits: a race shows as lost counts
     db = L.KmerDB(spec["keys"], np.ones(spec["keys"].size, np.uint8), 31, True)
     db.scan_flat_dev(reads_a.data_ptr(), reads_a.numel())
     L.check(L.lib().ss_device_sync(), "sync")
@@ -1445,3 +1448,99 @@ def test_destroying_a_read_set_waits_for_the_scan_in_flight(L):
             rs2.close()
     assert kept()[0] >= 1
     assert L.lib().ss_dev_big_release() == 0 and kept()[:2] == (0, 0)
+
+
+def _order_counters(L):
+    import ctypes as C
+    out = (C.c_uint64 * 2)()
+    L.check(L.lib().ss_reads_order_counters(out), "ss_reads_order_counters")
+    return int(out[0]), int(out[1])
+
+
+@pytest.mark.parametrize("length,n_rec", [(150, 20001), (151, 4097), (32, 70000), (33, 64), (100, 1), (250, 12345), (1023, 3000), (31, 5000), (1024, 700)])
+def test_binning_of_records_of_one_length(L, length, n_rec):
+    """ss_reorder.hip count_fixed_kernel / place_fixed_kernel: a slab whose records all have the length of the first goes through
+    the passes that KNOW where records begin (round 6: 3.7 -> ~2 ms per 20 M reads); the result obeys the same contract as
+    the general passes' -- every record once, whole, in bin order, slots of 8-byte multiples, counts bit-exact.  Lengths
+    32..1023 qualify (31 and 1024 take the general passes); record counts that are not multiples of 64, a single record,
+    trailing newline padding, records with N / lower case in their first k-mer."""
+    import torch
+    from oracle import oracle as orc
+    rs = np.random.RandomState(length * 7 + n_rec)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    g = lut[rs.randint(0, 4, size=60000 + length)]
+    starts = rs.randint(0, 60000, size=n_rec)
+    arr = np.stack([g[s:s + length] for s in starts]) if n_rec < 30000 else g[starts[:, None] + np.arange(length)[None, :]]
+    arr = arr.copy()
+    for i in range(0, n_rec, 211):
+        arr[i, rs.randint(0, length)] = ord("N")
+    for i in range(5, n_rec, 503):
+        arr[i] = np.frombuffer(arr[i].tobytes().lower(), np.uint8)
+    recs = [a.tobytes() for a in arr]
+    kfa = b"".join(b">1\n" + g[i:i + 31].tobytes() + b"\n" for i in range(0, 60000, 7))
+    db = L.KmerDB.from_text(kfa, 31, True)
+    for pad in (0, 9):
+        block = b"\n".join(recs) + b"\n" * (1 + pad)
+        db.reset()
+        db.scan_flat(block)
+        want = db.counts_rows().copy()
+        d = torch.frombuffer(bytearray(block), dtype=torch.uint8).cuda()
+        f0, g0 = _order_counters(L)
+        rset = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=True)
+        f1, g1 = _order_counters(L)
+        qualifies = 32 <= length <= 1023 and len(block) >= 64
+        assert (f1 - f0, g1 - g0) == ((1, 0) if qualifies else (0, 1)), (length, n_rec, pad)
+        db.reset()
+        rset.scan_into(db)
+        L.check(L.lib().ss_device_sync(), "sync")
+        assert np.array_equal(db.counts_rows(), want)
+        slots = rset.read_back()
+        back = [r for r in slots.split(b"\n") if r]
+        assert sorted(back) == sorted(recs)
+        assert len(slots) % 16 == 0 and slots.endswith(b"\n")
+        if length >= 31:
+            bits = 12
+            while bits < 22 and (len(block) // 152) >> (bits + 2):
+                bits += 1
+            bins = [_locality_bin(r, bits) for r in back]
+            assert bins == sorted(bins)
+        rset.close()
+    db.close()
+
+
+def test_binning_falls_back_when_one_record_differs(L):
+    """The count pass for records of one length CHECKS the slab: one record a base shorter (so that every later record is
+    shifted), a newline in the middle of a record (the byte count still divides), a record one base longer at the very end,
+    an empty record -- each sends the slab through the general passes, with the same result as ever.  And SS_ORDER_FIXED
+    is honoured (read once per process: checked in a child)."""
+    import torch
+    rs = np.random.RandomState(77)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    g = lut[rs.randint(0, 4, size=50150)]
+    base = [g[s:s + 150].tobytes() for s in rs.randint(0, 50000, size=9000)]
+    kfa = b"".join(b">1\n" + g[i:i + 31].tobytes() + b"\n" for i in range(0, 50000, 5))
+    db = L.KmerDB.from_text(kfa, 31, True)
+    variants = {}
+    v = list(base); v[4000] = v[4000][:-1]; variants["shorter"] = v
+    v = list(base); v[4000] = v[4000][:75] + b"\n" + v[4000][76:]; variants["split"] = v
+    v = list(base); v[-1] = v[-1] + b"A"; variants["longer_last"] = v
+    v = list(base); v[8999] = v[8999][:149]; v.append(b"A"); variants["short_then_one"] = v
+    v = list(base); v[100] = b""; variants["empty"] = v
+    for name, recs in variants.items():
+        block = b"\n".join(recs) + b"\n"
+        db.reset()
+        db.scan_flat(block)
+        want = db.counts_rows().copy()
+        d = torch.frombuffer(bytearray(block), dtype=torch.uint8).cuda()
+        f0, g0 = _order_counters(L)
+        rset = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=True)
+        f1, g1 = _order_counters(L)
+        assert (f1 - f0, g1 - g0) == (0, 1), name
+        db.reset()
+        rset.scan_into(db)
+        L.check(L.lib().ss_device_sync(), "sync")
+        assert np.array_equal(db.counts_rows(), want), name
+        back = [r for r in rset.read_back().split(b"\n") if r]
+        assert sorted(back) == sorted(r for chunk in recs for r in chunk.split(b"\n") if r), name
+        rset.close()
+    db.close()
