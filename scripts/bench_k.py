@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Cluster-table scans at k != 31 (`-k`, StrainScan.py:136,266-271; Vote_Strain_L2_Lasso_new_sp.py:359-371): the flat
-open-address table (ss_scan.hip) serves every k but 31, the minimizer-paged index (ss_mini.hip) k = 31.
+"""Cluster-table scans at k != 31 (`-k`, StrainScan.py:136,266-271; Vote_Strain_L2_Lasso_new_sp.py:359-371): the minimizer-paged
+index (ss_mini.hip) serves 17 <= k <= 31 (k = 31 through the tuned kernel, the others through scan_minik_kernel; round 6), the flat
+open-address table (ss_scan.hip) what is below -- and every k under SS_LAYOUT=flat (the A/B leg).
     bench_k.py [rows] [reads]      -> one JSON line per k: index build time from a k-mer FASTA, scan kernel time, reads/s
 Table: `rows` k-mers cut from random genomes (every 20th position, both orientations as the builder writes them);
 reads: 150 bp from the same genomes (5 % of their k-mers are table k-mers), resident flat block."""
@@ -28,7 +29,7 @@ def main():
     genome_len = rows // 2 * 20 + 64
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev)
     out = []
-    for k in (31, 25, 21):
+    for k in (31, 27, 25, 21, 17):
         starts = torch.arange(0, rows // 2, device=dev) * 20
         idx = starts[:, None] + torch.arange(k, device=dev)[None, :]
         fw = genome[idx]
@@ -66,7 +67,7 @@ def main():
         hits = int(db.counts_rows().astype(np.int64).sum())
         info = db.info()
         ms = float(np.median(ts[1:]))
-        out.append(dict(k=k, rows=int(both.shape[0]), reads=n_reads, layout="minimizer pages" if k == 31 else "flat table",
+        out.append(dict(k=k, rows=int(both.shape[0]), reads=n_reads, layout="minimizer pages" if info["layout"] == 1 else "flat table",
                         index_build_s=round(build_s, 3), scan_kernel_ms=round(ms, 3), m_reads_per_s=round(n_reads / ms / 1e3, 1),
                         algorithmic_gb_s=round(n_reads * (150 + (150 - k + 1) * 8) / ms / 1e6, 1), hits=hits,
                         device_mb=round(info["device_bytes"] / 1e6, 1)))

@@ -63,6 +63,7 @@ inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
 // A container with 16 CPUs of quota on a 256-thread host runs 64 busy threads SLOWER than 16 (CFS throttles the
 // whole group once the quota of a period is spent).
 unsigned host_cpus();
+extern std::atomic<long long> g_hook_generic_k;      // ss_test_hook 4 (ss_mini.hip)
 unsigned ingest_threads();      // FASTQ parse threads of this process: its share of host_cpus() (LOCAL_WORLD_SIZE), at most 20 (ss_ingest.hip)
 
 }  // namespace ss
@@ -75,7 +76,7 @@ struct ss_db {
     uint64_t n_distinct = 0;
     uint32_t log2cap = 0;
     uint64_t capacity = 0;
-    int layout = 0;                    // 0 = flat open-address table, 1 = minimizer buckets (k = 31)
+    int layout = 0;                    // 0 = flat open-address table, 1 = minimizer pages (17 <= k <= 31)
     uint64_t n_slots = 0;              // length of d_counts: capacity (flat) or n_mslots + 8 * n_dir (pages)
     uint64_t n_mslots = 0;             // pages: length of d_mkeys (bucket headers + k-mers)
     uint64_t n_inline = 0;             // pages: database k-mers held inline in page slots

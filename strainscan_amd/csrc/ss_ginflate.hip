@@ -2631,13 +2631,15 @@ extern "C" int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_
 
 // Test hooks, switched by an explicit call only (never by the environment): 1 = plant a wrong entry in search chunk `value`
 // (0 = off), 2 = this process declines .gz inputs on the device (range mode: it still serves the chain), 3 = this rank leaves
-// range mode without serving the chain (what a crashed peer looks like: the others' bounded wait must end it).
+// range mode without serving the chain (what a crashed peer looks like: the others' bounded wait must end it), 4 = tables of
+// k = 31 are scanned by the any-k kernel of the page index too (ss_mini.hip scan_minik_kernel: the two kernels held to each other).
 extern "C" int ss_test_hook(int which, long long value)
 {
     switch (which) {
     case 1: ss::g_hook_entry = value; return SS_OK;
     case 2: ss::g_hook_decline = value; return SS_OK;
     case 3: ss::g_hook_skip_chain = value; return SS_OK;
+    case 4: ss::g_hook_generic_k = value; return SS_OK;
     default: return SS_EINVAL;
     }
 }

@@ -898,7 +898,7 @@ int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *R, void *s
         int k = 0;
         ss_db_info(dbs[i], nullptr, nullptr, nullptr, &k);
         if (R->has_cut_record && k != 31) return SS_ERANGE;
-        if (dbs[i]->layout == 1) mini.push_back(dbs[i]);
+        if (dbs[i]->layout == 1 && k == 31) mini.push_back(dbs[i]);      // (the several-tables kernel is k = 31's)
         else { int rc = ss_scan_reads(dbs[i], R, stream); if (rc) return rc; }
     }
     constexpr int group = 4;

@@ -1057,7 +1057,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
                 }
                 const uint32_t o = sorted[a2].off;
                 if (inl) {
-                    items[it++] = Item{h, flank_of_key(sorted[a2].key, o), (uint16_t)(((h >> 8) & 0xFFFu) << 4), (uint8_t)(16u - o), a2, b2};
+                    items[it++] = Item{h, flank_of_key_k(sorted[a2].key, o, k), (uint16_t)(((h >> 8) & 0xFFFu) << 4), (uint8_t)((uint32_t)(k - MINI_M) - o), a2, b2};      // (e = k - 15 - o: 16 - o at k = 31)
                 } else {
                     if ((mask >> o) & 1u) multi = 1u;
                     mask |= 1u << o;
@@ -1188,7 +1188,7 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     SS_HIP(hipMemcpy(db->d_slot_of_row, slot_of_row.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
     SS_HIP(hipMemcpy(db->d_row_valid, row_valid.data(), nr, hipMemcpyHostToDevice));
     lap("5 bloom + upload");
-    return mark_solid(db);
+    return k == 31 ? mark_solid(db) : SS_OK;      // (PG_SOLID serves the combining kernel, which is k = 31 only)
 }
 
 // PG_SOLID for every bucket whose k-mers are one stretch of bases (ss_scan_dev.h): one thread per page slot, after either
@@ -1222,6 +1222,134 @@ int mark_solid(ss_db *db)
     hipLaunchKernelGGL(mark_solid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint8_t *)db->d_dir, n, db->d_mkeys);
     SS_HIP(hipGetLastError());
     SS_HIP(hipDeviceSynchronize());
+    return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The page index at ANY k from 17 to 30 (round 6; `-k`, StrainScan.py:136,266-271, reaches the layer-2 scans:
+// Vote_Strain_L2_Lasso_new_sp.py:359-371).  Until now every k but 31 went through the flat table (ss_scan.hip): one random
+// 64-byte sector per k-mer, 0.08 of the HBM peak by SURVEY 8(d)'s bytes.  The index itself never depended on k = 31 -- a
+// k-mer has k - 14 m-mers, its flank k - 15 bases (<= 32 bits), offsets 0..k-15 (<= 17 mask bits) -- only the scan kernel above
+// does, in every phase (17-m-mer windows split over two lanes, 16-lane candidate checks, the combining table).  This kernel is
+// the plain statement of the same lookups with k as a run-time value: ONE LANE PER START POSITION.  The m-mer keys of a
+// 1024-position tile go to LDS once; a position takes the minimum of its k - 14 keys (leftmost on ties, as the build),
+// mixes the minimizer, reads the head of its page and settles its own k-mer against the slots that match.  Consecutive
+// positions of a read share their minimizer for ~(k - 14) / 2 positions and sit in neighbouring lanes: their page loads are
+// the same address in one wave instruction -- one sector from L2 / HBM per run, as above, with no run queues at all.
+// ~70 lane instructions per position at k = 25 against the tuned kernel's 45 at k = 31.
+// ---------------------------------------------------------------------------------------------
+constexpr int KT = 256, KPOS = 1024, KW = KPOS / 16 + 3;      // threads, start positions per tile, 16-base code words per tile (tile + 48 bases)
+struct KShared {
+    uint32_t code[KW + 1];
+    alignas(8) uint16_t inv[KW + 5];
+    uint32_t key[KPOS + 16];
+};
+
+template <bool ALIGNED, bool BLOOM>
+__global__ __launch_bounds__(KT) void scan_minik_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, int k,
+                                                        const uint64_t *__restrict__ mkeys, const uint4 *__restrict__ pages, uint32_t n_pages,
+                                                        uint32_t *__restrict__ counts, uint32_t cbase, const uint32_t *__restrict__ bloom,
+                                                        uint32_t bloom_shift)
+{
+    __shared__ KShared S;
+    const int t = threadIdx.x;
+    const uint32_t W = (uint32_t)(k - ss::MINI_M + 1), F = W - 1u;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull, vmask = (1ull << k) - 1ull;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t b0 = tile * (uint64_t)KPOS;
+        __syncthreads();                                   // (the tile before is done with S)
+        if (t < KW) {
+            uint32_t w[4], code, inv;
+            load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, w);
+            encode16(w, code, inv);
+            S.code[t] = code;
+            S.inv[t] = (uint16_t)inv;
+        } else if (t < KW + 5) {
+            if (t == KW) S.code[KW] = 0u;
+            S.inv[t] = 0xFFFFu;
+        }
+        __syncthreads();
+        for (uint32_t p = (uint32_t)t; p < (uint32_t)KPOS + 16u; p += KT) {
+            const uint32_t x = __builtin_amdgcn_alignbit(S.code[(p >> 4) + 1], S.code[p >> 4], 2 * (p & 15));
+            S.key[p] = ss::mmkey(x) & ss::KEY_MASK;       // (mmkey looks at the low 24 bits only)
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t p = (uint32_t)t; p < (uint32_t)KPOS; p += KT) {
+            // live: the k bases from p on are all ACGT (bytes beyond the block read as '\n')
+            uint64_t iv;
+            __builtin_memcpy(&iv, &S.inv[p >> 4], 8);
+            if ((iv >> (p & 15)) & vmask) continue;
+            uint32_t best = S.key[p], o = 0;
+            for (uint32_t i = 1; i < W; i++) {
+                const uint32_t kk = S.key[p + i];
+                if (kk < best) { best = kk; o = i; }
+            }
+            const uint32_t q = p + o;                       // tile position of the minimizer
+            const uint32_t x = __builtin_amdgcn_alignbit(S.code[(q >> 4) + 1], S.code[q >> 4], 2 * (q & 15)) & ss::M30;
+            const uint32_t h = ss::mix30(x);
+            if (BLOOM && !((bloom[h >> (bloom_shift + 5)] >> ((h >> bloom_shift) & 31u)) & 1u)) continue;
+            // the k-mer: bases p .. p + k - 1, base i at bits 2 i
+            const uint32_t w0 = p >> 4, sh = 2 * (p & 15);
+            const uint32_t lo = __builtin_amdgcn_alignbit(S.code[w0 + 1], S.code[w0], sh), hi = __builtin_amdgcn_alignbit(S.code[w0 + 2], S.code[w0 + 1], sh);
+            const uint64_t key = (((uint64_t)hi << 32) | lo) & kmask;
+            uint32_t page = ss::page_of(h, n_pages);
+            const uint32_t tt = (h & 0xFFu) * 0x01010101u;
+            bool full;
+            do {
+                const uint4 tg = pages[(uint64_t)page * 4u];
+                const uint32_t x0 = tg.x ^ tt, x1 = tg.y ^ tt;                  // zero byte = tag8 matches
+                const uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u;
+                const uint32_t z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
+                uint32_t hit = (z0 >> 7) | (z1 >> 3);                           // slot s at bit 8 (s & 3) + 4 (s >> 2)
+                const char *pb = reinterpret_cast<const char *>(pages) + (uint64_t)page * 64u;
+                while (hit) {
+                    const uint32_t b = (uint32_t)__ffs(hit) - 1u, sl = (b >> 3) + (b & 4u);
+                    hit &= hit - 1u;
+                    const uint32_t hi8 = (((b & 4u) ? tg.w : tg.z) >> (b & 24u)) & 0xFFu;
+                    if (hi8 & 0x80u) {                                          // bucket reference
+                        if ((hi8 ^ (h >> 8)) & 0x3Fu) continue;
+                        const uint32_t l32 = reinterpret_cast<const uint32_t *>(pb + 16)[sl];
+                        const uint32_t mask = reinterpret_cast<const uint16_t *>(pb + 48)[sl] | ((hi8 & 0x40u) << 10);
+                        const uint32_t bstart = l32 & ss::START_MASK;
+                        bool found = false;
+                        if ((mask >> o) & 1u) {
+                            const uint32_t cpos = bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u));
+                            if (mkeys[cpos] == key) { atomicAdd(&counts[cpos], 1u); found = true; }
+                        }
+                        if (!found && (l32 >> 31)) {                            // several k-mers per offset: look through the bucket
+                            const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
+                            for (uint32_t c = 0; c < cnt; c++)
+                                if (mkeys[bstart + 1u + c] == key) { atomicAdd(&counts[bstart + 1u + c], 1u); break; }
+                        }
+                    } else if ((hi8 & 31u) == F - o) {                          // an inline k-mer with this minimizer offset
+                        const uint32_t mid = reinterpret_cast<const uint16_t *>(pb + 48)[sl];
+                        if ((mid >> 4) == ((h >> 8) & 0xFFFu) && reinterpret_cast<const uint32_t *>(pb + 16)[sl] == ss::flank_of_key_k(key, o, k))
+                            atomicAdd(&counts[cbase + page * 8u + sl], 1u);
+                    }
+                }
+                full = (tg.w >> 24) != (uint32_t)ss::PG_EMPTY_HI;
+                page++;                                                         // (the build guarantees a non-full page before the array ends)
+            } while (full);
+        }
+    }
+}
+
+std::atomic<long long> g_hook_generic_k{0};      // ss_test_hook(4, ...)
+static int launch_scan_minik(ss_db *db, const uint8_t *b, uint64_t n, hipStream_t stream)
+{
+    const uint64_t n_tiles = (n + KPOS - 1) / KPOS;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)256 * 8 * 16);
+    const bool aligned = (((uintptr_t)b) & 15) == 0;
+    const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
+    const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
+    const bool bl = db->d_bloom && !db->expect_hits;
+#define SS_LAUNCH_K(A, B) hipLaunchKernelGGL((scan_minik_kernel<A, B>), dim3(blocks), dim3(KT), 0, stream, b, n, n_tiles, db->k, db->d_mkeys, pages, db->n_dir, \
+                                             db->d_counts, cbase, db->d_bloom, bshift)
+    if (bl) { if (aligned) SS_LAUNCH_K(true, true); else SS_LAUNCH_K(false, true); }
+    else    { if (aligned) SS_LAUNCH_K(true, false); else SS_LAUNCH_K(false, false); }
+#undef SS_LAUNCH_K
+    SS_HIP(hipGetLastError());
     return SS_OK;
 }
 
@@ -1343,6 +1471,8 @@ static int launch_plain_or_comb(ss_db *db, bool comb, bool probe, const uint8_t 
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned /*blocks*/,
                      uint64_t n_tiles, bool binned, uint64_t set_id)
 {
+    // k other than 31 (and, under ss_test_hook 4, k = 31 too: the test that holds the two kernels to each other on one index)
+    if (db->k != 31 || g_hook_generic_k.load()) return launch_scan_minik(db, (const uint8_t *)bases_dev, n, stream);
     n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 62 x 16 positions
     const uint8_t *b = (const uint8_t *)bases_dev;
     // SS_COMBINE (A/B runs and tests): 0 never, 1 every scan of a table that expects hits -- binned or not --, 2 every binned scan
@@ -1389,7 +1519,7 @@ namespace {
 // inside its array (a truncated-and-padded or overwritten cache file must fail here, not read out of bounds later).
 __global__ void validate_image_kernel(const uint32_t *__restrict__ slot_of_row, uint64_t n_rows, uint64_t n_slots,
                                       const uint8_t *__restrict__ pages, uint64_t n_pages, const uint64_t *__restrict__ mkeys,
-                                      uint64_t n_mslots, uint32_t *__restrict__ bad)
+                                      uint64_t n_mslots, uint32_t e_max /* k - 15 */, uint32_t *__restrict__ bad)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rows) {
@@ -1408,7 +1538,7 @@ __global__ void validate_image_kernel(const uint32_t *__restrict__ slot_of_row, 
                 const uint64_t cnt = mkeys[start] >> 32;          // header at start, k-mers at start + 1 .. start + cnt
                 if (cnt < 1 || cnt > n_mslots || start + cnt >= n_mslots) atomicAdd(bad, 1u);
             }
-        } else if (hi8 != ss::PG_EMPTY_HI && (hi8 & 31u) > 16u) atomicAdd(bad, 1u);
+        } else if (hi8 != ss::PG_EMPTY_HI && (hi8 & 31u) > e_max) atomicAdd(bad, 1u);
     }
 }
 
@@ -1512,7 +1642,7 @@ int ss_db_import(const char *path, ss_db **out)
     ImageHeader h;
     struct stat st;
     if (fstat(fd, &st) != 0 || pread(fd, &h, sizeof(h), 0) != (ssize_t)sizeof(h) || memcmp(h.magic, "SSIDX10", 8) != 0 ||
-        h.layout != 1 || h.k != 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_dir_alloc != h.n_dir + h.n_dir / 1024 || h.n_slots != h.n_mslots + (uint64_t)h.n_dir_alloc * 8 ||
+        h.layout != 1 || h.k < ss::MINI_K_MIN || h.k > 31 || h.n_mslots == 0 || h.n_dir < ss::PG_MIN_PAGES || h.n_dir_alloc != h.n_dir + h.n_dir / 1024 || h.n_slots != h.n_mslots + (uint64_t)h.n_dir_alloc * 8 ||
         h.n_slots >= 0xFFFFFFF0ull || h.n_mslots >= (uint64_t)ss::START_MASK || (h.bloom_bits && (h.bloom_bits < 10 || h.bloom_bits > 30))) {
         close(fd);
         return SS_EINVAL;
@@ -1547,7 +1677,7 @@ int ss_db_import(const char *path, ss_db **out)
         ok = hipMalloc((void **)&d_bad, 4) == hipSuccess && hipMemset(d_bad, 0, 4) == hipSuccess;
         if (ok) {
             hipLaunchKernelGGL(validate_image_kernel, dim3((unsigned)((nchk + 255) / 256)), dim3(256), 0, 0, db->d_slot_of_row, h.n_rows,
-                               h.n_slots, (const uint8_t *)db->d_dir, (uint64_t)h.n_dir_alloc, db->d_mkeys, h.n_mslots, d_bad);
+                               h.n_slots, (const uint8_t *)db->d_dir, (uint64_t)h.n_dir_alloc, db->d_mkeys, h.n_mslots, (uint32_t)(h.k - ss::MINI_M), d_bad);
             ok = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
         }
         hipFree(d_bad);

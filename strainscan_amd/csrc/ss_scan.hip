@@ -241,10 +241,11 @@ int ss_db_build(const uint64_t *keys, const uint8_t *flags, uint64_t n_rows, int
     db->capacity = 1ull << log2cap;
     db->n_slots = db->capacity;
     if (hipGetDevice(&db->device) != hipSuccess) { delete db; return SS_ENODEV; }
-    // layout: minimizer buckets for k = 31 (the tree scan and the default layer-2 k), flat table
-    // otherwise; SS_LAYOUT=flat|mini overrides for A/B measurements
+    // layout: minimizer pages for 17 <= k <= 31 (k = 31, the tree scan and the default layer-2 k, through the tuned kernel;
+    // the other k through the one-lane-per-position kernel, ss_mini.hip scan_minik_kernel), flat table below that;
+    // SS_LAYOUT=flat overrides for A/B measurements
     const char *lay = getenv("SS_LAYOUT");
-    db->layout = (k == 31) ? 1 : 0;
+    db->layout = (k >= ss::MINI_K_MIN && k <= 31) ? 1 : 0;
     if (lay && !strcmp(lay, "flat")) db->layout = 0;
     if (db->layout == 1) {
         int mrc = ss::build_mini(db, keys, flags, n_rows, upper_keys);

@@ -82,6 +82,16 @@ __host__ __device__ __forceinline__ uint32_t flank_of_key(uint64_t key, uint32_t
     return (uint32_t)(r >> 30);
 }
 
+// the same for a k-mer of any length MINI_M + 2 <= k <= 31 (round 6: `-k` other than 31 on the page index): the key has 2 k bits,
+// the flank k - 15 bases (2 k - 30 bits).  k = 31 gives flank_of_key.
+constexpr int MINI_K_MIN = MINI_M + 2;           // 17: at least three m-mers per k-mer (below that the flat table serves)
+__host__ __device__ __forceinline__ uint32_t flank_of_key_k(uint64_t key, uint32_t off, int k)
+{
+    const uint64_t M = (1ull << (2 * k)) - 1;
+    const uint64_t r = off ? (((key >> (2 * off)) | (key << (2 * k - 2 * off))) & M) : key;
+    return (uint32_t)(r >> 30);
+}
+
 // minimizer (the m-mer itself) of a k-mer and its LEFTMOST offset inside the k-mer
 __host__ __device__ inline uint32_t mini_of_key(uint64_t key, int k, uint32_t *offset)
 {

@@ -100,13 +100,17 @@ def _random_db_and_reads(seed, n_sites, n_reads, read_len=150, k=31):
     return kfa, b"\n".join(recs) + b"\n"
 
 
-@pytest.mark.parametrize("k", [31, 21, 5])
+@pytest.mark.parametrize("k", [31, 21, 5, 17, 19, 23, 25, 27, 29, 30, 16])
 def test_random_vs_oracle(L, k):
+    """Hit counts bit-exact against the oracle (pinned to the real jellyfish at k = 31) at every k the reference's `-k` can ask
+    for: 17..31 on the minimizer-paged index (31 through the tuned kernel, the others through scan_minik_kernel: round 6),
+    16 and below on the flat table."""
     from oracle import oracle as orc
     kfa, flat = _random_db_and_reads(1234 + k, 120000 if k > 5 else 300, 30000, k=k)
     fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
     want, want_valid = orc.jellyfish_count(kfa, [fq], k=k, upper=True)
     db = L.KmerDB.from_text(kfa, k, True)
+    assert db.info()["layout"] == (1 if 17 <= k <= 31 else 0)      # 1: minimizer pages, 0: flat table
     db.scan_flat(flat)
     assert np.array_equal(db.row_valid, want_valid)
     assert np.array_equal(db.counts_rows(), want)
@@ -1544,3 +1548,90 @@ def test_binning_falls_back_when_one_record_differs(L):
         assert sorted(back) == sorted(r for chunk in recs for r in chunk.split(b"\n") if r), name
         rset.close()
     db.close()
+
+
+@pytest.mark.parametrize("shape", ["sampled", "dense", "repeats"])
+def test_any_k_kernel_equals_tuned_kernel_at_31(L, shape):
+    """ss_test_hook(4): the any-k kernel of the page index (scan_minik_kernel, one lane per start position) scans a k = 31
+    table too -- the SAME index image, the same reads, through both kernels: equal counters slot for slot.  Sampled node
+    sets (inline k-mers, no Bloom filter), a dense table with a Bloom filter (bucket references, super-k-mers), and a
+    table full of repeats (several k-mers per minimizer offset: the `multi` buckets, low-complexity minimizers)."""
+    import torch
+    from oracle import oracle as orc
+    if shape == "sampled":
+        kfa, flat = _random_db_and_reads(501, 200000, 40000)
+    elif shape == "dense":
+        kfa, flat = _dense_case(seed=6, G=60000, n_reads=20000)
+    else:
+        rs = np.random.RandomState(9)
+        unit = bytes(np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=40)])
+        g = (unit * 40 + b"A" * 80 + b"ACAC" * 30 + unit[::-1] * 20)
+        g = g + bytes(np.frombuffer(b"ACGT", np.uint8)[rs.randint(0, 4, size=5000)]) + g[:700]
+        kfa = b"".join(b">1\n" + g[i:i + 31] + b"\n" for i in range(len(g) - 30))
+        flat = b"\n".join(g[s:s + 150] for s in rs.randint(0, len(g) - 150, size=4000)) + b"\n"
+    db = L.KmerDB.from_text(kfa, 31, True)
+    assert db.info()["layout"] == 1
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+    want, _ = orc.jellyfish_count(kfa, [fq], k=31, upper=True)
+    d = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    got = {}
+    try:
+        for hook in (0, 1):
+            L.check(L.lib().ss_test_hook(4, hook), "ss_test_hook")
+            for off in (0, 3):                                     # aligned and unaligned block
+                t = torch.zeros(d.numel() + 16, dtype=torch.uint8, device="cuda")
+                t[off:off + d.numel()] = d
+                db.reset()
+                torch.cuda.synchronize()
+                db.scan_flat_dev(t.data_ptr() + off, d.numel(), torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                got[(hook, off)] = db.counts_rows().copy()
+    finally:
+        L.check(L.lib().ss_test_hook(4, 0), "ss_test_hook")
+    for key, c in got.items():
+        assert np.array_equal(c, want), (shape, key)
+    db.close()
+
+
+@pytest.mark.parametrize("k", [21, 25, 27])
+def test_any_k_index_image_and_resident_reads(L, k, tmp_path):
+    """k other than 31 on the page index through the rest of the ABI: the index image round trip (ss_db_export / ss_db_import),
+    a binned resident read set, several tables in one call (a k = 25 table beside k = 31 ones), a dense table with its Bloom
+    filter -- counts equal to the oracle's every time."""
+    import torch
+    from oracle import oracle as orc
+    rs = np.random.RandomState(k)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    g = lut[rs.randint(0, 4, size=80000)].tobytes()
+    kfa = b"".join(b">1\n" + g[i:i + k] + b"\n>1\n" + synth.revcomp(g[i:i + k]) + b"\n" for i in range(0, 70000))
+    recs = []
+    for s_ in rs.randint(0, 80000 - 150, size=15000):
+        r = g[s_:s_ + int(rs.randint(k, 151))]
+        recs.append(synth.revcomp(r) if rs.random_sample() < 0.5 else r)
+    flat = b"\n".join(recs) + b"\n"
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in recs)
+    want, _ = orc.jellyfish_count(kfa, [fq], k=k, upper=True)
+    db = L.KmerDB.from_text(kfa, k, True)
+    info = db.info()
+    assert info["layout"] == 1
+    db.scan_flat(flat)
+    assert np.array_equal(db.counts_rows(), want)
+    img = str(tmp_path / "k.img")
+    db.export(img)
+    db2 = L.KmerDB.from_image(img)
+    assert db2.info()["k"] == k
+    d = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+    rset = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=True)
+    rset.scan_into(db2)
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db2.counts_rows(), want)
+    kfa31, _ = _random_db_and_reads(77, 30000, 10)
+    db31 = L.KmerDB.from_text(kfa31, 31, True)
+    db.reset()
+    db2.reset()
+    rset.scan_into_many([db31, db, db2])
+    L.check(L.lib().ss_device_sync(), "sync")
+    assert np.array_equal(db.counts_rows(), want) and np.array_equal(db2.counts_rows(), want)
+    rset.close()
+    for x in (db, db2, db31):
+        x.close()
