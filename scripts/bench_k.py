@@ -29,7 +29,7 @@ def main():
     genome_len = rows // 2 * 20 + 64
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev)
     out = []
-    for k in (31, 27, 25, 21, 17):
+    for k in [int(x) for x in os.environ.get("BENCH_K_LIST", "31,27,25,21,17").split(",")]:
         starts = torch.arange(0, rows // 2, device=dev) * 20
         idx = starts[:, None] + torch.arange(k, device=dev)[None, :]
         fw = genome[idx]

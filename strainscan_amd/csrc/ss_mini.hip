@@ -1238,13 +1238,22 @@ int mark_solid(ss_db *db)
 // the same address in one wave instruction -- one sector from L2 / HBM per run, as above, with no run queues at all.
 // ~70 lane instructions per position at k = 25 against the tuned kernel's 45 at k = 31.
 // ---------------------------------------------------------------------------------------------
-constexpr int KT = 256, KPOS = 1024, KW = KPOS / 16 + 3;      // threads, start positions per tile, 16-base code words per tile (tile + 48 bases)
+constexpr int KT = 64, KPOS = 1024, KW = KPOS / 16 + 3;      // one wave per workgroup; start positions per tile; 16-base code words per tile (tile + 48 bases)
+constexpr int KQ = 320;                                       // candidates (positions whose page has a slot with their tag) queued at a time:
+                                                              // a round of 256 positions adds at most 256 to fewer than 64
 struct KShared {
     uint32_t code[KW + 1];
     alignas(8) uint16_t inv[KW + 5];
-    uint32_t key[KPOS + 16];
+    alignas(16) uint32_t key[KPOS + 32];
+    uint2 q[KQ];                                              // position | minimizer offset << 10, h
 };
 
+// How the time of a first version went (4 M reads, k = 25, profiles/r06_ab_log.md): one lane per position, four positions of a
+// thread one after the other: 4.0 ms -- 1.9 of it the minimizers (a loop of k - 14 dependent LDS reads per position at five waves
+// per SIMD), 0.2 the page sectors, 2.4 the slots: 4 % of the positions hit, so nearly every wave walked the whole hit path, four
+// times per tile.  Hence: a lane owns FOUR ADJACENT positions and reads their k - 11 keys once, as five 16-byte LDS loads (the
+// four windows share all but three keys on either side); the four page heads are in flight together; positions whose page shows
+// their tag (or is full) are compacted into an LDS queue with ballots and settled ONCE per tile, one candidate per lane.
 template <bool ALIGNED, bool BLOOM>
 __global__ __launch_bounds__(KT) void scan_minik_kernel(const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, int k,
                                                         const uint64_t *__restrict__ mkeys, const uint4 *__restrict__ pages, uint32_t n_pages,
@@ -1253,84 +1262,182 @@ __global__ __launch_bounds__(KT) void scan_minik_kernel(const uint8_t *__restric
 {
     __shared__ KShared S;
     const int t = threadIdx.x;
-    const uint32_t W = (uint32_t)(k - ss::MINI_M + 1), F = W - 1u;
+    const uint32_t W = (uint32_t)(k - ss::MINI_M + 1), F = W - 1u;      // m-mers per k-mer (3..17), flank bases
     const uint64_t kmask = (1ull << (2 * k)) - 1ull, vmask = (1ull << k) - 1ull;
+    // one k-mer against the slots of its minimizer's page(s): position p of the tile, minimizer offset o, h = mix30(minimizer)
+    auto settle = [&](uint32_t p, uint32_t o, uint32_t h, uint32_t page) {
+        const uint32_t w0 = p >> 4, sh = 2 * (p & 15);
+        const uint32_t lo = __builtin_amdgcn_alignbit(S.code[w0 + 1], S.code[w0], sh), hi = __builtin_amdgcn_alignbit(S.code[w0 + 2], S.code[w0 + 1], sh);
+        const uint64_t key = (((uint64_t)hi << 32) | lo) & kmask;      // bases p .. p + k - 1, base i at bits 2 i
+        const uint32_t tt = (h & 0xFFu) * 0x01010101u;
+        bool full;
+        do {
+            const uint4 tg = pages[(uint64_t)page * 4u];                        // (in L1 / L2: the lookup has just read it)
+            const uint32_t x0 = tg.x ^ tt, x1 = tg.y ^ tt;                      // zero byte = tag8 matches
+            const uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u;
+            const uint32_t z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
+            uint32_t hit = (z0 >> 7) | (z1 >> 3);                               // slot s at bit 8 (s & 3) + 4 (s >> 2)
+            const char *pb = reinterpret_cast<const char *>(pages) + (uint64_t)page * 64u;
+            while (hit) {
+                const uint32_t b = (uint32_t)__ffs(hit) - 1u, sl = (b >> 3) + (b & 4u);
+                hit &= hit - 1u;
+                const uint32_t hi8 = (((b & 4u) ? tg.w : tg.z) >> (b & 24u)) & 0xFFu;
+                if (hi8 & 0x80u) {                                              // bucket reference
+                    if ((hi8 ^ (h >> 8)) & 0x3Fu) continue;
+                    const uint32_t l32 = reinterpret_cast<const uint32_t *>(pb + 16)[sl];
+                    const uint32_t mask = reinterpret_cast<const uint16_t *>(pb + 48)[sl] | ((hi8 & 0x40u) << 10);
+                    const uint32_t bstart = l32 & ss::START_MASK;
+                    bool found = false;
+                    if ((mask >> o) & 1u) {
+                        const uint32_t cpos = bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u));
+                        if (mkeys[cpos] == key) { atomicAdd(&counts[cpos], 1u); found = true; }
+                    }
+                    if (!found && (l32 >> 31)) {                                // several k-mers per offset: look through the bucket
+                        const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
+                        for (uint32_t c = 0; c < cnt; c++)
+                            if (mkeys[bstart + 1u + c] == key) { atomicAdd(&counts[bstart + 1u + c], 1u); break; }
+                    }
+                } else if ((hi8 & 31u) == F - o) {                              // an inline k-mer with this minimizer offset
+                    const uint32_t mid = reinterpret_cast<const uint16_t *>(pb + 48)[sl];
+                    if ((mid >> 4) == ((h >> 8) & 0xFFFu) && reinterpret_cast<const uint32_t *>(pb + 16)[sl] == ss::flank_of_key_k(key, o, k))
+                        atomicAdd(&counts[cbase + page * 8u + sl], 1u);
+                }
+            }
+            full = (tg.w >> 24) != (uint32_t)ss::PG_EMPTY_HI;
+            page++;                                                             // (the build guarantees a non-full page before the array ends)
+        } while (full);
+    };
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t b0 = tile * (uint64_t)KPOS;
         __syncthreads();                                   // (the tile before is done with S)
-        if (t < KW) {
+        // ---- bases -> codes + invalid flags: 16 bases per lane, the 48 behind the tile by lanes 0..2
+        {
             uint32_t w[4], code, inv;
             load16<ALIGNED>(bases, b0 + (uint64_t)t * 16, n, w);
             encode16(w, code, inv);
             S.code[t] = code;
             S.inv[t] = (uint16_t)inv;
-        } else if (t < KW + 5) {
-            if (t == KW) S.code[KW] = 0u;
-            S.inv[t] = 0xFFFFu;
-        }
-        __syncthreads();
-        for (uint32_t p = (uint32_t)t; p < (uint32_t)KPOS + 16u; p += KT) {
-            const uint32_t x = __builtin_amdgcn_alignbit(S.code[(p >> 4) + 1], S.code[p >> 4], 2 * (p & 15));
-            S.key[p] = ss::mmkey(x) & ss::KEY_MASK;       // (mmkey looks at the low 24 bits only)
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (uint32_t p = (uint32_t)t; p < (uint32_t)KPOS; p += KT) {
-            // live: the k bases from p on are all ACGT (bytes beyond the block read as '\n')
-            uint64_t iv;
-            __builtin_memcpy(&iv, &S.inv[p >> 4], 8);
-            if ((iv >> (p & 15)) & vmask) continue;
-            uint32_t best = S.key[p], o = 0;
-            for (uint32_t i = 1; i < W; i++) {
-                const uint32_t kk = S.key[p + i];
-                if (kk < best) { best = kk; o = i; }
+            if (t < 3) {
+                load16<ALIGNED>(bases, b0 + (uint64_t)(KT + t) * 16, n, w);
+                encode16(w, code, inv);
+                S.code[KT + t] = code;
+                S.inv[KT + t] = (uint16_t)inv;
+            } else if (t < 8) {
+                if (t == 3) S.code[KW] = 0u;
+                S.inv[KT + t] = 0xFFFFu;
             }
-            const uint32_t q = p + o;                       // tile position of the minimizer
-            const uint32_t x = __builtin_amdgcn_alignbit(S.code[(q >> 4) + 1], S.code[q >> 4], 2 * (q & 15)) & ss::M30;
-            const uint32_t h = ss::mix30(x);
-            if (BLOOM && !((bloom[h >> (bloom_shift + 5)] >> ((h >> bloom_shift) & 31u)) & 1u)) continue;
-            // the k-mer: bases p .. p + k - 1, base i at bits 2 i
-            const uint32_t w0 = p >> 4, sh = 2 * (p & 15);
-            const uint32_t lo = __builtin_amdgcn_alignbit(S.code[w0 + 1], S.code[w0], sh), hi = __builtin_amdgcn_alignbit(S.code[w0 + 2], S.code[w0 + 1], sh);
-            const uint64_t key = (((uint64_t)hi << 32) | lo) & kmask;
-            uint32_t page = ss::page_of(h, n_pages);
-            const uint32_t tt = (h & 0xFFu) * 0x01010101u;
-            bool full;
-            do {
-                const uint4 tg = pages[(uint64_t)page * 4u];
-                const uint32_t x0 = tg.x ^ tt, x1 = tg.y ^ tt;                  // zero byte = tag8 matches
-                const uint32_t z0 = ~(((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u;
-                const uint32_t z1 = ~(((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u;
-                uint32_t hit = (z0 >> 7) | (z1 >> 3);                           // slot s at bit 8 (s & 3) + 4 (s >> 2)
-                const char *pb = reinterpret_cast<const char *>(pages) + (uint64_t)page * 64u;
-                while (hit) {
-                    const uint32_t b = (uint32_t)__ffs(hit) - 1u, sl = (b >> 3) + (b & 4u);
-                    hit &= hit - 1u;
-                    const uint32_t hi8 = (((b & 4u) ? tg.w : tg.z) >> (b & 24u)) & 0xFFu;
-                    if (hi8 & 0x80u) {                                          // bucket reference
-                        if ((hi8 ^ (h >> 8)) & 0x3Fu) continue;
-                        const uint32_t l32 = reinterpret_cast<const uint32_t *>(pb + 16)[sl];
-                        const uint32_t mask = reinterpret_cast<const uint16_t *>(pb + 48)[sl] | ((hi8 & 0x40u) << 10);
-                        const uint32_t bstart = l32 & ss::START_MASK;
-                        bool found = false;
-                        if ((mask >> o) & 1u) {
-                            const uint32_t cpos = bstart + 1u + (uint32_t)__popc(mask & ((1u << o) - 1u));
-                            if (mkeys[cpos] == key) { atomicAdd(&counts[cpos], 1u); found = true; }
-                        }
-                        if (!found && (l32 >> 31)) {                            // several k-mers per offset: look through the bucket
-                            const uint32_t cnt = (uint32_t)(mkeys[bstart] >> 32);
-                            for (uint32_t c = 0; c < cnt; c++)
-                                if (mkeys[bstart + 1u + c] == key) { atomicAdd(&counts[bstart + 1u + c], 1u); break; }
-                        }
-                    } else if ((hi8 & 31u) == F - o) {                          // an inline k-mer with this minimizer offset
-                        const uint32_t mid = reinterpret_cast<const uint16_t *>(pb + 48)[sl];
-                        if ((mid >> 4) == ((h >> 8) & 0xFFFu) && reinterpret_cast<const uint32_t *>(pb + 16)[sl] == ss::flank_of_key_k(key, o, k))
-                            atomicAdd(&counts[cbase + page * 8u + sl], 1u);
-                    }
+        }
+        __syncthreads();
+        // ---- ordering keys of the m-mers that start in the lane's 16 bases (and the 16 behind the tile: lanes 0..15, one each)
+        {
+            const uint32_t c0 = S.code[t], c1 = S.code[t + 1];
+            uint32_t kk[16];
+            kk[0] = ss::mmkey(c0) & ss::KEY_MASK;
+#pragma unroll
+            for (int i = 1; i < 16; i++) kk[i] = ss::mmkey(__builtin_amdgcn_alignbit(c1, c0, 2 * i)) & ss::KEY_MASK;      // (mmkey looks at the low 24 bits only)
+#pragma unroll
+            for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(&S.key[16 * t])[i] = make_uint4(kk[4 * i], kk[4 * i + 1], kk[4 * i + 2], kk[4 * i + 3]);
+            if (t < 16) {
+                const uint32_t q = (uint32_t)KPOS + (uint32_t)t;
+                S.key[q] = ss::mmkey(__builtin_amdgcn_alignbit(S.code[(q >> 4) + 1], S.code[q >> 4], 2 * (q & 15))) & ss::KEY_MASK;
+            } else if (t < 32) {
+                S.key[KPOS + t] = 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+        uint32_t nq = 0;                                   // candidates queued (the same in every lane)
+#pragma unroll 1
+        for (uint32_t g = 0; g <= (uint32_t)(KPOS / (4 * KT)); g++) {
+            if (g < (uint32_t)(KPOS / (4 * KT))) {
+            const uint32_t p0 = 4u * ((uint32_t)t + (uint32_t)KT * g);
+            // the 20 keys from p0 on, each tagged with its distance from p0 in its five free low bits: ONE v_min decides key
+            // and leftmost position.  Window j = keys j .. j + W - 1 = {j..2} + {3..W-1} (common to the four) + {W..W+j-1}
+            // (W is the same for the whole launch: the loops below leave through SCALAR branches -- no lane predicate, one v_min per key)
+            uint32_t K[20];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (i && (uint32_t)(4 * i) >= W) break;
+                const uint4 v = reinterpret_cast<const uint4 *>(&S.key[p0])[i];
+                K[4 * i] = v.x | (uint32_t)(4 * i); K[4 * i + 1] = v.y | (uint32_t)(4 * i + 1);
+                K[4 * i + 2] = v.z | (uint32_t)(4 * i + 2); K[4 * i + 3] = v.w | (uint32_t)(4 * i + 3);
+            }
+            const uint32_t T0 = S.key[p0 + W] | W, T1 = S.key[p0 + W + 1u] | (W + 1u), T2 = S.key[p0 + W + 2u] | (W + 2u);
+            uint32_t common = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 3; i < 17; i++) {
+                if ((uint32_t)i >= W) break;
+                common = min(common, K[i]);
+            }
+            uint32_t m_[4];
+            m_[0] = min(min(K[0], K[1]), min(K[2], common));
+            m_[1] = min(min(K[1], K[2]), min(common, T0));
+            m_[2] = min(min(K[2], common), min(T0, T1));
+            m_[3] = min(min(common, T0), min(T1, T2));
+            uint64_t iv;
+            __builtin_memcpy(&iv, &S.inv[p0 >> 4], 8);
+            iv >>= (p0 & 15u);
+            uint32_t h_[4], page_[4];
+            uint4 tg_[4];
+            bool go_[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                go_[j] = ((iv >> j) & vmask) == 0;          // live: the k bases from p0 + j on are all ACGT (bytes beyond the block read as '\n')
+                const uint32_t q = p0 + (m_[j] & 31u);       // tile position of the minimizer
+                const uint32_t x = __builtin_amdgcn_alignbit(S.code[(q >> 4) + 1], S.code[q >> 4], 2 * (q & 15)) & ss::M30;
+                h_[j] = ss::mix30(x);
+                page_[j] = ss::page_of(h_[j], n_pages);
+            }
+#if defined(SS_KSTOP) && SS_KSTOP == 1      // (debug builds: the time of the phases up to here; results are then of course wrong)
+            { uint32_t acc = 0; for (int r = 0; r < 4; r++) acc ^= h_[r] ^ m_[r] ^ (uint32_t)go_[r]; if (acc == 0x12345678u) atomicAdd(&counts[0], 1u); continue; }
+#endif
+            if (BLOOM) {
+                uint32_t bw[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bw[j] = go_[j] ? bloom[h_[j] >> (bloom_shift + 5)] : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) go_[j] = go_[j] && ((bw[j] >> ((h_[j] >> bloom_shift) & 31u)) & 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                tg_[j] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);      // (an empty page: nothing matches, not full)
+                if (go_[j]) tg_[j] = pages[(uint64_t)page_[j] * 4u];
+            }
+#if defined(SS_KSTOP) && SS_KSTOP == 2
+            { uint32_t acc = 0; for (int r = 0; r < 4; r++) acc ^= tg_[r].x ^ tg_[r].w ^ m_[r]; if (acc == 0x12345678u) atomicAdd(&counts[0], 1u); continue; }
+#endif
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // a candidate: some slot of the page carries the minimizer's tag8 AND is either an inline k-mer with THIS k-mer's
+                // minimizer offset (hi8 == e = F - o) or a bucket reference with the minimizer's filter bits (hi8 = 0x80 | mask bit
+                // 16 << 6 | h[13:8]) -- all eight slots at once, on the 16 bytes the lookup has read (a read k-mer shares its
+                // minimizer with a database k-mer six times as often as it IS one); or the page is full (its slots may go on)
+                auto zb = [](uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; };      // 0x80 where a byte is zero
+                const uint32_t tt = (h_[j] & 0xFFu) * 0x01010101u;
+                const uint32_t e4 = (F + (uint32_t)j - (m_[j] & 31u)) * 0x01010101u, r4 = (0x80u | ((h_[j] >> 8) & 0x3Fu)) * 0x01010101u;
+                const uint32_t c0 = zb(tg_[j].x ^ tt) & (zb(tg_[j].z ^ e4) | zb((tg_[j].z ^ r4) & 0xBFBFBFBFu));
+                const uint32_t c1 = zb(tg_[j].y ^ tt) & (zb(tg_[j].w ^ e4) | zb((tg_[j].w ^ r4) & 0xBFBFBFBFu));
+                const bool cand = go_[j] && ((c0 | c1) != 0u || (tg_[j].w >> 24) != (uint32_t)ss::PG_EMPTY_HI);
+                const uint64_t bal = __ballot(cand);
+                if (cand) S.q[nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+                    make_uint2((p0 + (uint32_t)j) | (((m_[j] & 31u) - (uint32_t)j) << 10), h_[j]);
+                nq += (uint32_t)__popcll(bal);
+            }
+            }
+#if defined(SS_KSTOP) && SS_KSTOP == 3
+            if (nq == 0x12345678u) atomicAdd(&counts[0], S.q[t].x);
+            nq = 0;
+            continue;
+#endif
+            // ---- the candidates, one per lane, whenever a wave's worth has come together (and at the end of the tile)
+            if (nq >= (uint32_t)KT || g == (uint32_t)(KPOS / (4 * KT))) {
+                __syncthreads();
+                for (uint32_t e = (uint32_t)t; e < nq; e += KT) {
+                    const uint2 c = S.q[e];
+                    settle(c.x & 1023u, c.x >> 10, c.y, ss::page_of(c.y, n_pages));
                 }
-                full = (tg.w >> 24) != (uint32_t)ss::PG_EMPTY_HI;
-                page++;                                                         // (the build guarantees a non-full page before the array ends)
-            } while (full);
+                __syncthreads();
+                nq = 0;
+            }
         }
     }
 }
@@ -1339,7 +1446,8 @@ std::atomic<long long> g_hook_generic_k{0};      // ss_test_hook(4, ...)
 static int launch_scan_minik(ss_db *db, const uint8_t *b, uint64_t n, hipStream_t stream)
 {
     const uint64_t n_tiles = (n + KPOS - 1) / KPOS;
-    const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)256 * 8 * 16);
+    static const uint64_t blocks_env = [] { const char *e = getenv("SS_KBLOCKS"); return e ? (uint64_t)atoll(e) : 0ull; }();      // (A/B runs)
+    const unsigned blocks = (unsigned)std::min<uint64_t>(n_tiles, blocks_env ? blocks_env : (uint64_t)256 * 32 * 16);      // (one-wave workgroups, grid stride: many short blocks)
     const bool aligned = (((uintptr_t)b) & 15) == 0;
     const uint4 *pages = reinterpret_cast<const uint4 *>(db->d_dir);
     const uint32_t cbase = (uint32_t)db->n_mslots, bshift = 30u - db->bloom_bits;
