@@ -363,6 +363,21 @@ int ss_rows_reduce(const ss_db *db, const uint32_t *rows, uint64_t n, ss_node_st
 typedef struct ss_l2 ss_l2;
 /* CSR of the K x S binary matrix (scipy.sparse.load_npz of all_strains_re.npz, :200) */
 int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out);
+/* The same with the column indices already in DEVICE memory (4-byte aligned; read, not kept).  With ss_npz_member_dev: the
+ * `indices.npy` member of all_strains_re.npz inflated on the device and packed from there -- a first run against a database
+ * spent 2.3 of its 3.5 s inflating these members on one host thread (np.load), 2.5 GB for a 5 M x 300 cluster. */
+int ss_l2_create_dev(const int64_t *indptr, const int32_t *indices_dev, uint64_t K, uint32_t S, ss_l2 **out);
+/* A deflated member of a ZIP archive (scipy.sparse.save_npz writes one .npy array per member: Recls_withR_new.py:110-112,
+ * Build_overlap_matrix_sp.py:89-98) inflated on the device: raw deflate data at [off, off + comp_n) of `path`, content CRC-32
+ * and length as the archive's directory states them (both are checked).  *d_data (64-byte aligned, *n == usize bytes: the
+ * .npy header, then the array) is lent until ss_npz_member_done(*lease).  SS_ERANGE: the device inflater declined (no
+ * dynamic-Huffman block to enter, an extreme ratio, too small) -- read the member on the host. */
+int ss_npz_member_dev(const char *path, uint64_t off, uint64_t comp_n, uint32_t crc, uint64_t usize, void **d_data, uint64_t *n,
+                      void **lease);
+int ss_npz_member_done(void *lease);
+/* zlib's CRC-32 of (a prefix whose CRC-32 is prefix_crc) followed by n copies of `byte`, in O(log n): what the `data.npy`
+ * member of a binary matrix must have for its content to be nnz ones -- known without inflating it. */
+int ss_crc32_repeat(uint32_t prefix_crc, int byte, uint64_t n, uint32_t *out);
 /* The same matrix as ready-made bit planes: planes[s * W + k / 32] bit k % 32, W = words_per_plane =
  * ((K + 31) / 32 rounded up to a multiple of 4), bits beyond K zero.  ss_l2_export_planes writes that
  * array (S * W dwords) from a handle: the host keeps it as a per-cluster image so that later runs skip

@@ -2607,6 +2607,72 @@ extern "C" int ss_gz_inflate_gpu(const char *path, char **text, uint64_t *len)
     return SS_OK;
 }
 
+// A deflated member of a ZIP archive (a .npy array of scipy.sparse.save_npz: all_strains_re.npz, Recls_withR_new.py:110-112)
+// inflated on the device and LEFT there: raw deflate data at [off, off + comp_n) of the file, CRC-32 and length of the content
+// as the archive's directory states them.  The member is dressed as a gzip member (10-byte header in front, CRC-32 + ISIZE
+// behind: the inflater checks both) and goes through gpu_gunzip.  *d_data is lent until ss_npz_member_done(*lease).
+// SS_ERANGE: not handled here (no dynamic blocks to enter, too small, an absurd ratio): the caller reads it on the host.
+extern "C" int ss_npz_member_dev(const char *path, uint64_t off, uint64_t comp_n, uint32_t crc, uint64_t usize, void **d_data, uint64_t *n,
+                                 void **lease)
+{
+    if (!path || !d_data || !n || !lease || comp_n < 64) return SS_EINVAL;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return SS_EIO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < off + comp_n) { close(fd); return SS_EIO; }
+    const uint64_t in_n = 10 + comp_n + 8;
+    std::unique_ptr<uint8_t[]> img(new (std::nothrow) uint8_t[in_n]);
+    if (!img) { close(fd); return SS_ENOMEM; }
+    static const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+    memcpy(img.get(), hdr, 10);
+    {   // the compressed bytes, by a few threads (the page cache hands a single pread ~3 GB/s)
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, comp_n >> 24));
+        std::atomic<bool> ok(true);
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < T; w++)
+            pool.emplace_back([&, w] {
+                uint64_t a = comp_n * w / T;
+                const uint64_t e = comp_n * (w + 1) / T;
+                while (a < e) {
+                    const ssize_t r = pread(fd, img.get() + 10 + a, (size_t)std::min<uint64_t>(e - a, 1u << 30), (off_t)(off + a));
+                    if (r <= 0) { ok = false; return; }
+                    a += (uint64_t)r;
+                }
+            });
+        for (auto &th : pool) th.join();
+        close(fd);
+        if (!ok) return SS_EIO;
+    }
+    uint8_t *t8 = img.get() + 10 + comp_n;
+    for (int q = 0; q < 4; q++) { t8[q] = (uint8_t)(crc >> (8 * q)); t8[4 + q] = (uint8_t)(usize >> (8 * q)); }
+    char *d = nullptr;
+    uint64_t len = 0;
+    void *ls = nullptr;
+    if (!ss::gpu_gunzip(img.get(), in_n, &d, &len, &ls, -1)) return SS_ERANGE;
+    if (len != usize) { ss::gpu_gunzip_done(ls); return SS_EIO; }
+    *d_data = d; *n = len; *lease = ls;
+    return SS_OK;
+}
+extern "C" int ss_npz_member_done(void *lease) { ss::gpu_gunzip_done(lease); return SS_OK; }
+
+// CRC-32 (zlib's) of `prefix` followed by n copies of one byte, from the prefix's CRC: O(log n) crc32_combine steps.  What
+// the `data.npy` member of a binary matrix must have -- a few header bytes, then nnz ones -- so that 630 MB of ones need not
+// be inflated to know that they are ones (the archive's directory carries the content's CRC-32 and length).
+extern "C" int ss_crc32_repeat(uint32_t prefix_crc, int byte, uint64_t n, uint32_t *out)
+{
+    if (!out || byte < 0 || byte > 255) return SS_EINVAL;
+    const unsigned char b = (unsigned char)byte;
+    uLong pw = crc32(crc32(0L, Z_NULL, 0), &b, 1);       // CRC of 2^i copies
+    uLong acc = prefix_crc;
+    uint64_t len = 1;
+    for (uint64_t m = n; m; m >>= 1, len <<= 1) {
+        if (m & 1) acc = crc32_combine(acc, pw, (z_off_t)len);
+        if (m >> 1) pw = crc32_combine(pw, pw, (z_off_t)len);
+    }
+    *out = (uint32_t)acc;
+    return SS_OK;
+}
+
 // the pinned upload buffers of `n_files` concurrent .gz inputs (at most two sets are kept), made ahead of time
 extern "C" int ss_gz_warm_up(int n_files)
 {

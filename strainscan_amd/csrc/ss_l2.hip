@@ -687,7 +687,22 @@ static int l2_fold_impl(const ss_l2 *h, const uint32_t *keep_dev, const uint32_t
     return rc;
 }
 
+static int l2_create_impl(const int64_t *indptr, const int32_t *indices, bool indices_on_device, uint64_t K, uint32_t S, ss_l2 **out);
+
 int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint32_t S, ss_l2 **out)
+{
+    return l2_create_impl(indptr, indices, false, K, S, out);
+}
+
+/* the same with the column indices ALREADY on the device (the inflated `indices.npy` member of all_strains_re.npz,
+ * ss_npz_member_dev: 2.5 GB for a 5 M x 300 cluster that neither visits the host nor crosses PCIe uncompressed) */
+int ss_l2_create_dev(const int64_t *indptr, const int32_t *indices_dev, uint64_t K, uint32_t S, ss_l2 **out)
+{
+    if (indices_dev && (((uintptr_t)indices_dev) & 3u)) return SS_EINVAL;
+    return l2_create_impl(indptr, indices_dev, true, K, S, out);
+}
+
+static int l2_create_impl(const int64_t *indptr, const int32_t *indices, bool indices_on_device, uint64_t K, uint32_t S, ss_l2 **out)
 {
     if (!out || !indptr || indptr[K] < 0 || (indptr[K] && !indices)) return SS_EINVAL;
     ss_l2 *h = new (std::nothrow) ss_l2();
@@ -703,16 +718,17 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
     int rc = SS_OK, bad = 0;
     const uint64_t xbytes = std::max<uint64_t>(1, (uint64_t)S) * h->W * 4;
     if (hipMalloc((void **)&h->d_x, xbytes) != hipSuccess || ss::l2s::dmalloc((void **)&d_ptr, (K + 1) * 8) != hipSuccess ||
-        ss::l2s::dmalloc((void **)&d_idx, std::max<uint64_t>(1, nnz) * 4) != hipSuccess ||
+        (!indices_on_device && ss::l2s::dmalloc((void **)&d_idx, std::max<uint64_t>(1, nnz) * 4) != hipSuccess) ||
         ss::l2s::dmalloc((void **)&d_bad, 4) != hipSuccess) {
         rc = SS_ENOMEM;
     } else if (ss::l2s::set(h->d_x, 0, xbytes) != hipSuccess || ss::l2s::set(d_bad, 0, 4) != hipSuccess ||
                ss::l2s::copy(d_ptr, indptr, (K + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
-               (nnz && ss::l2s::copy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
+               (nnz && !indices_on_device && ss::l2s::copy(d_idx, indices, nnz * 4, hipMemcpyHostToDevice) != hipSuccess)) {
         rc = SS_EHIP;
     } else if ((rc = csr_ptr_check(d_ptr, K, (int64_t)nnz)) != SS_OK) {
         // (a row pointer array the pack kernels could not walk safely)
     } else if (K) {
+        if (indices_on_device) d_idx = const_cast<int32_t *>(indices);                     // (the caller's: read only, not freed here)
         const bool force_atomic = getenv("SS_L2_PACK_ATOMIC") != nullptr;                 // tests: the general kernel
         int redo = 1;
         const bool no_span = getenv("SS_L2_PACK_WALK") != nullptr;                    // A/B and tests: the row-walk kernel
@@ -736,6 +752,7 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
             else if (bad) rc = SS_EINVAL;
         }
     }
+    if (indices_on_device) { d_idx = nullptr; if (ss::l2s::sync() != hipSuccess && !rc) rc = SS_EHIP; }      // (the pack kernels are done with the caller's array)
     ss::l2s::dfree(d_ptr); ss::l2s::dfree(d_idx); ss::l2s::dfree(d_bad);
     if (rc) { hipFree(h->d_x); delete h; return rc; }
     *out = h;

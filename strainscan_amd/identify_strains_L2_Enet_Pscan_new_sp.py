@@ -9,6 +9,9 @@ passes become bit-plane popcounts and masked radix selects on the MI355X
 coordinate descent on exact per-pattern statistics (ss_enet.hip); see SURVEY.md Appendix B/C.
 """
 
+import ctypes as C
+import os
+
 import numpy as np
 
 from . import _lib
@@ -293,6 +296,97 @@ def _load_npz_csr(path):
         return _CSR(indptr, indices, z["data"], shape)
 
 
+_NPZ_DEV_MIN = 4 << 20        # compressed bytes from which a member of all_strains_re.npz is inflated on the device
+
+
+def _npz_directory(path):
+    """The members of a .npz as the ZIP directory lists them: name -> (offset of the member's data in the file, compressed
+    bytes, CRC-32 of the content, content bytes, compression method)."""
+    import struct
+    import zipfile
+    out = {}
+    with zipfile.ZipFile(path) as z, open(path, "rb") as f:
+        for zi in z.infolist():
+            f.seek(zi.header_offset)
+            lh = f.read(30)
+            if len(lh) != 30 or lh[:4] != b"PK\x03\x04":
+                raise ValueError("%s: damaged ZIP local header" % path)
+            nlen, xlen = struct.unpack("<HH", lh[26:30])
+            out[zi.filename] = (zi.header_offset + 30 + nlen + xlen, zi.compress_size, zi.CRC, zi.file_size, zi.compress_type)
+    return out
+
+
+def _npy_header(head):
+    """(dtype, shape, fortran_order, header bytes) of a .npy image whose first bytes are `head`."""
+    import io
+    from numpy.lib import format as npf
+    f = io.BytesIO(head)
+    ver = npf.read_magic(f)
+    shape, fortran, dtype = (npf.read_array_header_1_0 if ver == (1, 0) else npf.read_array_header_2_0)(f)
+    return dtype, shape, fortran, f.tell()
+
+
+def _cluster_image_from_npz(path):
+    """all_strains_re.npz -> ClusterImage with its large members inflated ON THE DEVICE (round 6).  np.load inflates every
+    member on one host thread (zipfile: ~7 ms per million non-zeros; 2.3 of the 3.5 s of a first run against a database with a
+    5 M x 300 cluster): here `indices.npy` -- four bytes per non-zero -- goes through the device inflater (ss_npz_member_dev)
+    and is packed into bit planes from where it lands (ss_l2_create_dev); `data.npy` -- nnz ones -- is not inflated at all:
+    its length and CRC-32, which the archive's directory states, are those of its header followed by nnz bytes 0x01
+    (ss_crc32_repeat), or the file goes the old way.  None: not a file for this route (the caller takes np.load)."""
+    import zipfile
+    import zlib
+    try:
+        d = _npz_directory(path)
+    except (OSError, zipfile.BadZipFile, ValueError):
+        return None
+    need = ("format.npy", "shape.npy", "indptr.npy", "indices.npy", "data.npy")
+    if any(n not in d for n in need):
+        return None
+    off, comp_n, crc, usize, method = d["indices.npy"]
+    if method != zipfile.ZIP_DEFLATED or comp_n < _NPZ_DEV_MIN:
+        return None                                                   # small: np.load is as fast
+    with np.load(path, allow_pickle=False) as z:
+        fmt = z["format"].item()
+        fmt = fmt.decode() if isinstance(fmt, bytes) else fmt
+        if fmt != "csr":
+            return None
+        shape = tuple(int(x) for x in z["shape"])
+        indptr = z["indptr"]
+    if len(shape) != 2 or indptr.ndim != 1 or indptr.dtype.kind != "i" or len(indptr) != shape[0] + 1 or int(indptr[0]) != 0:
+        return None                                                   # (the old way raises what is to be raised)
+    nnz = int(indptr[-1])
+    # data.npy: nnz ones?  Its first bytes (the .npy header) from the head of its deflate stream, the rest from the CRC
+    doff, dcomp, dcrc, dusize, dmethod = d["data.npy"]
+    with open(path, "rb") as f:
+        f.seek(doff)
+        raw = f.read(min(dcomp, 1 << 16))
+    try:
+        head = zlib.decompressobj(-15).decompress(raw, 4096) if dmethod == zipfile.ZIP_DEFLATED else raw[:4096]
+        dtype, dshape, _, hlen = _npy_header(head)
+    except Exception:                                                 # noqa: B902 -- anything odd: the old way
+        return None
+    if dtype != np.dtype(np.int8) or tuple(dshape) != (nnz,) or dusize != hlen + nnz:
+        return None
+    want = C.c_uint32()
+    _lib.check(_lib.lib().ss_crc32_repeat(zlib.crc32(head[:hlen]), 1, nnz, C.byref(want)), "ss_crc32_repeat")
+    if want.value != dcrc:
+        return None                                                   # not all ones (or not canonical): np.load decides
+    dptr, n, lease = C.c_void_p(), C.c_uint64(), C.c_void_p()
+    rc = _lib.lib().ss_npz_member_dev(os.fsencode(path), off, comp_n, crc, usize, C.byref(dptr), C.byref(n), C.byref(lease))
+    if rc == _lib.SS_ERANGE:
+        return None                                                   # the device inflater declined: host
+    _lib.check(rc, "ss_npz_member_dev")
+    try:
+        head = np.zeros(min(int(n.value), 4096), np.uint8)
+        _lib.check(_lib.lib().ss_memcpy_d2h(_lib.ptr(head), dptr, head.size, None), "ss_memcpy_d2h")
+        idt, ishape, _, ihlen = _npy_header(head.tobytes())
+        if idt != np.dtype("<i4") or tuple(ishape) != (nnz,) or int(n.value) != ihlen + 4 * nnz or ihlen % 4:
+            return None                                               # int64 indices and the like: the old way
+        return L2.ClusterImage.from_device_csr(indptr, dptr.value + ihlen, shape[0], shape[1])
+    finally:
+        _lib.lib().ss_npz_member_done(lease)
+
+
 def _write_l2_cache(path, img, om):
     import os
     om = om.tocsr()
@@ -358,7 +452,9 @@ def detect_strains(input_csv, input_y, ids, ksize, npp25, npp75, npp_out, cls_co
     if img is None:
         # scipy reads the .npz through zipfile (inflate + CRC: ~7 ms per million non-zeros); done once per
         # database, the bit planes and the overlap arrays are then kept as a raw image
-        img = L2.ClusterImage(_load_npz_csr(input_csv))
+        img = _cluster_image_from_npz(input_csv)             # large members inflated on the device; None: the host's way
+        if img is None:
+            img = L2.ClusterImage(_load_npz_csr(input_csv))
         om = _load_npz_csr(omatrix)
         if cache:
             try:

@@ -89,6 +89,27 @@ class ClusterImage:
         self.om_cols = None
 
     @classmethod
+    def from_device_csr(cls, indptr, indices_dev, K, S):
+        """Row pointers on the host, column indices (int32) already in device memory at address `indices_dev`: ss_l2_create_dev."""
+        _lib.require_gpu()
+        self = cls.__new__(cls)
+        self.K, self.S = int(K), int(S)
+        indptr = np.ascontiguousarray(indptr, np.int64)
+        if indptr.size != self.K + 1:
+            raise ValueError("CSR arrays do not match the shape (%d row pointers for %d rows)" % (indptr.size, self.K))
+        h = C.c_void_p()
+        rc = _lib.lib().ss_l2_create_dev(_lib.ptr(indptr), C.c_void_p(int(indices_dev)), self.K, self.S, C.byref(h))
+        if rc == _lib.SS_EINVAL:
+            raise ValueError("all_strains_re.npz is not a valid CSR matrix (row pointers or column indices out of range)")
+        _lib.check(rc, "ss_l2_create_dev")
+        self._h = h
+        w = C.c_uint64()
+        _lib.check(_lib.lib().ss_l2_info(h, None, None, C.byref(w)), "ss_l2_info")
+        self.W = int(w.value)
+        self.om_cols = None
+        return self
+
+    @classmethod
     def from_planes(cls, planes, K, S):
         """Bit planes as ss_l2_export_planes wrote them (uint32[S * W])."""
         _lib.require_gpu()

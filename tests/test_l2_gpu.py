@@ -977,3 +977,78 @@ def test_shuffle_split_on_the_device_equals_numpy(n, frac, splits, seed):
     sp2 = l2.SplitDev(n, splits, frac, seed)            # abandoned before its walk is over: freed without a result
     sp2.close()
     assert not l2.SplitDev.usable(1, 0.5) and not l2.SplitDev.usable(5, 0.0) and l2.SplitDev.usable(2, 0.5)
+
+
+@pytest.mark.parametrize("K,S,density", [(400_000, 40, 0.4), (60_000, 300, 0.5)])
+def test_cluster_image_from_npz_on_the_device(K, S, density, tmp_path, monkeypatch):
+    """all_strains_re.npz read WITHOUT np.load's single-threaded inflation (round 6): `indices.npy` inflated on the device from
+    the ZIP member (ss_npz_member_dev, CRC-32 and length checked) and packed from there (ss_l2_create_dev), `data.npy` known to
+    be all ones from its CRC-32 alone (ss_crc32_repeat).  The bit planes equal those of the np.load route bit for bit; files
+    that are not what the route expects (an entry that is not 1, int64 indices, a stored archive, a damaged member) take the
+    old route and end as they always did."""
+    import scipy.sparse as sp
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    from strainscan_amd import l2 as L2
+    rs = np.random.RandomState(K % 1000 + S)
+    dense = (rs.random_sample((K, S)) < density).astype(np.int8)
+    dense[rs.randint(0, K, 50)] = 0                                  # some empty rows
+    X = sp.csr_matrix(dense)
+    p = str(tmp_path / "all_strains_re.npz")
+    sp.save_npz(p, X)
+    monkeypatch.setattr(m, "_NPZ_DEV_MIN", 1 << 16)
+    a, b = C_counters()
+    img = m._cluster_image_from_npz(p)
+    assert img is not None, "the device route declined a canonical file"
+    assert C_counters()[0] == a + 1                                  # the device inflater handled one member
+    ref = L2.ClusterImage(m._load_npz_csr(p))
+    assert (img.K, img.S, img.W) == (ref.K, ref.S, ref.W) and np.array_equal(img.planes(), ref.planes())
+    img.close()
+    # an entry that is not 1: the CRC of data.npy is not that of nnz ones -> old route -> its ValueError
+    Y = X.copy()
+    Y.data[len(Y.data) // 2] = 2
+    p2 = str(tmp_path / "two.npz")
+    sp.save_npz(p2, Y)
+    assert m._cluster_image_from_npz(p2) is None
+    with pytest.raises(ValueError):
+        L2.ClusterImage(m._load_npz_csr(p2))
+    # stored (uncompressed) archive, int64 indices: not for this route, equal planes through the old one
+    p3 = str(tmp_path / "stored.npz")
+    sp.save_npz(p3, X, compressed=False)
+    assert m._cluster_image_from_npz(p3) is None
+    Z = X.copy()
+    Z.indices = Z.indices.astype(np.int64)
+    Z.indptr = Z.indptr.astype(np.int64)
+    p4 = str(tmp_path / "i64.npz")
+    np.savez_compressed(p4, format=np.array("csr".encode()), shape=np.array(Z.shape), data=Z.data, indices=Z.indices, indptr=Z.indptr)
+    got = m._cluster_image_from_npz(p4)
+    assert got is None
+    alt = L2.ClusterImage(m._load_npz_csr(p4))
+    assert np.array_equal(alt.planes(), ref.planes())
+    alt.close()
+    # a damaged member: one byte of the indices' deflate data flipped -> the inflater's CRC check (or its parse) refuses; np.load
+    # raises as before
+    d = m._npz_directory(p)
+    off, comp_n = d["indices.npy"][0], d["indices.npy"][1]
+    raw = bytearray(open(p, "rb").read())
+    raw[off + comp_n // 2] ^= 0x55
+    p5 = str(tmp_path / "bad.npz")
+    open(p5, "wb").write(bytes(raw))
+    try:
+        bad = m._cluster_image_from_npz(p5)
+    except Exception:                                               # noqa: B902 -- an error is an honest answer too
+        bad = None
+    if bad is not None:                                              # (never: the CRC-32 of the content is checked on the device)
+        same = np.array_equal(bad.planes(), ref.planes())
+        bad.close()
+        assert same
+    with pytest.raises(Exception):
+        m._load_npz_csr(p5).indices.sum()
+    ref.close()
+
+
+def C_counters():
+    import ctypes as C
+    from strainscan_amd import _lib
+    a, b = C.c_uint64(), C.c_uint64()
+    _lib.check(_lib.lib().ss_gz_gpu_counters(C.byref(a), C.byref(b)), "ss_gz_gpu_counters")
+    return int(a.value), int(b.value)
