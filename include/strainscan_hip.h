@@ -367,13 +367,14 @@ int ss_l2_create(const int64_t *indptr, const int32_t *indices, uint64_t K, uint
  * `indices.npy` member of all_strains_re.npz inflated on the device and packed from there -- a first run against a database
  * spent 2.3 of its 3.5 s inflating these members on one host thread (np.load), 2.5 GB for a 5 M x 300 cluster. */
 int ss_l2_create_dev(const int64_t *indptr, const int32_t *indices_dev, uint64_t K, uint32_t S, ss_l2 **out);
-/* A deflated member of a ZIP archive (scipy.sparse.save_npz writes one .npy array per member: Recls_withR_new.py:110-112,
- * Build_overlap_matrix_sp.py:89-98) inflated on the device: raw deflate data at [off, off + comp_n) of `path`, content CRC-32
- * and length as the archive's directory states them (both are checked).  *d_data (64-byte aligned, *n == usize bytes: the
- * .npy header, then the array) is lent until ss_npz_member_done(*lease).  SS_ERANGE: the device inflater declined (no
- * dynamic-Huffman block to enter, an extreme ratio, too small) -- read the member on the host. */
-int ss_npz_member_dev(const char *path, uint64_t off, uint64_t comp_n, uint32_t crc, uint64_t usize, void **d_data, uint64_t *n,
-                      void **lease);
+/* A member of a ZIP archive (scipy.sparse.save_npz writes one .npy array per member: Recls_withR_new.py:110-112,
+ * Build_overlap_matrix_sp.py:89-98) brought to the device: the member's data at [off, off + comp_n) of `path`, content CRC-32
+ * and length as the archive's directory states them (both are checked).  method 8 (deflated): inflated on the device;
+ * method 0 (stored): uploaded through pinned pieces whose CRCs are taken by the reading threads.  *d_data (64-byte aligned,
+ * *n == usize bytes: the .npy header, then the array) is lent until ss_npz_member_done(*lease).  SS_ERANGE: the device
+ * inflater declined (no dynamic-Huffman block to enter, an extreme ratio, too small) -- read the member on the host. */
+int ss_npz_member_dev(const char *path, uint64_t off, uint64_t comp_n, uint32_t crc, uint64_t usize, int method, void **d_data,
+                      uint64_t *n, void **lease);
 int ss_npz_member_done(void *lease);
 /* zlib's CRC-32 of (a prefix whose CRC-32 is prefix_crc) followed by n copies of `byte`, in O(log n): what the `data.npy`
  * member of a binary matrix must have for its content to be nnz ones -- known without inflating it. */

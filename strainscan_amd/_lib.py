@@ -147,7 +147,7 @@ SIGNATURES = {
     "ss_rows_reduce": (i32, [vp, vp, u64, P(NodeStat)]),
     "ss_l2_create": (i32, [vp, vp, u64, u32, P(vp)]),
     "ss_l2_create_dev": (i32, [vp, vp, u64, u32, P(vp)]),
-    "ss_npz_member_dev": (i32, [C.c_char_p, u64, u64, C.c_uint32, u64, P(vp), P(u64), P(vp)]),
+    "ss_npz_member_dev": (i32, [C.c_char_p, u64, u64, C.c_uint32, u64, i32, P(vp), P(u64), P(vp)]),
     "ss_npz_member_done": (i32, [vp]),
     "ss_crc32_repeat": (i32, [C.c_uint32, i32, u64, P(C.c_uint32)]),
     "ss_l2_create_planes": (i32, [vp, u64, u32, P(vp)]),

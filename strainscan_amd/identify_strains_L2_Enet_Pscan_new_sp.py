@@ -330,7 +330,8 @@ def _cluster_image_from_npz(path):
     """all_strains_re.npz -> ClusterImage with its large members inflated ON THE DEVICE (round 6).  np.load inflates every
     member on one host thread (zipfile: ~7 ms per million non-zeros; 2.3 of the 3.5 s of a first run against a database with a
     5 M x 300 cluster): here `indices.npy` -- four bytes per non-zero -- goes through the device inflater (ss_npz_member_dev)
-    and is packed into bit planes from where it lands (ss_l2_create_dev); `data.npy` -- nnz ones -- is not inflated at all:
+    (a stored member: uploaded as it is, its CRC-32 taken on the way) and is packed into bit planes from where it lands
+    (ss_l2_create_dev); `data.npy` -- nnz ones -- is not inflated at all:
     its length and CRC-32, which the archive's directory states, are those of its header followed by nnz bytes 0x01
     (ss_crc32_repeat), or the file goes the old way.  None: not a file for this route (the caller takes np.load)."""
     import zipfile
@@ -343,7 +344,7 @@ def _cluster_image_from_npz(path):
     if any(n not in d for n in need):
         return None
     off, comp_n, crc, usize, method = d["indices.npy"]
-    if method != zipfile.ZIP_DEFLATED or comp_n < _NPZ_DEV_MIN:
+    if method not in (zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED) or comp_n < _NPZ_DEV_MIN:
         return None                                                   # small: np.load is as fast
     with np.load(path, allow_pickle=False) as z:
         fmt = z["format"].item()
@@ -361,6 +362,8 @@ def _cluster_image_from_npz(path):
         f.seek(doff)
         raw = f.read(min(dcomp, 1 << 16))
     try:
+        if dmethod not in (zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED):
+            return None
         head = zlib.decompressobj(-15).decompress(raw, 4096) if dmethod == zipfile.ZIP_DEFLATED else raw[:4096]
         dtype, dshape, _, hlen = _npy_header(head)
     except Exception:                                                 # noqa: B902 -- anything odd: the old way
@@ -372,7 +375,8 @@ def _cluster_image_from_npz(path):
     if want.value != dcrc:
         return None                                                   # not all ones (or not canonical): np.load decides
     dptr, n, lease = C.c_void_p(), C.c_uint64(), C.c_void_p()
-    rc = _lib.lib().ss_npz_member_dev(os.fsencode(path), off, comp_n, crc, usize, C.byref(dptr), C.byref(n), C.byref(lease))
+    rc = _lib.lib().ss_npz_member_dev(os.fsencode(path), off, comp_n, crc, usize, 8 if method == zipfile.ZIP_DEFLATED else 0,
+                                      C.byref(dptr), C.byref(n), C.byref(lease))
     if rc == _lib.SS_ERANGE:
         return None                                                   # the device inflater declined: host
     _lib.check(rc, "ss_npz_member_dev")

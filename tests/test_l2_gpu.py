@@ -1011,10 +1011,20 @@ def test_cluster_image_from_npz_on_the_device(K, S, density, tmp_path, monkeypat
     assert m._cluster_image_from_npz(p2) is None
     with pytest.raises(ValueError):
         L2.ClusterImage(m._load_npz_csr(p2))
-    # stored (uncompressed) archive, int64 indices: not for this route, equal planes through the old one
+    # a stored (uncompressed) archive: uploaded as it is, CRC-32 checked on the way; a flipped byte in it -> refused
     p3 = str(tmp_path / "stored.npz")
     sp.save_npz(p3, X, compressed=False)
-    assert m._cluster_image_from_npz(p3) is None
+    st = m._cluster_image_from_npz(p3)
+    assert st is not None and np.array_equal(st.planes(), ref.planes())
+    st.close()
+    d3 = m._npz_directory(p3)
+    raw3 = bytearray(open(p3, "rb").read())
+    raw3[d3["indices.npy"][0] + d3["indices.npy"][1] // 2] ^= 0x01
+    p3b = str(tmp_path / "stored_bad.npz")
+    open(p3b, "wb").write(bytes(raw3))
+    with pytest.raises(Exception):
+        m._cluster_image_from_npz(p3b)
+    # int64 indices: not for this route, equal planes through the old one
     Z = X.copy()
     Z.indices = Z.indices.astype(np.int64)
     Z.indptr = Z.indptr.astype(np.int64)
