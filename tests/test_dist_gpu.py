@@ -258,7 +258,7 @@ def test_sharded_scan_of_gz_pair_on_the_device(world, decline, mode, tmp_path):
     lut = np.frombuffer(b"ACGT", np.uint8)
     rows = lut[rs.randint(0, 4, (30000, 31))]
     kfa = b"".join(b">1\n" + r.tobytes() + b"\n" for r in rows)
-    n = 50000 if world < 8 else 160000      # (eight ranks: files of ~8 MB = 16 slices of the smallest size there is, 128 search chunks)
+    n = 50000 if world < 8 else 280000      # (eight ranks: files of ~8.5 MB = 17 slices of the smallest size there is, 128 search chunks)
     lvl = 6 if world < 8 else 1
     reads = lut[rs.randint(0, 4, (n, 150))]
     for i in range(0, n, 2):
