@@ -326,54 +326,53 @@ def _npy_header(head):
     return dtype, shape, fortran, f.tell()
 
 
-def _cluster_image_from_npz(path):
-    """all_strains_re.npz -> ClusterImage with its large members inflated ON THE DEVICE (round 6).  np.load inflates every
-    member on one host thread (zipfile: ~7 ms per million non-zeros; 2.3 of the 3.5 s of a first run against a database with a
-    5 M x 300 cluster): here `indices.npy` -- four bytes per non-zero -- goes through the device inflater (ss_npz_member_dev)
-    (a stored member: uploaded as it is, its CRC-32 taken on the way) and is packed into bit planes from where it lands
-    (ss_l2_create_dev); `data.npy` -- nnz ones -- is not inflated at all:
-    its length and CRC-32, which the archive's directory states, are those of its header followed by nnz bytes 0x01
-    (ss_crc32_repeat), or the file goes the old way.  None: not a file for this route (the caller takes np.load)."""
+def _npz_device_plan(path):
+    """Is `path` a file for the device route?  -> (shape, indptr, nnz, (offset, compressed bytes, CRC-32, bytes, method) of
+    indices.npy), or None: not canonical CSR as scipy.sparse.save_npz writes it, too small to be worth it, or `data.npy` is not
+    known to be nnz ones -- its .npy header is read from the head of its deflate stream, and the content's length and
+    CRC-32 (both in the archive's directory) must be those of that header followed by nnz bytes 0x01 (ss_crc32_repeat)."""
     import zipfile
     import zlib
+    ok = (zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED)
     try:
         d = _npz_directory(path)
-    except (OSError, zipfile.BadZipFile, ValueError):
-        return None
-    need = ("format.npy", "shape.npy", "indptr.npy", "indices.npy", "data.npy")
-    if any(n not in d for n in need):
-        return None
-    off, comp_n, crc, usize, method = d["indices.npy"]
-    if method not in (zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED) or comp_n < _NPZ_DEV_MIN:
-        return None                                                   # small: np.load is as fast
-    with np.load(path, allow_pickle=False) as z:
-        fmt = z["format"].item()
-        fmt = fmt.decode() if isinstance(fmt, bytes) else fmt
-        if fmt != "csr":
-            return None
-        shape = tuple(int(x) for x in z["shape"])
-        indptr = z["indptr"]
-    if len(shape) != 2 or indptr.ndim != 1 or indptr.dtype.kind != "i" or len(indptr) != shape[0] + 1 or int(indptr[0]) != 0:
-        return None                                                   # (the old way raises what is to be raised)
-    nnz = int(indptr[-1])
-    # data.npy: nnz ones?  Its first bytes (the .npy header) from the head of its deflate stream, the rest from the CRC
-    doff, dcomp, dcrc, dusize, dmethod = d["data.npy"]
-    with open(path, "rb") as f:
-        f.seek(doff)
-        raw = f.read(min(dcomp, 1 << 16))
-    try:
-        if dmethod not in (zipfile.ZIP_DEFLATED, zipfile.ZIP_STORED):
-            return None
+        ind, (doff, dcomp, dcrc, dusize, dmethod) = d["indices.npy"], d["data.npy"]
+        if ind[4] not in ok or dmethod not in ok or ind[1] < _NPZ_DEV_MIN:
+            return None                                               # small: np.load is as fast
+        with np.load(path, allow_pickle=False) as z:
+            fmt = z["format"].item()
+            shape = tuple(int(x) for x in z["shape"])
+            indptr = z["indptr"]
+        if (fmt.decode() if isinstance(fmt, bytes) else fmt) != "csr" or len(shape) != 2 or indptr.ndim != 1 or \
+                indptr.dtype.kind != "i" or len(indptr) != shape[0] + 1 or int(indptr[0]) != 0:
+            return None                                               # (the old way raises what is to be raised)
+        with open(path, "rb") as f:
+            f.seek(doff)
+            raw = f.read(min(dcomp, 1 << 16))
         head = zlib.decompressobj(-15).decompress(raw, 4096) if dmethod == zipfile.ZIP_DEFLATED else raw[:4096]
         dtype, dshape, _, hlen = _npy_header(head)
-    except Exception:                                                 # noqa: B902 -- anything odd: the old way
+    except (OSError, KeyError, ValueError, zipfile.BadZipFile, zlib.error):
         return None
-    if dtype != np.dtype(np.int8) or tuple(dshape) != (nnz,) or dusize != hlen + nnz:
-        return None
+    nnz = int(indptr[-1])
     want = C.c_uint32()
-    _lib.check(_lib.lib().ss_crc32_repeat(zlib.crc32(head[:hlen]), 1, nnz, C.byref(want)), "ss_crc32_repeat")
-    if want.value != dcrc:
+    _lib.check(_lib.lib().ss_crc32_repeat(zlib.crc32(head[:hlen]), 1, max(nnz, 0), C.byref(want)), "ss_crc32_repeat")
+    if dtype != np.dtype(np.int8) or tuple(dshape) != (nnz,) or dusize != hlen + nnz or want.value != dcrc:
         return None                                                   # not all ones (or not canonical): np.load decides
+    return shape, indptr, nnz, ind
+
+
+def _cluster_image_from_npz(path):
+    """all_strains_re.npz -> ClusterImage with its large members brought to the device directly (round 6).  np.load inflates
+    every member on one host thread (zipfile: ~7 ms per million non-zeros; 2.3 of the 3.5 s of a first run against a database
+    with a 5 M x 300 cluster): here `indices.npy` -- four bytes per non-zero -- is inflated by the device inflater (a stored
+    member: uploaded as it is, its CRC-32 taken on the way; ss_npz_member_dev) and packed into bit planes from where it lands
+    (ss_l2_create_dev); `data.npy` -- nnz ones -- is not inflated at all (_npz_device_plan).  None: not a file for this
+    route, or the device inflater declined (the caller takes np.load)."""
+    import zipfile
+    plan = _npz_device_plan(path)
+    if plan is None:
+        return None
+    shape, indptr, nnz, (off, comp_n, crc, usize, method) = plan
     dptr, n, lease = C.c_void_p(), C.c_uint64(), C.c_void_p()
     rc = _lib.lib().ss_npz_member_dev(os.fsencode(path), off, comp_n, crc, usize, 8 if method == zipfile.ZIP_DEFLATED else 0,
                                       C.byref(dptr), C.byref(n), C.byref(lease))

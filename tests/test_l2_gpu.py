@@ -779,6 +779,7 @@ def test_every_statement_of_the_l2_mirrors_is_pinned(golden, golden_dir, l1_dbs,
                         ("cache", lambda p: test_cluster_image_cache(p, monkeypatch)),
                         ("threads", lambda p: test_l2_batch_threads_equal_serial(p, monkeypatch)),
                         ("bad", test_damaged_csr_files_raise_value_error),
+                        ("npz", lambda p: test_cluster_image_from_npz_on_the_device(60_000, 300, 0.5, p, monkeypatch)),
                         ("branches", lambda p: _l2_branch_scenarios(p, monkeypatch, golden))):
             d = tmp_path / sub
             d.mkdir()
@@ -1053,6 +1054,30 @@ def test_cluster_image_from_npz_on_the_device(K, S, density, tmp_path, monkeypat
         assert same
     with pytest.raises(Exception):
         m._load_npz_csr(p5).indices.sum()
+    # not for this route at all: no ZIP archive, an archive without the members, a CSC matrix; a member deflated WITHOUT
+    # dynamic-Huffman blocks (level 0: stored blocks inside the deflate stream) is declined by the device inflater
+    p6 = str(tmp_path / "text.npz")
+    open(p6, "wb").write(b"not an archive" * 100)
+    assert m._cluster_image_from_npz(p6) is None
+    p7 = str(tmp_path / "other.npz")
+    np.savez_compressed(p7, a=np.arange(10))
+    assert m._cluster_image_from_npz(p7) is None
+    p8 = str(tmp_path / "csc.npz")
+    sp.save_npz(p8, sp.csc_matrix(X))
+    assert m._cluster_image_from_npz(p8) is None
+    import io
+    import zipfile
+    p9 = str(tmp_path / "level0.npz")
+    with zipfile.ZipFile(p9, "w", zipfile.ZIP_DEFLATED, compresslevel=0) as zf:
+        for name, arr in (("indices", X.indices), ("indptr", X.indptr), ("format", np.array("csr".encode())), ("shape", np.array(X.shape)),
+                          ("data", X.data)):
+            buf = io.BytesIO()
+            np.save(buf, arr)
+            zf.writestr(name + ".npy", buf.getvalue())
+    assert m._cluster_image_from_npz(p9) is None
+    alt = L2.ClusterImage(m._load_npz_csr(p9))
+    assert np.array_equal(alt.planes(), ref.planes())
+    alt.close()
     ref.close()
 
 

@@ -466,10 +466,10 @@ def test_index_image_roundtrip(L, tmp_path):
     open(str(tmp_path / "badref"), "wb").write(bytes(bad))
     with pytest.raises(L.SSError):
         L.KmerDB.from_image(str(tmp_path / "badref"))
-    # the flat layout (k != 31) is not exported
-    kfa5, _ = _random_db_and_reads(5, 300, 10, k=21)
+    # the flat layout (k < 17) is not exported
+    kfa5, _ = _random_db_and_reads(5, 300, 10, k=11)
     with pytest.raises(L.SSError):
-        L.KmerDB.from_text(kfa5, 21, True).export(str(tmp_path / "flat.bin"))
+        L.KmerDB.from_text(kfa5, 11, True).export(str(tmp_path / "flat.bin"))
     db.close()
 
 
