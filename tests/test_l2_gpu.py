@@ -1059,6 +1059,11 @@ def test_cluster_image_from_npz_on_the_device(K, S, density, tmp_path, monkeypat
     p6 = str(tmp_path / "text.npz")
     open(p6, "wb").write(b"not an archive" * 100)
     assert m._cluster_image_from_npz(p6) is None
+    raw10 = bytearray(open(p, "rb").read())                           # the directory is fine, a member's local header is not
+    raw10[0:4] = b"XXXX"
+    p10 = str(tmp_path / "localhdr.npz")
+    open(p10, "wb").write(bytes(raw10))
+    assert m._cluster_image_from_npz(p10) is None
     p7 = str(tmp_path / "other.npz")
     np.savez_compressed(p7, a=np.arange(10))
     assert m._cluster_image_from_npz(p7) is None
