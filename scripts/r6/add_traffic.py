@@ -39,7 +39,7 @@ for shape in ("sampled", "contiguous"):
     with open(os.path.join(ROOT, "profiles", "r06_%s_kernel_stats.csv" % shape), "w") as f:
         f.write("\n".join(ks[:14]) + "\n")
         f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --db-shape %s --no-cpu-baseline --no-phases --no-config3 --no-cli-e2e --no-file-order --steps 5 --warmup 2\n" % shape)
-        calls = int(first[1])
+        calls = int(first[-5])
         scans = 14
         f.write("# scan_mini_kernel: %d calls = %d scans: 7 headline steps (each bins the records anew: a probe of 8192 tiles = min_ms, then the rest) + 7 steps over the resident binned set (one probe).\n" % (calls, scans))
         f.write("# per scan: total_ms / %d = %.3f ms under the profiler; bench.py's HIP events around a headline step's scan (probe + host answer + rest): %.3f ms (roofline.kernel_ms)\n" % (scans, total / scans, ms))
