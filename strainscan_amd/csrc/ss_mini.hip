@@ -1405,6 +1405,7 @@ __global__ __launch_bounds__(KT) void scan_minik_kernel(const uint8_t *__restric
 #if defined(SS_KSTOP) && SS_KSTOP == 2
             { uint32_t acc = 0; for (int r = 0; r < 4; r++) acc ^= tg_[r].x ^ tg_[r].w ^ m_[r]; if (acc == 0x12345678u) atomicAdd(&counts[0], 1u); continue; }
 #endif
+            bool cand_[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // a candidate: some slot of the page carries the minimizer's tag8 AND is either an inline k-mer with THIS k-mer's
@@ -1416,11 +1417,21 @@ __global__ __launch_bounds__(KT) void scan_minik_kernel(const uint8_t *__restric
                 const uint32_t e4 = (F + (uint32_t)j - (m_[j] & 31u)) * 0x01010101u, r4 = (0x80u | ((h_[j] >> 8) & 0x3Fu)) * 0x01010101u;
                 const uint32_t c0 = zb(tg_[j].x ^ tt) & (zb(tg_[j].z ^ e4) | zb((tg_[j].z ^ r4) & 0xBFBFBFBFu));
                 const uint32_t c1 = zb(tg_[j].y ^ tt) & (zb(tg_[j].w ^ e4) | zb((tg_[j].w ^ r4) & 0xBFBFBFBFu));
-                const bool cand = go_[j] && ((c0 | c1) != 0u || (tg_[j].w >> 24) != (uint32_t)ss::PG_EMPTY_HI);
-                const uint64_t bal = __ballot(cand);
-                if (cand) S.q[nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
-                    make_uint2((p0 + (uint32_t)j) | (((m_[j] & 31u) - (uint32_t)j) << 10), h_[j]);
-                nq += (uint32_t)__popcll(bal);
+                cand_[j] = go_[j] && ((c0 | c1) != 0u || (tg_[j].w >> 24) != (uint32_t)ss::PG_EMPTY_HI);
+            }
+            // The queue is kept in POSITION order (a lane's candidates side by side, the lanes in order: a wave prefix sum of the
+            // lanes' counts), so that the lanes of a drain hold neighbouring positions: the k-mers of a run hit neighbouring
+            // counters of ONE bucket, and what an atomic costs on this chip is (instruction, 64-byte line) pairs (27 G/s,
+            // profiles/r04_atomics_micro_*.txt).  Queued position class by position class (0, 4, 8, ... then 1, 5, 9, ...) a cluster
+            // table's 111 hits per read were ~1.5 hits per pair: 18 ms per 8 M reads.
+            {
+                const uint32_t mine = (uint32_t)cand_[0] + (uint32_t)cand_[1] + (uint32_t)cand_[2] + (uint32_t)cand_[3];
+                const uint32_t incl = wave_inclusive_sum(mine);
+                uint32_t idx = nq + incl - mine;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (cand_[j]) S.q[idx++] = make_uint2((p0 + (uint32_t)j) | (((m_[j] & 31u) - (uint32_t)j) << 10), h_[j]);
+                nq += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
             }
 #if defined(SS_KSTOP) && SS_KSTOP == 3
