@@ -56,3 +56,20 @@ def mid_dbs(tmp_path_factory):
             f.write(reads)
         out["reads"][sname] = (p, reads)
     return out
+
+
+@pytest.fixture(scope="session")
+def built_db(tmp_path_factory):
+    """The Tree_database the reference's own builder wrote (tests/golden/built_tree_db.tar.gz, tests/scenarios_built.py), unpacked;
+    and its samples' FASTQ files: {"tdb": dir, "reads": {name: (path, bytes)}}."""
+    from tests import scenarios_built as sb
+    root = str(tmp_path_factory.mktemp("ss_built"))
+    tdb = sb.unpack_tree_database(os.path.join(GOLDEN, "built_tree_db.tar.gz"), root)
+    out = {"tdb": tdb, "reads": {}}
+    for sname in sb.BUILT_SAMPLES:
+        reads = sb.built_reads(sname)
+        p = os.path.join(root, sname + ".fq")
+        with open(p, "wb") as f:
+            f.write(reads)
+        out["reads"][sname] = (p, reads)
+    return out

@@ -71,6 +71,16 @@ class Tree(object):
             p = self._pred(p)
         return False
 
+    def depth(self, node=None):
+        """Levels below the root of `node` (a Node or an identifier); Build_tree.py:86 calls tree.depth(node=<Node>)."""
+        nid = node.identifier if isinstance(node, Node) else node
+        d = 0
+        p = self._pred(nid)
+        while p is not None:
+            d += 1
+            p = self._pred(p)
+        return d
+
     def paths_to_leaves(self):
         res = []
         for leaf in self.leaves():

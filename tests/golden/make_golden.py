@@ -222,6 +222,60 @@ def l2_big_section(scratch, l2mod, captured, synth):
     np.savez_compressed(os.path.join(HERE, "l2_big_arrays.npz"), **arrays)
 
 
+def built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth):
+    """A Tree_database written by the reference's OWN builder (library/Build_tree.py build_tree, in a child process: its sets
+    iterate in hash order, so PYTHONHASHSEED is fixed; Bio / bidict / treelib from tests/golden/_standin) on the seeded genomes of
+    tests/scenarios_built.py -> the committed fixture built_tree_db.tar.gz; then the reference's identify modules on reads of
+    those genomes -> built_l1.json."""
+    from tests import scenarios_built as sb
+    root = os.path.join(scratch, "built")
+    os.makedirs(root)
+    mpath, cpath = sb.write_builder_inputs(root)
+    tdir = os.path.join(root, "Tree_database")
+    os.makedirs(tdir)
+    drv = ("import sys, random, numpy; sys.path[:0] = [%r, %r, %r, %r]; random.seed(4321); numpy.random.seed(4321); import Build_tree; "
+           "Build_tree.build_tree([%r, %r, %r, 31, %r])"
+           % (REPO, os.path.join(HERE, "_standin"), os.path.join(REPO, "oracle", "_ref"), os.path.join(scratch, "ref", "library"),
+              mpath, cpath, tdir, sb.BUILT_PARAMS))
+    r = subprocess.run([sys.executable, "-c", drv], cwd=root, env=dict(os.environ, PYTHONHASHSEED="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        raise SystemExit("the reference's builder failed:\n" + r.stderr.decode()[-2000:])
+    blob = sb.pack_tree_database(tdir)
+    with open(os.path.join(HERE, "built_tree_db.tar.gz"), "wb") as f:
+        f.write(blob)
+    print("wrote built_tree_db.tar.gz", len(blob))
+    kfa = open(os.path.join(tdir, "kmer.fa"), "rb").read()
+    n_rows = kfa.count(b"\n") // 2
+    out = dict(builder=dict(params=sb.BUILT_PARAMS, tree_structure=open(os.path.join(tdir, "tree_structure.txt")).read(),
+                            node_length=open(os.path.join(tdir, "node_length.txt")).read(),
+                            reconstructed_nodes=open(os.path.join(tdir, "reconstructed_nodes.txt")).read(),
+                            kmer_fa_sha256=synth.sha256_of(kfa), n_rows=n_rows, fixture_sha256=synth.sha256_of(blob)), samples={})
+    for sname in sb.BUILT_SAMPLES:
+        reads = sb.built_reads(sname)
+        fq = os.path.join(root, sname + ".fq")
+        open(fq, "wb").write(reads)
+        entry = dict(sha256=synth.sha256_of(kfa, reads), n_reads=reads.count(b"\n") // 4, runs=[])
+        mr = identify.jellyfish_count((fq, ""), tdir)
+        cnt = np.zeros(n_rows, np.int64)
+        for k_, v_ in mr.items():
+            cnt[k_] = v_
+        entry["counts_sha256"] = synth.sha256_of(cnt.astype(np.uint32).tobytes())
+        entry["counts_sum"] = int(cnt.sum())
+        entry["n_valid"] = len(mr)
+        for cut in sc.CUTOFFS:
+            for modname, mod in (("identify", identify), ("identify_low_mem", identify_low_mem)):
+                np.random.seed(sc.POISSON_SEED)
+                res, err, txt = run_captured(mod.identify_cluster, (fq, ""), tdir, list(cut))
+                entry["runs"].append(dict(module=modname, cutoff=cut, error=err,
+                                          result=None if res is None else {int(k): dict(v) for k, v in res.items()},
+                                          trace=parse_trace(txt)))
+        res, err, txt = run_captured(identify_low_depth.identify_ranks, (fq, ""), tdir)
+        entry["ranks"] = dict(error=err, result=None if res is None else [[int(a), float(b)] for a, b in res])
+        out["samples"][sname] = entry
+        print("built L1", sname, [(r_["module"], r_["cutoff"][0], r_["error"], sorted((r_["result"] or {}).keys())) for r_ in entry["runs"]][:4])
+    dump_json("built_l1.json", out)
+
+
 def main():
     from tests import scenarios as sc
     from tests import synth
@@ -235,13 +289,18 @@ def main():
     import identify_strains_L2_Enet_Pscan_new_sp as l2mod
     import Vote_Strain_L2_Lasso_new_sp as vote
 
-    only = sys.argv[1] if len(sys.argv) > 1 else "all"          # all | mid (the round-6 sections alone: ~10 min)
+    only = sys.argv[1] if len(sys.argv) > 1 else "all"          # all | mid (round 6's sections alone: ~4 min) | built (the reference-built database alone)
     if only == "mid":
         import scipy.sparse as sp
         captured = {}
         _patch_sklearn(l2mod, captured)
         mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
         l2_big_section(scratch, l2mod, captured, synth)
+        built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+    if only == "built":
+        built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
         shutil.rmtree(scratch, ignore_errors=True)
         return
 
@@ -475,6 +534,7 @@ def main():
     # ---------------------------------------------------------------- round 6: configs[0]'s shape, whole flow + big clusters
     mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
     l2_big_section(scratch, l2mod, captured, synth)
+    built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
 
     # ---------------------------------------------------------------- seqpy.revcomp (oracle/_ref)
     refso = os.path.join(REPO, "oracle", "_ref")

@@ -186,3 +186,65 @@ def test_l2_big_oracle(name, golden_dir):
     assert np.allclose(coef, arrs[name + "_coef"], rtol=1e-9, atol=1e-9)
     for nm, c in zip(names, coef / coef.sum()):
         assert abs(c - g["res"][nm]) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# a Tree_database written by the reference's own builder (tests/scenarios_built.py)
+# ------------------------------------------------------------------------------------------------
+def test_built_db_fixture_is_the_builders_output(golden_dir, built_db):
+    """The committed fixture is what make_golden.py recorded of library/Build_tree.py's run: same archive, same kmer.fa, the
+    builder's own tree_structure / node_length / reconstructed_nodes -- with what synth.py never writes: sets down-sampled
+    to the cap in SET order (:590-591), a reconstructed node left with no k-mer at all, k-mers with an N (the builder takes
+    every window of a genome, :100-101), rows of kmer.fa in set order rather than node order."""
+    g = _load(golden_dir, "built_l1.json")["builder"]
+    blob = open(os.path.join(golden_dir, "built_tree_db.tar.gz"), "rb").read()
+    assert synth.sha256_of(blob) == g["fixture_sha256"]
+    tdb = built_db["tdb"]
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    assert synth.sha256_of(kfa) == g["kmer_fa_sha256"] and kfa.count(b"\n") // 2 == g["n_rows"]
+    for name in ("tree_structure", "node_length", "reconstructed_nodes"):
+        assert open(os.path.join(tdb, name + ".txt")).read() == g[name]
+    lens = dict(ln.split("\t") for ln in g["node_length"].strip().split("\n"))
+    assert max(int(v) for v in lens.values()) == 6000 and min(int(v) for v in lens.values()) == 0      # the cap; a node rebuilt to nothing
+    assert g["reconstructed_nodes"].split() and any(b"N" in r for r in kfa.split(b"\n")[1::2])
+    rows = [np.array(open(os.path.join(tdb, "kmers", n)).read().split(), np.int64) for n in lens]
+    assert not all(np.all(np.diff(r) > 0) for r in rows if r.size > 1)                                    # (set order, not sorted)
+
+
+@pytest.mark.parametrize("sname", ["T_mix", "T_single", "T_low", "T_none"])
+def test_built_db_walk_matches_reference(sname, golden_dir, built_db):
+    """Oracle counts = the real jellyfish's (sha256), and cst.Walk on them = what identify.py / identify_low_mem.py found in the
+    database their own builder wrote: result dicts, visit order, printed node lines, exceptions, under the four cutoffs."""
+    from strainscan_amd import identify_low_depth as ld
+    from strainscan_amd.tree import read_tree_structure
+    g = _load(golden_dir, "built_l1.json")["samples"][sname]
+    tdb = built_db["tdb"]
+    reads = built_db["reads"][sname][1]
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    assert synth.sha256_of(kfa, reads) == g["sha256"]
+    provs = {True: hl.OracleProvider(tdb, [reads], upper=True), False: hl.OracleProvider(tdb, [reads], upper=False)}
+    assert synth.sha256_of(provs[True].counts.tobytes()) == g["counts_sha256"]
+    assert int(provs[True].valid.sum()) == g["n_valid"] and int(provs[True].counts.sum()) == g["counts_sum"]
+    for run in g["runs"]:
+        low_mem = run["module"] == "identify_low_mem"
+        res, err, text = hl.run_walk(provs[not low_mem], tdb, run["cutoff"], low_mem, sc.POISSON_SEED)
+        tag = (sname, run["module"], run["cutoff"])
+        assert err == run["error"], (tag, err, text[-400:])
+        if err is None:
+            hl.assert_result_equal(res, run["result"], tag)
+        got_tr = hl.parse_trace(text)
+        assert [t[0] for t in got_tr] == [t[0] for t in run["trace"]], tag
+        for a, w in zip(got_tr, run["trace"]):
+            assert len(a) == len(w), (tag, a, w)
+            if len(w) == 4:
+                assert abs(a[1] - w[1]) < 2e-6 and abs(a[2] - w[2]) < 2e-6 and a[3] == w[3], (tag, a, w)
+    tree, _ = read_tree_structure(tdb)
+    frac = {}
+    for n in tree.all_nodes():
+        ln, nk, _ = provs[False].node_stat(n.identifier)
+        frac[n.identifier] = -1 if ln < ld.MIN_VALID else nk / ln
+    got = ld.rank_paths(tree, frac)
+    want = g["ranks"]
+    assert want["error"] is None and [a for a, _ in got] == [a for a, _ in want["result"]]
+    for (_, b), (_, wb) in zip(got, want["result"]):
+        assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))

@@ -163,3 +163,46 @@ def test_detect_strains_big(name, golden_dir):
     assert abs(trace["alpha"] - g["alpha"]) <= 1e-12 * max(1.0, abs(g["alpha"]))
     assert np.allclose(trace["coef_"], arrs[name + "_coef"], rtol=0, atol=ABUND_TOL)
     assert trace["n_iter"] == g["n_iter"]
+
+
+@pytest.mark.parametrize("sname", ["T_mix", "T_single", "T_low", "T_none"])
+def test_identify_on_the_database_the_references_builder_wrote(sname, golden_dir, built_db, tmp_path, monkeypatch):
+    """tests/golden/built_tree_db.tar.gz is the OUTPUT of library/Build_tree.py build_tree (tests/scenarios_built.py): its file
+    order, its sampled sets, its reconstructed nodes (one of them empty), its k-mers with an N.  The HIP path on it against what
+    the reference's identify modules found there: counts bit-exact vs the real jellyfish, result dicts, traces, exceptions,
+    identify_ranks."""
+    from strainscan_amd import identify, identify_low_mem, identify_low_depth
+    from strainscan_amd import db as ssdb
+    g = _load(golden_dir, "built_l1.json")["samples"][sname]
+    tdb = built_db["tdb"]
+    fq, reads = built_db["reads"][sname]
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    ssdb.clear_cache()
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    assert synth.sha256_of(kfa, reads) == g["sha256"]
+    mr = identify.jellyfish_count((fq, ""), tdb)
+    cnt = np.zeros(kfa.count(b"\n") // 2, np.uint32)
+    for k_, v_ in mr.items():
+        cnt[k_] = v_
+    assert synth.sha256_of(cnt.tobytes()) == g["counts_sha256"] and len(mr) == g["n_valid"] and int(cnt.sum()) == g["counts_sum"]
+    mods = {"identify": identify, "identify_low_mem": identify_low_mem}
+    for run in g["runs"]:
+        np.random.seed(sc.POISSON_SEED)
+        res, err, text = _run(mods[run["module"]].identify_cluster, (fq, ""), tdb, list(run["cutoff"]))
+        tag = (sname, run["module"], run["cutoff"])
+        assert err == run["error"], (tag, err, text[-300:])
+        if err is None:
+            hl.assert_result_equal(res, run["result"], tag)
+        got_tr = hl.parse_trace(text)
+        assert [t[0] for t in got_tr] == [t[0] for t in run["trace"]], tag
+        for a, w in zip(got_tr, run["trace"]):
+            assert len(a) == len(w), (tag, a, w)
+            if len(w) == 4:
+                assert abs(a[1] - w[1]) < 2e-6 and abs(a[2] - w[2]) < 2e-6 and a[3] == w[3], (tag, a, w)
+    res, err, _ = _run(identify_low_depth.identify_ranks, (fq, ""), tdb)
+    want = g["ranks"]
+    assert err == want["error"]
+    assert [a for a, _ in res] == [a for a, _ in want["result"]]
+    for (_, b), (_, wb) in zip(res, want["result"]):
+        assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+    ssdb.clear_cache()
