@@ -338,8 +338,15 @@ __device__ __forceinline__ void store_piece(char *__restrict__ dst, uint64_t out
         }
     }
     char *o8 = static_cast<char *>(__builtin_assume_aligned(dst + out, 8));
+#ifdef SS_PLACE_NT      // (A/B builds: the slab is written once and read by a later kernel -- stores that do not allocate in L2)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32x2 u32x2_a8 __attribute__((aligned(8)));
+    __builtin_nontemporal_store((u32x2){w[0], w[1]}, reinterpret_cast<u32x2_a8 *>(o8));
+    if (c + 16 <= rslot) __builtin_nontemporal_store((u32x2){w[2], w[3]}, reinterpret_cast<u32x2_a8 *>(o8 + 8));
+#else
     if (c + 16 <= rslot) __builtin_memcpy(o8, w, 16);
     else __builtin_memcpy(o8, w, 8);
+#endif
 }
 
 // the usual tile: everything is in the table.  The chain of dependent round trips is what bounds this pass, so it is kept
@@ -492,7 +499,13 @@ __global__ __launch_bounds__(256, 8) void place_fixed_kernel(const char *__restr
     const uint32_t L1 = L + 1u, nr = (uint32_t)min((uint64_t)64, n_rec - r0), slot = slot_of(L), P = (slot + 15u) >> 4, total = nr * P;
     const uint64_t base = r0 * L1;
     unsigned long long d0 = 0;
+#if defined(SS_PLACE_SEQ)          // (A/B builds, results unbinned: what the pass costs as a plain copy -- no atomics, sequential destinations)
+    if ((uint32_t)lane < nr) d0 = (r0 + (uint64_t)lane) * slot;
+#elif defined(SS_PLACE_HASH)       // (A/B builds, results WRONG: scattered like the real thing, no atomics)
+    if ((uint32_t)lane < nr) d0 = ((((r0 + (uint64_t)lane) * 0x9E3779B97F4A7C15ull) >> 20) % n_rec) * slot;
+#else
     if ((uint32_t)lane < nr) d0 = atomicAdd(&cursor[bins[r0 + lane]], (unsigned long long)slot);      // (answer needed at the stores)
+#endif
     for (uint32_t p0 = 0; p0 < total; p0 += 64u * FPRE) {
         uint4 v[FPRE];
         uint32_t rec[FPRE], off[FPRE];
