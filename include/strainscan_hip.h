@@ -135,8 +135,9 @@ int ss_gz_range_counters(uint64_t *files, uint64_t *pieces);
 /* Test hooks, switched by this call only (nothing in the environment does): which = 1: plant a wrong block entry in search
  * chunk `value` of every .gz inflated on the device (0 = off); 2: this process declines .gz inputs on the device (in range mode
  * it still serves the chain); 3: this rank leaves range mode WITHOUT serving the chain -- what a crashed peer looks like;
- * 4: tables of k = 31 are scanned by the any-k kernel of the page index as well (value != 0), so that a test can hold the
- * two scan kernels to each other on one index. */
+ * 4: which scan kernel of the page index a table goes through -- value 1: tables of k = 31 through the one-lane-per-position
+ * kernel, 2: tables of every k through it, 3: tables of every k through the run-queue kernel (k at run time), 0: the product's choice
+ * -- so that a test can hold the kernels to each other on one index. */
 int ss_test_hook(int which, long long value);
 
 /* The test sets of ShuffleSplit(n_splits, test_size, random_state=seed).split(range(n)) as scikit-learn 0.23

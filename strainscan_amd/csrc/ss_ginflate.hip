@@ -2751,8 +2751,9 @@ extern "C" int ss_gz_set_range(int rank, int world, uint64_t slice_bytes, ss_gz_
 
 // Test hooks, switched by an explicit call only (never by the environment): 1 = plant a wrong entry in search chunk `value`
 // (0 = off), 2 = this process declines .gz inputs on the device (range mode: it still serves the chain), 3 = this rank leaves
-// range mode without serving the chain (what a crashed peer looks like: the others' bounded wait must end it), 4 = tables of
-// k = 31 are scanned by the any-k kernel of the page index too (ss_mini.hip scan_minik_kernel: the two kernels held to each other).
+// range mode without serving the chain (what a crashed peer looks like: the others' bounded wait must end it), 4 = which scan
+// kernel of the page index a table goes through (ss_mini.hip launch_scan_mini: 1 = k = 31 through the per-position kernel, 2 = every
+// k through it, 3 = every k through scan_mini_kernel; 0 = the product's choice): the kernels held to each other.
 extern "C" int ss_test_hook(int which, long long value)
 {
     switch (which) {

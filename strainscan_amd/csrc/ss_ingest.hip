@@ -891,25 +891,34 @@ int ss_scan_reads(ss_db *db, const ss_reads *R, void *stream)
 int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *R, void *stream)
 {
     if (!dbs || n_dbs < 1 || !R) return SS_EINVAL;
-    std::vector<ss_db *> mini;
+    std::vector<ss_db *> mini_all;
     for (int i = 0; i < n_dbs; i++) {
         if (!dbs[i]) return SS_EINVAL;
         for (int j = 0; j < i; j++) if (dbs[j] == dbs[i]) return SS_EINVAL;           // a table twice would count twice
         int k = 0;
         ss_db_info(dbs[i], nullptr, nullptr, nullptr, &k);
         if (R->has_cut_record && k != 31) return SS_ERANGE;
-        if (dbs[i]->layout == 1 && k == 31) mini.push_back(dbs[i]);      // (the several-tables kernel is k = 31's)
+        // (several tables per pass: k = 31, and k >= 25 where scan_mini_kernel with k at run time serves -- ss_mini.hip launch_scan_mini)
+        if (dbs[i]->layout == 1 && k >= 25) mini_all.push_back(dbs[i]);
         else { int rc = ss_scan_reads(dbs[i], R, stream); if (rc) return rc; }
     }
+    // the tables of ONE k go through the several-tables kernel together (a tile's minimizers are made once per k)
+    std::stable_sort(mini_all.begin(), mini_all.end(), [](const ss_db *a, const ss_db *b) { return a->k < b->k; });
     constexpr int group = 4;
+    for (size_t k0 = 0; k0 < mini_all.size();) {
+    size_t k1 = k0;
+    while (k1 < mini_all.size() && mini_all[k1]->k == mini_all[k0]->k) k1++;
+    std::vector<ss_db *> mini(mini_all.begin() + (long)k0, mini_all.begin() + (long)k1);
+    k0 = k1;
     for (size_t g = 0; g < mini.size(); g += (size_t)group) {
         const int ng = (int)std::min<size_t>((size_t)group, mini.size() - g);
         for (const auto &sl : R->slabs) {
             if (!sl.used) continue;
             int rc = ng == 1 ? ss::scan_flat_dev(mini[g], sl.d, sl.used, stream, sl.binned, R->serial)
-                             : (sl.used < 31 ? SS_OK : ss::launch_scan_mini_multi(&mini[g], ng, sl.d, sl.used, ss::as_stream(stream), sl.binned));
+                             : (sl.used < (uint64_t)mini[g]->k ? SS_OK : ss::launch_scan_mini_multi(&mini[g], ng, sl.d, sl.used, ss::as_stream(stream), sl.binned));
             if (rc) return rc;
         }
+    }
     }
     return SS_OK;
 }

@@ -177,12 +177,13 @@ struct QComb {
 };
 
 // the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
-__device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t &lo, uint32_t &hi)
+// (khi_mask: the 2 k - 32 bits of the upper half: 0x3FFFFFFF at k = 31)
+__device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t &lo, uint32_t &hi, uint32_t khi_mask = 0x3FFFFFFFu)
 {
     const uint32_t w = pos >> 4, sh = 2 * (pos & 15);
     const uint32_t a = S.code_[w + 1], b = S.code_[w + 2], c = S.code_[w + 3];
     lo = __builtin_amdgcn_alignbit(b, a, sh);
-    hi = __builtin_amdgcn_alignbit(c, b, sh) & 0x3FFFFFFFu;
+    hi = __builtin_amdgcn_alignbit(c, b, sh) & khi_mask;
 }
 
 // the 15-mer starting at tile position p (one funnel shift over two code words)
@@ -201,12 +202,17 @@ __device__ __forceinline__ uint32_t win16_at(const QShared &S, int32_t p)
 // A found run carries the bucket's offset mask shifted so that the offset of the run's FIRST k-mer
 // sits at bit 16: the k-mer q positions further has offset bit 16 - q (the minimizer stands still
 // while the k-mer start moves right).  Slot of the database k-mer that k-mer q would be, 0 = none.
-__device__ __forceinline__ uint32_t cand_slot(uint32_t bstart, uint32_t amask, uint32_t q)
+// (F = k - 15, the largest minimizer offset: 16 at k = 31, where the comments above are written)
+__device__ __forceinline__ uint32_t cand_slot(uint32_t bstart, uint32_t amask, uint32_t q, uint32_t F = 16u)
 {
-    const uint32_t o = 16u - q;
+    const uint32_t o = F - q;
     return ((amask >> o) & 1u) ? bstart + 1u + (uint32_t)__popc(amask & ((1u << o) - 1u)) : 0u;
 }
-__device__ __forceinline__ uint32_t aligned_mask(uint32_t hdr, uint32_t o0) { return ((hdr & 0x1FFFFu) << (16u - o0)) & 0x1FFFFu; }
+__device__ __forceinline__ uint32_t aligned_mask(uint32_t hdr, uint32_t o0, uint32_t F = 16u)
+{
+    const uint32_t wm = (2u << F) - 1u;
+    return ((hdr & wm) << (F - o0)) & wm;
+}
 
 // one occurrence of the database k-mer in slot `cpos` of the bucket at `bstart`: into the LDS entry `ent` of the bucket when it
 // has one (QComb), else straight to the counter
@@ -223,10 +229,11 @@ __device__ __forceinline__ void count_slot(uint32_t cpos, uint32_t bstart, uint3
 template <bool COMB>
 __device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t multi, uint32_t cpos,
                                             uint64_t cand, const uint64_t *__restrict__ mkeys,
-                                            uint32_t *__restrict__ counts, uint32_t ent = COMB_NONE, uint32_t *__restrict__ acc5 = nullptr)
+                                            uint32_t *__restrict__ counts, uint32_t ent = COMB_NONE, uint32_t *__restrict__ acc5 = nullptr,
+                                            uint32_t khi_mask = 0x3FFFFFFFu)
 {
     uint32_t klo, khi;
-    kmer_at(S, pos, klo, khi);
+    kmer_at(S, pos, klo, khi, khi_mask);
     if ((uint32_t)cand == klo && (uint32_t)(cand >> 32) == khi) {
         count_slot<COMB>(cpos, bstart, ent, acc5, counts);
     } else if (multi) {
@@ -322,23 +329,49 @@ struct ScanTabs {
 // SGPRs decide the residency of this kernel: a SIMD admits floor(800 / (ceil(sgprs / 16) * 16 + 16)) waves
 // (MI355X_MICROARCH.md, residency), i.e. 8 waves at <= 80, 7 at <= 96, 6 beyond; VGPRs (58) and LDS (4.9 KB per
 // one-wave workgroup = 32 per CU) allow 8.
+// Minimizers of a lane's 16 k-mers when a k-mer has W < 17 m-mers (k < 31; the run-time-k instantiations, KK = 0): the window of
+// k-mer j = packed keys x[j .. j + W - 1] of the 32 the lane sees (its own 16, the next lane's 16).  A window of 17 is "own suffix +
+// neighbour's prefix" (the k = 31 network below); a shorter one may lie inside the lane's own 16, so: minima over 2, 4, 8(, 16)
+// consecutive keys by doubling, and every window = two overlapping power-of-two stretches.  W is a template argument here (the indices
+// must be constants: the keys live in registers), the kernel switches on it once per tile.
+template <int W>
+__device__ __forceinline__ void sliding_min(const uint32_t (&x)[32], uint32_t (&out)[PPT])
+{
+    constexpr int P = W >= 16 ? 16 : W >= 8 ? 8 : W >= 4 ? 4 : 2;
+    uint32_t m[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) m[i] = x[i];
+#pragma unroll
+    for (int s2 = 1; s2 < P; s2 <<= 1) {
+#pragma unroll
+        for (int i = 0; i + s2 < 32; i++) m[i] = min(m[i], m[i + s2]);      // (ascending i: m[i + s2] is still the narrower minimum)
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; j++) out[j] = min(m[j], m[j + W - P]);
+}
+
 #ifndef SS_NUM_SGPR
 #define SS_NUM_SGPR 80
 #endif
-template <bool ALIGNED, bool BLOOM, bool COMB, int WAVES_PER_SIMD, bool MULTI = false>
+// KK: 31 = the k this kernel was tuned for, everything about k a constant; 0 = k is the kernel argument k_rt (17 <= k <= 30, round 6)
+template <bool ALIGNED, bool BLOOM, bool COMB, int WAVES_PER_SIMD, bool MULTI = false, int KK = 31>
 __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(SS_NUM_SGPR))) void scan_mini_kernel(
     const uint8_t *__restrict__ bases, uint64_t n, uint64_t n_tiles, const uint64_t *__restrict__ mkeys0,
     const uint4 *__restrict__ pages0, uint32_t n_pages0, uint32_t *__restrict__ counts0, uint32_t cbase0,
-    const uint32_t *__restrict__ bloom, uint32_t bloom_shift, uint32_t xcd_swizzle, const ScanTabs tabs)
+    const uint32_t *__restrict__ bloom, uint32_t bloom_shift, uint32_t xcd_swizzle, const ScanTabs tabs, int k_rt)
 {
     static_assert(!(MULTI && BLOOM), "several tables: no minimizer filter (they are tables that expect hits)");
+    static_assert(KK == 31 || KK == 0, "k = 31, or k at run time");
     // the table of this pass over the tile's runs (MULTI: tabs.* in turn)
     const uint64_t *__restrict__ mkeys = mkeys0;
     const uint4 *__restrict__ pages = pages0;
     uint32_t *__restrict__ counts = counts0;
     uint32_t n_pages = n_pages0, cbase = cbase0, tab_key = 0u;
-    constexpr int K = 31;                            // 17 m-mers of length 15 per k-mer
-    static_assert(K - ss::MINI_M + 1 == PPT + 1, "a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
+    const int K = KK ? KK : k_rt;                    // k = 31: 17 m-mers of length 15 per k-mer
+    const uint32_t W = (uint32_t)(K - ss::MINI_M + 1), F = W - 1u;      // m-mers per k-mer, largest minimizer offset (= flank bases)
+    const uint32_t khi_mask = (1u << (2 * K - 32)) - 1u;                // upper half of a 2 k-bit key
+    const uint32_t fmask = F >= 16u ? 0xFFFFFFFFu : (1u << (2u * F)) - 1u;      // a flank's 2 F bits
+    static_assert(31 - ss::MINI_M + 1 == PPT + 1, "k = 31: a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
     __shared__ QShared S;
     __shared__ QBloom SB;                            // (dropped from the instantiations that never touch it)
     __shared__ QComb C;
@@ -463,7 +496,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         // (smeared downwards through a bit reversal: shift-left-or is one instruction), 31..46 in hi
         // (smeared upwards; k-mer j sees hi bits 0..j-1)
         uint32_t live = 0;
-        if (t < MLANES) {
+        if (KK == 31 && t < MLANES) {
             uint32_t lo;
             __builtin_memcpy(&lo, &S.inv[t], 4);
             uint32_t hi = __builtin_amdgcn_alignbit(S.inv[t + 2], lo, 31);
@@ -471,6 +504,13 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             lo |= lo << 1; lo |= lo << 2; lo |= lo << 4; lo |= lo << 8; lo |= lo << 16;
             hi |= hi << 1; hi |= hi << 2; hi |= hi << 4; hi |= hi << 8;
             live = ~(__builtin_bitreverse32(lo) | (hi << 1)) & 0xFFFFu;
+        } else if (KK != 31 && t < MLANES) {
+            // any k: a sliding OR of width k over the 48 flags from the lane's first base on = width 16 by doubling, then two
+            // stretches of 16 that overlap (17 <= k <= 31)
+            uint64_t y = (uint64_t)S.inv[t] | ((uint64_t)S.inv[t + 1] << 16) | ((uint64_t)S.inv[t + 2] << 32);
+            y |= y >> 1; y |= y >> 2; y |= y >> 4; y |= y >> 8;
+            y |= y >> (K - 16);
+            live = ~(uint32_t)y & 0xFFFFu;
         }
         // k-mer j covers m-mers j..j+16 = own m-mers j..15 (index j..15) and the next lane's m-mers 0..j
         // (index 16..16+j): suffix minima over the own packed words, prefix minima over the neighbour's;
@@ -480,7 +520,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         // go through LDS.  All lanes execute this (a DPP source lane must be enabled).
         uint32_t need = 0;
         uint32_t mh[PPT];
-        {
+        if (KK == 31) {
             uint32_t pf[PPT];
             pf[0] = hm[0] + 16u;
 #pragma unroll
@@ -491,6 +531,21 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             min_next_lane8(hm[8], hm[9], hm[10], hm[11], hm[12], hm[13], hm[14], hm[15], pf[8], pf[9], pf[10], pf[11], pf[12], pf[13], pf[14], pf[15]);
 #pragma unroll
             for (int j = 0; j < PPT; j++) mh[j] = hm[j];
+        } else {
+            // any k: the next lane's 16 keys through DPP wave shifts (index + 16, as the left lane counts them), then the window minima
+            uint32_t x[32];
+#pragma unroll
+            for (int i = 0; i < PPT; i++) {
+                x[i] = hm[i];
+                x[PPT + i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm[i], 0x130, 0xf, 0xf, false) + 16u;      // wave_shl:1 (lane 63 reads 0: unused)
+            }
+            switch (W) {
+            case 3: sliding_min<3>(x, mh); break;   case 4: sliding_min<4>(x, mh); break;   case 5: sliding_min<5>(x, mh); break;
+            case 6: sliding_min<6>(x, mh); break;   case 7: sliding_min<7>(x, mh); break;   case 8: sliding_min<8>(x, mh); break;
+            case 9: sliding_min<9>(x, mh); break;   case 10: sliding_min<10>(x, mh); break; case 11: sliding_min<11>(x, mh); break;
+            case 12: sliding_min<12>(x, mh); break; case 13: sliding_min<13>(x, mh); break; case 14: sliding_min<14>(x, mh); break;
+            case 15: sliding_min<15>(x, mh); break; default: sliding_min<16>(x, mh); break;
+            }
         }
         if (live) {
             // run starts as a bit mask: position j starts a run if it is live and (j == 0, or j-1 is
@@ -567,7 +622,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         // a bucket reference whose tag bits match becomes a found run in q2 (phase 3 gives it 16 lanes, one per position)
         auto push_found = [&](uint32_t lo, uint32_t mask17, uint32_t meta, uint32_t ridx, bool queued) {
             const uint32_t bstart = lo & ss::START_MASK, multi = lo >> 31;
-            const uint32_t amask = aligned_mask(mask17, (meta >> 17) & 31u);
+            const uint32_t amask = aligned_mask(mask17, (meta >> 17) & 31u, F);
             uint32_t i2 = Q1CAP;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
             if (i2 < Q1CAP) {
@@ -577,8 +632,8 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                 // over (runs that overflowed q1): settle this run here, so that no k-mer is ever dropped
                 const uint32_t rpos = meta & 0xFFFu, len = (meta >> 12) & 31u;
                 for (uint32_t q = 0; q < len; q++) {
-                    const uint32_t cpos = cand_slot(bstart, amask, q);
-                    if (cpos) settle_item<false>(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts);
+                    const uint32_t cpos = cand_slot(bstart, amask, q, F);
+                    if (cpos) settle_item<false>(S, rpos + q, bstart, multi, cpos, mkeys[cpos], mkeys, counts, COMB_NONE, nullptr, khi_mask);
                 }
             }
         };
@@ -601,7 +656,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     hit &= hit - 1u;
                     const uint32_t hi8 = (((b & 4u) ? tg.w : tg.z) >> (b & 24u)) & 0xFFu;
                     const bool ref = hi8 & 0x80u;
-                    const uint32_t e = hi8 & 31u, j = o0 + e - 16u;             // inline: k-mer j of the run has offset o0 - j
+                    const uint32_t e = hi8 & 31u, j = o0 + e - F;               // inline: k-mer j of the run has offset o0 - j (e = F - offset)
                     if (ref ? ((hi8 ^ (h >> 8)) & 0x3Fu) == 0u : j < len) {
                         const uint32_t lo = reinterpret_cast<const uint32_t *>(pb + 16)[sl];
                         const uint32_t mid = reinterpret_cast<const uint16_t *>(pb + 48)[sl];
@@ -609,9 +664,9 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                             push_found(lo, mid | ((hi8 & 0x40u) << 10), meta, ridx, queued);
                         } else if ((mid >> 4) == ((h >> 8) & 0xFFFu)) {
                             const int32_t q = (int32_t)((meta & 0xFFFu) + o0);  // tile position of the minimizer
-                            const uint32_t fa = win16_at(S, q + ss::MINI_M), fb = win16_at(S, q - 16);
+                            const uint32_t fa = win16_at(S, q + ss::MINI_M), fb = win16_at(S, q - (int32_t)F);      // the bases behind / the F bases in front
                             const uint32_t m = ((1u << e) << e) - 1u;           // low 2 e bits (e = 16: all)
-                            if (((fa & m) | (fb & ~m)) == lo) atomicAdd(&counts[cbase + page * 8u + sl], 1u);
+                            if ((((fa & m) | (fb & ~m)) & fmask) == lo) atomicAdd(&counts[cbase + page * 8u + sl], 1u);
                         }
                     }
                 } while (hit);
@@ -766,13 +821,13 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     pos[u] = (run & 0xFFFu) + q;
                     bst[u] = (uint32_t)(r >> 32) & ss::START_MASK;
                     mul[u] = (uint32_t)r >> 31;
-                    cps[u] = (v && q < ((run >> 12) & 31u)) ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q) : 0u;
+                    cps[u] = (v && q < ((run >> 12) & 31u)) ? cand_slot(bst[u], ((uint32_t)r >> 12) & 0x1FFFFu, q, F) : 0u;
                     cnd[u] = mkeys[cps[u]];
                     ent[u] = COMB ? (uint32_t)C.ent[fi] : COMB_NONE;
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++)
-                    if (cps[u]) settle_item<COMB>(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, ent[u], &C.acc[0][0]);
+                    if (cps[u]) settle_item<COMB>(S, pos[u], bst[u], mul[u], cps[u], cnd[u], mkeys, counts, ent[u], &C.acc[0][0], khi_mask);
                 SS_MARK(16);
             };
             // (only in the combining scans: a tree scan finds ~6 runs per tile, and six lanes walking through this path cost more
@@ -795,18 +850,20 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     const uint32_t bstart = (uint32_t)(q >> 32) & ss::START_MASK, amask = ((uint32_t)q >> 12) & 0x1FFFFu;
                     const uint32_t run = BLOOM ? (uint32_t)SB.q1b[(uint32_t)q & 0xFFFu] : S.q1[(uint32_t)q & 0xFFFu];
                     const uint32_t rpos = run & 0xFFFu, len = (run >> 12) & 31u;
-                    // position p of the run has offset 16 - p: the candidates are the offsets of amask at or above 17 - len
-                    const uint32_t am = amask & ~((1u << (17u - len)) - 1u);
+                    // position p of the run has offset F - p (16 - p at k = 31): the candidates are the offsets of amask at or above W - len
+                    const uint32_t am = amask & ~((1u << (W - len)) - 1u);
                     if (am) {
                         const uint32_t o_hi = 31u - (uint32_t)__clz(am), o_lo = (uint32_t)__ffs(am) - 1u, d = o_hi - o_lo;
                         const uint32_t slot_a = bstart + 1u + (uint32_t)__popc(amask & ((1u << o_hi) - 1u));      // the first position's k-mer
                         const uint64_t k1 = mkeys[slot_a], k2 = mkeys[slot_a - d];                                // ... and the last one's
-                        const int32_t P = (int32_t)(rpos + 16u - o_hi);
+                        const int32_t P = (int32_t)(rpos + F - o_hi);
                         const uint64_t lo64 = k1 | (k2 << (2u * d));
                         const uint32_t hi32 = d ? (uint32_t)(k2 >> (64u - 2u * d)) : 0u;
                         uint32_t x0 = win16_at(S, P) ^ (uint32_t)lo64;
-                        uint32_t x1 = (win16_at(S, P + 16) ^ (uint32_t)(lo64 >> 32)) & (d == 0u ? 0x3FFFFFFFu : 0xFFFFFFFFu);
-                        uint32_t x2 = d >= 2u ? (win16_at(S, P + 32) ^ hi32) & ((1u << (2u * d - 2u)) - 1u) : 0u;
+                        // the stretch is d + k bases: 16 in x0, the next min(16, d + k - 16) in x1, the d + k - 32 beyond (if any) in x2
+                        const uint32_t nb1 = d + (uint32_t)K - 16u, nb2 = d + (uint32_t)K > 32u ? d + (uint32_t)K - 32u : 0u;
+                        uint32_t x1 = (win16_at(S, P + 16) ^ (uint32_t)(lo64 >> 32)) & (nb1 >= 16u ? 0xFFFFFFFFu : (1u << (2u * nb1)) - 1u);
+                        uint32_t x2 = nb2 ? (win16_at(S, P + 32) ^ hi32) & ((1u << (2u * nb2)) - 1u) : 0u;
                         uint32_t match = (2u << d) - 1u;                                                           // k-mers 0 .. d of the stretch
                         // a base that differs strikes the k-mers covering it: j in [m - 30, m]
                         x0 = (x0 | (x0 >> 1)) & 0x55555555u; x1 = (x1 | (x1 >> 1)) & 0x55555555u; x2 = (x2 | (x2 >> 1)) & 0x55555555u;
@@ -814,7 +871,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                             while (xb) {
                                 const uint32_t m = base0 + (((uint32_t)__ffs(xb) - 1u) >> 1);
                                 xb &= xb - 1u;
-                                const uint32_t hi = min(m, d), lw = m > 30u ? m - 30u : 0u;
+                                const uint32_t hi = min(m, d), lw = m > (uint32_t)K - 1u ? m - ((uint32_t)K - 1u) : 0u;
                                 if (lw <= hi) match &= ~(((2u << hi) - 1u) & ~((1u << lw) - 1u));
                             }
                         };
@@ -1188,12 +1245,12 @@ int build_mini(ss_db *db, const uint64_t *keys, const uint8_t *flags, uint64_t n
     SS_HIP(hipMemcpy(db->d_slot_of_row, slot_of_row.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
     SS_HIP(hipMemcpy(db->d_row_valid, row_valid.data(), nr, hipMemcpyHostToDevice));
     lap("5 bloom + upload");
-    return k == 31 ? mark_solid(db) : SS_OK;      // (PG_SOLID serves the combining kernel, which is k = 31 only)
+    return mark_solid(db);
 }
 
 // PG_SOLID for every bucket whose k-mers are one stretch of bases (ss_scan_dev.h): one thread per page slot, after either
 // build has put pages and buckets on the device -- the same flags whichever build made the image.
-__global__ __launch_bounds__(256) void mark_solid_kernel(uint8_t *__restrict__ pages, uint64_t n_page_slots, const uint64_t *__restrict__ mkeys)
+__global__ __launch_bounds__(256) void mark_solid_kernel(uint8_t *__restrict__ pages, uint64_t n_page_slots, const uint64_t *__restrict__ mkeys, int k_of_db)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_page_slots) return;
@@ -1211,7 +1268,7 @@ __global__ __launch_bounds__(256) void mark_solid_kernel(uint8_t *__restrict__ p
     if (m & (m + 1u)) return;                                            // a gap in the offsets
     // slots ascend with the offset; the k-mer of offset o + 1 begins one base before the k-mer of offset o
     for (uint32_t k = 1; k < cnt; k++)
-        if ((mkeys[b + k] & ((1ull << 60) - 1ull)) != (mkeys[b + k + 1] >> 2)) return;
+        if ((mkeys[b + k] & ((1ull << (2 * k_of_db - 2)) - 1ull)) != (mkeys[b + k + 1] >> 2)) return;
     *lo32 = lo | ss::PG_SOLID;
 }
 
@@ -1219,7 +1276,7 @@ int mark_solid(ss_db *db)
 {
     const uint64_t n = (uint64_t)db->n_dir_alloc * ss::PG_SLOTS;
     if (!n) return SS_OK;
-    hipLaunchKernelGGL(mark_solid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint8_t *)db->d_dir, n, db->d_mkeys);
+    hipLaunchKernelGGL(mark_solid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (uint8_t *)db->d_dir, n, db->d_mkeys, db->k);
     SS_HIP(hipGetLastError());
     SS_HIP(hipDeviceSynchronize());
     return SS_OK;
@@ -1482,8 +1539,13 @@ static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stre
     const uint32_t swz = swz0 | (probe ? 2u : 0u);
     const ScanTabs none = {};
     // (the combining variant needs 79 VGPRs: there is no 8-waves-per-SIMD build of it -- it carried 32 bytes of scratch)
-#define SS_LAUNCH(A, B, C_) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (C_ && LB > 6) ? 6 : LB>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles, \
-                                               db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none)
+    // k = 31: the instantiation with k a constant; any other k (17..30): k at run time
+#define SS_LAUNCH(A, B, C_) do {                                                                                                                         \
+        if (db->k == 31) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (C_ && LB > 6) ? 6 : LB, false, 31>), dim3(blocks), dim3(MT), 0, stream, bases, n,    \
+                                            n_tiles, db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none, 31);               \
+        else hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (C_ && LB > 6) ? 6 : LB, false, 0>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,        \
+                                db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none, db->k);                                 \
+    } while (0)
     // a table that expects hits (ss_db_expect_hits) skips its Bloom filter: nearly every minimizer of the reads is in it
     if (comb)             { if (aligned) SS_LAUNCH(true, false, true); else SS_LAUNCH(false, false, true); }
     else if (db->d_bloom && !db->expect_hits) { if (aligned) SS_LAUNCH(true, true, false); else SS_LAUNCH(false, true, false); }
@@ -1497,9 +1559,10 @@ int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, 
     if (n_dbs < 1 || n_dbs > MULTI_MAX) return SS_EINVAL;
     ScanTabs tabs = {};
     bool expect = true;
+    const int k_all = dbs[0] ? dbs[0]->k : 0;              // (one k for the tables of a pass: the tile's minimizers are made once)
     for (int i = 0; i < n_dbs; i++) {
         ss_db *db = dbs[i];
-        if (!db || db->layout != 1) return SS_EINVAL;
+        if (!db || db->layout != 1 || db->k != k_all) return SS_EINVAL;
         tabs.mkeys[i] = db->d_mkeys;
         tabs.pages[i] = reinterpret_cast<const uint4 *>(db->d_dir);
         tabs.counts[i] = db->d_counts;
@@ -1516,9 +1579,14 @@ int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, 
     unsigned blocks = (unsigned)std::min<uint64_t>(units, (uint64_t)2048 * 256 * (256 / MT));
     blocks = (blocks + 7u) & ~7u;
     const uint8_t *b = (const uint8_t *)bases_dev;
-#define SS_LAUNCH_M(A, C_, LB) hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, LB, true>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles, \
-                                                  tabs.mkeys[0], tabs.pages[0], tabs.n_pages[0], tabs.counts[0], tabs.cbase[0],                \
-                                                  (const uint32_t *)nullptr, 0u, swz, tabs)
+#define SS_LAUNCH_M(A, C_, LB) do {                                                                                                          \
+        if (k_all == 31) hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, LB, true, 31>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles,      \
+                                            tabs.mkeys[0], tabs.pages[0], tabs.n_pages[0], tabs.counts[0], tabs.cbase[0],                        \
+                                            (const uint32_t *)nullptr, 0u, swz, tabs, 31);                                                       \
+        else hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, LB, true, 0>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles,                   \
+                                tabs.mkeys[0], tabs.pages[0], tabs.n_pages[0], tabs.counts[0], tabs.cbase[0],                                    \
+                                (const uint32_t *)nullptr, 0u, swz, tabs, k_all);                                                                \
+    } while (0)
     if (comb) { if (aligned) SS_LAUNCH_M(true, true, 6); else SS_LAUNCH_M(false, true, 6); }
     else      { if (aligned) SS_LAUNCH_M(true, false, 8); else SS_LAUNCH_M(false, false, 8); }
 #undef SS_LAUNCH_M
@@ -1590,8 +1658,22 @@ static int launch_plain_or_comb(ss_db *db, bool comb, bool probe, const uint8_t 
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned /*blocks*/,
                      uint64_t n_tiles, bool binned, uint64_t set_id)
 {
-    // k other than 31 (and, under ss_test_hook 4, k = 31 too: the test that holds the two kernels to each other on one index)
-    if (db->k != 31 || g_hook_generic_k.load()) return launch_scan_minik(db, (const uint8_t *)bases_dev, n, stream);
+    // Which kernel.  k = 31: scan_mini_kernel with k a constant (everything below).  17 <= k <= 30: the one-lane-per-position kernel
+    // (scan_minik_kernel), except where scan_mini_kernel with k at run time (KK = 0) is the faster -- measured (profiles/r06_k_index.json):
+    // a table that expects hits scanned by a BINNED read set (the combining variant: a cluster table at k = 25, 8 M reads: 4.8 against
+    // 9.9 ms) as long as a tile's runs fit its queues (k >= 25: ~170 runs of a 160-entry queue's worth; at k = 21 the overflow path
+    // makes it 19.9 against 15.4, and on a table with few hits the per-position kernel wins at every k: 2.3 against 2.5-2.7 at k = 25-27).
+    // ss_test_hook 4 (tests: the kernels held to each other on one index): 1 = tables of k = 31 through the per-position kernel,
+    // 2 = tables of every k through it, 3 = tables of every k through scan_mini_kernel.
+    {
+        const long long hk = g_hook_generic_k.load();
+        if (db->k == 31 ? (hk == 1 || hk == 2) : (hk != 3 && (hk == 2 || !(binned && db->expect_hits && db->k >= 25))))
+            return launch_scan_minik(db, (const uint8_t *)bases_dev, n, stream);
+        if (db->k != 31) {                                  // (no probe: the flag decides)
+            const uint64_t nt = (n + MTILE - 1) / MTILE;
+            return launch_plain_or_comb(db, binned && db->expect_hits, false, (const uint8_t *)bases_dev, n, nt, stream);
+        }
+    }
     n_tiles = (n + MTILE - 1) / MTILE;                      // this kernel's tile is 62 x 16 positions
     const uint8_t *b = (const uint8_t *)bases_dev;
     // SS_COMBINE (A/B runs and tests): 0 never, 1 every scan of a table that expects hits -- binned or not --, 2 every binned scan

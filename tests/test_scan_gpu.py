@@ -1635,3 +1635,101 @@ def test_any_k_index_image_and_resident_reads(L, k, tmp_path):
     rset.close()
     for x in (db, db2, db31):
         x.close()
+
+
+def _dense_case_k(k, seed=5, G=40000, n_reads=12000):
+    """_dense_case at any k: EVERY k-mer of a genome, both orientations, reads at high coverage with errors."""
+    rs = np.random.RandomState(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    ga = lut[rs.randint(0, 4, size=G + k - 1)]
+    g = ga.tobytes()
+    kfa = b"".join(b">1\n" + g[i:i + k] + b"\n>1\n" + synth.revcomp(g[i:i + k]) + b"\n" for i in range(G))
+    recs = []
+    for s in rs.randint(0, G - 150, size=n_reads):
+        r = ga[s:s + rs.randint(k, 151)].copy()
+        m = rs.random_sample(r.size) < 0.01
+        r[m] = lut[rs.randint(0, 4, size=int(m.sum()))]
+        b = r.tobytes()
+        recs.append(synth.revcomp(b) if rs.random_sample() < 0.5 else b)
+    return kfa, b"\n".join(recs) + b"\n"
+
+
+@pytest.mark.parametrize("k", [17, 20, 25, 30])
+def test_tuned_kernel_at_run_time_k(L, k):
+    """scan_mini_kernel with k at run time (KK = 0: the windows of k - 14 m-mers by a doubling network, the validity of k bases,
+    flanks of k - 15 bases, the combining table and the solid buckets' stretches of d + k bases; at k = 17 / 20 its run queues
+    overflow on every tile: the in-place path) against the oracle AND against the one-lane-per-position kernel on the same index
+    (ss_test_hook(4, ...): 0 = the product's choice -- the run-queue kernel for flagged tables under binned reads at k >= 25, the
+    per-position kernel otherwise --, 2 = always the per-position kernel, 3 = always the run-queue kernel): a dense table (every k-mer of a genome: buckets, solid
+    runs), a table of repeats (several k-mers per offset), a sparse one (inline k-mers); plain scans in file order, binned
+    resident reads with ss_db_expect_hits (the combining kernel), several tables of this k in one pass beside a k = 31 one."""
+    import torch
+    from oracle import oracle as orc
+    rs = np.random.RandomState(100 + k)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    cases = {}
+    cases["dense"] = _dense_case_k(k, seed=k, G=50000, n_reads=15000)
+    unit = bytes(lut[rs.randint(0, 4, size=37)])
+    g = unit * 40 + b"A" * 90 + b"ACAC" * 30 + b"ACG" * 40 + unit[::-1] * 20
+    g = g + bytes(lut[rs.randint(0, 4, size=6000)]) + g[:800]
+    cases["repeats"] = (b"".join(b">1\n" + g[i:i + k] + b"\n" for i in range(len(g) - k + 1)),
+                        b"\n".join(g[s:s + 150] for s in rs.randint(0, len(g) - 150, size=5000)) + b"\n")
+    cases["sparse"] = _random_db_and_reads(700 + k, 150000, 30000, k=k)
+    dbs, wants, flats = {}, {}, {}
+    for name, (kfa, flat) in cases.items():
+        fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+        wants[name], _ = orc.jellyfish_count(kfa, [fq], k=k, upper=True)
+        dbs[name] = L.KmerDB.from_text(kfa, k, True)
+        assert dbs[name].info()["layout"] == 1
+        flats[name] = flat
+    try:
+        for name, db in dbs.items():
+            d = torch.frombuffer(bytearray(flats[name]), dtype=torch.uint8).cuda()
+            for hook in (0, 2, 3):                            # the product's choice, the per-position kernel, the run-queue kernel
+                L.check(L.lib().ss_test_hook(4, hook), "ss_test_hook")
+                for off in (0, 5):
+                    tbuf = torch.zeros(d.numel() + 16, dtype=torch.uint8, device="cuda")
+                    tbuf[off:off + d.numel()] = d
+                    db.reset()
+                    torch.cuda.synchronize()
+                    db.scan_flat_dev(tbuf.data_ptr() + off, d.numel(), torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(db.counts_rows(), wants[name]), (k, name, hook, off)
+                # binned resident reads: unflagged (plain kernel), then flagged (hook 3 and, at k >= 25, the product: the combining kernel)
+                rset = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=True)
+                for flag in (False, True):
+                    db.expect_hits(flag)
+                    db.reset()
+                    rset.scan_into(db)
+                    L.check(L.lib().ss_device_sync(), "sync")
+                    assert np.array_equal(db.counts_rows(), wants[name]), (k, name, hook, "binned", flag)
+                    db.scan_flat_dev(d.data_ptr(), d.numel(), None)              # file order under the flag: accumulates
+                    L.check(L.lib().ss_device_sync(), "sync")
+                    assert np.array_equal(db.counts_rows(), 2 * wants[name]), (k, name, hook, "file order, flagged", flag)
+                rset.close()
+            L.check(L.lib().ss_test_hook(4, 0), "ss_test_hook")
+        # several tables in one pass: the three of this k (two flagged) + a k = 31 table, over the dense case's reads
+        kfa31, _ = _random_db_and_reads(55, 20000, 10)
+        db31 = L.KmerDB.from_text(kfa31, 31, True)
+        d = torch.frombuffer(bytearray(flats["dense"]), dtype=torch.uint8).cuda()
+        fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flats["dense"].split(b"\n") if r)
+        want_on_dense = {name: orc.jellyfish_count(cases[name][0], [fq], k=k, upper=True)[0] for name in cases}
+        want31, _ = orc.jellyfish_count(kfa31, [fq], k=31, upper=True)
+        for binned in (True, False):
+            rset = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=binned)
+            for all_flagged in (True, False):
+                for name, db in dbs.items():
+                    db.expect_hits(all_flagged or name == "dense")
+                    db.reset()
+                db31.reset()
+                rset.scan_into_many([dbs["dense"], db31, dbs["repeats"], dbs["sparse"]])
+                L.check(L.lib().ss_device_sync(), "sync")
+                for name, db in dbs.items():
+                    assert np.array_equal(db.counts_rows(), want_on_dense[name]), (k, name, "multi", binned, all_flagged)
+                assert np.array_equal(db31.counts_rows(), want31)
+            rset.close()
+        db31.close()
+    finally:
+        L.check(L.lib().ss_test_hook(4, 0), "ss_test_hook")
+        for db in dbs.values():
+            db.close()
