@@ -276,6 +276,23 @@ def built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, s
     dump_json("built_l1.json", out)
 
 
+def l2_k25_section(scratch, vote, sc, synth):
+    """vote_strain_L2_batch with ksize = 25 (`-k 25`) on clusters whose k-mer sets are 25-mers: the reference's report files."""
+    dbb, reads = sc.l2_k25_inputs(scratch)
+    fq = os.path.join(scratch, "l2_k25.fq")
+    open(fq, "wb").write(reads)
+    outdir = os.path.join(scratch, "l2k25_out")
+    os.makedirs(outdir)
+    _, err, _ = run_captured(vote.vote_strain_L2_batch, fq, "", dbb, outdir, 25, {k: dict(v) for k, v in sc.L2_K25_RES.items()}, 0, 40, 0, 0)
+    files = {}
+    for r_, _, fs in os.walk(outdir):
+        for f_ in fs:
+            p_ = os.path.join(r_, f_)
+            files[os.path.relpath(p_, outdir)] = open(p_).read()
+    dump_json("l2_k25.json", dict(sha256=synth.sha256_of(reads), error=err, files=files))
+    print("L2 k25", err, sorted(files))
+
+
 def main():
     from tests import scenarios as sc
     from tests import synth
@@ -297,10 +314,15 @@ def main():
         mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
         l2_big_section(scratch, l2mod, captured, synth)
         built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
+        l2_k25_section(scratch, vote, sc, synth)
         shutil.rmtree(scratch, ignore_errors=True)
         return
     if only == "built":
         built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+    if only == "k25":
+        l2_k25_section(scratch, vote, sc, synth)
         shutil.rmtree(scratch, ignore_errors=True)
         return
 
@@ -535,6 +557,7 @@ def main():
     mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
     l2_big_section(scratch, l2mod, captured, synth)
     built_section(scratch, identify, identify_low_mem, identify_low_depth, sc, synth)
+    l2_k25_section(scratch, vote, sc, synth)
 
     # ---------------------------------------------------------------- seqpy.revcomp (oracle/_ref)
     refso = os.path.join(REPO, "oracle", "_ref")

@@ -274,3 +274,21 @@ L2_BATCH_CASES = {
     "no_reads": ({1: _l1_entry(1), 4: _l1_entry(4)}, 0, 0),
     "only_no_reads": ({4: _l1_entry(4)}, 0, 0),
 }
+
+
+# ------------------------------------------------------------------------------------------------
+# `-k 25` (StrainScan.py:136, 266-271 hands ksize to the layer-2 scans: Vote_Strain_L2_Lasso_new_sp.py:359-371, and to the
+# pre-scan's cutoff msn * k: identify_strains_L2_Enet_Pscan_new_sp.py:226): a cluster whose all_kmer.fasta holds 25-mers
+# ------------------------------------------------------------------------------------------------
+def l2_k25_inputs(root):
+    """-> (db_dir, FASTQ bytes): clusters 1 and 2 of 3 with k = 25 k-mer sets; three strains of cluster 1 at 20x / 8x / 3x, one of cluster 2."""
+    db = os.path.join(root, "dbL2K25")
+    pres = [[1, 1, 0, 0, 1, 0], [1, 0, 1, 0, 0, 1], [0, 1, 1, 1, 0, 0], [1, 0, 0, 1, 1, 1]]
+    c1 = synth.build_l2_cluster(db, 1, 3, ["GCF_K1_0", "GCF_K1_1", "GCF_K1_2", "GCF_K1_3"], [1500, 1200, 1000, 1400, 900, 1100], pres, seed=91, k=25)
+    c2 = synth.build_l2_cluster(db, 2, 3, ["GCF_K2_0", "GCF_K2_1"], [1300, 1100, 900], [[1, 1, 0], [1, 0, 1]], seed=92, k=25)
+    mix = [(c1["strain_extra"]["GCF_K1_0"], 20.0), (c1["strain_extra"]["GCF_K1_2"], 8.0), (c1["strain_extra"]["GCF_K1_3"], 3.0),
+           (c2["strain_extra"]["GCF_K2_1"], 12.0)]
+    return db, synth.simulate_reads(mix, 515)
+
+
+L2_K25_RES = {1: _l1_entry(1), 2: _l1_entry(2)}

@@ -200,7 +200,7 @@ def build_l1_db(db_dir, parent, sites, seed, singleton=None, clusters=None, reco
 
 
 def build_l2_cluster(db_dir, cid, n_clusters, strains, seg_sites, presence, seed,
-                     shared_with=None):
+                     shared_with=None, k=None):
     """Write <db_dir>/Kmer_Sets_L2/Kmer_Sets/C<cid>.  Returns dict(strain_extra, K, X).
 
     strains    list of strain names (columns after re-clustering)
@@ -215,6 +215,7 @@ def build_l2_cluster(db_dir, cid, n_clusters, strains, seg_sites, presence, seed
     os.makedirs(cdir, exist_ok=True)
     presence = np.asarray(presence, bool)
     S, G = presence.shape
+    K = globals()["K"] if k is None else int(k)       # (the k-mer sets of a database built with StrainScan_build.py -k)
     seg_seq = [rand_seq(rs, n + K - 1) for n in seg_sites]
     kid = {}
     rows_i, rows_j, orow, ocol = [], [], [], []

@@ -248,3 +248,15 @@ def test_built_db_walk_matches_reference(sname, golden_dir, built_db):
     assert want["error"] is None and [a for a, _ in got] == [a for a, _ in want["result"]]
     for (_, b), (_, wb) in zip(got, want["result"]):
         assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
+
+
+def test_oracle_vote_batch_at_k25(golden_dir, tmp_path):
+    """`-k 25`: the reference's vote_strain_L2_batch with ksize = 25 on clusters whose k-mer sets are 25-mers (jellyfish -m 25, the
+    pre-scan's cutoff msn * 25) against the oracle's serial restatement."""
+    g = _load(golden_dir, "l2_k25.json")
+    dbb, reads = sc.l2_k25_inputs(str(tmp_path))
+    assert synth.sha256_of(reads) == g["sha256"] and g["error"] is None
+    files = orc.vote_batch(dbb, [reads], {k: dict(v) for k, v in sc.L2_K25_RES.items()}, 25, 0, 40, 0, 0)
+    assert sorted(files) == sorted(g["files"])
+    for rel, text in g["files"].items():
+        _cmp_report_text(files[rel], text, (3, 4, 5, 6) if rel == "final_report.txt" else (3, 4, 5, 6, 8, 9))

@@ -206,3 +206,29 @@ def test_identify_on_the_database_the_references_builder_wrote(sname, golden_dir
     for (_, b), (_, wb) in zip(res, want["result"]):
         assert abs(b - wb) <= 1e-12 * max(1.0, abs(wb))
     ssdb.clear_cache()
+
+
+def test_vote_batch_at_k25(golden_dir, tmp_path, monkeypatch):
+    """`strainscan -k 25` reaches the layer-2 scans (StrainScan.py:136,266-271 -> Vote_Strain_L2_Lasso_new_sp.py:359-371): cluster
+    tables of 25-mers on the minimizer-paged index, two of them in one pass (scan_mini_kernel with k at run time, the combining
+    variant) -- the reference's report files for ksize = 25, integer columns character for character, abundances within 1e-5."""
+    from strainscan_amd import Vote_Strain_L2_Lasso_new_sp as vote
+    from strainscan_amd import db as ssdb
+    g = _load(golden_dir, "l2_k25.json")
+    root = tmp_path / "in"
+    root.mkdir()
+    dbb, reads = sc.l2_k25_inputs(str(root))
+    assert synth.sha256_of(reads) == g["sha256"]
+    fq = root / "k25.fq"
+    fq.write_bytes(reads)
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    ssdb.clear_cache()
+    out = tmp_path / "out"
+    out.mkdir()
+    _, err, text = _run(vote.vote_strain_L2_batch, str(fq), "", dbb, str(out), 25, {k: dict(v) for k, v in sc.L2_K25_RES.items()}, 0, 40, 0, 0)
+    assert err == g["error"], (err, text[-300:])
+    files = {str(p.relative_to(out)): p.read_text() for p in out.rglob("*") if p.is_file()}
+    assert sorted(files) == sorted(g["files"])
+    for rel, want in g["files"].items():
+        _cmp_report(files[rel], want, float_cols=(3, 4, 5, 6) if rel == "final_report.txt" else (3, 4, 5, 6, 8, 9))
+    ssdb.clear_cache()
