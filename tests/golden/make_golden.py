@@ -182,7 +182,8 @@ def mid_section(scratch, identify, identify_low_mem, identify_low_depth, sc, syn
         tb = [ln for ln in errtxt.splitlines() if re.match(r"^[A-Za-z_.]*(Error|Exception)\b", ln)]
         flow[name] = dict(sample=sname, db=dbn, argv=extra, returncode=rc, error=(tb[-1].split(":")[0] if tb else None),
                           cls_dict=cls_line[-1][cls_line[-1].index("{"):-1] if cls_line else None,
-                          trace=parse_trace(out), messages=[ln for ln in out.splitlines() if ln.startswith(("- ", "Warning"))],
+                          trace=parse_trace(out),
+                          messages=[ln for ln in out.splitlines() if ln.startswith(("- ", "Warning")) and "running time" not in ln],      # (no wall-clock times)
                           files=files)
         print("mid flow", name, rc, flow[name]["error"], sorted(files))
     dump_json("mid_flow.json", flow)
