@@ -4,7 +4,8 @@
 Runs only in the build container (needs /root/reference and /opt/conda/bin/python3.9 with
 numpy 1.26 / scipy 1.7 / scikit-learn 0.24.2):
 
-    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py            # everything: ~5.5 min; every file regenerates byte-identically
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py mid|built|k25    # round 6's sections alone
 
 What it does, without modifying or copying any reference file into the repo:
   * copies /root/reference/library to a scratch dir (the wrappers exec the jellyfish ELF that
