@@ -133,11 +133,15 @@ def enet_cv_fit(img, cols, vec, trace=None, split=None):
     p = len(cols)
     n = vec.n_keep
     y_dev = vec.ykeep
+    fold = None
     if split is not None:                     # started in detect_core: the host walks the word stream, the device does the swaps
-        fold = img.fold_words_train(vec.keep, split, n)
-        tm["shuffle_split_walk"] = split.walk_ms
-        mark("wait_for_shuffle_split_and_fold_words")
-    else:
+        try:
+            fold = img.fold_words_train(vec.keep, split, n)
+            tm["shuffle_split_walk"] = split.walk_ms
+            mark("wait_for_shuffle_split_and_fold_words")
+        except _lib.SSError:                  # the device side of the splits failed late (memory, a HIP error): the host makes the same bits
+            fold = None
+    if fold is None:
         bits, n_test = L2.shuffle_split_test_bits(n, CV_NITER, TEST_SIZE, 0)
         mark("shuffle_split_host")
         assert bits.size == n

@@ -811,6 +811,15 @@ def _l2_branch_scenarios(tmp_path, monkeypatch, golden_l2):
     monkeypatch.setattr(l2mod.SplitDev, "__init__", no_room)
     test_detect_strains("three", golden_l2)
     monkeypatch.undo()
+    # ... and when the splits fail LATE (the walk started, the wait reports an error): the host's bits, same results
+    monkeypatch.setattr(m, "SPLIT_DEV_MIN", 1)
+
+    def late(self):
+        raise L_.SSError(L_.SS_EHIP, "ss_split_dev_wait")
+    monkeypatch.setattr(l2mod.SplitDev, "wait", late)
+    test_detect_strains("three", golden_l2)
+    test_detect_strains("many", golden_l2)
+    monkeypatch.undo()
     for name in sc.L2_BATCH_CASES:
         d = tmp_path / ("batch_" + name)
         d.mkdir()
