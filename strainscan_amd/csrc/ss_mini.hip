@@ -126,6 +126,13 @@ constexpr int Q1CAP = SS_Q1CAP;    // runs (q1), Bloom survivors (q1b) and found
                                    // reads: mean 94 runs, max ~110); overflow is handled inline.  With 160 the
                                    // workgroup needs 4.9 KB: 32 one-wave workgroups per CU.  Test builds shrink it.
 static_assert(Q1CAP <= 4096, "q2 keeps a q1b index in 12 bits");
+// ... and with k at run time (KK = 0, 17 <= k <= 30): a k-mer of k - 14 m-mers changes its minimizer every (k - 13) / 2 positions, so a
+// tile has ~2 x 992 / (k - 13) runs -- 165 at k = 25, 198 at k = 23, 248 at k = 21.  256: the most the combining table's byte-sized run
+// indices (QComb::ent / rest) can name; 7.2 KB per workgroup with it (22 one-wave workgroups per CU).
+#ifndef SS_Q1CAP_RT
+#define SS_Q1CAP_RT 256
+#endif
+constexpr int Q1CAP_RT = SS_Q1CAP_RT > 256 ? 256 : SS_Q1CAP_RT;
 // A tile is (MT - 2) x 16 start positions: all MT lanes load 16 bases and key the 16 m-mers that
 // START in them; lanes 0..MT-3 own 16 k-mers each, whose 17-m-mer windows end in the NEXT lane's
 // m-mers, whose last bases lie in the lane after that.  The last two lanes only feed their
@@ -134,13 +141,14 @@ static_assert(Q1CAP <= 4096, "q2 keeps a q1b index in 12 bits");
 constexpr int MLANES = MT - 2;
 constexpr int MTILE = MLANES * PPT;
 
-struct QShared {
+template <int CAP>
+struct QSharedT {
     uint32_t code_[MT + 3];            // code_[1 + i] = bases 16 i .. 16 i + 15 of the tile; one word of slack in front (the
                                        // window of 16 bases BEFORE a minimizer near the tile start) and two behind
     uint16_t inv[MT + 2];
-    uint32_t q1[Q1CAP + 64];           // run:   len << 12 | tile position of its first k-mer (+64 dump slots)
+    uint32_t q1[CAP + 64];             // run:   len << 12 | tile position of its first k-mer (+64 dump slots)
     alignas(16) uint8_t ib[MT * PPT];  // per tile position: index (0..31, counted from the lane's first m-mer) of the minimizer
-    uint64_t q2[Q1CAP];                // found bucket: bucket start << 32 | multi << 31 | aligned offset mask << 12 | run index (q1b with a
+    uint64_t q2[CAP];                  // found bucket: bucket start << 32 | multi << 31 | aligned offset mask << 12 | run index (q1b with a
                                        // Bloom filter, q1 without)
     uint32_t cnt[4];                   // [1] = found runs
 #ifdef SS_LDS_PAD
@@ -148,8 +156,9 @@ struct QShared {
 #endif
 };
 // (a __shared__ variable of its own: instantiations without a Bloom filter do not pay its 1.25 KB)
-struct QBloom {
-    uint64_t q1b[Q1CAP];               // run that passed the Bloom filter: h << 32 | minimizer offset in the first k-mer << 17 | q1 entry
+template <int CAP>
+struct QBloomT {
+    uint64_t q1b[CAP];                 // run that passed the Bloom filter: h << 32 | minimizer offset in the first k-mer << 17 | q1 entry
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -166,19 +175,22 @@ struct QBloom {
 constexpr int COMB_NE = 64;            // entries (= lanes of the wave: the flush looks at one entry per lane)
 constexpr int COMB_CH = 4;             // consecutive tiles per workgroup
 constexpr uint32_t COMB_NONE = 0xFFu;
-struct QComb {
+template <int CAP>
+struct QCombT {
+    static_assert(CAP <= 256, "run indices in bytes");
     uint32_t key[COMB_NE];             // bucket start + 1, 0 = free
     uint32_t nrun[COMB_NE];            // found runs that took this entry since the last flush (a byte counter holds 255)
     uint32_t acc[COMB_NE][5];          // byte o = occurrences of the bucket's slot o (1..19; slot 0 is the header)
-    uint8_t ent[Q1CAP];                // per found run of the tile: its entry, COMB_NONE = count in global memory
+    uint8_t ent[CAP];                  // per found run of the tile: its entry, COMB_NONE = count in global memory
     uint8_t list[COMB_NE];             // flush: the occupied entries
-    uint8_t rest[Q1CAP];               // phase 3: the found runs whose bucket is not solid, from the front; solid runs whose hits
+    uint8_t rest[CAP];                 // phase 3: the found runs whose bucket is not solid, from the front; solid runs whose hits
                                        // go straight to the counters, from the back (indices into q2)
 };
 
 // the 31-mer starting at tile position pos as two 32-bit halves (funnel shifts; no 64-bit shifts)
 // (khi_mask: the 2 k - 32 bits of the upper half: 0x3FFFFFFF at k = 31)
-__device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t &lo, uint32_t &hi, uint32_t khi_mask = 0x3FFFFFFFu)
+template <class QS>
+__device__ __forceinline__ void kmer_at(const QS &S, uint32_t pos, uint32_t &lo, uint32_t &hi, uint32_t khi_mask = 0x3FFFFFFFu)
 {
     const uint32_t w = pos >> 4, sh = 2 * (pos & 15);
     const uint32_t a = S.code_[w + 1], b = S.code_[w + 2], c = S.code_[w + 3];
@@ -187,13 +199,15 @@ __device__ __forceinline__ void kmer_at(const QShared &S, uint32_t pos, uint32_t
 }
 
 // the 15-mer starting at tile position p (one funnel shift over two code words)
-__device__ __forceinline__ uint32_t mmer_at(const QShared &S, uint32_t p)
+template <class QS>
+__device__ __forceinline__ uint32_t mmer_at(const QS &S, uint32_t p)
 {
     const uint32_t w = p >> 4;
     return __builtin_amdgcn_alignbit(S.code_[w + 2], S.code_[w + 1], 2 * (p & 15)) & ss::M30;
 }
 // the 16 bases starting at tile position p (p >= -16)
-__device__ __forceinline__ uint32_t win16_at(const QShared &S, int32_t p)
+template <class QS>
+__device__ __forceinline__ uint32_t win16_at(const QS &S, int32_t p)
 {
     const int32_t w = (p >> 4) + 1;
     return __builtin_amdgcn_alignbit(S.code_[w + 1], S.code_[w], 2 * (p & 15));
@@ -226,8 +240,8 @@ __device__ __forceinline__ void count_slot(uint32_t cpos, uint32_t bstart, uint3
 }
 // compare the candidate (already loaded) with k-mer `pos`; count; fall back to a bucket scan when
 // several database k-mers share a minimizer offset (repeated / colliding minimizer)
-template <bool COMB>
-__device__ __forceinline__ void settle_item(const QShared &S, uint32_t pos, uint32_t bstart, uint32_t multi, uint32_t cpos,
+template <bool COMB, class QS>
+__device__ __forceinline__ void settle_item(const QS &S, uint32_t pos, uint32_t bstart, uint32_t multi, uint32_t cpos,
                                             uint64_t cand, const uint64_t *__restrict__ mkeys,
                                             uint32_t *__restrict__ counts, uint32_t ent = COMB_NONE, uint32_t *__restrict__ acc5 = nullptr,
                                             uint32_t khi_mask = 0x3FFFFFFFu)
@@ -372,9 +386,10 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
     const uint32_t khi_mask = (1u << (2 * K - 32)) - 1u;                // upper half of a 2 k-bit key
     const uint32_t fmask = F >= 16u ? 0xFFFFFFFFu : (1u << (2u * F)) - 1u;      // a flank's 2 F bits
     static_assert(31 - ss::MINI_M + 1 == PPT + 1, "k = 31: a k-mer window = own m-mers j..15 + neighbour m-mers 0..j");
-    __shared__ QShared S;
-    __shared__ QBloom SB;                            // (dropped from the instantiations that never touch it)
-    __shared__ QComb C;
+    constexpr int QC = KK == 31 ? Q1CAP : Q1CAP_RT;  // runs a tile's queues hold
+    __shared__ QSharedT<QC> S;
+    __shared__ QBloomT<QC> SB;                       // (dropped from the instantiations that never touch it)
+    __shared__ QCombT<QC> C;
     const int t = threadIdx.x;
     const uint32_t vc1 = ss::MMK_C1;
     constexpr uint64_t CH = COMB ? COMB_CH : 1;      // consecutive tiles per workgroup
@@ -590,10 +605,10 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         {
             const uint32_t mine = (uint32_t)__popc(need);
             const uint32_t incl = wave_inclusive_sum(mine);
-            n1 = min((uint32_t)__builtin_amdgcn_readlane((int)incl, 63), (uint32_t)Q1CAP);
+            n1 = min((uint32_t)__builtin_amdgcn_readlane((int)incl, 63), (uint32_t)QC);
             const uint32_t mybase = incl - mine;
             if (need) {
-                const uint32_t dummy = (uint32_t)Q1CAP + (uint32_t)t;   // where entries beyond the capacity go
+                const uint32_t dummy = (uint32_t)QC + (uint32_t)t;   // where entries beyond the capacity go
                 const uint32_t stop1 = stop >> 1, tbase = (uint32_t)(t * PPT);
                 uint32_t idx = mybase;
                 for (uint32_t nd = need; nd; idx++) {
@@ -602,10 +617,10 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     const uint32_t len = (uint32_t)__ffs(stop1 >> j);                       // until the next run / gap
                     S.q1[min(idx, dummy)] = (len << 12) + (tbase + j + (nd ? 0u : ext12));
                 }
-                if (mybase + mine > (uint32_t)Q1CAP) {                          // rare: which of my runs did not fit
+                if (mybase + mine > (uint32_t)QC) {                          // rare: which of my runs did not fit
                     uint32_t r = mybase;
                     for (uint32_t nd = need; nd; nd &= nd - 1u, r++)
-                        if (r >= (uint32_t)Q1CAP) ovf |= nd & (0u - nd);
+                        if (r >= (uint32_t)QC) ovf |= nd & (0u - nd);
                 }
             }
         }
@@ -623,9 +638,9 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
         auto push_found = [&](uint32_t lo, uint32_t mask17, uint32_t meta, uint32_t ridx, bool queued) {
             const uint32_t bstart = lo & ss::START_MASK, multi = lo >> 31;
             const uint32_t amask = aligned_mask(mask17, (meta >> 17) & 31u, F);
-            uint32_t i2 = Q1CAP;
+            uint32_t i2 = QC;
             if (queued) i2 = atomicAdd(&S.cnt[1], 1u);
-            if (i2 < Q1CAP) {
+            if (i2 < QC) {
                 S.q2[i2] = ((uint64_t)(lo & (ss::START_MASK | ss::PG_SOLID)) << 32) | (multi << 31) | (amask << 12) | ridx;      // (bit 62: solid)
             } else {
                 // the queue is full (only with floods of tag collisions), or phase 3 is already
@@ -771,7 +786,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
 #define SS_U3 4
 #endif
             constexpr int U3 = SS_U3;
-            const uint32_t n2 = min(S.cnt[1], (uint32_t)Q1CAP);
+            const uint32_t n2 = min(S.cnt[1], (uint32_t)QC);
             // a probe launch (choose_comb: the first tiles of a binned set against a table nobody has flagged) reports its found runs
             if (!COMB && (xcd_swizzle & 2u) && t == 0) atomicAdd(&ss_probe_runs[blockIdx.x & 63u], n2);
             bool comb_full = false;
@@ -898,7 +913,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
                     }
                 }
                 const uint64_t hm = __ballot(hitmask != 0u);
-                if (hitmask) C.rest[Q1CAP - 1u - (n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)))] = (uint8_t)r;
+                if (hitmask) C.rest[QC - 1u - (n_hit + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u)))] = (uint8_t)r;
                 n_hit += (uint32_t)__popcll(hm);
             }
             if (COMB) __syncthreads();
@@ -906,7 +921,7 @@ __global__ __launch_bounds__(MT, WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(
             for (uint32_t g0 = 0; g0 < n_hit * 16u; g0 += MT) {
                 const uint32_t g = g0 + (uint32_t)t;
                 if ((g >> 4) < n_hit) {
-                    const uint64_t e = S.q2[C.rest[Q1CAP - 1u - (g >> 4)]];
+                    const uint64_t e = S.q2[C.rest[QC - 1u - (g >> 4)]];
                     const uint32_t j = g & 15u, slot_a = (uint32_t)(e >> 32), mt = (uint32_t)e;
                     if ((mt >> j) & 1u) atomicAdd(&counts[slot_a - j], 1u);
                     if (j == 0u && (mt >> 16)) atomicAdd(&counts[slot_a - 16u], 1u);
@@ -1539,11 +1554,11 @@ static void launch_lb(bool aligned, bool comb, unsigned blocks, hipStream_t stre
     const uint32_t swz = swz0 | (probe ? 2u : 0u);
     const ScanTabs none = {};
     // (the combining variant needs 79 VGPRs: there is no 8-waves-per-SIMD build of it -- it carried 32 bytes of scratch)
-    // k = 31: the instantiation with k a constant; any other k (17..30): k at run time
+    // k = 31: the instantiation with k a constant; any other k (17..30): k at run time (its queues of 256 runs: five waves per SIMD)
 #define SS_LAUNCH(A, B, C_) do {                                                                                                                         \
         if (db->k == 31) hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (C_ && LB > 6) ? 6 : LB, false, 31>), dim3(blocks), dim3(MT), 0, stream, bases, n,    \
                                             n_tiles, db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none, 31);               \
-        else hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (C_ && LB > 6) ? 6 : LB, false, 0>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,        \
+        else hipLaunchKernelGGL((scan_mini_kernel<A, B, C_, (LB > 5 ? 5 : LB), false, 0>), dim3(blocks), dim3(MT), 0, stream, bases, n, n_tiles,               \
                                 db->d_mkeys, pages, db->n_dir, db->d_counts, cbase, db->d_bloom, bshift, swz, none, db->k);                                 \
     } while (0)
     // a table that expects hits (ss_db_expect_hits) skips its Bloom filter: nearly every minimizer of the reads is in it
@@ -1583,7 +1598,7 @@ int launch_scan_mini_multi(ss_db *const *dbs, int n_dbs, const void *bases_dev, 
         if (k_all == 31) hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, LB, true, 31>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles,      \
                                             tabs.mkeys[0], tabs.pages[0], tabs.n_pages[0], tabs.counts[0], tabs.cbase[0],                        \
                                             (const uint32_t *)nullptr, 0u, swz, tabs, 31);                                                       \
-        else hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, LB, true, 0>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles,                   \
+        else hipLaunchKernelGGL((scan_mini_kernel<A, false, C_, (LB > 5 ? 5 : LB), true, 0>), dim3(blocks), dim3(MT), 0, stream, b, n, n_tiles,      \
                                 tabs.mkeys[0], tabs.pages[0], tabs.n_pages[0], tabs.counts[0], tabs.cbase[0],                                    \
                                 (const uint32_t *)nullptr, 0u, swz, tabs, k_all);                                                                \
     } while (0)
@@ -1659,15 +1674,16 @@ int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t s
                      uint64_t n_tiles, bool binned, uint64_t set_id)
 {
     // Which kernel.  k = 31: scan_mini_kernel with k a constant (everything below).  17 <= k <= 30: the one-lane-per-position kernel
-    // (scan_minik_kernel), except where scan_mini_kernel with k at run time (KK = 0) is the faster -- measured (profiles/r06_k_index.json):
-    // a table that expects hits scanned by a BINNED read set (the combining variant: a cluster table at k = 25, 8 M reads: 4.8 against
-    // 9.9 ms) as long as a tile's runs fit its queues (k >= 25: ~170 runs of a 160-entry queue's worth; at k = 21 the overflow path
-    // makes it 19.9 against 15.4, and on a table with few hits the per-position kernel wins at every k: 2.3 against 2.5-2.7 at k = 25-27).
+    // (scan_minik_kernel), except where scan_mini_kernel with k at run time (KK = 0, queues of 256 runs) is the faster -- measured
+    // (profiles/r06_k_index.json, a 5 M-row cluster table, 8 M reads): a table that expects hits scanned by a BINNED read set (the
+    // combining variant) at k >= 21: k = 27 / 25 / 23 / 21: 4.3 / 4.9 / 5.5 / 7.7 ms against 9.3 / 9.9 / 10.9 / 15.3; at k = 19 a tile's
+    // ~330 runs overflow the queues (18.0 against 18.5), in file order the two are equal at every k, and on a table with few hits the
+    // per-position kernel wins at every k (2.3 against 2.5-2.7 ms per 4 M reads at k = 25-27).
     // ss_test_hook 4 (tests: the kernels held to each other on one index): 1 = tables of k = 31 through the per-position kernel,
     // 2 = tables of every k through it, 3 = tables of every k through scan_mini_kernel.
     {
         const long long hk = g_hook_generic_k.load();
-        if (db->k == 31 ? (hk == 1 || hk == 2) : (hk != 3 && (hk == 2 || !(binned && db->expect_hits && db->k >= 25))))
+        if (db->k == 31 ? (hk == 1 || hk == 2) : (hk != 3 && (hk == 2 || !(binned && db->expect_hits && db->k >= 21))))
             return launch_scan_minik(db, (const uint8_t *)bases_dev, n, stream);
         if (db->k != 31) {                                  // (no probe: the flag decides)
             const uint64_t nt = (n + MTILE - 1) / MTILE;
