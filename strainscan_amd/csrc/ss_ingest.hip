@@ -898,8 +898,8 @@ int ss_scan_reads_multi(ss_db *const *dbs, int n_dbs, const ss_reads *R, void *s
         int k = 0;
         ss_db_info(dbs[i], nullptr, nullptr, nullptr, &k);
         if (R->has_cut_record && k != 31) return SS_ERANGE;
-        // (several tables per pass: k = 31, and k >= 21 where scan_mini_kernel with k at run time serves -- ss_mini.hip launch_scan_mini)
-        if (dbs[i]->layout == 1 && k >= 21) mini_all.push_back(dbs[i]);
+        // (several tables per pass: k = 31, and k >= 20 where scan_mini_kernel with k at run time serves every table -- ss_mini.hip launch_scan_mini)
+        if (dbs[i]->layout == 1 && k >= 20) mini_all.push_back(dbs[i]);
         else { int rc = ss_scan_reads(dbs[i], R, stream); if (rc) return rc; }
     }
     // the tables of ONE k go through the several-tables kernel together (a tile's minimizers are made once per k)

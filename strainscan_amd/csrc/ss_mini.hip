@@ -1673,17 +1673,18 @@ static int launch_plain_or_comb(ss_db *db, bool comb, bool probe, const uint8_t 
 int launch_scan_mini(ss_db *db, const void *bases_dev, uint64_t n, hipStream_t stream, unsigned /*blocks*/,
                      uint64_t n_tiles, bool binned, uint64_t set_id)
 {
-    // Which kernel.  k = 31: scan_mini_kernel with k a constant (everything below).  17 <= k <= 30: the one-lane-per-position kernel
-    // (scan_minik_kernel), except where scan_mini_kernel with k at run time (KK = 0, queues of 256 runs) is the faster -- measured
-    // (profiles/r06_k_index.json, a 5 M-row cluster table, 8 M reads): a table that expects hits scanned by a BINNED read set (the
-    // combining variant) at k >= 21: k = 27 / 25 / 23 / 21: 4.3 / 4.9 / 5.5 / 7.7 ms against 9.3 / 9.9 / 10.9 / 15.3; at k = 19 a tile's
-    // ~330 runs overflow the queues (18.0 against 18.5), in file order the two are equal at every k, and on a table with few hits the
-    // per-position kernel wins at every k (2.3 against 2.5-2.7 ms per 4 M reads at k = 25-27).
+    // Which kernel.  k = 31: scan_mini_kernel with k a constant (everything below).  17 <= k <= 30: scan_mini_kernel with k at run time
+    // (KK = 0, queues of 256 runs) -- measured against the one-lane-per-position kernel scan_minik_kernel (profiles/r06_k_index.json):
+    // a table with few hits, 4 M reads, k = 29 / 25 / 21 / 20 / 19 / 17: 1.38 / 1.51 / 1.73 / 1.82 / 2.63 / 3.46 ms against 2.24 / 2.31 /
+    // 2.75 / 2.95 / 3.18 / 3.64 (k = 31: 1.34); a cluster table under binned reads (the combining variant), 8 M reads, k = 29 / 25 / 21 /
+    // 20: 3.3 / 4.1 / 7.3 / 9.1 against 8.9 / 9.9 / 15.3 / 16.6.  The exception: tables that expect hits at k <= 19, where a tile's
+    // ~330+ runs overflow the queues and the per-position kernel is as fast or faster (k = 19: 18.5 binned / 18.9 in file order
+    // against 17.5 / 22.2).
     // ss_test_hook 4 (tests: the kernels held to each other on one index): 1 = tables of k = 31 through the per-position kernel,
     // 2 = tables of every k through it, 3 = tables of every k through scan_mini_kernel.
     {
         const long long hk = g_hook_generic_k.load();
-        if (db->k == 31 ? (hk == 1 || hk == 2) : (hk != 3 && (hk == 2 || !(binned && db->expect_hits && db->k >= 21))))
+        if (db->k == 31 ? (hk == 1 || hk == 2) : (hk != 3 && (hk == 2 || (db->k <= 19 && db->expect_hits))))
             return launch_scan_minik(db, (const uint8_t *)bases_dev, n, stream);
         if (db->k != 31) {                                  // (no probe: the flag decides)
             const uint64_t nt = (n + MTILE - 1) / MTILE;
