@@ -152,6 +152,77 @@ def test_edge_inputs(L):
     assert e.counts_rows().size == 0
 
 
+@pytest.mark.parametrize("k", [17, 18, 22, 26, 31])
+def test_edge_inputs_on_the_page_index_at_any_k(L, k):
+    """The page index's three kernels (ss_test_hook(4): 0 the product's choice, 2 the per-position kernel, 3 the run-queue kernel
+    with k at run time / the tuned one at 31) on the inputs that sit on their seams: records of k - 1, k, k + 1 ... k + 16 bases
+    (fewer m-mers than a window, exactly one window, one more), records of thousands of bases (tiles of 992 positions without a
+    separator, windows across a tile's halo), N inside the first / last k-mer of a record and in runs, lower-case bases, empty
+    lines, a block without a final separator, the same block at four byte offsets -- against the oracle every time."""
+    import torch
+    from oracle import oracle as orc
+    rs = np.random.RandomState(4000 + k)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    ga = lut[rs.randint(0, 4, size=30000)]
+    g = ga.tobytes()
+    kms = [g[i:i + k] for i in range(0, 30000 - k, 1 if k < 20 else 2)]
+    kfa = b"".join(b">1\n" + km + b"\n>1\n" + synth.revcomp(km) + b"\n" for km in kms)
+    recs = []
+    for ln in list(range(max(1, k - 2), k + 18)) * 6:                 # around one window
+        s = int(rs.randint(0, 30000 - ln))
+        recs.append(g[s:s + ln])
+    for ln in (991, 992, 993, 1023, 1984, 2500, 6000):                # whole tiles inside one record
+        s = int(rs.randint(0, 30000 - ln))
+        r = g[s:s + ln]
+        recs += [r, synth.revcomp(r)]
+    for _ in range(300):                                              # N at the seams of a record, runs of N, lower case
+        s = int(rs.randint(0, 30000 - 200))
+        r = bytearray(g[s:s + int(rs.randint(k, 200))])
+        how = int(rs.randint(0, 6))
+        if how == 0: r[0] = ord("N")
+        elif how == 1: r[-1] = ord("N")
+        elif how == 2: r[k - 1] = ord("N")
+        elif how == 3: r[len(r) - k] = ord("N")
+        elif how == 4:
+            a = int(rs.randint(0, len(r)))
+            e = min(len(r), a + int(rs.randint(1, 40)))
+            r[a:e] = b"N" * (e - a)
+        else: r = bytearray(bytes(r).lower())
+        recs.append(bytes(r))
+    recs += [b"", b"", b"N", b"n" * 50, g[:k], b""]
+    order = rs.permutation(len(recs))
+    flat = b"\n".join(recs[i] for i in order)                         # (no final separator)
+    fq = b"".join(b"@r\n" + r + b"\n+\n" + b"I" * len(r) + b"\n" for r in flat.split(b"\n") if r)
+    want, _ = orc.jellyfish_count(kfa, [fq], k=k, upper=True)
+    assert want.any()
+    db = L.KmerDB.from_text(kfa, k, True)
+    assert db.info()["layout"] == 1
+    try:
+        for hook in (0, 2, 3):
+            L.check(L.lib().ss_test_hook(4, hook), "ss_test_hook")
+            for flag in (False, True):
+                db.expect_hits(flag)
+                for off in (0, 1, 6, 13):
+                    t = torch.zeros(len(flat) + 64, dtype=torch.uint8, device="cuda")
+                    t[off:off + len(flat)] = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+                    db.reset()
+                    torch.cuda.synchronize()
+                    db.scan_flat_dev(t.data_ptr() + off, len(flat), torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(db.counts_rows(), want), (k, hook, flag, off)
+                d = torch.frombuffer(bytearray(flat), dtype=torch.uint8).cuda()
+                for binned in (True, False):
+                    rset = L.ReadSet.from_flat_dev(d.data_ptr(), d.numel(), order=binned)
+                    db.reset()
+                    rset.scan_into(db)
+                    L.check(L.lib().ss_device_sync(), "sync")
+                    assert np.array_equal(db.counts_rows(), want), (k, hook, flag, "resident", binned)
+                    rset.close()
+    finally:
+        L.check(L.lib().ss_test_hook(4, 0), "ss_test_hook")
+        db.close()
+
+
 def test_chunked_host_scan_equals_single_block(L):
     """ss_scan_flat_host stages 32 MiB chunks overlapping by k-1 bytes: exact-once counting."""
     import torch
