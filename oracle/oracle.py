@@ -340,7 +340,10 @@ def alpha_grid(X, y, l1_ratio=0.5, eps=1e-3, n_alphas=50):
     alpha_max = np.sqrt(Xy ** 2).max() / (len(y) * l1_ratio)
     if alpha_max <= np.finfo(float).resolution:
         return np.full(n_alphas, np.finfo(float).resolution)
-    return np.logspace(np.log10(alpha_max * eps), np.log10(alpha_max), num=n_alphas)[::-1]
+    # np.logspace(np.log10(alpha_max * eps), np.log10(alpha_max), num)[::-1] with log10 / pow taken from libm, as numpy 1.17.3 of the
+    # reference's environment.yaml takes them: later numpy builds bring their own SIMD log10 / pow, an ulp away now and then, and when
+    # the cross-validation picks alphas[0] that ulp decides between a coefficient of 0 and one of 1e-16 (tests/golden/fuzz_reference.py)
+    return np.array([math.pow(10.0, float(v)) for v in np.linspace(math.log10(alpha_max * eps), math.log10(alpha_max), num=n_alphas)])[::-1]
 
 
 def shuffle_split(n, n_splits=20, test_size=0.5, seed=0):

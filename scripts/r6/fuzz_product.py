@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""The HIP path against a directory of reference outputs on random scenarios (tests/golden/fuzz_reference.py gen, made in the
+build container where the reference runs; the directory travels with the tree, e.g. tests/golden/_fuzz_tmp/ -- not committed):
+    fuzz_product.py DIR l2      detect_core (device Pre_Scan, ElasticNetCV, refit) on every l2_<seed>.json: the pre-scan's integers
+                                bit-exact, alphas to 1e-12, mse_path to 1e-7, coefficients / abundances to 1e-5, n_iter equal
+    fuzz_product.py DIR l1      identify.jellyfish_count (bit-exact vs the real jellyfish), identify_cluster of both modules under the
+                                recorded cutoffs (result dicts, visit order, printed lines), identify_ranks on every l1_<seed>.json
+Prints one line per disagreement and a summary; exit code 1 on any."""
+import contextlib
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import hostlogic as hl          # noqa: E402
+from tests import scenarios as sc          # noqa: E402
+from tests import scenarios_fuzz as sf     # noqa: E402
+from tests import synth                    # noqa: E402
+
+TOL = 1e-5
+
+
+def _run(fn, *a, **kw):
+    buf = io.StringIO()
+    err = res = None
+    with contextlib.redirect_stdout(buf):
+        try:
+            res = fn(*a, **kw)
+        except BaseException as e:  # noqa: B902
+            err = type(e).__name__
+    return res, err, buf.getvalue()
+
+
+def product_l2(g, arrs):
+    """-> list of disagreements of the product's detect_core with one golden entry (also used by tests/test_fuzz_golden.py)."""
+    from strainscan_amd import identify_strains_L2_Enet_Pscan_new_sp as m
+    seed = g["seed"]
+    case = sf.l2_case(seed)
+    X, O, y = case["X"], case["O"], case["y"]
+    if synth.sha256_of(X.indptr.tobytes(), X.indices.tobytes(), O.indptr.tobytes(), O.indices.tobytes(), y.tobytes()) != g["sha256"]:
+        return [(seed, "inputs differ")]
+    trace = {}
+    out, err, _ = _run(m.detect_core, X, O, case["ids"], y.copy(), case["ksize"], case["npp25"], case["npp75"], case["npp_out"], case["cls_cov"],
+                       case["all_cls"], case["l2"], case["msn"], case["pmode"], case["emode"], trace=trace)
+    if err != g["error"]:
+        return [(seed, "error", err, g["error"])]
+    if err is not None:
+        return []
+    res, res2, scov, sval, fsrc = out
+    try:
+        assert list(scov) == g["order"], ("order", list(scov), g["order"])
+        assert {k: list(v) for k, v in scov.items()} == g["strain_cov"], "strain_cov"
+        assert {k: float(v) for k, v in sval.items()} == {k: float(v) for k, v in g["strain_val"].items()}, "strain_val"
+        for k, v in g["final_src"].items():
+            assert abs(fsrc[k] - v) < 1e-12, ("final_src", k)
+        assert set(res) == set(g["res"]), ("res keys", dict(res), g["res"])
+        for k, v in g["res"].items():
+            assert abs(float(res[k]) - float(v)) <= TOL, ("res", k, res[k], v)
+            assert abs(float(res2[k]) - float(g["res2"][k])) <= TOL * max(1.0, abs(float(g["res2"][k]))), ("res2", k, res2[k], g["res2"][k])
+        if arrs:
+            assert trace["n_rows"] == g["n_rows"] and trace["p"] == g["p"], ("shape", trace["n_rows"], trace["p"], g["n_rows"], g["p"])
+            assert np.allclose(trace["alphas_"], arrs["alphas"], rtol=1e-12, atol=0), "alphas"
+            assert np.allclose(trace["mse_path_"], arrs["mse_path"], rtol=1e-7, atol=1e-9), ("mse_path", float(np.max(np.abs(trace["mse_path_"] - arrs["mse_path"]) / np.abs(arrs["mse_path"]))))
+            assert abs(trace["alpha"] - g["alpha"]) <= 1e-12 * max(1.0, abs(g["alpha"])), ("alpha", trace["alpha"], g["alpha"])
+            assert np.allclose(trace["coef_"], arrs["coef"], rtol=0, atol=TOL), ("coef", trace["coef_"], arrs["coef"])
+            assert trace["n_iter"] == g["n_iter"], ("n_iter", trace["n_iter"], g["n_iter"])
+    except AssertionError as e:
+        return [(seed, str(e)[:400])]
+    return []
+
+
+def product_l1(g, root):
+    from strainscan_amd import identify, identify_low_mem, identify_low_depth
+    from strainscan_amd import db as ssdb
+    bad = []
+    seed = g["seed"]
+    info = sf.build_l1(seed, root)
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    mods = {"identify": identify, "identify_low_mem": identify_low_mem}
+    for which, ent in enumerate(g["samples"]):
+        reads = sf.l1_reads(info, seed, which)
+        if synth.sha256_of(kfa, reads) != ent["sha256"]:
+            bad.append((seed, which, "inputs differ"))
+            continue
+        fq = os.path.join(root, "f%d_s%d.fq" % (seed, which))
+        open(fq, "wb").write(reads)
+        mr = identify.jellyfish_count((fq, ""), tdb)
+        cnt = np.zeros(info["n_rows"], np.uint32)
+        for k_, v_ in mr.items():
+            cnt[k_] = v_
+        if synth.sha256_of(cnt.tobytes()) != ent["counts_sha256"] or len(mr) != ent["n_valid"]:
+            bad.append((seed, which, "counts differ from jellyfish's"))
+        for run in ent["runs"]:
+            np.random.seed(sc.POISSON_SEED)
+            res, err, text = _run(mods[run["module"]].identify_cluster, (fq, ""), tdb, list(run["cutoff"]))
+            tag = (seed, which, run["module"], run["cutoff"])
+            if err != run["error"]:
+                bad.append((tag, "error", err, run["error"], text[-200:]))
+                continue
+            try:
+                if err is None:
+                    hl.assert_result_equal(res, run["result"], tag)
+                got_tr = hl.parse_trace(text)
+                assert [t[0] for t in got_tr] == [t[0] for t in run["trace"]], "visit order"
+                for a, w in zip(got_tr, run["trace"]):
+                    assert len(a) == len(w), (a, w)
+                    if len(w) == 4:
+                        assert abs(a[1] - w[1]) < 2e-6 and abs(a[2] - w[2]) < 2e-6 and a[3] == w[3], (a, w)
+            except AssertionError as e:
+                bad.append((tag, "walk", str(e)[:300]))
+        res, err, _ = _run(identify_low_depth.identify_ranks, (fq, ""), tdb)
+        want = ent["ranks"]
+        if err != want["error"]:
+            bad.append((seed, which, "ranks error", err, want["error"]))
+        elif err is None and ([a for a, _ in res] != [a for a, _ in want["result"]] or
+                              any(abs(b - wb) > 1e-12 * max(1.0, abs(wb)) for (_, b), (_, wb) in zip(res, want["result"]))):
+            bad.append((seed, which, "ranks"))
+        os.unlink(fq)
+    ssdb.clear_cache()
+    shutil.rmtree(info["db_dir"], ignore_errors=True)
+    return bad
+
+
+def main():
+    d, kind = sys.argv[1], sys.argv[2]
+    files = sorted(f for f in os.listdir(d) if f.startswith(kind + "_") and f.endswith(".json"))
+    root = tempfile.mkdtemp(prefix="ss_fuzzp_")
+    os.environ.setdefault("SS_IMAGE_CACHE", os.path.join(root, "cache"))
+    n_bad = 0
+    for f in files:
+        g = json.load(open(os.path.join(d, f)))
+        if kind == "l2":
+            p = os.path.join(d, f[:-5] + ".npz")
+            bad = product_l2(g, dict(np.load(p)) if os.path.exists(p) else None)
+        else:
+            bad = product_l1(g, root)
+        for b in bad:
+            print("DISAGREES", b, flush=True)
+        n_bad += bool(bad)
+    shutil.rmtree(root, ignore_errors=True)
+    print("fuzz_product %s: %d seeds, %d with a disagreement" % (kind, len(files), n_bad), flush=True)
+    sys.exit(1 if n_bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -330,7 +330,12 @@ def alpha_grid(q_total, n, l1_ratio=0.5, eps=1e-3, n_alphas=50):
         alphas = np.empty(n_alphas)
         alphas.fill(np.finfo(float).resolution)
         return alphas
-    return np.logspace(np.log10(alpha_max * eps), np.log10(alpha_max), num=n_alphas)[::-1]
+    # sklearn: np.logspace(np.log10(alpha_max * eps), np.log10(alpha_max), num=n_alphas)[::-1].  log10 and pow are libm's here, as
+    # they are under numpy 1.17.3 of the reference's environment.yaml: newer numpy builds carry their own SIMD versions, one ulp away
+    # now and then (numpy 1.26 and 2.2 differ from libm AND from each other), and when the cross-validation settles on alphas[0]
+    # (= alpha_max up to that ulp: the all-zero model) the ulp decides whether the refit returns 0 or 1e-16 -- no report or a report.
+    lo, hi = math.log10(float(alpha_max) * eps), math.log10(float(alpha_max))
+    return np.array([math.pow(10.0, float(v)) for v in np.linspace(lo, hi, num=n_alphas)])[::-1]
 
 
 def count_keep(y, npp25, npp75, npp_out):

@@ -1,0 +1,309 @@
+#!/opt/conda/bin/python3.9
+"""A campaign of the REAL reference against the oracle and the product's host logic on seeded random scenarios
+(tests/scenarios_fuzz.py).  Build container only (needs /root/reference and /opt/conda/bin/python3.9, like make_golden.py).
+
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l2 A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
+    python3                  tests/golden/fuzz_reference.py check OUT l1|l2        # oracle + cst.Walk against every file in OUT
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_L1_KEPT / FUZZ_L2_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays)
+
+`gen` and `keep` run the reference (two interpreters: the reference needs its own numpy / scikit-learn 0.24.2); `check` is the
+comparison tests/test_fuzz_golden.py makes for the committed seeds, over a whole directory.  Nothing of the reference is copied:
+the files hold inputs' sha256 and the reference's outputs."""
+import json
+import os
+import pickle
+import shutil
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+warnings.filterwarnings("ignore")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the reference's side
+# --------------------------------------------------------------------------------------------------------------------
+def _reference():
+    sys.path.insert(0, HERE)
+    import make_golden as mg
+    scratch = tempfile.mkdtemp(prefix="ss_fuzz_")
+    mg.setup_reference(scratch)
+    os.chdir(scratch)
+    import identify
+    import identify_low_mem
+    import identify_low_depth
+    import identify_strains_L2_Enet_Pscan_new_sp as l2mod
+    captured = {}
+    mg._patch_sklearn(l2mod, captured)
+    if os.environ.get("SS_FUZZ_LIBM"):
+        _libm_alpha_grid()
+    return mg, scratch, dict(identify=identify, identify_low_mem=identify_low_mem, identify_low_depth=identify_low_depth), l2mod, captured
+
+
+def _libm_alpha_grid():
+    """SS_FUZZ_LIBM=1: scikit-learn's _alpha_grid sees a numpy whose log10 / logspace go through libm, as numpy 1.17.3 of the
+    reference's environment.yaml does (this interpreter's numpy 1.26 has its own AVX-512 log10 / pow, one ulp away now and then:
+    when the cross-validation picks the largest alpha, that ulp decides between a coefficient of 0 and one of 1e-16 -- between no
+    report and a report -- in the reference itself)."""
+    import math
+    import sklearn.linear_model._coordinate_descent as cd
+
+    class LibmNumpy:
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def log10(x):
+            return math.log10(float(x))
+
+        @staticmethod
+        def logspace(start, stop, num=50):
+            return np.array([math.pow(10.0, float(v)) for v in np.linspace(start, stop, num=num)])
+    cd.np = LibmNumpy()
+
+
+def ref_l1(mg, scratch, mods, seed):
+    from tests import scenarios as sc
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    root = os.path.join(scratch, "l1_%d" % seed)
+    info = sf.build_l1(seed, root)
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    out = dict(seed=seed, n_nodes=len(info["tree"].ids), samples=[])
+    for which in (0, 1):
+        reads = sf.l1_reads(info, seed, which)
+        fq = os.path.join(root, "s%d.fq" % which)
+        open(fq, "wb").write(reads)
+        ent = dict(sha256=synth.sha256_of(kfa, reads), runs=[])
+        mr = mods["identify"].jellyfish_count((fq, ""), tdb)
+        cnt = np.zeros(info["n_rows"], np.int64)
+        for k_, v_ in mr.items():
+            cnt[k_] = v_
+        ent["counts_sha256"] = synth.sha256_of(cnt.astype(np.uint32).tobytes())
+        ent["n_valid"] = len(mr)
+        for modname, cut in sf.l1_runs(seed):
+            np.random.seed(sc.POISSON_SEED)
+            res, err, text = mg.run_captured(mods[modname].identify_cluster, (fq, ""), tdb, list(cut))
+            ent["runs"].append(dict(module=modname, cutoff=cut, error=err,
+                                    result=None if res is None else {int(k): dict(v) for k, v in res.items()},
+                                    trace=mg.parse_trace(text)))
+        res, err, _ = mg.run_captured(mods["identify_low_depth"].identify_ranks, (fq, ""), tdb)
+        ent["ranks"] = dict(error=err, result=None if res is None else [[int(a), float(b)] for a, b in res])
+        out["samples"].append(ent)
+    shutil.rmtree(root, ignore_errors=True)
+    return mg.jsonable(out)
+
+
+def ref_l2(mg, scratch, l2mod, captured, seed):
+    import scipy.sparse as sp
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    case = sf.l2_case(seed)
+    cd = os.path.join(scratch, "l2_%d" % seed)
+    os.makedirs(cd)
+    sp.save_npz(os.path.join(cd, "X.npz"), case["X"])
+    sp.save_npz(os.path.join(cd, "O.npz"), case["O"])
+    pickle.dump(case["ids"], open(os.path.join(cd, "ids.pkl"), "wb"))
+    captured.clear()
+    out, err, _ = mg.run_captured(
+        l2mod.detect_strains, os.path.join(cd, "X.npz"), case["y"].copy(), os.path.join(cd, "ids.pkl"),
+        case["ksize"], case["npp25"], case["npp75"], case["npp_out"], case["cls_cov"],
+        os.path.join(cd, "O.npz"), case["all_cls"], case["l2"], case["msn"], case["pmode"], case["emode"])
+    ent = dict(seed=seed, sha256=synth.sha256_of(case["X"].indptr.tobytes(), case["X"].indices.tobytes(), case["O"].indptr.tobytes(),
+                                                 case["O"].indices.tobytes(), case["y"].tobytes()),
+               error=err, K=int(case["X"].shape[0]), S=int(case["X"].shape[1]))
+    arrays = {}
+    if out is not None:
+        res, res2, scov, sval, fsrc = out
+        ent.update(res=res, res2=res2, strain_cov=scov, strain_val=sval, final_src=fsrc, order=list(scov.keys()))
+    if "alphas_" in captured:
+        ent.update(alpha=captured["alpha"], n_rows=captured["n_rows"], p=captured["p"], n_iter=captured["n_iter_"])
+        arrays = dict(alphas=captured["alphas_"], mse_path=captured["mse_path_"], coef=captured["coef_"])
+    shutil.rmtree(cd, ignore_errors=True)
+    return mg.jsonable(ent), arrays
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the repo's side (also what tests/test_fuzz_golden.py calls)
+# --------------------------------------------------------------------------------------------------------------------
+def check_l1(g, root):
+    """One seed's golden entry against the oracle's counts and cst.Walk fed by them.  -> list of disagreements."""
+    from tests import hostlogic as hl
+    from tests import scenarios as sc
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    bad = []
+    seed = g["seed"]
+    info = sf.build_l1(seed, root)
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
+    for which, ent in enumerate(g["samples"]):
+        reads = sf.l1_reads(info, seed, which)
+        if synth.sha256_of(kfa, reads) != ent["sha256"]:
+            bad.append((seed, which, "inputs differ"))
+            continue
+        prov = {}
+        for run in ent["runs"]:
+            low_mem = run["module"] == "identify_low_mem"
+            if low_mem not in prov:
+                prov[low_mem] = hl.OracleProvider(tdb, [reads], upper=not low_mem)
+            if not low_mem and synth.sha256_of(prov[low_mem].counts.tobytes()) != ent["counts_sha256"]:
+                bad.append((seed, which, "counts differ from jellyfish's"))
+            res, err, text = hl.run_walk(prov[low_mem], tdb, run["cutoff"], low_mem, sc.POISSON_SEED)
+            tag = (seed, which, run["module"], run["cutoff"])
+            if err != run["error"]:
+                bad.append((tag, "error", err, run["error"]))
+                continue
+            try:
+                if err is None:
+                    hl.assert_result_equal(res, run["result"], tag)
+                got_tr = hl.parse_trace(text)
+                assert [t[0] for t in got_tr] == [t[0] for t in run["trace"]], "visit order"
+                for a, w in zip(got_tr, run["trace"]):
+                    assert len(a) == len(w), (a, w)
+                    if len(w) == 4:
+                        assert abs(a[1] - w[1]) < 2e-6 and abs(a[2] - w[2]) < 2e-6 and a[3] == w[3], (a, w)
+            except AssertionError as e:
+                bad.append((tag, "walk", str(e)[:300]))
+        # identify_ranks (identify_low_depth.py)
+        from strainscan_amd import identify_low_depth as ld
+        from strainscan_amd.tree import read_tree_structure
+        gr = ent["ranks"]
+        try:
+            tree, _ = read_tree_structure(tdb)
+            pv = prov.get(True) or hl.OracleProvider(tdb, [reads], upper=False)
+            frac = {}
+            for n in tree.all_nodes():
+                ln, nk, _ = pv.node_stat(n.identifier)
+                frac[n.identifier] = -1 if ln < ld.MIN_VALID else nk / ln
+            res, err = ld.rank_paths(tree, frac), None
+        except BaseException as e:      # noqa: B902
+            res, err = None, type(e).__name__
+        if err != gr["error"]:
+            bad.append((seed, which, "ranks error", err, gr["error"]))
+        elif err is None:
+            if [a for a, _ in res] != [a for a, _ in gr["result"]] or any(abs(b - wb) > 1e-12 * max(1.0, abs(wb)) for (_, b), (_, wb) in zip(res, gr["result"])):
+                bad.append((seed, which, "ranks", res[:4], gr["result"][:4]))
+    shutil.rmtree(info["db_dir"], ignore_errors=True)
+    return bad
+
+
+def check_l2(g, arrs):
+    """One seed's golden entry against oracle.detect_strains and its pieces.  -> list of disagreements."""
+    from oracle import oracle as orc
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    seed = g["seed"]
+    case = sf.l2_case(seed)
+    X, O, y = case["X"], case["O"], case["y"]
+    if synth.sha256_of(X.indptr.tobytes(), X.indices.tobytes(), O.indptr.tobytes(), O.indices.tobytes(), y.tobytes()) != g["sha256"]:
+        return [(seed, "inputs differ")]
+    bad = []
+    try:
+        out, err = orc.detect_strains(X.toarray(), O.toarray(), case["ids"], y, case["ksize"], case["npp25"], case["npp75"], case["npp_out"],
+                                      case["all_cls"], case["l2"], case["msn"], case["pmode"], case["emode"]), None
+    except BaseException as e:      # noqa: B902
+        out, err = None, type(e).__name__
+    if err != g["error"]:
+        return [(seed, "error", err, g["error"])]
+    if err is not None:
+        return []
+    res, res2, scov, sval, fsrc = out
+    try:
+        assert list(scov.keys()) == g["order"], ("order", list(scov.keys()), g["order"])
+        for nm in g["order"]:
+            assert list(scov[nm]) == list(g["strain_cov"][nm]), ("strain_cov", nm, scov[nm], g["strain_cov"][nm])
+            assert float(sval[nm]) == float(g["strain_val"][nm]), ("strain_val", nm)
+            assert abs(fsrc[nm] - g["final_src"][nm]) < 1e-12, ("final_src", nm)
+        assert set(res) == set(g["res"]), ("res keys", res, g["res"])
+        for nm in g["res"]:
+            assert abs(res[nm] - g["res"][nm]) < 1e-7, ("res", nm, res[nm], g["res"][nm])
+            assert abs(res2[nm] - g["res2"][nm]) < 1e-6 * max(1.0, abs(g["res2"][nm])), ("res2", nm, res2[nm], g["res2"][nm])
+        if arrs:
+            om = O.toarray()[:, [c - 1 for c in case["all_cls"]]].sum(axis=1)
+            om[om > 1] = 0
+            cols, names, *_ = orc.prescan(X.toarray(), y, y * om, case["ids"], case["msn"] * case["ksize"], case["l2"], case["pmode"], case["emode"])
+            keep = ~((y < case["npp25"]) | (y > case["npp75"]) | (y > case["npp_out"]))
+            Xs, ys = X.toarray()[keep][:, cols], y[keep]
+            assert Xs.shape == (g["n_rows"], g["p"]), ("shape", Xs.shape, g["n_rows"], g["p"])
+            alphas, mse = orc.enet_cv(Xs, ys)
+            assert np.allclose(alphas, arrs["alphas"], rtol=1e-12, atol=0), "alphas"
+            assert np.allclose(mse, arrs["mse_path"], rtol=1e-8, atol=1e-9), "mse_path"
+            alpha, _, _ = orc.lasso_mpm(alphas, mse)
+            assert abs(alpha - g["alpha"]) <= 1e-12 * max(1.0, abs(alpha)), ("alpha", alpha, g["alpha"])
+            coef = orc.enet_fit(Xs, ys, alpha)
+            assert np.allclose(coef, arrs["coef"], rtol=1e-9, atol=1e-9), ("coef", coef, arrs["coef"])
+    except AssertionError as e:
+        bad.append((seed, str(e)[:400]))
+    return bad
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "gen":
+        out, kind, a, b = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+        os.makedirs(out, exist_ok=True)
+        out = os.path.abspath(out)
+        mg, scratch, mods, l2mod, captured = _reference()
+        for seed in range(a, b):
+            if kind == "l1":
+                g = ref_l1(mg, scratch, mods, seed)
+                json.dump(g, open(os.path.join(out, "l1_%d.json" % seed), "w"))
+                print("l1", seed, g["n_nodes"], [(r["module"][9:], r["cutoff"][0], r["error"], sorted((r["result"] or {}).keys())) for s in g["samples"] for r in s["runs"]][:4], flush=True)
+            else:
+                g, arrays = ref_l2(mg, scratch, l2mod, captured, seed)
+                json.dump(g, open(os.path.join(out, "l2_%d.json" % seed), "w"))
+                if arrays:
+                    np.savez(os.path.join(out, "l2_%d.npz" % seed), **arrays)
+                print("l2", seed, g["K"], g["S"], g["error"], g.get("p"), g.get("res"), flush=True)
+        shutil.rmtree(scratch, ignore_errors=True)
+    elif mode == "check":
+        out, kind = sys.argv[2], sys.argv[3]
+        files = sorted(f for f in os.listdir(out) if f.startswith(kind + "_") and f.endswith(".json"))
+        n_bad = 0
+        root = tempfile.mkdtemp(prefix="ss_fuzzc_")
+        for f in files:
+            g = json.load(open(os.path.join(out, f)))
+            if kind == "l1":
+                bad = check_l1(g, root)
+            else:
+                p = os.path.join(out, f[:-5] + ".npz")
+                bad = check_l2(g, dict(np.load(p)) if os.path.exists(p) else None)
+            for b_ in bad:
+                print("DISAGREES", b_, flush=True)
+            n_bad += bool(bad)
+        shutil.rmtree(root, ignore_errors=True)
+        print("fuzz_reference check %s: %d seeds, %d with a disagreement" % (kind, len(files), n_bad))
+        sys.exit(1 if n_bad else 0)
+    elif mode == "keep":
+        # the committed seeds.  Layer 2 under SS_FUZZ_LIBM's numpy (see _libm_alpha_grid: the reference with its pinned numpy's
+        # log10 / pow) AND under this interpreter's own: where the two runs of the reference disagree on WHICH strains are
+        # reported, the entry says so ("res_keys_numpy_1_26")
+        from tests import scenarios_fuzz as sf
+        import sklearn.linear_model._coordinate_descent as cd
+        mg, scratch, mods, l2mod, captured = _reference()
+        plain = {s: ref_l2(mg, scratch, l2mod, captured, s)[0] for s in sf.FUZZ_L2_KEPT}
+        _libm_alpha_grid()
+        l2, arrays = {}, {}
+        for s in sf.FUZZ_L2_KEPT:
+            l2[str(s)], arr = ref_l2(mg, scratch, l2mod, captured, s)
+            if sorted(plain[s].get("res") or {}) != sorted(l2[str(s)].get("res") or {}):
+                l2[str(s)]["res_keys_numpy_1_26"] = sorted(plain[s].get("res") or {})
+            for k_, v_ in arr.items():
+                arrays["%d_%s" % (s, k_)] = v_
+        cd.np = np
+        l1 = {str(s): ref_l1(mg, scratch, mods, s) for s in sf.FUZZ_L1_KEPT}
+        mg.dump_json("fuzz_l1.json", l1)
+        mg.dump_json("fuzz_l2.json", l2)
+        np.savez_compressed(os.path.join(HERE, "fuzz_l2_arrays.npz"), **arrays)
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

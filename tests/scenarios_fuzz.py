@@ -1,0 +1,178 @@
+"""Seeded RANDOM scenarios for a campaign of the real reference against the oracle / the product (round 6).
+
+tests/scenarios.py and tests/scenarios_mid.py are hand-made: each case aims at branches somebody thought of.  The
+cases here are drawn from a seed -- tree shape, node sizes (strong / label-1 / weak / never dumped), reconstructed nodes
+and their overlaps, sample mixes from 0.2x to 40x with partial genomes and foreign reads; layer-2 clusters of 2..24
+strains with random presence patterns, depths, `-e`, low-depth mode, a small strain cap, outliers -- so that what
+nobody thought of gets a chance too.  tests/golden/fuzz_reference.py runs the reference on seeds [a, b) here in the
+build container and checks the oracle and the product's host logic against it (hundreds of seeds, nothing committed);
+the seeds listed in FUZZ_L1_KEPT / FUZZ_L2_KEPT are committed as goldens (fuzz_l1.json, fuzz_l2.json) and held by
+tests/test_fuzz_golden.py (CPU) and tests/test_mid_gpu.py (the HIP path).
+
+Everything is a pure function of the seed (numpy.random.RandomState only)."""
+import os
+
+import numpy as np
+
+from . import synth
+
+K = 31
+FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
+FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692]
+
+
+# ------------------------------------------------------------------------------------------------
+# layer 1: a random cluster search tree and samples
+# ------------------------------------------------------------------------------------------------
+def l1_tree(C, rs):
+    """Random binary tree with Build_tree.py's numbering (leaves 1..C, root C + 1, children's ids above their parent's)."""
+    parent = {C + 1: None}
+    leaf_ids = list(rs.permutation(C) + 1)
+    nxt = C + 1
+    queue = [(C + 1, C)]
+    skew = float(rs.choice([0.5, 0.9, 3.0]))
+    while queue:
+        nid, n = queue.pop(0)
+        a = int(np.clip(round(n * rs.beta(skew, skew)), 1, n - 1))
+        for m in (a, n - a):
+            if m == 1:
+                parent[int(leaf_ids.pop())] = nid
+            else:
+                nxt += 1
+                parent[nxt] = nid
+                queue.append((nxt, m))
+    return parent
+
+
+def l1_spec(seed):
+    rs = np.random.RandomState(100000 + seed)
+    C = int(rs.choice([2, 3, 4, 6, 9, 14, 22, 30]))
+    parent = l1_tree(C, rs)
+    T = synth.Tree(parent)
+    sites = {}
+    p_small = float(rs.choice([0.0, 0.15, 0.4]))
+    for i in T.ids:
+        u = rs.random_sample()
+        if u >= p_small:
+            sites[i] = int(rs.randint(1000, 1800))           # label 2
+        elif u >= p_small * 0.45:
+            sites[i] = int(rs.randint(500, 1000))            # label 1 under identify.py (1000-row bar counts both strands)
+        else:
+            sites[i] = int(rs.randint(120, 499))             # weak
+    multi_n = int(rs.randint(0, C + 1))
+    multi = [int(x) for x in rs.permutation(T.leaves)[:multi_n]]
+    clusters = {l: ["GCF_F%d_%02d_%02d" % (seed, l, j + 1) for j in range(int(rs.randint(2, 6)))] for l in multi}
+    singleton = {int(l): "GCF_F%d_S%02d" % (seed, l) for l in T.leaves if l not in clusters}
+    inner = [i for i in T.ids if i != T.root]
+    recon, overlaps = [], []
+    if len(inner) >= 3 and rs.random_sample() < 0.7:
+        for nj in rs.permutation(inner)[:int(rs.randint(1, min(5, len(inner)) + 1))]:
+            nj = int(nj)
+            recon.append(nj)
+            cand = [int(l) for l in T.leaves if nj not in T.path(l)]
+            if cand and rs.random_sample() < 0.8:
+                li = int(rs.choice(cand))
+                a = int(rs.randint(0, sites[nj] // 3))
+                b = int(rs.randint(a + 1, sites[nj] + 1))
+                overlaps.append((li, nj, a, b))
+    invalid = []
+    if len(inner) >= 4 and rs.random_sample() < 0.15:
+        invalid = [int(rs.choice(inner))]
+    return dict(parent=parent, sites=sites, singleton=singleton, clusters=clusters, reconstructed=recon, overlaps=overlaps,
+                invalid_nodes=invalid, db_seed=200000 + seed)
+
+
+def build_l1(seed, root_dir):
+    spec = l1_spec(seed)
+    db_dir = os.path.join(root_dir, "DB_F%d" % seed)
+    info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["db_seed"], spec["singleton"], spec["clusters"],
+                             spec["reconstructed"], spec["overlaps"], invalid_nodes=spec["invalid_nodes"])
+    info["db_dir"] = db_dir
+    info["spec"] = spec
+    return info
+
+
+def l1_reads(info, seed, which):
+    """Sample `which` (0 or 1) of database `seed`: FASTQ bytes."""
+    rs = np.random.RandomState(300000 + 10 * seed + which)
+    T = info["tree"]
+    n_src = int(rs.choice([1, 1, 2, 3, 5]))
+    gd = []
+    for l in rs.permutation(T.leaves)[:n_src]:
+        g = info["leaf_genome"][int(l)]
+        depth = float(np.exp(rs.uniform(np.log(0.2), np.log(40.0))))
+        how = rs.random_sample()
+        if how < 0.15:                                               # a fraction of every node on the path
+            a, b = sorted(rs.uniform(0, 1, size=2))
+            if b - a < 0.2:
+                a, b = 0.0, 0.6
+            g = b"N".join(info["node_seq"][i][int(a * len(info["node_seq"][i])):int(b * len(info["node_seq"][i]))] for i in T.path(int(l)))
+        elif how < 0.25:                                             # the path without its leaf: a relative the tree does not hold
+            g = b"".join(info["node_seq"][i] for i in T.path(int(l))[:-1]) or g
+        gd.append((g, depth))
+    if rs.random_sample() < 0.5:
+        gd.append((synth.rand_seq(rs, int(rs.randint(2000, 30000))), float(rs.uniform(1, 10))))
+    return synth.simulate_reads(gd, 400000 + 10 * seed + which, err=float(rs.choice([0.0, 0.005, 0.02])))
+
+
+def l1_runs(seed):
+    """Which (module, cutoff) pairs the reference is run with on both samples of this seed."""
+    from . import scenarios as sc
+    rs = np.random.RandomState(500000 + seed)
+    cuts = [sc.CUTOFFS[int(i)] for i in rs.permutation(4)[:2]]
+    return [(m, c) for c in cuts for m in ("identify", "identify_low_mem")]
+
+
+# ------------------------------------------------------------------------------------------------
+# layer 2: a random cluster for detect_strains
+# ------------------------------------------------------------------------------------------------
+def l2_case(seed):
+    """-> the dict of tests/scenarios.py l2_case (X, O csr; ids; y; the keyword values of detect_strains)."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(600000 + seed)
+    S = int(rs.choice([2, 3, 4, 6, 9, 13, 18, 24]))
+    G = S + int(rs.randint(1, 2 * S + 3))
+    dens = float(rs.choice([0.2, 0.4, 0.6]))
+    pres = rs.random_sample((S, G)) < dens
+    if rs.random_sample() < 0.7:
+        pres[:, 0] = True                                            # a core
+    for s in range(S):                                               # most strains own a private segment
+        if rs.random_sample() < 0.8 and 1 + s < G:
+            pres[:, 1 + s] = False
+            pres[s, 1 + s] = True
+    if rs.random_sample() < 0.2 and S >= 3:                          # two strains with the same column pattern
+        pres[1] = pres[0]
+    segs = [int(rs.randint(80, 900)) for _ in range(G)]
+    n_cls = int(rs.randint(2, 7))
+    all_cls = [int(x) for x in (rs.permutation(n_cls)[:int(rs.choice([1, 1, 2, 3]))] + 1)][:n_cls]
+    l2 = int(rs.random_sample() < 0.3)
+    emode = int(rs.random_sample() < 0.3)
+    msn = int(rs.choice([40, 40, 40, 3, 1]))
+    n_pres = int(rs.randint(1 if rs.random_sample() < 0.25 else 2, min(S, 8) + 1))
+    depths = np.zeros(S)
+    for s in rs.permutation(S)[:n_pres]:
+        depths[s] = float(np.exp(rs.uniform(np.log(2.0), np.log(9.0)))) if l2 else float(np.exp(rs.uniform(np.log(9.0), np.log(90.0))))
+    seg_of_row = np.repeat(np.arange(G), [2 * n for n in segs])
+    Kn = seg_of_row.size
+    Xd = pres[:, seg_of_row].T.astype(np.int8)
+    O = np.zeros((Kn, n_cls), np.int8)
+    O[:, all_cls[0] - 1] = 1
+    for c in all_cls[1:]:
+        O[rs.random_sample(Kn) < float(rs.choice([0.05, 0.3])), c - 1] = 1
+    lam = Xd.astype(np.float64) @ (depths * 0.4)
+    y = rs.poisson(lam).astype(np.int64)
+    if rs.random_sample() < 0.3:
+        y[rs.random_sample(Kn) < 0.003] += int(rs.randint(200, 5000))
+    if rs.random_sample() < 0.3:                                     # k-mers seen in the sample that no present strain explains
+        m = rs.random_sample(Kn) < 0.02
+        y[m] += rs.poisson(3.0, size=int(m.sum()))
+    y[y == 1] = 0                                                    # remove_1 (Vote_Strain_L2_Lasso_new_sp.py:312-322)
+    ids = ["GCF_Z%d_%d" % (seed, i + 1) for i in range(S)]
+    nz = y[y != 0]
+    npp25, npp_out = 0.0, float(np.median(nz) * 1000) if nz.size else 0.0      # what the caller passes (Vote_Strain_L2_Lasso_new_sp.py:401-409)
+    npp75 = npp_out
+    if nz.size and rs.random_sample() < 0.25:                        # a narrower window: the signature allows it
+        npp25, npp75, npp_out = float(np.percentile(nz, 10)), float(np.percentile(nz, 95)), float(np.percentile(nz, 99))
+    cls_cov = float(rs.choice([0.9, 0.5, 0.05]))
+    return dict(X=sp.csr_matrix(Xd), O=sp.csr_matrix(O), ids=ids, y=y, ksize=31, npp25=npp25, npp75=npp75, npp_out=npp_out,
+                cls_cov=cls_cov, all_cls=all_cls, l2=l2, msn=msn, pmode=int(rs.random_sample() < 0.1), emode=emode)

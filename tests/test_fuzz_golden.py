@@ -1,0 +1,83 @@
+"""Seeded random scenarios (tests/scenarios_fuzz.py) on which the REAL reference was run (tests/golden/fuzz_reference.py keep ->
+fuzz_l1.json, fuzz_l2.json, fuzz_l2_arrays.npz): the seeds kept from a campaign of 130 random databases x 2 samples x 4 walks and
+3 000 random layer-2 clusters in which the oracle, the product's host logic and (on the GPU) the HIP path agreed with the reference
+on every seed -- once the reference's alpha grid took log10 / pow from libm as its pinned numpy 1.17.3 does (DESIGN.md section 4:
+under numpy 1.26's own SIMD log10 / pow the reference itself flips between `no report` and `a strain at 1e-16` in ~1.5 % of
+random clusters, the ones where the cross-validation picks the largest alpha; entries with "res_keys_numpy_1_26" are such seeds).
+
+CPU: oracle + cst.Walk.  GPU: the product behind the reference's entry points."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import scenarios_fuzz as sf
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _module(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def fr():
+    return _module(os.path.join(HERE, "golden", "fuzz_reference.py"), "fuzz_reference")
+
+
+@pytest.fixture(scope="module")
+def fp():
+    return _module(os.path.join(os.path.dirname(HERE), "scripts", "r6", "fuzz_product.py"), "fuzz_product")
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+def _arrs(golden_dir, seed):
+    a = np.load(os.path.join(golden_dir, "fuzz_l2_arrays.npz"))
+    d = {k.split("_", 1)[1]: a[k] for k in a.files if k.startswith("%d_" % seed)}
+    return d or None
+
+
+def test_kept_seeds_are_the_committed_ones(golden_dir):
+    assert sorted(int(k) for k in _load(golden_dir, "fuzz_l1.json")) == sorted(sf.FUZZ_L1_KEPT)
+    g2 = _load(golden_dir, "fuzz_l2.json")
+    assert sorted(int(k) for k in g2) == sorted(sf.FUZZ_L2_KEPT)
+    # what the campaign is for: several columns through ElasticNetCV, empty results, seeds on the alpha_max edge
+    assert max(v.get("p") or 0 for v in g2.values()) >= 8
+    assert any(v.get("p") and not v["res"] for v in g2.values())
+    assert sum("res_keys_numpy_1_26" in v for v in g2.values()) >= 2
+
+
+@pytest.mark.parametrize("seed", sf.FUZZ_L1_KEPT)
+def test_fuzz_l1_oracle_and_host_walk(seed, golden_dir, fr, tmp_path):
+    g = _load(golden_dir, "fuzz_l1.json")[str(seed)]
+    assert fr.check_l1(g, str(tmp_path)) == []
+
+
+@pytest.mark.parametrize("seed", sf.FUZZ_L2_KEPT)
+def test_fuzz_l2_oracle(seed, golden_dir, fr):
+    g = _load(golden_dir, "fuzz_l2.json")[str(seed)]
+    assert fr.check_l2(g, _arrs(golden_dir, seed)) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sf.FUZZ_L1_KEPT)
+def test_fuzz_l1_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    g = _load(golden_dir, "fuzz_l1.json")[str(seed)]
+    assert fp.product_l1(g, str(tmp_path)) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sf.FUZZ_L2_KEPT)
+def test_fuzz_l2_hip_path(seed, golden_dir, fp):
+    g = _load(golden_dir, "fuzz_l2.json")[str(seed)]
+    assert fp.product_l2(g, _arrs(golden_dir, seed)) == []

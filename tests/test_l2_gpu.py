@@ -72,8 +72,10 @@ def test_end_to_end_reports(golden_dir, l1_dbs, tmp_path):
     from strainscan_amd import StrainScan
     with open(os.path.join(golden_dir, "e2e_reports.json")) as f:
         g = json.load(f)
+    import shutil
     info = l1_dbs["A"]
-    dbA = info["db_dir"]
+    dbA = str(tmp_path / "dbA")                          # (a copy: the session's DB_A stays without layer-2 sets for the other tests)
+    shutil.copytree(info["db_dir"], dbA)
     strains = ["GCF_A1", "GCF_A2", "GCF_A3"]
     l2info = synth.build_l2_cluster(dbA, 1, 6, strains, [1500, 1200, 1000, 1400, 900],
                                     [[1, 1, 0, 0, 1], [1, 0, 1, 0, 0], [0, 1, 1, 1, 0]], seed=77, shared_with={4: [3]})
