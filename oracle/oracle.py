@@ -531,6 +531,15 @@ def vote_batch(db_dir, reads, res, ksize=31, l2=0, msn=40, pmode=0, emode=0):
     import pickle
     import scipy.sparse as sp
     multi = [r for r in res if res[r]["strain"] == 0]
+    if not multi:                                                    # check_L1_res (:68-74) == 1: generate_single_report (:232-244) + exit()
+        ranked = sorted({res[c]["strain"]: res[c]["cls_per"] for c in res}.items(), key=lambda d: d[1], reverse=True)
+        by_name = {res[c]["strain"]: c for c in res}
+        out = ["Strain_ID\tStrain_Name\tCluster_ID\tRelative_Abundance_Inside_Cluster\tPredicted_Depth\tCoverage\tCovered/Total_kmr\n"]
+        for i, (name, _) in enumerate(ranked, 1):
+            e = res[by_name[name]]
+            out.append("%d\t%s\tC%s\t%s\t%s\t%s\t%s/%s\n" % (i, name, by_name[name], str(e["cls_per"]), str(e["cls_ab"]), str(e["cls_cov"]),
+                                                             str(e["cls_covered_num"]), str(e["cls_total_num"])))
+        return {"final_report.txt": "".join(out)}
     reports = {}
     for r in (list(res) if len(res) == 1 else multi):
         cd = os.path.join(db_dir, "Kmer_Sets_L2", "Kmer_Sets", "C" + str(r))

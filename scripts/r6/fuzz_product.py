@@ -5,6 +5,8 @@ build container where the reference runs; the directory travels with the tree, e
                                 bit-exact, alphas to 1e-12, mse_path to 1e-7, coefficients / abundances to 1e-5, n_iter equal
     fuzz_product.py DIR l1      identify.jellyfish_count (bit-exact vs the real jellyfish), identify_cluster of both modules under the
                                 recorded cutoffs (result dicts, visit order, printed lines), identify_ranks on every l1_<seed>.json
+    fuzz_product.py DIR flow    StrainScan.main with the recorded flags on every flow_<seed>.json: exceptions, the layer-1 dict and its order, every
+                                report file (integer columns character for character, abundances within 1e-5)
 Prints one line per disagreement and a summary; exit code 1 on any."""
 import contextlib
 import io
@@ -128,24 +130,100 @@ def product_l1(g, root):
     return bad
 
 
+def _cmp_report(got, want, float_cols):
+    gl, wl = got.strip().split("\n"), want.strip().split("\n")
+    assert gl[0] == wl[0] and len(gl) == len(wl), (got, want)
+    for a, b in zip(gl[1:], wl[1:]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert len(fa) == len(fb), (a, b)
+        for i, (x, y) in enumerate(zip(fa, fb)):
+            if i in float_cols and x != y:
+                assert abs(float(x) - float(y)) <= TOL * max(1.0, abs(float(y))), (i, a, b)
+            else:
+                assert x == y, (i, a, b)
+
+
+def product_flow(g, root):
+    """`strainscan -i reads.fq -d DB -o OUT [flags]` (StrainScan.main) against the reference's own StrainScan.py on the same bytes: the
+    exception where the reference dies, the printed layer-1 dict (order included), every file of the output directory."""
+    import ast
+    from strainscan_amd import StrainScan
+    from strainscan_amd import db as ssdb
+    seed = g["seed"]
+    info = sf.build_flow(seed, root)
+    paths, parts = sf.flow_inputs(info, seed, root)
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    try:
+        if synth.sha256_of(open(os.path.join(tdb, "kmer.fa"), "rb").read(), b"".join(parts)) != g["sha256"]:
+            return [(seed, "inputs differ")]
+        out = os.path.join(root, "out_%d" % seed)
+        ssdb.clear_cache()
+        np.random.seed(sc.POISSON_SEED)
+        _, err, text = _run(StrainScan.main, ["-i", paths[0]] + (["-j", paths[1]] if len(paths) > 1 else []) + ["-d", info["db_dir"], "-o", out] + list(g["argv"]))
+        if err == "SystemExit":
+            err = None                                                  # (the reference's exit() after generate_single_report: return code 0 there)
+        if err != g["error"]:
+            return [(seed, "error", err, g["error"], text[-300:])]
+        try:
+            line = [ln for ln in text.splitlines() if ln.startswith("defaultdict(") or ln.startswith("{")]
+            if g["cls_dict"] is not None:
+                got = ast.literal_eval(line[-1][line[-1].index("{"):].rstrip(")"))
+                want = ast.literal_eval(g["cls_dict"])
+                assert list(got) == list(want), ("layer-1 order", list(got), list(want))
+                hl.assert_result_equal(got, want, seed)
+            assert [t[0] for t in hl.parse_trace(text)] == [t[0] for t in g["trace"]], "visit order"
+            files = {}
+            for r_, _, fs in os.walk(out):
+                for f_ in fs:
+                    files[os.path.relpath(os.path.join(r_, f_), out)] = open(os.path.join(r_, f_)).read()
+            assert sorted(files) == sorted(g["files"]), ("files", sorted(files), sorted(g["files"]))
+            n_cls = len(ast.literal_eval(g["cls_dict"])) if g["cls_dict"] else 0
+            for rel, want_text in g["files"].items():
+                if rel == "strain_prob.txt":
+                    gl, wl = files[rel].strip().split("\n"), want_text.strip().split("\n")
+                    assert gl[0] == wl[0] and len(gl) == len(wl)
+                    for a, b in zip(gl[1:], wl[1:]):
+                        fa, fb = a.split("\t"), b.split("\t")
+                        assert fa[0] == fb[0] and fa[2:] == fb[2:] and abs(float(fa[1]) - float(fb[1])) <= 1e-12 * max(1.0, float(fb[1])), (a, b)
+                elif rel == "final_report.txt" and n_cls > 1:
+                    _cmp_report(files[rel], want_text, float_cols=(3, 4, 5, 6))
+                else:
+                    _cmp_report(files[rel], want_text, float_cols=(3, 4, 5, 6, 8, 9))
+        except AssertionError as e:
+            return [(seed, str(e)[:500])]
+        return []
+    finally:
+        ssdb.clear_cache()
+        for p_ in paths:
+            os.unlink(p_)
+        shutil.rmtree(info["db_dir"], ignore_errors=True)
+
+
 def main():
     d, kind = sys.argv[1], sys.argv[2]
     files = sorted(f for f in os.listdir(d) if f.startswith(kind + "_") and f.endswith(".json"))
     root = tempfile.mkdtemp(prefix="ss_fuzzp_")
     os.environ.setdefault("SS_IMAGE_CACHE", os.path.join(root, "cache"))
-    n_bad = 0
+    sf_ = sf
+    n_bad = n_known = 0
     for f in files:
         g = json.load(open(os.path.join(d, f)))
         if kind == "l2":
             p = os.path.join(d, f[:-5] + ".npz")
             bad = product_l2(g, dict(np.load(p)) if os.path.exists(p) else None)
+        elif kind == "flow":
+            if sf_.flow_known_deviation(g["seed"], g["memory_db"]):
+                n_known += 1
+                continue
+            bad = product_flow(g, root)
         else:
             bad = product_l1(g, root)
         for b in bad:
             print("DISAGREES", b, flush=True)
         n_bad += bool(bad)
     shutil.rmtree(root, ignore_errors=True)
-    print("fuzz_product %s: %d seeds, %d with a disagreement" % (kind, len(files), n_bad), flush=True)
+    print("fuzz_product %s: %d seeds, %d with a disagreement%s" % (kind, len(files), n_bad,
+          ", %d skipped (Memory_DB + .gz: scenarios_fuzz.flow_known_deviation)" % n_known if n_known else ""), flush=True)
     sys.exit(1 if n_bad else 0)
 
 

@@ -239,16 +239,33 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
         # reference does)
         counts = [None] * len(todo)
         if len(todo) > 1 and os.environ.get("SS_L2_ONE_PASS", "1") != "0":
-            counts = cluster_counts_many(input_fq, fq2, [item[1] for item in todo], ksize)
-            _lib.cli_clock("cluster tables scanned (%d)" % len(todo))
+            try:
+                counts = cluster_counts_many(input_fq, fq2, [item[1] for item in todo], ksize)
+                _lib.cli_clock("cluster tables scanned (%d)" % len(todo))
+            except (OSError, ValueError):
+                # a cluster whose k-mer set cannot be read: the reference's serial loop (:295-296) has written the reports of the
+                # clusters in front of it when it dies there -- so does the loop below, cluster by cluster
+                counts, nthreads = [None] * len(todo), 1
         if nthreads == 1:
             for item, c in zip(todo, counts):
                 vote_strain_L2(item, c)
         else:
             from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="ss-l2") as pool:
-                for fut in [pool.submit(vote_strain_L2, item, c) for item, c in zip(todo, counts)]:
-                    fut.result()                      # re-raises the first failure, in submission order
+            pool = ThreadPoolExecutor(max_workers=nthreads, thread_name_prefix="ss-l2")
+            futs = [pool.submit(vote_strain_L2, item, c) for item, c in zip(todo, counts)]
+            failed = None
+            for j, fut in enumerate(futs):
+                try:
+                    fut.result()
+                except BaseException as e:            # noqa: B902 -- the first failure in submission order is the one the serial loop meets
+                    failed = (j, e)
+                    break
+            pool.shutdown(wait=True, cancel_futures=True)
+            if failed is not None:                    # ... and what the threads behind it wrote meanwhile, the serial loop never wrote
+                for item in todo[failed[0] + 1:]:
+                    if os.path.exists(item[2] + "/StrainVote.report"):
+                        os.unlink(item[2] + "/StrainVote.report")
+                raise failed[1]
         _lib.cli_clock("clusters solved (%d)" % len(todo))
         print("- Generate final report ...")
         merge_res(out_dir, res)

@@ -176,14 +176,14 @@ def rank0_first(fn):
 def fasta_index(path, k, upper_keys):
     """Device index of a k-mer FASTA (a cluster's all_kmer.fasta): imported from the image cache when there is
     one for this file (path, size, mtime, k, key convention), else parsed, built and exported.  Only the
-    minimizer layout (k = 31) has an image; other k are built every time."""
+    minimizer-paged layout (17 <= k <= 31) has an image; a flat table (k <= 16) is built every time."""
     return rank0_first(lambda: _fasta_index(path, k, upper_keys))
 
 
 def _fasta_index(path, k, upper_keys):
     cdir = _cache_dir()
     img = None
-    if cdir and int(k) == 31:
+    if cdir and 17 <= int(k) <= 31:
         st = os.stat(path)
         tag = cache_tag("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, st.st_mtime_ns, int(k),
                                                  int(upper_keys)))

@@ -2,9 +2,9 @@
 """A campaign of the REAL reference against the oracle and the product's host logic on seeded random scenarios
 (tests/scenarios_fuzz.py).  Build container only (needs /root/reference and /opt/conda/bin/python3.9, like make_golden.py).
 
-    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l2 A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
-    python3                  tests/golden/fuzz_reference.py check OUT l1|l2        # oracle + cst.Walk against every file in OUT
-    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_L1_KEPT / FUZZ_L2_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays)
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l2|flow A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
+    python3                  tests/golden/fuzz_reference.py check OUT l1|l2|flow      # oracle + cst.Walk against every file in OUT
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_*_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays), fuzz_flow.json
 
 `gen` and `keep` run the reference (two interpreters: the reference needs its own numpy / scikit-learn 0.24.2); `check` is the
 comparison tests/test_fuzz_golden.py makes for the committed seeds, over a whole directory.  Nothing of the reference is copied:
@@ -129,6 +129,63 @@ def ref_l2(mg, scratch, l2mod, captured, seed):
     return mg.jsonable(ent), arrays
 
 
+LIBM_PATCH = """
+import math, numpy as _np, sklearn.linear_model._coordinate_descent as _cd
+class _LibmNumpy:
+    def __getattr__(self, name): return getattr(_np, name)
+    @staticmethod
+    def log10(x): return math.log10(float(x))
+    @staticmethod
+    def logspace(start, stop, num=50): return _np.array([math.pow(10.0, float(v)) for v in _np.linspace(start, stop, num=num)])
+_cd.np = _LibmNumpy()
+"""
+
+
+def _cli(mg, scratch, argv, seed):
+    """make_golden._reference_cli (the reference's StrainScan.py as a child process under this interpreter, numpy's global generator
+    seeded), with _libm_alpha_grid's patch applied in the child when SS_FUZZ_LIBM is set."""
+    import subprocess
+    root = os.path.join(scratch, "ref")
+    if not os.path.exists(os.path.join(root, "StrainScan.py")):
+        shutil.copy(os.path.join(mg.REF, "StrainScan.py"), root)
+    drv = ("import sys, runpy, numpy, warnings; warnings.filterwarnings('ignore'); sys.path.insert(0, %r); " % os.path.join(HERE, "_standin")
+           + ("exec(%r); " % LIBM_PATCH if os.environ.get("SS_FUZZ_LIBM") else "")
+           + "numpy.random.seed(%d); sys.argv = ['StrainScan.py'] + %r; runpy.run_path('StrainScan.py', run_name='__main__')" % (seed, list(argv)))
+    r = subprocess.run([sys.executable, "-c", drv], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+
+def ref_flow(mg, scratch, seed):
+    """The reference's own StrainScan.py (child process, numpy's generator seeded: make_golden._reference_cli) on a random database
+    with layer-2 sets, one sample, random flags."""
+    import re
+    from tests import scenarios as sc
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    root = os.path.join(scratch, "flow_%d" % seed)
+    info = sf.build_flow(seed, root)
+    paths, parts = sf.flow_inputs(info, seed, root)
+    reads = b"".join(parts)
+    argv = sf.flow_argv(seed)
+    outdir = os.path.join(root, "out")
+    rc, out, errtxt = _cli(mg, scratch, ["-i", paths[0]] + (["-j", paths[1]] if len(paths) > 1 else []) + ["-d", info["db_dir"], "-o", outdir] + argv,
+                           sc.POISSON_SEED)
+    files = {}
+    for r_, _, fs in os.walk(outdir):
+        for f_ in fs:
+            p_ = os.path.join(r_, f_)
+            files[os.path.relpath(p_, outdir)] = open(p_).read()
+    cls_line = [ln for ln in out.splitlines() if ln.startswith("defaultdict(")]
+    tb = [ln for ln in errtxt.splitlines() if re.match(r"^[A-Za-z_.]*(Error|Exception)\b", ln)]
+    kfa = open(os.path.join(info["db_dir"], "Tree_database", "kmer.fa"), "rb").read()
+    g = dict(seed=seed, sha256=synth.sha256_of(kfa, reads), argv=argv, memory_db=info["spec"]["memory_db"], returncode=rc,
+             error=(tb[-1].split(":")[0] if tb else None),
+             cls_dict=cls_line[-1][cls_line[-1].index("{"):-1] if cls_line else None, trace=mg.parse_trace(out),
+             messages=[ln for ln in out.splitlines() if ln.startswith(("- ", "Warning")) and "running time" not in ln], files=files)
+    shutil.rmtree(root, ignore_errors=True)
+    return mg.jsonable(g)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # the repo's side (also what tests/test_fuzz_golden.py calls)
 # --------------------------------------------------------------------------------------------------------------------
@@ -244,6 +301,88 @@ def check_l2(g, arrs):
     return bad
 
 
+def _flow_args(argv):
+    val = lambda f, d: int(argv[argv.index(f) + 1]) if f in argv else d      # noqa: E731
+    return val("-l", 0), val("-e", 0), val("-s", 40), val("-b", 0)
+
+
+def check_flow(g, root):
+    """One seed's whole-flow entry against the oracle's serial restatement (counts, cst.Walk under the cutoff ladder of
+    StrainScan.py:186-216, oracle.vote_batch's report files).  -> list of disagreements."""
+    import ast
+    from oracle import oracle as orc
+    from strainscan_amd import cst
+    from tests import hostlogic as hl
+    from tests import scenarios as sc
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    from tests.test_oracle_golden import _cmp_report_text
+    seed = g["seed"]
+    info = sf.build_flow(seed, root)
+    paths, parts = sf.flow_inputs(info, seed, root)
+    for p_ in paths:
+        os.unlink(p_)
+    reads = b"".join(parts)
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    try:
+        if synth.sha256_of(open(os.path.join(tdb, "kmer.fa"), "rb").read(), reads) != g["sha256"]:
+            return [(seed, "inputs differ")]
+        low_mem = g["memory_db"]
+        ldep, emode, msn, _ = _flow_args(g["argv"])
+        ksize = int(g["argv"][g["argv"].index("-k") + 1]) if "-k" in g["argv"] else 31
+        prov = hl.OracleProvider(tdb, parts, upper=not low_mem)
+        np.random.seed(sc.POISSON_SEED)
+
+        def walk(cut):
+            return cst.Walk(prov, tdb, list(cut), cst.Params(low_mem=low_mem), out=lambda *a: None).run()
+        err, files, res = None, {}, None
+        try:
+            l2 = 0
+            if ldep == 0:
+                res = walk([0.1, 0.4, 1])
+                if len(res) == 0:
+                    res = walk([0.05, 0.05, 1])
+                    l2 = 1
+            else:
+                res = walk([0.01, 0.05, 1] if ldep == 1 else [0.005, 0.01, 1])
+                l2 = 1
+        except BaseException as e:      # noqa: B902
+            err = type(e).__name__
+        if err is not None:
+            return [] if err == g["error"] else [(seed, "walk error", err, g["error"])]
+        want_cls = None if g["cls_dict"] is None else {int(k): v for k, v in ast.literal_eval(g["cls_dict"]).items()}
+        if want_cls is None:
+            return [] if len(res) == 0 or g["error"] else [(seed, "the reference printed no layer-1 dict", dict(res))]
+        try:
+            hl.assert_result_equal(res, want_cls, seed)
+            assert [int(k) for k in res] == list(want_cls), ("order", list(res), list(want_cls))
+        except AssertionError as e:
+            return [(seed, "layer 1", str(e)[:300])]
+        if len(res) == 0:                                             # 'Warning: No clusters can be detected!' + exit() (StrainScan.py:222-224)
+            left = [f for f in g["files"] if f != "strain_prob.txt"]
+            return [] if not left else [(seed, "no cluster found, yet the reference wrote", left)]
+        try:
+            files = orc.vote_batch(info["db_dir"], parts, {int(k): dict(v) for k, v in res.items()}, ksize, l2, msn, 0, emode)
+        except SystemExit:
+            files = None                                              # (all clusters singletons: generate_single_report + exit())
+        except Exception as e:          # noqa: B902
+            err = type(e).__name__
+        if err != g["error"]:
+            return [(seed, "layer 2 error", err, g["error"])]
+        if err is None and files is not None:
+            want = {k: v for k, v in g["files"].items() if k != "strain_prob.txt"}
+            try:
+                assert sorted(files) == sorted(want), ("files", sorted(files), sorted(want))
+                for rel, text in want.items():
+                    one = rel == "final_report.txt" and len(res) == 1
+                    _cmp_report_text(files[rel], text, (3, 4, 5, 6) if rel == "final_report.txt" and not one else (3, 4, 5, 6, 8, 9))
+            except AssertionError as e:
+                return [(seed, "reports", str(e)[:400])]
+        return []
+    finally:
+        shutil.rmtree(info["db_dir"], ignore_errors=True)
+
+
 def main():
     mode = sys.argv[1]
     if mode == "gen":
@@ -256,6 +395,10 @@ def main():
                 g = ref_l1(mg, scratch, mods, seed)
                 json.dump(g, open(os.path.join(out, "l1_%d.json" % seed), "w"))
                 print("l1", seed, g["n_nodes"], [(r["module"][9:], r["cutoff"][0], r["error"], sorted((r["result"] or {}).keys())) for s in g["samples"] for r in s["runs"]][:4], flush=True)
+            elif kind == "flow":
+                g = ref_flow(mg, scratch, seed)
+                json.dump(g, open(os.path.join(out, "flow_%d.json" % seed), "w"))
+                print("flow", seed, g["argv"], g["returncode"], g["error"], g["cls_dict"] and sorted(eval(g["cls_dict"])), sorted(g["files"]), flush=True)
             else:
                 g, arrays = ref_l2(mg, scratch, l2mod, captured, seed)
                 json.dump(g, open(os.path.join(out, "l2_%d.json" % seed), "w"))
@@ -266,12 +409,18 @@ def main():
     elif mode == "check":
         out, kind = sys.argv[2], sys.argv[3]
         files = sorted(f for f in os.listdir(out) if f.startswith(kind + "_") and f.endswith(".json"))
-        n_bad = 0
+        from tests import scenarios_fuzz as sf_
+        n_bad = n_known = 0
         root = tempfile.mkdtemp(prefix="ss_fuzzc_")
         for f in files:
             g = json.load(open(os.path.join(out, f)))
             if kind == "l1":
                 bad = check_l1(g, root)
+            elif kind == "flow":
+                if sf_.flow_known_deviation(g["seed"], g["memory_db"]):
+                    n_known += 1
+                    continue
+                bad = check_flow(g, root)
             else:
                 p = os.path.join(out, f[:-5] + ".npz")
                 bad = check_l2(g, dict(np.load(p)) if os.path.exists(p) else None)
@@ -279,7 +428,8 @@ def main():
                 print("DISAGREES", b_, flush=True)
             n_bad += bool(bad)
         shutil.rmtree(root, ignore_errors=True)
-        print("fuzz_reference check %s: %d seeds, %d with a disagreement" % (kind, len(files), n_bad))
+        print("fuzz_reference check %s: %d seeds, %d with a disagreement%s" % (kind, len(files), n_bad,
+              ", %d skipped (Memory_DB + .gz: scenarios_fuzz.flow_known_deviation)" % n_known if n_known else ""))
         sys.exit(1 if n_bad else 0)
     elif mode == "keep":
         # the committed seeds.  Layer 2 under SS_FUZZ_LIBM's numpy (see _libm_alpha_grid: the reference with its pinned numpy's
@@ -299,6 +449,9 @@ def main():
                 arrays["%d_%s" % (s, k_)] = v_
         cd.np = np
         l1 = {str(s): ref_l1(mg, scratch, mods, s) for s in sf.FUZZ_L1_KEPT}
+        os.environ["SS_FUZZ_LIBM"] = "1"                             # (the child processes of the whole-flow runs: _cli)
+        flow = {str(s): ref_flow(mg, scratch, s) for s in sf.FUZZ_FLOW_KEPT}
+        mg.dump_json("fuzz_flow.json", flow)
         mg.dump_json("fuzz_l1.json", l1)
         mg.dump_json("fuzz_l2.json", l2)
         np.savez_compressed(os.path.join(HERE, "fuzz_l2_arrays.npz"), **arrays)

@@ -6,8 +6,10 @@ and their overlaps, sample mixes from 0.2x to 40x with partial genomes and forei
 strains with random presence patterns, depths, `-e`, low-depth mode, a small strain cap, outliers -- so that what
 nobody thought of gets a chance too.  tests/golden/fuzz_reference.py runs the reference on seeds [a, b) here in the
 build container and checks the oracle and the product's host logic against it (hundreds of seeds, nothing committed);
-the seeds listed in FUZZ_L1_KEPT / FUZZ_L2_KEPT are committed as goldens (fuzz_l1.json, fuzz_l2.json) and held by
-tests/test_fuzz_golden.py (CPU) and tests/test_mid_gpu.py (the HIP path).
+the seeds listed in FUZZ_L1_KEPT / FUZZ_L2_KEPT / FUZZ_FLOW_KEPT are committed as goldens (fuzz_l1.json, fuzz_l2.json,
+fuzz_flow.json) and held by tests/test_fuzz_golden.py (CPU: oracle and host logic; -m gpu: the HIP path).  The third kind
+(flow_*) is the reference's whole command line on a random database WITH layer-2 k-mer sets: flags (-b, -e, -l, -s, -k),
+paired and gzip-compressed input, Memory_DB, clusters whose k-mer set is missing.
 
 Everything is a pure function of the seed (numpy.random.RandomState only)."""
 import os
@@ -19,6 +21,7 @@ from . import synth
 K = 31
 FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
 FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692]
+FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -176,3 +179,127 @@ def l2_case(seed):
     cls_cov = float(rs.choice([0.9, 0.5, 0.05]))
     return dict(X=sp.csr_matrix(Xd), O=sp.csr_matrix(O), ids=ids, y=y, ksize=31, npp25=npp25, npp75=npp75, npp_out=npp_out,
                 cls_cov=cls_cov, all_cls=all_cls, l2=l2, msn=msn, pmode=int(rs.random_sample() < 0.1), emode=emode)
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole command line: a random database with layer-2 k-mer sets, a sample, flags
+# ------------------------------------------------------------------------------------------------
+FLOW_FLAGS = [[], [], [], ["-b", "1"], ["-e", "1"], ["-l", "1"], ["-l", "2"], ["-s", "3"], ["-l", "1", "-e", "1"], ["-s", "1", "-b", "1"]]
+
+
+def flow_spec(seed):
+    """l1_spec(7000 + seed) with at least one multi-strain cluster, plus which clusters own a Kmer_Sets_L2 directory."""
+    spec = l1_spec(7000 + seed)
+    rs = np.random.RandomState(700000 + seed)
+    T = synth.Tree(spec["parent"])
+    if len(spec["clusters"]) < 2:                                    # make two of the leaves multi-strain clusters
+        for l in [int(x) for x in rs.permutation(T.leaves)[:2]]:
+            if l in spec["singleton"]:
+                del spec["singleton"][l]
+                spec["clusters"][l] = ["GCF_F%d_%02d_%02d" % (7000 + seed, l, j + 1) for j in range(int(rs.randint(2, 6)))]
+    # sampled leaves get strong paths often (else most samples end in "nothing found")
+    l2c = [int(x) for x in rs.permutation(sorted(spec["clusters"]))[:int(rs.randint(1, 4))]]
+    if rs.random_sample() < 0.75:
+        for l in l2c:
+            for i in T.path(l):
+                if spec["sites"][i] < 1000:
+                    spec["sites"][i] = int(rs.randint(1000, 1600))
+    spec["l2"] = {l: 710000 + 100 * seed + l for l in l2c}
+    spec["memory_db"] = bool(rs.random_sample() < 0.25)
+    return spec
+
+
+def build_flow(seed, root_dir):
+    spec = flow_spec(seed)
+    db_dir = os.path.join(root_dir, "DB_W%d" % seed)
+    info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["db_seed"], spec["singleton"], spec["clusters"],
+                             spec["reconstructed"], spec["overlaps"], invalid_nodes=spec["invalid_nodes"])
+    info["db_dir"] = db_dir
+    info["spec"] = spec
+    info["l2"] = {}
+    C = len(info["tree"].leaves)
+    cids = sorted(spec["l2"])
+    for cid in cids:
+        rs = np.random.RandomState(spec["l2"][cid])
+        strains = spec["clusters"][cid]
+        S = len(strains)
+        G = 2 * S + 3
+        pres = np.zeros((S, G), bool)
+        pres[:, 0] = True
+        for s in range(S):
+            pres[s, 1 + s] = True
+        pres[:, 1 + S:] = rs.random_sample((S, G - 1 - S)) < 0.45
+        seg = [int(rs.randint(1200, 2400))] + [int(rs.randint(450, 950)) for _ in range(S)] + [int(rs.randint(150, 600)) for _ in range(G - 1 - S)]
+        other = [c for c in cids if c != cid]
+        shared_with = {1 + S: [other[0]]} if other and rs.random_sample() < 0.6 else None
+        info["l2"][cid] = synth.build_l2_cluster(db_dir, cid, C, strains, seg, pres, seed=spec["l2"][cid] + 1, shared_with=shared_with,
+                                                 k=flow_variant(seed)["k"])
+    if spec["memory_db"]:
+        open(os.path.join(db_dir, "Memory_DB"), "w").close()
+    return info
+
+
+def flow_reads(info, seed):
+    rs = np.random.RandomState(800000 + seed)
+    spec = info["spec"]
+    low = rs.random_sample() < 0.3
+    gd = []
+    for cid in sorted(spec["l2"]):
+        if rs.random_sample() < 0.85:
+            strains = spec["clusters"][cid]
+            for j in rs.permutation(len(strains))[:int(rs.randint(1, min(3, len(strains)) + 1))]:
+                g = info["leaf_genome"][cid] + b"N" + info["l2"][cid]["strain_extra"][strains[int(j)]]
+                depth = float(np.exp(rs.uniform(np.log(0.5), np.log(3.0)))) if low else float(np.exp(rs.uniform(np.log(4.0), np.log(40.0))))
+                gd.append((g, depth))
+    others = [l for l in info["tree"].leaves if l not in spec["l2"]]
+    if others and rs.random_sample() < 0.5:
+        gd.append((info["leaf_genome"][int(rs.choice(others))], float(rs.uniform(2, 15))))
+    if rs.random_sample() < 0.3 or not gd:
+        gd.append((synth.rand_seq(rs, int(rs.randint(5000, 40000))), float(rs.uniform(1, 6))))
+    return synth.simulate_reads(gd, 900000 + seed)
+
+
+def flow_argv(seed):
+    rs = np.random.RandomState(950000 + seed)
+    k = flow_variant(seed)["k"]
+    return list(FLOW_FLAGS[int(rs.randint(0, len(FLOW_FLAGS)))]) + (["-k", str(k)] if k != 31 else [])
+
+
+def flow_variant(seed):
+    """Seeds from 1000 on also vary what the first campaign held fixed: the layer-2 k (`-k`, the database's k-mer sets built with
+    it), paired input (`-j`), gzip-compressed input."""
+    if seed < 1000:
+        return dict(k=31, paired=False, gz=False)
+    rs = np.random.RandomState(970000 + seed)
+    return dict(k=int(rs.choice([31, 31, 25, 21, 27, 19])), paired=bool(rs.random_sample() < 0.4), gz=bool(rs.random_sample() < 0.4))
+
+
+def flow_inputs(info, seed, root):
+    """Write the sample's file(s).  -> (paths as the command line takes them: [fq] or [fq1, fq2], the FASTQ bytes per file)."""
+    import gzip
+    reads = flow_reads(info, seed)
+    v = flow_variant(seed)
+    parts = [reads]
+    if v["paired"]:
+        recs = reads.split(b"\n")[:-1]
+        recs = [b"\n".join(recs[i:i + 4]) + b"\n" for i in range(0, len(recs), 4)]
+        parts = [b"".join(recs[0::2]), b"".join(recs[1::2])]
+    paths = []
+    for i, blob in enumerate(parts):
+        p = os.path.join(root, "w%d_%d.fq" % (seed, i + 1) + (".gz" if v["gz"] else ""))
+        if v["gz"]:
+            with open(p, "wb") as f, gzip.GzipFile(fileobj=f, mode="wb", compresslevel=1 + seed % 9, mtime=0) as z:
+                z.write(blob)
+        else:
+            with open(p, "wb") as f:
+                f.write(blob)
+        paths.append(p)
+    return paths, parts
+
+
+def flow_known_deviation(seed, memory_db):
+    """The one place where the product knowingly does not follow the reference: a Memory_DB database with
+    gzip-compressed reads.  identify_low_mem.jellyfish_count (identify_low_mem.py:67-75) hands the .gz file to jellyfish as it is --
+    identify.py:81-84 pipes it through zcat --, jellyfish finds no record in the compressed bytes, every node comes back empty and the
+    walk dies at the root (ZeroDivisionError).  The product inflates the file for both modules."""
+    return bool(memory_db) and flow_variant(seed)["gz"]

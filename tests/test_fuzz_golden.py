@@ -68,6 +68,34 @@ def test_fuzz_l2_oracle(seed, golden_dir, fr):
     assert fr.check_l2(g, _arrs(golden_dir, seed)) == []
 
 
+@pytest.mark.parametrize("seed", sf.FUZZ_FLOW_KEPT)
+def test_fuzz_flow_oracle(seed, golden_dir, fr, tmp_path):
+    """The reference's whole command line (flags, -k, paired / .gz input, Memory_DB, a cluster without its k-mer set: the reports
+    written before the reference dies there) against the oracle's serial restatement."""
+    g = _load(golden_dir, "fuzz_flow.json")[str(seed)]
+    assert not sf.flow_known_deviation(seed, g["memory_db"])
+    assert fr.check_flow(g, str(tmp_path)) == []
+
+
+def test_flow_seeds_cover_what_they_are_kept_for(golden_dir):
+    g = _load(golden_dir, "fuzz_flow.json")
+    assert sorted(int(k) for k in g) == sorted(sf.FUZZ_FLOW_KEPT)
+    assert {v["error"] for v in g.values()} >= {None, "FileNotFoundError"}
+    dead = [v for v in g.values() if v["error"] == "FileNotFoundError"]
+    assert any(len([f for f in v["files"] if f.endswith("StrainVote.report")]) >= 3 for v in dead)     # reports written before it died
+    assert {int(v["argv"][v["argv"].index("-k") + 1]) for v in g.values() if "-k" in v["argv"]} >= {19, 21, 25, 27}
+    assert sum(sf.flow_variant(int(k))["paired"] for k in g) >= 3 and sum(sf.flow_variant(int(k))["gz"] for k in g) >= 3
+    assert any(v["memory_db"] for v in g.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sf.FUZZ_FLOW_KEPT)
+def test_fuzz_flow_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    g = _load(golden_dir, "fuzz_flow.json")[str(seed)]
+    assert fp.product_flow(g, str(tmp_path)) == []
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", sf.FUZZ_L1_KEPT)
 def test_fuzz_l1_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
