@@ -5,7 +5,8 @@ build container where the reference runs; the directory travels with the tree, e
                                 bit-exact, alphas to 1e-12, mse_path to 1e-7, coefficients / abundances to 1e-5, n_iter equal
     fuzz_product.py DIR l1      identify.jellyfish_count (bit-exact vs the real jellyfish), identify_cluster of both modules under the
                                 recorded cutoffs (result dicts, visit order, printed lines), identify_ranks on every l1_<seed>.json
-    fuzz_product.py DIR flow    StrainScan.main with the recorded flags on every flow_<seed>.json: exceptions, the layer-1 dict and its order, every
+    fuzz_product.py DIR flow [WORLD]   (WORLD > 1: that many rank processes on one device over gloo, the reads sharded across them)
+                                StrainScan.main with the recorded flags on every flow_<seed>.json: exceptions, the layer-1 dict and its order, every
                                 report file (integer columns character for character, abundances within 1e-5)
 Prints one line per disagreement and a summary; exit code 1 on any."""
 import contextlib
@@ -143,23 +144,45 @@ def _cmp_report(got, want, float_cols):
                 assert x == y, (i, a, b)
 
 
+def _barrier():
+    from strainscan_amd import dist as sdist
+    if sdist.is_distributed():
+        import torch.distributed as td
+        td.barrier()
+
+
 def product_flow(g, root):
     """`strainscan -i reads.fq -d DB -o OUT [flags]` (StrainScan.main) against the reference's own StrainScan.py on the same bytes: the
-    exception where the reference dies, the printed layer-1 dict (order included), every file of the output directory."""
+    exception where the reference dies, the printed layer-1 dict (order included), every file of the output directory.
+    Under a process group (fuzz_product.py DIR flow WORLD: several ranks on one device over gloo) every rank runs the command on its
+    share of the reads, rank 0 writes the scenario, owns the output directory and compares; the others return []."""
     import ast
     from strainscan_amd import StrainScan
     from strainscan_amd import db as ssdb
+    from strainscan_amd import dist as sdist
+    rank, _ = sdist.rank_world()
     seed = g["seed"]
-    info = sf.build_flow(seed, root)
-    paths, parts = sf.flow_inputs(info, seed, root)
-    tdb = os.path.join(info["db_dir"], "Tree_database")
+    db_dir = os.path.join(root, "DB_W%d" % seed)
+    if rank == 0:
+        info = sf.build_flow(seed, root)
+        paths, parts = sf.flow_inputs(info, seed, root)
+        ok = synth.sha256_of(open(os.path.join(db_dir, "Tree_database", "kmer.fa"), "rb").read(), b"".join(parts)) == g["sha256"]
+        json.dump(dict(paths=paths, ok=ok), open(os.path.join(root, "w%d.json" % seed), "w"))
+    _barrier()
+    meta = json.load(open(os.path.join(root, "w%d.json" % seed)))
+    paths = meta["paths"]
     try:
-        if synth.sha256_of(open(os.path.join(tdb, "kmer.fa"), "rb").read(), b"".join(parts)) != g["sha256"]:
-            return [(seed, "inputs differ")]
+        if not meta["ok"]:
+            return [(seed, "inputs differ")] if rank == 0 else []
         out = os.path.join(root, "out_%d" % seed)
         ssdb.clear_cache()
         np.random.seed(sc.POISSON_SEED)
-        _, err, text = _run(StrainScan.main, ["-i", paths[0]] + (["-j", paths[1]] if len(paths) > 1 else []) + ["-d", info["db_dir"], "-o", out] + list(g["argv"]))
+        _, err, text = _run(StrainScan.main, ["-i", paths[0]] + (["-j", paths[1]] if len(paths) > 1 else []) + ["-d", db_dir, "-o", out] + list(g["argv"]))
+        if os.environ.get("SS_FUZZ_VERBOSE"):
+            print("rank", rank, "seed", seed, "left main with", err, repr(text[-160:]), flush=True)
+        _barrier()
+        if rank != 0:
+            return []
         if err == "SystemExit":
             err = None                                                  # (the reference's exit() after generate_single_report: return code 0 there)
         if err != g["error"]:
@@ -194,16 +217,43 @@ def product_flow(g, root):
         return []
     finally:
         ssdb.clear_cache()
-        for p_ in paths:
-            os.unlink(p_)
-        shutil.rmtree(info["db_dir"], ignore_errors=True)
+        _barrier()
+        if rank == 0:
+            for p_ in paths + [os.path.join(root, "w%d.json" % seed)]:
+                os.unlink(p_)
+            shutil.rmtree(db_dir, ignore_errors=True)
+            shutil.rmtree(os.path.join(root, "out_%d" % seed), ignore_errors=True)
+
+
+def _spawn_ranks(d, kind, world):
+    """`fuzz_product.py DIR flow WORLD`: WORLD rank processes of this script on device 0, gloo over a file store (as tests/test_dist_gpu.py
+    does: RCCL refuses two ranks on one device), one shared scratch directory."""
+    import subprocess
+    root = tempfile.mkdtemp(prefix="ss_fuzzp_")
+    env = dict(os.environ, WORLD_SIZE=str(world), LOCAL_RANK="0", SS_FUZZ_ROOT=root, SS_TEST_STORE=os.path.join(root, "store"),
+               SS_IMAGE_CACHE=os.path.join(root, "cache"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), d, kind], env=dict(env, RANK=str(r))) for r in range(world)]
+    rcs = [p.wait() for p in procs]
+    shutil.rmtree(root, ignore_errors=True)
+    sys.exit(max(rcs))
 
 
 def main():
     d, kind = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 3 and int(sys.argv[3]) > 1 and "RANK" not in os.environ:
+        _spawn_ranks(d, kind, int(sys.argv[3]))
     files = sorted(f for f in os.listdir(d) if f.startswith(kind + "_") and f.endswith(".json"))
-    root = tempfile.mkdtemp(prefix="ss_fuzzp_")
-    os.environ.setdefault("SS_IMAGE_CACHE", os.path.join(root, "cache"))
+    rank = 0
+    if "SS_FUZZ_ROOT" in os.environ:                                    # a rank of _spawn_ranks
+        import torch
+        import torch.distributed as td
+        rank = int(os.environ["RANK"])
+        torch.cuda.set_device(0)
+        td.init_process_group("gloo", init_method="file://" + os.environ["SS_TEST_STORE"], rank=rank, world_size=int(os.environ["WORLD_SIZE"]))
+        root = os.environ["SS_FUZZ_ROOT"]
+    else:
+        root = tempfile.mkdtemp(prefix="ss_fuzzp_")
+        os.environ.setdefault("SS_IMAGE_CACHE", os.path.join(root, "cache"))
     sf_ = sf
     n_bad = n_known = 0
     for f in files:
@@ -215,15 +265,27 @@ def main():
             if sf_.flow_known_deviation(g["seed"], g["memory_db"]):
                 n_known += 1
                 continue
+            if os.environ.get("SS_FUZZ_VERBOSE"):                      # which seed a hang belongs to, and where every rank stands in it
+                import faulthandler
+                faulthandler.dump_traceback_later(float(os.environ["SS_FUZZ_VERBOSE"]), exit=True)
+                if rank == 0:
+                    print("seed", g["seed"], g["argv"], g["error"], flush=True)
             bad = product_flow(g, root)
         else:
             bad = product_l1(g, root)
         for b in bad:
             print("DISAGREES", b, flush=True)
         n_bad += bool(bad)
-    shutil.rmtree(root, ignore_errors=True)
-    print("fuzz_product %s: %d seeds, %d with a disagreement%s" % (kind, len(files), n_bad,
-          ", %d skipped (Memory_DB + .gz: scenarios_fuzz.flow_known_deviation)" % n_known if n_known else ""), flush=True)
+    if "SS_FUZZ_ROOT" in os.environ:
+        import torch.distributed as td
+        td.barrier()
+        td.destroy_process_group()
+        if rank != 0:
+            sys.exit(0)
+    else:
+        shutil.rmtree(root, ignore_errors=True)
+    print("fuzz_product %s%s: %d seeds, %d with a disagreement%s" % (kind, " (%s ranks)" % os.environ["WORLD_SIZE"] if "SS_FUZZ_ROOT" in os.environ else "",
+          len(files), n_bad, ", %d skipped (Memory_DB + .gz: scenarios_fuzz.flow_known_deviation)" % n_known if n_known else ""), flush=True)
     sys.exit(1 if n_bad else 0)
 
 

@@ -121,8 +121,7 @@ def main(argv=None):
     out_dir = args.out_dir if args.out_dir else pwd + "/StrainScan_Result"
     if not re.search("/", out_dir):
         out_dir = pwd + "/" + out_dir
-    if not os.path.exists(out_dir):
-        os.makedirs(out_dir)
+    os.makedirs(out_dir, exist_ok=True)     # (exist_ok: under torchrun every rank arrives here with the same -o at the same moment)
 
     from . import dist
     rank, world = dist.init_from_env()      # torchrun: one process per GPU, reads shard across ranks

@@ -26,8 +26,7 @@ SINGLE_HEADER = ("Strain_ID\tStrain_Name\tCluster_ID\tRelative_Abundance_Inside_
 
 
 def build_dir(idir):
-    if not os.path.exists(idir):
-        os.makedirs(idir)
+    os.makedirs(idir, exist_ok=True)
 
 
 def check_L1_res(res):
@@ -242,9 +241,11 @@ def vote_strain_L2_batch(input_fq, fq2, db_dir, out_dir, ksize, res, l2, msn, pm
             try:
                 counts = cluster_counts_many(input_fq, fq2, [item[1] for item in todo], ksize)
                 _lib.cli_clock("cluster tables scanned (%d)" % len(todo))
-            except (OSError, ValueError):
+            except Exception:                         # noqa: B902
                 # a cluster whose k-mer set cannot be read: the reference's serial loop (:295-296) has written the reports of the
-                # clusters in front of it when it dies there -- so does the loop below, cluster by cluster
+                # clusters in front of it when it dies there -- so does the loop below, cluster by cluster.  (Every exception, not
+                # only OSError: under a process group the ranks behind rank 0 learn of its failure as a RuntimeError, db.rank0_first,
+                # and all of them must take this turn together.)
                 counts, nthreads = [None] * len(todo), 1
         if nthreads == 1:
             for item, c in zip(todo, counts):

@@ -109,3 +109,24 @@ def test_fuzz_l1_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
 def test_fuzz_l2_hip_path(seed, golden_dir, fp):
     g = _load(golden_dir, "fuzz_l2.json")[str(seed)]
     assert fp.product_l2(g, _arrs(golden_dir, seed)) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5])
+def test_fuzz_flow_hip_path_sharded(world, golden_dir, tmp_path):
+    """The kept command lines once more with the reads sharded over several rank processes on one device (gloo; rank 0 owns the output
+    directory): layer 1's exchange of node statistics AND layer 2's all-reduced cluster tables, the `.gz` inputs inflated in range
+    mode, the runs that die on a missing k-mer set (every rank must take the serial loop together: a RuntimeError on the ranks behind
+    rank 0, db.rank0_first) -- the same files as the reference wrote.  The campaign ran all 550 lines this way with 3 ranks; what it
+    found was every rank creating the output directory at the same moment (FileExistsError on two of three)."""
+    import subprocess
+    import sys
+    d = tmp_path / "flows"
+    d.mkdir()
+    for k, g in _load(golden_dir, "fuzz_flow.json").items():
+        (d / ("flow_%s.json" % k)).write_text(json.dumps(g))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "scripts", "r6", "fuzz_product.py"), str(d), "flow", str(world)],
+                       env=dict(os.environ, SS_FUZZ_VERBOSE="120"), capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    assert "fuzz_product flow (%d ranks): %d seeds, 0 with a disagreement" % (world, len(sf.FUZZ_FLOW_KEPT)) in r.stdout, tail
