@@ -183,8 +183,8 @@ def fasta_index(path, k, upper_keys):
 def _fasta_index(path, k, upper_keys):
     cdir = _cache_dir()
     img = None
+    st = os.stat(path)                                   # (a cluster without its k-mer set: FileNotFoundError, as the reference's open() raises)
     if cdir and 17 <= int(k) <= 31:
-        st = os.stat(path)
         tag = cache_tag("%s|%d|%d|%d|%d" % (os.path.realpath(path), st.st_size, st.st_mtime_ns, int(k),
                                                  int(upper_keys)))
         img = os.path.join(cdir, "index_%s.bin" % tag)
