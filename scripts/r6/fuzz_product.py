@@ -8,6 +8,8 @@ build container where the reference runs; the directory travels with the tree, e
     fuzz_product.py DIR flow [WORLD]   (WORLD > 1: that many rank processes on one device over gloo, the reads sharded across them)
                                 StrainScan.main with the recorded flags on every flow_<seed>.json: exceptions, the layer-1 dict and its order, every
                                 report file (integer columns character for character, abundances within 1e-5)
+    fuzz_product.py DIR fmt     identify.jellyfish_count on samples in random FASTA / FASTQ shapes (wrapped, CRLF, no final newline, '@' / '+' opening a
+                                quality line, .gz) against the real jellyfish's counts
 Prints one line per disagreement and a summary; exit code 1 on any."""
 import contextlib
 import io
@@ -129,6 +131,33 @@ def product_l1(g, root):
     ssdb.clear_cache()
     shutil.rmtree(info["db_dir"], ignore_errors=True)
     return bad
+
+
+def product_fmt(g, root):
+    """identify.jellyfish_count on a sample in random FASTA / FASTQ shapes against the real jellyfish's counts."""
+    from strainscan_amd import identify
+    from strainscan_amd import db as ssdb
+    seed = g["seed"]
+    info, paths, blobs, kinds = sf.fmt_case(seed, root)
+    try:
+        tdb = os.path.join(info["db_dir"], "Tree_database")
+        if synth.sha256_of(open(os.path.join(tdb, "kmer.fa"), "rb").read(), *blobs) != g["sha256"]:
+            return [(seed, "inputs differ")]
+        mr, err, _ = _run(identify.jellyfish_count, (paths[0], paths[1] if len(paths) > 1 else ""), tdb)
+        if err != g["error"]:
+            return [(seed, kinds, "error", err, g["error"])]
+        if err is None:
+            cnt = np.zeros(info["n_rows"], np.uint32)
+            for k_, v_ in mr.items():
+                cnt[k_] = v_
+            if synth.sha256_of(cnt.tobytes()) != g["counts_sha256"] or len(mr) != g["n_valid"]:
+                return [(seed, kinds, "counts differ from jellyfish's", int(cnt.sum()), g["counts_sum"], len(mr), g["n_valid"])]
+        return []
+    finally:
+        ssdb.clear_cache()
+        for p_ in paths:
+            os.unlink(p_)
+        shutil.rmtree(info["db_dir"], ignore_errors=True)
 
 
 def _cmp_report(got, want, float_cols):
@@ -261,6 +290,11 @@ def main():
         if kind == "l2":
             p = os.path.join(d, f[:-5] + ".npz")
             bad = product_l2(g, dict(np.load(p)) if os.path.exists(p) else None)
+        elif kind == "fmt":
+            if sf_.fmt_known_deviation(g["kinds"]):
+                n_known += 1
+                continue
+            bad = product_fmt(g, root)
         elif kind == "flow":
             if sf_.flow_known_deviation(g["seed"], g["memory_db"]):
                 n_known += 1
@@ -285,7 +319,7 @@ def main():
     else:
         shutil.rmtree(root, ignore_errors=True)
     print("fuzz_product %s%s: %d seeds, %d with a disagreement%s" % (kind, " (%s ranks)" % os.environ["WORLD_SIZE"] if "SS_FUZZ_ROOT" in os.environ else "",
-          len(files), n_bad, ", %d skipped (Memory_DB + .gz: scenarios_fuzz.flow_known_deviation)" % n_known if n_known else ""), flush=True)
+          len(files), n_bad, ", %d skipped (scenarios_fuzz.flow_known_deviation / fmt_known_deviation)" % n_known if n_known else ""), flush=True)
     sys.exit(1 if n_bad else 0)
 
 

@@ -2,9 +2,9 @@
 """A campaign of the REAL reference against the oracle and the product's host logic on seeded random scenarios
 (tests/scenarios_fuzz.py).  Build container only (needs /root/reference and /opt/conda/bin/python3.9, like make_golden.py).
 
-    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l2|flow A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
-    python3                  tests/golden/fuzz_reference.py check OUT l1|l2|flow      # oracle + cst.Walk against every file in OUT
-    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_*_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays), fuzz_flow.json
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l2|flow|fmt A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
+    python3                  tests/golden/fuzz_reference.py check OUT l1|l2|flow|fmt      # oracle + cst.Walk against every file in OUT
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_*_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays), fuzz_flow.json, fuzz_fmt.json
 
 `gen` and `keep` run the reference (two interpreters: the reference needs its own numpy / scikit-learn 0.24.2); `check` is the
 comparison tests/test_fuzz_golden.py makes for the committed seeds, over a whole directory.  Nothing of the reference is copied:
@@ -127,6 +127,26 @@ def ref_l2(mg, scratch, l2mod, captured, seed):
         arrays = dict(alphas=captured["alphas_"], mse_path=captured["mse_path_"], coef=captured["coef_"])
     shutil.rmtree(cd, ignore_errors=True)
     return mg.jsonable(ent), arrays
+
+
+def ref_fmt(mg, scratch, mods, seed):
+    """The real jellyfish (through identify.jellyfish_count: zcat in front of it for .gz, identify.py:73-103) on a sample rendered in
+    random FASTA / FASTQ shapes: the counts, as a sha256 over the rows of kmer.fa."""
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    root = os.path.join(scratch, "fmt_%d" % seed)
+    os.makedirs(root)
+    info, paths, blobs, kinds = sf.fmt_case(seed, root)
+    tdb = os.path.join(info["db_dir"], "Tree_database")
+    mr, err, _ = mg.run_captured(mods["identify"].jellyfish_count, (paths[0], paths[1] if len(paths) > 1 else ""), tdb)
+    g = dict(seed=seed, kinds=kinds, sha256=synth.sha256_of(open(os.path.join(tdb, "kmer.fa"), "rb").read(), *blobs), error=err)
+    if mr is not None:
+        cnt = np.zeros(info["n_rows"], np.int64)
+        for k_, v_ in mr.items():
+            cnt[k_] = v_
+        g.update(counts_sha256=synth.sha256_of(cnt.astype(np.uint32).tobytes()), n_valid=len(mr), counts_sum=int(cnt.sum()))
+    shutil.rmtree(root, ignore_errors=True)
+    return mg.jsonable(g)
 
 
 LIBM_PATCH = """
@@ -301,6 +321,33 @@ def check_l2(g, arrs):
     return bad
 
 
+def check_fmt(g, root):
+    """One seed's input-format entry against the oracle's reader + counter."""
+    from oracle import oracle as orc
+    from tests import scenarios_fuzz as sf
+    from tests import synth
+    seed = g["seed"]
+    info, paths, blobs, kinds = sf.fmt_case(seed, root)
+    try:
+        kfa = open(os.path.join(info["db_dir"], "Tree_database", "kmer.fa"), "rb").read()
+        if synth.sha256_of(kfa, *blobs) != g["sha256"]:
+            return [(seed, "inputs differ")]
+        try:
+            counts, valid = orc.jellyfish_count(kfa, blobs, k=31, upper=True)
+            err = None
+        except BaseException as e:      # noqa: B902
+            err = type(e).__name__
+        if err != g["error"]:
+            return [(seed, kinds, "error", err, g["error"])]
+        if err is None and (synth.sha256_of(counts.tobytes()) != g["counts_sha256"] or int(valid.sum()) != g["n_valid"]):
+            return [(seed, kinds, "counts differ from jellyfish's", int(counts.sum()), g["counts_sum"])]
+        return []
+    finally:
+        for p_ in paths:
+            os.unlink(p_)
+        shutil.rmtree(info["db_dir"], ignore_errors=True)
+
+
 def _flow_args(argv):
     val = lambda f, d: int(argv[argv.index(f) + 1]) if f in argv else d      # noqa: E731
     return val("-l", 0), val("-e", 0), val("-s", 40), val("-b", 0)
@@ -395,6 +442,10 @@ def main():
                 g = ref_l1(mg, scratch, mods, seed)
                 json.dump(g, open(os.path.join(out, "l1_%d.json" % seed), "w"))
                 print("l1", seed, g["n_nodes"], [(r["module"][9:], r["cutoff"][0], r["error"], sorted((r["result"] or {}).keys())) for s in g["samples"] for r in s["runs"]][:4], flush=True)
+            elif kind == "fmt":
+                g = ref_fmt(mg, scratch, mods, seed)
+                json.dump(g, open(os.path.join(out, "fmt_%d.json" % seed), "w"))
+                print("fmt", seed, g["kinds"], g["error"], g.get("counts_sum"), flush=True)
             elif kind == "flow":
                 g = ref_flow(mg, scratch, seed)
                 json.dump(g, open(os.path.join(out, "flow_%d.json" % seed), "w"))
@@ -416,6 +467,11 @@ def main():
             g = json.load(open(os.path.join(out, f)))
             if kind == "l1":
                 bad = check_l1(g, root)
+            elif kind == "fmt":
+                if sf_.fmt_known_deviation(g["kinds"]):
+                    n_known += 1
+                    continue
+                bad = check_fmt(g, root)
             elif kind == "flow":
                 if sf_.flow_known_deviation(g["seed"], g["memory_db"]):
                     n_known += 1
@@ -429,7 +485,7 @@ def main():
             n_bad += bool(bad)
         shutil.rmtree(root, ignore_errors=True)
         print("fuzz_reference check %s: %d seeds, %d with a disagreement%s" % (kind, len(files), n_bad,
-              ", %d skipped (Memory_DB + .gz: scenarios_fuzz.flow_known_deviation)" % n_known if n_known else ""))
+              ", %d skipped (scenarios_fuzz.flow_known_deviation / fmt_known_deviation)" % n_known if n_known else ""))
         sys.exit(1 if n_bad else 0)
     elif mode == "keep":
         # the committed seeds.  Layer 2 under SS_FUZZ_LIBM's numpy (see _libm_alpha_grid: the reference with its pinned numpy's
@@ -452,6 +508,7 @@ def main():
         os.environ["SS_FUZZ_LIBM"] = "1"                             # (the child processes of the whole-flow runs: _cli)
         flow = {str(s): ref_flow(mg, scratch, s) for s in sf.FUZZ_FLOW_KEPT}
         mg.dump_json("fuzz_flow.json", flow)
+        mg.dump_json("fuzz_fmt.json", {str(s): ref_fmt(mg, scratch, mods, s) for s in sf.FUZZ_FMT_KEPT})
         mg.dump_json("fuzz_l1.json", l1)
         mg.dump_json("fuzz_l2.json", l2)
         np.savez_compressed(os.path.join(HERE, "fuzz_l2_arrays.npz"), **arrays)

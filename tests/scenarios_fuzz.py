@@ -22,6 +22,7 @@ K = 31
 FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
 FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692]
 FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239]
+FUZZ_FMT_KEPT = [0, 4, 5, 8, 9, 13, 14, 16, 20, 21, 23, 29, 31, 33, 36, 38, 45, 51, 66, 84, 89, 92] + [2, 3, 149]      # (the last three: one per known deviation)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -303,3 +304,98 @@ def flow_known_deviation(seed, memory_db):
     identify.py:81-84 pipes it through zcat --, jellyfish finds no record in the compressed bytes, every node comes back empty and the
     walk dies at the root (ZeroDivisionError).  The product inflates the file for both modules."""
     return bool(memory_db) and flow_variant(seed)["gz"]
+
+
+# ------------------------------------------------------------------------------------------------
+# input formats: what jellyfish's reader accepts, rendered at random
+# ------------------------------------------------------------------------------------------------
+FMT_KINDS = ["fq4", "fq4_at", "fq_wrap", "fa1", "fa_wrap", "fq4_nonl", "fa_nonl", "fq4_crlf", "fa_crlf", "fq_blank_tail", "fa_lower_mix", "fq_plus_name"]
+
+
+def fmt_render(recs, kind, rs):
+    """[(name, sequence)] -> bytes in one of the shapes a FASTA / FASTQ file comes in."""
+    out = []
+    nl = b"\r\n" if kind.endswith("crlf") else b"\n"
+    for name, seq in recs:
+        if kind.startswith("fa"):
+            if kind == "fa_wrap":
+                w = int(rs.choice([1, 7, 60, 70, 149]))
+                body = nl.join(seq[i:i + w] for i in range(0, len(seq), w)) if seq else b""
+            else:
+                body = seq
+            if kind == "fa_lower_mix" and rs.random_sample() < 0.3:
+                body = bytes(c + 32 if (65 <= c <= 90 and rs.random_sample() < 0.5) else c for c in body)
+            out.append(b">" + name + nl + body + nl)
+        else:
+            qual = bytes(rs.randint(33, 74, size=len(seq)).astype(np.uint8)) if kind != "fq4" else b"I" * len(seq)
+            if kind == "fq4_at" and len(seq):
+                qual = b"@" + qual[1:] if rs.random_sample() < 0.5 else b"+" + qual[1:]
+            plus = b"+" + name if kind == "fq_plus_name" else b"+"
+            if kind == "fq_wrap":
+                w = int(rs.choice([13, 60, 100]))
+                sq = nl.join(seq[i:i + w] for i in range(0, len(seq), w))
+                ql = nl.join(qual[i:i + w] for i in range(0, len(qual), w))
+                out.append(b"@" + name + nl + sq + nl + plus + nl + ql + nl)
+            else:
+                out.append(b"@" + name + nl + seq + nl + plus + nl + qual + nl)
+    blob = b"".join(out)
+    if kind.endswith("nonl") and blob.endswith(nl):
+        blob = blob[:-len(nl)]
+    if kind == "fq_blank_tail":
+        blob += nl * int(rs.randint(1, 4))
+    return blob
+
+
+def fmt_case(seed, root_dir):
+    """A small database and a sample of one or two files, each in its own random shape, plain or gzip-compressed.
+    -> (info, [paths], [bytes as written, uncompressed], [kinds])"""
+    import gzip
+    rs = np.random.RandomState(1200000 + seed)
+    spec = l1_spec(9000 + seed % 40)                                  # forty small-to-mid databases shared by the seeds
+    db_dir = os.path.join(root_dir, "DB_X%d" % seed)
+    info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["db_seed"], spec["singleton"], spec["clusters"],
+                             spec["reconstructed"], spec["overlaps"], invalid_nodes=spec["invalid_nodes"])
+    info["db_dir"] = db_dir
+    T = info["tree"]
+    gd = [(info["leaf_genome"][int(l)], float(rs.uniform(1, 6))) for l in rs.permutation(T.leaves)[:int(rs.randint(1, 3))]]
+    gd.append((synth.rand_seq(rs, 3000), 2.0))
+    fq = synth.simulate_reads(gd, 1300000 + seed, read_len=int(rs.choice([150, 150, 100, 251, 75])))
+    lines = fq.split(b"\n")
+    recs = [(lines[i][1:], lines[i + 1]) for i in range(0, len(lines) - 1, 4)]
+    if rs.random_sample() < 0.3:                                      # a few records of odd lengths: empty, shorter than k, very long
+        recs.insert(int(rs.randint(0, len(recs))), (b"empty", b""))
+        recs.insert(int(rs.randint(0, len(recs))), (b"short", recs[0][1][:17]))
+        recs.insert(int(rs.randint(0, len(recs))), (b"long", b"".join(r[1] for r in recs[:40])))
+    n_files = 1 + int(rs.random_sample() < 0.4)
+    parts = [recs] if n_files == 1 else [recs[0::2], recs[1::2]]
+    paths, blobs, kinds = [], [], []
+    for i, part in enumerate(parts):
+        kind = str(rs.choice(FMT_KINDS))
+        blob = fmt_render(part, kind, rs)
+        gz = bool(rs.random_sample() < 0.3)
+        p = os.path.join(root_dir, "x%d_%d.%s%s" % (seed, i + 1, "fa" if kind.startswith("fa") else "fq", ".gz" if gz else ""))
+        if gz:
+            with open(p, "wb") as f, gzip.GzipFile(fileobj=f, mode="wb", compresslevel=1 + seed % 9, mtime=0) as z:
+                z.write(blob)
+        else:
+            with open(p, "wb") as f:
+                f.write(blob)
+        paths.append(p); blobs.append(blob); kinds.append(kind + ("+gz" if gz else ""))
+    return info, paths, blobs, kinds
+
+
+def fmt_known_deviation(kinds):
+    """Inputs on which the reference's pipeline loses reads and the product does not:
+    * a pair of files of which exactly ONE is gzip-compressed: identify.py:81-84 runs `zcat file1 file2 | jellyfish` as soon as either
+      name ends in .gz, zcat refuses the plain file ("not in gzip format") and only the compressed one is counted;
+    * a FASTQ file whose last line has no newline: jellyfish 2.3.0 takes the file for truncated and drops the buffer it was parsing
+      (every read of a small file, the last few of a large one);
+    * a pair of .gz files, FASTQ first and FASTA second: zcat makes ONE stream of them, jellyfish takes the stream's format from its
+      first byte and the FASTA records behind the FASTQ ones are lost (as two plain files each is read in its own format)."""
+    if len(kinds) == 2 and kinds[0].endswith("+gz") != kinds[1].endswith("+gz"):
+        return "one of two files is .gz"
+    if any(k.split("+")[0] == "fq4_nonl" for k in kinds):
+        return "FASTQ without a final newline"
+    if len(kinds) == 2 and all(k.endswith("+gz") for k in kinds) and kinds[0][:2] == "fq" and kinds[1][:2] == "fa":
+        return "a .gz pair, FASTQ then FASTA"
+    return None

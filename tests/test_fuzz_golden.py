@@ -88,6 +88,41 @@ def test_flow_seeds_cover_what_they_are_kept_for(golden_dir):
     assert any(v["memory_db"] for v in g.values())
 
 
+@pytest.mark.parametrize("seed", sf.FUZZ_FMT_KEPT)
+def test_fuzz_fmt_oracle(seed, golden_dir, fr, tmp_path):
+    """The shapes a FASTA / FASTQ file comes in (wrapped records, CRLF, no final newline, '@' or '+' opening a quality line, '+name',
+    blank lines at the end, lower case, two files of different formats, .gz) through the REAL jellyfish behind identify.py's zcat pipe:
+    the oracle's reader and counter give the same counts (sha256 over the rows).  Three kept seeds are inputs on which the reference's
+    pipeline LOSES reads (scenarios_fuzz.fmt_known_deviation): there the oracle, like the product, counts more -- asserted as such."""
+    g = _load(golden_dir, "fuzz_fmt.json")[str(seed)]
+    why = sf.fmt_known_deviation(g["kinds"])
+    bad = fr.check_fmt(g, str(tmp_path))
+    if why is None:
+        assert bad == []
+    else:
+        assert len(bad) == 1 and bad[0][2] == "counts differ from jellyfish's" and bad[0][3] > bad[0][4], (why, bad)
+
+
+def test_fmt_seeds_cover_every_shape(golden_dir):
+    g = _load(golden_dir, "fuzz_fmt.json")
+    kinds = {k.split("+")[0] for v in g.values() for k in v["kinds"]}
+    assert kinds == set(sf.FMT_KINDS)
+    assert {sf.fmt_known_deviation(v["kinds"]) for v in g.values()} == {None, "one of two files is .gz", "FASTQ without a final newline", "a .gz pair, FASTQ then FASTA"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sf.FUZZ_FMT_KEPT)
+def test_fuzz_fmt_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    g = _load(golden_dir, "fuzz_fmt.json")[str(seed)]
+    why = sf.fmt_known_deviation(g["kinds"])
+    bad = fp.product_fmt(g, str(tmp_path))
+    if why is None:
+        assert bad == []
+    else:                                                     # the product counts the reads the reference's pipeline loses
+        assert len(bad) == 1 and bad[0][2] == "counts differ from jellyfish's" and bad[0][3] > bad[0][4], (why, bad)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", sf.FUZZ_FLOW_KEPT)
 def test_fuzz_flow_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
