@@ -85,12 +85,13 @@ def product_l1(g, root):
     from strainscan_amd import db as ssdb
     bad = []
     seed = g["seed"]
-    info = sf.build_l1(seed, root)
+    info = sf.build_l1x(seed, root) if g.get("x") else sf.build_l1(seed, root)
+    rseed = 5000 + seed if g.get("x") else seed
     tdb = os.path.join(info["db_dir"], "Tree_database")
     kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
     mods = {"identify": identify, "identify_low_mem": identify_low_mem}
     for which, ent in enumerate(g["samples"]):
-        reads = sf.l1_reads(info, seed, which)
+        reads = sf.l1_reads(info, rseed, which)
         if synth.sha256_of(kfa, reads) != ent["sha256"]:
             bad.append((seed, which, "inputs differ"))
             continue
@@ -271,7 +272,7 @@ def main():
     d, kind = sys.argv[1], sys.argv[2]
     if len(sys.argv) > 3 and int(sys.argv[3]) > 1 and "RANK" not in os.environ:
         _spawn_ranks(d, kind, int(sys.argv[3]))
-    files = sorted(f for f in os.listdir(d) if f.startswith(kind + "_") and f.endswith(".json"))
+    files = sorted(f for f in os.listdir(d) if f.startswith(kind + "_") and f.endswith(".json"))      # (l1x_*: kind l1x, read by product_l1)
     rank = 0
     if "SS_FUZZ_ROOT" in os.environ:                                    # a rank of _spawn_ranks
         import torch

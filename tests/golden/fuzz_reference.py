@@ -2,9 +2,9 @@
 """A campaign of the REAL reference against the oracle and the product's host logic on seeded random scenarios
 (tests/scenarios_fuzz.py).  Build container only (needs /root/reference and /opt/conda/bin/python3.9, like make_golden.py).
 
-    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l2|flow|fmt A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
-    python3                  tests/golden/fuzz_reference.py check OUT l1|l2|flow|fmt      # oracle + cst.Walk against every file in OUT
-    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_*_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays), fuzz_flow.json, fuzz_fmt.json
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py gen  OUT l1|l1x|l2|flow|fmt A B    # the reference on seeds [A, B) -> OUT/<kind>_<seed>.json
+    python3                  tests/golden/fuzz_reference.py check OUT l1|l1x|l2|flow|fmt      # oracle + cst.Walk against every file in OUT
+    /opt/conda/bin/python3.9 tests/golden/fuzz_reference.py keep                   # the seeds of FUZZ_*_KEPT -> fuzz_l1.json, fuzz_l2.json (+ arrays), fuzz_flow.json, fuzz_fmt.json, fuzz_l1x.json
 
 `gen` and `keep` run the reference (two interpreters: the reference needs its own numpy / scikit-learn 0.24.2); `check` is the
 comparison tests/test_fuzz_golden.py makes for the committed seeds, over a whole directory.  Nothing of the reference is copied:
@@ -67,17 +67,19 @@ def _libm_alpha_grid():
     cd.np = LibmNumpy()
 
 
-def ref_l1(mg, scratch, mods, seed):
+def ref_l1(mg, scratch, mods, seed, x=False):
+    """x: the database of scenarios_fuzz.build_l1x (rows in kmer.fa that no node lists), reads and runs of seed 5000 + seed."""
     from tests import scenarios as sc
     from tests import scenarios_fuzz as sf
     from tests import synth
-    root = os.path.join(scratch, "l1_%d" % seed)
-    info = sf.build_l1(seed, root)
+    root = os.path.join(scratch, "l1%s_%d" % ("x" if x else "", seed))
+    info = sf.build_l1x(seed, root) if x else sf.build_l1(seed, root)
+    rseed = 5000 + seed if x else seed
     tdb = os.path.join(info["db_dir"], "Tree_database")
     kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
-    out = dict(seed=seed, n_nodes=len(info["tree"].ids), samples=[])
+    out = dict(seed=seed, x=bool(x), n_nodes=len(info["tree"].ids), samples=[])
     for which in (0, 1):
-        reads = sf.l1_reads(info, seed, which)
+        reads = sf.l1_reads(info, rseed, which)
         fq = os.path.join(root, "s%d.fq" % which)
         open(fq, "wb").write(reads)
         ent = dict(sha256=synth.sha256_of(kfa, reads), runs=[])
@@ -87,7 +89,7 @@ def ref_l1(mg, scratch, mods, seed):
             cnt[k_] = v_
         ent["counts_sha256"] = synth.sha256_of(cnt.astype(np.uint32).tobytes())
         ent["n_valid"] = len(mr)
-        for modname, cut in sf.l1_runs(seed):
+        for modname, cut in sf.l1_runs(rseed):
             np.random.seed(sc.POISSON_SEED)
             res, err, text = mg.run_captured(mods[modname].identify_cluster, (fq, ""), tdb, list(cut))
             ent["runs"].append(dict(module=modname, cutoff=cut, error=err,
@@ -217,23 +219,31 @@ def check_l1(g, root):
     from tests import synth
     bad = []
     seed = g["seed"]
-    info = sf.build_l1(seed, root)
+    info = sf.build_l1x(seed, root) if g.get("x") else sf.build_l1(seed, root)
+    rseed = 5000 + seed if g.get("x") else seed
     tdb = os.path.join(info["db_dir"], "Tree_database")
     kfa = open(os.path.join(tdb, "kmer.fa"), "rb").read()
     for which, ent in enumerate(g["samples"]):
-        reads = sf.l1_reads(info, seed, which)
+        reads = sf.l1_reads(info, rseed, which)
         if synth.sha256_of(kfa, reads) != ent["sha256"]:
             bad.append((seed, which, "inputs differ"))
             continue
         prov = {}
         for run in ent["runs"]:
             low_mem = run["module"] == "identify_low_mem"
+            tag = (seed, which, run["module"], run["cutoff"])
             if low_mem not in prov:
-                prov[low_mem] = hl.OracleProvider(tdb, [reads], upper=not low_mem)
+                try:
+                    prov[low_mem] = hl.OracleProvider(tdb, [reads], upper=not low_mem)
+                except KeyError:                                      # a dumped k-mer whose only row is lower case (identify_low_mem.py:88)
+                    prov[low_mem] = "KeyError"
+            if prov[low_mem] == "KeyError":
+                if run["error"] != "KeyError":
+                    bad.append((tag, "error", "KeyError", run["error"]))
+                continue
             if not low_mem and synth.sha256_of(prov[low_mem].counts.tobytes()) != ent["counts_sha256"]:
                 bad.append((seed, which, "counts differ from jellyfish's"))
             res, err, text = hl.run_walk(prov[low_mem], tdb, run["cutoff"], low_mem, sc.POISSON_SEED)
-            tag = (seed, which, run["module"], run["cutoff"])
             if err != run["error"]:
                 bad.append((tag, "error", err, run["error"]))
                 continue
@@ -255,6 +265,8 @@ def check_l1(g, root):
         try:
             tree, _ = read_tree_structure(tdb)
             pv = prov.get(True) or hl.OracleProvider(tdb, [reads], upper=False)
+            if pv == "KeyError":
+                raise KeyError("lower-case row")
             frac = {}
             for n in tree.all_nodes():
                 ln, nk, _ = pv.node_stat(n.identifier)
@@ -438,9 +450,9 @@ def main():
         out = os.path.abspath(out)
         mg, scratch, mods, l2mod, captured = _reference()
         for seed in range(a, b):
-            if kind == "l1":
-                g = ref_l1(mg, scratch, mods, seed)
-                json.dump(g, open(os.path.join(out, "l1_%d.json" % seed), "w"))
+            if kind in ("l1", "l1x"):
+                g = ref_l1(mg, scratch, mods, seed, x=kind == "l1x")
+                json.dump(g, open(os.path.join(out, "%s_%d.json" % (kind, seed)), "w"))
                 print("l1", seed, g["n_nodes"], [(r["module"][9:], r["cutoff"][0], r["error"], sorted((r["result"] or {}).keys())) for s in g["samples"] for r in s["runs"]][:4], flush=True)
             elif kind == "fmt":
                 g = ref_fmt(mg, scratch, mods, seed)
@@ -465,7 +477,7 @@ def main():
         root = tempfile.mkdtemp(prefix="ss_fuzzc_")
         for f in files:
             g = json.load(open(os.path.join(out, f)))
-            if kind == "l1":
+            if kind in ("l1", "l1x"):
                 bad = check_l1(g, root)
             elif kind == "fmt":
                 if sf_.fmt_known_deviation(g["kinds"]):
@@ -509,6 +521,7 @@ def main():
         flow = {str(s): ref_flow(mg, scratch, s) for s in sf.FUZZ_FLOW_KEPT}
         mg.dump_json("fuzz_flow.json", flow)
         mg.dump_json("fuzz_fmt.json", {str(s): ref_fmt(mg, scratch, mods, s) for s in sf.FUZZ_FMT_KEPT})
+        mg.dump_json("fuzz_l1x.json", {str(s): ref_l1(mg, scratch, mods, s, x=True) for s in sf.FUZZ_L1X_KEPT})
         mg.dump_json("fuzz_l1.json", l1)
         mg.dump_json("fuzz_l2.json", l2)
         np.savez_compressed(os.path.join(HERE, "fuzz_l2_arrays.npz"), **arrays)

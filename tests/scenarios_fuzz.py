@@ -22,6 +22,7 @@ K = 31
 FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
 FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692]
 FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239]
+FUZZ_L1X_KEPT = [0, 2, 6, 23, 92]                                    # (kmer.fa with rows no node lists: build_l1x)
 FUZZ_FMT_KEPT = [0, 4, 5, 8, 9, 13, 14, 16, 20, 21, 23, 29, 31, 33, 36, 38, 45, 51, 66, 84, 89, 92] + [2, 3, 149]      # (the last three: one per known deviation)
 
 
@@ -399,3 +400,47 @@ def fmt_known_deviation(kinds):
     if len(kinds) == 2 and all(k.endswith("+gz") for k in kinds) and kinds[0][:2] == "fq" and kinds[1][:2] == "fa":
         return "a .gz pair, FASTQ then FASTA"
     return None
+
+
+# ------------------------------------------------------------------------------------------------
+# layer 1 once more, on a kmer.fa with rows no node lists: duplicates, rows with an N, lower-case rows
+# ------------------------------------------------------------------------------------------------
+def build_l1x(seed, root_dir):
+    """l1_spec(5000 + seed)'s database with 1-40 extra rows spliced into kmer.fa (synth.build_l1_db extra_rows): exact copies of node
+    rows in front of or behind the original (kmer_index_dict keeps the LAST row of a k-mer, identify.py:91-95: a copy behind it takes
+    the node's row out of every profile), rows with an N (jellyfish never reports them), lower-case copies of node rows, and lower-case
+    rows of k-mers that occur in the reads but in no node (the junctions between two nodes' sequences in a leaf's genome):
+    identify.py looks rows up in upper case, identify_low_mem.py as written -- its KeyError is part of the result."""
+    import shutil
+    spec = l1_spec(5000 + seed)
+    rs = np.random.RandomState(1400000 + seed)
+    db_dir = os.path.join(root_dir, "DB_Y%d" % seed)
+    args = (spec["parent"], spec["sites"], spec["db_seed"], spec["singleton"], spec["clusters"], spec["reconstructed"], spec["overlaps"])
+    first = synth.build_l1_db(db_dir, *args, invalid_nodes=spec["invalid_nodes"])
+    rows = open(os.path.join(db_dir, "Tree_database", "kmer.fa"), "rb").read().split(b"\n")[1::2]
+    shutil.rmtree(db_dir)
+    T = first["tree"]
+    junction = []
+    for l in T.leaves:
+        p = T.path(l)
+        for a, b in zip(p[:-1], p[1:]):
+            j = first["node_seq"][a][-(K - 1):] + first["node_seq"][b][:K - 1]
+            junction += [j[i:i + K] for i in range(0, K - 1, 3)]
+    extra = []
+    lower_too = rs.random_sample() < 0.35                             # (a lower-case row ends identify_low_mem / identify_low_depth at once)
+    for _ in range(int(rs.randint(1, 41))):
+        pos = int(rs.randint(0, len(rows) + 1))
+        u = rs.random_sample() * (1.0 if lower_too else 0.55)
+        if u < 0.4:
+            txt = rows[int(rs.randint(0, len(rows)))]
+        elif u < 0.55:
+            txt = bytearray(synth.rand_seq(rs, K)); txt[int(rs.randint(0, K))] = ord("N"); txt = bytes(txt)
+        elif u < 0.8:
+            txt = rows[int(rs.randint(0, len(rows)))].lower()
+        else:
+            txt = junction[int(rs.randint(0, len(junction)))].lower() if junction else rows[0].lower()
+        extra.append((pos, txt))
+    info = synth.build_l1_db(db_dir, *args, extra_rows=extra, invalid_nodes=spec["invalid_nodes"])
+    info["db_dir"] = db_dir
+    info["spec"] = spec
+    return info

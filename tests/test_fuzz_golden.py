@@ -62,6 +62,23 @@ def test_fuzz_l1_oracle_and_host_walk(seed, golden_dir, fr, tmp_path):
     assert fr.check_l1(g, str(tmp_path)) == []
 
 
+@pytest.mark.parametrize("seed", sf.FUZZ_L1X_KEPT)
+def test_fuzz_l1x_oracle_and_host_walk(seed, golden_dir, fr, tmp_path):
+    """kmer.fa with rows that no node lists -- copies of node rows in front of and behind the original (the LAST row of a k-mer is the
+    one jellyfish's dump is credited to, identify.py:91-95), rows with an N, lower-case rows (identify_low_mem.py and
+    identify_low_depth.py look rows up as written: KeyError) -- through both modules and identify_ranks."""
+    g = _load(golden_dir, "fuzz_l1x.json")[str(seed)]
+    assert g["x"] and fr.check_l1(g, str(tmp_path)) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", sf.FUZZ_L1X_KEPT)
+def test_fuzz_l1x_hip_path(seed, golden_dir, fp, tmp_path, monkeypatch):
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    g = _load(golden_dir, "fuzz_l1x.json")[str(seed)]
+    assert fp.product_l1(g, str(tmp_path)) == []
+
+
 @pytest.mark.parametrize("seed", sf.FUZZ_L2_KEPT)
 def test_fuzz_l2_oracle(seed, golden_dir, fr):
     g = _load(golden_dir, "fuzz_l2.json")[str(seed)]
