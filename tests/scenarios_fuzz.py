@@ -135,8 +135,9 @@ def l2_case(seed):
     """-> the dict of tests/scenarios.py l2_case (X, O csr; ids; y; the keyword values of detect_strains)."""
     import scipy.sparse as sp
     rs = np.random.RandomState(600000 + seed)
-    S = int(rs.choice([2, 3, 4, 6, 9, 13, 18, 24]))
-    G = S + int(rs.randint(1, 2 * S + 3))
+    big = seed >= 10000                                              # seeds from 10000 on: 30-56 strains, 6-14 of them present (p > 6: the
+    S = int(rs.choice([30, 40, 56])) if big else int(rs.choice([2, 3, 4, 6, 9, 13, 18, 24]))      # per-fold-group statistics and wide refits)
+    G = S + int(rs.randint(1, (S // 2 if big else 2 * S) + 3))
     dens = float(rs.choice([0.2, 0.4, 0.6]))
     pres = rs.random_sample((S, G)) < dens
     if rs.random_sample() < 0.7:
@@ -153,7 +154,7 @@ def l2_case(seed):
     l2 = int(rs.random_sample() < 0.3)
     emode = int(rs.random_sample() < 0.3)
     msn = int(rs.choice([40, 40, 40, 3, 1]))
-    n_pres = int(rs.randint(1 if rs.random_sample() < 0.25 else 2, min(S, 8) + 1))
+    n_pres = int(rs.randint(6, 15)) if big else int(rs.randint(1 if rs.random_sample() < 0.25 else 2, min(S, 8) + 1))
     depths = np.zeros(S)
     for s in rs.permutation(S)[:n_pres]:
         depths[s] = float(np.exp(rs.uniform(np.log(2.0), np.log(9.0)))) if l2 else float(np.exp(rs.uniform(np.log(9.0), np.log(90.0))))

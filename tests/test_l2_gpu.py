@@ -766,6 +766,39 @@ DETECT_ALLOW = (
 )
 
 
+def test_what_is_on_disk_when_layer_2_dies(tmp_path, monkeypatch):
+    """The reference's loop over the identified clusters is serial (Vote_Strain_L2_Lasso_new_sp.py:295-296): when a cluster's files cannot be
+    read it has written the reports of the clusters in front of it, nothing of those behind, and no final_report.txt.  The product scans the
+    tables in one pass and solves on threads, and must leave the same: (a) a cluster without all_kmer.fasta (the one-pass scan cannot open
+    it: the serial loop takes over), (b) a cluster without all_strains_re.npz (the scan is fine, one solving thread fails, the threads behind
+    it may have written their reports already: removed).  Scenario: tests/scenarios_fuzz.py flow 10, three clusters identified in the
+    order 25, 24, 4 (fuzz_flow-like database; the campaign's 91 dying runs were all of kind (a))."""
+    import shutil
+    from strainscan_amd import StrainScan
+    from strainscan_amd import db as ssdb
+    from tests import scenarios_fuzz as sf
+    monkeypatch.setenv("SS_IMAGE_CACHE", str(tmp_path / "cache"))
+    info = sf.build_flow(10, str(tmp_path))
+    paths, _ = sf.flow_inputs(info, 10, str(tmp_path))
+    sets = os.path.join(info["db_dir"], "Kmer_Sets_L2", "Kmer_Sets")
+    for victim, threads in (("all_kmer.fasta", "4"), ("all_strains_re.npz", "4"), ("all_strains_re.npz", "1")):
+        moved = os.path.join(sets, "C24", victim)
+        os.rename(moved, moved + ".away")
+        monkeypatch.setenv("SS_L2_THREADS", threads)
+        out = tmp_path / ("out_%s_%s" % (victim.split(".")[0], threads))
+        ssdb.clear_cache()
+        np.random.seed(sc.POISSON_SEED)
+        with contextlib.redirect_stdout(io.StringIO()) as buf, pytest.raises(FileNotFoundError):
+            StrainScan.main(["-i", paths[0], "-d", info["db_dir"], "-o", str(out)])
+        assert "{25:" in buf.getvalue() and buf.getvalue().index("25:") < buf.getvalue().index("24:") < buf.getvalue().index(" 4:")
+        files = sorted(str(p.relative_to(out)) for p in out.rglob("*") if p.is_file())
+        assert files == ["C25/StrainVote.report"], (victim, threads, files)
+        assert sorted(os.listdir(out)) == ["C24", "C25", "C4"]             # (every directory is made before the first cluster is voted: :283-293)
+        os.rename(moved + ".away", moved)
+    ssdb.clear_cache()
+    shutil.rmtree(info["db_dir"])
+
+
 def test_every_statement_of_the_l2_mirrors_is_pinned(golden, golden_dir, l1_dbs, tmp_path, monkeypatch):
     """Coverage gate for Vote_Strain_L2_Lasso_new_sp.py and
     identify_strains_L2_Enet_Pscan_new_sp.py: under the golden layer-2 cases, the end-to-end reports and the multi-cluster
@@ -781,6 +814,7 @@ def test_every_statement_of_the_l2_mirrors_is_pinned(golden, golden_dir, l1_dbs,
                         ("cache", lambda p: test_cluster_image_cache(p, monkeypatch)),
                         ("threads", lambda p: test_l2_batch_threads_equal_serial(p, monkeypatch)),
                         ("bad", test_damaged_csr_files_raise_value_error),
+                        ("dies", lambda p: test_what_is_on_disk_when_layer_2_dies(p, monkeypatch)),
                         ("npz", lambda p: test_cluster_image_from_npz_on_the_device(60_000, 300, 0.5, p, monkeypatch)),
                         ("branches", lambda p: _l2_branch_scenarios(p, monkeypatch, golden))):
             d = tmp_path / sub
