@@ -17,6 +17,8 @@ run serial_l2_w3   3 SS_L2_ONE_PASS=0 SS_L2_THREADS=1
 run file_order_w3  3 SS_READS_ORDER=file
 run flat_table_w3  3 SS_LAYOUT=flat
 run host_build_w2  2 SS_BUILD=host
+run cached_second_run    1 SS_FUZZ_TWICE=1
+run cached_second_run_w3 3 SS_FUZZ_TWICE=1
 exit 0
 fi
 run streaming      1 SS_READS_RESIDENT_GB=0

@@ -208,6 +208,15 @@ def product_flow(g, root):
         ssdb.clear_cache()
         np.random.seed(sc.POISSON_SEED)
         _, err, text = _run(StrainScan.main, ["-i", paths[0]] + (["-j", paths[1]] if len(paths) > 1 else []) + ["-d", db_dir, "-o", out] + list(g["argv"]))
+        if os.environ.get("SS_FUZZ_TWICE"):                             # ... and once more, as a second process against the same database would:
+            _barrier()                                                  # the tree, index and cluster images come from the image cache now
+            if rank == 0:
+                shutil.rmtree(out, ignore_errors=True)
+            _barrier()
+            ssdb.wait_cache_writes()
+            ssdb.clear_cache()
+            np.random.seed(sc.POISSON_SEED)
+            _, err, text = _run(StrainScan.main, ["-i", paths[0]] + (["-j", paths[1]] if len(paths) > 1 else []) + ["-d", db_dir, "-o", out] + list(g["argv"]))
         if os.environ.get("SS_FUZZ_VERBOSE"):
             print("rank", rank, "seed", seed, "left main with", err, repr(text[-160:]), flush=True)
         _barrier()
