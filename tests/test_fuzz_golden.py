@@ -1,5 +1,5 @@
 """Seeded random scenarios (tests/scenarios_fuzz.py) on which the REAL reference was run (tests/golden/fuzz_reference.py keep ->
-fuzz_l1.json, fuzz_l2.json, fuzz_l2_arrays.npz): the seeds kept from a campaign of 130 random databases x 2 samples x 4 walks and
+fuzz_l1.json, fuzz_l2.json, fuzz_l2_arrays.npz): the seeds kept from campaigns of 360 random databases x 2 samples x 4 walks, 850 whole command lines, 500 samples in random file shapes and
 3 150 random layer-2 clusters in which the oracle, the product's host logic and (on the GPU) the HIP path agreed with the reference
 on every seed -- once the reference's alpha grid took log10 / pow from libm as its pinned numpy 1.17.3 does (DESIGN.md section 4:
 under numpy 1.26's own SIMD log10 / pow the reference itself flips between `no report` and `a strain at 1e-16` in ~1.5 % of
@@ -169,7 +169,7 @@ def test_fuzz_flow_hip_path_sharded(world, golden_dir, tmp_path):
     """The kept command lines once more with the reads sharded over several rank processes on one device (gloo; rank 0 owns the output
     directory): layer 1's exchange of node statistics AND layer 2's all-reduced cluster tables, the `.gz` inputs inflated in range
     mode, the runs that die on a missing k-mer set (every rank must take the serial loop together: a RuntimeError on the ranks behind
-    rank 0, db.rank0_first) -- the same files as the reference wrote.  The campaign ran all 550 lines this way with 3 ranks; what it
+    rank 0, db.rank0_first) -- the same files as the reference wrote.  The campaign ran 850 command lines this way with 3 ranks (550 of them also with 5 and 8); what it
     found was every rank creating the output directory at the same moment (FileExistsError on two of three)."""
     import subprocess
     import sys
