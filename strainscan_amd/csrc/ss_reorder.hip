@@ -470,6 +470,7 @@ __global__ __launch_bounds__(256, 8) void count_fixed_kernel(const char *__restr
     const uint32_t L1 = L + 1u, nr = (uint32_t)min((uint64_t)64, n_rec - r0), span = nr * L1;
     const uint64_t base = r0 * L1;
     bool bad = false;
+#ifndef SS_COUNT_NOVERIFY          // (A/B builds only: what the count pass costs when it reads each record's first bytes and nothing else)
     for (uint32_t off = (uint32_t)lane * 16u; off < span; off += 1024u) {
         const uint32_t m = nl_mask16(load16_nl(b, base + off, n));
         const uint32_t pos = off - __umulhi(off, magic_l1) * L1;           // offset of the piece's first byte within its record
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256, 8) void count_fixed_kernel(const char *__restr
         const uint32_t want = L - pos < 16u ? 1u << (L - pos) : 0u;        // (L >= 32: at most one record end in 16 bytes)
         bad |= ((m ^ want) & valid) != 0u;
     }
+#endif
     if (r0 + nr == n_rec) {                                                // behind the last record: newlines only (padding)
         for (uint64_t i = base + span + (uint32_t)lane; i < n; i += 64) bad |= b[i] != '\n';
     }
