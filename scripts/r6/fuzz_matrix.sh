@@ -19,6 +19,8 @@ run flat_table_w3  3 SS_LAYOUT=flat
 run host_build_w2  2 SS_BUILD=host
 run cached_second_run    1 SS_FUZZ_TWICE=1
 run cached_second_run_w3 3 SS_FUZZ_TWICE=1
+run gz_small_units       1 SS_GZ_SLICE_KB=64 SS_GZ_SEG_KB=64 SS_GZ_CHUNK=4096 SS_GZ_SPLIT_KB=4
+run gz_small_units_w3    3 SS_GZ_SLICE_KB=64 SS_GZ_SEG_KB=64 SS_GZ_CHUNK=4096 SS_GZ_SPLIT_KB=4
 exit 0
 fi
 run streaming      1 SS_READS_RESIDENT_GB=0
