@@ -21,7 +21,7 @@ from . import synth
 K = 31
 FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
 FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692, 10081, 10112]
-FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239]
+FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239, 2002, 2015, 2010, 2020, 2031, 2007]      # (2002...: an empty file, [2015: and the IndexError it ends in,] reads shorter than k, a single read, nothing but N, a handful of reads)
 FUZZ_L1X_KEPT = [0, 2, 6, 23, 92]                                    # (kmer.fa with rows no node lists: build_l1x)
 FUZZ_FMT_KEPT = [0, 4, 5, 8, 9, 13, 14, 16, 20, 21, 23, 29, 31, 33, 36, 38, 45, 51, 66, 84, 89, 92] + [2, 3, 149]      # (the last three: one per known deviation)
 
@@ -245,6 +245,19 @@ def build_flow(seed, root_dir):
 def flow_reads(info, seed):
     rs = np.random.RandomState(800000 + seed)
     spec = info["spec"]
+    if seed >= 2000:                                                  # seeds from 2000 on: samples at the edge of being a sample at all
+        u = np.random.RandomState(810000 + seed).random_sample()
+        leaf = info["leaf_genome"][sorted(spec["l2"])[0]]
+        if u < 0.15:
+            return b""                                                # an empty file
+        if u < 0.3:
+            return b"".join(b"@s%d\n%s\n+\n%s\n" % (i, leaf[40 * i:40 * i + 30], b"I" * 30) for i in range(200))      # every read shorter than k
+        if u < 0.45:
+            return b"".join(b"@n%d\n%s\n+\n%s\n" % (i, b"N" * 150, b"I" * 150) for i in range(100))                      # nothing but N
+        if u < 0.6:
+            return b"@one\n%s\n+\n%s\n" % (leaf[:150], b"I" * 150)                                                      # a single read
+        if u < 0.75:
+            return synth.simulate_reads([(leaf, 0.05)], 900000 + seed)                                                     # a handful of reads
     low = rs.random_sample() < 0.3
     gd = []
     for cid in sorted(spec["l2"]):
