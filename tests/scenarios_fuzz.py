@@ -20,7 +20,7 @@ from . import synth
 
 K = 31
 FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
-FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692, 10081, 10112]
+FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692, 10081, 10112, 20003, 20005, 20006, 20012, 20019]      # (20003...: no k-mer seen, all counts <= 2, one k-mer seen [IndexError / a result], a handful)
 FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239, 2002, 2015, 2010, 2020, 2031, 2007]      # (2002...: an empty file, [2015: and the IndexError it ends in,] reads shorter than k, a single read, nothing but N, a handful of reads)
 FUZZ_L1X_KEPT = [0, 2, 6, 23, 92]                                    # (kmer.fa with rows no node lists: build_l1x)
 FUZZ_FMT_KEPT = [0, 4, 5, 8, 9, 13, 14, 16, 20, 21, 23, 29, 31, 33, 36, 38, 45, 51, 66, 84, 89, 92] + [2, 3, 149]      # (the last three: one per known deviation)
@@ -172,6 +172,17 @@ def l2_case(seed):
     if rs.random_sample() < 0.3:                                     # k-mers seen in the sample that no present strain explains
         m = rs.random_sample(Kn) < 0.02
         y[m] += rs.poisson(3.0, size=int(m.sum()))
+    if 20000 <= seed < 30000:                                        # seeds 20000..: counts at the edge of being a sample
+        u = np.random.RandomState(620000 + seed).random_sample()
+        if u < 0.2:
+            y[:] = 0                                                 # no read hit the cluster at all
+        elif u < 0.4:
+            keep1 = np.random.RandomState(630000 + seed).randint(0, Kn)
+            y[np.arange(Kn) != keep1] = 0                            # one k-mer seen
+        elif u < 0.6:
+            y[np.random.RandomState(640000 + seed).random_sample(Kn) < 0.995] = 0      # a handful of k-mers seen
+        elif u < 0.8:
+            y[:] = np.minimum(y, 2)                                  # everything seen at most twice
     y[y == 1] = 0                                                    # remove_1 (Vote_Strain_L2_Lasso_new_sp.py:312-322)
     ids = ["GCF_Z%d_%d" % (seed, i + 1) for i in range(S)]
     nz = y[y != 0]
