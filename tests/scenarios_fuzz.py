@@ -21,7 +21,7 @@ from . import synth
 K = 31
 FUZZ_L1_KEPT = [5, 28, 36, 42, 43, 50, 63, 73, 81, 88, 92, 125]
 FUZZ_L2_KEPT = [2, 3, 11, 15, 28, 39, 62, 112, 147, 190, 377, 418, 420, 555, 676, 692, 10081, 10112, 20003, 20005, 20006, 20012, 20019]      # (20003...: no k-mer seen, all counts <= 2, one k-mer seen [IndexError / a result], a handful)
-FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239, 2002, 2015, 2010, 2020, 2031, 2007]      # (2002...: an empty file, [2015: and the IndexError it ends in,] reads shorter than k, a single read, nothing but N, a handful of reads)
+FUZZ_FLOW_KEPT = [0, 2, 28, 36, 63, 66, 1000, 1019, 1027, 1042, 1057, 1109, 1146, 1239, 2002, 2015, 2010, 2020, 2031, 2007, 3029, 3038]      # (2002...: an empty file, [2015: and the IndexError it ends in,] reads shorter than k, a single read, nothing but N, a handful of reads; 3029, 3038: a single-cluster database with its tree.pkl)
 FUZZ_L1X_KEPT = [0, 2, 6, 23, 92]                                    # (kmer.fa with rows no node lists: build_l1x)
 FUZZ_FMT_KEPT = [0, 4, 5, 8, 9, 13, 14, 16, 20, 21, 23, 29, 31, 33, 36, 38, 45, 51, 66, 84, 89, 92] + [2, 3, 149]      # (the last three: one per known deviation)
 
@@ -205,6 +205,12 @@ def flow_spec(seed):
     """l1_spec(7000 + seed) with at least one multi-strain cluster, plus which clusters own a Kmer_Sets_L2 directory."""
     spec = l1_spec(7000 + seed)
     rs = np.random.RandomState(700000 + seed)
+    if 3000 <= seed < 4000:                                           # seeds 3000..: a single-cluster database (tree_structure.txt "<id>\t" + tree.pkl,
+        n = int(rs.randint(600, 2600))                                # Build_tree.py:283-375; identify.py:19-21 unpickles the tree)
+        spec = dict(parent={1: None}, sites={1: n}, singleton={}, clusters={1: ["GCF_F%d_01_%02d" % (7000 + seed, j + 1) for j in range(int(rs.randint(2, 6)))]},
+                    reconstructed=[], overlaps=[], invalid_nodes=[], db_seed=200000 + 7000 + seed, single_cluster=True,
+                    l2={1: 710000 + 100 * seed + 1} if rs.random_sample() < 0.85 else {}, memory_db=bool(rs.random_sample() < 0.25))
+        return spec
     T = synth.Tree(spec["parent"])
     if len(spec["clusters"]) < 2:                                    # make two of the leaves multi-strain clusters
         for l in [int(x) for x in rs.permutation(T.leaves)[:2]]:
@@ -227,7 +233,7 @@ def build_flow(seed, root_dir):
     spec = flow_spec(seed)
     db_dir = os.path.join(root_dir, "DB_W%d" % seed)
     info = synth.build_l1_db(db_dir, spec["parent"], spec["sites"], spec["db_seed"], spec["singleton"], spec["clusters"],
-                             spec["reconstructed"], spec["overlaps"], invalid_nodes=spec["invalid_nodes"])
+                             spec["reconstructed"], spec["overlaps"], invalid_nodes=spec["invalid_nodes"], single_cluster=spec.get("single_cluster", False))
     info["db_dir"] = db_dir
     info["spec"] = spec
     info["l2"] = {}
@@ -256,7 +262,7 @@ def build_flow(seed, root_dir):
 def flow_reads(info, seed):
     rs = np.random.RandomState(800000 + seed)
     spec = info["spec"]
-    if seed >= 2000:                                                  # seeds from 2000 on: samples at the edge of being a sample at all
+    if 2000 <= seed < 3000:                                           # seeds 2000..2999: samples at the edge of being a sample at all
         u = np.random.RandomState(810000 + seed).random_sample()
         leaf = info["leaf_genome"][sorted(spec["l2"])[0]]
         if u < 0.15:
