@@ -1,6 +1,6 @@
 """Seeded random scenarios (tests/scenarios_fuzz.py) on which the REAL reference was run (tests/golden/fuzz_reference.py keep ->
 fuzz_l1.json, fuzz_l2.json, fuzz_l2_arrays.npz): the seeds kept from campaigns of 360 random databases x 2 samples x 4 walks, 950 whole command lines, 500 samples in random file shapes and
-3 150 random layer-2 clusters in which the oracle, the product's host logic and (on the GPU) the HIP path agreed with the reference
+3 270 random layer-2 clusters in which the oracle, the product's host logic and (on the GPU) the HIP path agreed with the reference
 on every seed -- once the reference's alpha grid took log10 / pow from libm as its pinned numpy 1.17.3 does (DESIGN.md section 4:
 under numpy 1.26's own SIMD log10 / pow the reference itself flips between `no report` and `a strain at 1e-16` in ~1.5 % of
 random clusters, the ones where the cross-validation picks the largest alpha; entries with "res_keys_numpy_1_26" are such seeds).
