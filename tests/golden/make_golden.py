@@ -14,6 +14,8 @@ What it does, without modifying or copying any reference file into the repo:
   * builds the synthetic inputs of tests/scenarios.py, runs the reference functions on them and
     stores inputs' sha256 + reference outputs as JSON / npz next to this script.
 Nothing here is imported by the product or by the tests; only the written data files are.
+(The fuzz_*.json / fuzz_l2_arrays.npz files are written by tests/golden/fuzz_reference.py keep, which borrows this script's helpers:
+random scenarios of tests/scenarios_fuzz.py through the same reference, 4 min.)
 """
 import contextlib
 import io
