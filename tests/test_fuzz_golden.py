@@ -165,7 +165,7 @@ def test_fuzz_l2_hip_path(seed, golden_dir, fp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("world", [2, 5, 8])
 def test_fuzz_flow_hip_path_sharded(world, golden_dir, tmp_path):
     """The kept command lines once more with the reads sharded over several rank processes on one device (gloo; rank 0 owns the output
     directory): layer 1's exchange of node statistics AND layer 2's all-reduced cluster tables, the `.gz` inputs inflated in range
